@@ -1,0 +1,123 @@
+/*
+ * pyg_hip.h -- C-ABI of the MI355X-native (gfx950) pyg-lib hot path.
+ *
+ * This is the drop-in boundary: a torch-free shared library (libpyg_hip.so) with plain
+ * pointers, sizes and a hipStream_t.  The thin torch binding (libpyg.so, sources in
+ * pyg_lib_amd/csrc/binding/) registers the reference's `pyg::*` operator schemas and calls
+ * nothing but these entry points; INTEGRATION.md shows the binding a pyg-lib maintainer
+ * would add.  Every entry point cites the reference interface it replaces
+ * (paths relative to the pyg-lib source tree, v0.9.0).
+ *
+ * Conventions
+ *  - every function returns PYG_HIP_OK (0) or a negative pyg_hip_status; no exception crosses
+ *    this boundary.  pyg_hip_last_error() returns a thread-local message for the last failure
+ *    (the binding turns it into TORCH_CHECK -> RuntimeError, the reference's error convention:
+ *    pyg_lib/csrc/ops/matmul.cpp:14-32,49-55).
+ *  - all data pointers are DEVICE pointers unless the name ends in `_host`.
+ *  - inputs are borrowed and never written; outputs are caller-allocated, or allocated through
+ *    the caller's allocator callback when their size is data dependent (sampler).
+ *  - `stream` is a hipStream_t passed as void* so that C callers need no HIP headers.  All work
+ *    is enqueued on it; only the sampler synchronises it (data-dependent output sizes).
+ */
+#ifndef PYG_HIP_H_
+#define PYG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYG_HIP_API __attribute__((visibility("default")))
+
+typedef enum {
+  PYG_HIP_OK = 0,
+  PYG_HIP_ERR_INVALID = -1,     /* argument check failed (reference: TORCH_CHECK)          */
+  PYG_HIP_ERR_UNSUPPORTED = -2, /* valid in the reference, not implemented on device yet     */
+  PYG_HIP_ERR_RUNTIME = -3,     /* HIP runtime / launch failure                              */
+  PYG_HIP_ERR_WORKSPACE = -4    /* workspace too small                                       */
+} pyg_hip_status;
+
+/* Arithmetic type of a buffer (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16),
+ * pyg_lib/csrc/ops/cpu/matmul_kernel.cpp:419-421). */
+typedef enum {
+  PYG_F32 = 0,
+  PYG_F64 = 1,
+  PYG_F16 = 2,
+  PYG_BF16 = 3,
+  PYG_I8 = 4,
+  PYG_U8 = 5,
+  PYG_I16 = 6,
+  PYG_I32 = 7,
+  PYG_I64 = 8
+} pyg_dtype;
+
+/* ---- library ----------------------------------------------------------------------------- */
+
+/* Replaces pyg::cuda_version (pyg_lib/csrc/library.cpp:19-29): returns the HIP runtime version
+ * the library was built against (HIP_VERSION), never -1. */
+PYG_HIP_API int64_t pyg_hip_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+PYG_HIP_API const char* pyg_hip_last_error(void);
+/* Name of the offload architecture the kernels were compiled for ("gfx950"). */
+PYG_HIP_API const char* pyg_hip_arch(void);
+
+/* ---- segment_matmul / grouped_matmul ------------------------------------------------------ */
+
+/* Workspace (device bytes) needed by pyg_hip_segment_matmul / pyg_hip_grouped_matmul for
+ * `num_groups` segments/groups. */
+PYG_HIP_API size_t pyg_hip_matmul_workspace_size(int64_t num_groups);
+
+/*
+ * out[ptr[b]:ptr[b+1]] = input[ptr[b]:ptr[b+1]] @ other[b]            for b in [0, B)
+ * Replaces pyg::segment_matmul (schema pyg_lib/csrc/ops/matmul.cpp:66-67; CPU kernel
+ * pyg_lib/csrc/ops/cpu/matmul_kernel.cpp:410-439; CUDA kernel
+ * pyg_lib/csrc/ops/cuda/matmul_kernel.cu:304-319).
+ *   input  [N, K] row-major, other [B, K, M] row-major, out [N, M] row-major, all `dtype`.
+ *   ptr    B+1 int64 boundaries; on device if ptr_on_device != 0, else on the host (the
+ *          reference's preferred placement, pyg_lib/ops/__init__.py:160-161).  Unlike the
+ *          reference no host synchronisation happens in either case.
+ *   bias   optional [B, M] (may be NULL): fused epilogue for the Python-side loop
+ *          pyg_lib/ops/__init__.py:169-171.
+ *   Rows outside [ptr[0], ptr[B]) are left untouched (the reference leaves them
+ *   uninitialised, matmul_kernel.cpp:416).
+ */
+PYG_HIP_API int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr,
+                                       int ptr_on_device, const void* other, const void* bias,
+                                       void* out, int64_t N, int64_t K, int64_t M, int64_t B,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* One group of a grouped matmul: out[rows, m] = input[rows, k] @ other[k, m].
+ * `other_trans` != 0 means `other` is stored [m, k] row-major (a transposed view, as produced
+ * by the backward pass pyg_lib/ops/__init__.py:84,91), read in place. */
+typedef struct {
+  const void* input;
+  const void* other;
+  void* out;
+  int64_t rows;
+  int32_t k;
+  int32_t m;
+  int32_t other_trans;
+  int32_t reserved;
+} pyg_hip_group;
+
+/*
+ * outs[i] = inputs[i] @ others[i] for i in [0, G).
+ * Replaces pyg::grouped_matmul (schema pyg_lib/csrc/ops/matmul.cpp:64-65; CPU kernel
+ * pyg_lib/csrc/ops/cpu/matmul_kernel.cpp:281-312; CUDA kernel
+ * pyg_lib/csrc/ops/cuda/matmul_kernel.cu:289-302).  `groups_host` is a HOST array of G
+ * descriptors (copied asynchronously into the workspace).
+ */
+PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_host, int64_t G,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Name of the kernel variant the last matmul call on this thread dispatched to
+ * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
+PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PYG_HIP_H_ */

@@ -1,0 +1,254 @@
+"""CPU oracle for the pyg-lib hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  The product (``pyg_lib_amd``) never does; it fails loudly without its HIP library.
+
+The arithmetic lives in the C files next to this one (``oracle_*.c``, each citing the reference
+``file:line`` it restates); this module is a thin ctypes/numpy wrapper around ``liboracle.so``.
+"""
+import ctypes
+import os
+import os.path as osp
+import subprocess
+
+import numpy as np
+
+_HERE = osp.dirname(osp.abspath(__file__))
+_LIB = None
+
+F32, F64, F16, BF16 = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (a few seconds)."""
+    so = osp.join(_HERE, 'liboracle.so')
+    srcs = [osp.join(_HERE, f) for f in sorted(os.listdir(_HERE)) if f.startswith('oracle_') and f.endswith('.c')]
+    if force or not osp.exists(so) or any(osp.getmtime(s) > osp.getmtime(so) for s in srcs):
+        subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle.so'])
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _declare(_LIB)
+    return _LIB
+
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_FILL = ctypes.CFUNCTYPE(None, ctypes.c_void_p, _i64p)
+
+
+def _declare(L):
+    L.oracle_segment_matmul.restype = ctypes.c_int
+    L.oracle_segment_matmul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int64]
+    L.oracle_matmul.restype = ctypes.c_int
+    L.oracle_matmul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.oracle_mt19937_words.restype = None
+    L.oracle_mt19937_words.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64]
+    L.oracle_hetero_neighbor_sample.restype = ctypes.c_void_p
+    L.oracle_hetero_neighbor_sample.argtypes = [
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,  # types, et_src, et_dst
+        ctypes.c_void_p, ctypes.c_void_p,  # rowptr**, col**
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,  # seeds
+        ctypes.c_void_p, ctypes.c_int,  # num_neighbors, L
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,  # node_time**, edge_time**, seed_time**
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,  # csc, replace, disjoint, last
+        ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    L.oracle_sample_free.restype = None
+    L.oracle_sample_free.argtypes = [ctypes.c_void_p]
+    for name in ('oracle_sample_num_nodes', 'oracle_sample_num_edges'):
+        getattr(L, name).restype = ctypes.c_int64
+        getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for name in ('oracle_sample_rng_blocks', 'oracle_sample_rng_draws'):
+        getattr(L, name).restype = ctypes.c_int64
+        getattr(L, name).argtypes = [ctypes.c_void_p]
+    L.oracle_sample_copy_nodes.restype = None
+    L.oracle_sample_copy_nodes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.oracle_sample_copy_edges.restype = None
+    L.oracle_sample_copy_edges.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p]
+    L.oracle_sample_copy_hops.restype = None
+    L.oracle_sample_copy_hops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+
+# ---- helpers ---------------------------------------------------------------------------------
+
+def _np_dtype_code(a: np.ndarray) -> int:
+    if a.dtype == np.float32:
+        return F32
+    if a.dtype == np.float64:
+        return F64
+    if a.dtype == np.float16:
+        return F16
+    raise TypeError(f'unsupported dtype {a.dtype} (pass bf16 as uint16 with dtype=BF16)')
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bit patterns (uint16)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    lsb = (u >> 16) & 1
+    return ((u + 0x7fff + lsb) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- matmul ----------------------------------------------------------------------------------
+
+def segment_matmul(inputs: np.ndarray, ptr: np.ndarray, other: np.ndarray, bias=None, dtype=None) -> np.ndarray:
+    """out[ptr[b]:ptr[b+1]] = inputs[ptr[b]:ptr[b+1]] @ other[b] (+ bias[b]).
+
+    bf16 tensors are passed as uint16 bit patterns with ``dtype=BF16``.
+    Rows outside [ptr[0], ptr[-1]) are returned as zeros.
+    """
+    code = dtype if dtype is not None else _np_dtype_code(inputs)
+    inputs = np.ascontiguousarray(inputs)
+    other = np.ascontiguousarray(other)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    N, K = inputs.shape
+    B, K2, M = other.shape
+    assert K == K2 and ptr.size == B + 1
+    out = np.zeros((N, M), dtype=inputs.dtype)
+    if bias is not None:
+        bias = np.ascontiguousarray(bias)
+    rc = lib().oracle_segment_matmul(code, _ptr(inputs), _ptr(ptr), _ptr(other), _ptr(bias), _ptr(out), N, K, M, B)
+    if rc != 0:
+        raise RuntimeError('oracle_segment_matmul: invalid ptr')
+    return out
+
+
+def matmul(a: np.ndarray, b: np.ndarray, dtype=None) -> np.ndarray:
+    code = dtype if dtype is not None else _np_dtype_code(a)
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    out = np.zeros((a.shape[0], b.shape[1]), dtype=a.dtype)
+    lib().oracle_matmul(code, _ptr(a), _ptr(b), _ptr(out), a.shape[0], a.shape[1], b.shape[1])
+    return out
+
+
+def grouped_matmul(inputs, others, dtype=None):
+    return [matmul(a, b, dtype) for a, b in zip(inputs, others)]
+
+
+# ---- RNG ---------------------------------------------------------------------------------------
+
+def mt19937_words(seed: int, n: int) -> np.ndarray:
+    """First n values of torch.randint(INT64_MIN, INT64_MAX, (n,)) after torch.manual_seed(seed)."""
+    out = np.zeros(n, dtype=np.int64)
+    lib().oracle_mt19937_words(seed & 0xFFFFFFFFFFFFFFFF, _ptr(out), n)
+    return out
+
+
+# ---- sampler -----------------------------------------------------------------------------------
+
+def _pp(arrs):
+    """array of pointers (NULL for None)"""
+    t = (ctypes.c_void_p * max(len(arrs), 1))()
+    for i, a in enumerate(arrs):
+        t[i] = None if a is None else a.ctypes.data
+    return t
+
+
+def _c64(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a), dtype=np.int64)
+
+
+def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_dict, num_neighbors_dict,
+                           node_time_dict=None, edge_time_dict=None, seed_time_dict=None, csc=False,
+                           replace=False, disjoint=False, temporal_strategy='uniform', return_edge_id=True,
+                           rng_seed=0, fill=None):
+    """Restates pyg::hetero_neighbor_sample (single-threaded order).
+
+    Dict keys: node types are strings, edge types are (src, rel, dst) tuples.  Returns
+    (row_dict, col_dict, node_id_dict, edge_id_dict|None, num_nodes_per_hop_dict,
+    num_edges_per_hop_dict, info) with numpy int64 arrays; `info` holds RNG consumption.
+    `rng_seed` plays the role of torch.manual_seed(seed) right before the call; `fill(buf128)`
+    optionally replaces the word source.
+    """
+    nt_index = {t: i for i, t in enumerate(node_types)}
+    E = len(edge_types)
+    et_src = np.array([nt_index[e[0]] for e in edge_types], dtype=np.int32)
+    et_dst = np.array([nt_index[e[2]] for e in edge_types], dtype=np.int32)
+    rowptrs = [_c64(rowptr_dict[e]) for e in edge_types]
+    cols = [_c64(col_dict[e]) for e in edge_types]
+    seed_keys = list(seed_dict.keys())
+    seed_types = np.array([nt_index[k] for k in seed_keys], dtype=np.int32)
+    seeds = [_c64(seed_dict[k]) for k in seed_keys]
+    seed_len = np.array([s.size for s in seeds], dtype=np.int64)
+    L = len(next(iter(num_neighbors_dict.values()))) if E else 0
+    nn = np.array([list(num_neighbors_dict[e]) for e in edge_types], dtype=np.int64).reshape(E, L)
+    ntimes = [_c64(node_time_dict.get(t)) if node_time_dict else None for t in node_types]
+    etimes = [_c64(edge_time_dict.get(e)) if edge_time_dict else None for e in edge_types]
+    stimes = [_c64(seed_time_dict.get(k)) if seed_time_dict else None for k in seed_keys]
+    status = ctypes.c_int(0)
+    cb = None
+    if fill is not None:
+        def _cb(_user, buf):
+            arr = np.ctypeslib.as_array(buf, shape=(128,))
+            fill(arr)
+        cb = _FILL(_cb)
+    L_ = lib()
+    h = L_.oracle_hetero_neighbor_sample(
+        len(node_types), E, _ptr(et_src), _ptr(et_dst), _pp(rowptrs), _pp(cols), len(seed_keys), _ptr(seed_types),
+        _pp(seeds), _ptr(seed_len), _ptr(nn), L, _pp(ntimes), _pp(etimes), _pp(stimes), int(csc), int(replace),
+        int(disjoint), int(temporal_strategy == 'last'), rng_seed & 0xFFFFFFFFFFFFFFFF,
+        ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None, ctypes.byref(status))
+    try:
+        if status.value != 0:
+            raise RuntimeError('Found invalid non-sorted temporal neighborhood')
+        rows, colsd, eids, nodes, nhops, ehops = {}, {}, {}, {}, {}, {}
+        for i, t in enumerate(node_types):
+            n = L_.oracle_sample_num_nodes(h, i)
+            out = np.zeros((n, 2) if disjoint else (n,), dtype=np.int64)
+            L_.oracle_sample_copy_nodes(h, i, _ptr(out))
+            nodes[t] = out
+            hops = np.zeros(L + 1, dtype=np.int64)
+            L_.oracle_sample_copy_hops(h, i, 0, _ptr(hops))
+            nhops[t] = hops.tolist()
+        for i, e in enumerate(edge_types):
+            n = L_.oracle_sample_num_edges(h, i)
+            r = np.zeros(n, dtype=np.int64)
+            c = np.zeros(n, dtype=np.int64)
+            d = np.zeros(n, dtype=np.int64)
+            L_.oracle_sample_copy_edges(h, i, _ptr(r), _ptr(c), _ptr(d))
+            if csc:
+                r, c = c, r  # get_sampled_edges(csc) swaps (neighbor_kernel.cpp:155-159)
+            rows[e], colsd[e], eids[e] = r, c, d
+            hops = np.zeros(L, dtype=np.int64)
+            L_.oracle_sample_copy_hops(h, i, 1, _ptr(hops))
+            ehops[e] = hops.tolist()
+        info = {'rng_blocks': L_.oracle_sample_rng_blocks(h), 'rng_draws': L_.oracle_sample_rng_draws(h)}
+    finally:
+        L_.oracle_sample_free(h)
+    return rows, colsd, nodes, (eids if return_edge_id else None), nhops, ehops, info
+
+
+def neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_time=None, seed_time=None, csc=False,
+                    replace=False, directed=True, disjoint=False, temporal_strategy='uniform',
+                    return_edge_id=True, rng_seed=0, fill=None):
+    """Restates pyg::neighbor_sample. Returns (row, col, node_id, edge_id|None, nodes_per_hop,
+    edges_per_hop, info)."""
+    if not directed:
+        raise RuntimeError('Undirected subgraphs not yet supported')
+    if (node_time is not None or edge_time is not None) and not disjoint:
+        raise RuntimeError('Temporal sampling needs to create disjoint subgraphs')
+    et = ('n', 'to', 'n')
+    out = hetero_neighbor_sample(
+        ['n'], [et], {et: rowptr}, {et: col}, {'n': seed}, {et: list(num_neighbors)},
+        node_time_dict=None if node_time is None else {'n': node_time},
+        edge_time_dict=None if edge_time is None else {et: edge_time},
+        seed_time_dict=None if seed_time is None else {'n': seed_time},
+        csc=csc, replace=replace, disjoint=disjoint, temporal_strategy=temporal_strategy,
+        return_edge_id=return_edge_id, rng_seed=rng_seed, fill=fill)
+    rows, cols, nodes, eids, nh, eh, info = out
+    return rows[et], cols[et], nodes['n'], (eids[et] if eids is not None else None), nh['n'], eh[et], info

@@ -1,0 +1,557 @@
+/*
+ * oracle_sampler.c -- CPU restatement of pyg-lib's neighbor_sample / hetero_neighbor_sample.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pyg_lib_amd/ may import, link or call this file; it
+ * is the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * Follows (paths relative to the pyg-lib v0.9.0 tree):
+ *   pyg_lib/csrc/random/cpu/rand_engine.h:14-17,41-92   PrefetchedRandint: 128 x int64 prefetch via
+ *       at::randint(INT64_MIN, INT64_MAX), consumed from the buffer tail 16/32/64 bits at a time.
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:58-72    uniform_sample
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:74-144   node_/edge_temporal_sample
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:177-243  _sample (full / with replacement /
+ *       Floyd-style without replacement)
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:287-317  add (dedup through Mapper)
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:332-514  homogeneous driver sample<>
+ *   pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:518-841  heterogeneous driver sample<> (the
+ *       single-threaded order; the reference's multi-threaded order races on the shared RNG)
+ *   pyg_lib/csrc/sampler/cpu/mapper.h:12-78               Mapper (insertion-ordered global->local)
+ *   pyg_lib/csrc/sampler/cpu/index_tracker.h:13-32        IndexTracker
+ *
+ * Third-party arithmetic: the random words come from libtorch's CPU generator (mt19937;
+ * at::randint -> random_from_to -> `random64() % (2^64-1) + INT64_MIN`,
+ * ATen/core/DistributionsHelper.h:40-56, ATen/core/TransformationHelper.h:42-44, torch 2.10).
+ * That algorithm is restated below (mt19937_*), pinned by tests/golden/mt19937_words.npz
+ * (words drawn with torch.randint here) and by the two seeded golden vectors of the reference's
+ * own test-suite (test/csrc/sampler/test_neighbor.cpp:59-113, at::manual_seed(123456)).
+ *
+ * The reference kernel cannot be built in this image (needs the un-vendored parallel-hashmap
+ * submodule and a cmake-generated config.h); the oracle is pinned against all ten golden tests of
+ * test/csrc/sampler/test_neighbor.cpp (biased cases excepted: they consume at::multinomial /
+ * uniform_ and are outside this path) -- see tests/golden/sampler_reference_vectors.py.
+ *
+ * Biased sampling (edge_weight) is not restated.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------------------------------------
+ * mt19937 exactly as at::mt19937 (ATen/core/MT19937RNGEngine.h): standard MT with 32-bit seed.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t mt[624];
+  int left;
+  int next;
+} mt19937_t;
+
+static void mt19937_seed(mt19937_t* g, uint64_t seed) {
+  g->mt[0] = (uint32_t)(seed & 0xffffffffu);
+  for (int j = 1; j < 624; ++j)
+    g->mt[j] = 1812433253u * (g->mt[j - 1] ^ (g->mt[j - 1] >> 30)) + (uint32_t)j;
+  g->left = 1;
+  g->next = 0;
+}
+
+static void mt19937_next_state(mt19937_t* g) {
+  uint32_t* p = g->mt;
+  const uint32_t UMASK = 0x80000000u, LMASK = 0x7fffffffu, MATRIX = 0x9908b0dfu;
+  for (int j = 0; j < 624; ++j) {
+    uint32_t y = (p[j] & UMASK) | (p[(j + 1) % 624] & LMASK);
+    uint32_t v = p[(j + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? MATRIX : 0u);
+    p[j] = v;
+  }
+  g->left = 624;
+  g->next = 0;
+}
+
+static uint32_t mt19937_u32(mt19937_t* g) {
+  if (--g->left == 0) mt19937_next_state(g);
+  uint32_t y = g->mt[g->next++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+/* CPUGeneratorImpl::random64(): two 32-bit draws, first is the high word. */
+static uint64_t mt19937_u64(mt19937_t* g) {
+  uint32_t hi = mt19937_u32(g);
+  uint32_t lo = mt19937_u32(g);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+/* One element of at::randint(INT64_MIN, INT64_MAX, ...) / random_(INT64_MIN, INT64_MAX). */
+static int64_t torch_randint_full(mt19937_t* g) {
+  const uint64_t range = 0xffffffffffffffffull; /* INT64_MAX - INT64_MIN */
+  uint64_t v = mt19937_u64(g) % range;
+  return (int64_t)(v + (uint64_t)INT64_MIN);
+}
+
+/* Exposed for tests: the first n words torch.randint(INT64_MIN, INT64_MAX, (n,)) yields after
+ * torch.manual_seed(seed). */
+void oracle_mt19937_words(uint64_t seed, int64_t* out, int64_t n) {
+  mt19937_t g;
+  mt19937_seed(&g, seed);
+  for (int64_t i = 0; i < n; ++i) out[i] = torch_randint_full(&g);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * RandintEngine / PrefetchedRandint (rand_engine.h:41-92).
+ * ------------------------------------------------------------------------------------------- */
+typedef void (*oracle_fill_fn)(void* user, int64_t* buf128);
+
+typedef struct {
+  uint64_t buf[128];
+  int size;
+  int bits;
+  mt19937_t gen;          /* used when fill == NULL */
+  oracle_fill_fn fill;    /* optional external word source (e.g. torch's generator) */
+  void* user;
+  int64_t blocks;         /* number of 128-word prefetches so far */
+  int64_t draws;
+} engine_t;
+
+static void engine_prefetch(engine_t* e) {
+  if (e->fill) {
+    e->fill(e->user, (int64_t*)e->buf);
+  } else {
+    for (int i = 0; i < 128; ++i) e->buf[i] = (uint64_t)torch_randint_full(&e->gen);
+  }
+  e->size = 127;
+  e->bits = 64;
+  e->blocks++;
+}
+
+static void engine_init(engine_t* e, uint64_t seed, oracle_fill_fn fill, void* user) {
+  memset(e, 0, sizeof(*e));
+  e->fill = fill;
+  e->user = user;
+  if (!fill) mt19937_seed(&e->gen, seed);
+  engine_prefetch(e); /* the engine constructor always prefetches once (rand_engine.h:27-29) */
+}
+
+static uint64_t engine_next(engine_t* e, uint64_t range) {
+  int needed = 64;
+  if (range < (1ull << 16)) needed = 16;
+  else if (range < (1ull << 32)) needed = 32;
+  if (e->bits < needed) {
+    if (e->size > 0) {
+      e->size--;
+      e->bits = 64;
+    } else {
+      engine_prefetch(e);
+    }
+  }
+  const uint64_t mask = needed == 64 ? ~0ull : ((1ull << needed) - 1);
+  const uint64_t res = (e->buf[e->size] & mask) % range;
+  if (needed == 64) e->buf[e->size] = 0; /* x >>= 64 is UB in C; the bits are spent either way */
+  else e->buf[e->size] >>= needed;
+  e->bits -= needed;
+  e->draws++;
+  return res;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Small containers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t* d;
+  int64_t n, cap;
+} vec64;
+
+static void vpush(vec64* v, int64_t x) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 1024;
+    v->d = (int64_t*)realloc(v->d, sizeof(int64_t) * (size_t)v->cap);
+  }
+  v->d[v->n++] = x;
+}
+
+/* Mapper: (batch, node) -> local id in insertion order (mapper.h:30-46). */
+typedef struct {
+  int64_t* ka;
+  int64_t* kb;
+  int64_t* val;
+  int64_t cap, n;
+} mapper_t;
+
+static uint64_t mix(uint64_t a, uint64_t b) {
+  uint64_t x = a * 0x9e3779b97f4a7c15ull ^ (b + 0x7f4a7c15ull + (a << 6) + (a >> 2));
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+static void mapper_init(mapper_t* m) {
+  m->cap = 1024;
+  m->n = 0;
+  m->ka = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  m->kb = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  m->val = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  for (int64_t i = 0; i < m->cap; ++i) m->val[i] = -1;
+}
+
+static void mapper_free(mapper_t* m) {
+  free(m->ka);
+  free(m->kb);
+  free(m->val);
+}
+
+static void mapper_grow(mapper_t* m) {
+  mapper_t o = *m;
+  m->cap = o.cap * 2;
+  m->ka = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  m->kb = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  m->val = (int64_t*)malloc(sizeof(int64_t) * (size_t)m->cap);
+  for (int64_t i = 0; i < m->cap; ++i) m->val[i] = -1;
+  for (int64_t i = 0; i < o.cap; ++i) {
+    if (o.val[i] < 0) continue;
+    uint64_t h = mix((uint64_t)o.ka[i], (uint64_t)o.kb[i]) & (uint64_t)(m->cap - 1);
+    while (m->val[h] >= 0) h = (h + 1) & (uint64_t)(m->cap - 1);
+    m->ka[h] = o.ka[i];
+    m->kb[h] = o.kb[i];
+    m->val[h] = o.val[i];
+  }
+  mapper_free(&o);
+}
+
+/* returns local id; *inserted = 1 if new */
+static int64_t mapper_insert(mapper_t* m, int64_t a, int64_t b, int* inserted) {
+  if ((m->n + 1) * 2 > m->cap) mapper_grow(m);
+  uint64_t h = mix((uint64_t)a, (uint64_t)b) & (uint64_t)(m->cap - 1);
+  while (m->val[h] >= 0) {
+    if (m->ka[h] == a && m->kb[h] == b) {
+      *inserted = 0;
+      return m->val[h];
+    }
+    h = (h + 1) & (uint64_t)(m->cap - 1);
+  }
+  m->ka[h] = a;
+  m->kb[h] = b;
+  m->val[h] = m->n;
+  *inserted = 1;
+  return m->n++;
+}
+
+/* IndexTracker for one node: set of chosen offsets. */
+typedef struct {
+  int64_t* slot;
+  int64_t cap;
+} tracker_t;
+
+static void tracker_reset(tracker_t* t, int64_t count) {
+  int64_t want = 16;
+  while (want < 2 * count + 2) want <<= 1;
+  if (want > t->cap) {
+    t->slot = (int64_t*)realloc(t->slot, sizeof(int64_t) * (size_t)want);
+    t->cap = want;
+  }
+  for (int64_t i = 0; i < want; ++i) t->slot[i] = -1;
+  /* only the first `want` slots are used this round */
+  t->cap = want;
+}
+
+static int tracker_try_insert(tracker_t* t, int64_t x) {
+  uint64_t h = mix((uint64_t)x, 0) & (uint64_t)(t->cap - 1);
+  while (t->slot[h] >= 0) {
+    if (t->slot[h] == x) return 0;
+    h = (h + 1) & (uint64_t)(t->cap - 1);
+  }
+  t->slot[h] = x;
+  return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * NeighborSampler for one CSR (one edge type).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const int64_t* rowptr;
+  const int64_t* col;
+  vec64 rows, cols, eids; /* sampled_rows_/cols_/edge_ids_ */
+  vec64 edges_per_hop;
+} sampler_t;
+
+typedef struct {
+  vec64 batch; /* only when disjoint */
+  vec64 node;
+  mapper_t map;
+  vec64 nodes_per_hop;
+  int64_t slice_b, slice_e;
+} nodeset_t;
+
+/* add (neighbor_kernel.cpp:287-317) */
+static void sampler_add(sampler_t* s, int64_t edge_id, int64_t src_batch, int64_t local_src,
+                        nodeset_t* dst, int disjoint) {
+  const int64_t w = s->col[edge_id];
+  int inserted;
+  const int64_t loc = mapper_insert(&dst->map, disjoint ? src_batch : 0, w, &inserted);
+  if (inserted) {
+    if (disjoint) vpush(&dst->batch, src_batch);
+    vpush(&dst->node, w);
+  }
+  s->edges_per_hop.d[s->edges_per_hop.n - 1]++;
+  vpush(&s->rows, local_src);
+  vpush(&s->cols, loc);
+  vpush(&s->eids, edge_id);
+}
+
+/* _sample (neighbor_kernel.cpp:177-243) */
+static void sampler_sample(sampler_t* s, int64_t row_start, int64_t row_end, int64_t count,
+                           int replace, int64_t src_batch, int64_t local_src, nodeset_t* dst,
+                           int disjoint, engine_t* eng, tracker_t* trk) {
+  const int64_t population = row_end - row_start;
+  if (count < 0 || (!replace && count >= population)) {
+    for (int64_t e = row_start; e < row_end; ++e)
+      sampler_add(s, e, src_batch, local_src, dst, disjoint);
+  } else if (replace) {
+    for (int64_t i = 0; i < count; ++i) {
+      const int64_t e = row_start + (int64_t)engine_next(eng, (uint64_t)population);
+      sampler_add(s, e, src_batch, local_src, dst, disjoint);
+    }
+  } else {
+    tracker_reset(trk, count);
+    for (int64_t i = population - count; i < population; ++i) {
+      int64_t rnd = (int64_t)engine_next(eng, (uint64_t)(i + 1));
+      if (!tracker_try_insert(trk, rnd)) {
+        rnd = i;
+        tracker_try_insert(trk, i);
+      }
+      sampler_add(s, row_start + rnd, src_batch, local_src, dst, disjoint);
+    }
+  }
+}
+
+/* upper_bound helpers for temporal sampling (neighbor_kernel.cpp:74-144) */
+static int64_t ub_node_time(const int64_t* col, int64_t b, int64_t e, int64_t seed_time,
+                            const int64_t* time) {
+  /* first position p in [b,e) with seed_time < time[col[p]] */
+  while (b < e) {
+    int64_t mid = b + (e - b) / 2;
+    if (seed_time < time[col[mid]]) e = mid; else b = mid + 1;
+  }
+  return b;
+}
+
+static int64_t ub_edge_time(int64_t b, int64_t e, int64_t seed_time, const int64_t* time) {
+  while (b < e) {
+    int64_t mid = b + (e - b) / 2;
+    if (seed_time < time[mid]) e = mid; else b = mid + 1;
+  }
+  return b;
+}
+
+/* One frontier node through one edge type.  Returns -1 on the reference's TORCH_CHECK failure. */
+static int expand_node(sampler_t* s, int64_t v, int64_t src_batch, int64_t local_src,
+                       int64_t count, int replace, nodeset_t* dst, int disjoint, engine_t* eng,
+                       tracker_t* trk, const int64_t* node_time, const int64_t* edge_time,
+                       int64_t seed_time, int temporal_last) {
+  int64_t rs = s->rowptr[v], re = s->rowptr[v + 1];
+  if (re - rs == 0 || count == 0) return 0;
+  if (node_time || edge_time) {
+    if (node_time) re = ub_node_time(s->col, rs, re, seed_time, node_time);
+    else re = ub_edge_time(rs, re, seed_time, edge_time);
+    if (temporal_last && count >= 0) {
+      if (re - count > rs) rs = re - count;
+    }
+    if (re - rs == 0) return 0;
+    if (re - rs > 1) {
+      if (node_time) {
+        if (!(node_time[s->col[rs]] <= node_time[s->col[re - 1]])) return -1;
+      } else {
+        if (!(edge_time[rs] <= edge_time[re - 1])) return -1;
+      }
+    }
+  }
+  sampler_sample(s, rs, re, count, replace, src_batch, local_src, dst, disjoint, eng, trk);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Result handle.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int num_node_types, num_edge_types, L, disjoint;
+  nodeset_t* ns;
+  sampler_t* sm;
+  int64_t rng_blocks, rng_draws;
+} oracle_result;
+
+static void nodeset_init(nodeset_t* n) {
+  memset(n, 0, sizeof(*n));
+  mapper_init(&n->map);
+}
+
+void oracle_sample_free(oracle_result* r) {
+  if (!r) return;
+  for (int i = 0; i < r->num_node_types; ++i) {
+    free(r->ns[i].batch.d);
+    free(r->ns[i].node.d);
+    free(r->ns[i].nodes_per_hop.d);
+    mapper_free(&r->ns[i].map);
+  }
+  for (int i = 0; i < r->num_edge_types; ++i) {
+    free(r->sm[i].rows.d);
+    free(r->sm[i].cols.d);
+    free(r->sm[i].eids.d);
+    free(r->sm[i].edges_per_hop.d);
+  }
+  free(r->ns);
+  free(r->sm);
+  free(r);
+}
+
+int64_t oracle_sample_num_nodes(const oracle_result* r, int t) { return r->ns[t].node.n; }
+int64_t oracle_sample_num_edges(const oracle_result* r, int e) { return r->sm[e].rows.n; }
+int64_t oracle_sample_rng_blocks(const oracle_result* r) { return r->rng_blocks; }
+int64_t oracle_sample_rng_draws(const oracle_result* r) { return r->rng_draws; }
+
+/* node ids: [n] or, when disjoint, [n, 2] = (batch, node) pairs (from_vector of pairs). */
+void oracle_sample_copy_nodes(const oracle_result* r, int t, int64_t* out) {
+  const nodeset_t* n = &r->ns[t];
+  if (!r->disjoint) {
+    memcpy(out, n->node.d, sizeof(int64_t) * (size_t)n->node.n);
+  } else {
+    for (int64_t i = 0; i < n->node.n; ++i) {
+      out[2 * i] = n->batch.d[i];
+      out[2 * i + 1] = n->node.d[i];
+    }
+  }
+}
+
+void oracle_sample_copy_edges(const oracle_result* r, int e, int64_t* row, int64_t* col,
+                              int64_t* eid) {
+  const sampler_t* s = &r->sm[e];
+  if (row) memcpy(row, s->rows.d, sizeof(int64_t) * (size_t)s->rows.n);
+  if (col) memcpy(col, s->cols.d, sizeof(int64_t) * (size_t)s->cols.n);
+  if (eid) memcpy(eid, s->eids.d, sizeof(int64_t) * (size_t)s->eids.n);
+}
+
+/* per-hop counts: nodes L+1 entries, edges L entries */
+void oracle_sample_copy_hops(const oracle_result* r, int t_or_e, int is_edge, int64_t* out) {
+  const vec64* v = is_edge ? &r->sm[t_or_e].edges_per_hop : &r->ns[t_or_e].nodes_per_hop;
+  memcpy(out, v->d, sizeof(int64_t) * (size_t)v->n);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Heterogeneous driver (neighbor_kernel.cpp:518-841), single-threaded order.  The homogeneous
+ * driver (:332-514) is the special case of one node type and one edge type -- see
+ * oracle_neighbor_sample below.
+ *
+ *  et_src/et_dst     node-type index of each edge type's (src, dst) as listed in `edge_types`
+ *                    (roles swap when csc, :715-716)
+ *  seed_types        node types in seed_dict iteration order (insertion order of c10::Dict)
+ *  num_neighbors     [num_edge_types, L]
+ *  node_time[t] / edge_time[e] / seed_time (per seed type) may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+oracle_result* oracle_hetero_neighbor_sample(
+    int num_node_types, int num_edge_types, const int* et_src, const int* et_dst,
+    const int64_t* const* rowptr, const int64_t* const* col, int num_seed_types,
+    const int* seed_types, const int64_t* const* seed, const int64_t* seed_len,
+    const int64_t* num_neighbors, int L, const int64_t* const* node_time,
+    const int64_t* const* edge_time, const int64_t* const* seed_time, int csc, int replace,
+    int disjoint, int temporal_last, uint64_t rng_seed, oracle_fill_fn fill, void* user,
+    int* status) {
+  oracle_result* r = (oracle_result*)calloc(1, sizeof(oracle_result));
+  r->num_node_types = num_node_types;
+  r->num_edge_types = num_edge_types;
+  r->L = L;
+  r->disjoint = disjoint;
+  r->ns = (nodeset_t*)calloc((size_t)num_node_types, sizeof(nodeset_t));
+  r->sm = (sampler_t*)calloc((size_t)num_edge_types, sizeof(sampler_t));
+  for (int t = 0; t < num_node_types; ++t) nodeset_init(&r->ns[t]);
+  for (int e = 0; e < num_edge_types; ++e) {
+    r->sm[e].rowptr = rowptr[e];
+    r->sm[e].col = col[e];
+  }
+  *status = 0;
+
+  engine_t eng;
+  engine_init(&eng, rng_seed, fill, user); /* one engine per call (:606) */
+  tracker_t trk = {0, 0};
+  vec64 seed_times = {0, 0, 0};
+
+  int64_t batch_idx = 0; /* global across seed types (:667-683) */
+  for (int si = 0; si < num_seed_types; ++si) {
+    const int t = seed_types[si];
+    nodeset_t* n = &r->ns[t];
+    n->slice_b = 0;
+    n->slice_e = seed_len[si];
+    for (int64_t i = 0; i < seed_len[si]; ++i) {
+      int ins;
+      if (!disjoint) {
+        vpush(&n->node, seed[si][i]); /* sampled_nodes = all seeds, duplicates included */
+        mapper_insert(&n->map, 0, seed[si][i], &ins);
+      } else {
+        vpush(&n->batch, batch_idx);
+        vpush(&n->node, seed[si][i]);
+        mapper_insert(&n->map, batch_idx, seed[si][i], &ins);
+        if (seed_time && seed_time[si]) vpush(&seed_times, seed_time[si][i]);
+        else if (node_time && node_time[t]) vpush(&seed_times, node_time[t][seed[si][i]]);
+        batch_idx++;
+      }
+    }
+  }
+  for (int t = 0; t < num_node_types; ++t) vpush(&r->ns[t].nodes_per_hop, r->ns[t].node.n);
+
+  for (int ell = 0; ell < L && *status == 0; ++ell) {
+    for (int e = 0; e < num_edge_types && *status == 0; ++e) {
+      const int src = !csc ? et_src[e] : et_dst[e];
+      const int dst = !csc ? et_dst[e] : et_src[e];
+      const int64_t count = num_neighbors[(int64_t)e * L + ell];
+      nodeset_t* sn = &r->ns[src];
+      nodeset_t* dn = &r->ns[dst];
+      sampler_t* s = &r->sm[e];
+      vpush(&s->edges_per_hop, 0);
+      const int64_t* nt = (node_time && node_time[dst]) ? node_time[dst] : NULL;
+      const int64_t* et = (edge_time && edge_time[e]) ? edge_time[e] : NULL;
+      const int64_t b = sn->slice_b, en = sn->slice_e; /* fixed at hop start (:725) */
+      for (int64_t i = b; i < en; ++i) {
+        const int64_t v = sn->node.d[i];
+        const int64_t sb = disjoint ? sn->batch.d[i] : 0;
+        const int64_t st = (nt || et) ? seed_times.d[sb] : 0;
+        if (expand_node(s, v, sb, i, count, replace, dn, disjoint, &eng, &trk, et ? NULL : nt, et,
+                        st, temporal_last) != 0) {
+          *status = -1;
+          break;
+        }
+      }
+    }
+    for (int t = 0; t < num_node_types; ++t) {
+      nodeset_t* n = &r->ns[t];
+      n->slice_b = n->slice_e;
+      n->slice_e = n->node.n;
+      vpush(&n->nodes_per_hop, n->slice_e - n->slice_b);
+    }
+  }
+  r->rng_blocks = eng.blocks;
+  r->rng_draws = eng.draws;
+  free(trk.slot);
+  free(seed_times.d);
+  return r;
+}
+
+/* Homogeneous entry (neighbor_kernel.cpp:332-514): one node type, one edge type.  `csc` only
+ * swaps the returned (row, col) (:155-159) -- done by the caller. */
+oracle_result* oracle_neighbor_sample(const int64_t* rowptr, const int64_t* col,
+                                      const int64_t* seed, int64_t S,
+                                      const int64_t* num_neighbors, int L,
+                                      const int64_t* node_time, const int64_t* edge_time,
+                                      const int64_t* seed_time, int replace, int disjoint,
+                                      int temporal_last, uint64_t rng_seed, oracle_fill_fn fill,
+                                      void* user, int* status) {
+  const int zero = 0;
+  const int64_t* rp[1] = {rowptr};
+  const int64_t* cl[1] = {col};
+  const int64_t* sd[1] = {seed};
+  const int64_t* nt[1] = {node_time};
+  const int64_t* et[1] = {edge_time};
+  const int64_t* st[1] = {seed_time};
+  return oracle_hetero_neighbor_sample(1, 1, &zero, &zero, rp, cl, 1, &zero, sd, &S,
+                                       num_neighbors, L, nt, et, st, 0, replace, disjoint,
+                                       temporal_last, rng_seed, fill, user, status);
+}

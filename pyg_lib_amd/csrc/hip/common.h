@@ -1,0 +1,75 @@
+// Shared host/device helpers for the gfx950 kernels behind include/pyg_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "pyg_hip.h"
+
+namespace pyg_hip {
+
+// ---- error reporting (thread local; see pyg_hip_last_error) ---------------------------------
+char* last_error_buffer();
+constexpr int kErrLen = 512;
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buffer(), kErrLen, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define PYG_HIP_CHECK(expr)                                                             \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return ::pyg_hip::fail(PYG_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr,       \
+                             hipGetErrorString(_e), __FILE__, __LINE__);                \
+  } while (0)
+
+#define PYG_HIP_REQUIRE(cond, ...)                                           \
+  do {                                                                       \
+    if (!(cond)) return ::pyg_hip::fail(PYG_HIP_ERR_INVALID, __VA_ARGS__);   \
+  } while (0)
+
+inline size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case PYG_F32: return 4;
+    case PYG_F64: return 8;
+    case PYG_F16: return 2;
+    case PYG_BF16: return 2;
+    case PYG_I8: return 1;
+    case PYG_U8: return 1;
+    case PYG_I16: return 2;
+    case PYG_I32: return 4;
+    case PYG_I64: return 8;
+    default: return 0;
+  }
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Device properties, cached per device index (the reference keeps un-keyed process globals,
+// pyg_lib/csrc/ops/cuda/matmul_kernel.cu:19,118-119 -- not replicated).
+struct DeviceInfo {
+  int num_cus;
+  int max_lds_per_block;
+};
+const DeviceInfo& device_info();
+
+// Pinned host staging buffer (thread local) used for small asynchronous H2D descriptor copies.
+// `acquire` waits for the previous copy that used the buffer before handing it out again.
+struct PinnedStage {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+  int acquire(size_t bytes, void** out);
+  int commit(hipStream_t stream);
+};
+PinnedStage& pinned_stage();
+
+}  // namespace pyg_hip

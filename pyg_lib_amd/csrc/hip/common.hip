@@ -1,0 +1,73 @@
+// Library-level entry points and shared host helpers (see include/pyg_hip.h).
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace pyg_hip {
+
+char* last_error_buffer() {
+  static thread_local char buf[kErrLen] = {0};
+  return buf;
+}
+
+const DeviceInfo& device_info() {
+  static std::mutex mu;
+  static std::vector<DeviceInfo> cache(64, DeviceInfo{0, 0});
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache[dev].num_cus == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      cache[dev].num_cus = prop.multiProcessorCount;
+      cache[dev].max_lds_per_block = (int)prop.sharedMemPerBlock;
+    } else {
+      cache[dev].num_cus = 256;  // MI355X
+      cache[dev].max_lds_per_block = 160 * 1024;
+    }
+  }
+  return cache[dev];
+}
+
+int PinnedStage::acquire(size_t bytes, void** out) {
+  if (pending) {
+    PYG_HIP_CHECK(hipEventSynchronize(ev));
+    pending = false;
+  }
+  if (bytes > cap) {
+    if (ptr) PYG_HIP_CHECK(hipHostFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = align_up(bytes < 65536 ? 65536 : bytes, 4096);
+    PYG_HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+    cap = want;
+  }
+  if (!ev) PYG_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *out = ptr;
+  return PYG_HIP_OK;
+}
+
+int PinnedStage::commit(hipStream_t stream) {
+  PYG_HIP_CHECK(hipEventRecord(ev, stream));
+  pending = true;
+  return PYG_HIP_OK;
+}
+
+PinnedStage& pinned_stage() {
+  static thread_local PinnedStage st;
+  return st;
+}
+
+}  // namespace pyg_hip
+
+extern "C" {
+
+int64_t pyg_hip_version(void) { return (int64_t)HIP_VERSION; }
+
+const char* pyg_hip_last_error(void) { return pyg_hip::last_error_buffer(); }
+
+const char* pyg_hip_arch(void) { return "gfx950"; }
+
+}  // extern "C"

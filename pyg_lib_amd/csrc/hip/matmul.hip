@@ -1,0 +1,663 @@
+// segment_matmul / grouped_matmul for gfx950 (MI355X).
+//
+// Replaces pyg_lib/csrc/ops/cuda/matmul_kernel.cu (CUTLASS GemmGrouped, fp32 only) and the
+// CPU path pyg_lib/csrc/ops/cpu/matmul_kernel.cpp:281-312,410-439.
+//
+// Design (DESIGN.md "segment_matmul"): the op is a stream of rows through a small per-relation
+// weight, i.e. HBM-bound for bf16 (64 flop/B at F=128) and f32-MFMA bound for fp32.  One
+// persistent launch walks a list of (group, 128-row tile) work items in contiguous ranges per
+// workgroup, so a workgroup re-stages the relation's weight into LDS only when it crosses a
+// segment boundary.  Every wave owns 32 rows x MC output columns:
+//   * X rows go HBM -> VGPR directly as 16-byte loads; lane (x, h) owns the contiguous half-row
+//     X[row x][h*K/2 .. (h+1)*K/2) -- the contraction index is permuted between MFMA k-slots so
+//     that each lane's fragments are contiguous in memory (k = h*K/2 + 8*s + e for step s).
+//   * W^T lives in LDS as [MC][K] (+16 B row pad => conflict-free ds_read_b128) and is the MFMA
+//     "A" operand, X is the "B" operand, so D = W^T X^T: lane (x, h) ends up with
+//     out[row x][h*MC/2 .. (h+1)*MC/2) -- again contiguous, stored as 16-byte writes.  The
+//     output-column permutation that makes this true is folded into the LDS row a lane reads.
+//   * v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation and one rounding at the store for
+//     16-bit types; v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) for fp32 -- gfx950 has no TF32.
+// Shapes outside the specialised (K, M) set, and the remaining dtypes of
+// AT_DISPATCH_ALL_TYPES_AND2, run a plain one-thread-per-output kernel ("naive").
+#include "common.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace pyg_hip {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct bf16_t {
+  uint16_t v;
+};
+struct f16_t {
+  uint16_t v;
+};
+
+// Device-side group descriptor (48 bytes).
+struct DevGroup {
+  const char* a;
+  const char* w;
+  char* c;
+  const char* bias;
+  int64_t rows;
+  int32_t k;
+  int32_t m;
+  int32_t trans;
+  int32_t pad;
+};
+
+constexpr int kTileRows = 128;  // rows per workgroup tile in the MFMA kernels (4 waves x 32)
+
+// ---- plan kernel: ptr on device -> descriptors + tile/row prefix sums --------------------------
+__global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B, const char* a,
+                                     const char* w, char* c, const char* bias, int64_t K,
+                                     int64_t M, int elt, DevGroup* __restrict__ descs,
+                                     int32_t* __restrict__ tile_start,
+                                     int64_t* __restrict__ row_start) {
+  // Single block; B is the number of relations (hundreds): a serial-per-chunk scan is plenty.
+  __shared__ int64_t s_tiles[256];
+  __shared__ int64_t s_rows[256];
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int64_t per = (B + nthr - 1) / nthr;
+  const int64_t beg = min((int64_t)tid * per, B), end = min(beg + per, B);
+  int64_t tiles = 0, rows = 0;
+  for (int64_t b = beg; b < end; ++b) {
+    int64_t r = ptr[b + 1] - ptr[b];
+    if (r < 0) r = 0;
+    rows += r;
+    tiles += (r + kTileRows - 1) / kTileRows;
+  }
+  s_tiles[tid] = tiles;
+  s_rows[tid] = rows;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t t = 0, r = 0;
+    for (int i = 0; i < nthr; ++i) {
+      int64_t tt = s_tiles[i], rr = s_rows[i];
+      s_tiles[i] = t;
+      s_rows[i] = r;
+      t += tt;
+      r += rr;
+    }
+    tile_start[B] = (int32_t)t;
+    row_start[B] = r;
+  }
+  __syncthreads();
+  int64_t t = s_tiles[tid], rs = s_rows[tid];
+  for (int64_t b = beg; b < end; ++b) {
+    const int64_t p0 = ptr[b];
+    int64_t r = ptr[b + 1] - p0;
+    if (r < 0) r = 0;
+    DevGroup d;
+    d.a = a + p0 * K * elt;
+    d.w = w + b * K * M * elt;
+    d.c = c + p0 * M * elt;
+    d.bias = bias ? bias + b * M * elt : nullptr;
+    d.rows = r;
+    d.k = (int32_t)K;
+    d.m = (int32_t)M;
+    d.trans = 0;
+    d.pad = 0;
+    descs[b] = d;
+    tile_start[b] = (int32_t)t;
+    row_start[b] = rs;
+    t += (r + kTileRows - 1) / kTileRows;
+    rs += r;
+  }
+}
+
+// ---- MFMA kernels ------------------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<bf16_t> {
+  static constexpr int kSize = 2;
+  static constexpr int kPerChunk = 8;   // elements per 16-byte chunk
+  static constexpr int kStepsPerChunk = 1;  // MFMA k-steps fed by one chunk
+};
+template <>
+struct Elem<f16_t> {
+  static constexpr int kSize = 2;
+  static constexpr int kPerChunk = 8;
+  static constexpr int kStepsPerChunk = 1;
+};
+template <>
+struct Elem<float> {
+  static constexpr int kSize = 4;
+  static constexpr int kPerChunk = 4;
+  static constexpr int kStepsPerChunk = 4;
+};
+
+__device__ __forceinline__ f32x16 mfma_chunk(bf16_t, u32x4 a, u32x4 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_chunk(f16_t, u32x4 a, u32x4 b, f32x16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_chunk(float, u32x4 a, u32x4 b, f32x16 acc) {
+  f32x4 af = __builtin_bit_cast(f32x4, a);
+  f32x4 bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ float load_bias(const bf16_t* p) {
+  return __builtin_bit_cast(float, (uint32_t)p->v << 16);
+}
+__device__ __forceinline__ float load_bias(const f16_t* p) {
+  return (float)__builtin_bit_cast(_Float16, p->v);
+}
+__device__ __forceinline__ float load_bias(const float* p) { return *p; }
+__device__ __forceinline__ float round_to(bf16_t, float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ float round_to(f16_t, float v) { return (float)(_Float16)v; }
+__device__ __forceinline__ float round_to(float, float v) { return v; }
+
+// Store 16 consecutive output elements (fp32 accumulators -> T) at `dst` (16-byte aligned).
+__device__ __forceinline__ void store16(bf16_t*, char* dst, const float (&v)[16]) {
+  u32x4 lo, hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint16_t a = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i]);
+    uint16_t b = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i + 1]);
+    lo[i] = (uint32_t)a | ((uint32_t)b << 16);
+    uint16_t c = __builtin_bit_cast(uint16_t, (__bf16)v[8 + 2 * i]);
+    uint16_t d = __builtin_bit_cast(uint16_t, (__bf16)v[8 + 2 * i + 1]);
+    hi[i] = (uint32_t)c | ((uint32_t)d << 16);
+  }
+  reinterpret_cast<u32x4*>(dst)[0] = lo;
+  reinterpret_cast<u32x4*>(dst)[1] = hi;
+}
+__device__ __forceinline__ void store16(f16_t*, char* dst, const float (&v)[16]) {
+  u32x4 lo, hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint16_t a = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i]);
+    uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i + 1]);
+    lo[i] = (uint32_t)a | ((uint32_t)b << 16);
+    uint16_t c = __builtin_bit_cast(uint16_t, (_Float16)v[8 + 2 * i]);
+    uint16_t d = __builtin_bit_cast(uint16_t, (_Float16)v[8 + 2 * i + 1]);
+    hi[i] = (uint32_t)c | ((uint32_t)d << 16);
+  }
+  reinterpret_cast<u32x4*>(dst)[0] = lo;
+  reinterpret_cast<u32x4*>(dst)[1] = hi;
+}
+__device__ __forceinline__ void store16(float*, char* dst, const float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 q = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    reinterpret_cast<f32x4*>(dst)[i] = q;
+  }
+}
+
+// K: contraction length (compile time), MC: output columns per workgroup pass (grid.y walks
+// M / MC column chunks), NW: waves per workgroup (tile = NW * 32 rows).
+template <typename T, int K, int MC, int NW>
+__global__ __launch_bounds__(NW * 64) void mfma_rows_kernel(const DevGroup* __restrict__ descs,
+                                                            const int32_t* __restrict__ tile_start,
+                                                            int B) {
+  constexpr int SZ = Elem<T>::kSize;
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int NCH = (K / 2) / EPC;           // 16-byte chunks per lane (half row)
+  constexpr int NT = MC / 32;                  // 32-column MFMA tiles per wave
+  constexpr int LDW = K * SZ + 16;             // LDS row stride (bytes) of the W^T image
+  constexpr int BM = NW * 32;
+  static_assert(BM == kTileRows, "tile table is built for 128-row tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int x = lane & 31;
+  const int h = lane >> 5;
+  const int col0 = blockIdx.y * MC;
+
+  const int total = tile_start[B];
+  const int t0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
+  const int t1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+  if (t0 >= t1) return;
+
+  // group of the first tile: largest g with tile_start[g] <= t0
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= t0) lo = mid; else hi = mid;
+  }
+  int g = lo;
+  int staged = -1;
+
+  // LDS row (output column within the chunk) whose fragment this lane reads for tile t:
+  // c(t, x) = (MC/2)*bit2(x) + 16 t + 4*(x>>3) + (x&3)   (see header comment)
+  const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
+  const char* wfrag = smem + crow0 * LDW + (K / 2) * h * SZ;
+
+  DevGroup d = descs[g];
+  for (int t = t0; t < t1; ++t) {
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      d = descs[g];
+    }
+    if (g != staged) {
+      __syncthreads();  // every wave is done reading the previous relation's weight
+      const char* w = d.w;
+      const int M = d.m;
+      if (!d.trans) {
+        // W is [K][M]: read 16-byte pieces along M, scatter transposed into the [MC][K] image.
+        constexpr int CPR = MC / EPC;  // chunks per W row (within the column chunk)
+        for (int idx = tid; idx < K * CPR; idx += NW * 64) {
+          const int k = idx / CPR;
+          const int cc = (idx - k * CPR) * EPC;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * M + col0 + cc) * SZ);
+          if constexpr (SZ == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint16_t s = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+              *reinterpret_cast<uint16_t*>(smem + (cc + e) * LDW + k * 2) = s;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              *reinterpret_cast<uint32_t*>(smem + (cc + e) * LDW + k * 4) = v[e];
+          }
+        }
+      } else {
+        // W is stored [M][K] (transposed view): straight 16-byte copies.
+        constexpr int CPR = K / EPC;
+        for (int idx = tid; idx < MC * CPR; idx += NW * 64) {
+          const int c = idx / CPR;
+          const int kk = (idx - c * CPR) * EPC;
+          const u32x4 v =
+              *reinterpret_cast<const u32x4*>(w + ((int64_t)(col0 + c) * K + kk) * SZ);
+          *reinterpret_cast<u32x4*>(smem + c * LDW + kk * SZ) = v;
+        }
+      }
+      __syncthreads();
+      staged = g;
+    }
+
+    const int64_t rows = d.rows;
+    const int64_t row_base = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    if (row_base >= rows) continue;  // wave-uniform: ragged last tile of a segment
+    const int64_t row = row_base + x;
+    const bool valid = row < rows;
+    const int64_t lrow = valid ? row : rows - 1;
+
+    // ---- X: lane's contiguous half row, HBM -> VGPR ----
+    u32x4 xv[NCH];
+    const u32x4* xp =
+        reinterpret_cast<const u32x4*>(d.a + (lrow * K + (K / 2) * h) * SZ);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) xv[i] = __builtin_nontemporal_load(xp + i);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW + s * 16);
+        acc[tt] = mfma_chunk(T{}, wv, xv[s], acc[tt]);
+      }
+    }
+
+    // ---- epilogue: lane (x, h) owns out[row][col0 + h*MC/2 + 16 tt + r] ----
+    if (valid) {
+      const int M = d.m;
+      char* op = d.c + (row * M + col0 + (MC / 2) * h) * SZ;
+      const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + col0 + (MC / 2) * h : nullptr;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+        if (bp) {
+          // reference semantics (pyg_lib/ops/__init__.py:169-171): `out` is materialised in T
+          // first, then `out += bias` -- so round the product before adding for 16-bit types.
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+        }
+        store16((T*)nullptr, op + tt * 16 * SZ, v);
+      }
+    }
+  }
+}
+
+// ---- generic kernel: one thread per output element, any dtype / shape ----------------------------
+template <typename T, typename Acc>
+struct NaiveCvt {
+  __device__ static Acc load(const T* p) { return (Acc)*p; }
+  __device__ static void store(T* p, Acc v) { *p = (T)v; }
+  __device__ static Acc round(Acc v) { return (Acc)(T)v; }
+};
+template <>
+struct NaiveCvt<bf16_t, float> {
+  __device__ static float load(const bf16_t* p) { return load_bias(p); }
+  __device__ static void store(bf16_t* p, float v) {
+    p->v = __builtin_bit_cast(uint16_t, (__bf16)v);
+  }
+  __device__ static float round(float v) { return (float)(__bf16)v; }
+};
+template <>
+struct NaiveCvt<f16_t, float> {
+  __device__ static float load(const f16_t* p) { return load_bias(p); }
+  __device__ static void store(f16_t* p, float v) {
+    p->v = __builtin_bit_cast(uint16_t, (_Float16)v);
+  }
+  __device__ static float round(float v) { return (float)(_Float16)v; }
+};
+
+template <typename T, typename Acc>
+__global__ void naive_kernel(const DevGroup* __restrict__ descs,
+                             const int64_t* __restrict__ out_start, int B, int64_t total) {
+  // out_start[g] = number of output elements in groups < g
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx >= out_start[B]) break;
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (out_start[mid] <= idx) lo = mid; else hi = mid;
+    }
+    const DevGroup d = descs[lo];
+    const int64_t local = idx - out_start[lo];
+    const int64_t r = local / d.m;
+    const int c = (int)(local - r * d.m);
+    const T* a = reinterpret_cast<const T*>(d.a) + r * d.k;
+    const T* w = reinterpret_cast<const T*>(d.w);
+    Acc acc = 0;
+    if (!d.trans) {
+      for (int k = 0; k < d.k; ++k)
+        acc += NaiveCvt<T, Acc>::load(a + k) * NaiveCvt<T, Acc>::load(w + (int64_t)k * d.m + c);
+    } else {
+      for (int k = 0; k < d.k; ++k)
+        acc += NaiveCvt<T, Acc>::load(a + k) * NaiveCvt<T, Acc>::load(w + (int64_t)c * d.k + k);
+    }
+    if (d.bias)
+      acc = NaiveCvt<T, Acc>::round(acc) +
+            NaiveCvt<T, Acc>::load(reinterpret_cast<const T*>(d.bias) + c);
+    NaiveCvt<T, Acc>::store(reinterpret_cast<T*>(d.c) + r * d.m + c, acc);
+  }
+}
+
+__global__ void out_start_kernel(const DevGroup* __restrict__ descs, int B,
+                                 int64_t* __restrict__ out_start) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t s = 0;
+    for (int b = 0; b < B; ++b) {
+      out_start[b] = s;
+      s += descs[b].rows * descs[b].m;
+    }
+    out_start[B] = s;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+thread_local const char* g_last_variant = "";
+
+struct Workspace {
+  DevGroup* descs;
+  int32_t* tile_start;
+  int64_t* row_start;   // also reused as out_start by the naive path
+  int64_t* ptr_copy;
+};
+
+size_t workspace_bytes(int64_t B) {
+  size_t n = 0;
+  n += align_up(sizeof(DevGroup) * (size_t)std::max<int64_t>(B, 1), 256);
+  n += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  return n;
+}
+
+Workspace carve(void* ws, int64_t B) {
+  char* p = static_cast<char*>(ws);
+  Workspace w;
+  w.descs = reinterpret_cast<DevGroup*>(p);
+  p += align_up(sizeof(DevGroup) * (size_t)std::max<int64_t>(B, 1), 256);
+  w.tile_start = reinterpret_cast<int32_t*>(p);
+  p += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  w.row_start = reinterpret_cast<int64_t*>(p);
+  p += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  w.ptr_copy = reinterpret_cast<int64_t*>(p);
+  return w;
+}
+
+template <typename T, int K, int MC>
+int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream_t stream) {
+  constexpr int NW = 4;
+  constexpr int lds = MC * (K * Elem<T>::kSize + 16);
+  auto kern = mfma_rows_kernel<T, K, MC, NW>;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const DeviceInfo& di = device_info();
+  int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
+  int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
+  dim3 grid((unsigned)gx, (unsigned)(M / MC), 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T>
+int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, int64_t tiles_upper,
+                  hipStream_t stream, bool* handled) {
+  static thread_local char name[64];
+  *handled = true;
+  const int MC = (M % 128 == 0) ? 128 : 64;
+  snprintf(name, sizeof(name), "mfma_%s_k%d_mc%d", tname, K, MC);
+  g_last_variant = name;
+#define PYG_CASE(KK, MM)            \
+  if (K == KK && MC == MM) return launch_mfma<T, KK, MM>(w, B, M, tiles_upper, stream);
+  PYG_CASE(64, 64)
+  PYG_CASE(64, 128)
+  PYG_CASE(128, 64)
+  PYG_CASE(128, 128)
+  PYG_CASE(256, 64)
+  PYG_CASE(256, 128)
+#undef PYG_CASE
+  *handled = false;
+  return PYG_HIP_OK;
+}
+
+bool mfma_shape_ok(int dtype, int64_t K, int64_t M) {
+  if (!(dtype == PYG_F32 || dtype == PYG_BF16 || dtype == PYG_F16)) return false;
+  if (!(K == 64 || K == 128 || K == 256)) return false;
+  if (M < 64 || M % 64 != 0 || M > (1 << 20)) return false;
+  if (dtype == PYG_F32 && K == 256 && (M % 128 == 0)) {
+    // fp32 K=256 x 128 columns needs 133 KB of LDS; fine on gfx950 (160 KB), 1 block/CU.
+  }
+  return true;
+}
+
+template <typename T, typename Acc>
+int launch_naive(const Workspace& w, int B, int64_t total_upper, hipStream_t stream) {
+  hipLaunchKernelGGL(out_start_kernel, dim3(1), dim3(64), 0, stream, w.descs, B, w.row_start);
+  PYG_HIP_CHECK(hipGetLastError());
+  int64_t blocks = std::min<int64_t>((total_upper + 255) / 256, 256 * 16);
+  if (blocks < 1) blocks = 1;
+  // `total` is read on device from out_start[B]; pass the host upper bound for the loop limit
+  hipLaunchKernelGGL((naive_kernel<T, Acc>), dim3((unsigned)blocks), dim3(256), 0, stream, w.descs,
+                     w.row_start, B, total_upper);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+int dispatch_naive(int dtype, const Workspace& w, int B, int64_t total, hipStream_t stream) {
+  g_last_variant = "naive";
+  switch (dtype) {
+    case PYG_F32: return launch_naive<float, float>(w, B, total, stream);
+    case PYG_F64: return launch_naive<double, double>(w, B, total, stream);
+    case PYG_F16: return launch_naive<f16_t, float>(w, B, total, stream);
+    case PYG_BF16: return launch_naive<bf16_t, float>(w, B, total, stream);
+    case PYG_I8: return launch_naive<int8_t, int8_t>(w, B, total, stream);
+    case PYG_U8: return launch_naive<uint8_t, uint8_t>(w, B, total, stream);
+    case PYG_I16: return launch_naive<int16_t, int16_t>(w, B, total, stream);
+    case PYG_I32: return launch_naive<int32_t, int32_t>(w, B, total, stream);
+    case PYG_I64: return launch_naive<int64_t, int64_t>(w, B, total, stream);
+    default: return fail(PYG_HIP_ERR_INVALID, "matmul: unknown dtype %d", dtype);
+  }
+}
+
+int run_planned(int dtype, const Workspace& w, int B, int64_t K, int64_t M, bool uniform,
+                int64_t tiles_upper, int64_t out_elems_upper, hipStream_t stream) {
+  if (uniform && mfma_shape_ok(dtype, K, M)) {
+    bool handled = false;
+    int rc = PYG_HIP_OK;
+    if (dtype == PYG_BF16)
+      rc = dispatch_mfma<bf16_t>("bf16", w, B, (int)K, (int)M, tiles_upper, stream, &handled);
+    else if (dtype == PYG_F16)
+      rc = dispatch_mfma<f16_t>("f16", w, B, (int)K, (int)M, tiles_upper, stream, &handled);
+    else
+      rc = dispatch_mfma<float>("f32", w, B, (int)K, (int)M, tiles_upper, stream, &handled);
+    if (rc != PYG_HIP_OK) return rc;
+    if (handled) return PYG_HIP_OK;
+  }
+  return dispatch_naive(dtype, w, B, out_elems_upper, stream);
+}
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" {
+
+size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
+  return workspace_bytes(num_groups < 0 ? 0 : num_groups);
+}
+
+const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
+
+int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,
+                           const void* other, const void* bias, void* out, int64_t N, int64_t K,
+                           int64_t M, int64_t B, void* workspace, size_t workspace_bytes_,
+                           void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const size_t elt = dtype_size(dtype);
+  PYG_HIP_REQUIRE(elt != 0, "segment_matmul: unknown dtype %d", dtype);
+  PYG_HIP_REQUIRE(N >= 0 && K >= 0 && M >= 0 && B >= 0, "segment_matmul: negative size");
+  PYG_HIP_REQUIRE(ptr != nullptr, "segment_matmul: 'ptr' is NULL");
+  PYG_HIP_REQUIRE(B < (1LL << 31), "segment_matmul: too many segments");
+  g_last_variant = "none";
+  if (B == 0 || N == 0 || M == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(input && other && out, "segment_matmul: NULL tensor");
+  PYG_HIP_REQUIRE((N + kTileRows - 1) / kTileRows + B < (1LL << 31),
+                  "segment_matmul: too many row tiles");
+  if (workspace_bytes_ < workspace_bytes(B) || workspace == nullptr)
+    return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul: workspace of %zu bytes needed, got %zu",
+                workspace_bytes(B), workspace_bytes_);
+  Workspace w = carve(workspace, B);
+
+  const int64_t* dptr = ptr;
+  if (!ptr_on_device) {
+    // ptr lives on the host (the reference's preferred placement): validate, then ship it.
+    for (int64_t b = 0; b < B; ++b)
+      PYG_HIP_REQUIRE(ptr[b + 1] >= ptr[b] && ptr[b] >= 0 && ptr[b + 1] <= N,
+                      "segment_matmul: 'ptr' must be non-decreasing within [0, %lld]",
+                      (long long)N);
+    void* staged = nullptr;
+    int rc = pinned_stage().acquire(sizeof(int64_t) * (size_t)(B + 1), &staged);
+    if (rc != PYG_HIP_OK) return rc;
+    ::memcpy(staged, ptr, sizeof(int64_t) * (size_t)(B + 1));
+    PYG_HIP_CHECK(hipMemcpyAsync(w.ptr_copy, staged, sizeof(int64_t) * (size_t)(B + 1),
+                                 hipMemcpyHostToDevice, stream));
+    rc = pinned_stage().commit(stream);
+    if (rc != PYG_HIP_OK) return rc;
+    dptr = w.ptr_copy;
+  }
+  hipLaunchKernelGGL(plan_segments_kernel, dim3(1), dim3(256), 0, stream, dptr, B,
+                     static_cast<const char*>(input), static_cast<const char*>(other),
+                     static_cast<char*>(out), static_cast<const char*>(bias), K, M, (int)elt,
+                     w.descs, w.tile_start, w.row_start);
+  PYG_HIP_CHECK(hipGetLastError());
+  if (K == 0) {
+    // empty contraction: out = 0 (+ bias), handled by the generic kernel
+    return dispatch_naive(dtype, w, (int)B, N * M, stream);
+  }
+  const int64_t tiles_upper = (N + kTileRows - 1) / kTileRows + B;
+  return run_planned(dtype, w, (int)B, K, M, true, tiles_upper, N * M, stream);
+}
+
+int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, void* workspace,
+                           size_t workspace_bytes_, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const size_t elt = dtype_size(dtype);
+  PYG_HIP_REQUIRE(elt != 0, "grouped_matmul: unknown dtype %d", dtype);
+  PYG_HIP_REQUIRE(G >= 0 && G < (1LL << 31), "grouped_matmul: bad group count");
+  g_last_variant = "none";
+  if (G == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(groups != nullptr, "grouped_matmul: 'groups' is NULL");
+  if (workspace_bytes_ < workspace_bytes(G) || workspace == nullptr)
+    return fail(PYG_HIP_ERR_WORKSPACE, "grouped_matmul: workspace of %zu bytes needed, got %zu",
+                workspace_bytes(G), workspace_bytes_);
+  Workspace w = carve(workspace, G);
+
+  // Host-side plan (G is small): descriptors + tile prefix, one pinned H2D copy.
+  const size_t descs_b = align_up(sizeof(DevGroup) * (size_t)G, 256);
+  const size_t tiles_b = align_up(sizeof(int32_t) * (size_t)(G + 1), 256);
+  void* staged = nullptr;
+  int rc = pinned_stage().acquire(descs_b + tiles_b, &staged);
+  if (rc != PYG_HIP_OK) return rc;
+  DevGroup* hd = static_cast<DevGroup*>(staged);
+  int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b);
+  bool uniform = true, any_trans = false;
+  int64_t tiles = 0, out_elems = 0;
+  for (int64_t i = 0; i < G; ++i) {
+    const pyg_hip_group& gr = groups[i];
+    PYG_HIP_REQUIRE(gr.rows >= 0 && gr.k >= 0 && gr.m >= 0, "grouped_matmul: negative size");
+    PYG_HIP_REQUIRE(gr.rows == 0 || gr.m == 0 || (gr.out && (gr.k == 0 || (gr.input && gr.other))),
+                    "grouped_matmul: NULL tensor in group %lld", (long long)i);
+    hd[i].a = static_cast<const char*>(gr.input);
+    hd[i].w = static_cast<const char*>(gr.other);
+    hd[i].c = static_cast<char*>(gr.out);
+    hd[i].bias = nullptr;
+    hd[i].rows = gr.m == 0 ? 0 : gr.rows;
+    hd[i].k = gr.k;
+    hd[i].m = gr.m;
+    hd[i].trans = gr.other_trans ? 1 : 0;
+    hd[i].pad = 0;
+    if (gr.k != groups[0].k || gr.m != groups[0].m) uniform = false;
+    if (gr.other_trans) any_trans = true;
+    ht[i] = (int32_t)tiles;
+    tiles += (hd[i].rows + kTileRows - 1) / kTileRows;
+    out_elems += hd[i].rows * gr.m;
+    PYG_HIP_REQUIRE(tiles < (1LL << 31), "grouped_matmul: too many row tiles");
+  }
+  (void)any_trans;
+  ht[G] = (int32_t)tiles;
+  PYG_HIP_CHECK(hipMemcpyAsync(w.descs, hd, sizeof(DevGroup) * (size_t)G, hipMemcpyHostToDevice,
+                               stream));
+  PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start, ht, sizeof(int32_t) * (size_t)(G + 1),
+                               hipMemcpyHostToDevice, stream));
+  rc = pinned_stage().commit(stream);
+  if (rc != PYG_HIP_OK) return rc;
+  if (out_elems == 0) return PYG_HIP_OK;
+  if (groups[0].k == 0) uniform = false;
+  return run_planned(dtype, w, (int)G, groups[0].k, groups[0].m, uniform, tiles, out_elems,
+                     stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""Golden vectors held by the reference's own sampler tests (data only).
+
+Source of the numbers: pyg-lib v0.9.0 ``test/csrc/sampler/test_neighbor.cpp`` (test name and
+line range given per case) on the 6-node cycle graph of ``test/csrc/graph.h:5-13``.  Cases that
+need ``edge_weight`` (BiasedNeighborTest :300-328, HeteroBiasedNeighborTest :330-377) consume
+at::multinomial / Tensor.uniform_ and are outside the restated path.
+"""
+import numpy as np
+
+
+def cycle_graph(n=6):
+    """test/csrc/graph.h:5-13: rowptr = [0,2,..,2n], col = [(i-1)%n, (i+1)%n]."""
+    rowptr = np.arange(0, 2 * n + 1, 2, dtype=np.int64)
+    col = np.stack([(np.arange(-1, n - 1) % n), (np.arange(1, n + 1) % n)], axis=1).reshape(-1).astype(np.int64)
+    return rowptr, col
+
+
+ROWPTR, COL = cycle_graph(6)
+# NodeLevelTemporalNeighborTest sorts each neighbourhood by node id (:156):
+COL_SORTED = np.sort(COL.reshape(-1, 2), axis=1).reshape(-1)
+
+CASES = [
+    dict(  # BasicNeighborTest :8-31
+        name='basic', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[-1, -1], kwargs={},
+        row=[0, 0, 1, 1, 2, 2, 3, 3], col_out=[2, 1, 0, 3, 4, 0, 1, 5], node=[2, 3, 1, 4, 0, 5],
+        edge=[4, 5, 6, 7, 2, 3, 8, 9], nodes_per_hop=[2, 2, 2], edges_per_hop=[4, 4]),
+    dict(  # ZeroNeighborTest :33-57
+        name='zero_degree', rowptr=np.zeros(6, dtype=np.int64), col=np.zeros(0, dtype=np.int64),
+        seed=[0, 1, 2, 3, 4], num_neighbors=[-1, -1], kwargs={},
+        row=[], col_out=[], node=[0, 1, 2, 3, 4], edge=[], nodes_per_hop=[5, 0, 0], edges_per_hop=[0, 0]),
+    dict(  # WithoutReplacementNeighborTest :59-85 (at::manual_seed(123456))
+        name='without_replacement_seeded', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[1, 1],
+        kwargs=dict(replace=False), manual_seed=123456,
+        row=[0, 1, 2, 3], col_out=[2, 3, 0, 4], node=[2, 3, 1, 4, 5], edge=[4, 7, 3, 9]),
+    dict(  # WithReplacementNeighborTest :87-113 (at::manual_seed(123456))
+        name='with_replacement_seeded', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[1, 1],
+        kwargs=dict(replace=True), manual_seed=123456,
+        row=[0, 1, 2, 3], col_out=[2, 3, 0, 4], node=[2, 3, 1, 4, 5], edge=[4, 7, 3, 9]),
+    dict(  # DisjointNeighborTest :115-144
+        name='disjoint', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[2, 2],
+        kwargs=dict(replace=False, directed=True, disjoint=True),
+        row=[0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5], col_out=[2, 3, 4, 5, 6, 0, 0, 7, 8, 1, 1, 9],
+        node=[[0, 2], [1, 3], [0, 1], [0, 3], [1, 2], [1, 4], [0, 0], [0, 4], [1, 1], [1, 5]],
+        edge=[4, 5, 6, 7, 2, 3, 6, 7, 4, 5, 8, 9]),
+    dict(  # NodeLevelTemporalNeighborTest out1 :158-180
+        name='node_temporal', rowptr=ROWPTR, col=COL_SORTED, seed=[2, 3], num_neighbors=[2, 2],
+        kwargs=dict(node_time=np.arange(6, dtype=np.int64), replace=False, directed=True, disjoint=True),
+        row=[0, 1, 2, 2, 3, 3], col_out=[2, 3, 4, 0, 5, 1],
+        node=[[0, 2], [1, 3], [0, 1], [1, 2], [0, 0], [1, 1]], edge=[4, 6, 2, 3, 4, 5]),
+    dict(  # NodeLevelTemporalNeighborTest out2 :182-201 ("last" strategy, same expectation)
+        name='node_temporal_last', rowptr=ROWPTR, col=COL_SORTED, seed=[2, 3], num_neighbors=[1, 2],
+        kwargs=dict(node_time=np.arange(6, dtype=np.int64), replace=False, directed=True, disjoint=True,
+                    temporal_strategy='last'),
+        row=[0, 1, 2, 2, 3, 3], col_out=[2, 3, 4, 0, 5, 1],
+        node=[[0, 2], [1, 3], [0, 1], [1, 2], [0, 0], [1, 1]], edge=[4, 6, 2, 3, 4, 5]),
+    dict(  # EdgeLevelTemporalNeighborTest out :214-237
+        name='edge_temporal', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[2, 2],
+        kwargs=dict(edge_time=np.arange(12, dtype=np.int64), seed_time=np.array([5, 6], dtype=np.int64),
+                    replace=False, directed=True, disjoint=True),
+        row=[0, 0, 1, 2, 2, 4, 4], col_out=[2, 3, 4, 5, 0, 6, 1],
+        node=[[0, 2], [1, 3], [0, 1], [0, 3], [1, 2], [0, 0], [1, 1]], edge=[4, 5, 6, 2, 3, 4, 5]),
+    dict(  # EdgeLevelTemporalNeighborTest out2 :239-256
+        name='edge_temporal_none', rowptr=ROWPTR, col=COL, seed=[2, 3], num_neighbors=[1, 1],
+        kwargs=dict(edge_time=np.arange(12, dtype=np.int64), seed_time=np.array([-1, -1], dtype=np.int64),
+                    replace=True, directed=True, disjoint=True),
+        row=[], col_out=[], node=[[0, 2], [1, 3]], edge=[]),
+]
+
+# HeteroNeighborTest :259-298 (one node type "paper", one relation, fanout [2, 2]): identical
+# expectation to BasicNeighborTest because 2 >= degree.
+HETERO_CASE = dict(
+    node_types=['paper'], edge_types=[('paper', 'to', 'paper')], seed=[2, 3], num_neighbors=[2, 2],
+    row=[0, 0, 1, 1, 2, 2, 3, 3], col_out=[2, 1, 0, 3, 4, 0, 1, 5], node=[2, 3, 1, 4, 0, 5],
+    edge=[4, 5, 6, 7, 2, 3, 8, 9], nodes_per_hop=[2, 2, 2], edges_per_hop=[4, 4])
