@@ -1,0 +1,223 @@
+"""bench.py -- headline measurement of the hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
+``segment_matmul`` on BASELINE.json configs[1] (154 relations, 21,111,007 rows, F=128, bf16;
+SURVEY.md 8(d) C2).  `value` is whole-job GFLOP/s (2*N*K*M flop per step / wall time).  With
+N > 1 ranks the row range is sharded contiguously (relation list cut at row boundaries), each
+rank multiplies its shard, and the timed region is compute-only with the outputs left sharded
+("scaling": "strong"); the RCCL all-gather of the outputs that BASELINE's north_star names is timed
+separately and reported under "allgather" (it is xGMI-bound and ~26x slower than
+the HBM-bound shard compute, so folding it in would only measure the links).
+
+The JSON line also carries `roofline` (dominant kernel vs the HBM roofline, durations measured
+with HIP events on the launch stream through pyg_hip_profile_*), `cpu_baseline` (the oracle timed
+on the host cores on a bounded sample, rank 0 / N=1 only) and `sampler` (neighbor_sample
+sampled-edges/s on the C3-shaped synthetic graph, when the HIP sampler is built).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+C2 = dict(B=154, N=21_111_007, F=128)
+
+
+def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
+    B, N, F = C2['B'], int(C2['N'] * scale), C2['F']
+    g = torch.Generator(device='cpu').manual_seed(0)
+    frac = torch.rand(B, generator=g)
+    sizes = torch.floor(frac / frac.sum() * N).long()
+    sizes[-1] += N - sizes.sum()
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    # contiguous row shard of this rank, ptr clipped to it
+    r0 = N * rank // world
+    r1 = N * (rank + 1) // world
+    lptr = (ptr.clamp(r0, r1) - r0)
+    gd = torch.Generator(device=device).manual_seed(1 + rank)
+    x = torch.empty(r1 - r0, F, device=device, dtype=dtype)
+    step = 4_000_000
+    for s in range(0, r1 - r0, step):
+        e = min(s + step, r1 - r0)
+        x[s:e] = torch.randn(e - s, F, device=device, generator=gd, dtype=torch.float32).to(dtype)
+    w = (torch.randn(B, F, F, device=device, generator=gd, dtype=torch.float32) / F ** 0.5).to(dtype)
+    return x, lptr, w, (N, B, F)
+
+
+def cpu_baseline_segment_matmul(sample_rows=120_000):
+    """Oracle (kind "port") on a bounded sample of the same workload: the first relations of C2
+    truncated to `sample_rows` rows, bf16, F=128."""
+    import oracle
+    B, F = 8, C2['F']
+    rng = np.random.default_rng(0)
+    sizes = np.full(B, sample_rows // B)
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(ptr[-1])
+    x = oracle.f32_to_bf16_bits(rng.standard_normal((n, F), dtype=np.float32))
+    w = oracle.f32_to_bf16_bits(rng.standard_normal((B, F, F), dtype=np.float32) / F ** 0.5)
+    oracle.segment_matmul(x[:1024], np.array([0, 1024]), w[:1], dtype=oracle.BF16)  # warm up / build
+    best = None
+    t_all = time.perf_counter()
+    reps = 0
+    while reps < 3 and time.perf_counter() - t_all < 25.0:
+        t0 = time.perf_counter()
+        oracle.segment_matmul(x, ptr, w, dtype=oracle.BF16)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
+    return dict(value=round(2.0 * n * F * F / best / 1e9, 2), unit='GFLOP/s', cores=threads, kind='port',
+                sample=f'oracle/oracle_matmul.c segment_matmul, {B} relations x {sample_rows // B} rows, '
+                       f'F=128 bf16, best of {reps}, OpenMP')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sampler', action='store_true')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    import torch.distributed as dist
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import pyg_lib_amd
+    from pyg_lib_amd import ops, _capi
+    L = _capi.lib()
+    L.pyg_hip_profile_enable.argtypes = [ctypes.c_int]
+    L.pyg_hip_profile_collect.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.pyg_hip_profile_collect.restype = ctypes.c_int
+
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    x, ptr, w, (N, B, F) = make_c2(device, rank, world, dtype, args.scale)
+    esz = x.element_size()
+
+    def step():
+        return ops.segment_matmul(x, ptr, w)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.pyg_hip_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    buf = (ctypes.c_float * max(args.steps, 1))()
+    nk = L.pyg_hip_profile_collect(buf, args.steps)
+    L.pyg_hip_profile_enable(0)
+    kernel_ms = float(np.mean([buf[i] for i in range(min(nk, args.steps))])) if nk else float('nan')
+    variant = ops.matmul_last_variant()
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    flops = 2.0 * N * F * F
+    value = flops / (elapsed / args.steps) / 1e9
+
+    # dominant kernel vs HBM roofline (this rank's shard): algorithmic bytes per launch
+    n_local = x.size(0)
+    alg_bytes = esz * (n_local * F + n_local * F + B * F * F) + 8 * (B + 1)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
+    roofline = dict(bound='hbm', achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=None, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
+                    mfma_tflops=None if achieved is None else round(2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12, 1))
+
+    allgather = None
+    if distributed:
+        # RCCL all-gather(v) of the sharded outputs over xGMI, timed on its own (see module docstring)
+        counts = [N * (r + 1) // world - N * r // world for r in range(world)]
+        full = torch.empty(N, F, device=device, dtype=dtype)
+        outs = list(full.split(counts, dim=0))
+        dist.all_gather(outs, out)  # warm-up (uneven sizes -> grouped send/recv inside RCCL)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dist.all_gather(outs, out)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = torch.tensor([(time.perf_counter() - ta) / reps], device=device, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        ag_ms = float(tg.item()) * 1e3
+        allgather = dict(ms=round(ag_ms, 3), bytes_per_rank_received=int((N - n_local) * F * esz),
+                         value_incl_allgather=round(flops / ((ms_per_step + ag_ms) * 1e-3) / 1e9, 1))
+        del full, outs
+
+    result = None
+    if rank == 0:
+        result = {
+            'metric': 'segment_matmul GFLOP/s + sampled-edges/sec, 1/2/4/8 MI355X vs CPU ref',
+            'value': round(value, 1), 'unit': 'GFLOP/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'segment_matmul ogbn-mag-shaped: 154 relations, 21,111,007 rows, '
+                                   'F_in=F_out=128 (BASELINE.json configs[1])',
+                       'relations': B, 'rows': N, 'F': F, 'scale': args.scale,
+                       'sharding': f'contiguous row shards x{world}, outputs left sharded'},
+            'roofline': roofline,
+        }
+        if allgather is not None:
+            result['allgather'] = allgather
+
+    del out
+    # secondary metric: sampled-edges/s of the HIP neighbour sampler (single GPU by design)
+    if rank == 0 and not args.no_sampler:
+        try:
+            from pyg_lib_amd import sampler_bench
+            result['sampler'] = sampler_bench.run(device)
+        except ImportError:
+            result['sampler'] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline_segment_matmul()
+    elif rank == 0:
+        result['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,6 +116,15 @@ PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_ho
  * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 
+/* ---- measurement hooks (bench.py) --------------------------------------------------------- */
+
+/* When enabled (per calling thread), every dominant-kernel launch is bracketed by a pair of HIP
+ * events recorded on the stream the kernel is launched on.  pyg_hip_profile_collect waits for the
+ * recorded launches, writes up to `capacity` durations (milliseconds, launch order) and returns
+ * how many launches were recorded since the last collect. */
+PYG_HIP_API void pyg_hip_profile_enable(int on);
+PYG_HIP_API int pyg_hip_profile_collect(float* ms_out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -412,6 +412,30 @@ __global__ void out_start_kernel(const DevGroup* __restrict__ descs, int B,
 // ---- host side -----------------------------------------------------------------------------------
 thread_local const char* g_last_variant = "";
 
+// Optional per-launch timing of the dominant kernel (bench.py roofline leg): when enabled, a pair of
+// HIP events brackets the main kernel on the stream it is launched on.
+struct ProfPair { hipEvent_t a, b; };
+thread_local bool g_prof_on = false;
+thread_local std::vector<ProfPair> g_prof;
+
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfPair p;
+  explicit ProfScope(hipStream_t st) : s(st), on(g_prof_on) {
+    if (on) {
+      on = hipEventCreate(&p.a) == hipSuccess && hipEventCreate(&p.b) == hipSuccess;
+      if (on) (void)hipEventRecord(p.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(p.b, s);
+      g_prof.push_back(p);
+    }
+  }
+};
+
 struct Workspace {
   DevGroup* descs;
   int32_t* tile_start;
@@ -456,7 +480,10 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
   int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
   dim3 grid((unsigned)gx, (unsigned)(M / MC), 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B);
+  {
+    ProfScope prof(stream);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B);
+  }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
 }
@@ -499,8 +526,11 @@ int launch_naive(const Workspace& w, int B, int64_t total_upper, hipStream_t str
   int64_t blocks = std::min<int64_t>((total_upper + 255) / 256, 256 * 16);
   if (blocks < 1) blocks = 1;
   // `total` is read on device from out_start[B]; pass the host upper bound for the loop limit
-  hipLaunchKernelGGL((naive_kernel<T, Acc>), dim3((unsigned)blocks), dim3(256), 0, stream, w.descs,
-                     w.row_start, B, total_upper);
+  {
+    ProfScope prof(stream);
+    hipLaunchKernelGGL((naive_kernel<T, Acc>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       w.descs, w.row_start, B, total_upper);
+  }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
 }
@@ -520,6 +550,8 @@ int dispatch_naive(int dtype, const Workspace& w, int B, int64_t total, hipStrea
     default: return fail(PYG_HIP_ERR_INVALID, "matmul: unknown dtype %d", dtype);
   }
 }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int run_planned(int dtype, const Workspace& w, int B, int64_t K, int64_t M, bool uniform,
                 int64_t tiles_upper, int64_t out_elems_upper, hipStream_t stream) {
@@ -550,6 +582,32 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 }
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
+
+void pyg_hip_profile_enable(int on) {
+  g_prof_on = on != 0;
+  if (!g_prof_on) {
+    for (auto& p : g_prof) {
+      (void)hipEventDestroy(p.a);
+      (void)hipEventDestroy(p.b);
+    }
+    g_prof.clear();
+  }
+}
+
+int pyg_hip_profile_collect(float* ms_out, int capacity) {
+  int n = 0;
+  for (auto& p : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      if (n < capacity && ms_out) ms_out[n] = ms;
+      ++n;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  g_prof.clear();
+  return n;
+}
 
 int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,
                            const void* other, const void* bias, void* out, int64_t N, int64_t K,
@@ -598,7 +656,8 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
     return dispatch_naive(dtype, w, (int)B, N * M, stream);
   }
   const int64_t tiles_upper = (N + kTileRows - 1) / kTileRows + B;
-  return run_planned(dtype, w, (int)B, K, M, true, tiles_upper, N * M, stream);
+  const bool fast = aligned16(input) && aligned16(other) && aligned16(out);
+  return run_planned(dtype, w, (int)B, K, M, fast, tiles_upper, N * M, stream);
 }
 
 int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, void* workspace,
@@ -640,6 +699,7 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
     hd[i].trans = gr.other_trans ? 1 : 0;
     hd[i].pad = 0;
     if (gr.k != groups[0].k || gr.m != groups[0].m) uniform = false;
+    if (!aligned16(gr.input) || !aligned16(gr.other) || !aligned16(gr.out)) uniform = false;
     if (gr.other_trans) any_trans = true;
     ht[i] = (int32_t)tiles;
     tiles += (hd[i].rows + kTileRows - 1) / kTileRows;

@@ -1,0 +1,262 @@
+"""Parity of the HIP segment_matmul / grouped_matmul with the oracle and the golden fixtures.
+
+Modelled on the reference's test/ops/test_matmul.py (:14-45 segment, :48-93 grouped) and
+test/csrc/ops/test_matmul.cpp.  Tolerances: fp32 <= 1e-5 relative (norm-wise);
+bf16/fp16 within one rounding of the correctly rounded result.
+"""
+import os.path as osp
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import pyg_lib_amd
+from pyg_lib_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(osp.join(osp.dirname(__file__), 'golden', 'matmul_golden.npz'))
+DEV = 'cuda:0'
+
+
+def rel_fro(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def from_bits(a):
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+
+
+def test_c1_fp32_matches_golden_and_oracle():
+    x, ptr, w = (torch.from_numpy(GOLD[k]) for k in ('c1_x', 'c1_ptr', 'c1_w'))
+    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
+    assert ops.matmul_last_variant() == 'mfma_f32_k64_mc64'
+    assert rel_fro(out.cpu().numpy(), GOLD['c1_out']) <= 1e-5
+    assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(GOLD['c1_x'], GOLD['c1_ptr'], GOLD['c1_w'])) <= 1e-5
+    # atol of the reference's own test (test_matmul.py:31) scaled by sqrt(K)*sigma: elementwise check
+    np.testing.assert_allclose(out.cpu().numpy(), GOLD['c1_out'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('ptr_on_device', [False, True])
+def test_docstring_example_generic_path(ptr_on_device):
+    x, ptr, w, b = (torch.from_numpy(GOLD[k]) for k in ('doc_x', 'doc_ptr', 'doc_w', 'doc_bias'))
+    p = ptr.to(DEV) if ptr_on_device else ptr
+    out = ops.segment_matmul(x.to(DEV), p, w.to(DEV))
+    assert ops.matmul_last_variant() == 'naive'
+    np.testing.assert_allclose(out.cpu().numpy(), GOLD['doc_out'], atol=1e-5)
+    outb = ops.segment_matmul(x.to(DEV), p, w.to(DEV), bias=b.to(DEV))
+    np.testing.assert_allclose(outb.cpu().numpy(), GOLD['doc_out_bias'], atol=1e-5)
+
+
+@pytest.mark.parametrize('ptr_on_device', [False, True])
+def test_ragged_bf16_with_empty_segments(ptr_on_device):
+    x, w, b = from_bits(GOLD['bf_x']), from_bits(GOLD['bf_w']), from_bits(GOLD['bf_bias'])
+    ptr = torch.from_numpy(GOLD['bf_ptr'])
+    p = ptr.to(DEV) if ptr_on_device else ptr
+    out = ops.segment_matmul(x.to(DEV), p, w.to(DEV))
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128'
+    got = bits(out)
+    ref = oracle.segment_matmul(GOLD['bf_x'], GOLD['bf_ptr'], GOLD['bf_w'], dtype=oracle.BF16)
+    for expect in (ref, GOLD['bf_out']):
+        np.testing.assert_allclose(oracle.bf16_bits_to_f32(got), oracle.bf16_bits_to_f32(expect), rtol=2 ** -7,
+                                   atol=1e-6)
+        assert (got == expect).mean() > 0.995
+    outb = ops.segment_matmul(x.to(DEV), p, w.to(DEV), bias=b.to(DEV))
+    np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(outb)), oracle.bf16_bits_to_f32(GOLD['bf_out_bias']),
+                               rtol=2 ** -6, atol=1e-6)
+
+
+def test_ragged_fp32_mfma_1e5():
+    x = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_x']))
+    w = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_w']))
+    ptr = torch.from_numpy(GOLD['bf_ptr'])
+    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
+    assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128'
+    assert rel_fro(out.cpu().numpy(), GOLD['f32r_out']) <= 1e-5
+    assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(x.numpy(), GOLD['bf_ptr'], w.numpy())) <= 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('K', [64, 128, 256])
+@pytest.mark.parametrize('M', [64, 128, 192, 256])
+def test_mfma_shape_sweep_vs_oracle(dtype, K, M):
+    torch.manual_seed(K * 1000 + M)
+    sizes = [130, 0, 1, 257, 64]
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    x = torch.randn(n, K).to(dtype)
+    w = (torch.randn(len(sizes), K, M) / K ** 0.5).to(dtype)
+    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
+    assert ops.matmul_last_variant().startswith('mfma_'), ops.matmul_last_variant()
+    if dtype == torch.float32:
+        ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy())
+        assert rel_fro(out.cpu().numpy(), ref) <= 1e-5
+    elif dtype == torch.float16:
+        ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy())
+        np.testing.assert_allclose(out.cpu().float().numpy(), ref.astype(np.float32), rtol=2 ** -10, atol=1e-4)
+    else:
+        ref = oracle.segment_matmul(bits(x), ptr.numpy(), bits(w), dtype=oracle.BF16)
+        np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -7,
+                                   atol=1e-4)
+        assert (bits(out) == ref).mean() > 0.99
+
+
+def test_asymmetric_weight_detects_transposes():
+    # A = I picks rows of W; an asymmetric W catches row/col swaps in the MFMA C-layout.
+    K = M = 128
+    x = torch.eye(K).bfloat16().repeat(3, 1)
+    w = (torch.arange(K * M, dtype=torch.float32).reshape(1, K, M) % 251).bfloat16()
+    out = ops.segment_matmul(x.to(DEV), torch.tensor([0, 3 * K]), w.to(DEV))
+    assert torch.equal(out.cpu(), w[0].repeat(3, 1))
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.int32, torch.int64, torch.int16, torch.int8, torch.uint8])
+def test_remaining_dtypes_generic_kernel(dtype):
+    torch.manual_seed(5)
+    ptr = torch.tensor([0, 3, 3, 10])
+    if dtype.is_floating_point:
+        x, w = torch.randn(10, 7, dtype=dtype), torch.randn(3, 7, 5, dtype=dtype)
+    else:
+        x = torch.randint(0, 4, (10, 7)).to(dtype)
+        w = torch.randint(0, 4, (3, 7, 5)).to(dtype)
+    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
+    assert ops.matmul_last_variant() == 'naive'
+    ref = torch.cat([x[0:3] @ w[0], x[3:3] @ w[1], x[3:10] @ w[2]])
+    if dtype == torch.float64:
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-12, atol=1e-12)
+    else:
+        assert torch.equal(out.cpu(), ref)
+
+
+def test_argument_checks_raise_runtime_error():
+    x = torch.randn(8, 16, device=DEV)
+    w = torch.randn(2, 16, 32, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.segment_matmul(x, torch.tensor([0, 5, 8]), w.double())  # dtype mismatch
+    with pytest.raises(RuntimeError):
+        ops.segment_matmul(x, torch.tensor([0, 8]), w)  # ptr.numel() != B + 1
+    with pytest.raises(RuntimeError):
+        ops.segment_matmul(x, torch.tensor([0, 5, 8], dtype=torch.int32), w)  # Long expected
+    with pytest.raises(RuntimeError):
+        ops.segment_matmul(x, torch.tensor([0, 9, 8]), w)  # decreasing ptr (host check)
+    with pytest.raises(RuntimeError):
+        ops.segment_matmul(x, torch.tensor([0, 5, 8]), torch.randn(2, 15, 32, device=DEV))
+
+
+def test_segment_matmul_backward():
+    # test/ops/test_matmul.py:33-45: gradient shapes; plus values against plain autograd
+    torch.manual_seed(0)
+    x = torch.randn(8, 16, device=DEV, requires_grad=True)
+    ptr = torch.tensor([0, 5, 8])
+    w = torch.randn(2, 16, 32, device=DEV, requires_grad=True)
+    b = torch.randn(2, 32, device=DEV, requires_grad=True)
+    out = ops.segment_matmul(x, ptr, w, bias=b)
+    out.mean().backward()
+    assert x.grad.shape == x.shape and w.grad.shape == w.shape and b.grad.shape == b.shape
+    x2 = x.detach().clone().requires_grad_()
+    w2 = w.detach().clone().requires_grad_()
+    ref = torch.cat([x2[0:5] @ w2[0] + b.detach()[0], x2[5:8] @ w2[1] + b.detach()[1]])
+    ref.mean().backward()
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(x.grad, x2.grad, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(w.grad, w2.grad, atol=1e-5, rtol=1e-5)
+
+
+def test_grouped_matmul_golden_and_transposed():
+    ins = [torch.from_numpy(GOLD[f'g_in{i}']) for i in range(3)]
+    oth = [torch.from_numpy(GOLD[f'g_ot{i}']) for i in range(3)]
+    outs = ops.grouped_matmul([a.to(DEV) for a in ins], [o.to(DEV) for o in oth])
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.cpu().numpy(), GOLD[f'g_out{i}'], atol=1e-4)
+    # transposed (non-contiguous) others, test_matmul.py:60-62
+    oth_t = [o.t().contiguous().to(DEV).t() for o in oth]
+    assert not oth_t[0].is_contiguous()
+    outs = ops.grouped_matmul([a.to(DEV) for a in ins], oth_t)
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.cpu().numpy(), GOLD[f'g_out{i}'], atol=1e-4)
+    biases = [torch.randn(o.size(-1), device=DEV) for o in oth]
+    outs_b = ops.grouped_matmul([a.to(DEV) for a in ins], [o.to(DEV) for o in oth], biases)
+    for o, ob, b in zip(outs, outs_b, biases):
+        torch.testing.assert_close(ob, o + b)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('trans', [False, True])
+def test_grouped_matmul_mfma_uniform_groups(dtype, trans):
+    # C4-shaped (F=256) but small: variable N_i, uniform K=M=256 -> MFMA path
+    torch.manual_seed(7)
+    rows = [300, 1, 0, 129, 512]
+    ins = [torch.randn(r, 256).to(dtype) for r in rows]
+    oth = [(torch.randn(256, 256) / 16).to(dtype) for _ in rows]
+    d_oth = [o.to(DEV) for o in oth]
+    if trans:
+        d_oth = [o.t().contiguous().t() for o in d_oth]
+    outs = ops.grouped_matmul([a.to(DEV) for a in ins], d_oth)
+    assert ops.matmul_last_variant().startswith('mfma_'), ops.matmul_last_variant()
+    for a, o, out in zip(ins, oth, outs):
+        if dtype == torch.float32:
+            ref = oracle.matmul(a.numpy(), o.numpy())
+            if a.size(0):
+                assert rel_fro(out.cpu().numpy(), ref) <= 1e-5
+        else:
+            ref = oracle.matmul(bits(a), bits(o), dtype=oracle.BF16)
+            np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref),
+                                       rtol=2 ** -7, atol=1e-4)
+
+
+def test_grouped_matmul_backward_shapes():
+    # test/ops/test_matmul.py:77-93
+    ins = [torch.randn(5, 16, device=DEV, requires_grad=True), torch.randn(6, 9, device=DEV, requires_grad=True)]
+    oth = [torch.randn(16, 48, device=DEV, requires_grad=True), torch.randn(9, 42, device=DEV, requires_grad=True)]
+    outs = ops.grouped_matmul(ins, oth)
+    sum(o.sum() for o in outs).backward()
+    for a, o in zip(ins, oth):
+        assert a.grad.shape == a.shape and o.grad.shape == o.shape
+        torch.testing.assert_close(a.grad, torch.ones(a.size(0), o.size(1), device=DEV) @ o.detach().t(),
+                                   atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(o.grad, a.detach().t() @ torch.ones(a.size(0), o.size(1), device=DEV),
+                                   atol=1e-4, rtol=1e-4)
+
+
+def test_full_size_c2_properties():
+    """BASELINE config C2 (154 relations, 21,111,007 rows, F=128, bf16): size-independent checks.
+
+    With W_b = 2^(b % 5 - 2) * P_b (a signed permutation scaled by a power of two) every output
+    element is an exactly representable bf16, so the result must equal the permuted, scaled input
+    bit for bit; a checksum of all outputs is compared in fp64.
+    """
+    B, N, F = 154, 21_111_007, 128
+    g = torch.Generator(device='cpu').manual_seed(0)
+    frac = torch.rand(B, generator=g)
+    sizes = torch.floor(frac / frac.sum() * N).long()
+    sizes[-1] += N - sizes.sum()
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    gd = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, F, device=DEV, generator=gd, dtype=torch.float32).bfloat16()
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in range(B)])
+    sign = (torch.randint(0, 2, (B, F), generator=g) * 2 - 1).float()
+    scale = 2.0 ** (torch.arange(B) % 5 - 2).float()
+    w = torch.zeros(B, F, F)
+    w[torch.arange(B)[:, None], perm, torch.arange(F)[None, :]] = sign * scale[:, None]
+    out = ops.segment_matmul(x, ptr, w.bfloat16().to(DEV))
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128'
+    # expected: out[r, j] = sign[b, j] * scale[b] * x[r, perm[b, j]]
+    seg = torch.repeat_interleave(torch.arange(B, device=DEV), sizes.to(DEV))
+    total = 0.0
+    bad = 0
+    step = 2_000_000
+    for s in range(0, N, step):
+        e = min(s + step, N)
+        sb = seg[s:e]
+        exp = torch.gather(x[s:e].float(), 1, perm.to(DEV)[sb]) * (sign * scale[:, None]).to(DEV)[sb]
+        bad += int((exp.bfloat16() != out[s:e]).sum())
+        total += float(out[s:e].double().sum() - exp.double().sum())
+    assert bad == 0
+    assert abs(total) < 1e-6
