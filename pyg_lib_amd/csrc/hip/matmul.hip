@@ -340,6 +340,202 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_kernel(const DevGroup* __re
   }
 }
 
+// ---- v2: LDS-staged streaming kernel for 16-bit types (the HBM-bound configs) ---------------------
+// Same tile walk and MFMA mapping as mfma_rows_kernel, but X and the output move between HBM and
+// registers as fully coalesced 1 KiB wave accesses (every instruction covers whole 256-byte rows)
+// and are re-shaped into / out of MFMA fragment order through a per-wave LDS stage with a 16-byte
+// XOR swizzle (conflict-free ds_read_b128 / ds_write_b128).  The next tile's rows are prefetched
+// into registers while the current tile is multiplied (issue-early / write-late).
+__device__ __forceinline__ u32x4 pack8(bf16_t, const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint16_t a = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i]);
+    uint16_t b = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i + 1]);
+    o[i] = (uint32_t)a | ((uint32_t)b << 16);
+  }
+  return o;
+}
+__device__ __forceinline__ u32x4 pack8(f16_t, const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint16_t a = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i]);
+    uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i + 1]);
+    o[i] = (uint32_t)a | ((uint32_t)b << 16);
+  }
+  return o;
+}
+
+template <typename T, int K, int MC, int NW>
+__global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
+    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B) {
+  constexpr int SZ = 2;
+  static_assert(Elem<T>::kSize == 2, "16-bit element types only");
+  constexpr int NT = MC / 32;
+  constexpr int LDW = K * SZ + 16;
+  constexpr int BM = NW * 32;
+  static_assert(BM == kTileRows, "tile table is built for 128-row tiles");
+  constexpr int CPR = K * SZ / 16;              // 16-byte chunks per X row
+  constexpr int NI = CPR / 2;                   // coalesced wave loads per 32-row tile
+  constexpr int XM = (CPR < 16 ? CPR : 16) - 1; // swizzle mask
+  constexpr int CPO = MC * SZ / 16;             // chunks per output row (this column chunk)
+  constexpr int NO = CPO / 2;
+  constexpr int OM = (CPO < 16 ? CPO : 16) - 1;
+  constexpr int STAGE = 32 * 16 * (CPR > CPO ? CPR : CPO);  // bytes per wave
+  constexpr int WBYTES = MC * LDW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int x = lane & 31;
+  const int h = lane >> 5;
+  const int col0 = blockIdx.y * MC;
+  char* stage = smem + WBYTES + wave * STAGE;
+
+  const int total = tile_start[B];
+  const int t0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
+  const int t1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+  if (t0 >= t1) return;
+
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= t0) lo = mid; else hi = mid;
+  }
+  int g = lo;       // group of the tile being prefetched
+  int staged = -1;  // group whose weight is in LDS
+
+  const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
+  const char* wfrag = smem + crow0 * LDW + (K / 2) * h * SZ;
+
+  // per-lane constants of the coalesced <-> fragment re-shaping
+  // load/store side: position p = i*64 + lane -> row r = p / CPR, slot c' = p % CPR
+  // fragment side:   lane (x, h) reads row x, chunk c at slot c ^ (x & XM)
+  u32x4 xr[NI];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+
+  auto prefetch = [&](int t) {
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPR;
+        const int cs = p % CPR;
+        const int c = cs ^ (r & XM);
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        xr[i] = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x4*>(dn.a + row * (K * SZ) + c * 16));
+      }
+    }
+  };
+
+  prefetch(t0);
+  for (int t = t0; t < t1; ++t) {
+    const DevGroup d = dn;
+    const int cg = g;
+    const int64_t row0 = n_row0, rows = n_rows;
+    const bool valid = n_valid;
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+    }
+    if (t + 1 < t1) prefetch(t + 1);
+
+    if (cg != staged) {
+      __syncthreads();
+      const char* w = d.w;
+      const int M = d.m;
+      if (!d.trans) {
+        constexpr int CW = MC / 8;
+        for (int idx = tid; idx < K * CW; idx += NW * 64) {
+          const int k = idx / CW;
+          const int cc = (idx - k * CW) * 8;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * M + col0 + cc) * SZ);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint16_t sv = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            *reinterpret_cast<uint16_t*>(smem + (cc + e) * LDW + k * 2) = sv;
+          }
+        }
+      } else {
+        constexpr int CW = K / 8;
+        for (int idx = tid; idx < MC * CW; idx += NW * 64) {
+          const int c = idx / CW;
+          const int kk = (idx - c * CW) * 8;
+          const u32x4 v =
+              *reinterpret_cast<const u32x4*>(w + ((int64_t)(col0 + c) * K + kk) * SZ);
+          *reinterpret_cast<u32x4*>(smem + c * LDW + kk * SZ) = v;
+        }
+      }
+      __syncthreads();
+      staged = cg;
+    }
+    if (!valid) continue;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      const int c = NI * h + s;
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(stage + (x * CPR + (c ^ (x & XM))) * 16);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW + s * 16);
+        acc[tt] = mfma_chunk(T{}, wv, xv, acc[tt]);
+      }
+    }
+
+    // epilogue: fragment order -> swizzled stage -> coalesced row stores
+    const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + col0 + (MC / 2) * h : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+      if (bp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = NO * h + 2 * tt + j;
+        *reinterpret_cast<u32x4*>(stage + (x * CPO + (c ^ (x & OM))) * 16) = pack8(T{}, v + 8 * j);
+      }
+    }
+    {
+      const int M = d.m;
+      char* obase = d.c + (row0 * M + col0) * SZ;
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPO;
+        const int cs = p % CPO;
+        const int c = cs ^ (r & OM);
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + p * 16);
+        if (row0 + r < rows)
+          __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(obase + (int64_t)r * M * SZ + c * 16));
+      }
+    }
+  }
+}
+
 // ---- generic kernel: one thread per output element, any dtype / shape ----------------------------
 template <typename T, typename Acc>
 struct NaiveCvt {
@@ -468,21 +664,34 @@ Workspace carve(void* ws, int64_t B) {
 template <typename T, int K, int MC>
 int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream_t stream) {
   constexpr int NW = 4;
-  constexpr int lds = MC * (K * Elem<T>::kSize + 16);
-  auto kern = mfma_rows_kernel<T, K, MC, NW>;
+  constexpr int SZ = Elem<T>::kSize;
+  constexpr int wbytes = MC * (K * SZ + 16);
+  constexpr int stage = 32 * (K > MC ? K : MC) * SZ;
+  constexpr int lds_v2 = wbytes + NW * stage;
+  // 16-bit types stream through the LDS-staged kernel (coalesced HBM access); fp32 is bound by
+  // the f32 MFMA rate, so the direct-fragment kernel is kept for it.
+  constexpr bool use_v2 = (SZ == 2) && (lds_v2 <= 160 * 1024);
+  constexpr int lds = use_v2 ? lds_v2 : wbytes;
+  const void* kern;
+  if constexpr (use_v2) kern = reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW>);
+  else kern = reinterpret_cast<const void*>(&mfma_rows_kernel<T, K, MC, NW>);
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const DeviceInfo& di = device_info();
-  int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
+  int per_cu = std::max(1, std::min(use_v2 ? 2 : 4, (160 * 1024) / lds));
   int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
   dim3 grid((unsigned)gx, (unsigned)(M / MC), 1);
   {
     ProfScope prof(stream);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B);
+    if constexpr (use_v2)
+      hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
+                         w.descs, w.tile_start, B);
+    else
+      hipLaunchKernelGGL((mfma_rows_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
+                         w.descs, w.tile_start, B);
   }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
