@@ -116,6 +116,82 @@ PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_ho
  * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 
+/* ---- neighbor_sample / hetero_neighbor_sample ---------------------------------------------- */
+
+/* Host services the sampler needs from its caller (the torch binding supplies the PyTorch
+ * caching allocator and the global CPU generator, so device memory and torch.manual_seed()
+ * behave exactly as for the reference operator). */
+typedef struct {
+  void* user;
+  /* Device allocation on the stream the sampler runs on; NULL on failure. */
+  void* (*alloc)(void* user, size_t bytes);
+  /* Release a block obtained from `alloc` (stream-ordered with the sampler's stream). */
+  void (*free)(void* user, void* ptr);
+  /* Fill 128 host int64 words exactly like RandintEngine's prefetch
+   * (pyg_lib/csrc/random/cpu/rand_engine.h:79-91): first != 0 -> at::randint(INT64_MIN,
+   * INT64_MAX, {128}); otherwise the in-place refill random_(INT64_MIN, INT64_MAX). */
+  void (*rng_block)(void* user, int64_t* words128_host, int first);
+} pyg_hip_sampler_host;
+
+/* One CSR relation of a (heterogeneous) graph.  src_type / dst_type index `node_types` in the
+ * order the reference's `edge_types` tuples name them (roles swap when csc, neighbor_kernel.cpp
+ * :715-716). */
+typedef struct {
+  const int64_t* rowptr; /* device, num_rows + 1 */
+  int64_t num_rows;
+  const int64_t* col;    /* device */
+  int64_t num_cols;
+  int32_t src_type;
+  int32_t dst_type;
+  const int64_t* num_neighbors_host; /* L fan-outs, host */
+} pyg_hip_relation;
+
+/* Seeds of one node type, in seed_dict iteration order. */
+typedef struct {
+  int32_t node_type;
+  int32_t reserved;
+  const int64_t* seed; /* device */
+  int64_t num_seed;
+} pyg_hip_seed_set;
+
+/* Results.  All pointers come from host->alloc and are owned by the caller afterwards (blocks
+ * may be larger than the element counts given here).
+ *   per node type t:  node_id[t] -> num_nodes[t] ids ([n] int64, or [n, 2] (batch, node) pairs
+ *                     when disjoint), nodes_per_hop_host[t*(L+1) ..]
+ *   per relation e:   row[e], col[e], edge_id[e] (NULL unless return_edge_id) -> num_edges[e],
+ *                     edges_per_hop_host[e*L ..]
+ * The `*_host` arrays and the pointer arrays are caller-provided host memory. */
+typedef struct {
+  int64_t** node_id;
+  int64_t* num_nodes;
+  int64_t* nodes_per_hop_host;
+  int64_t** row;
+  int64_t** col;
+  int64_t** edge_id;
+  int64_t* num_edges;
+  int64_t* edges_per_hop_host;
+  int64_t rng_blocks; /* 128-word prefetches consumed (incl. the constructor's) */
+} pyg_hip_sample_result;
+
+/*
+ * Multi-hop neighbour sampling with first-occurrence-ordered node relabelling, bit-exact with
+ * the reference's single-threaded CPU kernel (pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp
+ * :518-841; homogeneous :332-514 is the 1-type / 1-relation case; schemas
+ * pyg_lib/csrc/sampler/neighbor.cpp:130-147).  The reference has no device sampler at all.
+ *
+ * flags: csc, replace, disjoint, return_edge_id as in the schema.  `directed` must be true
+ * (the reference errors otherwise, neighbor_kernel.cpp:501).  Temporal (node_time / edge_time)
+ * and biased (edge_weight) sampling return PYG_HIP_ERR_UNSUPPORTED on the device path.
+ * Synchronises `stream` (output sizes are data dependent).
+ */
+PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
+                                               const pyg_hip_relation* relations_host,
+                                               int num_seed_sets,
+                                               const pyg_hip_seed_set* seeds_host, int L, int csc,
+                                               int replace, int disjoint, int return_edge_id,
+                                               const pyg_hip_sampler_host* host,
+                                               pyg_hip_sample_result* result, void* stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 
 /* When enabled (per calling thread), every dominant-kernel launch is bracketed by a pair of HIP

@@ -1,0 +1,942 @@
+// neighbor_sample / hetero_neighbor_sample for gfx950 (MI355X), bit-exact with the reference's
+// single-threaded CPU kernel (pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp).  The reference has
+// no device sampler; its CPU kernel is the semantic specification restated in oracle/.
+//
+// How a strictly sequential algorithm is made parallel without changing a single output
+// (DESIGN.md "neighbor_sample"):
+//   * RNG.  The reference consumes one stream of 64-bit words 16/32/64 bits at a time
+//     (rand_engine.h:41-76).  Which bits a draw uses depends only on how many bits every earlier
+//     draw took, and that is known from degrees and fan-outs before any sampling happens.  Each
+//     frontier node is summarised as a transition table over the five possible "bits left in the
+//     current word" states {0,16,32,48,64}; an exclusive scan under table composition gives every
+//     node its exact (word index, bit offset) start state.  The words themselves are drawn on the
+//     host by the caller's generator (torch.manual_seed compatible) and shipped to the device.
+//   * Sampling.  One wave per frontier node: full neighbourhoods are copied 64 edges at a time,
+//     Floyd's without-replacement picks (neighbor_kernel.cpp:231-240) are evaluated in draw order
+//     with the chosen set held across the wave's lanes.
+//   * Relabelling.  Local ids are first-occurrence ranks in emission order (mapper.h:30-46).
+//     Every emitted edge inserts its destination into an open-addressing hash table with
+//     atomicMin(emission position); an edge owns its node iff it holds the minimum; an exclusive
+//     scan of the owner flags yields the ranks, i.e. exactly the ids the sequential Mapper hands
+//     out.  Duplicate seeds keep the reference's quirk (ids count distinct nodes, rows count
+//     positions).
+// Everything per hop is HBM/latency-bound integer work: 8-byte gathers of col[], 16-byte hash
+// slots, coalesced row/col/edge-id streams.
+#include "common.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace pyg_hip {
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 kEmpty = ~0ull;           // empty hash key / unset value (memset 0xFF)
+constexpr u64 kProvisional = 1ull << 62;  // values >= this are emission positions, below: final ids
+
+// ---- RNG state algebra ---------------------------------------------------------------------------
+// State = number of unused 16-bit units in the current word (0..4).  tab.dw[u] / tab.nb[u]: words
+// advanced and units left after running a node's draws from state u.
+struct RngTab {
+  int32_t dw[5];
+  int32_t nb[5];
+};
+
+__host__ __device__ inline RngTab rng_identity() {
+  RngTab t;
+  for (int u = 0; u < 5; ++u) {
+    t.dw[u] = 0;
+    t.nb[u] = u;
+  }
+  return t;
+}
+
+__host__ __device__ inline int need_units(u64 range) {
+  // rand_engine.h:44-50: 16 bits below 2^16, 32 below 2^32, else 64
+  return range < (1ull << 16) ? 1 : (range < (1ull << 32) ? 2 : 4);
+}
+
+__host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
+  for (int u = 0; u < 5; ++u) {
+    if (t.nb[u] < n) {
+      t.dw[u] += 1;
+      t.nb[u] = 4 - n;
+    } else {
+      t.nb[u] -= n;
+    }
+  }
+}
+
+__host__ __device__ inline RngTab rng_compose(const RngTab& f, const RngTab& g) {
+  RngTab h;
+  for (int u = 0; u < 5; ++u) {
+    const int m = f.nb[u];
+    h.dw[u] = f.dw[u] + g.dw[m];
+    h.nb[u] = g.nb[m];
+  }
+  return h;
+}
+
+struct CountAgg {
+  int64_t edges;
+  RngTab tab;
+};
+
+struct CountOp {
+  __host__ __device__ CountAgg operator()(const CountAgg& a, const CountAgg& b) const {
+    CountAgg r;
+    r.edges = a.edges + b.edges;
+    r.tab = rng_compose(a.tab, b.tab);
+    return r;
+  }
+  __host__ __device__ static CountAgg identity() {
+    CountAgg r;
+    r.edges = 0;
+    r.tab = rng_identity();
+    return r;
+  }
+};
+
+struct SumOp {
+  __host__ __device__ int64_t operator()(int64_t a, int64_t b) const { return a + b; }
+  __host__ __device__ static int64_t identity() { return 0; }
+};
+
+// ---- device-wide exclusive scan (order preserving, generic operator) -------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+template <typename T, typename Op>
+__device__ T block_exclusive(T agg, T* lds, Op op, T* total) {
+  const int tid = threadIdx.x;
+  T* a = lds;
+  T* b = lds + kScanThreads;
+  a[tid] = agg;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {
+    T v = a[tid];
+    if (tid >= d) v = op(a[tid - d], v);
+    b[tid] = v;
+    __syncthreads();
+    T* tmp = a;
+    a = b;
+    b = tmp;
+  }
+  const T excl = tid ? a[tid - 1] : Op::identity();
+  *total = a[kScanThreads - 1];
+  __syncthreads();
+  return excl;
+}
+
+// Phase A: per-tile aggregates.
+template <typename T, typename Op, typename Load>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, int64_t n,
+                                                                   T* __restrict__ tile_agg) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  T agg = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) agg = op(agg, load(base + k));
+  T total;
+  (void)block_exclusive<T, Op>(agg, lds, op, &total);
+  if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
+}
+
+// Phase B: exclusive scan of the tile aggregates by one block; writes the grand total.
+template <typename T, typename Op>
+__global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(T* __restrict__ tile_agg,
+                                                                  int64_t ntiles,
+                                                                  T* __restrict__ total_out) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  T carry = Op::identity();
+  for (int64_t c0 = 0; c0 < ntiles; c0 += kScanThreads) {
+    const int64_t i = c0 + threadIdx.x;
+    const T v = i < ntiles ? tile_agg[i] : Op::identity();
+    T total;
+    const T excl = block_exclusive<T, Op>(v, lds, op, &total);
+    if (i < ntiles) tile_agg[i] = op(carry, excl);
+    carry = op(carry, total);
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+// Phase C: per-element exclusive prefixes -> Store.
+template <typename T, typename Op, typename Load, typename Store>
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Store store, int64_t n,
+                                                                  const T* __restrict__ tile_prefix,
+                                                                  T* __restrict__ total_out) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  T v[kScanItems];
+  T agg = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = base + k < n ? load(base + k) : Op::identity();
+    agg = op(agg, v[k]);
+  }
+  T total;
+  T run = block_exclusive<T, Op>(agg, lds, op, &total);
+  if (tile_prefix) run = op(tile_prefix[blockIdx.x], run);
+  else if (threadIdx.x == 0 && blockIdx.x == 0 && total_out) *total_out = total;  // single tile
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) store(base + k, run, v[k]);
+    run = op(run, v[k]);
+  }
+}
+
+// scratch: ntiles * sizeof(T) + sizeof(T) (total).  Returns device pointer to the total.
+template <typename T, typename Op, typename Load, typename Store>
+int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hipStream_t stream) {
+  if (n <= 0) {
+    T id = Op::identity();
+    PYG_HIP_CHECK(hipMemcpyAsync(total_dev, &id, sizeof(T), hipMemcpyHostToDevice, stream));
+    return PYG_HIP_OK;
+  }
+  const int64_t ntiles = (n + kScanTile - 1) / kScanTile;
+  if (ntiles == 1) {
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3(1), dim3(kScanThreads), 0,
+                       stream, load, store, n, (const T*)nullptr, total_dev);
+  } else {
+    hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, n, tile_buf);
+    hipLaunchKernelGGL((scan_spine_kernel<T, Op>), dim3(1), dim3(kScanThreads), 0, stream, tile_buf,
+                       ntiles, total_dev);
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf,
+                       (T*)nullptr);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+// ---- hash table ------------------------------------------------------------------------------------
+struct HashTable {
+  u64* keys;
+  u64* vals;
+  u64 mask;  // capacity - 1
+};
+
+__device__ __forceinline__ u64 hash64(u64 x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+// Find-or-claim the slot of `key`; returns the slot index.
+__device__ __forceinline__ u64 table_slot(const HashTable& t, u64 key) {
+  u64 s = hash64(key) & t.mask;
+  while (true) {
+    u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return s;
+    if (k == kEmpty) {
+      u64 expected = kEmpty;
+      if (__hip_atomic_compare_exchange_strong(&t.keys[s], &expected, key, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return s;
+      if (expected == key) return s;
+    }
+    s = (s + 1) & t.mask;
+  }
+}
+
+__device__ __forceinline__ u64 make_key(int64_t node, int64_t batch, int64_t num_batches) {
+  // non-disjoint: num_batches == 1, batch == 0
+  return (u64)node * (u64)num_batches + (u64)batch;
+}
+
+__global__ void rehash_kernel(HashTable oldt, HashTable newt) {
+  const u64 n = oldt.mask + 1;
+  for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    const u64 k = oldt.keys[i];
+    if (k == kEmpty) continue;
+    const u64 s = table_slot(newt, k);
+    newt.vals[s] = oldt.vals[i];
+  }
+}
+
+// ---- seeds -----------------------------------------------------------------------------------------
+// mapper.fill(seed) / per-seed insert (neighbor_kernel.cpp:409-416, 667-683): emission position =
+// seed index within its type; value = min position.
+__global__ void seed_insert_kernel(const int64_t* __restrict__ seed, int64_t n, int64_t batch0,
+                                   int disjoint, int64_t num_batches, HashTable t,
+                                   int64_t* __restrict__ nodes, int64_t* __restrict__ batch,
+                                   u64* __restrict__ slots) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = seed[i];
+  const int64_t b = disjoint ? batch0 + i : 0;
+  nodes[i] = v;
+  if (disjoint) batch[i] = b;
+  const u64 s = table_slot(t, make_key(v, b, num_batches));
+  slots[i] = s;
+  __hip_atomic_fetch_min(&t.vals[s], kProvisional + (u64)i, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-hop kernels -------------------------------------------------------------------------------
+struct CountLoad {
+  const int64_t* nodes;   // src node list
+  int64_t begin;          // frontier begin
+  const int64_t* rowptr;
+  int64_t count;          // fan-out (may be negative)
+  int replace;
+  __device__ CountAgg operator()(int64_t i) const {
+    CountAgg r;
+    r.tab = rng_identity();
+    const int64_t v = nodes[begin + i];
+    const int64_t rs = rowptr[v], re = rowptr[v + 1];
+    const int64_t deg = re - rs;
+    if (deg <= 0 || count == 0) {
+      r.edges = 0;
+      return r;
+    }
+    if (count < 0 || (!replace && count >= deg)) {
+      r.edges = deg;  // full neighbourhood, no draws (neighbor_kernel.cpp:188-193)
+      return r;
+    }
+    r.edges = count;
+    if ((u64)deg < (1ull << 16)) {
+      // all draws take 16 bits: closed form
+      for (int u = 0; u < 5; ++u) {
+        if (count <= u) {
+          r.tab.dw[u] = 0;
+          r.tab.nb[u] = u - (int)count;
+        } else {
+          const int64_t c2 = count - u;
+          const int64_t dw = (c2 + 3) / 4;
+          r.tab.dw[u] = (int32_t)dw;
+          r.tab.nb[u] = (int32_t)(4 * dw - c2);
+        }
+      }
+    } else if (replace) {
+      const int n = need_units((u64)deg);
+      for (int64_t j = 0; j < count; ++j) rng_push_draw(r.tab, n);
+    } else {
+      for (int64_t j = deg - count; j < deg; ++j) rng_push_draw(r.tab, need_units((u64)(j + 1)));
+    }
+    return r;
+  }
+};
+
+struct CountStore {
+  int64_t* edge_off;
+  int64_t* rng_word;
+  int32_t* rng_units;
+  int64_t word0;   // hop start state
+  int32_t units0;
+  __device__ void operator()(int64_t i, const CountAgg& prefix, const CountAgg&) const {
+    edge_off[i] = prefix.edges;
+    rng_word[i] = word0 + prefix.tab.dw[units0];
+    rng_units[i] = prefix.tab.nb[units0];
+  }
+};
+
+struct HopArgs {
+  const int64_t* nodes;       // src node list (positions are the emitted `row`)
+  const int64_t* batch;       // src batch ids (disjoint) or nullptr
+  int64_t begin;              // frontier begin (position of frontier node 0)
+  int64_t frontier;           // frontier size
+  const int64_t* rowptr;
+  const int64_t* col;
+  int64_t count;
+  int replace;
+  int64_t num_batches;
+  const int64_t* edge_off;
+  const int64_t* rng_word;
+  const int32_t* rng_units;
+  const u64* words;           // all prefetched RNG words, block-major
+  // emission buffers of this hop
+  int64_t* e_row;
+  int64_t* e_node;            // global dst node id
+  int64_t* e_batch;           // (disjoint) or nullptr
+  int64_t* e_eid;             // or nullptr
+  u64* e_slot;
+  HashTable table;
+};
+
+struct RngCursor {
+  int64_t word;
+  int units;
+  const u64* words;
+  // rand_engine.h:41-76 with the buffer laid out block-major: linear word index W lives at
+  // words[(W / 128) * 128 + (127 - W % 128)] (the reference consumes each 128-word block from
+  // its tail).
+  __device__ u64 next(u64 range) {
+    const int n = need_units(range);
+    if (units < n) {
+      ++word;
+      units = 4;
+    }
+    const u64 w = words[(word >> 7) * 128 + (127 - (word & 127))];
+    const int shift = (4 - units) * 16;
+    u64 v = w >> shift;
+    if (n == 1) v &= 0xffffull;
+    else if (n == 2) v &= 0xffffffffull;
+    units -= n;
+    return v % range;
+  }
+};
+
+__device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge, int64_t src_pos,
+                                     int64_t src_batch) {
+  const int64_t w = a.col[edge];
+  a.e_row[pos] = src_pos;
+  a.e_node[pos] = w;
+  if (a.e_batch) a.e_batch[pos] = src_batch;
+  if (a.e_eid) a.e_eid[pos] = edge;
+  const u64 s = table_slot(a.table, make_key(w, src_batch, a.num_batches));
+  a.e_slot[pos] = s;
+  __hip_atomic_fetch_min(&a.table.vals[s], kProvisional + (u64)pos, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave per frontier node (_sample, neighbor_kernel.cpp:177-243).
+__global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (i >= a.frontier) return;
+  const int64_t src_pos = a.begin + i;
+  const int64_t v = a.nodes[src_pos];
+  const int64_t src_batch = a.batch ? a.batch[src_pos] : 0;
+  const int64_t rs = a.rowptr[v];
+  const int64_t deg = a.rowptr[v + 1] - rs;
+  const int64_t count = a.count;
+  if (deg <= 0 || count == 0) return;
+  const int64_t off = a.edge_off[i];
+
+  if (count < 0 || (!a.replace && count >= deg)) {
+    for (int64_t t = lane; t < deg; t += 64) emit(a, off + t, rs + t, src_pos, src_batch);
+    return;
+  }
+
+  RngCursor rng{a.rng_word[i], a.rng_units[i], a.words};
+  if (a.replace) {
+    // `count` independent draws from [0, deg) (:196-210); lanes take turns holding a draw
+    int64_t mine = 0;
+    for (int64_t j = 0; j < count; ++j) {
+      const int64_t r = (int64_t)rng.next((u64)deg);
+      if (lane == (j & 63)) mine = r;
+      if ((j & 63) == 63 || j == count - 1) {
+        const int64_t jb = j & ~63ll;
+        if (jb + lane <= j) emit(a, off + jb + lane, rs + mine, src_pos, src_batch);
+      }
+    }
+    return;
+  }
+
+  // Floyd-style sampling without replacement (:231-240): for i in [deg-count, deg):
+  //   r = rand[0, i]; if r already chosen: r = i.
+  // The chosen set lives in the lanes (64 picks per round); earlier rounds are re-read from the
+  // edge ids already written to global memory.
+  int64_t mine = -1;
+  for (int64_t j = 0; j < count; ++j) {
+    const int64_t idx = deg - count + j;
+    int64_t r = (int64_t)rng.next((u64)(idx + 1));
+    const int64_t jb = j & ~63ll;
+    bool dup = (jb + lane < j) && (mine == r);
+    // picks of completed 64-draw rounds of this node were flushed to e_eid[off ..]
+    for (int64_t q = lane; q < jb; q += 64) dup = dup || (a.e_eid[off + q] - rs == r);
+    if (__any(dup)) r = idx;
+    if (lane == (j & 63)) mine = r;
+    if ((j & 63) == 63 || j == count - 1) {
+      if (jb + lane <= j) emit(a, off + jb + lane, rs + mine, src_pos, src_batch);
+      // make this round's edge ids visible to the wave's later history reads
+      if (j != count - 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+  }
+}
+
+// owner flag of emission p: it holds the table minimum  <=>  first occurrence of a NEW node
+struct FlagLoad {
+  const u64* slots;
+  const u64* vals;
+  __device__ int64_t operator()(int64_t p) const {
+    return vals[slots[p]] == kProvisional + (u64)p ? 1 : 0;
+  }
+};
+
+struct AssignStore {
+  const u64* slots;
+  u64* vals;
+  const int64_t* e_node;
+  const int64_t* e_batch;
+  int64_t* nodes;      // dst node list
+  int64_t* batch;      // dst batch list (disjoint) or nullptr
+  int64_t size_base;   // dst list size before this hop-relation
+  int64_t id_base;     // dst mapper `curr` before this hop-relation
+  int write_nodes;
+  __device__ void operator()(int64_t p, const int64_t& rank, const int64_t& flag) const {
+    if (!flag) return;
+    vals[slots[p]] = (u64)(id_base + rank);
+    if (write_nodes) {
+      nodes[size_base + rank] = e_node[p];
+      if (batch) batch[size_base + rank] = e_batch[p];
+    }
+  }
+};
+
+__global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __restrict__ vals,
+                                int64_t n, int64_t* __restrict__ out_col) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p < n) out_col[p] = (int64_t)vals[slots[p]];
+}
+
+__global__ void interleave_kernel(const int64_t* __restrict__ batch,
+                                  const int64_t* __restrict__ node, int64_t n,
+                                  int64_t* __restrict__ out) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p < n) {
+    out[2 * p] = batch[p];
+    out[2 * p + 1] = node[p];
+  }
+}
+
+// ---- host driver -----------------------------------------------------------------------------------
+struct Ctx {
+  const pyg_hip_sampler_host* host;
+  hipStream_t stream;
+  std::vector<void*> live;  // every block obtained from host->alloc and not yet handed out/freed
+  void* alloc(size_t bytes) {
+    void* p = host->alloc(host->user, bytes ? bytes : 16);
+    if (p) live.push_back(p);
+    return p;
+  }
+  void release(void* p) {
+    if (!p) return;
+    auto it = std::find(live.begin(), live.end(), p);
+    if (it != live.end()) live.erase(it);
+    host->free(host->user, p);
+  }
+  void keep(void* p) {  // ownership passes to the caller
+    auto it = std::find(live.begin(), live.end(), p);
+    if (it != live.end()) live.erase(it);
+  }
+  void release_all() {
+    for (void* p : live) host->free(host->user, p);
+    live.clear();
+  }
+};
+
+#define PYG_ALLOC(ptr, type, ctx, bytes)                                                   \
+  do {                                                                                     \
+    ptr = static_cast<type>((ctx).alloc(bytes));                                           \
+    if (!ptr) return fail(PYG_HIP_ERR_RUNTIME, "sampler: device allocation of %zu bytes failed", \
+                          (size_t)(bytes));                                                \
+  } while (0)
+
+// growable device array of int64
+struct DevVec {
+  int64_t* p = nullptr;
+  int64_t size = 0;
+  int64_t cap = 0;
+  int reserve(Ctx& c, int64_t n) {
+    if (n <= cap) return PYG_HIP_OK;
+    const int64_t ncap = std::max<int64_t>(n, std::max<int64_t>(2 * cap, 1024));
+    int64_t* np;
+    PYG_ALLOC(np, int64_t*, c, sizeof(int64_t) * (size_t)ncap);
+    if (size > 0)
+      PYG_HIP_CHECK(hipMemcpyAsync(np, p, sizeof(int64_t) * (size_t)size, hipMemcpyDeviceToDevice,
+                                   c.stream));
+    c.release(p);
+    p = np;
+    cap = ncap;
+    return PYG_HIP_OK;
+  }
+};
+
+struct NodeSet {
+  DevVec nodes, batch;
+  int64_t distinct = 0;  // Mapper::curr
+  int64_t slice_b = 0, slice_e = 0;
+  HashTable table{nullptr, nullptr, 0};
+  int64_t entries_bound = 0;  // upper bound of keys present in the table
+};
+
+int table_reserve(Ctx& c, NodeSet& ns, int64_t extra) {
+  const int64_t need = ns.entries_bound + extra;
+  u64 cap = ns.table.keys ? ns.table.mask + 1 : 0;
+  if (cap >= 2 * (u64)need && cap > 0) {
+    ns.entries_bound = need;
+    return PYG_HIP_OK;
+  }
+  u64 ncap = 1024;
+  while (ncap < 4 * (u64)need) ncap <<= 1;
+  HashTable nt;
+  PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * ncap);
+  PYG_ALLOC(nt.vals, u64*, c, sizeof(u64) * ncap);
+  nt.mask = ncap - 1;
+  PYG_HIP_CHECK(hipMemsetAsync(nt.keys, 0xFF, sizeof(u64) * ncap, c.stream));
+  PYG_HIP_CHECK(hipMemsetAsync(nt.vals, 0xFF, sizeof(u64) * ncap, c.stream));
+  if (ns.table.keys) {
+    hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)std::min<u64>((cap + 255) / 256, 4096)),
+                       dim3(256), 0, c.stream, ns.table, nt);
+    PYG_HIP_CHECK(hipGetLastError());
+    c.release(ns.table.keys);
+    c.release(ns.table.vals);
+  }
+  ns.table = nt;
+  ns.entries_bound = need;
+  return PYG_HIP_OK;
+}
+
+struct HostPinned {
+  void* p = nullptr;
+  ~HostPinned() {}
+};
+
+int get_pinned(void** out, size_t bytes) {
+  static thread_local void* buf = nullptr;
+  static thread_local size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) PYG_HIP_CHECK(hipHostFree(buf));
+    buf = nullptr;
+    cap = 0;
+    PYG_HIP_CHECK(hipHostMalloc(&buf, std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+    cap = std::max<size_t>(bytes, 4096);
+  }
+  *out = buf;
+  return PYG_HIP_OK;
+}
+
+struct RngHost {
+  int64_t blocks = 0;         // 128-word blocks generated so far
+  u64* dev = nullptr;         // device copy of all blocks
+  int64_t dev_cap_blocks = 0;
+  int64_t word = 0;           // engine state: linear word index
+  int units = 4;              //               16-bit units left in that word
+};
+
+int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
+  const int64_t need_blocks = last_word / 128 + 1;
+  if (need_blocks <= r.blocks) return PYG_HIP_OK;
+  if (need_blocks > r.dev_cap_blocks) {
+    const int64_t ncap = std::max<int64_t>(need_blocks, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
+    u64* nd;
+    PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
+    if (r.blocks > 0)
+      PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(u64) * 128 * (size_t)r.blocks,
+                                   hipMemcpyDeviceToDevice, c.stream));
+    c.release(r.dev);
+    r.dev = nd;
+    r.dev_cap_blocks = ncap;
+  }
+  const int64_t nnew = need_blocks - r.blocks;
+  std::vector<int64_t> tmp((size_t)nnew * 128);
+  for (int64_t b = 0; b < nnew; ++b)
+    c.host->rng_block(c.host->user, tmp.data() + b * 128, (r.blocks + b) == 0 ? 1 : 0);
+  // pageable -> device; the vector dies at scope exit, so make the copy synchronous
+  PYG_HIP_CHECK(hipMemcpyAsync(r.dev + r.blocks * 128, tmp.data(), sizeof(u64) * 128 * (size_t)nnew,
+                               hipMemcpyHostToDevice, c.stream));
+  PYG_HIP_CHECK(hipStreamSynchronize(c.stream));
+  r.blocks = need_blocks;
+  return PYG_HIP_OK;
+}
+
+struct RelState {
+  DevVec row, col, eid;
+  std::vector<int64_t> edges_per_hop;
+};
+
+int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* rels,
+                int num_seed_sets, const pyg_hip_seed_set* seeds, int L, int csc, int replace,
+                int disjoint, int return_edge_id, Ctx& c, pyg_hip_sample_result* res) {
+  hipStream_t stream = c.stream;
+  std::vector<NodeSet> ns((size_t)num_node_types);
+  std::vector<RelState> rs((size_t)num_relations);
+  std::vector<std::vector<int64_t>> nodes_per_hop((size_t)num_node_types);
+  RngHost rng;
+
+  int64_t num_batches = 1;
+  if (disjoint) {
+    num_batches = 0;
+    for (int s = 0; s < num_seed_sets; ++s) num_batches += seeds[s].num_seed;
+    if (num_batches < 1) num_batches = 1;
+    PYG_HIP_REQUIRE(num_batches < (1ll << 22), "sampler: too many seeds for disjoint sampling");
+  }
+
+  void* pinned = nullptr;
+  {
+    int rc = get_pinned(&pinned, 4096);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+
+  // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
+  {
+    int rc = rng_ensure(c, rng, 0);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+
+  // ---- seeds ----
+  int64_t batch0 = 0;
+  for (int s = 0; s < num_seed_sets; ++s) {
+    const pyg_hip_seed_set& ss = seeds[s];
+    PYG_HIP_REQUIRE(ss.node_type >= 0 && ss.node_type < num_node_types, "sampler: bad seed type");
+    NodeSet& n = ns[(size_t)ss.node_type];
+    PYG_HIP_REQUIRE(n.nodes.size == 0, "sampler: node type seeded twice");
+    const int64_t S = ss.num_seed;
+    n.slice_b = 0;
+    n.slice_e = S;
+    if (S == 0) continue;
+    int rc = n.nodes.reserve(c, S);
+    if (rc != PYG_HIP_OK) return rc;
+    if (disjoint) {
+      rc = n.batch.reserve(c, S);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    rc = table_reserve(c, n, S);
+    if (rc != PYG_HIP_OK) return rc;
+    u64* slots;
+    PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
+    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
+                       disjoint ? n.batch.p : (int64_t*)nullptr, slots);
+    PYG_HIP_CHECK(hipGetLastError());
+    // ranks of first occurrences = local ids (duplicates keep their first id)
+    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
+    int64_t* tile_buf;
+    PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
+    FlagLoad fl{slots, n.table.vals};
+    AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, tile_buf + ntiles, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                 stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    n.distinct = *static_cast<int64_t*>(pinned);
+    n.nodes.size = S;
+    if (disjoint) n.batch.size = S;
+    c.release(slots);
+    c.release(tile_buf);
+    batch0 += S;
+  }
+  for (int t = 0; t < num_node_types; ++t) nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size);
+
+  // ---- hops ----
+  for (int ell = 0; ell < L; ++ell) {
+    for (int e = 0; e < num_relations; ++e) {
+      const pyg_hip_relation& r = rels[e];
+      const int src = !csc ? r.src_type : r.dst_type;
+      const int dst = !csc ? r.dst_type : r.src_type;
+      NodeSet& sn = ns[(size_t)src];
+      NodeSet& dn = ns[(size_t)dst];
+      RelState& st = rs[(size_t)e];
+      const int64_t count = r.num_neighbors_host[ell];
+      const int64_t F = sn.slice_e - sn.slice_b;
+      st.edges_per_hop.push_back(0);
+      if (F <= 0 || count == 0 || r.num_cols == 0) continue;
+
+      // 1. per-node edge counts + RNG transition tables -> exclusive scan
+      const int64_t ntiles = (F + kScanTile - 1) / kScanTile;
+      CountAgg* tile_buf;
+      PYG_ALLOC(tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
+      int64_t* edge_off;
+      int64_t* rng_word;
+      int32_t* rng_units;
+      PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
+      PYG_ALLOC(rng_word, int64_t*, c, sizeof(int64_t) * (size_t)F);
+      PYG_ALLOC(rng_units, int32_t*, c, sizeof(int32_t) * (size_t)F);
+      CountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, replace};
+      CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
+      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, tile_buf + ntiles, stream);
+      if (rc != PYG_HIP_OK) return rc;
+      PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(CountAgg), hipMemcpyDeviceToHost,
+                                   stream));
+      PYG_HIP_CHECK(hipStreamSynchronize(stream));
+      const CountAgg tot = *static_cast<CountAgg*>(pinned);
+      const int64_t E = tot.edges;
+      const int64_t end_word = rng.word + tot.tab.dw[rng.units];
+      const int end_units = tot.tab.nb[rng.units];
+      c.release(tile_buf);
+      if (E == 0) {
+        c.release(edge_off);
+        c.release(rng_word);
+        c.release(rng_units);
+        continue;
+      }
+      // 2. make the consumed random words resident (drawn by the caller's generator)
+      rc = rng_ensure(c, rng, end_word);
+      if (rc != PYG_HIP_OK) return rc;
+      rng.word = end_word;
+      rng.units = end_units;
+
+      // 3. sample + insert
+      rc = st.row.reserve(c, st.row.size + E);
+      if (rc != PYG_HIP_OK) return rc;
+      rc = st.col.reserve(c, st.col.size + E);
+      if (rc != PYG_HIP_OK) return rc;
+      // edge ids are always produced: they double as the chosen-set history of large fan-outs
+      rc = st.eid.reserve(c, st.eid.size + E);
+      if (rc != PYG_HIP_OK) return rc;
+      rc = dn.nodes.reserve(c, dn.nodes.size + E);
+      if (rc != PYG_HIP_OK) return rc;
+      if (disjoint) {
+        rc = dn.batch.reserve(c, dn.batch.size + E);
+        if (rc != PYG_HIP_OK) return rc;
+      }
+      rc = table_reserve(c, dn, E);
+      if (rc != PYG_HIP_OK) return rc;
+      int64_t* e_node;
+      int64_t* e_batch = nullptr;
+      u64* e_slot;
+      PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
+      HopArgs a;
+      a.nodes = sn.nodes.p;
+      a.batch = disjoint ? sn.batch.p : nullptr;
+      a.begin = sn.slice_b;
+      a.frontier = F;
+      a.rowptr = r.rowptr;
+      a.col = r.col;
+      a.count = count;
+      a.replace = replace;
+      a.num_batches = num_batches;
+      a.edge_off = edge_off;
+      a.rng_word = rng_word;
+      a.rng_units = rng_units;
+      a.words = rng.dev;
+      a.e_row = st.row.p + st.row.size;
+      a.e_node = e_node;
+      a.e_batch = e_batch;
+      a.e_eid = st.eid.p + st.eid.size;
+      a.e_slot = e_slot;
+      a.table = dn.table;
+      hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, a);
+      PYG_HIP_CHECK(hipGetLastError());
+
+      // 4. first occurrences -> ranks -> new local ids / appended nodes
+      const int64_t etiles = (E + kScanTile - 1) / kScanTile;
+      int64_t* ftile;
+      PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
+      FlagLoad fl{e_slot, dn.table.vals};
+      AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
+                     disjoint ? dn.batch.p : (int64_t*)nullptr, dn.nodes.size, dn.distinct, 1};
+      rc = device_scan<int64_t, SumOp>(fl, as, E, ftile, ftile + etiles, stream);
+      if (rc != PYG_HIP_OK) return rc;
+      // 5. local ids of every emitted edge
+      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream,
+                         e_slot, dn.table.vals, E, st.col.p + st.col.size);
+      PYG_HIP_CHECK(hipGetLastError());
+      PYG_HIP_CHECK(hipMemcpyAsync(pinned, ftile + etiles, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                   stream));
+      PYG_HIP_CHECK(hipStreamSynchronize(stream));
+      const int64_t U = *static_cast<int64_t*>(pinned);
+      dn.nodes.size += U;
+      if (disjoint) dn.batch.size += U;
+      dn.distinct += U;
+      dn.entries_bound = dn.entries_bound - E + U;
+      st.row.size += E;
+      st.col.size += E;
+      st.eid.size += E;
+      st.edges_per_hop.back() = E;
+      c.release(edge_off);
+      c.release(rng_word);
+      c.release(rng_units);
+      c.release(e_node);
+      if (e_batch) c.release(e_batch);
+      c.release(e_slot);
+      c.release(ftile);
+    }
+    for (int t = 0; t < num_node_types; ++t) {
+      NodeSet& n = ns[(size_t)t];
+      n.slice_b = n.slice_e;
+      n.slice_e = n.nodes.size;
+      nodes_per_hop[(size_t)t].push_back(n.slice_e - n.slice_b);
+    }
+  }
+
+  // ---- hand the results over ----
+  for (int t = 0; t < num_node_types; ++t) {
+    NodeSet& n = ns[(size_t)t];
+    res->num_nodes[t] = n.nodes.size;
+    for (int l = 0; l <= L; ++l) res->nodes_per_hop_host[(size_t)t * (L + 1) + l] = nodes_per_hop[(size_t)t][(size_t)l];
+    if (!disjoint) {
+      if (!n.nodes.p) PYG_ALLOC(n.nodes.p, int64_t*, c, 16);
+      res->node_id[t] = n.nodes.p;
+      c.keep(n.nodes.p);
+    } else {
+      int64_t* out;
+      PYG_ALLOC(out, int64_t*, c, sizeof(int64_t) * 2 * (size_t)std::max<int64_t>(n.nodes.size, 1));
+      if (n.nodes.size > 0) {
+        hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((n.nodes.size + 255) / 256)), dim3(256),
+                           0, stream, n.batch.p, n.nodes.p, n.nodes.size, out);
+        PYG_HIP_CHECK(hipGetLastError());
+      }
+      res->node_id[t] = out;
+      c.keep(out);
+    }
+  }
+  for (int e = 0; e < num_relations; ++e) {
+    RelState& st = rs[(size_t)e];
+    if (!st.row.p) PYG_ALLOC(st.row.p, int64_t*, c, 16);
+    if (!st.col.p) PYG_ALLOC(st.col.p, int64_t*, c, 16);
+    if (!st.eid.p) PYG_ALLOC(st.eid.p, int64_t*, c, 16);
+    // csc only swaps the returned (row, col) (get_sampled_edges, neighbor_kernel.cpp:155-159)
+    res->row[e] = !csc ? st.row.p : st.col.p;
+    res->col[e] = !csc ? st.col.p : st.row.p;
+    c.keep(st.row.p);
+    c.keep(st.col.p);
+    res->num_edges[e] = st.row.size;
+    if (return_edge_id) {
+      res->edge_id[e] = st.eid.p;
+      c.keep(st.eid.p);
+    } else {
+      res->edge_id[e] = nullptr;
+    }
+    for (int l = 0; l < L; ++l) res->edges_per_hop_host[(size_t)e * L + l] = st.edges_per_hop[(size_t)l];
+  }
+  res->rng_blocks = rng.blocks;
+  PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  return PYG_HIP_OK;
+}
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
+                                              const pyg_hip_relation* relations, int num_seed_sets,
+                                              const pyg_hip_seed_set* seeds, int L, int csc,
+                                              int replace, int disjoint, int return_edge_id,
+                                              const pyg_hip_sampler_host* host,
+                                              pyg_hip_sample_result* result, void* stream_) {
+  PYG_HIP_REQUIRE(num_node_types > 0 && num_relations >= 0 && num_seed_sets >= 0 && L >= 0,
+                  "sampler: bad sizes");
+  PYG_HIP_REQUIRE(host && host->alloc && host->free && host->rng_block,
+                  "sampler: host callbacks missing");
+  PYG_HIP_REQUIRE(result && result->node_id && result->num_nodes && result->nodes_per_hop_host &&
+                      (num_relations == 0 ||
+                       (result->row && result->col && result->edge_id && result->num_edges &&
+                        result->edges_per_hop_host)),
+                  "sampler: result arrays missing");
+  for (int e = 0; e < num_relations; ++e) {
+    const pyg_hip_relation& r = relations[e];
+    PYG_HIP_REQUIRE(r.src_type >= 0 && r.src_type < num_node_types && r.dst_type >= 0 &&
+                        r.dst_type < num_node_types,
+                    "sampler: relation %d names an unknown node type", e);
+    PYG_HIP_REQUIRE(r.rowptr && (r.col || r.num_cols == 0) && r.num_neighbors_host,
+                    "sampler: relation %d has NULL arrays", e);
+  }
+  Ctx c;
+  c.host = host;
+  c.stream = static_cast<hipStream_t>(stream_);
+  int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, L, csc,
+                       replace, disjoint, return_edge_id, c, result);
+  if (rc != PYG_HIP_OK) {
+    (void)hipStreamSynchronize(c.stream);
+  }
+  c.release_all();  // scratch (and, on failure, everything)
+  return rc;
+}
