@@ -131,10 +131,12 @@ def _sample(node_types: List[str], edge_types: List[EdgeType], rowptr_dict, col_
     if len(Ls) > 1:
         raise RuntimeError('pyg_lib_amd: all relations must list the same number of hops')
     device = None
-    for k, v in list(rowptr_dict.items()) + list(col_dict.items()):
-        _check_index_tensor(v, 'rowptr' if k in rowptr_dict and v is rowptr_dict[k] else 'col')
+    for v in rowptr_dict.values():
+        _check_index_tensor(v, 'rowptr')
         device = device or v.device
-    for k, v in seed_dict.items():
+    for v in col_dict.values():
+        _check_index_tensor(v, 'col')
+    for v in seed_dict.values():
         _check_index_tensor(v, 'seed')
         device = device or v.device
     rels = (_Relation * max(E, 1))()

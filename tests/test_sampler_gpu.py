@@ -1,0 +1,188 @@
+"""Bit-exact parity of the HIP neighbour sampler with the oracle and the reference's golden vectors.
+
+Modelled on test/csrc/sampler/test_neighbor.cpp; every comparison is exact (integer outputs,
+SURVEY.md 8(a) S1-S5), including how far torch's global CPU generator advanced.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pyg_lib_amd import sampler
+from tests.golden import sampler_reference_vectors as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+I64_MIN, I64_MAX = -2**63, 2**63 - 1
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.long).to(DEV)
+
+
+def random_csr(n, avg_deg, seed, max_deg=None, zero_frac=0.1):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(avg_deg, n).astype(np.int64)
+    deg[rng.random(n) < zero_frac] = 0
+    if max_deg is not None:
+        deg = np.minimum(deg, max_deg)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
+    return rowptr, col
+
+
+def run_both(rowptr, col, seed, fanout, manual_seed, **kw):
+    torch.manual_seed(manual_seed)
+    out = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seed), fanout, **kw)
+    after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+    ref = oracle.neighbor_sample(rowptr, col, np.asarray(seed, dtype=np.int64), fanout, rng_seed=manual_seed, **kw)
+    return out, after, ref
+
+
+def assert_same(out, after, ref, manual_seed, return_edge_id=True):
+    row, col, node, eid, nh, eh = out
+    rrow, rcol, rnode, reid, rnh, reh, info = ref
+    assert nh == rnh and eh == reh
+    assert torch.equal(row.cpu(), torch.from_numpy(rrow))
+    assert torch.equal(col.cpu(), torch.from_numpy(rcol))
+    assert torch.equal(node.cpu(), torch.from_numpy(rnode))
+    if return_edge_id:
+        assert torch.equal(eid.cpu(), torch.from_numpy(reid))
+    else:
+        assert eid is None
+    # the global CPU generator advanced by exactly the reference's number of 128-word prefetches
+    expect_after = int(oracle.mt19937_words(manual_seed, info['rng_blocks'] * 128 + 1)[-1])
+    assert after == expect_after
+
+
+SUPPORTED = [c for c in G.CASES if 'node_time' not in c['kwargs'] and 'edge_time' not in c['kwargs']]
+
+
+@pytest.mark.parametrize('case', SUPPORTED, ids=[c['name'] for c in SUPPORTED])
+def test_reference_golden_vectors(case):
+    torch.manual_seed(case.get('manual_seed', 0))
+    row, col, node, eid, nh, eh = sampler.neighbor_sample(dev(case['rowptr']), dev(case['col']), dev(case['seed']),
+                                                          case['num_neighbors'], **case['kwargs'])
+    assert row.cpu().tolist() == case['row']
+    assert col.cpu().tolist() == case['col_out']
+    assert node.cpu().tolist() == case['node']
+    assert eid.cpu().tolist() == case['edge']
+    if 'nodes_per_hop' in case:
+        assert nh == case['nodes_per_hop'] and eh == case['edges_per_hop']
+
+
+def test_reference_hetero_golden_vector():
+    c = G.HETERO_CASE
+    et = c['edge_types'][0]
+    out = sampler.hetero_neighbor_sample({et: dev(G.ROWPTR)}, {et: dev(G.COL)}, {'paper': dev(c['seed'])},
+                                         {et: c['num_neighbors']})
+    assert out[0][et].cpu().tolist() == c['row']
+    assert out[1][et].cpu().tolist() == c['col_out']
+    assert out[2]['paper'].cpu().tolist() == c['node']
+    assert out[3][et].cpu().tolist() == c['edge']
+    assert out[4]['paper'] == c['nodes_per_hop'] and out[5][et] == c['edges_per_hop']
+
+
+@pytest.mark.parametrize('manual_seed', [0, 12345, 123456])
+@pytest.mark.parametrize('variant', ['plain', 'disjoint', 'csc', 'no_edge_id', 'replace', 'replace_disjoint'])
+def test_random_graph_matches_oracle(manual_seed, variant):
+    rowptr, col = random_csr(5000, 12, seed=1)
+    seeds = np.random.default_rng(2).permutation(5000)[:64]
+    kw = dict(plain={}, disjoint=dict(disjoint=True), csc=dict(csc=True), no_edge_id=dict(return_edge_id=False),
+              replace=dict(replace=True), replace_disjoint=dict(replace=True, disjoint=True))[variant]
+    out, after, ref = run_both(rowptr, col, seeds, [15, 10, 5], manual_seed, **kw)
+    assert_same(out, after, ref, manual_seed, return_edge_id=kw.get('return_edge_id', True))
+    assert sum(ref[5]) > 5000  # a real workload, several RNG refills
+    assert ref[6]['rng_blocks'] > 3
+
+
+def test_duplicate_seeds_and_zero_degree_and_full_neighbourhood():
+    rowptr, col = random_csr(300, 6, seed=3, zero_frac=0.3)
+    seeds = np.array([5, 5, 7, 5, 9, 7, 0, 1, 2])
+    for fan in ([-1, -1], [3, -1, 2], [0, 4], [100]):
+        out, after, ref = run_both(rowptr, col, seeds, fan, 7)
+        assert_same(out, after, ref, 7)
+    out, after, ref = run_both(rowptr, col, np.zeros(0, dtype=np.int64), [3, 3], 7)
+    assert_same(out, after, ref, 7)
+
+
+def test_large_fanout_uses_history_of_earlier_rounds():
+    # fan-out > 64: Floyd's chosen set spans several 64-lane rounds
+    rowptr, col = random_csr(2000, 400, seed=4, zero_frac=0.0)
+    seeds = np.arange(0, 2000, 97)
+    out, after, ref = run_both(rowptr, col, seeds, [150, 3], 11)
+    assert_same(out, after, ref, 11)
+    out, after, ref = run_both(rowptr, col, seeds, [200], 11, replace=True)
+    assert_same(out, after, ref, 11)
+
+
+def test_wide_draws_above_65535():
+    # hubs with degree >= 2^16 switch their draws to 32 bits (rand_engine.h:44-50) in the middle of
+    # the stream; neighbours keep 16-bit draws.
+    rng = np.random.default_rng(5)
+    n = 4000
+    deg = rng.poisson(20, n).astype(np.int64)
+    deg[17] = 70000
+    deg[123] = 65536
+    deg[500] = 65535
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
+    seeds = np.array([17, 3, 123, 500, 9, 17])
+    for kw in ({}, dict(replace=True), dict(disjoint=True)):
+        out, after, ref = run_both(rowptr, col, seeds, [25, 10], 99, **kw)
+        assert_same(out, after, ref, 99)
+
+
+@pytest.mark.parametrize('csc', [False, True])
+@pytest.mark.parametrize('disjoint', [False, True])
+def test_hetero_random_graph_matches_oracle(csc, disjoint):
+    rng = np.random.default_rng(6)
+    sizes = {'a': 700, 'b': 300, 'c': 1100}
+    ets = [('a', 'x', 'b'), ('b', 'y', 'a'), ('a', 'z', 'c'), ('c', 'w', 'c'), ('b', 'v', 'c')]
+    rp, cl = {}, {}
+    for (s, r, d) in ets:
+        rows, cols = (sizes[s], sizes[d]) if not csc else (sizes[d], sizes[s])
+        deg = rng.poisson(7, rows).astype(np.int64)
+        rp[(s, r, d)] = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        cl[(s, r, d)] = rng.integers(0, cols, int(deg.sum()), dtype=np.int64)
+    seeds = {'a': rng.permutation(700)[:20].astype(np.int64), 'c': rng.permutation(1100)[:12].astype(np.int64)}
+    fan = {e: [8, 4] for e in ets}
+    torch.manual_seed(31)
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                         {k: dev(v) for k, v in seeds.items()}, fan, csc=csc, disjoint=disjoint)
+    ref = oracle.hetero_neighbor_sample(['a', 'b', 'c'], ets, rp, cl, seeds, fan, csc=csc, disjoint=disjoint,
+                                        rng_seed=31)
+    for e in ets:
+        assert torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e]))
+        assert torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
+        assert torch.equal(out[3][e].cpu(), torch.from_numpy(ref[3][e]))
+        assert out[5][e] == ref[5][e]
+    for t in ('a', 'b', 'c'):
+        assert torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t]))
+        assert out[4][t] == ref[4][t]
+
+
+def test_unsupported_modes_fail_loudly():
+    rowptr, col = dev(G.ROWPTR), dev(G.COL)
+    with pytest.raises(RuntimeError):
+        sampler.neighbor_sample(rowptr, col, dev([2, 3]), [2], directed=False)
+    with pytest.raises(RuntimeError, match='disjoint'):
+        sampler.neighbor_sample(rowptr, col, dev([2, 3]), [2], node_time=dev(np.arange(6)))
+    with pytest.raises(RuntimeError, match='not implemented'):
+        sampler.neighbor_sample(rowptr, col, dev([2, 3]), [2], edge_weight=torch.ones(12, device=DEV))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        sampler.neighbor_sample(torch.from_numpy(G.ROWPTR), torch.from_numpy(G.COL), torch.tensor([2, 3]), [2])
+
+
+def test_products_scale_batch_is_bit_exact():
+    """BASELINE config C3 shape: N=2,449,029 nodes, log-normal degrees clipped to [1, 17481]
+    (~100 M edges), fan-out [15, 10, 5], batch 1024, torch.manual_seed(12345)."""
+    rng = np.random.default_rng(0)
+    n = 2_449_029
+    deg = np.clip(np.rint(rng.lognormal(3.3, 1.0, n)), 1, 17481).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
+    seeds = rng.permutation(n)[:1024].astype(np.int64)
+    out, after, ref = run_both(rowptr, col, seeds, [15, 10, 5], 12345)
+    assert_same(out, after, ref, 12345)
+    assert sum(ref[5]) > 500_000
