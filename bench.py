@@ -204,7 +204,7 @@ def main():
     # secondary metric: sampled-edges/s of the HIP neighbour sampler (single GPU by design)
     if rank == 0 and not args.no_sampler:
         try:
-            from pyg_lib_amd import sampler_bench
+            import bench_sampler as sampler_bench
             result['sampler'] = sampler_bench.run(device)
         except ImportError:
             result['sampler'] = None

@@ -1,0 +1,65 @@
+"""bench_sampler.py -- secondary leg of bench.py: sampled-edges/s of the HIP neighbour sampler on BASELINE config C3.
+
+ogbn-products cannot be downloaded here, so the graph is synthetic with the same scale
+(SURVEY.md 8(d)): N = 2,449,029 nodes, per-node degree ~ log-normal(3.3, 1.0) clipped to
+[1, 17481] (~100 M directed edges), col uniform, int64; batch 1024, fan-out [15, 10, 5],
+replace=False, directed=True, disjoint=False, return_edge_id=True.
+"""
+import time
+
+import numpy as np
+import torch
+
+N_NODES = 2_449_029
+FANOUT = [15, 10, 5]
+BATCH = 1024
+
+
+def make_graph(device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    deg = torch.exp(torch.randn(N_NODES, device=device, generator=g) * 1.0 + 3.3).round().clamp_(1, 17481).long()
+    rowptr = torch.zeros(N_NODES + 1, dtype=torch.long, device=device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    E = int(rowptr[-1])
+    col = torch.randint(0, N_NODES, (E,), device=device, generator=g, dtype=torch.long)
+    return rowptr, col
+
+
+def run(device, batches=20, warmup=3, cpu_batches=2):
+    from pyg_lib_amd import sampler
+    rowptr, col = make_graph(device)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    perm = torch.randperm(N_NODES, generator=g)[:BATCH * (batches + warmup)].to(device)
+    seeds = perm.view(batches + warmup, BATCH)
+    for b in range(warmup):
+        sampler.neighbor_sample(rowptr, col, seeds[b], FANOUT)
+    torch.cuda.synchronize()
+    edges = 0
+    t0 = time.perf_counter()
+    for b in range(warmup, warmup + batches):
+        torch.manual_seed(12345)
+        out = sampler.neighbor_sample(rowptr, col, seeds[b], FANOUT)
+        edges += sum(out[5])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = dict(metric='neighbor_sample sampled-edges/s', value=round(edges / dt, 1), unit='edges/s',
+               ms_per_batch=round(dt / batches * 1e3, 3), edges_per_batch=edges // batches, batch=BATCH,
+               fanout=FANOUT, graph=f'synthetic ogbn-products scale: {N_NODES} nodes, {col.numel()} edges')
+    # algorithmic bytes: 16 F + 8 E_s + 24 E_s + 8 U per batch
+    nh, eh = out[4], out[5]
+    F = sum(nh[:-1])
+    alg = 16 * F + 32 * sum(eh) + 8 * sum(nh)
+    res['alg_bytes_per_batch'] = int(alg)
+    res['alg_GBps'] = round(alg / (dt / batches) / 1e9, 2)
+    if cpu_batches > 0:
+        import oracle
+        rp, cl = rowptr.cpu().numpy(), col.cpu().numpy()
+        t0 = time.perf_counter()
+        ce = 0
+        for b in range(cpu_batches):
+            r = oracle.neighbor_sample(rp, cl, seeds[warmup + b].cpu().numpy(), FANOUT, rng_seed=12345)
+            ce += sum(r[5])
+        cdt = time.perf_counter() - t0
+        res['cpu_baseline'] = dict(value=round(ce / cdt, 1), unit='edges/s', cores=1, kind='port',
+                                   sample=f'oracle/oracle_sampler.c, {cpu_batches} batches of {BATCH} seeds')
+    return res

@@ -127,10 +127,12 @@ typedef struct {
   void* (*alloc)(void* user, size_t bytes);
   /* Release a block obtained from `alloc` (stream-ordered with the sampler's stream). */
   void (*free)(void* user, void* ptr);
-  /* Fill 128 host int64 words exactly like RandintEngine's prefetch
-   * (pyg_lib/csrc/random/cpu/rand_engine.h:79-91): first != 0 -> at::randint(INT64_MIN,
-   * INT64_MAX, {128}); otherwise the in-place refill random_(INT64_MIN, INT64_MAX). */
-  void (*rng_block)(void* user, int64_t* words128_host, int first);
+  /* Fill num_blocks x 128 host int64 words exactly like that many consecutive RandintEngine
+   * prefetches (pyg_lib/csrc/random/cpu/rand_engine.h:79-91): the first prefetch of a call is
+   * at::randint(INT64_MIN, INT64_MAX, {128}) (first != 0), later ones are in-place
+   * random_(INT64_MIN, INT64_MAX) refills.  Both draw the same serial mt19937 stream, so one
+   * random_ over num_blocks*128 elements is equivalent. */
+  void (*rng_blocks)(void* user, int64_t* words_host, int64_t num_blocks, int first);
 } pyg_hip_sampler_host;
 
 /* One CSR relation of a (heterogeneous) graph.  src_type / dst_type index `node_types` in the

@@ -1,0 +1,505 @@
+// libpyg.so -- the drop-in operator library.
+//
+// Registers the reference's operator schemas in namespace `pyg` (byte-identical strings, cited
+// per op) and implements them for PyTorch-ROCm tensors by calling the torch-free C-ABI of
+// include/pyg_hip.h and nothing else.  PyTorch is plumbing here: argument checks in the
+// reference's wording, output allocation through the caching allocator, the current HIP stream,
+// the global CPU generator for the sampler's random words, and autograd glue.
+//
+// There is deliberately no CPU registration: a CPU tensor reaches the dispatcher's own
+// "could not run ... with arguments from the 'CPU' backend" error instead of a silent fallback.
+#include <ATen/ATen.h>
+#include <ATen/core/dispatch/Dispatcher.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/autograd.h>
+#include <torch/library.h>
+
+#include <limits>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "pyg_hip.h"
+
+namespace pyg_amd {
+
+using at::Tensor;
+
+typedef std::string node_type;
+typedef std::string rel_type;
+typedef std::tuple<std::string, std::string, std::string> edge_type;
+
+// pyg_lib/csrc/utils/types.h:10-12
+inline rel_type to_rel_type(const edge_type& key) {
+  return std::get<0>(key) + "__" + std::get<1>(key) + "__" + std::get<2>(key);
+}
+
+static int dtype_code(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return PYG_F32;
+    case at::kDouble: return PYG_F64;
+    case at::kHalf: return PYG_F16;
+    case at::kBFloat16: return PYG_BF16;
+    case at::kChar: return PYG_I8;
+    case at::kByte: return PYG_U8;
+    case at::kShort: return PYG_I16;
+    case at::kInt: return PYG_I32;
+    case at::kLong: return PYG_I64;
+    default: TORCH_CHECK(false, "pyg (HIP): unsupported dtype ", t); return -1;
+  }
+}
+
+static void check_status(int rc) {
+  TORCH_CHECK(rc == PYG_HIP_OK, pyg_hip_last_error());
+}
+
+static void* current_stream(const Tensor& t) {
+  return static_cast<void*>(c10::hip::getCurrentHIPStream(t.get_device()).stream());
+}
+
+// ---------------------------------------------------------------------------------------------
+// library.cpp:19-29
+// ---------------------------------------------------------------------------------------------
+int64_t cuda_version() { return pyg_hip_version(); }
+
+// ---------------------------------------------------------------------------------------------
+// matmul  (front: pyg_lib/csrc/ops/matmul.cpp:12-61, kernels: ops/cuda/matmul_kernel.cu:289-319)
+// ---------------------------------------------------------------------------------------------
+static Tensor segment_matmul_impl(const Tensor& input, const Tensor& ptr, const Tensor& other,
+                                  const c10::optional<Tensor>& bias) {
+  at::TensorArg input_arg{input, "input", 0};
+  at::TensorArg ptr_arg{ptr, "ptr", 1};
+  at::TensorArg other_arg{other, "other", 2};
+  at::CheckedFrom c{"segment_matmul"};
+  at::checkAllDefined(c, {input_arg, ptr_arg, other_arg});
+  at::checkSameType(c, input_arg, other_arg);
+  at::checkDim(c, input_arg, 2);
+  at::checkDim(c, ptr_arg, 1);
+  at::checkDim(c, other_arg, 3);
+  at::checkSize(c, other_arg, 1, input_arg->size(-1));
+  at::checkNumel(c, ptr_arg, other_arg->size(0) + 1);
+  TORCH_CHECK(ptr.scalar_type() == at::kLong, "expected scalar type Long but found ",
+              ptr.scalar_type());
+  TORCH_CHECK(input.is_cuda() && other.is_cuda() && input.device() == other.device(),
+              "segment_matmul: 'input' and 'other' must live on the same HIP device");
+
+  c10::hip::HIPGuard guard(input.device());
+  const auto x = input.contiguous();
+  const auto w = other.contiguous();
+  const auto p = ptr.contiguous();
+  const int64_t N = x.size(0), K = x.size(1), B = w.size(0), M = w.size(2);
+  auto out = x.new_empty({N, M});
+  Tensor b;
+  if (bias.has_value()) {
+    b = bias.value().to(x.options()).contiguous();
+    TORCH_CHECK(b.dim() == 2 && b.size(0) == B && b.size(1) == M, "segment_matmul: expected 'bias' of shape [",
+                B, ", ", M, "]");
+  }
+  auto ws = at::empty({(int64_t)pyg_hip_matmul_workspace_size(B)}, x.options().dtype(at::kByte));
+  check_status(pyg_hip_segment_matmul(dtype_code(x.scalar_type()), x.data_ptr(), p.data_ptr<int64_t>(),
+                                      p.is_cuda() ? 1 : 0, w.data_ptr(),
+                                      b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), N, K, M, B,
+                                      ws.data_ptr(), (size_t)ws.numel(), current_stream(x)));
+  return out;
+}
+
+Tensor segment_matmul_kernel(const Tensor& input, const Tensor& ptr, const Tensor& other) {
+  return segment_matmul_impl(input, ptr, other, c10::nullopt);
+}
+
+// Extra op of this build: bias fused as GEMM epilogue (the reference adds it in a Python loop of
+// B slice updates, pyg_lib/ops/__init__.py:169-171).
+Tensor segment_matmul_bias_kernel(const Tensor& input, const Tensor& ptr, const Tensor& other,
+                                  const Tensor& bias) {
+  return segment_matmul_impl(input, ptr, other, bias);
+}
+
+std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::TensorList other) {
+  TORCH_CHECK(input.size() == other.size(),
+              "Number of 'input' tensors must match number of 'other' tensors");
+  const size_t G = input.size();
+  std::vector<Tensor> outs;
+  if (G == 0) return outs;
+  at::CheckedFrom c{"grouped_matmul"};
+  std::vector<std::string> names;  // keep the TensorArg names alive
+  names.reserve(2 * G);
+  for (size_t i = 0; i < G; ++i) {
+    names.push_back("input[" + std::to_string(i) + "]");
+    names.push_back("other[" + std::to_string(i) + "]");
+  }
+  for (size_t i = 0; i < G; ++i) {
+    at::TensorArg a{input[i], names[2 * i].c_str(), 0};
+    at::TensorArg o{other[i], names[2 * i + 1].c_str(), 1};
+    at::checkDefined(c, a);
+    at::checkDefined(c, o);
+    at::checkScalarType(c, a, input[0].scalar_type());
+    at::checkScalarType(c, o, input[0].scalar_type());
+    at::checkDim(c, a, 2);
+    at::checkDim(c, o, 2);
+    at::checkSize(c, o, 0, a->size(-1));
+    TORCH_CHECK(input[i].is_cuda() && other[i].is_cuda(), "grouped_matmul: tensors must live on a HIP device");
+  }
+  c10::hip::HIPGuard guard(input[0].device());
+  std::vector<pyg_hip_group> groups(G);
+  std::vector<Tensor> keep;
+  keep.reserve(2 * G);
+  outs.reserve(G);
+  for (size_t i = 0; i < G; ++i) {
+    auto a = input[i].contiguous();
+    Tensor o = other[i];
+    int trans = 0;
+    if (!o.is_contiguous()) {
+      // a transposed view (backward pass, pyg_lib/ops/__init__.py:84,91) is read in place
+      if (o.t().is_contiguous()) trans = 1;
+      else o = o.contiguous();
+    }
+    auto out = a.new_empty({a.size(0), other[i].size(-1)});
+    groups[i].input = a.data_ptr();
+    groups[i].other = o.data_ptr();
+    groups[i].out = out.data_ptr();
+    groups[i].rows = a.size(0);
+    groups[i].k = (int32_t)a.size(1);
+    groups[i].m = (int32_t)other[i].size(-1);
+    groups[i].other_trans = trans;
+    groups[i].reserved = 0;
+    keep.push_back(a);
+    keep.push_back(o);
+    outs.push_back(out);
+  }
+  auto ws = at::empty({(int64_t)pyg_hip_matmul_workspace_size((int64_t)G)},
+                      input[0].options().dtype(at::kByte));
+  check_status(pyg_hip_grouped_matmul(dtype_code(input[0].scalar_type()), groups.data(), (int64_t)G,
+                                      ws.data_ptr(), (size_t)ws.numel(), current_stream(input[0])));
+  return outs;
+}
+
+// Autograd, mirroring SegmentMatmul (pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:68-111).
+static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& ptr, const Tensor& other) {
+  static auto op = c10::Dispatcher::singleton()
+                       .findSchemaOrThrow("pyg::segment_matmul", "")
+                       .typed<Tensor(const Tensor&, const Tensor&, const Tensor&)>();
+  return op.call(input, ptr, other);
+}
+
+class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
+ public:
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx,
+                                                const Tensor& input, const Tensor& ptr,
+                                                const Tensor& other) {
+    at::AutoDispatchBelowADInplaceOrView g;
+    Tensor out = segment_matmul_below_autograd(input, ptr, other);
+    ctx->save_for_backward({input, ptr, other});
+    return {out};
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grad_outs) {
+    const auto grad_out = grad_outs[0];
+    const auto saved = ctx->get_saved_variables();
+    const auto input = saved[0], ptr = saved[1], other = saved[2];
+    Tensor input_grad, other_grad;
+    if (torch::autograd::any_variable_requires_grad({input})) {
+      // dX = segment_matmul(dY, ptr, W^T)
+      input_grad = segment_matmul_below_autograd(grad_out, ptr, other.transpose(-2, -1));
+    }
+    if (torch::autograd::any_variable_requires_grad({other})) {
+      // dW[b] = X_b^T @ dY_b
+      const auto size = (ptr.narrow(0, 1, ptr.numel() - 1) - ptr.narrow(0, 0, ptr.numel() - 1)).cpu();
+      const auto sizes = at::IntArrayRef(size.data_ptr<int64_t>(), (size_t)size.numel());
+      const auto xs = input.split_with_sizes(sizes, 0);
+      const auto gs = grad_out.split_with_sizes(sizes, 0);
+      std::vector<Tensor> parts;
+      parts.reserve(xs.size());
+      for (size_t i = 0; i < xs.size(); ++i) parts.push_back(at::matmul(xs[i].t(), gs[i]));
+      other_grad = at::stack(parts);
+    }
+    return {input_grad, Tensor(), other_grad};
+  }
+};
+
+Tensor segment_matmul_autograd(const Tensor& input, const Tensor& ptr, const Tensor& other) {
+  return SegmentMatmul::apply(input, ptr, other)[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler (schemas: pyg_lib/csrc/sampler/neighbor.cpp:129-147)
+// ---------------------------------------------------------------------------------------------
+struct SamplerHost {
+  hipStream_t stream;
+  std::string error;
+};
+
+static void* host_alloc(void* user, size_t bytes) {
+  auto* h = static_cast<SamplerHost*>(user);
+  try {
+    return c10::hip::HIPCachingAllocator::raw_alloc_with_stream(bytes ? bytes : 16, h->stream);
+  } catch (const std::exception& e) {
+    h->error = e.what();
+    return nullptr;
+  }
+}
+
+static void host_free(void*, void* ptr) {
+  if (ptr) c10::hip::HIPCachingAllocator::raw_delete(ptr);
+}
+
+// rand_engine.h:79-91.  at::randint(lo, hi, {n}) is empty({n}).random_(lo, hi), and random_ walks
+// the CPU generator's mt19937 serially, so filling num_blocks*128 words in one call yields exactly
+// the words of that many consecutive 128-word prefetches.
+static void host_rng_blocks(void* user, int64_t* words, int64_t num_blocks, int /*first*/) {
+  auto* h = static_cast<SamplerHost*>(user);
+  try {
+    auto buf = at::from_blob(words, {num_blocks * 128}, at::TensorOptions().dtype(at::kLong));
+    buf.random_(std::numeric_limits<int64_t>::min(), std::numeric_limits<int64_t>::max());
+  } catch (const std::exception& e) {
+    h->error = e.what();
+  }
+}
+
+static Tensor adopt(int64_t* ptr, at::IntArrayRef sizes, const at::TensorOptions& opts) {
+  return at::from_blob(
+      ptr, sizes, [](void* p) { c10::hip::HIPCachingAllocator::raw_delete(p); }, opts);
+}
+
+static void check_index(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_contiguous(), "Non-contiguous '", what, "'");
+  TORCH_CHECK(t.is_cuda(), "pyg (HIP): '", what, "' must live on a HIP device");
+  TORCH_CHECK(t.scalar_type() == at::kLong, "pyg (HIP): '", what, "' must be int64 on the device path");
+}
+
+struct SampleOutput {
+  std::vector<Tensor> node_id, row, col, edge_id;
+  std::vector<std::vector<int64_t>> nodes_per_hop, edges_per_hop;
+};
+
+static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
+                                const std::vector<pyg_hip_seed_set>& seeds, int num_node_types, int L,
+                                bool csc, bool replace, bool disjoint, bool return_edge_id,
+                                const at::Device& device) {
+  c10::hip::HIPGuard guard(device);
+  const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
+  SamplerHost host;
+  host.stream = c10::hip::getCurrentHIPStream(device.index()).stream();
+  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks};
+  const int T = num_node_types, E = (int)rels.size();
+  std::vector<int64_t*> node_id((size_t)T, nullptr), row((size_t)std::max(E, 1), nullptr),
+      col((size_t)std::max(E, 1), nullptr), eid((size_t)std::max(E, 1), nullptr);
+  std::vector<int64_t> num_nodes((size_t)T, 0), num_edges((size_t)std::max(E, 1), 0);
+  std::vector<int64_t> nph((size_t)T * (L + 1), 0), eph((size_t)std::max(E * L, 1), 0);
+  pyg_hip_sample_result res;
+  res.node_id = node_id.data();
+  res.num_nodes = num_nodes.data();
+  res.nodes_per_hop_host = nph.data();
+  res.row = row.data();
+  res.col = col.data();
+  res.edge_id = eid.data();
+  res.num_edges = num_edges.data();
+  res.edges_per_hop_host = eph.data();
+  res.rng_blocks = 0;
+  const int rc = pyg_hip_hetero_neighbor_sample(T, E, rels.data(), (int)seeds.size(), seeds.data(), L,
+                                                csc, replace, disjoint, return_edge_id, &cb, &res,
+                                                host.stream);
+  TORCH_CHECK(host.error.empty(), host.error);
+  check_status(rc);
+  SampleOutput out;
+  for (int t = 0; t < T; ++t) {
+    const int64_t n = num_nodes[(size_t)t];
+    out.node_id.push_back(disjoint ? adopt(node_id[(size_t)t], {n, 2}, opts) : adopt(node_id[(size_t)t], {n}, opts));
+    out.nodes_per_hop.emplace_back(nph.begin() + (size_t)t * (L + 1), nph.begin() + (size_t)(t + 1) * (L + 1));
+  }
+  for (int e = 0; e < E; ++e) {
+    const int64_t n = num_edges[(size_t)e];
+    out.row.push_back(adopt(row[(size_t)e], {n}, opts));
+    out.col.push_back(adopt(col[(size_t)e], {n}, opts));
+    if (return_edge_id) out.edge_id.push_back(adopt(eid[(size_t)e], {n}, opts));
+    out.edges_per_hop.emplace_back(eph.begin() + (size_t)e * L, eph.begin() + (size_t)(e + 1) * L);
+  }
+  return out;
+}
+
+static void check_modes(bool has_node_time, bool has_edge_time, bool has_weight, bool directed, bool disjoint,
+                        const std::string& temporal_strategy) {
+  // precondition checks of the reference kernel, sampler/cpu/neighbor_kernel.cpp:34-36,354-380,501
+  TORCH_CHECK(temporal_strategy == "uniform" || temporal_strategy == "last", "No valid temporal strategy found");
+  TORCH_CHECK(!has_node_time || disjoint, "Temporal sampling needs to create disjoint subgraphs");
+  TORCH_CHECK(!has_edge_time || disjoint, "Temporal sampling needs to create disjoint subgraphs");
+  TORCH_CHECK(!(has_node_time && has_edge_time), "Only one of node-level or edge-level sampling is supported ");
+  TORCH_CHECK(directed, "Undirected subgraphs not yet supported");
+  TORCH_CHECK(!has_node_time && !has_edge_time,
+              "pyg (HIP): temporal sampling is not implemented on the device path yet; refusing to fall back "
+              "to a CPU kernel");
+  TORCH_CHECK(!has_weight,
+              "pyg (HIP): biased sampling is not implemented on the device path yet; refusing to fall back "
+              "to a CPU kernel");
+}
+
+std::tuple<Tensor, Tensor, Tensor, c10::optional<Tensor>, std::vector<int64_t>, std::vector<int64_t>>
+neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& seed,
+                       const std::vector<int64_t>& num_neighbors, const c10::optional<Tensor>& node_time,
+                       const c10::optional<Tensor>& edge_time, const c10::optional<Tensor>& seed_time,
+                       const c10::optional<Tensor>& edge_weight, bool csc, bool replace, bool directed,
+                       bool disjoint, std::string temporal_strategy, bool return_edge_id) {
+  check_modes(node_time.has_value(), edge_time.has_value(), edge_weight.has_value(), directed, disjoint,
+              temporal_strategy);
+  check_index(rowptr, "rowptr");
+  check_index(col, "col");
+  check_index(seed, "seed");
+  std::vector<pyg_hip_relation> rels(1);
+  rels[0].rowptr = rowptr.data_ptr<int64_t>();
+  rels[0].num_rows = rowptr.numel() - 1;
+  rels[0].col = col.data_ptr<int64_t>();
+  rels[0].num_cols = col.numel();
+  rels[0].src_type = 0;
+  rels[0].dst_type = 0;
+  rels[0].num_neighbors_host = num_neighbors.data();
+  std::vector<pyg_hip_seed_set> seeds(1);
+  seeds[0].node_type = 0;
+  seeds[0].reserved = 0;
+  seeds[0].seed = seed.data_ptr<int64_t>();
+  seeds[0].num_seed = seed.numel();
+  auto out = run_sampler(rels, seeds, 1, (int)num_neighbors.size(), csc, replace, disjoint, return_edge_id,
+                         rowptr.device());
+  c10::optional<Tensor> eid = c10::nullopt;
+  if (return_edge_id) eid = out.edge_id[0];
+  return std::make_tuple(out.row[0], out.col[0], out.node_id[0], eid, out.nodes_per_hop[0],
+                         out.edges_per_hop[0]);
+}
+
+std::tuple<c10::Dict<rel_type, Tensor>, c10::Dict<rel_type, Tensor>, c10::Dict<node_type, Tensor>,
+           c10::optional<c10::Dict<rel_type, Tensor>>, c10::Dict<node_type, std::vector<int64_t>>,
+           c10::Dict<rel_type, std::vector<int64_t>>>
+hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const std::vector<edge_type>& edge_types,
+                              const c10::Dict<rel_type, Tensor>& rowptr_dict,
+                              const c10::Dict<rel_type, Tensor>& col_dict,
+                              const c10::Dict<node_type, Tensor>& seed_dict,
+                              const c10::Dict<rel_type, std::vector<int64_t>>& num_neighbors_dict,
+                              const c10::optional<c10::Dict<node_type, Tensor>>& node_time_dict,
+                              const c10::optional<c10::Dict<rel_type, Tensor>>& edge_time_dict,
+                              const c10::optional<c10::Dict<node_type, Tensor>>& seed_time_dict,
+                              const c10::optional<c10::Dict<rel_type, Tensor>>& edge_weight_dict, bool csc,
+                              bool replace, bool directed, bool disjoint, std::string temporal_strategy,
+                              bool return_edge_id) {
+  check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), edge_weight_dict.has_value(), directed,
+              disjoint, temporal_strategy);
+  std::unordered_map<std::string, int> nt_index;
+  for (size_t i = 0; i < node_types.size(); ++i) nt_index[node_types[i]] = (int)i;
+  size_t L = 0;
+  std::vector<pyg_hip_relation> rels(edge_types.size());
+  std::vector<std::vector<int64_t>> fanouts(edge_types.size());
+  c10::optional<at::Device> device;
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    const auto& k = edge_types[e];
+    const auto rel = to_rel_type(k);
+    const Tensor& rowptr = rowptr_dict.at(rel);
+    const Tensor& col = col_dict.at(rel);
+    check_index(rowptr, "rowptr");
+    check_index(col, "col");
+    if (!device.has_value()) device = rowptr.device();
+    fanouts[e] = num_neighbors_dict.at(rel);
+    L = std::max(L, fanouts[e].size());
+    TORCH_CHECK(nt_index.count(std::get<0>(k)) && nt_index.count(std::get<2>(k)),
+                "hetero_neighbor_sample: edge type names an unknown node type");
+    rels[e].rowptr = rowptr.data_ptr<int64_t>();
+    rels[e].num_rows = rowptr.numel() - 1;
+    rels[e].col = col.data_ptr<int64_t>();
+    rels[e].num_cols = col.numel();
+    rels[e].src_type = nt_index[std::get<0>(k)];
+    rels[e].dst_type = nt_index[std::get<2>(k)];
+  }
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    TORCH_CHECK(fanouts[e].size() == L, "hetero_neighbor_sample: all relations must list ", L, " hops");
+    rels[e].num_neighbors_host = fanouts[e].data();
+  }
+  std::vector<pyg_hip_seed_set> seeds;
+  for (const auto& kv : seed_dict) {  // c10::Dict iterates in insertion order, as the reference relies on
+    const Tensor& seed = kv.value();
+    check_index(seed, "seed");
+    if (!device.has_value()) device = seed.device();
+    TORCH_CHECK(nt_index.count(kv.key()), "hetero_neighbor_sample: seed type '", kv.key(), "' is not a node type");
+    pyg_hip_seed_set s;
+    s.node_type = nt_index[kv.key()];
+    s.reserved = 0;
+    s.seed = seed.data_ptr<int64_t>();
+    s.num_seed = seed.numel();
+    seeds.push_back(s);
+  }
+  TORCH_CHECK(device.has_value(), "hetero_neighbor_sample: no tensors given");
+  auto out = run_sampler(rels, seeds, (int)node_types.size(), (int)L, csc, replace, disjoint, return_edge_id,
+                         device.value());
+  c10::Dict<rel_type, Tensor> out_row, out_col;
+  c10::Dict<node_type, Tensor> out_node;
+  c10::optional<c10::Dict<rel_type, Tensor>> out_eid;
+  if (return_edge_id) out_eid = c10::Dict<rel_type, Tensor>();
+  c10::Dict<node_type, std::vector<int64_t>> out_nph;
+  c10::Dict<rel_type, std::vector<int64_t>> out_eph;
+  for (size_t t = 0; t < node_types.size(); ++t) {
+    out_node.insert(node_types[t], out.node_id[t]);
+    out_nph.insert(node_types[t], out.nodes_per_hop[t]);
+  }
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    const auto rel = to_rel_type(edge_types[e]);
+    out_row.insert(rel, out.row[e]);
+    out_col.insert(rel, out.col[e]);
+    out_eph.insert(rel, out.edges_per_hop[e]);
+    if (return_edge_id) out_eid.value().insert(rel, out.edge_id[e]);
+  }
+  return std::make_tuple(out_row, out_col, out_node, out_eid, out_nph, out_eph);
+}
+
+// ---------------------------------------------------------------------------------------------
+// registration
+// ---------------------------------------------------------------------------------------------
+TORCH_LIBRARY_FRAGMENT(pyg, m) {
+  // pyg_lib/csrc/library.cpp:27-29
+  m.def("cuda_version", &cuda_version);
+  // pyg_lib/csrc/ops/matmul.cpp:63-68
+  m.def(TORCH_SELECTIVE_SCHEMA("pyg::grouped_matmul(Tensor[] input, Tensor[] other) -> Tensor[]"));
+  m.def(TORCH_SELECTIVE_SCHEMA("pyg::segment_matmul(Tensor input, Tensor ptr, Tensor other) -> Tensor"));
+  // this build only: bias as a fused epilogue
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::segment_matmul_bias(Tensor input, Tensor ptr, Tensor other, Tensor bias) -> Tensor"));
+  // pyg_lib/csrc/sampler/neighbor.cpp:129-147
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::neighbor_sample(Tensor rowptr, Tensor col, Tensor seed, int[] "
+      "num_neighbors, Tensor? node_time = None, Tensor? edge_time = None, "
+      "Tensor? seed_time = None, Tensor? edge_weight = None, bool csc = False, "
+      "bool replace = False, bool directed = True, bool disjoint = False, "
+      "str temporal_strategy = 'uniform', bool return_edge_id = True) -> "
+      "(Tensor, Tensor, Tensor, Tensor?, int[], int[])"));
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::hetero_neighbor_sample(str[] node_types, (str, str, str)[] "
+      "edge_types, Dict(str, Tensor) rowptr_dict, Dict(str, Tensor) col_dict, "
+      "Dict(str, Tensor) seed_dict, Dict(str, int[]) num_neighbors_dict, "
+      "Dict(str, Tensor)? node_time_dict = None, Dict(str, Tensor)? "
+      "edge_time_dict = None, Dict(str, Tensor)? seed_time_dict = None, "
+      "Dict(str, Tensor)? edge_weight_dict = None, bool csc = False, "
+      "bool replace = False, bool directed = True, bool disjoint = False, "
+      "str temporal_strategy = 'uniform', bool return_edge_id = True) -> "
+      "(Dict(str, Tensor), Dict(str, Tensor), Dict(str, Tensor), "
+      "Dict(str, Tensor)?, Dict(str, int[]), Dict(str, int[]))"));
+}
+
+// HIP tensors dispatch under the CUDA key on PyTorch-ROCm.
+TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
+  m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul"), TORCH_FN(grouped_matmul_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
+}
+
+// pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:121-124
+TORCH_LIBRARY_IMPL(pyg, Autograd, m) {
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_autograd));
+}
+
+// Tensors inside Dicts cannot drive dispatch (sampler/cpu/neighbor_kernel.cpp:985-991): the
+// kernel checks the device itself and refuses CPU graphs.
+TORCH_LIBRARY_IMPL(pyg, BackendSelect, m) {
+  m.impl(TORCH_SELECTIVE_NAME("pyg::hetero_neighbor_sample"), TORCH_FN(hetero_neighbor_sample_kernel));
+}
+
+}  // namespace pyg_amd

@@ -633,8 +633,7 @@ int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
   }
   const int64_t nnew = need_blocks - r.blocks;
   std::vector<int64_t> tmp((size_t)nnew * 128);
-  for (int64_t b = 0; b < nnew; ++b)
-    c.host->rng_block(c.host->user, tmp.data() + b * 128, (r.blocks + b) == 0 ? 1 : 0);
+  c.host->rng_blocks(c.host->user, tmp.data(), nnew, r.blocks == 0 ? 1 : 0);
   // pageable -> device; the vector dies at scope exit, so make the copy synchronous
   PYG_HIP_CHECK(hipMemcpyAsync(r.dev + r.blocks * 128, tmp.data(), sizeof(u64) * 128 * (size_t)nnew,
                                hipMemcpyHostToDevice, c.stream));
@@ -914,7 +913,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
                                               pyg_hip_sample_result* result, void* stream_) {
   PYG_HIP_REQUIRE(num_node_types > 0 && num_relations >= 0 && num_seed_sets >= 0 && L >= 0,
                   "sampler: bad sizes");
-  PYG_HIP_REQUIRE(host && host->alloc && host->free && host->rng_block,
+  PYG_HIP_REQUIRE(host && host->alloc && host->free && host->rng_blocks,
                   "sampler: host callbacks missing");
   PYG_HIP_REQUIRE(result && result->node_id && result->num_nodes && result->nodes_per_hop_host &&
                       (num_relations == 0 ||
