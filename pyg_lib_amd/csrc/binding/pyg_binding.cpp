@@ -10,10 +10,9 @@
 // "could not run ... with arguments from the 'CPU' backend" error instead of a silent fallback.
 #include <ATen/ATen.h>
 #include <ATen/core/dispatch/Dispatcher.h>
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
-#include <c10/hip/HIPCachingAllocator.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 
@@ -57,8 +56,16 @@ static void check_status(int rc) {
   TORCH_CHECK(rc == PYG_HIP_OK, pyg_hip_last_error());
 }
 
+// PyTorch-ROCm types HIP devices/streams as "cuda" (masquerading), hence these spellings.
+namespace alloc = c10::hip::HIPCachingAllocatorMasqueradingAsCUDA;
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+
+static hipStream_t current_hip_stream(c10::DeviceIndex index) {
+  return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(index).stream();
+}
+
 static void* current_stream(const Tensor& t) {
-  return static_cast<void*>(c10::hip::getCurrentHIPStream(t.get_device()).stream());
+  return static_cast<void*>(current_hip_stream((c10::DeviceIndex)t.get_device()));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -87,7 +94,7 @@ static Tensor segment_matmul_impl(const Tensor& input, const Tensor& ptr, const 
   TORCH_CHECK(input.is_cuda() && other.is_cuda() && input.device() == other.device(),
               "segment_matmul: 'input' and 'other' must live on the same HIP device");
 
-  c10::hip::HIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const auto x = input.contiguous();
   const auto w = other.contiguous();
   const auto p = ptr.contiguous();
@@ -143,7 +150,7 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
     at::checkSize(c, o, 0, a->size(-1));
     TORCH_CHECK(input[i].is_cuda() && other[i].is_cuda(), "grouped_matmul: tensors must live on a HIP device");
   }
-  c10::hip::HIPGuard guard(input[0].device());
+  DeviceGuard guard(input[0].device());
   std::vector<pyg_hip_group> groups(G);
   std::vector<Tensor> keep;
   keep.reserve(2 * G);
@@ -236,7 +243,7 @@ struct SamplerHost {
 static void* host_alloc(void* user, size_t bytes) {
   auto* h = static_cast<SamplerHost*>(user);
   try {
-    return c10::hip::HIPCachingAllocator::raw_alloc_with_stream(bytes ? bytes : 16, h->stream);
+    return alloc::raw_alloc_with_stream(bytes ? bytes : 16, h->stream);
   } catch (const std::exception& e) {
     h->error = e.what();
     return nullptr;
@@ -244,7 +251,7 @@ static void* host_alloc(void* user, size_t bytes) {
 }
 
 static void host_free(void*, void* ptr) {
-  if (ptr) c10::hip::HIPCachingAllocator::raw_delete(ptr);
+  if (ptr) alloc::raw_delete(ptr);
 }
 
 // rand_engine.h:79-91.  at::randint(lo, hi, {n}) is empty({n}).random_(lo, hi), and random_ walks
@@ -262,7 +269,7 @@ static void host_rng_blocks(void* user, int64_t* words, int64_t num_blocks, int 
 
 static Tensor adopt(int64_t* ptr, at::IntArrayRef sizes, const at::TensorOptions& opts) {
   return at::from_blob(
-      ptr, sizes, [](void* p) { c10::hip::HIPCachingAllocator::raw_delete(p); }, opts);
+      ptr, sizes, [](void* p) { alloc::raw_delete(p); }, opts);
 }
 
 static void check_index(const Tensor& t, const char* what) {
@@ -280,10 +287,10 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
                                 const std::vector<pyg_hip_seed_set>& seeds, int num_node_types, int L,
                                 bool csc, bool replace, bool disjoint, bool return_edge_id,
                                 const at::Device& device) {
-  c10::hip::HIPGuard guard(device);
+  DeviceGuard guard(device);
   const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
   SamplerHost host;
-  host.stream = c10::hip::getCurrentHIPStream(device.index()).stream();
+  host.stream = current_hip_stream(device.index());
   pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks};
   const int T = num_node_types, E = (int)rels.size();
   std::vector<int64_t*> node_id((size_t)T, nullptr), row((size_t)std::max(E, 1), nullptr),

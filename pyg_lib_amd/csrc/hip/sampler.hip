@@ -27,10 +27,32 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 namespace pyg_hip {
 namespace {
+
+// PYG_HIP_SAMPLER_TRACE=1 prints host wall time per phase of a sampler call (diagnostics only).
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point last;
+  double acc[8] = {0};
+  PhaseTimer() : on(getenv("PYG_HIP_SAMPLER_TRACE") != nullptr), last(std::chrono::steady_clock::now()) {}
+  void lap(int k) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    acc[k] += std::chrono::duration<double, std::micro>(now - last).count();
+    last = now;
+  }
+  ~PhaseTimer() {
+    if (on)
+      fprintf(stderr,
+              "[pyg_hip sampler] us: seeds=%.0f count+scan+sync=%.0f rng=%.0f reserve=%.0f "
+              "sample+dedup-launch=%.0f sync2=%.0f release=%.0f finish=%.0f\n",
+              acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+  }
+};
 
 typedef unsigned long long u64;
 constexpr u64 kEmpty = ~0ull;           // empty hash key / unset value (memset 0xFF)
@@ -655,6 +677,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   std::vector<RelState> rs((size_t)num_relations);
   std::vector<std::vector<int64_t>> nodes_per_hop((size_t)num_node_types);
   RngHost rng;
+  PhaseTimer pt;
 
   int64_t num_batches = 1;
   if (disjoint) {
@@ -720,6 +743,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     batch0 += S;
   }
   for (int t = 0; t < num_node_types; ++t) nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size);
+  pt.lap(0);
 
   // ---- hops ----
   for (int ell = 0; ell < L; ++ell) {
@@ -757,6 +781,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       const int64_t end_word = rng.word + tot.tab.dw[rng.units];
       const int end_units = tot.tab.nb[rng.units];
       c.release(tile_buf);
+      pt.lap(1);
       if (E == 0) {
         c.release(edge_off);
         c.release(rng_word);
@@ -768,6 +793,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       if (rc != PYG_HIP_OK) return rc;
       rng.word = end_word;
       rng.units = end_units;
+      pt.lap(2);
 
       // 3. sample + insert
       rc = st.row.reserve(c, st.row.size + E);
@@ -791,6 +817,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
       if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)E);
       PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
+      pt.lap(3);
       HopArgs a;
       a.nodes = sn.nodes.p;
       a.batch = disjoint ? sn.batch.p : nullptr;
@@ -829,7 +856,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       PYG_HIP_CHECK(hipGetLastError());
       PYG_HIP_CHECK(hipMemcpyAsync(pinned, ftile + etiles, sizeof(int64_t), hipMemcpyDeviceToHost,
                                    stream));
+      pt.lap(4);
       PYG_HIP_CHECK(hipStreamSynchronize(stream));
+      pt.lap(5);
       const int64_t U = *static_cast<int64_t*>(pinned);
       dn.nodes.size += U;
       if (disjoint) dn.batch.size += U;
@@ -846,6 +875,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       if (e_batch) c.release(e_batch);
       c.release(e_slot);
       c.release(ftile);
+      pt.lap(6);
     }
     for (int t = 0; t < num_node_types; ++t) {
       NodeSet& n = ns[(size_t)t];
@@ -897,6 +927,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   }
   res->rng_blocks = rng.blocks;
   PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  pt.lap(7);
   return PYG_HIP_OK;
 }
 
