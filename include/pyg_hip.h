@@ -194,6 +194,72 @@ PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relat
                                                const pyg_hip_sampler_host* host,
                                                pyg_hip_sample_result* result, void* stream);
 
+/* ---- index_sort ---------------------------------------------------------------------------- */
+
+PYG_HIP_API size_t pyg_hip_index_sort_workspace_size(int dtype, int64_t n);
+
+/*
+ * Ascending STABLE sort of `n` integer keys: keys_out = sorted keys (same dtype), index_out =
+ * int64 permutation, bit-identical to torch.sort(stable=True).
+ * Replaces pyg::index_sort (schema pyg_lib/csrc/ops/index_sort.cpp:25-28; CPU kernel
+ * pyg_lib/csrc/ops/cpu/index_sort_kernel.cpp:14-59 + ops/cpu/radix_sort.h:58-198; the reference
+ * has no device kernel, pyg_lib/ops/__init__.py:319-320 falls back to torch.sort).
+ *   dtype      PYG_U8 / PYG_I8 / PYG_I16 / PYG_I32 / PYG_I64 (anything else: "Input should contain
+ *              integral values.", index_sort_kernel.cpp:55-56)
+ *   max_value  with has_max != 0: an upper bound of the (non-negative) keys, only sets the number of
+ *              8-bit passes (radix_sort.h:170-176).  With has_max == 0 the extremes are reduced on
+ *              the device and read back (one stream synchronisation, like the reference's
+ *              input.max().item()); negative keys are then sorted correctly as well.
+ */
+PYG_HIP_API int pyg_hip_index_sort(int dtype, const void* keys, int64_t n, int64_t max_value,
+                                   int has_max, void* keys_out, int64_t* index_out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
+/* ---- scatter / segment_coo / gather_coo ---------------------------------------------------- */
+
+typedef enum {
+  PYG_REDUCE_SUM = 0,
+  PYG_REDUCE_MUL = 1,
+  PYG_REDUCE_MIN = 2,
+  PYG_REDUCE_MAX = 3
+} pyg_reduce;
+
+/*
+ * out[b, index(b, e, k), k]  (op)=  src[b, e, k]      over the (B, E, K) view of `src`
+ * (layout of pyg_lib/csrc/ops/cpu/scatter_kernel.cpp:16-24; `out` is [B, N, K]).
+ * Replaces pyg::scatter_{sum,mul,min,max} (schemas pyg_lib/csrc/ops/scatter.cpp:156-172; CPU
+ * kernels ops/cpu/scatter_kernel.cpp:29-511; CUDA ops/cuda/scatter_kernel.cu:56-651) and, with a
+ * sorted [B, E] index, pyg::segment_{sum,min,max}_coo (schemas ops/segment_coo.cpp:150-165; CPU
+ * ops/cpu/segment_coo_kernel.cpp:31-651; CUDA ops/cuda/segment_coo_kernel.cu:73-1301).
+ *   index     int64, element (b, e, k) at index[b*stride_b + e*stride_e + k*stride_k]; a stride of
+ *             0 broadcasts (1-D index: (0, 1, 0); COO index [B, E]: (E, 1, 0); fully expanded:
+ *             (E*K, K, 1)).
+ *   out       running state, updated in place (`out=` contract, ops/scatter.h:11-113): the caller
+ *             pre-fills it (zeros / ones / pyg_hip_fill_reduce_identity for fresh outputs).
+ *   MIN/MAX   arg_out [B, N, K] int64 is filled here: source position of the first element that
+ *             produced the final value, or the sentinel E.  out_init = NULL means `out` was filled
+ *             with the reduce identity: empty buckets are then reset to 0
+ *             (scatter_kernel.cpp:351-360).  Otherwise out_init points to a copy of the caller's
+ *             initial `out` and untouched buckets keep their value.
+ */
+PYG_HIP_API int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index,
+                                int64_t index_stride_b, int64_t index_stride_e,
+                                int64_t index_stride_k, void* out, int64_t* arg_out,
+                                const void* out_init, int64_t B, int64_t E, int64_t K, int64_t N,
+                                void* stream);
+
+/* Fill `n` elements with numeric_limits<T>::max() (MIN) / lowest() (MAX): the start state of a
+ * fresh min/max output (scatter_kernel.cpp:296-300). */
+PYG_HIP_API int pyg_hip_fill_reduce_identity(int op, int dtype, void* out, int64_t n, void* stream);
+
+/*
+ * out[b, e, k] = src[b, index[b, e], k]     src [B, N, K], index [B, E] contiguous, out [B, E, K].
+ * Replaces pyg::gather_coo (schema ops/segment_coo.cpp:164-165; CPU
+ * ops/cpu/segment_coo_kernel.cpp:666-746; CUDA ops/cuda/segment_coo_kernel.cu:1316-1444).
+ */
+PYG_HIP_API int pyg_hip_gather_coo(int dtype, const void* src, const int64_t* index, void* out,
+                                   int64_t B, int64_t E, int64_t K, int64_t N, void* stream);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 
 /* When enabled (per calling thread), every dominant-kernel launch is bracketed by a pair of HIP

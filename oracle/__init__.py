@@ -252,3 +252,180 @@ def neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_time=
         return_edge_id=return_edge_id, rng_seed=rng_seed, fill=fill)
     rows, cols, nodes, eids, nh, eh, info = out
     return rows[et], cols[et], nodes['n'], (eids[et] if eids is not None else None), nh['n'], eh[et], info
+
+
+# ---- scatter / segment_coo / gather_coo / index_sort ---------------------------------------------
+SUM, MUL, MIN, MAX = 0, 1, 2, 3
+I8, U8, I16, I32, I64 = 4, 5, 6, 7, 8
+_NP_CODES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.float16): F16,
+             np.dtype(np.int8): I8, np.dtype(np.uint8): U8, np.dtype(np.int16): I16,
+             np.dtype(np.int32): I32, np.dtype(np.int64): I64}
+
+
+def _code(a, dtype):
+    return dtype if dtype is not None else _NP_CODES[a.dtype]
+
+
+def _declare_reduce(L):
+    if getattr(L, '_reduce_declared', False):
+        return
+    c = ctypes
+    L.oracle_scatter.restype = c.c_int
+    L.oracle_scatter.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int,
+                                 c.c_int64, c.c_int64, c.c_int64, c.c_int64]
+    L.oracle_segment_sum_coo.restype = c.c_int
+    L.oracle_segment_sum_coo.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64,
+                                         c.c_int64, c.c_int64]
+    L.oracle_gather_coo.restype = c.c_int
+    L.oracle_gather_coo.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_int64,
+                                    c.c_int64]
+    L.oracle_index_sort.restype = c.c_int
+    L.oracle_index_sort.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    L._reduce_declared = True
+
+
+def _identity(op, a, dtype):
+    """numeric_limits<T>::max() / lowest() in the storage representation of `a`."""
+    code = _code(a, dtype)
+    if code == BF16:
+        return np.uint16(0x7f7f if op == MIN else 0xff7f)
+    if code == F16:
+        return np.float16(65504.0 if op == MIN else -65504.0)
+    if np.issubdtype(a.dtype, np.floating):
+        return np.finfo(a.dtype).max if op == MIN else np.finfo(a.dtype).min
+    return np.iinfo(a.dtype).max if op == MIN else np.iinfo(a.dtype).min
+
+
+def _bcast_index(index, src, dim):
+    """pyg_lib/csrc/ops/utils.h:22-34"""
+    idx = np.asarray(index, dtype=np.int64)
+    if idx.ndim == 1:
+        idx = idx.reshape((1,) * dim + idx.shape)
+    while idx.ndim < src.ndim:
+        idx = idx[..., None]
+    return np.ascontiguousarray(np.broadcast_to(idx, src.shape))
+
+
+def scatter(op, src, index, dim=-1, out=None, dim_size=None, dtype=None):
+    """scatter_{sum,mul,min,max}: returns (out, arg_out or None).  `out` (if given) is updated in place
+    semantics-wise but a new array is returned."""
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src)
+    dim = dim + src.ndim if dim < 0 else dim
+    idx = _bcast_index(index, src, dim)
+    fresh = out is None
+    if fresh:
+        n = dim_size if dim_size is not None else (0 if idx.size == 0 else int(idx.max()) + 1)
+        shape = list(src.shape)
+        shape[dim] = n
+        if op == SUM:
+            out = np.zeros(shape, dtype=src.dtype)
+        elif op == MUL:
+            out = np.ones(shape, dtype=src.dtype) if _code(src, dtype) != BF16 else np.full(shape, 0x3f80, np.uint16)
+        else:
+            out = np.full(shape, _identity(op, src, dtype), dtype=src.dtype)
+    else:
+        out = np.ascontiguousarray(out).copy()
+    B = int(np.prod(src.shape[:dim], dtype=np.int64))
+    E = src.shape[dim]
+    K = int(np.prod(src.shape[dim + 1:], dtype=np.int64))
+    N = out.shape[dim]
+    arg = np.full(out.shape, E, dtype=np.int64) if op in (MIN, MAX) else None
+    if src.size:
+        rc = L.oracle_scatter(op, _code(src, dtype), _ptr(src), _ptr(idx), _ptr(out), _ptr(arg), int(fresh), B, E, K, N)
+        if rc != 0:
+            raise RuntimeError('oracle_scatter: index out of range')
+    elif op in (MIN, MAX) and fresh:
+        out[...] = 0
+    return out, arg
+
+
+def scatter_mean(src, index, dim=-1, out=None, dim_size=None, dtype=None):
+    """ops/autograd/scatter_kernel.cpp:161-233 (floating dtypes only in this oracle wrapper)."""
+    src = np.ascontiguousarray(src)
+    d = dim + src.ndim if dim < 0 else dim
+    s, _ = scatter(SUM, src, index, d, out, dim_size, dtype)
+    idx = _bcast_index(index, src, d)
+    ones = np.ones(src.shape, dtype=np.float64)
+    cnt, _ = scatter(SUM, ones, idx, d, None, s.shape[d])
+    cnt[cnt < 1] = 1
+    if dtype == BF16:
+        res = bf16_bits_to_f32(s) / cnt.astype(np.float32)
+        return f32_to_bf16_bits(res)
+    if np.issubdtype(src.dtype, np.floating):
+        return (s / cnt.astype(s.dtype)).astype(s.dtype)
+    return np.floor_divide(s, cnt.astype(s.dtype))
+
+
+def _coo_shapes(src, index):
+    index = np.asarray(index, dtype=np.int64)
+    dim = index.ndim - 1
+    idx = np.ascontiguousarray(np.broadcast_to(index, src.shape[:index.ndim]))
+    B = int(np.prod(idx.shape[:dim], dtype=np.int64))
+    E = src.shape[dim]
+    K = int(np.prod(src.shape[index.ndim:], dtype=np.int64))
+    return idx, dim, B, E, K
+
+
+def segment_sum_coo(src, index, out=None, dim_size=None, dtype=None):
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src)
+    idx, dim, B, E, K = _coo_shapes(src, index)
+    if out is None:
+        n = dim_size if dim_size is not None else (0 if idx.size == 0 else int(idx[..., -1].max()) + 1)
+        shape = list(src.shape)
+        shape[dim] = n
+        out = np.zeros(shape, dtype=src.dtype)
+    else:
+        out = np.ascontiguousarray(out).copy()
+    if src.size:
+        rc = L.oracle_segment_sum_coo(_code(src, dtype), _ptr(src), _ptr(idx), _ptr(out), B, E, K, out.shape[dim])
+        if rc != 0:
+            raise RuntimeError('oracle_segment_sum_coo: index out of range')
+    return out
+
+
+def segment_minmax_coo(op, src, index, out=None, dim_size=None, dtype=None):
+    """segment_{min,max}_coo == scatter_{min,max} with the [.., E] index broadcast over trailing dims."""
+    src = np.ascontiguousarray(src)
+    idx, dim, B, E, K = _coo_shapes(src, index)
+    full = idx.reshape(idx.shape + (1,) * (src.ndim - idx.ndim))
+    if out is None and dim_size is None:
+        dim_size = 0 if idx.size == 0 else int(idx[..., -1].max()) + 1
+    return scatter(op, src, np.broadcast_to(full, src.shape), dim, out, dim_size, dtype)
+
+
+def gather_coo(src, index, dtype=None):
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    dim = index.ndim - 1
+    B = int(np.prod(index.shape[:dim], dtype=np.int64))
+    E = index.shape[dim]
+    N = src.shape[dim]
+    K = int(np.prod(src.shape[index.ndim:], dtype=np.int64))
+    shape = list(src.shape)
+    shape[dim] = E
+    out = np.zeros(shape, dtype=src.dtype)
+    if out.size and src.size:
+        rc = L.oracle_gather_coo(_code(src, dtype), _ptr(src), _ptr(index), _ptr(out), B, E, K, N)
+        if rc != 0:
+            raise RuntimeError('oracle_gather_coo: index out of range')
+    return out
+
+
+def index_sort(keys):
+    L = lib()
+    _declare_reduce(L)
+    keys = np.ascontiguousarray(keys)
+    if keys.ndim != 1:
+        raise RuntimeError('Input should be 1-dimensional.')
+    out = np.zeros_like(keys)
+    idx = np.zeros(keys.size, dtype=np.int64)
+    rc = L.oracle_index_sort(_NP_CODES[keys.dtype], _ptr(keys), keys.size, _ptr(out), _ptr(idx))
+    if rc != 0:
+        raise RuntimeError('Input should contain integral values.')
+    return out, idx

@@ -1,0 +1,47 @@
+// Helpers shared by the binding translation units (libpyg.so).
+#pragma once
+
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include "pyg_hip.h"
+
+namespace pyg_amd {
+
+using at::Tensor;
+
+inline int dtype_code(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return PYG_F32;
+    case at::kDouble: return PYG_F64;
+    case at::kHalf: return PYG_F16;
+    case at::kBFloat16: return PYG_BF16;
+    case at::kChar: return PYG_I8;
+    case at::kByte: return PYG_U8;
+    case at::kShort: return PYG_I16;
+    case at::kInt: return PYG_I32;
+    case at::kLong: return PYG_I64;
+    default: TORCH_CHECK(false, "pyg (HIP): unsupported dtype ", t); return -1;
+  }
+}
+
+inline void check_status(int rc) {
+  TORCH_CHECK(rc == PYG_HIP_OK, pyg_hip_last_error());
+}
+
+// PyTorch-ROCm types HIP devices/streams as "cuda" (masquerading), hence these spellings.
+namespace alloc = c10::hip::HIPCachingAllocatorMasqueradingAsCUDA;
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+
+inline hipStream_t current_hip_stream(c10::DeviceIndex index) {
+  return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(index).stream();
+}
+
+inline void* current_stream(const Tensor& t) {
+  return static_cast<void*>(current_hip_stream((c10::DeviceIndex)t.get_device()));
+}
+
+
+}  // namespace pyg_amd

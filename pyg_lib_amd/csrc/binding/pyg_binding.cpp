@@ -22,11 +22,9 @@
 #include <unordered_map>
 #include <vector>
 
-#include "pyg_hip.h"
+#include "binding_common.h"
 
 namespace pyg_amd {
-
-using at::Tensor;
 
 typedef std::string node_type;
 typedef std::string rel_type;
@@ -35,37 +33,6 @@ typedef std::tuple<std::string, std::string, std::string> edge_type;
 // pyg_lib/csrc/utils/types.h:10-12
 inline rel_type to_rel_type(const edge_type& key) {
   return std::get<0>(key) + "__" + std::get<1>(key) + "__" + std::get<2>(key);
-}
-
-static int dtype_code(at::ScalarType t) {
-  switch (t) {
-    case at::kFloat: return PYG_F32;
-    case at::kDouble: return PYG_F64;
-    case at::kHalf: return PYG_F16;
-    case at::kBFloat16: return PYG_BF16;
-    case at::kChar: return PYG_I8;
-    case at::kByte: return PYG_U8;
-    case at::kShort: return PYG_I16;
-    case at::kInt: return PYG_I32;
-    case at::kLong: return PYG_I64;
-    default: TORCH_CHECK(false, "pyg (HIP): unsupported dtype ", t); return -1;
-  }
-}
-
-static void check_status(int rc) {
-  TORCH_CHECK(rc == PYG_HIP_OK, pyg_hip_last_error());
-}
-
-// PyTorch-ROCm types HIP devices/streams as "cuda" (masquerading), hence these spellings.
-namespace alloc = c10::hip::HIPCachingAllocatorMasqueradingAsCUDA;
-using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
-
-static hipStream_t current_hip_stream(c10::DeviceIndex index) {
-  return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(index).stream();
-}
-
-static void* current_stream(const Tensor& t) {
-  return static_cast<void*>(current_hip_stream((c10::DeviceIndex)t.get_device()));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,12 +4,14 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libpyg_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I../../include -Ihip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden -I../../include -Ihip"
 mkdir -p build
 objs=""
 for f in hip/*.hip; do
   o=build/$(basename "$f" .hip).o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ hip/common.h -nt "$o" ] || [ ../../include/pyg_hip.h -nt "$o" ]; then
+  stale=0
+  for h in hip/*.h ../../include/pyg_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     echo "hipcc $f"
     $HIPCC $FLAGS -c "$f" -o "$o"
   fi

@@ -1,0 +1,527 @@
+// scatter_{sum,mul,min,max}, segment_*_coo and gather_coo for gfx950 (MI355X).
+//
+// Replaces pyg_lib/csrc/ops/cuda/scatter_kernel.cu and segment_coo_kernel.cu (warp-32 shuffles
+// and CAS-emulated atomics, "ROCm wave64 is not a target") and follows the CPU contracts of
+// pyg_lib/csrc/ops/cpu/scatter_kernel.cpp and segment_coo_kernel.cpp.
+//
+// One (B, E, K) layout serves every op (scatter_kernel.cpp:16-24): src[b, e, k] is reduced into
+// out[b, index(b, e, k), k].  The index is addressed through three element strides so that a 1-D
+// index broadcast along B and K (the common PyG case) or a COO index of shape [B, E] is read in
+// place: algorithmic traffic stays 8*E + s*E*K + s*N*K instead of materialising an int64 per
+// element as the reference front does (ops/autograd/scatter_kernel.cpp:33-39).
+//
+// HBM-bound byte work; the levers are coalesced 16-byte rows and few, native atomics:
+//   * sum (fp32 / bf16 / fp16 / fp64 / int32 / int64): each thread owns a 16-byte column slice and a
+//     short run of consecutive rows, accumulates in fp32 while the index repeats (sorted COO input
+//     collapses whole runs, matching segment_coo_kernel.cpp's run accumulation) and flushes with
+//     native global atomics (global_atomic_add_f32 / _pk_add_bf16 / _pk_add_f16 / _add_f64 / _add_x2).
+//   * min / max: value pass with native integer atomics (CAS loop on the reference's `<` / `>` for
+//     floating types), then an arg pass atomicMin(arg, e) over the elements that equal the final
+//     value and strictly improved the initial one -- exactly the CPU kernel's first-match rule
+//     (scatter_kernel.cpp:249-369), so values AND arg indices are bit-exact.
+//   * mul and the 8/16-bit integer types: CAS loop on the containing 32-bit word.
+#include "common.h"
+
+#include <limits>
+#include <type_traits>
+
+namespace pyg_hip {
+namespace {
+
+typedef __bf16 bf16_raw;
+struct bf16_t {
+  uint16_t v;
+};
+struct f16_t {
+  uint16_t v;
+};
+
+enum { OP_SUM = 0, OP_MUL = 1, OP_MIN = 2, OP_MAX = 3 };
+
+// ---- scalar element helpers ----------------------------------------------------------------------
+template <typename T>
+struct Math {
+  using acc_t = T;
+  __device__ static acc_t up(T v) { return v; }
+  __device__ static T down(acc_t v) { return v; }
+};
+template <>
+struct Math<bf16_t> {
+  using acc_t = float;
+  __device__ static float up(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v.v << 16); }
+  __device__ static bf16_t down(float f) {
+    bf16_t r;
+    r.v = __builtin_bit_cast(uint16_t, (__bf16)f);
+    return r;
+  }
+};
+template <>
+struct Math<f16_t> {
+  using acc_t = float;
+  __device__ static float up(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.v); }
+  __device__ static f16_t down(float f) {
+    f16_t r;
+    r.v = __builtin_bit_cast(uint16_t, (_Float16)f);
+    return r;
+  }
+};
+
+template <typename T>
+__device__ T type_max();
+template <typename T>
+__device__ T type_lowest();
+#define PYG_LIMITS(T, MAXV, LOWV)                     \
+  template <>                                         \
+  __device__ T type_max<T>() { return MAXV; }         \
+  template <>                                         \
+  __device__ T type_lowest<T>() { return LOWV; }
+PYG_LIMITS(float, 3.402823466e+38f, -3.402823466e+38f)
+PYG_LIMITS(double, 1.7976931348623157e+308, -1.7976931348623157e+308)
+PYG_LIMITS(int8_t, 127, -128)
+PYG_LIMITS(uint8_t, 255, 0)
+PYG_LIMITS(int16_t, 32767, -32768)
+PYG_LIMITS(int32_t, 2147483647, (-2147483647 - 1))
+PYG_LIMITS(int64_t, 9223372036854775807ll, (-9223372036854775807ll - 1))
+#undef PYG_LIMITS
+template <>
+__device__ bf16_t type_max<bf16_t>() { return bf16_t{0x7f7f}; }
+template <>
+__device__ bf16_t type_lowest<bf16_t>() { return bf16_t{0xff7f}; }
+template <>
+__device__ f16_t type_max<f16_t>() { return f16_t{0x7bff}; }
+template <>
+__device__ f16_t type_lowest<f16_t>() { return f16_t{0xfbff}; }
+
+template <typename T>
+__device__ bool bits_equal(T a, T b) {
+  return Math<T>::up(a) == Math<T>::up(b);
+}
+
+// ---- atomic read-modify-write on any 1/2/4/8-byte element -----------------------------------------
+// f(old) -> {changed, new}.  Loops on the containing 32-bit word for sub-word types.
+template <typename T, typename F>
+__device__ void atomic_rmw(T* addr, F f) {
+  if constexpr (sizeof(T) == 8) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      T cur = __builtin_bit_cast(T, old);
+      T nv;
+      if (!f(cur, &nv)) return;
+      unsigned long long want = __builtin_bit_cast(unsigned long long, nv);
+      if (__hip_atomic_compare_exchange_strong(p, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    }
+  } else if constexpr (sizeof(T) == 4) {
+    unsigned int* p = reinterpret_cast<unsigned int*>(addr);
+    unsigned int old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      T cur = __builtin_bit_cast(T, old);
+      T nv;
+      if (!f(cur, &nv)) return;
+      unsigned int want = __builtin_bit_cast(unsigned int, nv);
+      if (__hip_atomic_compare_exchange_strong(p, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    }
+  } else {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(addr);
+    unsigned int* p = reinterpret_cast<unsigned int*>(a & ~(uintptr_t)3);
+    const int shift = (int)(a & 3) * 8;
+    constexpr unsigned int mask = sizeof(T) == 2 ? 0xffffu : 0xffu;
+    unsigned int old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      using U = typename std::conditional<sizeof(T) == 2, uint16_t, uint8_t>::type;
+      const U curbits = (U)((old >> shift) & mask);
+      T cur = __builtin_bit_cast(T, curbits);
+      T nv;
+      if (!f(cur, &nv)) return;
+      const unsigned int want =
+          (old & ~(mask << shift)) | ((unsigned int)__builtin_bit_cast(U, nv) << shift);
+      if (__hip_atomic_compare_exchange_strong(p, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+        return;
+    }
+  }
+}
+
+template <typename T>
+__device__ void atomic_add(T* addr, typename Math<T>::acc_t v) {
+  if constexpr (std::is_same<T, float>::value) {
+    unsafeAtomicAdd(addr, v);  // global_atomic_add_f32
+  } else if constexpr (std::is_same<T, double>::value) {
+    unsafeAtomicAdd(addr, v);  // global_atomic_add_f64
+  } else if constexpr (std::is_same<T, int32_t>::value) {
+    atomicAdd(addr, v);
+  } else if constexpr (std::is_same<T, int64_t>::value) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)v);
+  } else {
+    atomic_rmw(addr, [v](T cur, T* nv) {
+      *nv = Math<T>::down((typename Math<T>::acc_t)(Math<T>::up(cur) + v));
+      return true;
+    });
+  }
+}
+
+template <typename T>
+__device__ void atomic_mul(T* addr, T v) {
+  atomic_rmw(addr, [v](T cur, T* nv) {
+    *nv = Math<T>::down((typename Math<T>::acc_t)(Math<T>::up(cur) * Math<T>::up(v)));
+    return true;
+  });
+}
+
+template <typename T, bool IS_MIN>
+__device__ void atomic_minmax(T* addr, T v) {
+  if constexpr (std::is_same<T, int32_t>::value) {
+    if (IS_MIN) atomicMin(addr, v); else atomicMax(addr, v);
+  } else if constexpr (std::is_same<T, int64_t>::value) {
+    if (IS_MIN) atomicMin(reinterpret_cast<long long*>(addr), (long long)v);
+    else atomicMax(reinterpret_cast<long long*>(addr), (long long)v);
+  } else {
+    // the reference's strict comparison (v < *slot / v > *slot), NaNs never win
+    atomic_rmw(addr, [v](T cur, T* nv) {
+      const bool better = IS_MIN ? (Math<T>::up(v) < Math<T>::up(cur)) : (Math<T>::up(v) > Math<T>::up(cur));
+      *nv = v;
+      return better;
+    });
+  }
+}
+
+struct Shape {
+  int64_t B, E, K, N;
+  int64_t isb, ise, isk;  // index strides (elements) along b, e, k
+};
+
+__device__ __forceinline__ int64_t index_at(const int64_t* index, const Shape& s, int64_t b, int64_t e,
+                                            int64_t k) {
+  return index[b * s.isb + e * s.ise + k * s.isk];
+}
+
+// ---- generic element-per-thread kernels -------------------------------------------------------------
+template <typename T, int OP>
+__global__ void scatter_elem_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* out,
+                                    Shape s) {
+  const int64_t total = s.B * s.E * s.K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i % s.K;
+    const int64_t e = (i / s.K) % s.E;
+    const int64_t b = i / (s.K * s.E);
+    const int64_t idx = index_at(index, s, b, e, k);
+    T* dst = out + (b * s.N + idx) * s.K + k;
+    const T v = src[i];
+    if (OP == OP_SUM) atomic_add<T>(dst, Math<T>::up(v));
+    else if (OP == OP_MUL) atomic_mul<T>(dst, v);
+    else if (OP == OP_MIN) atomic_minmax<T, true>(dst, v);
+    else atomic_minmax<T, false>(dst, v);
+  }
+}
+
+// arg pass of min/max: first source position whose value equals the final bucket value, provided the
+// bucket strictly improved on its initial state (init == nullptr: the type's max()/lowest()).
+template <typename T, bool IS_MIN>
+__global__ void scatter_arg_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                   const T* __restrict__ out, const T* __restrict__ init,
+                                   int64_t* arg, Shape s) {
+  const int64_t total = s.B * s.E * s.K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i % s.K;
+    const int64_t e = (i / s.K) % s.E;
+    const int64_t b = i / (s.K * s.E);
+    const int64_t idx = index_at(index, s, b, e, k);
+    const int64_t o = (b * s.N + idx) * s.K + k;
+    const T fin = out[o];
+    const T v = src[i];
+    if (!bits_equal(v, fin)) continue;
+    const T start = init ? init[o] : (IS_MIN ? type_max<T>() : type_lowest<T>());
+    const bool improved = IS_MIN ? (Math<T>::up(fin) < Math<T>::up(start)) : (Math<T>::up(fin) > Math<T>::up(start));
+    if (improved) atomicMin(reinterpret_cast<long long*>(arg + o), (long long)e);
+  }
+}
+
+// empty buckets (arg still the sentinel E) of a freshly allocated min/max output are reset to 0
+template <typename T>
+__global__ void reset_empty_kernel(T* out, const int64_t* __restrict__ arg, int64_t n, int64_t sentinel) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && arg[i] == sentinel) out[i] = Math<T>::down((typename Math<T>::acc_t)0);
+}
+
+template <typename T>
+__global__ void fill_kernel(T* out, int64_t n, T v) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
+__global__ void fill_i64_kernel(int64_t* out, int64_t n, int64_t v) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
+// ---- vectorised sum: 16-byte column slices, run accumulation over consecutive rows ---------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct Vec;  // VEC elements per 16 bytes, accumulate in float/double/int
+template <>
+struct Vec<float> {
+  static constexpr int N = 4;
+  using acc_t = float;
+  __device__ static void unpack(u32x4 v, float* a) {
+    for (int i = 0; i < 4; ++i) a[i] += __builtin_bit_cast(float, v[i]);
+  }
+  __device__ static void flush(float* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, a[i]);
+  }
+};
+template <>
+struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  using acc_t = float;
+  __device__ static void unpack(u32x4 v, float* a) {
+    for (int i = 0; i < 4; ++i) {
+      a[2 * i] += __builtin_bit_cast(float, v[i] << 16);
+      a[2 * i + 1] += __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+  __device__ static void flush(bf16_t* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) {
+      bf16x2 p = {(__bf16)a[2 * i], (__bf16)a[2 * i + 1]};
+      // global_atomic_pk_add_bf16
+      (void)__builtin_amdgcn_global_atomic_fadd_v2bf16(
+          (__attribute__((address_space(1))) bf16x2*)(dst + 2 * i), p);
+    }
+  }
+};
+template <>
+struct Vec<f16_t> {
+  static constexpr int N = 8;
+  using acc_t = float;
+  __device__ static void unpack(u32x4 v, float* a) {
+    for (int i = 0; i < 4; ++i) {
+      a[2 * i] += (float)__builtin_bit_cast(_Float16, (uint16_t)(v[i] & 0xffffu));
+      a[2 * i + 1] += (float)__builtin_bit_cast(_Float16, (uint16_t)(v[i] >> 16));
+    }
+  }
+  __device__ static void flush(f16_t* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) {
+      f16x2 p = {(_Float16)a[2 * i], (_Float16)a[2 * i + 1]};
+      (void)__builtin_amdgcn_global_atomic_fadd_v2f16(
+          (__attribute__((address_space(1))) f16x2*)(dst + 2 * i), p);
+    }
+  }
+};
+
+constexpr int kRowsPerThread = 8;
+
+// Requires K % Vec<T>::N == 0, 16-byte aligned src/out, index constant along k (isk == 0).
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restrict__ src,
+                                                              const int64_t* __restrict__ index, T* out,
+                                                              Shape s) {
+  constexpr int VN = Vec<T>::N;
+  const int64_t kv = s.K / VN;                                  // 16-byte slices per row
+  const int64_t chunks = (s.E + kRowsPerThread - 1) / kRowsPerThread;
+  const int64_t total = s.B * chunks * kv;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = t % kv;
+    const int64_t ch = (t / kv) % chunks;
+    const int64_t b = t / (kv * chunks);
+    const int64_t e0 = ch * kRowsPerThread;
+    const int64_t e1 = min(e0 + kRowsPerThread, s.E);
+    float acc[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+    int64_t cur = index[b * s.isb + e0 * s.ise];
+    const T* row = src + (b * s.E + e0) * s.K + c * VN;
+    for (int64_t e = e0; e < e1; ++e, row += s.K) {
+      const int64_t idx = index[b * s.isb + e * s.ise];
+      if (idx != cur) {
+        Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
+#pragma unroll
+        for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+        cur = idx;
+      }
+      Vec<T>::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row)), acc);
+    }
+    Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
+  }
+}
+
+// ---- gather_coo -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gather_elem_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* out,
+                                   int64_t B, int64_t E, int64_t K, int64_t N) {
+  const int64_t total = B * E * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i % K;
+    const int64_t e = (i / K) % E;
+    const int64_t b = i / (K * E);
+    out[i] = src[(b * N + index[b * E + e]) * K + k];
+  }
+}
+
+// 16-byte slices: `kv` slices per row
+__global__ void gather_vec_kernel(const u32x4* __restrict__ src, const int64_t* __restrict__ index,
+                                  u32x4* out, int64_t B, int64_t E, int64_t kv, int64_t N) {
+  const int64_t total = B * E * kv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % kv;
+    const int64_t e = (i / kv) % E;
+    const int64_t b = i / (kv * E);
+    __builtin_nontemporal_store(src[(b * N + index[b * E + e]) * kv + c], out + i);
+  }
+}
+
+// ---- host dispatch ----------------------------------------------------------------------------------------
+inline unsigned grid_for(int64_t n, int threads = 256) {
+  int64_t blocks = (n + threads - 1) / threads;
+  const int64_t cap = (int64_t)device_info().num_cus * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int64_t* arg, const void* init_,
+                const Shape& s, hipStream_t stream) {
+  const T* src = static_cast<const T*>(src_);
+  T* out = static_cast<T*>(out_);
+  const T* init = static_cast<const T*>(init_);
+  const int64_t total = s.B * s.E * s.K;
+  const int64_t outn = s.B * s.N * s.K;
+  if (total == 0) return PYG_HIP_OK;
+  const unsigned grid = grid_for(total);
+  if (op == OP_SUM) {
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
+                  std::is_same<T, f16_t>::value) {
+      if (s.isk == 0 && s.K % Vec<T>::N == 0 && aligned16(src) && aligned16(out)) {
+        const int64_t threads = s.B * ((s.E + kRowsPerThread - 1) / kRowsPerThread) * (s.K / Vec<T>::N);
+        hipLaunchKernelGGL((scatter_sum_vec_kernel<T>), dim3(grid_for(threads)), dim3(256), 0, stream, src,
+                           index, out, s);
+        PYG_HIP_CHECK(hipGetLastError());
+        return PYG_HIP_OK;
+      }
+    }
+    hipLaunchKernelGGL((scatter_elem_kernel<T, OP_SUM>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
+  } else if (op == OP_MUL) {
+    hipLaunchKernelGGL((scatter_elem_kernel<T, OP_MUL>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
+  } else if (op == OP_MIN || op == OP_MAX) {
+    PYG_HIP_REQUIRE(arg != nullptr, "scatter_min/max: 'arg_out' is NULL");
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, stream, arg, outn,
+                       s.E);
+    if (op == OP_MIN) {
+      hipLaunchKernelGGL((scatter_elem_kernel<T, OP_MIN>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
+      hipLaunchKernelGGL((scatter_arg_kernel<T, true>), dim3(grid), dim3(256), 0, stream, src, index, out, init,
+                         arg, s);
+    } else {
+      hipLaunchKernelGGL((scatter_elem_kernel<T, OP_MAX>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
+      hipLaunchKernelGGL((scatter_arg_kernel<T, false>), dim3(grid), dim3(256), 0, stream, src, index, out, init,
+                         arg, s);
+    }
+    if (!init)
+      hipLaunchKernelGGL((reset_empty_kernel<T>), dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, stream, out,
+                         arg, outn, s.E);
+  } else {
+    return fail(PYG_HIP_ERR_INVALID, "scatter: unknown reduce op %d", op);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T>
+int run_fill_extreme(int op, void* out_, int64_t n, hipStream_t stream) {
+  if (n == 0) return PYG_HIP_OK;
+  T* out = static_cast<T*>(out_);
+  T v;
+  // host-side constants (the device helpers are not callable here)
+  if constexpr (std::is_same<T, bf16_t>::value) v = bf16_t{(uint16_t)(op == OP_MIN ? 0x7f7f : 0xff7f)};
+  else if constexpr (std::is_same<T, f16_t>::value) v = f16_t{(uint16_t)(op == OP_MIN ? 0x7bff : 0xfbff)};
+  else v = op == OP_MIN ? std::numeric_limits<T>::max() : std::numeric_limits<T>::lowest();
+  hipLaunchKernelGGL((fill_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, v);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T>
+int run_gather(const void* src, const int64_t* index, void* out, int64_t B, int64_t E, int64_t K, int64_t N,
+               hipStream_t stream) {
+  const int64_t total = B * E * K;
+  if (total == 0) return PYG_HIP_OK;
+  const int64_t row_bytes = K * (int64_t)sizeof(T);
+  if (row_bytes % 16 == 0 && aligned16(src) && aligned16(out)) {
+    const int64_t kv = row_bytes / 16;
+    hipLaunchKernelGGL(gather_vec_kernel, dim3(grid_for(B * E * kv)), dim3(256), 0, stream,
+                       static_cast<const u32x4*>(src), index, static_cast<u32x4*>(out), B, E, kv, N);
+  } else {
+    hipLaunchKernelGGL((gather_elem_kernel<T>), dim3(grid_for(total)), dim3(256), 0, stream,
+                       static_cast<const T*>(src), index, static_cast<T*>(out), B, E, K, N);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+#define PYG_DISPATCH_ALL(dtype, CALL)                                         \
+  switch (dtype) {                                                            \
+    case PYG_F32: { using scalar_t = float; return CALL; }                    \
+    case PYG_F64: { using scalar_t = double; return CALL; }                   \
+    case PYG_F16: { using scalar_t = f16_t; return CALL; }                    \
+    case PYG_BF16: { using scalar_t = bf16_t; return CALL; }                  \
+    case PYG_I8: { using scalar_t = int8_t; return CALL; }                    \
+    case PYG_U8: { using scalar_t = uint8_t; return CALL; }                   \
+    case PYG_I16: { using scalar_t = int16_t; return CALL; }                  \
+    case PYG_I32: { using scalar_t = int32_t; return CALL; }                  \
+    case PYG_I64: { using scalar_t = int64_t; return CALL; }                  \
+    default: return fail(PYG_HIP_ERR_INVALID, "unknown dtype %d", dtype);     \
+  }
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" {
+
+int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index, int64_t index_stride_b,
+                    int64_t index_stride_e, int64_t index_stride_k, void* out, int64_t* arg_out,
+                    const void* out_init, int64_t B, int64_t E, int64_t K, int64_t N, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, "scatter: negative size");
+  if (B * E * K == 0) {
+    if ((op == OP_MIN || op == OP_MAX) && arg_out && B * N * K > 0) {
+      hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((B * N * K + 255) / 256)), dim3(256), 0, stream,
+                         arg_out, B * N * K, E);
+      PYG_HIP_CHECK(hipGetLastError());
+    }
+    return PYG_HIP_OK;
+  }
+  PYG_HIP_REQUIRE(src && index && out, "scatter: NULL tensor");
+  Shape s{B, E, K, N, index_stride_b, index_stride_e, index_stride_k};
+  PYG_DISPATCH_ALL(dtype, (run_scatter<scalar_t>(op, src, index, out, arg_out, out_init, s, stream)));
+}
+
+int pyg_hip_fill_reduce_identity(int op, int dtype, void* out, int64_t n, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(op == OP_MIN || op == OP_MAX, "fill_reduce_identity: only min/max need a non-trivial fill");
+  PYG_DISPATCH_ALL(dtype, (run_fill_extreme<scalar_t>(op, out, n, stream)));
+}
+
+int pyg_hip_gather_coo(int dtype, const void* src, const int64_t* index, void* out, int64_t B, int64_t E,
+                       int64_t K, int64_t N, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, "gather_coo: negative size");
+  if (B * E * K == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(src && index && out, "gather_coo: NULL tensor");
+  PYG_DISPATCH_ALL(dtype, (run_gather<scalar_t>(src, index, out, B, E, K, N, stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// Order-preserving device-wide exclusive scan with a generic (possibly non-commutative) operator.
+// Three launches (tile aggregates, spine, apply) or one for inputs of a single tile.  Load / Store
+// are functors so that producers and consumers fuse into the scan's passes.
+#pragma once
+
+#include "common.h"
+
+namespace pyg_hip {
+
+struct SumOp {
+  __host__ __device__ int64_t operator()(int64_t a, int64_t b) const { return a + b; }
+  __host__ __device__ static int64_t identity() { return 0; }
+};
+
+// ---- device-wide exclusive scan (order preserving, generic operator) -------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+template <typename T, typename Op>
+__device__ T block_exclusive(T agg, T* lds, Op op, T* total) {
+  const int tid = threadIdx.x;
+  T* a = lds;
+  T* b = lds + kScanThreads;
+  a[tid] = agg;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {
+    T v = a[tid];
+    if (tid >= d) v = op(a[tid - d], v);
+    b[tid] = v;
+    __syncthreads();
+    T* tmp = a;
+    a = b;
+    b = tmp;
+  }
+  const T excl = tid ? a[tid - 1] : Op::identity();
+  *total = a[kScanThreads - 1];
+  __syncthreads();
+  return excl;
+}
+
+// Phase A: per-tile aggregates.
+template <typename T, typename Op, typename Load>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, int64_t n,
+                                                                   T* __restrict__ tile_agg) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  T agg = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) agg = op(agg, load(base + k));
+  T total;
+  (void)block_exclusive<T, Op>(agg, lds, op, &total);
+  if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
+}
+
+// Phase B: exclusive scan of the tile aggregates by one block; writes the grand total.
+template <typename T, typename Op>
+__global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(T* __restrict__ tile_agg,
+                                                                  int64_t ntiles,
+                                                                  T* __restrict__ total_out) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  T carry = Op::identity();
+  for (int64_t c0 = 0; c0 < ntiles; c0 += kScanThreads) {
+    const int64_t i = c0 + threadIdx.x;
+    const T v = i < ntiles ? tile_agg[i] : Op::identity();
+    T total;
+    const T excl = block_exclusive<T, Op>(v, lds, op, &total);
+    if (i < ntiles) tile_agg[i] = op(carry, excl);
+    carry = op(carry, total);
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+// Phase C: per-element exclusive prefixes -> Store.
+template <typename T, typename Op, typename Load, typename Store>
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Store store, int64_t n,
+                                                                  const T* __restrict__ tile_prefix,
+                                                                  T* __restrict__ total_out) {
+  __shared__ T lds[2 * kScanThreads];
+  Op op;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  T v[kScanItems];
+  T agg = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = base + k < n ? load(base + k) : Op::identity();
+    agg = op(agg, v[k]);
+  }
+  T total;
+  T run = block_exclusive<T, Op>(agg, lds, op, &total);
+  if (tile_prefix) run = op(tile_prefix[blockIdx.x], run);
+  else if (threadIdx.x == 0 && blockIdx.x == 0 && total_out) *total_out = total;  // single tile
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) store(base + k, run, v[k]);
+    run = op(run, v[k]);
+  }
+}
+
+// scratch: ntiles * sizeof(T) + sizeof(T) (total).  Returns device pointer to the total.
+template <typename T, typename Op, typename Load, typename Store>
+int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hipStream_t stream) {
+  if (n <= 0) {
+    T id = Op::identity();
+    PYG_HIP_CHECK(hipMemcpyAsync(total_dev, &id, sizeof(T), hipMemcpyHostToDevice, stream));
+    return PYG_HIP_OK;
+  }
+  const int64_t ntiles = (n + kScanTile - 1) / kScanTile;
+  if (ntiles == 1) {
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3(1), dim3(kScanThreads), 0,
+                       stream, load, store, n, (const T*)nullptr, total_dev);
+  } else {
+    hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, n, tile_buf);
+    hipLaunchKernelGGL((scan_spine_kernel<T, Op>), dim3(1), dim3(kScanThreads), 0, stream, tile_buf,
+                       ntiles, total_dev);
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf,
+                       (T*)nullptr);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+
+}  // namespace pyg_hip

@@ -115,6 +115,223 @@ def grouped_matmul(
     return outs
 
 
+# ---------------------------------------------------------------------------------------------------
+# index_sort
+# ---------------------------------------------------------------------------------------------------
+
+def index_sort(
+    inputs: Tensor,
+    max_value: Optional[int] = None,
+) -> Tuple[Tensor, Tensor]:
+    r"""Sorts the elements of the :obj:`inputs` tensor in ascending order
+    (same contract as :func:`pyg_lib.ops.index_sort`, pyg_lib/ops/__init__.py:295-321).
+    It is expected that :obj:`inputs` is one-dimensional and that it only
+    contains positive integer values. If :obj:`max_value` is given, it can be
+    used by the underlying algorithm for better performance.
+
+    Unlike the reference, device tensors are *not* handed to :func:`torch.sort`
+    (:319-320): they run the LDS radix sort of this library; the result equals
+    ``torch.sort(inputs, stable=True)``.
+
+    Args:
+        inputs: A vector with positive integer values.
+        max_value: The maximum value stored inside :obj:`inputs`. This value
+            can be an estimation, but needs to be greater than or equal to the
+            real maximum.
+
+    Returns:
+        A tuple containing sorted values and indices of the elements in the
+        original :obj:`input` tensor.
+    """
+    return torch.ops.pyg.index_sort(inputs, max_value)
+
+
+# ---------------------------------------------------------------------------------------------------
+# scatter / segment_coo / gather_coo  (pyg_lib/ops/__init__.py:353-631, 764-835)
+# ---------------------------------------------------------------------------------------------------
+
+def scatter_sum(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tensor:
+    r"""Reduces all values from :obj:`src` into :obj:`out` at the indices specified in :obj:`index`
+    along :obj:`dim`, using ``sum``.  A fresh :obj:`out` is zero-initialised; a given :obj:`out` is
+    **accumulated** into (pyg_lib/ops/__init__.py:353-380)."""
+    return torch.ops.pyg.scatter_sum(src, index, dim, out, dim_size)
+
+
+scatter_add = scatter_sum
+
+
+def scatter_mul(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tensor:
+    r"""``mul`` reduction; a fresh :obj:`out` starts from ones, a given one is multiplied into."""
+    return torch.ops.pyg.scatter_mul(src, index, dim, out, dim_size)
+
+
+def scatter_mean(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                 dim_size: Optional[int] = None) -> Tensor:
+    r"""``mean`` reduction (sum / count, floor division for integer dtypes; empty buckets give 0)."""
+    return torch.ops.pyg.scatter_mean(src, index, dim, out, dim_size)
+
+
+def scatter_min(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    r"""``min`` reduction.  Returns ``(values, argindex)``; empty buckets yield value ``0`` and
+    argindex ``src.size(dim)`` (sentinel); on ties the first source position wins."""
+    return torch.ops.pyg.scatter_min(src, index, dim, out, dim_size)
+
+
+def scatter_max(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    r"""``max`` reduction.  Returns ``(values, argindex)`` (see :func:`scatter_min`)."""
+    return torch.ops.pyg.scatter_max(src, index, dim, out, dim_size)
+
+
+def segment_sum_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None,
+                    dim_size: Optional[int] = None) -> Tensor:
+    r"""Sums :obj:`src` over the runs of a **sorted** :obj:`index` along ``index.dim() - 1``."""
+    return torch.ops.pyg.segment_sum_coo(src, index, out, dim_size)
+
+
+segment_add_coo = segment_sum_coo
+
+
+def segment_mean_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None,
+                     dim_size: Optional[int] = None) -> Tensor:
+    r"""Mean over the runs of a sorted :obj:`index`; buckets touched by :obj:`index` are overwritten."""
+    return torch.ops.pyg.segment_mean_coo(src, index, out, dim_size)
+
+
+def segment_min_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None,
+                    dim_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    r"""Min over the runs of a sorted :obj:`index`; returns ``(values, argindex)``."""
+    return torch.ops.pyg.segment_min_coo(src, index, out, dim_size)
+
+
+def segment_max_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None,
+                    dim_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    r"""Max over the runs of a sorted :obj:`index`; returns ``(values, argindex)``."""
+    return torch.ops.pyg.segment_max_coo(src, index, out, dim_size)
+
+
+def gather_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    r"""``out[..., i, ...] = src[..., index[..., i], ...]`` along ``index.dim() - 1``."""
+    return torch.ops.pyg.gather_coo(src, index, out)
+
+
+def scatter(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+            dim_size: Optional[int] = None, reduce: str = 'sum') -> Tensor:
+    r"""Routes to the typed scatter op by :obj:`reduce` (``"sum"``/``"add"``, ``"mul"``, ``"mean"``,
+    ``"min"``, ``"max"``); min/max return only the values (pyg_lib/ops/__init__.py:764-791)."""
+    if reduce == 'sum' or reduce == 'add':
+        return scatter_sum(src, index, dim, out, dim_size)
+    if reduce == 'mul':
+        return scatter_mul(src, index, dim, out, dim_size)
+    if reduce == 'mean':
+        return scatter_mean(src, index, dim, out, dim_size)
+    if reduce == 'min':
+        return scatter_min(src, index, dim, out, dim_size)[0]
+    if reduce == 'max':
+        return scatter_max(src, index, dim, out, dim_size)[0]
+    raise ValueError(f'Unknown reduce: {reduce!r}')
+
+
+def segment_coo(src: Tensor, index: Tensor, out: Optional[Tensor] = None, dim_size: Optional[int] = None,
+                reduce: str = 'sum') -> Tensor:
+    r"""Routes by :obj:`reduce` to the typed ``segment_*_coo`` op (pyg_lib/ops/__init__.py:794-813)."""
+    if reduce == 'sum' or reduce == 'add':
+        return segment_sum_coo(src, index, out, dim_size)
+    if reduce == 'mean':
+        return segment_mean_coo(src, index, out, dim_size)
+    if reduce == 'min':
+        return segment_min_coo(src, index, out, dim_size)[0]
+    if reduce == 'max':
+        return segment_max_coo(src, index, out, dim_size)[0]
+    raise ValueError(f'Unknown reduce: {reduce!r}')
+
+
+def _broadcast(index: Tensor, src: Tensor, dim: int) -> Tensor:
+    if dim < 0:
+        dim = src.dim() + dim
+    if index.dim() == 1:
+        for _ in range(dim):
+            index = index.unsqueeze(0)
+    for _ in range(index.dim(), src.dim()):
+        index = index.unsqueeze(-1)
+    return index.expand(src.size())
+
+
+def _require_float(name: str, src: Tensor) -> None:
+    if not src.is_floating_point():
+        raise ValueError(f'{name} requires a floating-point src tensor (got {src.dtype})')
+
+
+def scatter_softmax(src: Tensor, index: Tensor, dim: int = -1, dim_size: Optional[int] = None) -> Tensor:
+    r"""Softmax over the groups given by :obj:`index` (pyg_lib/ops/__init__.py:838-862): recentre by
+    the per-group max, exponentiate, divide by the per-group sum."""
+    _require_float('scatter_softmax', src)
+    idx = _broadcast(index, src, dim)
+    group_max = scatter_max(src, index, dim, dim_size=dim_size)[0]
+    ex = (src - group_max.gather(dim, idx)).exp()
+    group_sum = scatter_sum(ex, index, dim, dim_size=dim_size)
+    return ex / group_sum.gather(dim, idx)
+
+
+def scatter_log_softmax(src: Tensor, index: Tensor, dim: int = -1, dim_size: Optional[int] = None,
+                        eps: float = 1e-12) -> Tensor:
+    r"""Log-softmax over the groups given by :obj:`index` (pyg_lib/ops/__init__.py:865-889)."""
+    _require_float('scatter_log_softmax', src)
+    idx = _broadcast(index, src, dim)
+    group_max = scatter_max(src, index, dim, dim_size=dim_size)[0]
+    centred = src - group_max.gather(dim, idx)
+    group_sum = scatter_sum(centred.exp(), index, dim, dim_size=dim_size)
+    return centred - torch.log(group_sum.gather(dim, idx) + eps)
+
+
+def scatter_std(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                dim_size: Optional[int] = None, unbiased: bool = True) -> Tensor:
+    r"""Standard deviation per group (pyg_lib/ops/__init__.py:892-931): two :func:`scatter_sum`
+    passes, Bessel's correction ``N / (N - 1)`` when :obj:`unbiased`."""
+    _require_float('scatter_std', src)
+    if out is not None:
+        dim_size = out.size(dim)
+    idx = _broadcast(index, src, dim)
+    count = scatter_sum(torch.ones_like(src), idx, dim, dim_size=dim_size)
+    total = scatter_sum(src, idx, dim, dim_size=dim_size)
+    count_safe = count.clamp(min=1)
+    dev = src - (total / count_safe).gather(dim, idx)
+    res = scatter_sum(dev * dev, idx, dim, out, dim_size)
+    denom = (count - 1).clamp(min=1) if unbiased else count_safe
+    return (res / denom).sqrt()
+
+
+def scatter_logsumexp(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None,
+                      dim_size: Optional[int] = None, eps: float = 1e-12) -> Tensor:
+    r"""Numerically stable log-sum-exp per group (pyg_lib/ops/__init__.py:934-984).  Empty buckets
+    give ``0`` for a fresh output and keep the caller's value when :obj:`out` is supplied."""
+    _require_float('scatter_logsumexp', src)
+    if out is not None:
+        dim_size = out.size(dim)
+    size = list(src.size())
+    if dim_size is not None:
+        size[dim] = dim_size
+    elif index.numel() == 0:
+        size[dim] = 0
+    else:
+        size[dim] = int(index.max().item()) + 1
+    group_max = torch.full(size, float('-inf'), dtype=src.dtype, device=src.device)
+    scatter_max(src, index, dim, group_max, dim_size)
+    idx = _broadcast(index, src, dim)
+    centred = src - group_max.gather(dim, idx)
+    centred = torch.where(torch.isnan(centred), torch.full_like(centred, float('-inf')), centred)
+    group_sum = scatter_sum(centred.exp(), index, dim, dim_size=dim_size)
+    res = group_max + (group_sum + eps).log()
+    if out is None:
+        return res.nan_to_num(nan=0.0, posinf=0.0, neginf=0.0)
+    keep = out.clone()
+    out.copy_(torch.where(~torch.isfinite(res), keep, res))
+    return out
+
+
 def matmul_last_variant() -> str:
     """Name of the kernel variant the last matmul call dispatched to (test/diagnostic hook)."""
     return _capi.lib().pyg_hip_matmul_last_variant().decode()
@@ -123,4 +340,23 @@ def matmul_last_variant() -> str:
 __all__ = [
     'grouped_matmul',
     'segment_matmul',
+    'index_sort',
+    'scatter',
+    'scatter_sum',
+    'scatter_add',
+    'scatter_mul',
+    'scatter_mean',
+    'scatter_min',
+    'scatter_max',
+    'scatter_softmax',
+    'scatter_log_softmax',
+    'scatter_std',
+    'scatter_logsumexp',
+    'segment_coo',
+    'segment_sum_coo',
+    'segment_add_coo',
+    'segment_mean_coo',
+    'segment_min_coo',
+    'segment_max_coo',
+    'gather_coo',
 ]
