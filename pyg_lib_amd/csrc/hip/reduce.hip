@@ -272,7 +272,11 @@ struct Vec<float> {
   static constexpr int N = 4;
   using acc_t = float;
   __device__ static void unpack(u32x4 v, float* a) {
-    for (int i = 0; i < 4; ++i) a[i] += __builtin_bit_cast(float, v[i]);
+    // (bit_cast straight from a vector-element lvalue miscompiles to element 0: copy out first)
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t w = v[i];
+      a[i] += __builtin_bit_cast(float, w);
+    }
   }
   __device__ static void flush(float* dst, const float* a) {
     for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, a[i]);

@@ -34,7 +34,11 @@ def check(got, ref_np, bf16, sum_like):
     if not ref.is_floating_point() or not sum_like:
         assert torch.equal(got, ref)  # integers, min/max values: exact
     elif ref.dtype in (torch.float16, torch.bfloat16):
-        torch.testing.assert_close(got, ref, atol=1e-2, rtol=1e-2)
+        # 16-bit sums round after every update in the reference and after every atomic here, in a
+        # different order: allow two bf16 ulps of the largest bucket (test_scatter.py:80-86 uses a flat
+        # 1e-2 on 8 elements; the recorded cases go up to 3000 x 32).
+        scale = max(1.0, float(ref.float().abs().max()))
+        torch.testing.assert_close(got.float(), ref.float(), atol=scale * 2 ** -7, rtol=2e-2)
     else:
         torch.testing.assert_close(got, ref)
 
@@ -151,7 +155,8 @@ def test_scatter_sum_random_vs_oracle(dtype, K):
     if not dtype.is_floating_point:
         assert torch.equal(got.cpu(), ref)
     elif dtype in (torch.float16, torch.bfloat16):
-        torch.testing.assert_close(got.cpu().float(), ref.float(), atol=6e-2, rtol=2e-2)
+        scale = max(1.0, float(ref.float().abs().max()))  # a few 16-bit ulps of the largest bucket
+        torch.testing.assert_close(got.cpu().float(), ref.float(), atol=scale * 2 ** -6, rtol=2e-2)
     else:
         torch.testing.assert_close(got.cpu(), ref, atol=1e-4, rtol=1e-5)
 
