@@ -44,10 +44,9 @@ def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
     sizes = torch.floor(frac / frac.sum() * N).long()
     sizes[-1] += N - sizes.sum()
     ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
-    # contiguous row shard of this rank, ptr clipped to it
-    r0 = N * rank // world
-    r1 = N * (rank + 1) // world
-    lptr = (ptr.clamp(r0, r1) - r0)
+    # contiguous row shard of this rank, ptr clipped to it (pyg_lib_amd/sharding.py)
+    from pyg_lib_amd import sharding
+    r0, r1, lptr = sharding.shard_ptr(ptr, rank, world)
     gd = torch.Generator(device=device).manual_seed(1 + rank)
     x = torch.empty(r1 - r0, F, device=device, dtype=dtype)
     step = 4_000_000
@@ -164,25 +163,26 @@ def main():
     allgather = None
     if distributed:
         # RCCL all-gather(v) of the sharded outputs over xGMI, timed on its own (see module docstring)
-        counts = [N * (r + 1) // world - N * r // world for r in range(world)]
-        full = torch.empty(N, F, device=device, dtype=dtype)
-        outs = list(full.split(counts, dim=0))
-        dist.all_gather(outs, out)  # warm-up (uneven sizes -> grouped send/recv inside RCCL)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            dist.all_gather(outs, out)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = torch.tensor([(time.perf_counter() - ta) / reps], device=device, dtype=torch.float64)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        ag_ms = float(tg.item()) * 1e3
-        allgather = dict(ms=round(ag_ms, 3), bytes_per_rank_received=int((N - n_local) * F * esz),
-                         value_incl_allgather=round(flops / ((ms_per_step + ag_ms) * 1e-3) / 1e9, 1))
-        del full, outs
+        try:
+            from pyg_lib_amd import sharding
+            sharding.all_gather_rows(out, N)  # warm-up
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                full = sharding.all_gather_rows(out, N)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = torch.tensor([(time.perf_counter() - ta) / reps], device=device, dtype=torch.float64)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            ag_ms = float(tg.item()) * 1e3
+            allgather = dict(ms=round(ag_ms, 3), bytes_per_rank_received=int((N - n_local) * F * esz),
+                             value_incl_allgather=round(flops / ((ms_per_step + ag_ms) * 1e-3) / 1e9, 1))
+            del full
+        except Exception as e:  # noqa: BLE001 - the headline line must survive a collective failure
+            allgather = dict(error=repr(e)[:200])
 
     result = None
     if rank == 0:
