@@ -155,9 +155,18 @@ def main():
     n_local = x.size(0)
     alg_bytes = esz * (n_local * F + n_local * F + B * F * F) + 8 * (B + 1)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
+    # HBM bytes from PMC (FETCH_SIZE/WRITE_SIZE, separate --pmc passes of this command, corrected as
+    # MI355X_MICROARCH.md prescribes): recorded in profiles/, valid for the full single-GPU C2 launch
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r1_segment_matmul_c2_pmc.json')
+    if world == 1 and args.scale == 1.0 and args.dtype == 'bf16' and os.path.exists(pmc):
+        try:
+            traffic = int(json.load(open(pmc))['hbm_traffic_bytes'])
+        except Exception:  # noqa: BLE001
+            traffic = None
     roofline = dict(bound='hbm', achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
+                    traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
                     mfma_tflops=None if achieved is None else round(2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12, 1))
 
     allgather = None

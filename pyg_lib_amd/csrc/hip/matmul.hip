@@ -21,6 +21,7 @@
 // AT_DISPATCH_ALL_TYPES_AND2, run a plain one-thread-per-output kernel ("naive").
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -367,9 +368,11 @@ __device__ __forceinline__ u32x4 pack8(f16_t, const float* v) {
   return o;
 }
 
-template <typename T, int K, int MC, int NW>
+template <typename T, int K, int MC, int NW, int FLAGS = 3>
 __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
-    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B) {
+    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk) {
+  constexpr bool NT_LOAD = (FLAGS & 1) != 0;
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
   constexpr int SZ = 2;
   static_assert(Elem<T>::kSize == 2, "16-bit element types only");
   constexpr int NT = MC / 32;
@@ -394,15 +397,40 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   const int col0 = blockIdx.y * MC;
   char* stage = smem + WBYTES + wave * STAGE;
 
+  // Tile schedule: workgroup b owns the tile chunks b, b + G, b + 2G, ... of `chunk` consecutive
+  // tiles each (chunk <= 0: one contiguous range per workgroup).  Local tile i of this workgroup is
+  // global tile tile_of(i).
   const int total = tile_start[B];
-  const int t0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
-  const int t1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
-  if (t0 >= t1) return;
+  const int G = gridDim.x;
+  int nloc, cbase = 0;
+  if (chunk <= 0) {
+    cbase = (int)((int64_t)blockIdx.x * total / G);
+    nloc = (int)((int64_t)(blockIdx.x + 1) * total / G) - cbase;
+  } else {
+    const int nchunks = (total + chunk - 1) / chunk;
+    const int mine = nchunks > (int)blockIdx.x ? (nchunks - 1 - (int)blockIdx.x) / G + 1 : 0;
+    nloc = mine * chunk;
+    if (mine > 0) {
+      const int last_chunk = (mine - 1) * G + blockIdx.x;  // may be the ragged final chunk
+      const int over = (last_chunk + 1) * chunk - total;
+      if (over > 0) nloc -= over;
+    }
+  }
+  if (nloc <= 0) return;
+  auto tile_of = [&](int i) -> int {
+    if (chunk <= 0) return cbase + i;
+    const int j = i / chunk;
+    return (j * G + (int)blockIdx.x) * chunk + (i - j * chunk);
+  };
+  const int t0 = 0, t1 = nloc;  // local tile indices
 
   int lo = 0, hi = B;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (tile_start[mid] <= t0) lo = mid; else hi = mid;
+  {
+    const int first = tile_of(0);
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= first) lo = mid; else hi = mid;
+    }
   }
   int g = lo;       // group of the tile being prefetched
   int staged = -1;  // group whose weight is in LDS
@@ -418,7 +446,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   int64_t n_row0 = 0, n_rows = 0;
   bool n_valid = false;
 
-  auto prefetch = [&](int t) {
+  auto prefetch = [&](int ti) {
+    const int t = tile_of(ti);
     while (t >= tile_start[g + 1]) {
       ++g;
       dn = descs[g];
@@ -435,25 +464,32 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         const int c = cs ^ (r & XM);
         int64_t row = n_row0 + r;
         if (row >= n_rows) row = n_rows - 1;
-        xr[i] = __builtin_nontemporal_load(
-            reinterpret_cast<const u32x4*>(dn.a + row * (K * SZ) + c * 16));
+        const u32x4* src = reinterpret_cast<const u32x4*>(dn.a + row * (K * SZ) + c * 16);
+        xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
       }
     }
   };
 
+  // Software pipeline (per wave; the stage buffer is private to the wave):
+  //   loop top: X_t is in the LDS stage, L_{t+1} (next tile's rows) is in flight into xr.
+  //   1. multiply X_t by W (MFMA, fragments double-buffered in registers)
+  //   2. pack the result, swizzle it through the stage, read it back in row order (ov)
+  //   3. wait for L_{t+1} (issued a whole tile ago, as were the stores S_{t-1} ahead of it in the
+  //      in-order memory queue), write it to the stage
+  //   4. issue L_{t+2}, then the global stores S_t
+  // so no wave ever waits on a store it has just issued.
   prefetch(t0);
-  for (int t = t0; t < t1; ++t) {
-    const DevGroup d = dn;
-    const int cg = g;
-    const int64_t row0 = n_row0, rows = n_rows;
-    const bool valid = n_valid;
-    if (valid) {
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+  if (valid) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
-    }
-    if (t + 1 < t1) prefetch(t + 1);
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+  }
+  if (t0 + 1 < t1) prefetch(t0 + 1);
 
+  for (int t = t0; t < t1; ++t) {
     if (cg != staged) {
       __syncthreads();
       const char* w = d.w;
@@ -483,54 +519,95 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       __syncthreads();
       staged = cg;
     }
-    if (!valid) continue;
 
-    f32x16 acc[NT];
+    u32x4 ov[NO];
+    if (valid) {
+      f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+      // fragments of step s+1 are read from LDS while the MFMAs of step s run
+      u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h) ^ (x & XM))) * 16);
+      u32x4 wa[NT];
 #pragma unroll
-    for (int s = 0; s < NI; ++s) {
-      const int c = NI * h + s;
-      const u32x4 xv = *reinterpret_cast<const u32x4*>(stage + (x * CPR + (c ^ (x & XM))) * 16);
+      for (int tt = 0; tt < NT; ++tt) wa[tt] = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW);
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        u32x4 xb = xa;
+        u32x4 wb[NT];
+        if (s + 1 < NI) {
+          const int c = NI * h + s + 1;
+          xb = *reinterpret_cast<const u32x4*>(stage + (x * CPR + (c ^ (x & XM))) * 16);
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            wb[tt] = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW + (s + 1) * 16);
+        }
+        // keep the order "issue the next step's LDS reads, then this step's MFMAs": left alone, the
+        // scheduler sinks every ds_read to just before its MFMA (lgkmcnt(0) x32 per tile)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma_chunk(T{}, wa[tt], xa, acc[tt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NI) {
+          xa = xb;
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) wa[tt] = wb[tt];
+        }
+      }
+
+      // epilogue: fragment order -> swizzled stage -> row order (ov)
+      const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + col0 + (MC / 2) * h : nullptr;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        const u32x4 wv = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW + s * 16);
-        acc[tt] = mfma_chunk(T{}, wv, xv, acc[tt]);
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+        if (bp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = NO * h + 2 * tt + j;
+          *reinterpret_cast<u32x4*>(stage + (x * CPO + (c ^ (x & OM))) * 16) = pack8(T{}, v + 8 * j);
+        }
       }
+#pragma unroll
+      for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
     }
 
-    // epilogue: fragment order -> swizzled stage -> coalesced row stores
-    const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + col0 + (MC / 2) * h : nullptr;
+    // stage the next tile (its loads were issued one tile ago) and issue the loads after it
+    const DevGroup d_out = d;
+    const int64_t row0_out = row0, rows_out = rows;
+    const bool valid_out = valid;
+    if (t + 1 < t1) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+      if (valid) {
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
-      if (bp) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = NO * h + 2 * tt + j;
-        *reinterpret_cast<u32x4*>(stage + (x * CPO + (c ^ (x & OM))) * 16) = pack8(T{}, v + 8 * j);
-      }
+      if (t + 2 < t1) prefetch(t + 2);
     }
-    {
-      const int M = d.m;
-      char* obase = d.c + (row0 * M + col0) * SZ;
+
+    if (valid_out) {
+      const int M = d_out.m;
+      char* obase = d_out.c + (row0_out * M + col0) * SZ;
 #pragma unroll
       for (int i = 0; i < NO; ++i) {
         const int p = i * 64 + lane;
         const int r = p / CPO;
         const int cs = p % CPO;
         const int c = cs ^ (r & OM);
-        const u32x4 ov = *reinterpret_cast<const u32x4*>(stage + p * 16);
-        if (row0 + r < rows)
-          __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(obase + (int64_t)r * M * SZ + c * 16));
+        if (row0_out + r < rows_out) {
+          u32x4* dst = reinterpret_cast<u32x4*>(obase + (int64_t)r * M * SZ + c * 16);
+          if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+        }
       }
     }
   }
@@ -682,14 +759,36 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   }
   const DeviceInfo& di = device_info();
   int per_cu = std::max(1, std::min(use_v2 ? 2 : 4, (160 * 1024) / lds));
+  // experiment knobs (tools/mm_variants.py): PYG_HIP_MM_FLAGS (bit0 nt loads, bit1 nt stores),
+  // PYG_HIP_MM_WGS (workgroups per CU in the persistent grid)
+  int flags = 3;
+  int chunk = 0;
+  if (const char* e = getenv("PYG_HIP_MM_FLAGS")) flags = atoi(e) & 3;
+  if (const char* e = getenv("PYG_HIP_MM_CHUNK")) chunk = atoi(e);
+  if (const char* e = getenv("PYG_HIP_MM_WGS")) per_cu = std::max(1, atoi(e));
   int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
   dim3 grid((unsigned)gx, (unsigned)(M / MC), 1);
   {
     ProfScope prof(stream);
-    if constexpr (use_v2)
-      hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
-                         w.descs, w.tile_start, B);
-    else
+    if constexpr (use_v2) {
+      if constexpr (K == 128 && MC == 128) {
+        // the headline shape carries the experiment variants
+        static thread_local bool attr2 = false;
+        if (!attr2) {
+          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          attr2 = true;
+        }
+        if (flags == 0) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 0>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
+        else if (flags == 1) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 1>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
+        else if (flags == 2) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 2>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
+        else hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 3>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
+      } else {
+        hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
+                           w.descs, w.tile_start, B, chunk);
+      }
+    } else
       hipLaunchKernelGGL((mfma_rows_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
                          w.descs, w.tile_start, B);
   }
