@@ -146,6 +146,7 @@ typedef struct {
   int32_t src_type;
   int32_t dst_type;
   const int64_t* num_neighbors_host; /* L fan-outs, host */
+  const int64_t* edge_time;          /* device, per edge, or NULL (edge-level temporal sampling) */
 } pyg_hip_relation;
 
 /* Seeds of one node type, in seed_dict iteration order. */
@@ -154,6 +155,7 @@ typedef struct {
   int32_t reserved;
   const int64_t* seed; /* device */
   int64_t num_seed;
+  const int64_t* seed_time; /* device, per seed, or NULL (then node_time[seed] is used) */
 } pyg_hip_seed_set;
 
 /* Results.  All pointers come from host->alloc and are owned by the caller afterwards (blocks
@@ -182,15 +184,21 @@ typedef struct {
  * pyg_lib/csrc/sampler/neighbor.cpp:130-147).  The reference has no device sampler at all.
  *
  * flags: csc, replace, disjoint, return_edge_id as in the schema.  `directed` must be true
- * (the reference errors otherwise, neighbor_kernel.cpp:501).  Temporal (node_time / edge_time)
- * and biased (edge_weight) sampling return PYG_HIP_ERR_UNSUPPORTED on the device path.
+ * (the reference errors otherwise, neighbor_kernel.cpp:501).
+ * Temporal sampling (node_temporal_sample / edge_temporal_sample, neighbor_kernel.cpp:74-144;
+ * requires disjoint): node_time_by_type is a host array of num_node_types device pointers (entries
+ * or the array itself may be NULL), relation.edge_time takes precedence; temporal_last selects the
+ * "last" strategy.  A neighbourhood that is not time-sorted fails with the reference's message.
+ * Biased sampling (edge_weight) is not available on the device path.
  * Synchronises `stream` (output sizes are data dependent).
  */
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                                const pyg_hip_relation* relations_host,
                                                int num_seed_sets,
-                                               const pyg_hip_seed_set* seeds_host, int L, int csc,
-                                               int replace, int disjoint, int return_edge_id,
+                                               const pyg_hip_seed_set* seeds_host,
+                                               const int64_t* const* node_time_by_type,
+                                               int temporal_last, int L, int csc, int replace,
+                                               int disjoint, int return_edge_id,
                                                const pyg_hip_sampler_host* host,
                                                pyg_hip_sample_result* result, void* stream);
 

@@ -251,9 +251,10 @@ struct SampleOutput {
 };
 
 static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
-                                const std::vector<pyg_hip_seed_set>& seeds, int num_node_types, int L,
-                                bool csc, bool replace, bool disjoint, bool return_edge_id,
-                                const at::Device& device) {
+                                const std::vector<pyg_hip_seed_set>& seeds,
+                                const std::vector<const int64_t*>& node_time, bool temporal_last,
+                                int num_node_types, int L, bool csc, bool replace, bool disjoint,
+                                bool return_edge_id, const at::Device& device) {
   DeviceGuard guard(device);
   const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
   SamplerHost host;
@@ -274,9 +275,10 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
   res.num_edges = num_edges.data();
   res.edges_per_hop_host = eph.data();
   res.rng_blocks = 0;
-  const int rc = pyg_hip_hetero_neighbor_sample(T, E, rels.data(), (int)seeds.size(), seeds.data(), L,
-                                                csc, replace, disjoint, return_edge_id, &cb, &res,
-                                                host.stream);
+  const int rc = pyg_hip_hetero_neighbor_sample(T, E, rels.data(), (int)seeds.size(), seeds.data(),
+                                                node_time.empty() ? nullptr : node_time.data(),
+                                                temporal_last, L, csc, replace, disjoint, return_edge_id,
+                                                &cb, &res, host.stream);
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);
   SampleOutput out;
@@ -295,20 +297,27 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
   return out;
 }
 
-static void check_modes(bool has_node_time, bool has_edge_time, bool has_weight, bool directed, bool disjoint,
-                        const std::string& temporal_strategy) {
+static void check_modes(bool has_node_time, bool has_edge_time, bool has_seed_time, bool has_weight,
+                        bool directed, bool disjoint, const std::string& temporal_strategy) {
   // precondition checks of the reference kernel, sampler/cpu/neighbor_kernel.cpp:34-36,354-380,501
   TORCH_CHECK(temporal_strategy == "uniform" || temporal_strategy == "last", "No valid temporal strategy found");
   TORCH_CHECK(!has_node_time || disjoint, "Temporal sampling needs to create disjoint subgraphs");
   TORCH_CHECK(!has_edge_time || disjoint, "Temporal sampling needs to create disjoint subgraphs");
   TORCH_CHECK(!(has_node_time && has_edge_time), "Only one of node-level or edge-level sampling is supported ");
+  TORCH_CHECK(!has_edge_time || has_seed_time, "Seed time needs to be specified");
+  TORCH_CHECK(!(has_node_time && has_weight), "Biased node temporal sampling not yet supported");
+  TORCH_CHECK(!(has_edge_time && has_weight), "Biased edge temporal sampling not yet supported");
   TORCH_CHECK(directed, "Undirected subgraphs not yet supported");
-  TORCH_CHECK(!has_node_time && !has_edge_time,
-              "pyg (HIP): temporal sampling is not implemented on the device path yet; refusing to fall back "
-              "to a CPU kernel");
   TORCH_CHECK(!has_weight,
               "pyg (HIP): biased sampling is not implemented on the device path yet; refusing to fall back "
               "to a CPU kernel");
+}
+
+static const int64_t* time_ptr(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_contiguous(), "Non-contiguous '", what, "'");
+  TORCH_CHECK(t.is_cuda(), "pyg (HIP): '", what, "' must live on a HIP device");
+  TORCH_CHECK(t.scalar_type() == at::kLong, "pyg (HIP): '", what, "' must be int64");  // temporal_t, :393-394
+  return t.data_ptr<int64_t>();
 }
 
 std::tuple<Tensor, Tensor, Tensor, c10::optional<Tensor>, std::vector<int64_t>, std::vector<int64_t>>
@@ -317,8 +326,8 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
                        const c10::optional<Tensor>& edge_time, const c10::optional<Tensor>& seed_time,
                        const c10::optional<Tensor>& edge_weight, bool csc, bool replace, bool directed,
                        bool disjoint, std::string temporal_strategy, bool return_edge_id) {
-  check_modes(node_time.has_value(), edge_time.has_value(), edge_weight.has_value(), directed, disjoint,
-              temporal_strategy);
+  check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(),
+              directed, disjoint, temporal_strategy);
   check_index(rowptr, "rowptr");
   check_index(col, "col");
   check_index(seed, "seed");
@@ -330,13 +339,17 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   rels[0].src_type = 0;
   rels[0].dst_type = 0;
   rels[0].num_neighbors_host = num_neighbors.data();
+  rels[0].edge_time = edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr;
   std::vector<pyg_hip_seed_set> seeds(1);
   seeds[0].node_type = 0;
   seeds[0].reserved = 0;
   seeds[0].seed = seed.data_ptr<int64_t>();
   seeds[0].num_seed = seed.numel();
-  auto out = run_sampler(rels, seeds, 1, (int)num_neighbors.size(), csc, replace, disjoint, return_edge_id,
-                         rowptr.device());
+  seeds[0].seed_time = seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr;
+  std::vector<const int64_t*> ntime;
+  if (node_time.has_value()) ntime.push_back(time_ptr(node_time.value(), "node_time"));
+  auto out = run_sampler(rels, seeds, ntime, temporal_strategy == "last", 1, (int)num_neighbors.size(), csc,
+                         replace, disjoint, return_edge_id, rowptr.device());
   c10::optional<Tensor> eid = c10::nullopt;
   if (return_edge_id) eid = out.edge_id[0];
   return std::make_tuple(out.row[0], out.col[0], out.node_id[0], eid, out.nodes_per_hop[0],
@@ -357,8 +370,8 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
                               const c10::optional<c10::Dict<rel_type, Tensor>>& edge_weight_dict, bool csc,
                               bool replace, bool directed, bool disjoint, std::string temporal_strategy,
                               bool return_edge_id) {
-  check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), edge_weight_dict.has_value(), directed,
-              disjoint, temporal_strategy);
+  check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), seed_time_dict.has_value(),
+              edge_weight_dict.has_value(), directed, disjoint, temporal_strategy);
   std::unordered_map<std::string, int> nt_index;
   for (size_t i = 0; i < node_types.size(); ++i) nt_index[node_types[i]] = (int)i;
   size_t L = 0;
@@ -383,6 +396,9 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     rels[e].num_cols = col.numel();
     rels[e].src_type = nt_index[std::get<0>(k)];
     rels[e].dst_type = nt_index[std::get<2>(k)];
+    rels[e].edge_time = nullptr;
+    if (edge_time_dict.has_value() && edge_time_dict.value().contains(rel))
+      rels[e].edge_time = time_ptr(edge_time_dict.value().at(rel), "edge_time");
   }
   for (size_t e = 0; e < edge_types.size(); ++e) {
     TORCH_CHECK(fanouts[e].size() == L, "hetero_neighbor_sample: all relations must list ", L, " hops");
@@ -399,11 +415,21 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     s.reserved = 0;
     s.seed = seed.data_ptr<int64_t>();
     s.num_seed = seed.numel();
+    s.seed_time = nullptr;
+    if (seed_time_dict.has_value()) s.seed_time = time_ptr(seed_time_dict.value().at(kv.key()), "seed_time");
     seeds.push_back(s);
   }
+  std::vector<const int64_t*> ntime;
+  if (node_time_dict.has_value()) {
+    ntime.assign(node_types.size(), nullptr);
+    for (const auto& kv : node_time_dict.value()) {
+      TORCH_CHECK(nt_index.count(kv.key()), "hetero_neighbor_sample: time given for unknown node type '", kv.key(), "'");
+      ntime[(size_t)nt_index[kv.key()]] = time_ptr(kv.value(), "node_time");
+    }
+  }
   TORCH_CHECK(device.has_value(), "hetero_neighbor_sample: no tensors given");
-  auto out = run_sampler(rels, seeds, (int)node_types.size(), (int)L, csc, replace, disjoint, return_edge_id,
-                         device.value());
+  auto out = run_sampler(rels, seeds, ntime, temporal_strategy == "last", (int)node_types.size(), (int)L, csc,
+                         replace, disjoint, return_edge_id, device.value());
   c10::Dict<rel_type, Tensor> out_row, out_col;
   c10::Dict<node_type, Tensor> out_node;
   c10::optional<c10::Dict<rel_type, Tensor>> out_eid;

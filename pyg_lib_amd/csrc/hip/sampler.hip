@@ -189,18 +189,63 @@ __global__ void seed_insert_kernel(const int64_t* __restrict__ seed, int64_t n, 
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// seed_times[batch] = seed_time[i], or node_time[seed[i]] (neighbor_kernel.cpp:417-428, 684-699)
+__global__ void seed_time_kernel(const int64_t* __restrict__ seed, const int64_t* __restrict__ seed_time,
+                                 const int64_t* __restrict__ node_time, int64_t n, int64_t batch0,
+                                 int64_t* __restrict__ seed_times) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) seed_times[batch0 + i] = seed_time ? seed_time[i] : node_time[seed[i]];
+}
+
 // ---- per-hop kernels -------------------------------------------------------------------------------
+// Effective neighbourhood [rs, re) of a frontier node: the CSR row, narrowed by the temporal
+// constraints of node_temporal_sample / edge_temporal_sample (neighbor_kernel.cpp:74-144):
+// upper bound on time <= seed_time (neighbourhoods are time-sorted), and for the "last" strategy
+// the `count` most recent ones.
+struct RangeCtx {
+  const int64_t* rowptr;
+  const int64_t* col;
+  const int64_t* time;        // nullptr: no temporal constraint
+  int edge_level;             // time indexed by edge (1) or by destination node (0)
+  int last;                   // temporal_strategy == "last"
+  const int64_t* seed_times;  // per batch id
+  const int64_t* batch;       // batch id of every node of the src list
+  int* error;                 // set to 1 on a non time-sorted neighbourhood
+  __device__ void operator()(int64_t v, int64_t src_pos, int64_t count, int64_t* rs_out, int64_t* re_out) const {
+    int64_t rs = rowptr[v], re = rowptr[v + 1];
+    if (time && re > rs && count != 0) {
+      const int64_t st = seed_times[batch[src_pos]];
+      int64_t lo = rs, hi = re;  // first p in [rs, re) with st < time(p)
+      while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const int64_t tm = edge_level ? time[mid] : time[col[mid]];
+        if (st < tm) hi = mid; else lo = mid + 1;
+      }
+      re = lo;
+      if (last && count >= 0 && re - count > rs) rs = re - count;
+      if (re - rs > 1) {
+        const int64_t t0 = edge_level ? time[rs] : time[col[rs]];
+        const int64_t t1 = edge_level ? time[re - 1] : time[col[re - 1]];
+        if (!(t0 <= t1)) *error = 1;  // "Found invalid non-sorted temporal neighborhood"
+      }
+    }
+    *rs_out = rs;
+    *re_out = re;
+  }
+};
+
 struct CountLoad {
   const int64_t* nodes;   // src node list
   int64_t begin;          // frontier begin
-  const int64_t* rowptr;
+  RangeCtx range;
   int64_t count;          // fan-out (may be negative)
   int replace;
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
     r.tab = rng_identity();
     const int64_t v = nodes[begin + i];
-    const int64_t rs = rowptr[v], re = rowptr[v + 1];
+    int64_t rs, re;
+    range(v, begin + i, count, &rs, &re);
     const int64_t deg = re - rs;
     if (deg <= 0 || count == 0) {
       r.edges = 0;
@@ -252,7 +297,7 @@ struct HopArgs {
   const int64_t* batch;       // src batch ids (disjoint) or nullptr
   int64_t begin;              // frontier begin (position of frontier node 0)
   int64_t frontier;           // frontier size
-  const int64_t* rowptr;
+  RangeCtx range;
   const int64_t* col;
   int64_t count;
   int replace;
@@ -314,9 +359,10 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
   const int64_t src_pos = a.begin + i;
   const int64_t v = a.nodes[src_pos];
   const int64_t src_batch = a.batch ? a.batch[src_pos] : 0;
-  const int64_t rs = a.rowptr[v];
-  const int64_t deg = a.rowptr[v + 1] - rs;
   const int64_t count = a.count;
+  int64_t rs, re_;
+  a.range(v, src_pos, count, &rs, &re_);
+  const int64_t deg = re_ - rs;
   if (deg <= 0 || count == 0) return;
   const int64_t off = a.edge_off[i];
 
@@ -553,8 +599,9 @@ struct RelState {
 };
 
 int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* rels,
-                int num_seed_sets, const pyg_hip_seed_set* seeds, int L, int csc, int replace,
-                int disjoint, int return_edge_id, Ctx& c, pyg_hip_sample_result* res) {
+                int num_seed_sets, const pyg_hip_seed_set* seeds, const int64_t* const* node_time,
+                int temporal_last, int L, int csc, int replace, int disjoint, int return_edge_id,
+                Ctx& c, pyg_hip_sample_result* res) {
   hipStream_t stream = c.stream;
   std::vector<NodeSet> ns((size_t)num_node_types);
   std::vector<RelState> rs((size_t)num_relations);
@@ -582,6 +629,19 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (rc != PYG_HIP_OK) return rc;
   }
 
+  // temporal sampling: one seed time per disjoint subgraph (batch id)
+  bool temporal = false;
+  for (int t = 0; t < num_node_types && node_time; ++t) temporal = temporal || node_time[t] != nullptr;
+  for (int e = 0; e < num_relations; ++e) temporal = temporal || rels[e].edge_time != nullptr;
+  int64_t* seed_times = nullptr;
+  int* err_flag = nullptr;
+  if (temporal) {
+    PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
+    PYG_ALLOC(seed_times, int64_t*, c, sizeof(int64_t) * (size_t)num_batches);
+    PYG_ALLOC(err_flag, int*, c, sizeof(int));
+    PYG_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int), stream));
+  }
+
   // ---- seeds ----
   int64_t batch0 = 0;
   for (int s = 0; s < num_seed_sets; ++s) {
@@ -607,6 +667,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                        ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
                        disjoint ? n.batch.p : (int64_t*)nullptr, slots);
     PYG_HIP_CHECK(hipGetLastError());
+    if (temporal) {
+      const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
+      if (ss.seed_time || nt) {
+        hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                           ss.seed, ss.seed_time, nt, S, batch0, seed_times);
+        PYG_HIP_CHECK(hipGetLastError());
+      } else {
+        // the reference would index an empty seed_times vector here (undefined behaviour)
+        return fail(PYG_HIP_ERR_INVALID, "Seed time needs to be specified");
+      }
+    }
     // ranks of first occurrences = local ids (duplicates keep their first id)
     const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
     int64_t* tile_buf;
@@ -652,7 +723,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
       PYG_ALLOC(rng_word, int64_t*, c, sizeof(int64_t) * (size_t)F);
       PYG_ALLOC(rng_units, int32_t*, c, sizeof(int32_t) * (size_t)F);
-      CountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, replace};
+      // edge-level time wins over node-level time of the destination type (neighbor_kernel.cpp:746-789)
+      RangeCtx range;
+      range.rowptr = r.rowptr;
+      range.col = r.col;
+      range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
+      range.edge_level = r.edge_time ? 1 : 0;
+      range.last = temporal_last;
+      range.seed_times = seed_times;
+      range.batch = disjoint ? sn.batch.p : nullptr;
+      range.error = err_flag;
+      CountLoad cl{sn.nodes.p, sn.slice_b, range, count, replace};
       CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
       int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, tile_buf + ntiles, stream);
       if (rc != PYG_HIP_OK) return rc;
@@ -660,6 +741,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                                    stream));
       PYG_HIP_CHECK(hipStreamSynchronize(stream));
       const CountAgg tot = *static_cast<CountAgg*>(pinned);
+      if (range.time) {
+        int* herr = reinterpret_cast<int*>(static_cast<char*>(pinned) + 256);
+        PYG_HIP_CHECK(hipMemcpyAsync(herr, err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+        PYG_HIP_CHECK(hipStreamSynchronize(stream));
+        PYG_HIP_REQUIRE(*herr == 0, "Found invalid non-sorted temporal neighborhood");
+      }
       const int64_t E = tot.edges;
       const int64_t end_word = rng.word + tot.tab.dw[rng.units];
       const int end_units = tot.tab.nb[rng.units];
@@ -706,7 +793,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       a.batch = disjoint ? sn.batch.p : nullptr;
       a.begin = sn.slice_b;
       a.frontier = F;
-      a.rowptr = r.rowptr;
+      a.range = range;
       a.col = r.col;
       a.count = count;
       a.replace = replace;
@@ -821,9 +908,10 @@ using namespace pyg_hip;
 
 extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                               const pyg_hip_relation* relations, int num_seed_sets,
-                                              const pyg_hip_seed_set* seeds, int L, int csc,
-                                              int replace, int disjoint, int return_edge_id,
-                                              const pyg_hip_sampler_host* host,
+                                              const pyg_hip_seed_set* seeds,
+                                              const int64_t* const* node_time, int temporal_last,
+                                              int L, int csc, int replace, int disjoint,
+                                              int return_edge_id, const pyg_hip_sampler_host* host,
                                               pyg_hip_sample_result* result, void* stream_) {
   PYG_HIP_REQUIRE(num_node_types > 0 && num_relations >= 0 && num_seed_sets >= 0 && L >= 0,
                   "sampler: bad sizes");
@@ -845,8 +933,8 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   Ctx c;
   c.host = host;
   c.stream = static_cast<hipStream_t>(stream_);
-  int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, L, csc,
-                       replace, disjoint, return_edge_id, c, result);
+  int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time,
+                       temporal_last, L, csc, replace, disjoint, return_edge_id, c, result);
   if (rc != PYG_HIP_OK) {
     (void)hipStreamSynchronize(c.stream);
   }

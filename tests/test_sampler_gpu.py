@@ -33,7 +33,8 @@ def random_csr(n, avg_deg, seed, max_deg=None, zero_frac=0.1):
 
 def run_both(rowptr, col, seed, fanout, manual_seed, **kw):
     torch.manual_seed(manual_seed)
-    out = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seed), fanout, **kw)
+    dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    out = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seed), fanout, **dkw)
     after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
     ref = oracle.neighbor_sample(rowptr, col, np.asarray(seed, dtype=np.int64), fanout, rng_seed=manual_seed, **kw)
     return out, after, ref
@@ -55,14 +56,15 @@ def assert_same(out, after, ref, manual_seed, return_edge_id=True):
     assert after == expect_after
 
 
-SUPPORTED = [c for c in G.CASES if 'node_time' not in c['kwargs'] and 'edge_time' not in c['kwargs']]
+SUPPORTED = list(G.CASES)  # all ten non-biased golden tests of test_neighbor.cpp
 
 
 @pytest.mark.parametrize('case', SUPPORTED, ids=[c['name'] for c in SUPPORTED])
 def test_reference_golden_vectors(case):
     torch.manual_seed(case.get('manual_seed', 0))
+    kw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case['kwargs'].items()}
     row, col, node, eid, nh, eh = sampler.neighbor_sample(dev(case['rowptr']), dev(case['col']), dev(case['seed']),
-                                                          case['num_neighbors'], **case['kwargs'])
+                                                          case['num_neighbors'], **kw)
     assert row.cpu().tolist() == case['row']
     assert col.cpu().tolist() == case['col_out']
     assert node.cpu().tolist() == case['node']
@@ -160,6 +162,47 @@ def test_hetero_random_graph_matches_oracle(csc, disjoint):
     for t in ('a', 'b', 'c'):
         assert torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t]))
         assert out[4][t] == ref[4][t]
+
+
+@pytest.mark.parametrize('level', ['node', 'edge'])
+@pytest.mark.parametrize('strategy', ['uniform', 'last'])
+@pytest.mark.parametrize('replace', [False, True])
+def test_temporal_random_graph_matches_oracle(level, strategy, replace):
+    # neighbourhoods sorted by time, as node_/edge_temporal_sample require (neighbor_kernel.cpp:74-144)
+    rng = np.random.default_rng(8)
+    n = 3000
+    deg = rng.poisson(14, n).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
+    node_time = rng.integers(0, 1000, n, dtype=np.int64)
+    edge_time = rng.integers(0, 1000, col.size, dtype=np.int64)
+    for v in range(n):
+        a, b = rowptr[v], rowptr[v + 1]
+        if level == 'node':
+            order = np.argsort(node_time[col[a:b]], kind='stable')
+            col[a:b] = col[a:b][order]
+        else:
+            edge_time[a:b] = np.sort(edge_time[a:b])
+    seeds = rng.permutation(n)[:48]
+    kw = dict(disjoint=True, replace=replace, temporal_strategy=strategy)
+    if level == 'node':
+        kw['node_time'] = node_time
+        if strategy == 'last':
+            kw['seed_time'] = rng.integers(200, 1000, 48, dtype=np.int64)
+    else:
+        kw['edge_time'] = edge_time
+        kw['seed_time'] = rng.integers(200, 1000, 48, dtype=np.int64)
+    out, after, ref = run_both(rowptr, col, seeds, [6, 4, 3], 77, **kw)
+    assert_same(out, after, ref, 77)
+    assert sum(ref[5]) > 500
+
+
+def test_temporal_unsorted_neighbourhood_raises():
+    rowptr = np.array([0, 3, 3, 3, 3], dtype=np.int64)
+    col = np.array([1, 2, 3], dtype=np.int64)
+    node_time = np.array([9, 5, 1, 3], dtype=np.int64)  # times of the neighbours: 5, 1, 3 -> not sorted
+    with pytest.raises(RuntimeError, match='non-sorted temporal'):
+        sampler.neighbor_sample(dev(rowptr), dev(col), dev([0]), [2], node_time=dev(node_time), disjoint=True)
 
 
 def test_unsupported_modes_fail_loudly():
