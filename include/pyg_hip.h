@@ -121,6 +121,13 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 /* Host services the sampler needs from its caller (the torch binding supplies the PyTorch
  * caching allocator and the global CPU generator, so device memory and torch.manual_seed()
  * behave exactly as for the reference operator). */
+/* State of an at::mt19937 engine (ATen/core/MT19937RNGEngine.h: state_[624], left_, next_). */
+typedef struct {
+  uint32_t state[624];
+  int32_t left;
+  uint32_t next;
+} pyg_hip_mt19937;
+
 typedef struct {
   void* user;
   /* Device allocation on the stream the sampler runs on; NULL on failure. */
@@ -133,6 +140,11 @@ typedef struct {
    * random_(INT64_MIN, INT64_MAX) refills.  Both draw the same serial mt19937 stream, so one
    * random_ over num_blocks*128 elements is equivalent. */
   void (*rng_blocks)(void* user, int64_t* words_host, int64_t num_blocks, int first);
+  /* Optional fast path: the state of the CPU generator's mt19937 engine (in/out, host memory).  If
+   * non-NULL the words are generated ON THE DEVICE by continuing this engine exactly as random_
+   * would (two 32-bit outputs per word, high half first, % (2^64-1) + INT64_MIN), rng_blocks is not
+   * called, and the advanced state is written back before the call returns. */
+  pyg_hip_mt19937* mt19937;
 } pyg_hip_sampler_host;
 
 /* One CSR relation of a (heterogeneous) graph.  src_type / dst_type index `node_types` in the

@@ -9,6 +9,7 @@
 // There is deliberately no CPU registration: a CPU tensor reaches the dispatcher's own
 // "could not run ... with arguments from the 'CPU' backend" error instead of a silent fallback.
 #include <ATen/ATen.h>
+#include <ATen/CPUGeneratorImpl.h>
 #include <ATen/core/dispatch/Dispatcher.h>
 #include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -16,7 +17,9 @@
 #include <torch/autograd.h>
 #include <torch/library.h>
 
+#include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -259,7 +262,20 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
   const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
   SamplerHost host;
   host.stream = current_hip_stream(device.index());
-  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks};
+  // Fast path for the random words: hand the CPU generator's mt19937 engine to the library, which
+  // continues it on the device and returns the advanced state (the generator ends up exactly where
+  // the reference's at::randint / random_ calls would leave it).
+  auto* gen = at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator());
+  std::lock_guard<std::mutex> gen_lock(gen->mutex_);
+  at::mt19937 engine = gen->engine();
+  at::mt19937_data_pod pod = engine.data();
+  pyg_hip_mt19937 mt;
+  static_assert(sizeof(mt.state) == sizeof(uint32_t) * at::MERSENNE_STATE_N, "mt19937 state size");
+  std::memcpy(mt.state, pod.state_.data(), sizeof(mt.state));
+  mt.left = pod.left_;
+  mt.next = pod.next_;
+  const bool engine_ok = engine.is_valid();
+  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks, engine_ok ? &mt : nullptr};
   const int T = num_node_types, E = (int)rels.size();
   std::vector<int64_t*> node_id((size_t)T, nullptr), row((size_t)std::max(E, 1), nullptr),
       col((size_t)std::max(E, 1), nullptr), eid((size_t)std::max(E, 1), nullptr);
@@ -279,6 +295,13 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
                                                 node_time.empty() ? nullptr : node_time.data(),
                                                 temporal_last, L, csc, replace, disjoint, return_edge_id,
                                                 &cb, &res, host.stream);
+  if (engine_ok && rc == PYG_HIP_OK) {
+    std::memcpy(pod.state_.data(), mt.state, sizeof(mt.state));
+    pod.left_ = mt.left;
+    pod.next_ = mt.next;
+    engine.set_data(pod);
+    gen->set_engine(engine);
+  }
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);
   SampleOutput out;

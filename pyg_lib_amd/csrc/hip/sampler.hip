@@ -92,12 +92,18 @@ __host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
   }
 }
 
+// a[m] for a run-time m without dynamic register indexing (which would push the tables to scratch)
+__host__ __device__ inline int32_t sel5(const int32_t (&a)[5], int m) {
+  return m == 0 ? a[0] : (m == 1 ? a[1] : (m == 2 ? a[2] : (m == 3 ? a[3] : a[4])));
+}
+
 __host__ __device__ inline RngTab rng_compose(const RngTab& f, const RngTab& g) {
   RngTab h;
+#pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int m = f.nb[u];
-    h.dw[u] = f.dw[u] + g.dw[m];
-    h.nb[u] = g.nb[m];
+    h.dw[u] = f.dw[u] + sel5(g.dw, m);
+    h.nb[u] = sel5(g.nb, m);
   }
   return h;
 }
@@ -287,8 +293,8 @@ struct CountStore {
   int32_t units0;
   __device__ void operator()(int64_t i, const CountAgg& prefix, const CountAgg&) const {
     edge_off[i] = prefix.edges;
-    rng_word[i] = word0 + prefix.tab.dw[units0];
-    rng_units[i] = prefix.tab.nb[units0];
+    rng_word[i] = word0 + sel5(prefix.tab.dw, units0);
+    rng_units[i] = sel5(prefix.tab.nb, units0);
   }
 };
 
@@ -453,6 +459,96 @@ __global__ void interleave_kernel(const int64_t* __restrict__ batch,
   }
 }
 
+// ---- device-side mt19937 (continues the caller's CPU engine) ---------------------------------------
+// The reference draws its words with at::randint / Tensor.random_ on torch's CPU generator, i.e.
+// at::mt19937 (ATen/core/MT19937RNGEngine.h) + random64() = (hi << 32 | lo) of two consecutive
+// outputs + `% (2^64 - 1) + INT64_MIN` (ATen/core/DistributionsHelper.h:40-56).  Generating the
+// ~2e5 words of a products-scale batch on the host costs more than all sampling kernels together, so
+// the engine state (624 words + left/next) is shipped to the device, one wave runs the recurrence
+// with the state held in registers (element j lives in lane j & 63, register j >> 6; the twist of
+// register r reads old registers >= r and already-updated registers < r, exactly the in-place order
+// of mt19937_engine::next_state), and the advanced state is handed back to the caller afterwards.
+struct MtDev {
+  uint32_t state[624];
+  int32_t left;
+  uint32_t next;
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
+  return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Emits `n32` consecutive 32-bit engine outputs as the halves of 64-bit words out[0 .. n32/2):
+// output 2k is the HIGH half of word k (CPUGeneratorImpl::random64), and INT64_MIN is folded in by
+// flipping the top bit; the (2^-64) case x == 2^64-1 -> 0 is patched by mt_fixup_kernel.
+//
+// mt19937_engine::next_state() is the linear recurrence x[n+624] = x[n+397] ^ twist(x[n], x[n+1])
+// evaluated in place one 624-array at a time; element n only needs values at least 227 positions
+// back, so one workgroup produces 227 new values per step (one barrier each) in a 1024-word
+// circular LDS window -- the same numbers in the same order, ~4x fewer dependent steps than a
+// per-array update.  On exit the engine holds exactly the array torch would hold (the array that
+// contains the last consumed output, fully regenerated) with matching left/next.
+constexpr int kMtStep = 227;
+
+__global__ __launch_bounds__(256) void mt_generate_kernel(MtDev* st, uint32_t* out32, int64_t n32) {
+  __shared__ uint32_t x[1024];  // x-stream index n lives at x[n & 1023]; x[0..623] = current array
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 624; i += 256) x[i] = st->state[i];
+  const int64_t left0 = st->left;
+  const int64_t next0 = st->next;
+  __syncthreads();
+  auto emit = [&](int64_t o, uint32_t raw) {
+    const uint32_t y = mt_temper(raw);
+    // little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
+    if ((o & 1) == 0) out32[o + 1] = y ^ 0x80000000u;
+    else out32[o - 1] = y;
+  };
+  const int64_t a0 = left0 - 1;  // outputs still available in the current array, from index next0
+  const int64_t take0 = a0 < n32 ? a0 : n32;
+  for (int64_t q = tid; q < take0; q += 256) emit(q, x[next0 + q]);
+  if (n32 <= a0) {
+    if (tid == 0) {
+      st->left = (int32_t)(left0 - n32);
+      st->next = (uint32_t)(next0 + n32);
+    }
+    return;
+  }
+  const int64_t mp = n32 - a0;           // outputs taken from regenerated arrays
+  const int64_t k = (mp + 623) / 624;    // number of regenerations
+  const int64_t gen_end = 624 * (k + 1);  // produce x[624 .. gen_end)
+  for (int64_t n0 = 624; n0 < gen_end; n0 += kMtStep) {
+    const int64_t n = n0 + tid;
+    if (tid < kMtStep && n < gen_end) {
+      const uint32_t v = x[(n - 227) & 1023] ^ mt_twist(x[(n - 624) & 1023], x[(n - 623) & 1023]);
+      x[n & 1023] = v;  // slot of x[n - 1024]: no longer needed by this or any later step
+      const int64_t o = a0 + (n - 624);
+      if (o < n32) emit(o, v);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 624; i += 256) st->state[i] = x[(624 * k + i) & 1023];
+  if (tid == 0) {
+    const int64_t nx = mp - 624 * (k - 1);
+    st->next = (uint32_t)nx;
+    st->left = (int32_t)(625 - nx);
+  }
+}
+
+// uniform_int_from_to: x % (2^64 - 1) differs from x only for x == 2^64 - 1 (-> 0); the generator
+// already added INT64_MIN by flipping bit 63, so that word reads 0x7fff...f and must become 0x8000...0.
+__global__ void mt_fixup_kernel(u64* words, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && words[i] == 0x7fffffffffffffffull) words[i] = 0x8000000000000000ull;
+}
+
 // ---- host driver -----------------------------------------------------------------------------------
 struct Ctx {
   const pyg_hip_sampler_host* host;
@@ -566,6 +662,7 @@ struct RngHost {
   int64_t dev_cap_blocks = 0;
   int64_t word = 0;           // engine state: linear word index
   int units = 4;              //               16-bit units left in that word
+  MtDev* mt = nullptr;        // device copy of the caller's mt19937 engine (fast path) or nullptr
 };
 
 int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
@@ -583,6 +680,17 @@ int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
     r.dev_cap_blocks = ncap;
   }
   const int64_t nnew = need_blocks - r.blocks;
+  if (r.mt) {
+    // continue the caller's engine on the device: no host work, no synchronisation
+    u64* dst = r.dev + r.blocks * 128;
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(256), 0, c.stream, r.mt,
+                       reinterpret_cast<uint32_t*>(dst), nnew * 256);
+    hipLaunchKernelGGL(mt_fixup_kernel, dim3((unsigned)((nnew * 128 + 255) / 256)), dim3(256), 0, c.stream,
+                       dst, nnew * 128);
+    PYG_HIP_CHECK(hipGetLastError());
+    r.blocks = need_blocks;
+    return PYG_HIP_OK;
+  }
   std::vector<int64_t> tmp((size_t)nnew * 128);
   c.host->rng_blocks(c.host->user, tmp.data(), nnew, r.blocks == 0 ? 1 : 0);
   // pageable -> device; the vector dies at scope exit, so make the copy synchronous
@@ -623,6 +731,14 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (rc != PYG_HIP_OK) return rc;
   }
 
+  if (c.host->mt19937) {
+    static_assert(sizeof(MtDev) == sizeof(pyg_hip_mt19937), "engine layouts must match");
+    PYG_HIP_REQUIRE(c.host->mt19937->left > 0 && c.host->mt19937->left <= 624 && c.host->mt19937->next <= 624,
+                    "sampler: invalid mt19937 engine state");
+    PYG_ALLOC(rng.mt, MtDev*, c, sizeof(MtDev));
+    PYG_HIP_CHECK(hipMemcpyAsync(rng.mt, c.host->mt19937, sizeof(MtDev), hipMemcpyHostToDevice, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));  // the host struct may be pageable
+  }
   // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
   {
     int rc = rng_ensure(c, rng, 0);
@@ -896,6 +1012,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     for (int l = 0; l < L; ++l) res->edges_per_hop_host[(size_t)e * L + l] = st.edges_per_hop[(size_t)l];
   }
   res->rng_blocks = rng.blocks;
+  if (rng.mt)  // hand the advanced engine back
+    PYG_HIP_CHECK(hipMemcpyAsync(c.host->mt19937, rng.mt, sizeof(MtDev), hipMemcpyDeviceToHost, stream));
   PYG_HIP_CHECK(hipStreamSynchronize(stream));
   pt.lap(7);
   return PYG_HIP_OK;
@@ -915,7 +1033,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
                                               pyg_hip_sample_result* result, void* stream_) {
   PYG_HIP_REQUIRE(num_node_types > 0 && num_relations >= 0 && num_seed_sets >= 0 && L >= 0,
                   "sampler: bad sizes");
-  PYG_HIP_REQUIRE(host && host->alloc && host->free && host->rng_blocks,
+  PYG_HIP_REQUIRE(host && host->alloc && host->free && (host->rng_blocks || host->mt19937),
                   "sampler: host callbacks missing");
   PYG_HIP_REQUIRE(result && result->node_id && result->num_nodes && result->nodes_per_hop_host &&
                       (num_relations == 0 ||

@@ -17,24 +17,46 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
+// Shuffle any trivially copyable T up by `delta` lanes, 4 bytes at a time.
+template <typename T>
+__device__ __forceinline__ T shfl_up_any(const T& v, int delta) {
+  static_assert(sizeof(T) % 4 == 0, "4-byte multiples only");
+  T out;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = (uint32_t)__shfl_up((int)src[i], delta);
+  return out;
+}
+
+// Ordered exclusive scan across the 256 threads of a block: wave64 shuffle scan, then the four wave
+// totals through LDS.  `lds` needs 8 entries.  Valid for any associative operator (not necessarily
+// commutative): lane order is thread order.
 template <typename T, typename Op>
 __device__ T block_exclusive(T agg, T* lds, Op op, T* total) {
   const int tid = threadIdx.x;
-  T* a = lds;
-  T* b = lds + kScanThreads;
-  a[tid] = agg;
-  __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {
-    T v = a[tid];
-    if (tid >= d) v = op(a[tid - d], v);
-    b[tid] = v;
-    __syncthreads();
-    T* tmp = a;
-    a = b;
-    b = tmp;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  T incl = agg;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T up = shfl_up_any(incl, d);
+    if (lane >= d) incl = op(up, incl);
   }
-  const T excl = tid ? a[tid - 1] : Op::identity();
-  *total = a[kScanThreads - 1];
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  T before = Op::identity();
+  T all = Op::identity();
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    const T t = lds[w];
+    if (w < wave) before = op(before, t);
+    all = op(all, t);
+  }
+  T excl = shfl_up_any(incl, 1);
+  if (lane == 0) excl = Op::identity();
+  excl = op(before, excl);
+  *total = all;
   __syncthreads();
   return excl;
 }
@@ -43,7 +65,7 @@ __device__ T block_exclusive(T agg, T* lds, Op op, T* total) {
 template <typename T, typename Op, typename Load>
 __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, int64_t n,
                                                                    T* __restrict__ tile_agg) {
-  __shared__ T lds[2 * kScanThreads];
+  __shared__ T lds[8];
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   T agg = Op::identity();
@@ -60,7 +82,7 @@ template <typename T, typename Op>
 __global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(T* __restrict__ tile_agg,
                                                                   int64_t ntiles,
                                                                   T* __restrict__ total_out) {
-  __shared__ T lds[2 * kScanThreads];
+  __shared__ T lds[8];
   Op op;
   T carry = Op::identity();
   for (int64_t c0 = 0; c0 < ntiles; c0 += kScanThreads) {
@@ -79,7 +101,7 @@ template <typename T, typename Op, typename Load, typename Store>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Store store, int64_t n,
                                                                   const T* __restrict__ tile_prefix,
                                                                   T* __restrict__ total_out) {
-  __shared__ T lds[2 * kScanThreads];
+  __shared__ T lds[8];
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   T v[kScanItems];
