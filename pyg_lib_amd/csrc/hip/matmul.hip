@@ -368,13 +368,22 @@ __device__ __forceinline__ u32x4 pack8(f16_t, const float* v) {
   return o;
 }
 
+__device__ __forceinline__ u32x4 pack_chunk(bf16_t t, const float* v) { return pack8(t, v); }
+__device__ __forceinline__ u32x4 pack_chunk(f16_t t, const float* v) { return pack8(t, v); }
+__device__ __forceinline__ u32x4 pack_chunk(float, const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __builtin_bit_cast(uint32_t, v[i]);
+  return o;
+}
+
 template <typename T, int K, int MC, int NW, int FLAGS = 3>
 __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
     const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk) {
   constexpr bool NT_LOAD = (FLAGS & 1) != 0;
   constexpr bool NT_STORE = (FLAGS & 2) != 0;
-  constexpr int SZ = 2;
-  static_assert(Elem<T>::kSize == 2, "16-bit element types only");
+  constexpr int SZ = Elem<T>::kSize;
+  constexpr int EPC = Elem<T>::kPerChunk;  // elements per 16-byte chunk
   constexpr int NT = MC / 32;
   constexpr int LDW = K * SZ + 16;
   constexpr int BM = NW * 32;
@@ -495,22 +504,30 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       const char* w = d.w;
       const int M = d.m;
       if (!d.trans) {
-        constexpr int CW = MC / 8;
+        constexpr int CW = MC / EPC;
         for (int idx = tid; idx < K * CW; idx += NW * 64) {
           const int k = idx / CW;
-          const int cc = (idx - k * CW) * 8;
+          const int cc = (idx - k * CW) * EPC;
           const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * M + col0 + cc) * SZ);
+          if constexpr (SZ == 2) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const uint16_t sv = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
-            *reinterpret_cast<uint16_t*>(smem + (cc + e) * LDW + k * 2) = sv;
+            for (int e = 0; e < 8; ++e) {
+              const uint16_t sv = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+              *reinterpret_cast<uint16_t*>(smem + (cc + e) * LDW + k * 2) = sv;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t sv = v[e];
+              *reinterpret_cast<uint32_t*>(smem + (cc + e) * LDW + k * 4) = sv;
+            }
           }
         }
       } else {
-        constexpr int CW = K / 8;
+        constexpr int CW = K / EPC;
         for (int idx = tid; idx < MC * CW; idx += NW * 64) {
           const int c = idx / CW;
-          const int kk = (idx - c * CW) * 8;
+          const int kk = (idx - c * CW) * EPC;
           const u32x4 v =
               *reinterpret_cast<const u32x4*>(w + ((int64_t)(col0 + c) * K + kk) * SZ);
           *reinterpret_cast<u32x4*>(smem + c * LDW + kk * SZ) = v;
@@ -569,9 +586,9 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
           for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int c = NO * h + 2 * tt + j;
-          *reinterpret_cast<u32x4*>(stage + (x * CPO + (c ^ (x & OM))) * 16) = pack8(T{}, v + 8 * j);
+        for (int j = 0; j < SZ; ++j) {  // 16 values = SZ chunks of EPC elements
+          const int c = NO * h + SZ * tt + j;
+          *reinterpret_cast<u32x4*>(stage + (x * CPO + (c ^ (x & OM))) * 16) = pack_chunk(T{}, v + EPC * j);
         }
       }
 #pragma unroll
@@ -745,9 +762,9 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   constexpr int wbytes = MC * (K * SZ + 16);
   constexpr int stage = 32 * (K > MC ? K : MC) * SZ;
   constexpr int lds_v2 = wbytes + NW * stage;
-  // 16-bit types stream through the LDS-staged kernel (coalesced HBM access); fp32 is bound by
-  // the f32 MFMA rate, so the direct-fragment kernel is kept for it.
-  constexpr bool use_v2 = (SZ == 2) && (lds_v2 <= 160 * 1024);
+  // Everything that fits streams through the LDS-staged kernel (fully coalesced HBM access); the
+  // direct-fragment kernel remains for fp32 K=256, whose weight image + stages exceed 160 KB of LDS.
+  constexpr bool use_v2 = lds_v2 <= 160 * 1024;
   constexpr int lds = use_v2 ? lds_v2 : wbytes;
   const void* kern;
   if constexpr (use_v2) kern = reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW>);
