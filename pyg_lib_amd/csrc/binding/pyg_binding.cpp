@@ -125,6 +125,18 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
   std::vector<Tensor> keep;
   keep.reserve(2 * G);
   outs.reserve(G);
+  // One allocation for all outputs (the reference makes G of them, matmul_kernel.cpp:296-298); each
+  // output is a 16-byte aligned view into it.
+  const int64_t elt = (int64_t)input[0].element_size();
+  const int64_t align = 16 / elt > 0 ? 16 / elt : 1;
+  std::vector<int64_t> offs(G);
+  int64_t total = 0;
+  for (size_t i = 0; i < G; ++i) {
+    offs[i] = total;
+    const int64_t n = input[i].size(0) * other[i].size(-1);
+    total += (n + align - 1) / align * align;
+  }
+  auto pool = at::empty({std::max<int64_t>(total, 1)}, input[0].options());
   for (size_t i = 0; i < G; ++i) {
     auto a = input[i].contiguous();
     Tensor o = other[i];
@@ -134,7 +146,7 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
       if (o.t().is_contiguous()) trans = 1;
       else o = o.contiguous();
     }
-    auto out = a.new_empty({a.size(0), other[i].size(-1)});
+    auto out = pool.narrow(0, offs[i], a.size(0) * other[i].size(-1)).view({a.size(0), other[i].size(-1)});
     groups[i].input = a.data_ptr();
     groups[i].other = o.data_ptr();
     groups[i].out = out.data_ptr();

@@ -152,9 +152,16 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
     }
     return std::make_tuple(out, arg);
   }
+  // scratch for the sort-based sum (large unsorted float scatters only; see pyg_hip_scatter)
+  Tensor ws;
+  if (op == OP_SUM && !coo && l.B == 1 && l.isk == 0 && l.ise == 1 && l.E >= (1 << 15) &&
+      at::isFloatingType(src_c.scalar_type()) && l.K * (int64_t)src_c.element_size() >= 64)
+    ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.E)}, src_c.options().dtype(at::kByte));
   check_status(pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk,
                                out.data_ptr(), minmax ? arg.data_ptr<int64_t>() : nullptr,
-                               init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N, stream));
+                               init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N, coo ? 1 : 0,
+                               ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0,
+                               stream));
   return std::make_tuple(out, arg);
 }
 

@@ -72,4 +72,10 @@ struct PinnedStage {
 };
 PinnedStage& pinned_stage();
 
+// int64 key sort shared between index_sort and the sort-based scatter (index_sort.hip).  `max_value`
+// bounds the (non-negative) keys, so no device->host read is needed.
+size_t index_sort_ws_bytes_i64(int64_t n);
+int index_sort_i64(const int64_t* keys, int64_t n, int64_t max_value, int64_t* keys_out, int64_t* idx_out,
+                   void* ws, size_t ws_bytes, hipStream_t stream);
+
 }  // namespace pyg_hip

@@ -284,6 +284,14 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
 }
 
 }  // namespace
+
+size_t index_sort_ws_bytes_i64(int64_t n) { return ws_bytes(n < 0 ? 0 : n, sizeof(int64_t)); }
+
+int index_sort_i64(const int64_t* keys, int64_t n, int64_t max_value, int64_t* keys_out, int64_t* idx_out,
+                   void* ws, size_t ws_size, hipStream_t stream) {
+  return run_sort<int64_t>(keys, n, max_value, 1, keys_out, idx_out, ws, ws_size, stream);
+}
+
 }  // namespace pyg_hip
 
 using namespace pyg_hip;

@@ -281,6 +281,11 @@ struct Vec<float> {
   __device__ static void flush(float* dst, const float* a) {
     for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, a[i]);
   }
+  __device__ static void add_plain(float* dst, const float* a) {  // rows owned by this thread only
+    float4 v = *reinterpret_cast<float4*>(dst);
+    v.x += a[0]; v.y += a[1]; v.z += a[2]; v.w += a[3];
+    *reinterpret_cast<float4*>(dst) = v;
+  }
 };
 template <>
 struct Vec<bf16_t> {
@@ -300,6 +305,17 @@ struct Vec<bf16_t> {
           (__attribute__((address_space(1))) bf16x2*)(dst + 2 * i), p);
     }
   }
+  __device__ static void add_plain(bf16_t* dst, const float* a) {
+    float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unpack(*reinterpret_cast<const u32x4*>(dst), cur);
+    u32x4 o;
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)(cur[2 * i] + a[2 * i]));
+      const uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)(cur[2 * i + 1] + a[2 * i + 1]));
+      o[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(dst) = o;
+  }
 };
 template <>
 struct Vec<f16_t> {
@@ -318,40 +334,60 @@ struct Vec<f16_t> {
           (__attribute__((address_space(1))) f16x2*)(dst + 2 * i), p);
     }
   }
+  __device__ static void add_plain(f16_t* dst, const float* a) {
+    float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unpack(*reinterpret_cast<const u32x4*>(dst), cur);
+    u32x4 o;
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)(cur[2 * i] + a[2 * i]));
+      const uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)(cur[2 * i + 1] + a[2 * i + 1]));
+      o[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(dst) = o;
+  }
 };
 
-constexpr int kRowsPerThread = 8;
-
 // Requires K % Vec<T>::N == 0, 16-byte aligned src/out, index constant along k (isk == 0).
-template <typename T>
+// SORTED: the index is ascending along e (segment_*_coo, or scatter through a sort permutation).  Then
+// a thread owns 32 consecutive positions, every run strictly inside its chunk belongs to it alone and is
+// added with a plain 16-byte read-modify-write; only the first and last run of a chunk (which may
+// continue in the neighbouring chunks) use atomics.  Unsorted input: 8 positions, every flush atomic.
+// perm (optional): source row of sorted position e (scatter via index_sort); index is then the SORTED key.
+template <typename T, bool SORTED>
 __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restrict__ src,
-                                                              const int64_t* __restrict__ index, T* out,
+                                                              const int64_t* __restrict__ index,
+                                                              const int64_t* __restrict__ perm, T* out,
                                                               Shape s) {
   constexpr int VN = Vec<T>::N;
-  const int64_t kv = s.K / VN;                                  // 16-byte slices per row
-  const int64_t chunks = (s.E + kRowsPerThread - 1) / kRowsPerThread;
+  constexpr int R = SORTED ? 32 : 8;
+  const int64_t kv = s.K / VN;  // 16-byte slices per row
+  const int64_t chunks = (s.E + R - 1) / R;
   const int64_t total = s.B * chunks * kv;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = t % kv;
     const int64_t ch = (t / kv) % chunks;
     const int64_t b = t / (kv * chunks);
-    const int64_t e0 = ch * kRowsPerThread;
-    const int64_t e1 = min(e0 + kRowsPerThread, s.E);
+    const int64_t e0 = ch * R;
+    const int64_t e1 = min(e0 + R, s.E);
     float acc[VN];
 #pragma unroll
     for (int i = 0; i < VN; ++i) acc[i] = 0.f;
     int64_t cur = index[b * s.isb + e0 * s.ise];
-    const T* row = src + (b * s.E + e0) * s.K + c * VN;
-    for (int64_t e = e0; e < e1; ++e, row += s.K) {
+    bool first = true;
+    for (int64_t e = e0; e < e1; ++e) {
       const int64_t idx = index[b * s.isb + e * s.ise];
       if (idx != cur) {
-        Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
+        T* dst = out + (b * s.N + cur) * s.K + c * VN;
+        if (SORTED && !first) Vec<T>::add_plain(dst, acc);
+        else Vec<T>::flush(dst, acc);
+        first = false;
 #pragma unroll
         for (int i = 0; i < VN; ++i) acc[i] = 0.f;
         cur = idx;
       }
-      Vec<T>::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row)), acc);
+      const int64_t srow = perm ? perm[e] : (b * s.E + e);
+      Vec<T>::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + srow * s.K + c * VN)), acc);
     }
     Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
   }
@@ -395,9 +431,14 @@ inline unsigned grid_for(int64_t n, int threads = 256) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// workspace of the sort-based scatter: sorted keys + permutation + index_sort's own workspace
+inline size_t scatter_sort_ws_bytes(int64_t E) {
+  return 2 * align_up(sizeof(int64_t) * (size_t)(E > 0 ? E : 1), 256) + index_sort_ws_bytes_i64(E);
+}
+
 template <typename T>
 int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int64_t* arg, const void* init_,
-                const Shape& s, hipStream_t stream) {
+                const Shape& s, int sorted, void* ws, size_t ws_bytes, hipStream_t stream) {
   const T* src = static_cast<const T*>(src_);
   T* out = static_cast<T*>(out_);
   const T* init = static_cast<const T*>(init_);
@@ -409,9 +450,37 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
     if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
                   std::is_same<T, f16_t>::value) {
       if (s.isk == 0 && s.K % Vec<T>::N == 0 && aligned16(src) && aligned16(out)) {
-        const int64_t threads = s.B * ((s.E + kRowsPerThread - 1) / kRowsPerThread) * (s.K / Vec<T>::N);
-        hipLaunchKernelGGL((scatter_sum_vec_kernel<T>), dim3(grid_for(threads)), dim3(256), 0, stream, src,
-                           index, out, s);
+        if (sorted) {
+          const int64_t threads = s.B * ((s.E + 31) / 32) * (s.K / Vec<T>::N);
+          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
+                             src, index, (const int64_t*)nullptr, out, s);
+          PYG_HIP_CHECK(hipGetLastError());
+          return PYG_HIP_OK;
+        }
+        // Unsorted index, rows of >= 64 bytes, one index vector (B == 1): sort the E indices once
+        // (3-4 radix passes over 16 E bytes) and reduce runs through the permutation -- ~E/16 atomics
+        // instead of E, see DESIGN.md 2.4.
+        const size_t need = scatter_sort_ws_bytes(s.E);
+        if (s.B == 1 && s.ise == 1 && s.E >= (1 << 15) && s.K * (int64_t)sizeof(T) >= 64 && ws && ws_bytes >= need) {
+          char* w = static_cast<char*>(ws);
+          int64_t* keys = reinterpret_cast<int64_t*>(w);
+          int64_t* perm = reinterpret_cast<int64_t*>(w + align_up(sizeof(int64_t) * (size_t)s.E, 256));
+          void* sws = w + 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256);
+          int rc = index_sort_i64(index, s.E, s.N > 0 ? s.N - 1 : 0, keys, perm, sws,
+                                  ws_bytes - 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256), stream);
+          if (rc != PYG_HIP_OK) return rc;
+          Shape ss = s;
+          ss.isb = 0;
+          ss.ise = 1;
+          const int64_t threads = ((s.E + 31) / 32) * (s.K / Vec<T>::N);
+          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
+                             src, (const int64_t*)keys, (const int64_t*)perm, out, ss);
+          PYG_HIP_CHECK(hipGetLastError());
+          return PYG_HIP_OK;
+        }
+        const int64_t threads = s.B * ((s.E + 7) / 8) * (s.K / Vec<T>::N);
+        hipLaunchKernelGGL((scatter_sum_vec_kernel<T, false>), dim3(grid_for(threads)), dim3(256), 0, stream,
+                           src, index, (const int64_t*)nullptr, out, s);
         PYG_HIP_CHECK(hipGetLastError());
         return PYG_HIP_OK;
       }
@@ -495,9 +564,12 @@ using namespace pyg_hip;
 
 extern "C" {
 
+size_t pyg_hip_scatter_workspace_size(int64_t E) { return scatter_sort_ws_bytes(E < 0 ? 0 : E); }
+
 int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index, int64_t index_stride_b,
                     int64_t index_stride_e, int64_t index_stride_k, void* out, int64_t* arg_out,
-                    const void* out_init, int64_t B, int64_t E, int64_t K, int64_t N, void* stream_) {
+                    const void* out_init, int64_t B, int64_t E, int64_t K, int64_t N, int index_sorted,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, "scatter: negative size");
   if (B * E * K == 0) {
@@ -510,7 +582,8 @@ int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index, in
   }
   PYG_HIP_REQUIRE(src && index && out, "scatter: NULL tensor");
   Shape s{B, E, K, N, index_stride_b, index_stride_e, index_stride_k};
-  PYG_DISPATCH_ALL(dtype, (run_scatter<scalar_t>(op, src, index, out, arg_out, out_init, s, stream)));
+  PYG_DISPATCH_ALL(dtype, (run_scatter<scalar_t>(op, src, index, out, arg_out, out_init, s, index_sorted, workspace,
+                                                 workspace_bytes, stream)));
 }
 
 int pyg_hip_fill_reduce_identity(int op, int dtype, void* out, int64_t n, void* stream_) {
