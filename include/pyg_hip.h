@@ -214,6 +214,25 @@ PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relat
                                                const pyg_hip_sampler_host* host,
                                                pyg_hip_sample_result* result, void* stream);
 
+/*
+ * One-hop sampling WITHOUT relabelling for PyG's distributed sampler.
+ * Replaces pyg::dist_neighbor_sample (schema pyg_lib/csrc/sampler/neighbor.cpp:148-153; CPU kernel
+ * sampler/cpu/neighbor_kernel.cpp:957-978, `distributed` flag :296-303,386-388,446-447).
+ *   node_id   -> S + E ids (seeds first, then every sampled destination, duplicates kept;
+ *                [S+E, 2] (batch, node) pairs when disjoint), from host->alloc
+ *   edge_id   -> E sampled edge ids, from host->alloc
+ *   cumsum_host  caller array of S + 1 entries: [S, size after seed 0, size after seed 1, ...]
+ * Random words, temporal arguments and error behaviour as in pyg_hip_hetero_neighbor_sample.
+ */
+PYG_HIP_API int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col,
+                                             const int64_t* seed, int64_t num_seed,
+                                             int64_t num_neighbors, const int64_t* node_time,
+                                             const int64_t* edge_time, const int64_t* seed_time,
+                                             int temporal_last, int replace, int disjoint,
+                                             const pyg_hip_sampler_host* host, int64_t** node_id,
+                                             int64_t** edge_id, int64_t* num_edges,
+                                             int64_t* cumsum_host, void* stream);
+
 /* ---- index_sort ---------------------------------------------------------------------------- */
 
 PYG_HIP_API size_t pyg_hip_index_sort_workspace_size(int dtype, int64_t n);

@@ -31,6 +31,9 @@
  * uniform_ and are outside this path) -- see tests/golden/sampler_reference_vectors.py.
  *
  * Biased sampling (edge_weight) is not restated.
+ *
+ * dist_neighbor_sample (neighbor_kernel.cpp:957-978, the `distributed` template flag :296-303,
+ * 386-388,446-447): one hop, no relabelling -- see oracle_dist_neighbor_sample at the end.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -554,4 +557,79 @@ oracle_result* oracle_neighbor_sample(const int64_t* rowptr, const int64_t* col,
   return oracle_hetero_neighbor_sample(1, 1, &zero, &zero, rp, cl, 1, &zero, sd, &S,
                                        num_neighbors, L, nt, et, st, 0, replace, disjoint,
                                        temporal_last, rng_seed, fill, user, status);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * dist_neighbor_sample (neighbor_kernel.cpp:957-978): ONE hop over the seeds with the same per-node
+ * sampling, but destinations are appended WITHOUT the mapper (no dedup, :296-303), only node ids and
+ * edge ids are returned, plus cumsum_neighbors_per_node = [S, size after seed 0, size after seed 1, ...]
+ * (:386-388,446-447).  Pinned by the golden vectors of test/csrc/sampler/test_dist_neighbor.cpp.
+ *
+ * out_nodes: [(S+E)] or [(S+E), 2] when disjoint; out_edges: [E]; cumsum: [S+1].
+ * Returns E (>= 0) or -1; call with out_* == NULL first to size the buffers.
+ * ------------------------------------------------------------------------------------------- */
+int64_t oracle_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S,
+                                    int64_t count, const int64_t* node_time, const int64_t* edge_time,
+                                    const int64_t* seed_time, int replace, int disjoint, int temporal_last,
+                                    uint64_t rng_seed, int64_t* out_nodes, int64_t* out_edges, int64_t* cumsum,
+                                    int64_t* rng_blocks) {
+  engine_t eng;
+  engine_init(&eng, rng_seed, NULL, NULL);
+  tracker_t trk = {0, 0};
+  vec64 eids = {0, 0, 0}, nodes = {0, 0, 0}, batches = {0, 0, 0};
+  int64_t rc = 0;
+  if (cumsum) cumsum[0] = S;
+  for (int64_t i = 0; i < S && rc == 0; ++i) {
+    const int64_t v = seed[i];
+    int64_t rs = rowptr[v], re = rowptr[v + 1];
+    int skip = (re - rs == 0 || count == 0);
+    if (!skip && (node_time || edge_time)) {
+      const int64_t st = seed_time ? seed_time[i] : node_time[seed[i]];
+      if (edge_time) re = ub_edge_time(rs, re, st, edge_time);
+      else re = ub_node_time(col, rs, re, st, node_time);
+      if (temporal_last && count >= 0 && re - count > rs) rs = re - count;
+      if (re - rs == 0) skip = 1;
+      else if (re - rs > 1) {
+        if (edge_time ? !(edge_time[rs] <= edge_time[re - 1]) : !(node_time[col[rs]] <= node_time[col[re - 1]]))
+          rc = -1;
+      }
+    }
+    if (!skip && rc == 0) {
+      const int64_t pop = re - rs;
+      if (count < 0 || (!replace && count >= pop)) {
+        for (int64_t e = rs; e < re; ++e) { vpush(&eids, e); vpush(&nodes, col[e]); vpush(&batches, i); }
+      } else if (replace) {
+        for (int64_t j = 0; j < count; ++j) {
+          const int64_t e = rs + (int64_t)engine_next(&eng, (uint64_t)pop);
+          vpush(&eids, e); vpush(&nodes, col[e]); vpush(&batches, i);
+        }
+      } else {
+        tracker_reset(&trk, count);
+        for (int64_t j = pop - count; j < pop; ++j) {
+          int64_t rnd = (int64_t)engine_next(&eng, (uint64_t)(j + 1));
+          if (!tracker_try_insert(&trk, rnd)) { rnd = j; tracker_try_insert(&trk, j); }
+          vpush(&eids, rs + rnd); vpush(&nodes, col[rs + rnd]); vpush(&batches, i);
+        }
+      }
+    }
+    if (cumsum) cumsum[i + 1] = S + nodes.n;
+  }
+  const int64_t E = nodes.n;
+  if (rc == 0 && out_nodes) {
+    for (int64_t i = 0; i < S; ++i) {
+      if (disjoint) { out_nodes[2 * i] = i; out_nodes[2 * i + 1] = seed[i]; }
+      else out_nodes[i] = seed[i];
+    }
+    for (int64_t j = 0; j < E; ++j) {
+      if (disjoint) { out_nodes[2 * (S + j)] = batches.d[j]; out_nodes[2 * (S + j) + 1] = nodes.d[j]; }
+      else out_nodes[S + j] = nodes.d[j];
+    }
+  }
+  if (rc == 0 && out_edges) memcpy(out_edges, eids.d, sizeof(int64_t) * (size_t)E);
+  if (rng_blocks) *rng_blocks = eng.blocks;
+  free(eids.d);
+  free(nodes.d);
+  free(batches.d);
+  free(trk.slot);
+  return rc == 0 ? E : -1;
 }

@@ -249,6 +249,34 @@ static void host_rng_blocks(void* user, int64_t* words, int64_t num_blocks, int 
   }
 }
 
+// Lends the default CPU generator's mt19937 engine to the library for the duration of one call and
+// installs the advanced state afterwards (see pyg_hip_sampler_host::mt19937).
+struct EngineLoan {
+  at::CPUGeneratorImpl* gen;
+  std::unique_lock<std::mutex> lock;
+  at::mt19937 engine;
+  at::mt19937_data_pod pod;
+  pyg_hip_mt19937 mt;
+  bool ok;
+  EngineLoan()
+      : gen(at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator())),
+        lock(gen->mutex_), engine(gen->engine()), pod(engine.data()), ok(engine.is_valid()) {
+    static_assert(sizeof(mt.state) == sizeof(uint32_t) * at::MERSENNE_STATE_N, "mt19937 state size");
+    std::memcpy(mt.state, pod.state_.data(), sizeof(mt.state));
+    mt.left = pod.left_;
+    mt.next = pod.next_;
+  }
+  pyg_hip_mt19937* ptr() { return ok ? &mt : nullptr; }
+  void commit() {
+    if (!ok) return;
+    std::memcpy(pod.state_.data(), mt.state, sizeof(mt.state));
+    pod.left_ = mt.left;
+    pod.next_ = mt.next;
+    engine.set_data(pod);
+    gen->set_engine(engine);
+  }
+};
+
 static Tensor adopt(int64_t* ptr, at::IntArrayRef sizes, const at::TensorOptions& opts) {
   return at::from_blob(
       ptr, sizes, [](void* p) { alloc::raw_delete(p); }, opts);
@@ -274,20 +302,10 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
   const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
   SamplerHost host;
   host.stream = current_hip_stream(device.index());
-  // Fast path for the random words: hand the CPU generator's mt19937 engine to the library, which
-  // continues it on the device and returns the advanced state (the generator ends up exactly where
-  // the reference's at::randint / random_ calls would leave it).
-  auto* gen = at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator());
-  std::lock_guard<std::mutex> gen_lock(gen->mutex_);
-  at::mt19937 engine = gen->engine();
-  at::mt19937_data_pod pod = engine.data();
-  pyg_hip_mt19937 mt;
-  static_assert(sizeof(mt.state) == sizeof(uint32_t) * at::MERSENNE_STATE_N, "mt19937 state size");
-  std::memcpy(mt.state, pod.state_.data(), sizeof(mt.state));
-  mt.left = pod.left_;
-  mt.next = pod.next_;
-  const bool engine_ok = engine.is_valid();
-  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks, engine_ok ? &mt : nullptr};
+  // Fast path for the random words: the CPU generator's mt19937 engine is continued on the device
+  // (the generator ends up exactly where the reference's at::randint / random_ calls would leave it).
+  EngineLoan loan;
+  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks, loan.ptr()};
   const int T = num_node_types, E = (int)rels.size();
   std::vector<int64_t*> node_id((size_t)T, nullptr), row((size_t)std::max(E, 1), nullptr),
       col((size_t)std::max(E, 1), nullptr), eid((size_t)std::max(E, 1), nullptr);
@@ -307,13 +325,7 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
                                                 node_time.empty() ? nullptr : node_time.data(),
                                                 temporal_last, L, csc, replace, disjoint, return_edge_id,
                                                 &cb, &res, host.stream);
-  if (engine_ok && rc == PYG_HIP_OK) {
-    std::memcpy(pod.state_.data(), mt.state, sizeof(mt.state));
-    pod.left_ = mt.left;
-    pod.next_ = mt.next;
-    engine.set_data(pod);
-    gen->set_engine(engine);
-  }
+  if (rc == PYG_HIP_OK) loan.commit();
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);
   SampleOutput out;
@@ -485,6 +497,42 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
   return std::make_tuple(out_row, out_col, out_node, out_eid, out_nph, out_eph);
 }
 
+// pyg::dist_neighbor_sample (sampler/cpu/neighbor_kernel.cpp:957-978)
+std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
+    const Tensor& rowptr, const Tensor& col, const Tensor& seed, const int64_t num_neighbors,
+    const c10::optional<Tensor>& node_time, const c10::optional<Tensor>& edge_time,
+    const c10::optional<Tensor>& seed_time, const c10::optional<Tensor>& edge_weight, bool csc, bool replace,
+    bool directed, bool disjoint, std::string temporal_strategy) {
+  check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(), directed,
+              disjoint, temporal_strategy);
+  check_index(rowptr, "rowptr");
+  check_index(col, "col");
+  check_index(seed, "seed");
+  DeviceGuard guard(rowptr.device());
+  const auto opts = at::TensorOptions().dtype(at::kLong).device(rowptr.device());
+  SamplerHost host;
+  host.stream = current_hip_stream(rowptr.device().index());
+  EngineLoan loan;
+  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks, loan.ptr()};
+  const int64_t S = seed.numel();
+  std::vector<int64_t> cumsum((size_t)S + 1, 0);
+  int64_t* node_ptr = nullptr;
+  int64_t* edge_ptr = nullptr;
+  int64_t E = 0;
+  const int rc = pyg_hip_dist_neighbor_sample(
+      rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), seed.data_ptr<int64_t>(), S, num_neighbors,
+      node_time.has_value() ? time_ptr(node_time.value(), "node_time") : nullptr,
+      edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr,
+      seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr, temporal_strategy == "last",
+      replace, disjoint, &cb, &node_ptr, &edge_ptr, &E, cumsum.data(), host.stream);
+  if (rc == PYG_HIP_OK) loan.commit();
+  TORCH_CHECK(host.error.empty(), host.error);
+  check_status(rc);
+  auto nodes = disjoint ? adopt(node_ptr, {S + E, 2}, opts) : adopt(node_ptr, {S + E}, opts);
+  auto edges = adopt(edge_ptr, {E}, opts);
+  return std::make_tuple(nodes, edges, cumsum);
+}
+
 // ---------------------------------------------------------------------------------------------
 // registration
 // ---------------------------------------------------------------------------------------------
@@ -516,6 +564,12 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
       "str temporal_strategy = 'uniform', bool return_edge_id = True) -> "
       "(Dict(str, Tensor), Dict(str, Tensor), Dict(str, Tensor), "
       "Dict(str, Tensor)?, Dict(str, int[]), Dict(str, int[]))"));
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::dist_neighbor_sample(Tensor rowptr, Tensor col, Tensor seed, int "
+      "num_neighbors, Tensor? node_time = None, Tensor? edge_time = None, "
+      "Tensor? seed_time = None, Tensor? edge_weight = None, bool csc = False, "
+      "bool replace = False, bool directed = True, bool disjoint = False, "
+      "str temporal_strategy = 'uniform') -> (Tensor, Tensor, int[])"));
 }
 
 // HIP tensors dispatch under the CUDA key on PyTorch-ROCm.
@@ -524,6 +578,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::dist_neighbor_sample"), TORCH_FN(dist_neighbor_sample_kernel));
 }
 
 // pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:121-124

@@ -351,6 +351,7 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
   a.e_node[pos] = w;
   if (a.e_batch) a.e_batch[pos] = src_batch;
   if (a.e_eid) a.e_eid[pos] = edge;
+  if (!a.table.keys) return;  // dist_neighbor_sample: no relabelling (neighbor_kernel.cpp:296-303)
   const u64 s = table_slot(a.table, make_key(w, src_batch, a.num_batches));
   a.e_slot[pos] = s;
   __hip_atomic_fetch_min(&a.table.vals[s], kProvisional + (u64)pos, __ATOMIC_RELAXED,
@@ -1019,6 +1020,158 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   return PYG_HIP_OK;
 }
 
+__global__ void iota_kernel(int64_t* out, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
+__global__ void dist_nodes_kernel(const int64_t* __restrict__ seed, int64_t S, const int64_t* __restrict__ e_node,
+                                  const int64_t* __restrict__ e_batch, int64_t E, int disjoint,
+                                  int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= S + E) return;
+  const int64_t node = i < S ? seed[i] : e_node[i - S];
+  if (disjoint) {
+    out[2 * i] = i < S ? i : e_batch[i - S];
+    out[2 * i + 1] = node;
+  } else {
+    out[i] = node;
+  }
+}
+
+// dist_neighbor_sample (neighbor_kernel.cpp:957-978): one hop over the seeds, no relabelling.
+int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S, int64_t count,
+                     const int64_t* node_time, const int64_t* edge_time, const int64_t* seed_time,
+                     int temporal_last, int replace, int disjoint, Ctx& c, int64_t** out_node, int64_t** out_edge,
+                     int64_t* num_edges, int64_t* cumsum_host) {
+  hipStream_t stream = c.stream;
+  RngHost rng;
+  void* pinned = nullptr;
+  {
+    int rc = get_pinned(&pinned, 4096);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  const bool temporal = node_time || edge_time;
+  if (temporal) PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
+  if (edge_time) PYG_HIP_REQUIRE(seed_time != nullptr, "Seed time needs to be specified");
+  if (c.host->mt19937) {
+    PYG_HIP_REQUIRE(c.host->mt19937->left > 0 && c.host->mt19937->left <= 624 && c.host->mt19937->next <= 624,
+                    "sampler: invalid mt19937 engine state");
+    PYG_ALLOC(rng.mt, MtDev*, c, sizeof(MtDev));
+    PYG_HIP_CHECK(hipMemcpyAsync(rng.mt, c.host->mt19937, sizeof(MtDev), hipMemcpyHostToDevice, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  {
+    int rc = rng_ensure(c, rng, 0);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  cumsum_host[0] = S;
+  int64_t E = 0;
+  int64_t* e_node = nullptr;
+  int64_t* e_batch = nullptr;
+  int64_t* e_eid = nullptr;
+  if (S > 0) {
+    int64_t* batch = nullptr;
+    int64_t* seed_times = nullptr;
+    int* err_flag = nullptr;
+    if (disjoint) {
+      PYG_ALLOC(batch, int64_t*, c, sizeof(int64_t) * (size_t)S);
+      hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, batch, S);
+    }
+    if (temporal) {
+      PYG_ALLOC(seed_times, int64_t*, c, sizeof(int64_t) * (size_t)S);
+      PYG_ALLOC(err_flag, int*, c, sizeof(int));
+      PYG_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int), stream));
+      hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, seed,
+                         seed_time, node_time, S, (int64_t)0, seed_times);
+    }
+    PYG_HIP_CHECK(hipGetLastError());
+    RangeCtx range;
+    range.rowptr = rowptr;
+    range.col = col;
+    range.time = edge_time ? edge_time : node_time;
+    range.edge_level = edge_time ? 1 : 0;
+    range.last = temporal_last;
+    range.seed_times = seed_times;
+    range.batch = batch;
+    range.error = err_flag;
+    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
+    CountAgg* tile_buf;
+    int64_t* edge_off;
+    int64_t* rng_word;
+    int32_t* rng_units;
+    PYG_ALLOC(tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
+    PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)S);
+    PYG_ALLOC(rng_word, int64_t*, c, sizeof(int64_t) * (size_t)S);
+    PYG_ALLOC(rng_units, int32_t*, c, sizeof(int32_t) * (size_t)S);
+    CountLoad cl{seed, 0, range, count, replace};
+    CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
+    int rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(CountAgg), hipMemcpyDeviceToHost, stream));
+    // per-seed prefix of emitted neighbours -> cumsum_neighbors_per_node (:386-388,446-447)
+    PYG_HIP_CHECK(hipMemcpyAsync(cumsum_host + 1, edge_off, sizeof(int64_t) * (size_t)S, hipMemcpyDeviceToHost,
+                                 stream));
+    int herr = 0;
+    if (temporal) PYG_HIP_CHECK(hipMemcpyAsync(&herr, err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    PYG_HIP_REQUIRE(herr == 0, "Found invalid non-sorted temporal neighborhood");
+    const CountAgg tot = *static_cast<CountAgg*>(pinned);
+    E = tot.edges;
+    // cumsum_host[1 + i] currently holds the EXCLUSIVE prefix of seed i; shift to "size after seed i"
+    for (int64_t i = 0; i + 1 < S; ++i) cumsum_host[1 + i] = S + cumsum_host[2 + i];
+    cumsum_host[S] = S + E;
+    if (E > 0) {
+      const int64_t end_word = rng.word + tot.tab.dw[rng.units];
+      rc = rng_ensure(c, rng, end_word);
+      if (rc != PYG_HIP_OK) return rc;
+      PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      PYG_ALLOC(e_eid, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      int64_t* e_row;
+      PYG_ALLOC(e_row, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)E);
+      HopArgs a;
+      a.nodes = seed;
+      a.batch = batch;
+      a.begin = 0;
+      a.frontier = S;
+      a.range = range;
+      a.col = col;
+      a.count = count;
+      a.replace = replace;
+      a.num_batches = 1;
+      a.edge_off = edge_off;
+      a.rng_word = rng_word;
+      a.rng_units = rng_units;
+      a.words = rng.dev;
+      a.e_row = e_row;
+      a.e_node = e_node;
+      a.e_batch = e_batch;
+      a.e_eid = e_eid;
+      a.e_slot = nullptr;
+      a.table = HashTable{nullptr, nullptr, 0};
+      hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, stream, a);
+      PYG_HIP_CHECK(hipGetLastError());
+    }
+  }
+  int64_t* nodes_out;
+  PYG_ALLOC(nodes_out, int64_t*, c, sizeof(int64_t) * (size_t)std::max<int64_t>((S + E) * (disjoint ? 2 : 1), 1));
+  if (S + E > 0) {
+    hipLaunchKernelGGL(dist_nodes_kernel, dim3((unsigned)((S + E + 255) / 256)), dim3(256), 0, stream, seed, S,
+                       e_node, e_batch, E, disjoint, nodes_out);
+    PYG_HIP_CHECK(hipGetLastError());
+  }
+  if (!e_eid) PYG_ALLOC(e_eid, int64_t*, c, 16);
+  *out_node = nodes_out;
+  *out_edge = e_eid;
+  *num_edges = E;
+  c.keep(nodes_out);
+  c.keep(e_eid);
+  if (rng.mt) PYG_HIP_CHECK(hipMemcpyAsync(c.host->mt19937, rng.mt, sizeof(MtDev), hipMemcpyDeviceToHost, stream));
+  PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  return PYG_HIP_OK;
+}
+
 }  // namespace
 }  // namespace pyg_hip
 
@@ -1057,5 +1210,25 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
     (void)hipStreamSynchronize(c.stream);
   }
   c.release_all();  // scratch (and, on failure, everything)
+  return rc;
+}
+
+extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, const int64_t* seed,
+                                            int64_t num_seed, int64_t num_neighbors, const int64_t* node_time,
+                                            const int64_t* edge_time, const int64_t* seed_time, int temporal_last,
+                                            int replace, int disjoint, const pyg_hip_sampler_host* host,
+                                            int64_t** node_id, int64_t** edge_id, int64_t* num_edges,
+                                            int64_t* cumsum_host, void* stream_) {
+  PYG_HIP_REQUIRE(host && host->alloc && host->free && (host->rng_blocks || host->mt19937),
+                  "dist sampler: host callbacks missing");
+  PYG_HIP_REQUIRE(rowptr && (num_seed == 0 || seed) && node_id && edge_id && num_edges && cumsum_host,
+                  "dist sampler: NULL argument");
+  Ctx c;
+  c.host = host;
+  c.stream = static_cast<hipStream_t>(stream_);
+  int rc = run_dist_sampler(rowptr, col, seed, num_seed, num_neighbors, node_time, edge_time, seed_time,
+                            temporal_last, replace, disjoint, c, node_id, edge_id, num_edges, cumsum_host);
+  if (rc != PYG_HIP_OK) (void)hipStreamSynchronize(c.stream);
+  c.release_all();
   return rc;
 }

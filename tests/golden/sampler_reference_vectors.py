@@ -72,3 +72,22 @@ HETERO_CASE = dict(
     node_types=['paper'], edge_types=[('paper', 'to', 'paper')], seed=[2, 3], num_neighbors=[2, 2],
     row=[0, 0, 1, 1, 2, 2, 3, 3], col_out=[2, 1, 0, 3, 4, 0, 1, 5], node=[2, 3, 1, 4, 0, 5],
     edge=[4, 5, 6, 7, 2, 3, 8, 9], nodes_per_hop=[2, 2, 2], edges_per_hop=[4, 4])
+
+
+# test/csrc/sampler/test_dist_neighbor.cpp: (node_id, edge_id, cumsum_neighbors_per_node) of ONE hop
+DIST_CASES = [
+    dict(name='dist_basic', col=COL, seed=[2, 3], num_neighbors=-1, kwargs={},  # :8-27
+         node=[2, 3, 1, 3, 2, 4], edge=[4, 5, 6, 7], cumsum=[2, 4, 6]),
+    dict(name='dist_without_replacement_seeded', col=COL, seed=[2, 3], num_neighbors=1, kwargs={},  # :29-49
+         manual_seed=123456, node=[2, 3, 1, 4], edge=[4, 7], cumsum=[2, 3, 4]),
+    dict(name='dist_with_replacement_seeded', col=COL, seed=[2, 3], num_neighbors=2,  # :51-77
+         kwargs=dict(replace=True), manual_seed=123456, node=[2, 3, 1, 3, 4, 4], edge=[4, 5, 7, 7],
+         cumsum=[2, 4, 6]),
+    dict(name='dist_disjoint', col=COL, seed=[2, 3], num_neighbors=2,  # :79-107
+         kwargs=dict(replace=False, directed=True, disjoint=True),
+         node=[[0, 2], [1, 3], [0, 1], [0, 3], [1, 2], [1, 4]], edge=[4, 5, 6, 7], cumsum=[2, 4, 6]),
+    dict(name='dist_temporal', col=COL_SORTED, seed=[2, 3], num_neighbors=2,  # :109-144
+         kwargs=dict(node_time=np.arange(6, dtype=np.int64), replace=False, directed=True, disjoint=True,
+                     temporal_strategy='uniform'),
+         node=[[0, 2], [1, 3], [0, 1], [1, 2]], edge=[4, 6], cumsum=[2, 3, 4]),
+]

@@ -52,3 +52,13 @@ def test_csc_swaps_row_and_col():
     a = oracle.neighbor_sample(G.ROWPTR, G.COL, np.array([2, 3]), [-1, -1], csc=False)
     b = oracle.neighbor_sample(G.ROWPTR, G.COL, np.array([2, 3]), [-1, -1], csc=True)
     assert a[0].tolist() == b[1].tolist() and a[1].tolist() == b[0].tolist()
+
+
+@pytest.mark.parametrize('case', G.DIST_CASES, ids=[c['name'] for c in G.DIST_CASES])
+def test_dist_reference_golden_vectors(case):
+    node, edge, cumsum, _ = oracle.dist_neighbor_sample(G.ROWPTR, case['col'], np.array(case['seed']),
+                                                        case['num_neighbors'], rng_seed=case.get('manual_seed', 0),
+                                                        **case['kwargs'])
+    assert node.tolist() == case['node']
+    assert edge.tolist() == case['edge']
+    assert cumsum == case['cumsum']

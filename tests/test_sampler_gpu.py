@@ -229,3 +229,43 @@ def test_products_scale_batch_is_bit_exact():
     out, after, ref = run_both(rowptr, col, seeds, [15, 10, 5], 12345)
     assert_same(out, after, ref, 12345)
     assert sum(ref[5]) > 500_000
+
+
+@pytest.mark.parametrize('case', G.DIST_CASES, ids=[c['name'] for c in G.DIST_CASES])
+def test_dist_reference_golden_vectors(case):
+    # test/csrc/sampler/test_dist_neighbor.cpp
+    kw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case['kwargs'].items()}
+    torch.manual_seed(case.get('manual_seed', 0))
+    node, edge, cumsum = torch.ops.pyg.dist_neighbor_sample(dev(G.ROWPTR), dev(case['col']), dev(case['seed']),
+                                                            case['num_neighbors'], **kw)
+    assert node.cpu().tolist() == case['node']
+    assert edge.cpu().tolist() == case['edge']
+    assert cumsum == case['cumsum']
+
+
+@pytest.mark.parametrize('variant', ['plain', 'replace', 'disjoint', 'full', 'temporal'])
+def test_dist_random_graph_matches_oracle(variant):
+    rowptr, col = random_csr(4000, 20, seed=12)
+    seeds = np.random.default_rng(13).permutation(4000)[:500]
+    kw, fan = {}, 7
+    if variant == 'replace':
+        kw = dict(replace=True)
+    elif variant == 'disjoint':
+        kw = dict(disjoint=True)
+    elif variant == 'full':
+        fan = -1
+    elif variant == 'temporal':
+        rng = np.random.default_rng(14)
+        et = rng.integers(0, 500, col.size, dtype=np.int64)
+        for v in range(4000):
+            et[rowptr[v]:rowptr[v + 1]] = np.sort(et[rowptr[v]:rowptr[v + 1]])
+        kw = dict(disjoint=True, edge_time=et, seed_time=rng.integers(100, 500, 500, dtype=np.int64))
+    torch.manual_seed(5)
+    dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    node, edge, cumsum = torch.ops.pyg.dist_neighbor_sample(dev(rowptr), dev(col), dev(seeds), fan, **dkw)
+    after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+    rnode, redge, rcumsum, info = oracle.dist_neighbor_sample(rowptr, col, seeds, fan, rng_seed=5, **kw)
+    assert torch.equal(node.cpu(), torch.from_numpy(rnode))
+    assert torch.equal(edge.cpu(), torch.from_numpy(redge))
+    assert cumsum == rcumsum
+    assert after == int(oracle.mt19937_words(5, info['rng_blocks'] * 128 + 1)[-1])
