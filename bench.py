@@ -7,11 +7,14 @@
 A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
 ``segment_matmul`` on BASELINE.json configs[1] (154 relations, 21,111,007 rows, F=128, bf16;
 SURVEY.md 8(d) C2).  `value` is whole-job GFLOP/s (2*N*K*M flop per step / wall time).  With
-N > 1 ranks the row range is sharded contiguously (relation list cut at row boundaries), each
-rank multiplies its shard, and the timed region is compute-only with the outputs left sharded
-("scaling": "strong"); the RCCL all-gather of the outputs that BASELINE's north_star names is timed
-separately and reported under "allgather" (it is xGMI-bound and ~26x slower than
-the HBM-bound shard compute, so folding it in would only measure the links).
+N > 1 ranks the relation list is sharded contiguously by rows (pyg_lib_amd/sharding.py), each rank
+multiplies its shard, and the timed region is compute-only with the outputs left sharded -- no
+data-path collective.  Default "scaling": "weak": the job is the C2 relation list with every
+relation N x as many rows, so each rank's shard is one C2-sized launch (per-GPU work fixed);
+``--scaling strong`` shards the fixed C2 job instead (0.25 ms launches at N=8).  The RCCL all-gather
+of the outputs that BASELINE's north_star names is timed separately and reported under "allgather"
+(it is xGMI-bound and ~26x slower than the HBM-bound shard compute, so folding it
+in would only measure the links).
 
 The JSON line also carries `roofline` (dominant kernel vs the HBM roofline, durations measured
 with HIP events on the launch stream through pyg_hip_profile_*), `cpu_baseline` (the oracle timed
@@ -94,6 +97,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sampler', action='store_true')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -116,7 +120,8 @@ def main():
     L.pyg_hip_profile_collect.restype = ctypes.c_int
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    x, ptr, w, (N, B, F) = make_c2(device, rank, world, dtype, args.scale)
+    job_scale = args.scale * (world if args.scaling == 'weak' else 1)
+    x, ptr, w, (N, B, F) = make_c2(device, rank, world, dtype, job_scale)
     esz = x.element_size()
 
     def step():
@@ -199,10 +204,10 @@ def main():
             'metric': 'segment_matmul GFLOP/s + sampled-edges/sec, 1/2/4/8 MI355X vs CPU ref',
             'value': round(value, 1), 'unit': 'GFLOP/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'segment_matmul ogbn-mag-shaped: 154 relations, 21,111,007 rows, '
                                    'F_in=F_out=128 (BASELINE.json configs[1])',
-                       'relations': B, 'rows': N, 'F': F, 'scale': args.scale,
+                       'relations': B, 'rows': N, 'rows_per_gpu': N // world, 'F': F, 'scale': args.scale,
                        'sharding': f'contiguous row shards x{world}, outputs left sharded'},
             'roofline': roofline,
         }
