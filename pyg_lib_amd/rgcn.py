@@ -1,0 +1,68 @@
+"""One relational graph convolution over a sampled heterogeneous neighbourhood, on the device.
+
+SURVEY.md 8(f) N1 / BASELINE.json configs[4]: the step either side of the two hot operators --
+
+    hetero_neighbor_sample  ->  gather_coo (neighbour features)  ->  segment_matmul (one weight per
+    relation)  ->  scatter_sum (into the expanded nodes)
+
+The sampler already emits its edges grouped by relation, so the relation pointer of
+``segment_matmul`` is just the running sum of the per-relation edge counts (tensor sizes, known
+on the host without a synchronisation) and no ``index_sort`` by relation is needed in between.
+Node features of all types live in ONE ``[sum_t n_t, F]`` buffer (type offsets), so one gather and
+one scatter serve every relation.
+
+For ``csc=False`` sampler output and edge type ``(src, rel, dst)``: ``row`` holds local ids of the
+expanded ``src``-type nodes, ``col`` local ids of the sampled ``dst``-type neighbours
+(pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:587-602); messages flow col -> row.  With
+``csc=True`` the roles of the two end types swap (row indexes ``dst``-type nodes).
+"""
+from typing import Dict, List, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+EdgeType = Tuple[str, str, str]
+
+
+def type_offsets(num_nodes: Dict[str, int], node_types: List[str]) -> Dict[str, int]:
+    off, acc = {}, 0
+    for t in node_types:
+        off[t] = acc
+        acc += int(num_nodes[t])
+    off['__total__'] = acc
+    return off
+
+
+def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
+               col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
+               csc: bool = False) -> Tensor:
+    r"""out[row] += x[col] @ weight[r] over every sampled edge of every relation r.
+
+    Args:
+        x: ``[sum_t n_t, F_in]`` features of the sampled nodes, types concatenated at `offsets`.
+        offsets: first row of every node type in `x` (``type_offsets``).
+        row_dict, col_dict: local indices from ``hetero_neighbor_sample``.
+        edge_types: relation order; ``weight[i]`` belongs to ``edge_types[i]``.
+        weight: ``[R, F_in, F_out]``.
+    Returns:
+        ``[sum_t n_t, F_out]`` aggregated messages (same type layout as `x`).
+    """
+    counts, gather_idx, scatter_idx = [0], [], []
+    for et in edge_types:
+        src, _, dst = et
+        row_t, col_t = (src, dst) if not csc else (dst, src)
+        row, col = row_dict[et], col_dict[et]
+        counts.append(counts[-1] + row.numel())
+        gather_idx.append(col + offsets[col_t] if offsets[col_t] else col)
+        scatter_idx.append(row + offsets[row_t] if offsets[row_t] else row)
+    total = offsets['__total__']
+    if counts[-1] == 0:
+        return x.new_zeros(total, weight.size(-1))
+    gidx = torch.cat(gather_idx)
+    sidx = torch.cat(scatter_idx)
+    ptr = torch.tensor(counts, dtype=torch.long)  # host pointer: staged, never synchronises
+    feats = ops.gather_coo(x, gidx)                           # [E, F_in]
+    msgs = ops.segment_matmul(feats, ptr, weight)              # [E, F_out]
+    return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
