@@ -60,19 +60,25 @@ constexpr u64 kEmpty = ~0ull;           // empty hash key / unset value (memset 
 constexpr u64 kProvisional = 1ull << 62;  // values >= this are emission positions, below: final ids
 
 // ---- RNG state algebra ---------------------------------------------------------------------------
-// State = number of unused 16-bit units in the current word (0..4).  tab.dw[u] / tab.nb[u]: words
-// advanced and units left after running a node's draws from state u.
-struct RngTab {
-  int32_t dw[5];
-  int32_t nb[5];
-};
+// State = number of unused 16-bit units in the current word (0..4).  A node's draws map a start state
+// u to (words advanced dw[u], units left nb[u]).  Start states only differ until each has fetched its
+// first fresh word (after which all hold 4 - n units), so dw[u] is D or D + 1 for one common D, and
+// the whole table packs into ONE 64-bit value -- bits 4u..4u+2 = nb[u], bit 4u+3 = dw[u] - D,
+// bits 20.. = D -- which keeps the scan's operator a handful of shifts (the scan kernels are
+// latency-bound; the first version carried 5 x (int32, int32) tables and ran 3-5x longer).
+typedef u64 RngTab;
 
-__host__ __device__ inline RngTab rng_identity() {
-  RngTab t;
-  for (int u = 0; u < 5; ++u) {
-    t.dw[u] = 0;
-    t.nb[u] = u;
-  }
+__host__ __device__ inline RngTab rng_identity() { return 0x43210ull; }
+__host__ __device__ inline int64_t tab_dw(RngTab t, int u) { return (int64_t)(t >> 20) + (int64_t)((t >> (4 * u + 3)) & 1); }
+__host__ __device__ inline int tab_nb(RngTab t, int u) { return (int)((t >> (4 * u)) & 7); }
+
+__host__ __device__ inline RngTab tab_pack(const int64_t (&dw)[5], const int (&nb)[5]) {
+  int64_t d = dw[0];
+#pragma unroll
+  for (int u = 1; u < 5; ++u) d = dw[u] < d ? dw[u] : d;
+  RngTab t = (u64)d << 20;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) t |= (u64)((nb[u] & 7) | ((int)(dw[u] - d) << 3)) << (4 * u);
   return t;
 }
 
@@ -81,30 +87,39 @@ __host__ __device__ inline int need_units(u64 range) {
   return range < (1ull << 16) ? 1 : (range < (1ull << 32) ? 2 : 4);
 }
 
+// one more draw of n units appended to the table (only rows of degree >= 2^16 take this path)
 __host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
-  for (int u = 0; u < 5; ++u) {
-    if (t.nb[u] < n) {
-      t.dw[u] += 1;
-      t.nb[u] = 4 - n;
-    } else {
-      t.nb[u] -= n;
-    }
-  }
-}
-
-// a[m] for a run-time m without dynamic register indexing (which would push the tables to scratch)
-__host__ __device__ inline int32_t sel5(const int32_t (&a)[5], int m) {
-  return m == 0 ? a[0] : (m == 1 ? a[1] : (m == 2 ? a[2] : (m == 3 ? a[3] : a[4])));
-}
-
-__host__ __device__ inline RngTab rng_compose(const RngTab& f, const RngTab& g) {
-  RngTab h;
+  int64_t dw[5];
+  int nb[5];
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
-    const int m = f.nb[u];
-    h.dw[u] = f.dw[u] + sel5(g.dw, m);
-    h.nb[u] = sel5(g.nb, m);
+    dw[u] = tab_dw(t, u);
+    nb[u] = tab_nb(t, u);
+    if (nb[u] < n) {
+      dw[u] += 1;
+      nb[u] = 4 - n;
+    } else {
+      nb[u] -= n;
+    }
   }
+  t = tab_pack(dw, nb);
+}
+
+// g after f
+__host__ __device__ inline RngTab rng_compose(RngTab f, RngTab g) {
+  u64 e[5];
+  u64 mn = 3;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const u64 ef = (f >> (4 * u)) & 0xF;
+    const u64 eg = (g >> (4 * (ef & 7))) & 0xF;
+    const u64 b = (ef >> 3) + (eg >> 3);
+    e[u] = (eg & 7) | (b << 3);  // b in 0..2, temporarily 2 bits wide
+    mn = b < mn ? b : mn;
+  }
+  RngTab h = ((f >> 20) + (g >> 20) + mn) << 20;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) h |= (e[u] - (mn << 3)) << (4 * u);
   return h;
 }
 
@@ -264,17 +279,21 @@ struct CountLoad {
     r.edges = count;
     if ((u64)deg < (1ull << 16)) {
       // all draws take 16 bits: closed form
+      int64_t dwv[5];
+      int nbv[5];
+#pragma unroll
       for (int u = 0; u < 5; ++u) {
         if (count <= u) {
-          r.tab.dw[u] = 0;
-          r.tab.nb[u] = u - (int)count;
+          dwv[u] = 0;
+          nbv[u] = u - (int)count;
         } else {
           const int64_t c2 = count - u;
           const int64_t dw = (c2 + 3) / 4;
-          r.tab.dw[u] = (int32_t)dw;
-          r.tab.nb[u] = (int32_t)(4 * dw - c2);
+          dwv[u] = dw;
+          nbv[u] = (int)(4 * dw - c2);
         }
       }
+      r.tab = tab_pack(dwv, nbv);
     } else if (replace) {
       const int n = need_units((u64)deg);
       for (int64_t j = 0; j < count; ++j) rng_push_draw(r.tab, n);
@@ -293,8 +312,8 @@ struct CountStore {
   int32_t units0;
   __device__ void operator()(int64_t i, const CountAgg& prefix, const CountAgg&) const {
     edge_off[i] = prefix.edges;
-    rng_word[i] = word0 + sel5(prefix.tab.dw, units0);
-    rng_units[i] = sel5(prefix.tab.nb, units0);
+    rng_word[i] = word0 + tab_dw(prefix.tab, units0);
+    rng_units[i] = tab_nb(prefix.tab, units0);
   }
 };
 
@@ -334,7 +353,10 @@ struct RngCursor {
       ++word;
       units = 4;
     }
-    const u64 w = words[(word >> 7) * 128 + (127 - (word & 127))];
+    u64 w = words[(word >> 7) * 128 + (127 - (word & 127))];
+    // uniform_int_from_to's `x % (2^64 - 1)` differs from x only for x == 2^64 - 1 (-> 0); the device
+    // generator stores x + INT64_MIN un-reduced (so the stream stays invertible, mt_finish_kernel)
+    if (w == 0x7fffffffffffffffull) w = 0x8000000000000000ull;
     const int shift = (4 - units) * 16;
     u64 v = w >> shift;
     if (n == 1) v &= 0xffffull;
@@ -415,6 +437,86 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
   }
 }
 
+// G lanes per frontier node, 64 / G nodes per wave, for fan-outs 0 < count <= G: lane g owns draw g.
+// The wave-per-node kernel above spends every lane on the same serial draw loop (64-bit modulo
+// included); here each draw is computed once, and only the "already chosen?" resolution of Floyd's
+// algorithm stays sequential -- `count` steps of one shuffle + one ballot.
+//
+// Position of draw g in the word stream when every draw of the node takes the same n units
+// (rand_engine.h:41-76): the current word still serves u / n draws, every later word 4 / n.
+template <int G>
+__global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const bool live = i < a.frontier;
+  const int64_t count = a.count;  // 0 < count <= G
+  int64_t src_pos = 0, src_batch = 0, rs = 0, deg = 0, off = 0;
+  if (live) {
+    src_pos = a.begin + i;
+    const int64_t v = a.nodes[src_pos];
+    src_batch = a.batch ? a.batch[src_pos] : 0;
+    int64_t re_;
+    a.range(v, src_pos, count, &rs, &re_);
+    deg = re_ - rs;
+    off = a.edge_off[i];
+  }
+  const bool all = live && deg > 0 && !a.replace && count >= deg;  // whole neighbourhood, no draws
+  const bool samp = live && deg > 0 && !all && g < count;
+  int64_t pick = -1 - g;  // distinct negatives: never equal to a real draw
+  int64_t idx = 0;
+  if (samp) {
+    idx = a.replace ? deg - 1 : deg - count + g;  // draw g is uniform in [0, idx]
+    const u64 range = (u64)idx + 1;
+    const int n = need_units(range);
+    const int n0 = need_units(a.replace ? (u64)deg : (u64)(deg - count + 1));
+    const int64_t w0 = a.rng_word[i];
+    const int u0 = a.rng_units[i];
+    u64 val;
+    if (n0 == need_units((u64)deg)) {
+      // uniform draw width: closed-form position
+      const int first = u0 / n;
+      int64_t word;
+      int unit;
+      if (g < first) {
+        word = w0;
+        unit = (4 - u0) + g * n;
+      } else {
+        const int t = g - first;
+        const int per = 4 / n;
+        word = w0 + 1 + t / per;
+        unit = (t % per) * n;
+      }
+      u64 w = a.words[(word >> 7) * 128 + (127 - (word & 127))];
+      if (w == 0x7fffffffffffffffull) w = 0x8000000000000000ull;
+      val = w >> (unit * 16);
+      if (n == 1) val &= 0xffffull;
+      else if (n == 2) val &= 0xffffffffull;
+      if ((val >> 32) == 0 && (range >> 32) == 0) val = (u64)((uint32_t)val % (uint32_t)range);
+      else val = val % range;
+    } else {
+      // the draw width changes inside this node's sequence (degree straddles 2^16 / 2^32): walk it
+      RngCursor rng{w0, u0, a.words};
+      val = 0;
+      for (int t = 0; t <= g; ++t) val = rng.next((u64)(deg - count + t) + 1);
+    }
+    pick = (int64_t)val;
+  }
+  if (!a.replace) {
+    // Floyd (:231-240): draw j is replaced by idx_j when its value was already chosen
+    for (int j = 1; j < (int)count; ++j) {
+      const int64_t rj = __shfl(pick, gbase + j);
+      const bool dup = samp && g < j && pick == rj;
+      const u64 m = __ballot(dup);
+      const bool hit = ((m >> gbase) & (G == 64 ? ~0ull : ((1ull << G) - 1))) != 0;
+      if (samp && g == j && hit) pick = idx;
+    }
+  }
+  if (samp) emit(a, off + g, rs + pick, src_pos, src_batch);
+  else if (all && g < deg) emit(a, off + g, rs + g, src_pos, src_batch);
+}
+
 // owner flag of emission p: it holds the table minimum  <=>  first occurrence of a NEW node
 struct FlagLoad {
   const u64* slots;
@@ -460,15 +562,36 @@ __global__ void interleave_kernel(const int64_t* __restrict__ batch,
   }
 }
 
+// fan-outs up to 64 use sub-wave groups (8/16/32/64 lanes per node); "all neighbours" and larger
+// fan-outs one wave per node
+void launch_sample(const HopArgs& a, int64_t F, hipStream_t stream) {
+  const int64_t c = a.count;
+  if (c > 0 && c <= 8)
+    hipLaunchKernelGGL(sample_group_kernel<8>, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, stream, a);
+  else if (c > 0 && c <= 16)
+    hipLaunchKernelGGL(sample_group_kernel<16>, dim3((unsigned)((F + 15) / 16)), dim3(256), 0, stream, a);
+  else if (c > 0 && c <= 32)
+    hipLaunchKernelGGL(sample_group_kernel<32>, dim3((unsigned)((F + 7) / 8)), dim3(256), 0, stream, a);
+  else if (c > 0 && c <= 64)
+    hipLaunchKernelGGL(sample_group_kernel<64>, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, a);
+}
+
 // ---- device-side mt19937 (continues the caller's CPU engine) ---------------------------------------
 // The reference draws its words with at::randint / Tensor.random_ on torch's CPU generator, i.e.
 // at::mt19937 (ATen/core/MT19937RNGEngine.h) + random64() = (hi << 32 | lo) of two consecutive
 // outputs + `% (2^64 - 1) + INT64_MIN` (ATen/core/DistributionsHelper.h:40-56).  Generating the
 // ~2e5 words of a products-scale batch on the host costs more than all sampling kernels together, so
-// the engine state (624 words + left/next) is shipped to the device, one wave runs the recurrence
-// with the state held in registers (element j lives in lane j & 63, register j >> 6; the twist of
-// register r reads old registers >= r and already-updated registers < r, exactly the in-place order
-// of mt19937_engine::next_state), and the advanced state is handed back to the caller afterwards.
+// the engine state (624 words + left/next) is handed to the device as a kernel argument, the device
+// continues the very same stream, and the advanced engine is handed back to the caller afterwards.
+//
+// Stream coordinates of one call: output o = 0, 1, 2, ... counted from the engine position at call
+// start.  The engine's current array A_0 still holds a0 = left - 1 outputs (o < a0 reads
+// state[next + o]); array A_j (j >= 1, the j-th mt19937_engine::next_state()) covers
+// o in [a0 + 624 (j-1), a0 + 624 j).  Output 2k is the HIGH half of 64-bit word k
+// (CPUGeneratorImpl::random64), INT64_MIN is folded in by flipping bit 63; the words are stored
+// un-reduced (see RngCursor::next), so the raw engine values can be recovered from them.
 struct MtDev {
   uint32_t state[624];
   int32_t left;
@@ -483,77 +606,107 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
+__device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
+  y ^= y >> 18;
+  y ^= (y << 15) & 0xefc60000u;
+  uint32_t t = y;  // invert y ^= (y << 7) & B: 7 known low bits grow by 7 per round
+  for (int i = 0; i < 4; ++i) t = y ^ ((t << 7) & 0x9d2c5680u);
+  y = t;
+  t = y;           // invert y ^= y >> 11
+  for (int i = 0; i < 2; ++i) t = y ^ (t >> 11);
+  return t;
+}
+
 __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
   return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Emits `n32` consecutive 32-bit engine outputs as the halves of 64-bit words out[0 .. n32/2):
-// output 2k is the HIGH half of word k (CPUGeneratorImpl::random64), and INT64_MIN is folded in by
-// flipping the top bit; the (2^-64) case x == 2^64-1 -> 0 is patched by mt_fixup_kernel.
-//
 // mt19937_engine::next_state() is the linear recurrence x[n+624] = x[n+397] ^ twist(x[n], x[n+1])
 // evaluated in place one 624-array at a time; element n only needs values at least 227 positions
 // back, so one workgroup produces 227 new values per step (one barrier each) in a 1024-word
 // circular LDS window -- the same numbers in the same order, ~4x fewer dependent steps than a
-// per-array update.  On exit the engine holds exactly the array torch would hold (the array that
-// contains the last consumed output, fully regenerated) with matching left/next.
+// per-array update.  One launch continues from array A_from (held in `window`, or in `init` for
+// A_0) and produces arrays A_from+1 .. A_from+m, leaving A_from+m in `window`.  The kernel runs on a
+// side stream ahead of the sampling kernels (speculatively: the exact consumption of a hop is only
+// known after its count scan); `stop` (pinned host memory) lets the host cancel what nobody will read.
 constexpr int kMtStep = 227;
 
-__global__ __launch_bounds__(256) void mt_generate_kernel(MtDev* st, uint32_t* out32, int64_t n32) {
-  __shared__ uint32_t x[1024];  // x-stream index n lives at x[n & 1023]; x[0..623] = current array
+__global__ __launch_bounds__(256) void mt_generate_kernel(const MtDev init, uint32_t* __restrict__ window,
+                                                          uint32_t* __restrict__ out32, int64_t from, int64_t m,
+                                                          const int* stop) {
+  __shared__ uint32_t x[1024];  // x-stream index n lives at x[n & 1023]; x[0..623] = array A_from
+  __shared__ int stop_s;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 624; i += 256) x[i] = st->state[i];
-  const int64_t left0 = st->left;
-  const int64_t next0 = st->next;
-  __syncthreads();
+  const int64_t a0 = (int64_t)init.left - 1;
   auto emit = [&](int64_t o, uint32_t raw) {
     const uint32_t y = mt_temper(raw);
     // little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
     if ((o & 1) == 0) out32[o + 1] = y ^ 0x80000000u;
     else out32[o - 1] = y;
   };
-  const int64_t a0 = left0 - 1;  // outputs still available in the current array, from index next0
-  const int64_t take0 = a0 < n32 ? a0 : n32;
-  for (int64_t q = tid; q < take0; q += 256) emit(q, x[next0 + q]);
-  if (n32 <= a0) {
-    if (tid == 0) {
-      st->left = (int32_t)(left0 - n32);
-      st->next = (uint32_t)(next0 + n32);
-    }
+  if (from == 0) {
+    for (int i = tid; i < 624; i += 256) x[i] = init.state[i];
+    __syncthreads();
+    for (int64_t q = tid; q < a0; q += 256) emit(q, x[init.next + q]);
+  } else {
+    for (int i = tid; i < 624; i += 256) x[i] = window[i];
+    __syncthreads();
+  }
+  if (m <= 0) {
+    if (from == 0) for (int i = tid; i < 624; i += 256) window[i] = x[i];
     return;
   }
-  const int64_t mp = n32 - a0;           // outputs taken from regenerated arrays
-  const int64_t k = (mp + 623) / 624;    // number of regenerations
-  const int64_t gen_end = 624 * (k + 1);  // produce x[624 .. gen_end)
-  for (int64_t n0 = 624; n0 < gen_end; n0 += kMtStep) {
+  const int64_t o_base = a0 + 624 * from - 624;  // output index of x-stream position 0 ... + n
+  const int64_t gen_end = 624 * (m + 1);         // produce x[624 .. gen_end)
+  int step = 0;
+  for (int64_t n0 = 624; n0 < gen_end; n0 += kMtStep, ++step) {
+    if ((step & 63) == 63) {
+      if (tid == 0) stop_s = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __syncthreads();
+      if (stop_s) return;  // cancelled: nothing past the consumed words is ever read
+    }
     const int64_t n = n0 + tid;
     if (tid < kMtStep && n < gen_end) {
       const uint32_t v = x[(n - 227) & 1023] ^ mt_twist(x[(n - 624) & 1023], x[(n - 623) & 1023]);
       x[n & 1023] = v;  // slot of x[n - 1024]: no longer needed by this or any later step
-      const int64_t o = a0 + (n - 624);
-      if (o < n32) emit(o, v);
+      emit(o_base + n, v);
     }
     __syncthreads();
   }
-  for (int i = tid; i < 624; i += 256) st->state[i] = x[(624 * k + i) & 1023];
-  if (tid == 0) {
+  for (int i = tid; i < 624; i += 256) window[i] = x[(624 * m + i) & 1023];
+}
+
+// Engine state after consuming n32 > a0 outputs: the array that holds the last consumed output, fully
+// regenerated, with torch's left/next bookkeeping -- rebuilt from the stored words by un-tempering.
+__global__ __launch_bounds__(256) void mt_finish_kernel(const uint32_t* __restrict__ out32, int64_t a0, int64_t n32,
+                                                        MtDev* __restrict__ st) {
+  const int64_t mp = n32 - a0;          // outputs taken from regenerated arrays
+  const int64_t k = (mp + 623) / 624;   // index of the final array
+  const int64_t o0 = a0 + 624 * (k - 1);
+  for (int i = threadIdx.x; i < 624; i += 256) {
+    const int64_t o = o0 + i;
+    const uint32_t y = (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
+    st->state[i] = mt_untemper(y);
+  }
+  if (threadIdx.x == 0) {
     const int64_t nx = mp - 624 * (k - 1);
     st->next = (uint32_t)nx;
     st->left = (int32_t)(625 - nx);
   }
 }
 
-// uniform_int_from_to: x % (2^64 - 1) differs from x only for x == 2^64 - 1 (-> 0); the generator
-// already added INT64_MIN by flipping bit 63, so that word reads 0x7fff...f and must become 0x8000...0.
-__global__ void mt_fixup_kernel(u64* words, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n && words[i] == 0x7fffffffffffffffull) words[i] = 0x8000000000000000ull;
-}
-
 // ---- host driver -----------------------------------------------------------------------------------
 struct Ctx {
   const pyg_hip_sampler_host* host;
   hipStream_t stream;
+  hipStream_t side = nullptr;     // side stream with random-word generation in flight (or nullptr)
+  volatile int* side_stop = nullptr;
+  void quiesce_side() {           // cancel speculation and wait: scratch may be freed afterwards
+    if (!side) return;
+    if (side_stop) *side_stop = 1;
+    (void)hipStreamSynchronize(side);
+    side = nullptr;
+  }
   std::vector<void*> live;  // every block obtained from host->alloc and not yet handed out/freed
   void* alloc(size_t bytes) {
     void* p = host->alloc(host->user, bytes ? bytes : 16);
@@ -657,17 +810,170 @@ int get_pinned(void** out, size_t bytes) {
   return PYG_HIP_OK;
 }
 
+// Per-thread, per-device side stream + event pool for the speculative word generation.
+struct SideStream {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t used = 0;
+  int next_event(hipEvent_t* ev) {
+    if (used == events.size()) {
+      hipEvent_t e;
+      PYG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      events.push_back(e);
+    }
+    *ev = events[used++];
+    return PYG_HIP_OK;
+  }
+};
+
+int get_side_stream(SideStream** out) {
+  static thread_local std::vector<SideStream*> cache;
+  int dev = 0;
+  PYG_HIP_CHECK(hipGetDevice(&dev));
+  for (SideStream* ss : cache)
+    if (ss->device == dev) {
+      ss->used = 0;
+      *out = ss;
+      return PYG_HIP_OK;
+    }
+  SideStream* ss = new SideStream();
+  ss->device = dev;
+  PYG_HIP_CHECK(hipStreamCreateWithFlags(&ss->stream, hipStreamNonBlocking));
+  cache.push_back(ss);
+  *out = ss;
+  return PYG_HIP_OK;
+}
+
 struct RngHost {
-  int64_t blocks = 0;         // 128-word blocks generated so far
+  int64_t blocks = 0;         // 128-word blocks consumed (prefetched, in the reference's terms) so far
   u64* dev = nullptr;         // device copy of all blocks
   int64_t dev_cap_blocks = 0;
   int64_t word = 0;           // engine state: linear word index
   int units = 4;              //               16-bit units left in that word
-  MtDev* mt = nullptr;        // device copy of the caller's mt19937 engine (fast path) or nullptr
+  // device continuation of the caller's mt19937 (fast path)
+  bool engine = false;
+  MtDev init;                 // the caller's engine at call start
+  int64_t a0 = 0;             // outputs left in its current array
+  int64_t arrays = 0;         // regenerated arrays launched so far: a0 + 624 * arrays outputs exist
+  bool started = false;
+  uint32_t* window = nullptr; // device: raw values of the newest array
+  volatile int* stop = nullptr;
+  SideStream* side = nullptr;
+  struct Mark {
+    int64_t upto32;           // outputs complete once `ev` has fired
+    hipEvent_t ev;
+  };
+  std::vector<Mark> marks;
+  size_t waited = 0;          // marks[0 .. waited) are already ordered before the main stream
+  int64_t generated32() const { return started ? a0 + 624 * arrays : 0; }
 };
 
+constexpr int64_t kSpecCapWords = 1ll << 20;  // speculation never runs more than 8 MB ahead
+
+// Launches generation on the side stream until at least `target32` outputs exist.
+int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
+  if (r.started && r.generated32() >= target32) return PYG_HIP_OK;
+  const int64_t m = std::max<int64_t>(0, (target32 - (r.a0 + 624 * r.arrays) + 623) / 624);
+  const int64_t new_gen = r.a0 + 624 * (r.arrays + m);
+  const int64_t need_cap = (new_gen + 2 + 255) / 256;
+  if (need_cap > r.dev_cap_blocks) {
+    const int64_t ncap = std::max<int64_t>(need_cap, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
+    u64* nd;
+    PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
+    if (r.started) {  // rare: the speculation cap was too small -- move what exists, in main-stream order
+      PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks.back().ev, 0));
+      r.waited = r.marks.size();
+      PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(uint32_t) * (size_t)(r.generated32() + 1),
+                                   hipMemcpyDeviceToDevice, c.stream));
+    }
+    // the block may be recycled from main-stream work that is still in flight
+    hipEvent_t ev;
+    int rc = r.side->next_event(&ev);
+    if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
+    PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
+    c.release(r.dev);
+    r.dev = nd;
+    r.dev_cap_blocks = ncap;
+  }
+  hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(256), 0, r.side->stream, r.init, r.window,
+                     reinterpret_cast<uint32_t*>(r.dev), r.arrays, m, const_cast<const int*>(r.stop));
+  PYG_HIP_CHECK(hipGetLastError());
+  hipEvent_t ev;
+  int rc = r.side->next_event(&ev);
+  if (rc != PYG_HIP_OK) return rc;
+  PYG_HIP_CHECK(hipEventRecord(ev, r.side->stream));
+  r.arrays += m;
+  r.started = true;
+  r.marks.push_back({r.generated32(), ev});
+  return PYG_HIP_OK;
+}
+
+// Adopts the caller's engine and starts generating on the side stream: `spec_words[h]` is the
+// cumulative number of words hop h may consume at most (16-bit draws), one launch per entry so that
+// early hops need not wait for the words of late ones.
+int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec_words) {
+  const pyg_hip_mt19937* e = c.host->mt19937;
+  PYG_HIP_REQUIRE(e->left > 0 && e->left <= 624 && e->next <= 624 && (int64_t)e->next + e->left <= 625,
+                  "sampler: invalid mt19937 engine state");
+  static_assert(sizeof(MtDev) == sizeof(pyg_hip_mt19937), "engine layouts must match");
+  ::memcpy(&r.init, e, sizeof(MtDev));
+  r.engine = true;
+  r.a0 = (int64_t)r.init.left - 1;
+  int rc = get_side_stream(&r.side);
+  if (rc != PYG_HIP_OK) return rc;
+  r.stop = reinterpret_cast<volatile int*>(static_cast<char*>(pinned) + 512);
+  *r.stop = 0;
+  c.side = r.side->stream;
+  c.side_stop = r.stop;
+  PYG_ALLOC(r.window, uint32_t*, c, sizeof(uint32_t) * 624);
+  // one allocation for everything the speculation may write
+  int64_t top = 128;
+  for (int64_t w : spec_words) top = std::max(top, std::min(w, kSpecCapWords));
+  {
+    const int64_t cap = (2 * top + 624 + r.a0 + 2 + 255) / 256 + 1;
+    PYG_ALLOC(r.dev, u64*, c, sizeof(u64) * 128 * (size_t)cap);
+    r.dev_cap_blocks = cap;
+    hipEvent_t ev;  // order the side stream after whatever used these blocks before
+    rc = r.side->next_event(&ev);
+    if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
+    PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
+  }
+  int64_t prev = 0;
+  for (int64_t w : spec_words) {
+    w = std::min(w, kSpecCapWords);
+    if (w <= prev) continue;
+    rc = rng_generate(c, r, 2 * w);
+    if (rc != PYG_HIP_OK) return rc;
+    prev = w;
+  }
+  // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
+  rc = rng_generate(c, r, 256);
+  if (rc != PYG_HIP_OK) return rc;
+  r.blocks = 1;
+  return PYG_HIP_OK;
+}
+
+// Makes every word up to `last_word` readable by work submitted to the main stream afterwards.
 int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
   const int64_t need_blocks = last_word / 128 + 1;
+  if (r.engine) {
+    const int64_t need32 = need_blocks * 256;
+    if (r.generated32() < need32) {  // beyond the speculation: top up with some slack
+      int rc = rng_generate(c, r, need32 + need32 / 4);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    size_t k = 0;
+    while (r.marks[k].upto32 < need32) ++k;
+    if (k >= r.waited) {
+      PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
+      r.waited = k + 1;
+    }
+    r.blocks = std::max(r.blocks, need_blocks);
+    return PYG_HIP_OK;
+  }
   if (need_blocks <= r.blocks) return PYG_HIP_OK;
   if (need_blocks > r.dev_cap_blocks) {
     const int64_t ncap = std::max<int64_t>(need_blocks, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
@@ -681,17 +987,6 @@ int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
     r.dev_cap_blocks = ncap;
   }
   const int64_t nnew = need_blocks - r.blocks;
-  if (r.mt) {
-    // continue the caller's engine on the device: no host work, no synchronisation
-    u64* dst = r.dev + r.blocks * 128;
-    hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(256), 0, c.stream, r.mt,
-                       reinterpret_cast<uint32_t*>(dst), nnew * 256);
-    hipLaunchKernelGGL(mt_fixup_kernel, dim3((unsigned)((nnew * 128 + 255) / 256)), dim3(256), 0, c.stream,
-                       dst, nnew * 128);
-    PYG_HIP_CHECK(hipGetLastError());
-    r.blocks = need_blocks;
-    return PYG_HIP_OK;
-  }
   std::vector<int64_t> tmp((size_t)nnew * 128);
   c.host->rng_blocks(c.host->user, tmp.data(), nnew, r.blocks == 0 ? 1 : 0);
   // pageable -> device; the vector dies at scope exit, so make the copy synchronous
@@ -699,6 +994,33 @@ int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
                                hipMemcpyHostToDevice, c.stream));
   PYG_HIP_CHECK(hipStreamSynchronize(c.stream));
   r.blocks = need_blocks;
+  return PYG_HIP_OK;
+}
+
+// Hands the advanced engine back (queued on the main stream; the caller synchronises it).
+int rng_finish(Ctx& c, RngHost& r) {
+  if (!r.engine) return PYG_HIP_OK;
+  const int64_t n32 = r.blocks * 256;
+  pyg_hip_mt19937* e = c.host->mt19937;
+  if (n32 <= r.a0) {
+    PYG_HIP_CHECK(hipEventSynchronize(r.marks[0].ev));
+    c.quiesce_side();
+    e->left = (int32_t)(r.init.left - n32);
+    e->next = (uint32_t)(r.init.next + n32);
+    return PYG_HIP_OK;
+  }
+  // every consumed block was waited for, and launches produce whole arrays: the final array exists
+  size_t k = 0;
+  while (r.marks[k].upto32 < n32) ++k;
+  // the launch that produces the last consumed words must not be cancelled below
+  PYG_HIP_CHECK(hipEventSynchronize(r.marks[k].ev));
+  MtDev* out;
+  PYG_ALLOC(out, MtDev*, c, sizeof(MtDev));
+  hipLaunchKernelGGL(mt_finish_kernel, dim3(1), dim3(256), 0, c.stream,
+                     reinterpret_cast<const uint32_t*>(r.dev), r.a0, n32, out);
+  PYG_HIP_CHECK(hipGetLastError());
+  PYG_HIP_CHECK(hipMemcpyAsync(e, out, sizeof(MtDev), hipMemcpyDeviceToHost, c.stream));
+  c.quiesce_side();
   return PYG_HIP_OK;
 }
 
@@ -733,15 +1055,37 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   }
 
   if (c.host->mt19937) {
-    static_assert(sizeof(MtDev) == sizeof(pyg_hip_mt19937), "engine layouts must match");
-    PYG_HIP_REQUIRE(c.host->mt19937->left > 0 && c.host->mt19937->left <= 624 && c.host->mt19937->next <= 624,
-                    "sampler: invalid mt19937 engine state");
-    PYG_ALLOC(rng.mt, MtDev*, c, sizeof(MtDev));
-    PYG_HIP_CHECK(hipMemcpyAsync(rng.mt, c.host->mt19937, sizeof(MtDev), hipMemcpyHostToDevice, stream));
-    PYG_HIP_CHECK(hipStreamSynchronize(stream));  // the host struct may be pageable
-  }
-  // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
-  {
+    // upper bounds of the words each hop can consume: every frontier node draws `count` 16-bit numbers
+    std::vector<int64_t> spec;
+    std::vector<double> fb((size_t)num_node_types, 0.0);
+    for (int s = 0; s < num_seed_sets; ++s)
+      if (seeds[s].node_type >= 0 && seeds[s].node_type < num_node_types)
+        fb[(size_t)seeds[s].node_type] += (double)seeds[s].num_seed;
+    double cum = 128.0;
+    for (int ell = 0; ell < L; ++ell) {
+      std::vector<double> nf((size_t)num_node_types, 0.0);
+      double draws = 0.0;
+      bool open_ended = false;
+      for (int e = 0; e < num_relations; ++e) {
+        const int src = !csc ? rels[e].src_type : rels[e].dst_type;
+        const int dst = !csc ? rels[e].dst_type : rels[e].src_type;
+        const int64_t count = rels[e].num_neighbors_host[ell];
+        if (count < 0) {
+          open_ended = open_ended || fb[(size_t)src] > 0;
+          continue;
+        }
+        draws += fb[(size_t)src] * (double)count;
+        nf[(size_t)dst] += fb[(size_t)src] * (double)count;
+      }
+      cum += draws / 4.0 + 128.0;
+      spec.push_back((int64_t)std::min<double>(cum, (double)kSpecCapWords));
+      if (open_ended || cum >= (double)kSpecCapWords) break;  // later frontiers are unbounded / too far ahead
+      fb.swap(nf);
+    }
+    int rc = rng_begin(c, rng, pinned, spec);
+    if (rc != PYG_HIP_OK) return rc;
+  } else {
+    // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
     int rc = rng_ensure(c, rng, 0);
     if (rc != PYG_HIP_OK) return rc;
   }
@@ -865,8 +1209,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         PYG_HIP_REQUIRE(*herr == 0, "Found invalid non-sorted temporal neighborhood");
       }
       const int64_t E = tot.edges;
-      const int64_t end_word = rng.word + tot.tab.dw[rng.units];
-      const int end_units = tot.tab.nb[rng.units];
+      const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
+      const int end_units = tab_nb(tot.tab, rng.units);
       c.release(tile_buf);
       pt.lap(1);
       if (E == 0) {
@@ -925,7 +1269,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       a.e_eid = st.eid.p + st.eid.size;
       a.e_slot = e_slot;
       a.table = dn.table;
-      hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, a);
+      launch_sample(a, F, stream);
       PYG_HIP_CHECK(hipGetLastError());
 
       // 4. first occurrences -> ranks -> new local ids / appended nodes
@@ -1013,8 +1357,10 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     for (int l = 0; l < L; ++l) res->edges_per_hop_host[(size_t)e * L + l] = st.edges_per_hop[(size_t)l];
   }
   res->rng_blocks = rng.blocks;
-  if (rng.mt)  // hand the advanced engine back
-    PYG_HIP_CHECK(hipMemcpyAsync(c.host->mt19937, rng.mt, sizeof(MtDev), hipMemcpyDeviceToHost, stream));
+  {
+    int rc = rng_finish(c, rng);  // hand the advanced engine back
+    if (rc != PYG_HIP_OK) return rc;
+  }
   PYG_HIP_CHECK(hipStreamSynchronize(stream));
   pt.lap(7);
   return PYG_HIP_OK;
@@ -1055,13 +1401,11 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   if (temporal) PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
   if (edge_time) PYG_HIP_REQUIRE(seed_time != nullptr, "Seed time needs to be specified");
   if (c.host->mt19937) {
-    PYG_HIP_REQUIRE(c.host->mt19937->left > 0 && c.host->mt19937->left <= 624 && c.host->mt19937->next <= 624,
-                    "sampler: invalid mt19937 engine state");
-    PYG_ALLOC(rng.mt, MtDev*, c, sizeof(MtDev));
-    PYG_HIP_CHECK(hipMemcpyAsync(rng.mt, c.host->mt19937, sizeof(MtDev), hipMemcpyHostToDevice, stream));
-    PYG_HIP_CHECK(hipStreamSynchronize(stream));
-  }
-  {
+    std::vector<int64_t> spec;
+    if (count > 0) spec.push_back(std::min<int64_t>(kSpecCapWords, 256 + (int64_t)((double)S * (double)count / 4.0)));
+    int rc = rng_begin(c, rng, pinned, spec);
+    if (rc != PYG_HIP_OK) return rc;
+  } else {
     int rc = rng_ensure(c, rng, 0);
     if (rc != PYG_HIP_OK) return rc;
   }
@@ -1122,7 +1466,7 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     for (int64_t i = 0; i + 1 < S; ++i) cumsum_host[1 + i] = S + cumsum_host[2 + i];
     cumsum_host[S] = S + E;
     if (E > 0) {
-      const int64_t end_word = rng.word + tot.tab.dw[rng.units];
+      const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
       rc = rng_ensure(c, rng, end_word);
       if (rc != PYG_HIP_OK) return rc;
       PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
@@ -1150,7 +1494,7 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
       a.e_eid = e_eid;
       a.e_slot = nullptr;
       a.table = HashTable{nullptr, nullptr, 0};
-      hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, stream, a);
+      launch_sample(a, S, stream);
       PYG_HIP_CHECK(hipGetLastError());
     }
   }
@@ -1167,7 +1511,10 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   *num_edges = E;
   c.keep(nodes_out);
   c.keep(e_eid);
-  if (rng.mt) PYG_HIP_CHECK(hipMemcpyAsync(c.host->mt19937, rng.mt, sizeof(MtDev), hipMemcpyDeviceToHost, stream));
+  {
+    int rc = rng_finish(c, rng);
+    if (rc != PYG_HIP_OK) return rc;
+  }
   PYG_HIP_CHECK(hipStreamSynchronize(stream));
   return PYG_HIP_OK;
 }
@@ -1206,6 +1553,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   c.stream = static_cast<hipStream_t>(stream_);
   int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time,
                        temporal_last, L, csc, replace, disjoint, return_edge_id, c, result);
+  c.quiesce_side();
   if (rc != PYG_HIP_OK) {
     (void)hipStreamSynchronize(c.stream);
   }
@@ -1228,6 +1576,7 @@ extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t
   c.stream = static_cast<hipStream_t>(stream_);
   int rc = run_dist_sampler(rowptr, col, seed, num_seed, num_neighbors, node_time, edge_time, seed_time,
                             temporal_last, replace, disjoint, c, node_id, edge_id, num_edges, cumsum_host);
+  c.quiesce_side();
   if (rc != PYG_HIP_OK) (void)hipStreamSynchronize(c.stream);
   c.release_all();
   return rc;

@@ -68,10 +68,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, in
   __shared__ T lds[8];
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  // loads are unconditional (index clamped) so that the gathers of all items issue back to back
+  T v[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) v[k] = load(base + k < n ? base + k : n - 1);
   T agg = Op::identity();
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
-    if (base + k < n) agg = op(agg, load(base + k));
+    if (base + k < n) agg = op(agg, v[k]);
   T total;
   (void)block_exclusive<T, Op>(agg, lds, op, &total);
   if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
@@ -105,10 +109,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Sto
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   T v[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) v[k] = load(base + k < n ? base + k : n - 1);
   T agg = Op::identity();
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
-    v[k] = base + k < n ? load(base + k) : Op::identity();
+    if (base + k >= n) v[k] = Op::identity();
     agg = op(agg, v[k]);
   }
   T total;
