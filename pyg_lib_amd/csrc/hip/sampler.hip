@@ -621,59 +621,87 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
   return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// mt19937_engine::next_state() is the linear recurrence x[n+624] = x[n+397] ^ twist(x[n], x[n+1])
-// evaluated in place one 624-array at a time; element n only needs values at least 227 positions
-// back, so one workgroup produces 227 new values per step (one barrier each) in a 1024-word
-// circular LDS window -- the same numbers in the same order, ~4x fewer dependent steps than a
-// per-array update.  One launch continues from array A_from (held in `window`, or in `init` for
-// A_0) and produces arrays A_from+1 .. A_from+m, leaving A_from+m in `window`.  The kernel runs on a
-// side stream ahead of the sampling kernels (speculatively: the exact consumption of a hop is only
-// known after its count scan); `stop` (pinned host memory) lets the host cancel what nobody will read.
-constexpr int kMtStep = 227;
+// mt19937_engine::next_state() is the linear recurrence x[n] = x[n-227] ^ T(x[n-624], x[n-623])
+// (T = twist) evaluated in place one 624-array at a time.  Substituting x[n-227] once more gives
+//     x[n] = x[n-454] ^ T(x[n-851], x[n-850]) ^ T(x[n-624], x[n-623]),
+// whose newest operand lies 454 positions back: 454 new values per step (one per thread), the
+// same numbers in the same order, 2.7x fewer dependent steps than array-at-a-time.  x[n-454] is the
+// value the same thread produced one step earlier (a register); the others come from a 2048-word
+// circular LDS window.  The kernel is issue/latency-bound on one CU, so the step barrier only waits
+// for LDS (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads() would also drain the global stores.
+// One launch continues from array A_from (held in `window`, or in `init` for A_0) and produces arrays
+// A_from+1 .. A_from+m, leaving A_from+m in `window`; the first two steps use the plain recurrence
+// because only 624 values of history exist.  The kernel runs on a side stream ahead of the sampling
+// kernels (speculatively: the exact consumption of a hop is only known after its count scan);
+// `stop` (pinned host memory) lets the host cancel what nobody will read.
+constexpr int kMtThreads = 512;
+constexpr int kMtStep = 454;
 
-__global__ __launch_bounds__(256) void mt_generate_kernel(const MtDev init, uint32_t* __restrict__ window,
-                                                          uint32_t* __restrict__ out32, int64_t from, int64_t m,
-                                                          const int* stop) {
-  __shared__ uint32_t x[1024];  // x-stream index n lives at x[n & 1023]; x[0..623] = array A_from
+__device__ __forceinline__ void mt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev init, uint32_t* __restrict__ window,
+                                                                 uint32_t* __restrict__ out32, int64_t from,
+                                                                 int64_t m, const int* stop) {
+  __shared__ uint32_t x[2048];  // x-stream index n lives at x[n & 2047]; x[0..623] = array A_from
   __shared__ int stop_s;
   const int tid = threadIdx.x;
   const int64_t a0 = (int64_t)init.left - 1;
-  auto emit = [&](int64_t o, uint32_t raw) {
-    const uint32_t y = mt_temper(raw);
-    // little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
-    if ((o & 1) == 0) out32[o + 1] = y ^ 0x80000000u;
-    else out32[o - 1] = y;
+  const int64_t o_base = a0 + 624 * from - 624;  // output index of x-stream position n is o_base + n
+  uint32_t* const obase = out32 + o_base;
+  const uint32_t par = (uint32_t)(o_base & 1);
+  // little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
+  auto emit = [&](uint32_t n, uint32_t raw) {
+    const uint32_t odd = (n + par) & 1u;
+    obase[(int64_t)n + 1 - 2 * (int64_t)odd] = mt_temper(raw) ^ (odd ? 0u : 0x80000000u);
   };
   if (from == 0) {
-    for (int i = tid; i < 624; i += 256) x[i] = init.state[i];
+    for (int i = tid; i < 624; i += kMtThreads) x[i] = init.state[i];
     __syncthreads();
-    for (int64_t q = tid; q < a0; q += 256) emit(q, x[init.next + q]);
+    // the a0 outputs still held by the caller's current array: output q <- state[next + q]
+    for (int64_t q = tid; q < a0; q += kMtThreads) {
+      const uint32_t y = mt_temper(x[init.next + q]);
+      if ((q & 1) == 0) out32[q + 1] = y ^ 0x80000000u;
+      else out32[q - 1] = y;
+    }
   } else {
-    for (int i = tid; i < 624; i += 256) x[i] = window[i];
+    for (int i = tid; i < 624; i += kMtThreads) x[i] = window[i];
     __syncthreads();
   }
   if (m <= 0) {
-    if (from == 0) for (int i = tid; i < 624; i += 256) window[i] = x[i];
+    if (from == 0) for (int i = tid; i < 624; i += kMtThreads) window[i] = x[i];
     return;
   }
-  const int64_t o_base = a0 + 624 * from - 624;  // output index of x-stream position 0 ... + n
-  const int64_t gen_end = 624 * (m + 1);         // produce x[624 .. gen_end)
+  const uint32_t gen_end = (uint32_t)(624 * (m + 1));  // produce x[624 .. gen_end)
+  // two plain steps of 227: history grows to 1078 values
+  uint32_t n0 = 624;
+  for (int k = 0; k < 2; ++k, n0 += 227) {
+    const uint32_t n = n0 + tid;
+    if (tid < 227 && n < gen_end) {
+      const uint32_t v = x[(n - 227) & 2047] ^ mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
+      x[n & 2047] = v;
+      emit(n, v);
+    }
+    mt_lds_barrier();
+  }
+  uint32_t prev = x[(n0 + tid - kMtStep) & 2047];  // x[n - 454] of this thread's element
   int step = 0;
-  for (int64_t n0 = 624; n0 < gen_end; n0 += kMtStep, ++step) {
+  for (; n0 < gen_end; n0 += kMtStep, ++step) {
     if ((step & 63) == 63) {
       if (tid == 0) stop_s = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __syncthreads();
       if (stop_s) return;  // cancelled: nothing past the consumed words is ever read
     }
-    const int64_t n = n0 + tid;
+    const uint32_t n = n0 + tid;
     if (tid < kMtStep && n < gen_end) {
-      const uint32_t v = x[(n - 227) & 1023] ^ mt_twist(x[(n - 624) & 1023], x[(n - 623) & 1023]);
-      x[n & 1023] = v;  // slot of x[n - 1024]: no longer needed by this or any later step
-      emit(o_base + n, v);
+      const uint32_t v = prev ^ mt_twist(x[(n - 851) & 2047], x[(n - 850) & 2047]) ^
+                         mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
+      x[n & 2047] = v;  // slot of x[n - 2048]: no longer needed by this or any later step
+      prev = v;
+      emit(n, v);
     }
-    __syncthreads();
+    mt_lds_barrier();
   }
-  for (int i = tid; i < 624; i += 256) window[i] = x[(624 * m + i) & 1023];
+  for (int i = tid; i < 624; i += kMtThreads) window[i] = x[(624 * (uint32_t)m + i) & 2047];
 }
 
 // Engine state after consuming n32 > a0 outputs: the array that holds the last consumed output, fully
@@ -741,9 +769,10 @@ struct DevVec {
   int64_t* p = nullptr;
   int64_t size = 0;
   int64_t cap = 0;
-  int reserve(Ctx& c, int64_t n) {
+  // `hint`: expected final size (later hops included), so that one allocation usually lasts the call
+  int reserve(Ctx& c, int64_t n, int64_t hint = 0) {
     if (n <= cap) return PYG_HIP_OK;
-    const int64_t ncap = std::max<int64_t>(n, std::max<int64_t>(2 * cap, 1024));
+    const int64_t ncap = std::max<int64_t>(std::max<int64_t>(n, hint), std::max<int64_t>(2 * cap, 1024));
     int64_t* np;
     PYG_ALLOC(np, int64_t*, c, sizeof(int64_t) * (size_t)ncap);
     if (size > 0)
@@ -764,27 +793,28 @@ struct NodeSet {
   int64_t entries_bound = 0;  // upper bound of keys present in the table
 };
 
-int table_reserve(Ctx& c, NodeSet& ns, int64_t extra) {
+// keys and vals share one block (one allocation, one memset); `hint` = entries expected by the end of
+// the call, so that the table is usually built once instead of being rehashed every hop.
+int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   const int64_t need = ns.entries_bound + extra;
   u64 cap = ns.table.keys ? ns.table.mask + 1 : 0;
   if (cap >= 2 * (u64)need && cap > 0) {
     ns.entries_bound = need;
     return PYG_HIP_OK;
   }
+  const int64_t want = std::max<int64_t>(need, std::min<int64_t>(hint, 1ll << 20));
   u64 ncap = 1024;
-  while (ncap < 4 * (u64)need) ncap <<= 1;
+  while (ncap < 4 * (u64)need || ncap < 2 * (u64)want) ncap <<= 1;
   HashTable nt;
-  PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * ncap);
-  PYG_ALLOC(nt.vals, u64*, c, sizeof(u64) * ncap);
+  PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * 2 * ncap);
+  nt.vals = nt.keys + ncap;
   nt.mask = ncap - 1;
-  PYG_HIP_CHECK(hipMemsetAsync(nt.keys, 0xFF, sizeof(u64) * ncap, c.stream));
-  PYG_HIP_CHECK(hipMemsetAsync(nt.vals, 0xFF, sizeof(u64) * ncap, c.stream));
+  PYG_HIP_CHECK(hipMemsetAsync(nt.keys, 0xFF, sizeof(u64) * 2 * ncap, c.stream));
   if (ns.table.keys) {
     hipLaunchKernelGGL(rehash_kernel, dim3((unsigned)std::min<u64>((cap + 255) / 256, 4096)),
                        dim3(256), 0, c.stream, ns.table, nt);
     PYG_HIP_CHECK(hipGetLastError());
     c.release(ns.table.keys);
-    c.release(ns.table.vals);
   }
   ns.table = nt;
   ns.entries_bound = need;
@@ -897,7 +927,7 @@ int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
     r.dev = nd;
     r.dev_cap_blocks = ncap;
   }
-  hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(256), 0, r.side->stream, r.init, r.window,
+  hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(kMtThreads), 0, r.side->stream, r.init, r.window,
                      reinterpret_cast<uint32_t*>(r.dev), r.arrays, m, const_cast<const int*>(r.stop));
   PYG_HIP_CHECK(hipGetLastError());
   hipEvent_t ev;
@@ -1099,8 +1129,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   if (temporal) {
     PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
     PYG_ALLOC(seed_times, int64_t*, c, sizeof(int64_t) * (size_t)num_batches);
-    PYG_ALLOC(err_flag, int*, c, sizeof(int));
-    PYG_HIP_CHECK(hipMemsetAsync(err_flag, 0, sizeof(int), stream));
+    // kernels raise the flag straight in pinned host memory: no copy, no extra synchronisation
+    err_flag = reinterpret_cast<int*>(static_cast<char*>(pinned) + 256);
+    *err_flag = 0;
   }
 
   // ---- seeds ----
@@ -1145,12 +1176,11 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
     FlagLoad fl{slots, n.table.vals};
     AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, tile_buf + ntiles, stream);
+    // scan totals land directly in pinned host memory (device-visible): no D2H copy to launch
+    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, static_cast<int64_t*>(pinned), stream);
     if (rc != PYG_HIP_OK) return rc;
-    PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost,
-                                 stream));
     PYG_HIP_CHECK(hipStreamSynchronize(stream));
-    n.distinct = *static_cast<int64_t*>(pinned);
+    n.distinct = *static_cast<volatile int64_t*>(pinned);
     n.nodes.size = S;
     if (disjoint) n.batch.size = S;
     c.release(slots);
@@ -1196,18 +1226,15 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       range.error = err_flag;
       CountLoad cl{sn.nodes.p, sn.slice_b, range, count, replace};
       CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
-      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, tile_buf + ntiles, stream);
+      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, static_cast<CountAgg*>(pinned), stream);
       if (rc != PYG_HIP_OK) return rc;
-      PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(CountAgg), hipMemcpyDeviceToHost,
-                                   stream));
       PYG_HIP_CHECK(hipStreamSynchronize(stream));
-      const CountAgg tot = *static_cast<CountAgg*>(pinned);
-      if (range.time) {
-        int* herr = reinterpret_cast<int*>(static_cast<char*>(pinned) + 256);
-        PYG_HIP_CHECK(hipMemcpyAsync(herr, err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
-        PYG_HIP_CHECK(hipStreamSynchronize(stream));
-        PYG_HIP_REQUIRE(*herr == 0, "Found invalid non-sorted temporal neighborhood");
-      }
+      CountAgg tot;
+      tot.edges = static_cast<volatile CountAgg*>(pinned)->edges;
+      tot.tab = static_cast<volatile CountAgg*>(pinned)->tab;
+      if (range.time)
+        PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
+                        "Found invalid non-sorted temporal neighborhood");
       const int64_t E = tot.edges;
       const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
       const int end_units = tab_nb(tot.tab, rng.units);
@@ -1227,20 +1254,28 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       pt.lap(2);
 
       // 3. sample + insert
-      rc = st.row.reserve(c, st.row.size + E);
+      // Expected growth over the remaining hops (this relation's own fan-outs, every node expanding
+      // fully): sizes the outputs and the hash table once instead of copying / rehashing them per hop.
+      double mult = 1.0, term = 1.0;
+      for (int l2 = ell + 1; l2 < L && r.num_neighbors_host[l2] > 0; ++l2) {
+        term *= (double)r.num_neighbors_host[l2];
+        mult += term;
+      }
+      const int64_t grow = (int64_t)std::min<double>((double)E * mult, 16.0 * 1024 * 1024);
+      rc = st.row.reserve(c, st.row.size + E, st.row.size + grow);
       if (rc != PYG_HIP_OK) return rc;
-      rc = st.col.reserve(c, st.col.size + E);
+      rc = st.col.reserve(c, st.col.size + E, st.col.size + grow);
       if (rc != PYG_HIP_OK) return rc;
       // edge ids are always produced: they double as the chosen-set history of large fan-outs
-      rc = st.eid.reserve(c, st.eid.size + E);
+      rc = st.eid.reserve(c, st.eid.size + E, st.eid.size + grow);
       if (rc != PYG_HIP_OK) return rc;
-      rc = dn.nodes.reserve(c, dn.nodes.size + E);
+      rc = dn.nodes.reserve(c, dn.nodes.size + E, dn.nodes.size + grow);
       if (rc != PYG_HIP_OK) return rc;
       if (disjoint) {
-        rc = dn.batch.reserve(c, dn.batch.size + E);
+        rc = dn.batch.reserve(c, dn.batch.size + E, dn.batch.size + grow);
         if (rc != PYG_HIP_OK) return rc;
       }
-      rc = table_reserve(c, dn, E);
+      rc = table_reserve(c, dn, E, dn.entries_bound + grow);
       if (rc != PYG_HIP_OK) return rc;
       int64_t* e_node;
       int64_t* e_batch = nullptr;
@@ -1279,18 +1314,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       FlagLoad fl{e_slot, dn.table.vals};
       AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
                      disjoint ? dn.batch.p : (int64_t*)nullptr, dn.nodes.size, dn.distinct, 1};
-      rc = device_scan<int64_t, SumOp>(fl, as, E, ftile, ftile + etiles, stream);
+      int64_t* u_host = reinterpret_cast<int64_t*>(static_cast<char*>(pinned) + 64);
+      rc = device_scan<int64_t, SumOp>(fl, as, E, ftile, u_host, stream);
       if (rc != PYG_HIP_OK) return rc;
       // 5. local ids of every emitted edge
       hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream,
                          e_slot, dn.table.vals, E, st.col.p + st.col.size);
       PYG_HIP_CHECK(hipGetLastError());
-      PYG_HIP_CHECK(hipMemcpyAsync(pinned, ftile + etiles, sizeof(int64_t), hipMemcpyDeviceToHost,
-                                   stream));
       pt.lap(4);
       PYG_HIP_CHECK(hipStreamSynchronize(stream));
       pt.lap(5);
-      const int64_t U = *static_cast<int64_t*>(pinned);
+      const int64_t U = *static_cast<volatile int64_t*>(u_host);
       dn.nodes.size += U;
       if (disjoint) dn.batch.size += U;
       dn.distinct += U;
