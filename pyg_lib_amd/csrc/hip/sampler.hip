@@ -317,7 +317,22 @@ struct CountStore {
   }
 };
 
+// Device-resident results of one hop of one relation; published to pinned host memory by the hop's
+// last kernel so that the host needs ONE synchronisation per hop.
+struct HopInfo {
+  CountAgg tot;      // count-scan total: emitted edges + RNG transition table of the whole frontier
+  int64_t uniq;      // nodes seen for the first time
+  int32_t overflow;  // the hop needs random words beyond the generated ones: nothing was sampled
+  int32_t pad;
+};
+
 struct HopArgs {
+  // run-ahead mode (info != nullptr): the kernel is launched before the host knows the count-scan
+  // total; it checks on its own that every random word it may read has been generated
+  HopInfo* info = nullptr;
+  int64_t word0 = 0;          // engine position at the start of the hop
+  int units0 = 4;
+  int64_t avail_blocks = 0;   // 128-word blocks readable by this launch
   const int64_t* nodes;       // src node list (positions are the emitted `row`)
   const int64_t* batch;       // src batch ids (disjoint) or nullptr
   int64_t begin;              // frontier begin (position of frontier node 0)
@@ -380,8 +395,19 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Run-ahead guard: true (for every thread of the launch alike) when the hop would read random words
+// that do not exist yet; the host then generates them and repeats the hop.
+__device__ __forceinline__ bool hop_overflow(const HopArgs& a) {
+  if (!a.info) return false;
+  const int64_t end_word = a.word0 + tab_dw(a.info->tot.tab, a.units0);
+  const bool over = a.info->tot.edges > 0 && end_word / 128 + 1 > a.avail_blocks;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.info->overflow = over ? 1 : 0;
+  return over;
+}
+
 // One wave per frontier node (_sample, neighbor_kernel.cpp:177-243).
 __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
+  if (hop_overflow(a)) return;
   const int lane = threadIdx.x & 63;
   const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (i >= a.frontier) return;
@@ -446,6 +472,7 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
 // (rand_engine.h:41-76): the current word still serves u / n draws, every later word 4 / n.
 template <int G>
 __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
+  if (hop_overflow(a)) return;
   const int lane = threadIdx.x & 63;
   const int g = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -521,7 +548,9 @@ __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
 struct FlagLoad {
   const u64* slots;
   const u64* vals;
+  const HopInfo* info;  // run-ahead mode: emissions [0, info->tot.edges) exist (none after an overflow)
   __device__ int64_t operator()(int64_t p) const {
+    if (info && (p >= info->tot.edges || info->overflow)) return 0;
     return vals[slots[p]] == kProvisional + (u64)p ? 1 : 0;
   }
 };
@@ -547,8 +576,11 @@ struct AssignStore {
 };
 
 __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __restrict__ vals,
-                                int64_t n, int64_t* __restrict__ out_col) {
+                                int64_t n, int64_t* __restrict__ out_col, const HopInfo* __restrict__ info,
+                                HopInfo* __restrict__ publish) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p == 0 && publish) *publish = *info;  // pinned host memory: read by the host after the hop's sync
+  if (info && (p >= info->tot.edges || info->overflow)) return;
   if (p < n) out_col[p] = (int64_t)vals[slots[p]];
 }
 
@@ -642,7 +674,9 @@ __device__ __forceinline__ void mt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev init, uint32_t* __restrict__ window,
                                                                  uint32_t* __restrict__ out32, int64_t from,
                                                                  int64_t m, const int* stop) {
-  __shared__ uint32_t x[2048];  // x-stream index n lives at x[n & 2047]; x[0..623] = array A_from
+  // x-stream index n lives at x[n & 2047]; x[0..623] = array A_from.  x[2048] mirrors x[0] so that the
+  // operand pairs (x[k], x[k+1]) are always adjacent (one ds_read2_b32 each).
+  __shared__ uint32_t x[2048 + 1];
   __shared__ int stop_s;
   const int tid = threadIdx.x;
   const int64_t a0 = (int64_t)init.left - 1;
@@ -654,8 +688,12 @@ __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev ini
     const uint32_t odd = (n + par) & 1u;
     obase[(int64_t)n + 1 - 2 * (int64_t)odd] = mt_temper(raw) ^ (odd ? 0u : 0x80000000u);
   };
+  auto put = [&](uint32_t slot, uint32_t v) {
+    x[slot] = v;
+    if (slot == 0) x[2048] = v;
+  };
   if (from == 0) {
-    for (int i = tid; i < 624; i += kMtThreads) x[i] = init.state[i];
+    for (int i = tid; i < 624; i += kMtThreads) put(i, init.state[i]);
     __syncthreads();
     // the a0 outputs still held by the caller's current array: output q <- state[next + q]
     for (int64_t q = tid; q < a0; q += kMtThreads) {
@@ -664,7 +702,7 @@ __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev ini
       else out32[q - 1] = y;
     }
   } else {
-    for (int i = tid; i < 624; i += kMtThreads) x[i] = window[i];
+    for (int i = tid; i < 624; i += kMtThreads) put(i, window[i]);
     __syncthreads();
   }
   if (m <= 0) {
@@ -678,12 +716,17 @@ __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev ini
     const uint32_t n = n0 + tid;
     if (tid < 227 && n < gen_end) {
       const uint32_t v = x[(n - 227) & 2047] ^ mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
-      x[n & 2047] = v;
+      put(n & 2047, v);
       emit(n, v);
     }
     mt_lds_barrier();
   }
-  uint32_t prev = x[(n0 + tid - kMtStep) & 2047];  // x[n - 454] of this thread's element
+  // main loop: the step is even, so each thread keeps its slot arithmetic, output parity and pointer
+  uint32_t slot = (n0 + tid) & 2047;
+  uint32_t prev = x[(slot + 2048 - kMtStep) & 2047];  // x[n - 454] of this thread's element
+  const uint32_t odd = (n0 + tid + par) & 1u;
+  const uint32_t flip = odd ? 0u : 0x80000000u;
+  uint32_t* op = obase + ((int64_t)(n0 + tid) + 1 - 2 * (int64_t)odd);
   int step = 0;
   for (; n0 < gen_end; n0 += kMtStep, ++step) {
     if ((step & 63) == 63) {
@@ -691,14 +734,18 @@ __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev ini
       __syncthreads();
       if (stop_s) return;  // cancelled: nothing past the consumed words is ever read
     }
-    const uint32_t n = n0 + tid;
-    if (tid < kMtStep && n < gen_end) {
-      const uint32_t v = prev ^ mt_twist(x[(n - 851) & 2047], x[(n - 850) & 2047]) ^
-                         mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
-      x[n & 2047] = v;  // slot of x[n - 2048]: no longer needed by this or any later step
+    const uint32_t left = gen_end - n0;
+    const uint32_t lim = left < (uint32_t)kMtStep ? left : (uint32_t)kMtStep;
+    if ((uint32_t)tid < lim) {
+      const uint32_t s1 = (slot + (2048 - 851)) & 2047;
+      const uint32_t s2 = (slot + (2048 - 624)) & 2047;
+      const uint32_t v = prev ^ mt_twist(x[s1], x[s1 + 1]) ^ mt_twist(x[s2], x[s2 + 1]);
+      put(slot, v);  // slot of x[n - 2048]: no longer needed by this or any later step
       prev = v;
-      emit(n, v);
+      *op = mt_temper(v) ^ flip;
     }
+    slot = (slot + kMtStep) & 2047;
+    op += kMtStep;
     mt_lds_barrier();
   }
   for (int i = tid; i < 624; i += kMtThreads) window[i] = x[(624 * (uint32_t)m + i) & 2047];
@@ -986,21 +1033,32 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
   return PYG_HIP_OK;
 }
 
-// Makes every word up to `last_word` readable by work submitted to the main stream afterwards.
+// Device engine only: orders the words up to `last_word` (and whatever else the same launch produced)
+// before work submitted to the main stream afterwards; `avail_blocks` = whole 128-word blocks covered.
+// No consumption accounting: also used for words a hop MAY read.
+int rng_wait(Ctx& c, RngHost& r, int64_t last_word, int64_t* avail_blocks) {
+  const int64_t need32 = (last_word / 128 + 1) * 256;
+  if (r.generated32() < need32) {  // beyond the speculation: top up with some slack
+    int rc = rng_generate(c, r, need32 + need32 / 4);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  size_t k = 0;
+  while (r.marks[k].upto32 < need32) ++k;
+  if (k >= r.waited) {
+    PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
+    r.waited = k + 1;
+  }
+  if (avail_blocks) *avail_blocks = r.marks[r.waited - 1].upto32 / 256;
+  return PYG_HIP_OK;
+}
+
+// Makes every word up to `last_word` readable by work submitted to the main stream afterwards and
+// counts its blocks as drawn from the caller's generator.
 int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
   const int64_t need_blocks = last_word / 128 + 1;
   if (r.engine) {
-    const int64_t need32 = need_blocks * 256;
-    if (r.generated32() < need32) {  // beyond the speculation: top up with some slack
-      int rc = rng_generate(c, r, need32 + need32 / 4);
-      if (rc != PYG_HIP_OK) return rc;
-    }
-    size_t k = 0;
-    while (r.marks[k].upto32 < need32) ++k;
-    if (k >= r.waited) {
-      PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
-      r.waited = k + 1;
-    }
+    int rc = rng_wait(c, r, last_word, nullptr);
+    if (rc != PYG_HIP_OK) return rc;
     r.blocks = std::max(r.blocks, need_blocks);
     return PYG_HIP_OK;
   }
@@ -1191,6 +1249,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   pt.lap(0);
 
   // ---- hops ----
+  HopInfo* info_dev;
+  PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo));
   for (int ell = 0; ell < L; ++ell) {
     for (int e = 0; e < num_relations; ++e) {
       const pyg_hip_relation& r = rels[e];
@@ -1204,7 +1264,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       st.edges_per_hop.push_back(0);
       if (F <= 0 || count == 0 || r.num_cols == 0) continue;
 
-      // 1. per-node edge counts + RNG transition tables -> exclusive scan
+      // 1. per-node edge counts + RNG transition tables -> exclusive scan (total -> info_dev->tot)
       const int64_t ntiles = (F + kScanTile - 1) / kScanTile;
       CountAgg* tile_buf;
       PYG_ALLOC(tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
@@ -1226,31 +1286,43 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       range.error = err_flag;
       CountLoad cl{sn.nodes.p, sn.slice_b, range, count, replace};
       CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
-      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, static_cast<CountAgg*>(pinned), stream);
+      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev->tot, stream);
       if (rc != PYG_HIP_OK) return rc;
-      PYG_HIP_CHECK(hipStreamSynchronize(stream));
-      CountAgg tot;
-      tot.edges = static_cast<volatile CountAgg*>(pinned)->edges;
-      tot.tab = static_cast<volatile CountAgg*>(pinned)->tab;
-      if (range.time)
-        PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
-                        "Found invalid non-sorted temporal neighborhood");
-      const int64_t E = tot.edges;
-      const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
-      const int end_units = tab_nb(tot.tab, rng.units);
-      c.release(tile_buf);
-      pt.lap(1);
-      if (E == 0) {
-        c.release(edge_off);
-        c.release(rng_word);
-        c.release(rng_units);
-        continue;
+
+      // Run-ahead: with a bounded fan-out the hop's kernels are queued behind the count scan without
+      // waiting for its total -- buffers are sized for the bound F * count, the kernels read the exact
+      // edge count from `info_dev`, and the words the hop may read (16-bit draws) are already being
+      // generated.  One synchronisation per hop instead of two.  Unbounded / large fan-outs and the
+      // host-callback word source (which must draw exactly what is consumed) learn the total first.
+      volatile HopInfo* info_host = static_cast<volatile HopInfo*>(pinned);
+      const bool presync = count < 0 || count > 64 || !rng.engine;
+      int64_t Eb = presync ? 0 : F * count;
+      int64_t avail_blocks = 0;
+      if (presync) {
+        PYG_HIP_CHECK(hipMemcpyAsync(pinned, info_dev, sizeof(HopInfo), hipMemcpyDeviceToHost, stream));
+        PYG_HIP_CHECK(hipStreamSynchronize(stream));
+        if (range.time)
+          PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
+                          "Found invalid non-sorted temporal neighborhood");
+        Eb = info_host->tot.edges;
+        pt.lap(1);
+        if (Eb == 0) {
+          c.release(tile_buf);
+          c.release(edge_off);
+          c.release(rng_word);
+          c.release(rng_units);
+          continue;
+        }
+        // 2. make the consumed random words resident (drawn by the caller's generator)
+        const int64_t end_word = rng.word + tab_dw(info_host->tot.tab, rng.units);
+        if (rng.engine) rc = rng_wait(c, rng, end_word, &avail_blocks);
+        else rc = rng_ensure(c, rng, end_word);
+        if (rc != PYG_HIP_OK) return rc;
+        if (!rng.engine) avail_blocks = rng.blocks;
+      } else {
+        rc = rng_wait(c, rng, rng.word + (F * count + 3) / 4 + 1, &avail_blocks);
+        if (rc != PYG_HIP_OK) return rc;
       }
-      // 2. make the consumed random words resident (drawn by the caller's generator)
-      rc = rng_ensure(c, rng, end_word);
-      if (rc != PYG_HIP_OK) return rc;
-      rng.word = end_word;
-      rng.units = end_units;
       pt.lap(2);
 
       // 3. sample + insert
@@ -1261,78 +1333,107 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         term *= (double)r.num_neighbors_host[l2];
         mult += term;
       }
-      const int64_t grow = (int64_t)std::min<double>((double)E * mult, 16.0 * 1024 * 1024);
-      rc = st.row.reserve(c, st.row.size + E, st.row.size + grow);
+      const int64_t grow = (int64_t)std::min<double>((double)Eb * mult, 16.0 * 1024 * 1024);
+      rc = st.row.reserve(c, st.row.size + Eb, st.row.size + grow);
       if (rc != PYG_HIP_OK) return rc;
-      rc = st.col.reserve(c, st.col.size + E, st.col.size + grow);
+      rc = st.col.reserve(c, st.col.size + Eb, st.col.size + grow);
       if (rc != PYG_HIP_OK) return rc;
       // edge ids are always produced: they double as the chosen-set history of large fan-outs
-      rc = st.eid.reserve(c, st.eid.size + E, st.eid.size + grow);
+      rc = st.eid.reserve(c, st.eid.size + Eb, st.eid.size + grow);
       if (rc != PYG_HIP_OK) return rc;
-      rc = dn.nodes.reserve(c, dn.nodes.size + E, dn.nodes.size + grow);
+      rc = dn.nodes.reserve(c, dn.nodes.size + Eb, dn.nodes.size + grow);
       if (rc != PYG_HIP_OK) return rc;
       if (disjoint) {
-        rc = dn.batch.reserve(c, dn.batch.size + E, dn.batch.size + grow);
+        rc = dn.batch.reserve(c, dn.batch.size + Eb, dn.batch.size + grow);
         if (rc != PYG_HIP_OK) return rc;
       }
-      rc = table_reserve(c, dn, E, dn.entries_bound + grow);
+      rc = table_reserve(c, dn, Eb, dn.entries_bound + grow);
       if (rc != PYG_HIP_OK) return rc;
       int64_t* e_node;
       int64_t* e_batch = nullptr;
       u64* e_slot;
-      PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
-      if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)E);
-      PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
-      pt.lap(3);
-      HopArgs a;
-      a.nodes = sn.nodes.p;
-      a.batch = disjoint ? sn.batch.p : nullptr;
-      a.begin = sn.slice_b;
-      a.frontier = F;
-      a.range = range;
-      a.col = r.col;
-      a.count = count;
-      a.replace = replace;
-      a.num_batches = num_batches;
-      a.edge_off = edge_off;
-      a.rng_word = rng_word;
-      a.rng_units = rng_units;
-      a.words = rng.dev;
-      a.e_row = st.row.p + st.row.size;
-      a.e_node = e_node;
-      a.e_batch = e_batch;
-      a.e_eid = st.eid.p + st.eid.size;
-      a.e_slot = e_slot;
-      a.table = dn.table;
-      launch_sample(a, F, stream);
-      PYG_HIP_CHECK(hipGetLastError());
-
-      // 4. first occurrences -> ranks -> new local ids / appended nodes
-      const int64_t etiles = (E + kScanTile - 1) / kScanTile;
+      PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)Eb);
+      if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)Eb);
+      PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)Eb);
+      const int64_t etiles = (Eb + kScanTile - 1) / kScanTile;
       int64_t* ftile;
       PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
-      FlagLoad fl{e_slot, dn.table.vals};
-      AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
-                     disjoint ? dn.batch.p : (int64_t*)nullptr, dn.nodes.size, dn.distinct, 1};
-      int64_t* u_host = reinterpret_cast<int64_t*>(static_cast<char*>(pinned) + 64);
-      rc = device_scan<int64_t, SumOp>(fl, as, E, ftile, u_host, stream);
-      if (rc != PYG_HIP_OK) return rc;
-      // 5. local ids of every emitted edge
-      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream,
-                         e_slot, dn.table.vals, E, st.col.p + st.col.size);
-      PYG_HIP_CHECK(hipGetLastError());
-      pt.lap(4);
-      PYG_HIP_CHECK(hipStreamSynchronize(stream));
-      pt.lap(5);
-      const int64_t U = *static_cast<volatile int64_t*>(u_host);
+      pt.lap(3);
+      int64_t E = 0, U = 0;
+      for (int attempt = 0;; ++attempt) {
+        HopArgs a;
+        a.info = info_dev;
+        a.word0 = rng.word;
+        a.units0 = rng.units;
+        a.avail_blocks = avail_blocks;
+        a.nodes = sn.nodes.p;
+        a.batch = disjoint ? sn.batch.p : nullptr;
+        a.begin = sn.slice_b;
+        a.frontier = F;
+        range.batch = a.batch;  // the reserve above may have moved the list (src type == dst type)
+        a.range = range;
+        a.col = r.col;
+        a.count = count;
+        a.replace = replace;
+        a.num_batches = num_batches;
+        a.edge_off = edge_off;
+        a.rng_word = rng_word;
+        a.rng_units = rng_units;
+        a.words = rng.dev;
+        a.e_row = st.row.p + st.row.size;
+        a.e_node = e_node;
+        a.e_batch = e_batch;
+        a.e_eid = st.eid.p + st.eid.size;
+        a.e_slot = e_slot;
+        a.table = dn.table;
+        launch_sample(a, F, stream);
+        PYG_HIP_CHECK(hipGetLastError());
+
+        // 4. first occurrences -> ranks -> new local ids / appended nodes
+        FlagLoad fl{e_slot, dn.table.vals, info_dev};
+        AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
+                       disjoint ? dn.batch.p : (int64_t*)nullptr, dn.nodes.size, dn.distinct, 1};
+        rc = device_scan<int64_t, SumOp>(fl, as, Eb, ftile, &info_dev->uniq, stream);
+        if (rc != PYG_HIP_OK) return rc;
+        // 5. local ids of every emitted edge; publishes the hop's totals to the host
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Eb + 255) / 256)), dim3(256), 0, stream,
+                           e_slot, dn.table.vals, Eb, st.col.p + st.col.size, info_dev,
+                           static_cast<HopInfo*>(pinned));
+        PYG_HIP_CHECK(hipGetLastError());
+        pt.lap(4);
+        PYG_HIP_CHECK(hipStreamSynchronize(stream));
+        pt.lap(5);
+        if (range.time)
+          PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
+                          "Found invalid non-sorted temporal neighborhood");
+        E = info_host->tot.edges;
+        U = info_host->uniq;
+        const RngTab tab = info_host->tot.tab;
+        const int64_t end_word = rng.word + tab_dw(tab, rng.units);
+        if (info_host->overflow) {
+          // rare: draws wider than 16 bits, or more words than the speculation may run ahead --
+          // nothing was sampled; generate what the hop really needs and repeat it
+          PYG_HIP_REQUIRE(attempt == 0 && rng.engine, "sampler: random words missing after regeneration");
+          rc = rng_wait(c, rng, end_word, &avail_blocks);
+          if (rc != PYG_HIP_OK) return rc;
+          continue;
+        }
+        if (E > 0) {
+          if (rng.engine) rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
+          rng.word = end_word;
+          rng.units = tab_nb(tab, rng.units);
+        }
+        break;
+      }
       dn.nodes.size += U;
       if (disjoint) dn.batch.size += U;
       dn.distinct += U;
-      dn.entries_bound = dn.entries_bound - E + U;
+      dn.entries_bound = dn.entries_bound - Eb + U;
       st.row.size += E;
       st.col.size += E;
       st.eid.size += E;
       st.edges_per_hop.back() = E;
+      c.release(tile_buf);
       c.release(edge_off);
       c.release(rng_word);
       c.release(rng_units);

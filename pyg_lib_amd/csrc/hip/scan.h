@@ -1,5 +1,6 @@
 // Order-preserving device-wide exclusive scan with a generic (possibly non-commutative) operator.
-// Three launches (tile aggregates, spine, apply) or one for inputs of a single tile.  Load / Store
+// One launch for a single tile, two (tile aggregates; apply with a per-block spine) up to 2048 tiles,
+// three (tile aggregates, spine, apply) beyond.  Load / Store
 // are functors so that producers and consumers fuse into the scan's passes.
 #pragma once
 
@@ -100,8 +101,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(T* __restrict_
   if (threadIdx.x == 0) *total_out = carry;
 }
 
-// Phase C: per-element exclusive prefixes -> Store.
-template <typename T, typename Op, typename Load, typename Store>
+// Phase C: per-element exclusive prefixes -> Store.  `tile_prefix` holds exclusive tile prefixes (after
+// the spine kernel), or -- SELF_SPINE -- the raw tile aggregates, which every block reduces for itself
+// (tiles [0, blockIdx.x), in order): one dependent launch less for the few hundred tiles of a hop.
+template <typename T, typename Op, typename Load, typename Store, bool SELF_SPINE>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Store store, int64_t n,
                                                                   const T* __restrict__ tile_prefix,
                                                                   T* __restrict__ total_out) {
@@ -119,8 +122,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Sto
   }
   T total;
   T run = block_exclusive<T, Op>(agg, lds, op, &total);
-  if (tile_prefix) run = op(tile_prefix[blockIdx.x], run);
-  else if (threadIdx.x == 0 && blockIdx.x == 0 && total_out) *total_out = total;  // single tile
+  if (SELF_SPINE) {
+    T before = Op::identity();
+    for (int64_t c0 = 0; c0 < (int64_t)blockIdx.x; c0 += kScanThreads) {
+      const int64_t i = c0 + threadIdx.x;
+      const T t = i < (int64_t)blockIdx.x ? tile_prefix[i] : Op::identity();
+      T chunk;
+      (void)block_exclusive<T, Op>(t, lds, op, &chunk);
+      before = op(before, chunk);
+    }
+    run = op(before, run);
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && total_out) *total_out = op(before, total);
+  } else if (tile_prefix) {
+    run = op(tile_prefix[blockIdx.x], run);
+  } else if (threadIdx.x == 0 && blockIdx.x == 0 && total_out) {
+    *total_out = total;  // single tile
+  }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     if (base + k < n) store(base + k, run, v[k]);
@@ -138,14 +155,19 @@ int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hi
   }
   const int64_t ntiles = (n + kScanTile - 1) / kScanTile;
   if (ntiles == 1) {
-    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3(1), dim3(kScanThreads), 0,
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store, false>), dim3(1), dim3(kScanThreads), 0,
                        stream, load, store, n, (const T*)nullptr, total_dev);
+  } else if (ntiles <= 2048) {
+    hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, n, tile_buf);
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store, true>), dim3((unsigned)ntiles),
+                       dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf, total_dev);
   } else {
     hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
                        dim3(kScanThreads), 0, stream, load, n, tile_buf);
     hipLaunchKernelGGL((scan_spine_kernel<T, Op>), dim3(1), dim3(kScanThreads), 0, stream, tile_buf,
                        ntiles, total_dev);
-    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store>), dim3((unsigned)ntiles),
+    hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store, false>), dim3((unsigned)ntiles),
                        dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf,
                        (T*)nullptr);
   }
