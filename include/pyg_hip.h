@@ -308,6 +308,48 @@ PYG_HIP_API int pyg_hip_gather_coo(int dtype, const void* src, const int64_t* in
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 
+/*
+ * CSR reductions.  src viewed as [leading, E, K]; indptr holds rows + 1 ascending offsets per slice,
+ * `indptr_slice_stride` elements apart (0: one indptr shared by all slices, read in place);
+ * out / arg_out [leading, rows, K].  Replaces pyg::segment_{sum,mean,min,max}_csr (schemas
+ * ops/segment_csr.cpp:153-172; CPU ops/cpu/segment_csr_kernel.cpp:32-536; CUDA
+ * ops/cuda/segment_csr_kernel.cu).
+ *   op 0 sum : every row adds src[slice, indptr[r] .. indptr[r+1]) to the CURRENT contents of its out
+ *              slot (the caller zero-fills a fresh output; a caller-supplied `out` accumulates)
+ *   op 1 mean: out = row sum / max(row length, 1), previous contents ignored; floating dtypes only
+ *   op 2 min / 3 max: strict < / >, first match; the running state starts from the current contents
+ *              of `out` (numeric_limits max()/lowest() for a fresh output: pyg_hip_fill_reduce_identity);
+ *              arg_out receives the winning source position or the sentinel E; fresh != 0 resets rows
+ *              without a contribution to 0.
+ * Rows are reduced in source order in the reference's opmath, so results are bit-identical to the CPU
+ * kernel for every dtype unless rows are long and few (then lanes split a row and floating sums
+ * differ by rounding; min/max/arg stay exact).
+ */
+PYG_HIP_API int pyg_hip_segment_csr(int op, int dtype, const void* src, const int64_t* indptr,
+                                    int64_t indptr_slice_stride, void* out, int64_t* arg_out, int fresh,
+                                    int64_t leading, int64_t rows, int64_t E, int64_t K, void* stream);
+
+/*
+ * out[slice, e, :] = src[slice, r, :] for every position e of row r; positions covered by no row keep
+ * their contents.  src [leading, rows, K], out [leading, E, K].  Replaces pyg::gather_csr (schema
+ * ops/segment_csr.cpp:170-172; CPU ops/cpu/segment_csr_kernel.cpp:551-648).
+ */
+PYG_HIP_API int pyg_hip_gather_csr(int dtype, const void* src, const int64_t* indptr,
+                                   int64_t indptr_slice_stride, void* out, int64_t leading, int64_t rows,
+                                   int64_t E, int64_t K, void* stream);
+
+/*
+ * Softmax over the groups ptr[g] .. ptr[g+1] along the middle axis of src [outer, D, inner], per
+ * (group, outer, inner) head; `out` must be zero-filled by the caller (positions outside every group
+ * stay 0).  float32 / float64.  Replaces pyg::softmax_csr / pyg::softmax_csr_backward (schemas
+ * ops/softmax.cpp:46-53; CPU only in the reference: ops/cpu/softmax_kernel.cpp:58-222).
+ */
+PYG_HIP_API int pyg_hip_softmax_csr(int dtype, const void* src, const int64_t* ptr, void* out, int64_t outer,
+                                    int64_t D, int64_t inner, int64_t groups, void* stream);
+PYG_HIP_API int pyg_hip_softmax_csr_backward(int dtype, const void* out, const void* out_grad,
+                                             const int64_t* ptr, void* in_grad, int64_t outer, int64_t D,
+                                             int64_t inner, int64_t groups, void* stream);
+
 /* When enabled (per calling thread), every dominant-kernel launch is bracketed by a pair of HIP
  * events recorded on the stream the kernel is launched on.  pyg_hip_profile_collect waits for the
  * recorded launches, writes up to `capacity` durations (milliseconds, launch order) and returns

@@ -281,6 +281,17 @@ def _declare_reduce(L):
                                     c.c_int64]
     L.oracle_index_sort.restype = c.c_int
     L.oracle_index_sort.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    L.oracle_segment_csr.restype = c.c_int
+    L.oracle_segment_csr.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int,
+                                     c.c_int64, c.c_int64, c.c_int64, c.c_int64]
+    L.oracle_gather_csr.restype = c.c_int
+    L.oracle_gather_csr.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_int64,
+                                    c.c_int64]
+    L.oracle_softmax_csr.restype = None
+    L.oracle_softmax_csr.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_int64, c.c_int64]
+    L.oracle_softmax_csr_backward.restype = None
+    L.oracle_softmax_csr_backward.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64,
+                                              c.c_int64, c.c_int64]
     L._reduce_declared = True
 
 
@@ -456,3 +467,95 @@ def dist_neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_
     blocks = ctypes.c_int64(0)
     L.oracle_dist_neighbor_sample(*args, _ptr(nodes), _ptr(edges), _ptr(cumsum), ctypes.byref(blocks))
     return nodes, edges, cumsum.tolist(), {'rng_blocks': blocks.value}
+
+
+# ---- CSR family (segment_*_csr, gather_csr, softmax_csr) ----------------------------------------------
+CSR_SUM, CSR_MEAN, CSR_MIN, CSR_MAX = 0, 1, 2, 3
+
+
+def _csr_layout(src, indptr):
+    """(indptr broadcast to [leading, rows + 1], leading, rows, dim) as segment_csr_kernel.cpp:44-58."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    if src.ndim < indptr.ndim:
+        raise RuntimeError('src.dim() must be >= indptr.dim()')
+    dim = indptr.ndim - 1
+    shape = list(src.shape[:dim]) + [indptr.shape[-1]]
+    ib = np.ascontiguousarray(np.broadcast_to(indptr, shape))
+    leading = int(np.prod(shape[:-1], dtype=np.int64))
+    return ib, leading, indptr.shape[-1] - 1, dim
+
+
+def segment_csr(op, src, indptr, out=None, dtype=None):
+    """segment_{sum,mean,min,max}_csr: returns (out, arg_out or None)."""
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src)
+    ib, leading, rows, dim = _csr_layout(src, indptr)
+    fresh = out is None
+    shape = list(src.shape)
+    shape[dim] = max(rows, 0)
+    red = MIN if op == CSR_MIN else MAX
+    if fresh or op == CSR_MEAN:
+        if op in (CSR_SUM, CSR_MEAN):
+            out = np.zeros(shape, dtype=src.dtype)
+        else:
+            out = np.full(shape, _identity(red, src, dtype), dtype=src.dtype)
+    else:
+        out = np.ascontiguousarray(out).copy()
+    E = src.shape[dim]
+    K = int(np.prod(src.shape[dim + 1:], dtype=np.int64))
+    arg = np.full(out.shape, E, dtype=np.int64) if op in (CSR_MIN, CSR_MAX) else None
+    if src.size:
+        rc = L.oracle_segment_csr(op, _code(src, dtype), _ptr(src), _ptr(ib), _ptr(out), _ptr(arg), int(fresh),
+                                  leading, rows, E, K)
+        if rc != 0:
+            raise RuntimeError(f'oracle_segment_csr failed ({rc})')
+    elif op in (CSR_MIN, CSR_MAX) and fresh:
+        out[...] = 0
+    return out, arg
+
+
+def gather_csr(src, indptr, out, dtype=None):
+    """gather_csr into a copy of `out` (positions outside every row keep `out`'s contents)."""
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src)
+    ib, leading, rows, dim = _csr_layout(src, indptr)
+    out = np.ascontiguousarray(out).copy()
+    E = out.shape[dim]
+    K = int(np.prod(src.shape[dim + 1:], dtype=np.int64))
+    if src.size:
+        rc = L.oracle_gather_csr(_code(src, dtype), _ptr(src), _ptr(ib), _ptr(out), leading, rows, E, K)
+        if rc != 0:
+            raise RuntimeError('oracle_gather_csr: indptr out of range')
+    return out
+
+
+def _softmax_layout(src, dim):
+    dim = dim + src.ndim if dim < 0 else dim
+    outer = int(np.prod(src.shape[:dim], dtype=np.int64))
+    inner = int(np.prod(src.shape[dim + 1:], dtype=np.int64))
+    return outer, src.shape[dim], inner
+
+
+def softmax_csr(src, ptr, dim=0):
+    L = lib()
+    _declare_reduce(L)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    outer, D, inner = _softmax_layout(src, dim)
+    out = np.empty_like(src)
+    L.oracle_softmax_csr(_ptr(src), _ptr(ptr), _ptr(out), outer, D, inner, ptr.size - 1)
+    return out
+
+
+def softmax_csr_backward(out, out_grad, ptr, dim=0):
+    L = lib()
+    _declare_reduce(L)
+    out = np.ascontiguousarray(out, dtype=np.float32)
+    out_grad = np.ascontiguousarray(out_grad, dtype=np.float32)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    outer, D, inner = _softmax_layout(out, dim)
+    gin = np.empty_like(out)
+    L.oracle_softmax_csr_backward(_ptr(out), _ptr(out_grad), _ptr(ptr), _ptr(gin), outer, D, inner, ptr.size - 1)
+    return gin

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds oracle/_ref/libpyg_ref.so: the part of the REAL reference CPU path that compiles from its
-# own sources with g++ and libtorch alone -- index_sort, scatter_*, segment_*_coo / gather_coo
-# (front + CPU kernels + autograd wrappers).  Sources are compiled where they lie under
+# own sources with g++ and libtorch alone -- index_sort, scatter_*, segment_*_coo / gather_coo,
+# segment_*_csr / gather_csr, softmax_csr (front + CPU kernels + autograd wrappers).  Sources are compiled where they lie under
 # /root/reference; nothing is copied and no stand-in header is written.
 #
 # NOT built (unbuildable in this image, see DESIGN.md "Oracle"): ops/cpu/matmul_kernel.cpp and
@@ -18,7 +18,7 @@ OUT="$HERE/_ref"
 mkdir -p "$OUT/obj"
 TORCH=$(python -c "import torch, os; print(os.path.dirname(torch.__file__))")
 ABI=$(python -c "import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
-SRCS="ops/index_sort ops/cpu/index_sort_kernel ops/scatter ops/cpu/scatter_kernel ops/autograd/scatter_kernel ops/segment_coo ops/cpu/segment_coo_kernel ops/autograd/segment_coo_kernel"
+SRCS="ops/index_sort ops/cpu/index_sort_kernel ops/scatter ops/cpu/scatter_kernel ops/autograd/scatter_kernel ops/segment_coo ops/cpu/segment_coo_kernel ops/autograd/segment_coo_kernel ops/segment_csr ops/cpu/segment_csr_kernel ops/autograd/segment_csr_kernel ops/softmax ops/cpu/softmax_kernel ops/autograd/softmax_kernel"
 objs=""
 pids=""
 for s in $SRCS; do

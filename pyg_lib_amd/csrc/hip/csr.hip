@@ -1,0 +1,365 @@
+// segment_{sum,mean,min,max}_csr, gather_csr and softmax_csr (+ backward) for gfx950 (MI355X).
+//
+// Replaces pyg_lib/csrc/ops/cuda/segment_csr_kernel.cu (warp-32 shuffles) and gives
+// pyg::softmax_csr -- CPU only in the reference (ops/cpu/softmax_kernel.cpp) -- a device path.
+// Contracts follow pyg_lib/csrc/ops/cpu/segment_csr_kernel.cpp: src viewed as [leading, E, K],
+// indptr [leading, rows + 1] (slice stride 0 = one indptr broadcast over the slices, read in place
+// instead of `expand().contiguous()`), out / arg [leading, rows, K].
+//
+// CSR rows write disjoint outputs, so nothing is atomic.  HBM-bound byte work:
+//   * L = 1 (default): one thread per (row, 16-byte column slice) walks its row in source order and
+//     accumulates in the reference's opmath -- the CPU kernel's exact operation order, so sums and
+//     means are BIT-exact with the reference for every dtype (min/max/arg trivially).
+//   * L = 8 / 64 lanes per (row, slice) when rows are long and few (average length >= 64 / 1024 and
+//     too few rows to fill the chip): lane j takes e = a + j, a + j + L, ...; partial results are
+//     combined by xor shuffles (floating sums then differ from the CPU order by rounding; min/max and
+//     their first-match arg stay exact through a lexicographic (value, position) combine).
+#include "common.h"
+#include "elem.h"
+
+#include <type_traits>
+
+namespace pyg_hip {
+namespace {
+
+enum { CSR_SUM = 0, CSR_MEAN = 1, CSR_MIN = 2, CSR_MAX = 3 };
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+  T v[V];
+};
+
+template <typename A>
+__device__ __forceinline__ A shfl_xor_any(A v, int mask) {
+  static_assert(sizeof(A) % 4 == 0 || sizeof(A) < 4, "unsupported accumulator");
+  if constexpr (sizeof(A) < 4) {
+    int t = (int)v;
+    t = __shfl_xor(t, mask);
+    return (A)t;
+  } else {
+    A out;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); ++i) d[i] = (uint32_t)__shfl_xor((int)s[i], mask);
+    return out;
+  }
+}
+
+struct CsrShape {
+  int64_t leading, rows, E, K;
+  int64_t indptr_stride;  // elements between the indptr of consecutive slices (0 = broadcast)
+};
+
+// OP: CSR_SUM / CSR_MEAN / CSR_MIN / CSR_MAX.  V elements (16 bytes, or 1) per thread, L lanes per item.
+template <typename T, int OP, int V, int L>
+__global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                          T* __restrict__ out, int64_t* __restrict__ arg,
+                                                          int fresh, CsrShape s) {
+  using acc_t = typename Math<T>::acc_t;
+  using P = Pack<T, V>;
+  const int64_t kv = s.K / V;
+  const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / L;
+  const int lane = threadIdx.x & (L - 1);
+  const int64_t items = s.leading * s.rows * kv;
+  const bool live = t < items;
+  const int64_t tt = live ? t : 0;
+  const int64_t n = tt / kv;        // flat row
+  const int64_t c = (tt % kv) * V;  // first column of this thread's slice
+  const int64_t slice = n / s.rows;
+  const int64_t row = n % s.rows;
+  const int64_t a = indptr[slice * s.indptr_stride + row];
+  const int64_t b = indptr[slice * s.indptr_stride + row + 1];
+  const T* sp = src + slice * s.E * s.K + c;
+  T* op = out + n * s.K + c;
+
+  acc_t acc[V];
+  int64_t best[V];
+  if constexpr (OP == CSR_SUM) {
+    // the accumulator is seeded from the current `out` slot (zeros or the caller's values)
+    P cur = *reinterpret_cast<const P*>(op);
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = lane == 0 ? Math<T>::up(cur.v[i]) : acc_t(0);
+  } else if constexpr (OP == CSR_MEAN) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = acc_t(0);
+  } else {
+    P cur = *reinterpret_cast<const P*>(op);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      acc[i] = Math<T>::up(cur.v[i]);
+      best[i] = s.E;
+    }
+  }
+  if (live) {
+    for (int64_t e = a + lane; e < b; e += L) {
+      const P x = *reinterpret_cast<const P*>(sp + e * s.K);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const acc_t v = Math<T>::up(x.v[i]);
+        if constexpr (OP == CSR_SUM || OP == CSR_MEAN) {
+          acc[i] += v;
+        } else if constexpr (OP == CSR_MIN) {
+          if (v < acc[i]) { acc[i] = v; best[i] = e; }
+        } else {
+          if (v > acc[i]) { acc[i] = v; best[i] = e; }
+        }
+      }
+    }
+  }
+  if constexpr (L > 1) {
+#pragma unroll
+    for (int m = L >> 1; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const acc_t ov = shfl_xor_any(acc[i], m);
+        if constexpr (OP == CSR_SUM || OP == CSR_MEAN) {
+          acc[i] += ov;
+        } else {
+          const int64_t ob = shfl_xor_any(best[i], m);
+          const bool better = OP == CSR_MIN ? ov < acc[i] : ov > acc[i];
+          const bool worse = OP == CSR_MIN ? acc[i] < ov : acc[i] > ov;
+          if (better || (!worse && ob < best[i])) { acc[i] = ov; best[i] = ob; }
+        }
+      }
+    }
+  }
+  if (!live || lane != 0) return;
+  P res;
+  if constexpr (OP == CSR_MEAN) {
+    const int64_t len = b - a;
+    const acc_t denom = (acc_t)(len > 0 ? len : 1);
+#pragma unroll
+    for (int i = 0; i < V; ++i) res.v[i] = Math<T>::down(acc[i] / denom);
+  } else if constexpr (OP == CSR_SUM) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) res.v[i] = Math<T>::down(acc[i]);
+  } else {
+    // rows without a contribution of a fresh output read 0 (segment_csr_kernel.cpp:416-418)
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      res.v[i] = Math<T>::down(acc[i]);
+      if (fresh && best[i] == s.E) res.v[i] = Math<T>::down(acc_t(0));
+      arg[n * s.K + c + i] = best[i];
+    }
+  }
+  *reinterpret_cast<P*>(op) = res;
+}
+
+// out[slice, e, :] = src[slice, r, :] for the row r that covers position e (if any).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gather_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                         T* __restrict__ out, CsrShape s) {
+  using P = Pack<T, V>;
+  const int64_t kv = s.K / V;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= s.leading * s.E * kv) return;
+  const int64_t c = (t % kv) * V;
+  const int64_t pe = t / kv;
+  const int64_t slice = pe / s.E, e = pe % s.E;
+  const int64_t* ip = indptr + slice * s.indptr_stride;
+  // last r in [0, rows] with ip[r] <= e
+  int64_t lo = 0, hi = s.rows + 1;  // first r with ip[r] > e
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (ip[mid] > e) hi = mid; else lo = mid + 1;
+  }
+  const int64_t r = lo - 1;
+  if (r < 0 || r >= s.rows) return;  // before the first / after the last row: left untouched
+  *reinterpret_cast<P*>(out + (slice * s.E + e) * s.K + c) =
+      *reinterpret_cast<const P*>(src + (slice * s.rows + r) * s.K + c);
+}
+
+// ---- softmax over CSR groups (float / double) ------------------------------------------------------
+// src [outer, D, inner]; one item per (group, outer, inner) "head".  L lanes per item.
+template <typename T, int L, bool BACKWARD>
+__global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const int64_t* __restrict__ ptr, T* __restrict__ y,
+                                                          int64_t outer, int64_t D, int64_t inner, int64_t groups) {
+  const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / L;
+  const int lane = threadIdx.x & (L - 1);
+  const bool live = t < groups * outer * inner;
+  const int64_t tt = live ? t : 0;
+  const int64_t sidx = tt % inner;
+  const int64_t i = (tt / inner) % outer;
+  const int64_t g = tt / (inner * outer);
+  const int64_t a = ptr[g], b = ptr[g + 1];
+  const int64_t base = i * D * inner + sidx;
+  auto reduce = [&](T v, bool is_max) {
+#pragma unroll
+    for (int m = L >> 1; m >= 1; m >>= 1) {
+      const T o = shfl_xor_any(v, m);
+      v = is_max ? (v < o ? o : v) : v + o;
+    }
+    return v;
+  };
+  if constexpr (BACKWARD) {
+    // x = out, dy = out_grad, y = in_grad (softmax_kernel.cpp:148-222)
+    T sum = 0;
+    if (live)
+      for (int64_t p = a + lane; p < b; p += L) sum += x[base + p * inner] * dy[base + p * inner];
+    if (L > 1) sum = reduce(sum, false);
+    if (live)
+      for (int64_t p = a + lane; p < b; p += L)
+        y[base + p * inner] = x[base + p * inner] * (dy[base + p * inner] - sum);
+  } else {
+    if (live && b - a == 1) {  // single-element groups are exactly 1 (softmax_kernel.cpp:102-109)
+      if (lane == 0) y[base + a * inner] = T(1);
+      // (falls through the reductions below with an empty range)
+    }
+    const bool work = live && b - a != 1;
+    T mx = type_lowest<T>();
+    if (work)
+      for (int64_t p = a + lane; p < b; p += L) {
+        const T v = x[base + p * inner];
+        mx = mx < v ? v : mx;  // std::max(max, v)
+      }
+    if (L > 1) mx = reduce(mx, true);
+    T sum = 0;
+    if (work)
+      for (int64_t p = a + lane; p < b; p += L) {
+        const T v = exp(x[base + p * inner] - mx);
+        sum += v;
+        y[base + p * inner] = v;
+      }
+    if (L > 1) sum = reduce(sum, false);
+    if (work)
+      for (int64_t p = a + lane; p < b; p += L) y[base + p * inner] /= sum;
+  }
+}
+
+// lanes per item: long rows + too few items to fill the chip
+int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
+  if (units <= 0 || items <= 0) return 1;
+  const int64_t avg = total_len / units;
+  const int64_t chip = (int64_t)device_info().num_cus * 2048;  // resident threads
+  if (avg >= 1024 && items * 8 < chip) return 64;
+  if (avg >= 64 && items < chip) return 8;
+  return 1;
+}
+
+template <typename T, int OP, int V>
+int launch_segment(const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
+                   hipStream_t stream) {
+  const int64_t items = s.leading * s.rows * (s.K / V);
+  const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
+  const T* sp = static_cast<const T*>(src);
+  T* op = static_cast<T*>(out);
+#define PYG_CSR_LAUNCH(LL)                                                                                   \
+  hipLaunchKernelGGL((segment_csr_kernel<T, OP, V, LL>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), 0, \
+                     stream, sp, indptr, op, arg, fresh, s)
+  if (L == 64) PYG_CSR_LAUNCH(64);
+  else if (L == 8) PYG_CSR_LAUNCH(8);
+  else PYG_CSR_LAUNCH(1);
+#undef PYG_CSR_LAUNCH
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T>
+int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
+                hipStream_t stream) {
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+#define PYG_CSR_OP(OPC)                                                                              \
+  return vec ? launch_segment<T, OPC, VMAX>(src, indptr, out, arg, fresh, s, stream)                 \
+             : launch_segment<T, OPC, 1>(src, indptr, out, arg, fresh, s, stream)
+  switch (op) {
+    case CSR_SUM: PYG_CSR_OP(CSR_SUM);
+    case CSR_MEAN:
+      if constexpr (std::is_integral<T>::value) return fail(PYG_HIP_ERR_INVALID, "segment_mean_csr: floating dtypes only");
+      else PYG_CSR_OP(CSR_MEAN);
+    case CSR_MIN: PYG_CSR_OP(CSR_MIN);
+    case CSR_MAX: PYG_CSR_OP(CSR_MAX);
+    default: return fail(PYG_HIP_ERR_INVALID, "segment_csr: unknown reduction %d", op);
+  }
+#undef PYG_CSR_OP
+}
+
+template <typename T>
+int run_gather_csr(const void* src, const int64_t* indptr, void* out, const CsrShape& s, hipStream_t stream) {
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec) {
+    const int64_t total = s.leading * s.E * (s.K / VMAX);
+    hipLaunchKernelGGL((gather_csr_kernel<T, VMAX>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const T*>(src), indptr, static_cast<T*>(out), s);
+  } else {
+    const int64_t total = s.leading * s.E * s.K;
+    hipLaunchKernelGGL((gather_csr_kernel<T, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const T*>(src), indptr, static_cast<T*>(out), s);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T, bool BACKWARD>
+int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int64_t outer, int64_t D, int64_t inner,
+                int64_t groups, hipStream_t stream) {
+  const int64_t items = groups * outer * inner;
+  const int L = pick_lanes(items, D * outer * inner, items);
+#define PYG_SM_LAUNCH(LL)                                                                                         \
+  hipLaunchKernelGGL((softmax_csr_kernel<T, LL, BACKWARD>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), \
+                     0, stream, static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), outer, \
+                     D, inner, groups)
+  if (L == 64) PYG_SM_LAUNCH(64);
+  else if (L == 8) PYG_SM_LAUNCH(8);
+  else PYG_SM_LAUNCH(1);
+#undef PYG_SM_LAUNCH
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" {
+
+int pyg_hip_segment_csr(int op, int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride,
+                        void* out, int64_t* arg_out, int fresh, int64_t leading, int64_t rows, int64_t E, int64_t K,
+                        void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(leading >= 0 && rows >= 0 && E >= 0 && K >= 0, "segment_csr: negative size");
+  if (leading * rows * K == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(indptr && out && (src || E == 0), "segment_csr: NULL tensor");
+  PYG_HIP_REQUIRE((op != CSR_MIN && op != CSR_MAX) || arg_out, "segment_csr: min/max need arg_out");
+  PYG_HIP_REQUIRE(indptr_slice_stride == 0 || indptr_slice_stride >= rows + 1, "segment_csr: bad indptr stride");
+  const CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(op, src, indptr, out, arg_out, fresh, s, stream)));
+}
+
+int pyg_hip_gather_csr(int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride, void* out,
+                       int64_t leading, int64_t rows, int64_t E, int64_t K, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(leading >= 0 && rows >= 0 && E >= 0 && K >= 0, "gather_csr: negative size");
+  if (leading * E * K == 0 || rows == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(src && indptr && out, "gather_csr: NULL tensor");
+  const CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  PYG_DISPATCH_ALL(dtype, (run_gather_csr<scalar_t>(src, indptr, out, s, stream)));
+}
+
+int pyg_hip_softmax_csr(int dtype, const void* src, const int64_t* ptr, void* out, int64_t outer, int64_t D,
+                        int64_t inner, int64_t groups, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(outer >= 0 && D >= 0 && inner >= 0 && groups >= 0, "softmax_csr: negative size");
+  if (outer * D * inner == 0 || groups == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(src && ptr && out, "softmax_csr: NULL tensor");
+  if (dtype == PYG_F32) return run_softmax<float, false>(src, nullptr, ptr, out, outer, D, inner, groups, stream);
+  if (dtype == PYG_F64) return run_softmax<double, false>(src, nullptr, ptr, out, outer, D, inner, groups, stream);
+  return fail(PYG_HIP_ERR_INVALID, "softmax_csr: float32 / float64 only (dtype %d)", dtype);
+}
+
+int pyg_hip_softmax_csr_backward(int dtype, const void* out, const void* out_grad, const int64_t* ptr, void* in_grad,
+                                 int64_t outer, int64_t D, int64_t inner, int64_t groups, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(outer >= 0 && D >= 0 && inner >= 0 && groups >= 0, "softmax_csr_backward: negative size");
+  if (outer * D * inner == 0 || groups == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(out && out_grad && ptr && in_grad, "softmax_csr_backward: NULL tensor");
+  if (dtype == PYG_F32) return run_softmax<float, true>(out, out_grad, ptr, in_grad, outer, D, inner, groups, stream);
+  if (dtype == PYG_F64) return run_softmax<double, true>(out, out_grad, ptr, in_grad, outer, D, inner, groups, stream);
+  return fail(PYG_HIP_ERR_INVALID, "softmax_csr_backward: float32 / float64 only (dtype %d)", dtype);
+}
+
+}  // extern "C"

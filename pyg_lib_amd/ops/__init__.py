@@ -332,6 +332,58 @@ def scatter_logsumexp(src: Tensor, index: Tensor, dim: int = -1, out: Optional[T
     return out
 
 
+# ---- CSR family (pyg_lib/ops/__init__.py:324-350, 634-745, 816-836) -----------------------------------
+def softmax_csr(src: Tensor, ptr: Tensor, dim: int = 0) -> Tensor:
+    r"""Sparsely evaluated softmax: groups the values of :obj:`src` along :obj:`dim` by the CSR
+    pointer :obj:`ptr` and normalises every group on its own (pyg_lib/ops/__init__.py:324-350)."""
+    dim = dim + src.dim() if dim < 0 else dim
+    return torch.ops.pyg.softmax_csr(src, ptr, dim)
+
+
+def segment_sum_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    r"""Row sums of :obj:`src` along ``indptr.dim() - 1`` by the CSR pointer :obj:`indptr`
+    (``[..., R+1]``); a given :obj:`out` is **accumulated** into."""
+    return torch.ops.pyg.segment_sum_csr(src, indptr, out)
+
+
+segment_add_csr = segment_sum_csr
+
+
+def segment_mean_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    r"""Row means (empty rows read 0); a given :obj:`out` is overwritten."""
+    return torch.ops.pyg.segment_mean_csr(src, indptr, out)
+
+
+def segment_min_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    r"""Row minima and the source position of the first one (sentinel ``src.size(dim)`` for rows
+    without a contribution)."""
+    return torch.ops.pyg.segment_min_csr(src, indptr, out)
+
+
+def segment_max_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    r"""Row maxima and the source position of the first one."""
+    return torch.ops.pyg.segment_max_csr(src, indptr, out)
+
+
+def gather_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    r"""Inverse of :func:`segment_sum_csr`: row ``r`` of :obj:`src` is written to the positions
+    ``indptr[r] .. indptr[r+1]`` of the output."""
+    return torch.ops.pyg.gather_csr(src, indptr, out)
+
+
+def segment_csr(src: Tensor, indptr: Tensor, out: Optional[Tensor] = None, reduce: str = 'sum') -> Tensor:
+    r"""Polymorphic CSR segment dispatcher; min/max return only the value tensor."""
+    if reduce == 'sum' or reduce == 'add':
+        return segment_sum_csr(src, indptr, out)
+    if reduce == 'mean':
+        return segment_mean_csr(src, indptr, out)
+    if reduce == 'min':
+        return segment_min_csr(src, indptr, out)[0]
+    if reduce == 'max':
+        return segment_max_csr(src, indptr, out)[0]
+    raise ValueError(f'Unknown reduce: {reduce!r}')
+
+
 def matmul_last_variant() -> str:
     """Name of the kernel variant the last matmul call dispatched to (test/diagnostic hook)."""
     return _capi.lib().pyg_hip_matmul_last_variant().decode()
@@ -359,4 +411,12 @@ __all__ = [
     'segment_min_coo',
     'segment_max_coo',
     'gather_coo',
+    'softmax_csr',
+    'segment_sum_csr',
+    'segment_add_csr',
+    'segment_mean_csr',
+    'segment_min_csr',
+    'segment_max_csr',
+    'gather_csr',
+    'segment_csr',
 ]

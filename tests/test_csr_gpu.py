@@ -1,0 +1,190 @@
+"""Parity of the HIP segment_*_csr / gather_csr / softmax_csr with the real reference's recorded
+outputs (tests/golden/csr_golden.npz) and with the oracle on larger random inputs.
+
+Modelled on the reference's test/ops/test_segment_csr.py and test_softmax.py.  Rows are reduced in
+source order in the reference's opmath, so sums and means are compared BIT for bit as well (the
+lane-split path for long, few rows is checked separately with a tolerance); min/max values, arg
+indices and gathers are always exact.  softmax differs from glibc's expf by at most a few ulps.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pyg_lib_amd import ops
+from tests.golden import csr_cases as CC
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+OPS = {'sum': oracle.CSR_SUM, 'mean': oracle.CSR_MEAN, 'min': oracle.CSR_MIN, 'max': oracle.CSR_MAX}
+
+
+def to_t(a, bf16=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a).copy())
+    if bf16:
+        t = t.view(torch.int16).view(torch.bfloat16)
+    return t
+
+
+def same_bits(got, ref):
+    got = got.cpu().contiguous()
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    if got.dtype in (torch.bfloat16, torch.float16):
+        return torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    if got.is_floating_point():
+        return torch.equal(got.view(torch.int32 if got.dtype == torch.float32 else torch.int64),
+                           ref.contiguous().view(torch.int32 if got.dtype == torch.float32 else torch.int64))
+    return torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('name', CC.names('reduce'))
+def test_segment_csr_matches_reference(name):
+    c = CC.case(name)
+    src = to_t(c['src'], c['bf16']).to(DEV)
+    indptr = to_t(c['indptr']).to(DEV)
+    out0 = to_t(c['out0'], c['bf16'])
+    out = out0.to(DEV) if out0 is not None else None
+    res = getattr(ops, f"segment_{c['op']}_csr")(src, indptr, out)
+    val = res[0] if c['op'] in ('min', 'max') else res
+    assert same_bits(val, to_t(c['res'], c['bf16'])), name
+    if c['op'] in ('min', 'max'):
+        assert torch.equal(res[1].cpu(), to_t(c['arg']))
+    if out is not None:
+        assert val.data_ptr() == out.data_ptr()  # written in place
+
+
+@pytest.mark.parametrize('name', CC.names('gather'))
+def test_gather_csr_matches_reference(name):
+    c = CC.case(name)
+    src = to_t(c['src'], c['bf16']).to(DEV)
+    indptr = to_t(c['indptr']).to(DEV)
+    out = to_t(c['out0'], c['bf16']).to(DEV)
+    res = ops.gather_csr(src, indptr, out)
+    assert same_bits(res, to_t(c['res'], c['bf16']))
+
+
+def test_gather_csr_allocates_last_offset():
+    indptr = torch.tensor([0, 2, 5, 5, 6], device=DEV)
+    src = torch.arange(8., device=DEV).view(4, 2)
+    out = ops.gather_csr(src, indptr)
+    assert out.shape == (6, 2)
+    assert torch.equal(out.cpu(), src.cpu()[[0, 0, 1, 1, 1, 3]])
+
+
+@pytest.mark.parametrize('name', CC.names('softmax'))
+def test_softmax_csr_matches_reference(name):
+    c = CC.case(name)
+    src = to_t(c['src']).to(DEV)
+    ptr = to_t(c['ptr']).to(DEV)
+    out = ops.softmax_csr(src, ptr, c['dim'])
+    torch.testing.assert_close(out.cpu(), to_t(c['res']), rtol=2e-6, atol=1e-9)
+    gin = torch.ops.pyg.softmax_csr_backward(to_t(c['res']).to(DEV), to_t(c['out_grad']).to(DEV), ptr, c['dim'])
+    torch.testing.assert_close(gin.cpu(), to_t(c['in_grad']), rtol=1e-5, atol=1e-7)
+
+
+def random_csr(rng, rows, mean_len):
+    lens = rng.poisson(mean_len, rows).astype(np.int64)
+    lens[rng.integers(0, rows, rows // 10)] = 0
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16, torch.int32, torch.int64, torch.float64])
+@pytest.mark.parametrize('K', [1, 5, 128])
+def test_random_rows_match_oracle_bit_for_bit(dtype, K):
+    rng = np.random.default_rng(21)
+    indptr = random_csr(rng, 3000, 12)
+    E = int(indptr[-1])
+    if dtype.is_floating_point:
+        src_t = torch.from_numpy(rng.standard_normal((E, K)).astype(np.float32)).to(dtype)
+    else:
+        src_t = torch.from_numpy(rng.integers(-50, 50, (E, K))).to(dtype)
+    bf16 = dtype == torch.bfloat16
+    src_np = src_t.view(torch.int16).numpy().view(np.uint16) if bf16 else src_t.numpy()
+    for op in ('sum', 'mean', 'min', 'max'):
+        if op == 'mean' and not dtype.is_floating_point:
+            continue
+        want, warg = oracle.segment_csr(OPS[op], src_np, indptr, None, oracle.BF16 if bf16 else None)
+        res = getattr(ops, f'segment_{op}_csr')(src_t.to(DEV), torch.from_numpy(indptr).to(DEV))
+        val = res[0] if op in ('min', 'max') else res
+        assert same_bits(val, to_t(want, bf16)), (op, dtype, K)
+        if op in ('min', 'max'):
+            assert torch.equal(res[1].cpu(), torch.from_numpy(warg))
+
+
+@pytest.mark.parametrize('K', [1, 8])
+def test_long_rows_use_lane_split_within_tolerance(K):
+    # few, long rows: lanes split a row (sums differ by rounding only; min/max/arg stay exact)
+    rng = np.random.default_rng(22)
+    lens = np.array([50_000, 0, 120_000, 3, 80_000], dtype=np.int64)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    src = rng.standard_normal((int(indptr[-1]), K)).astype(np.float32)
+    s = torch.from_numpy(src).to(DEV)
+    ip = torch.from_numpy(indptr).to(DEV)
+    want, _ = oracle.segment_csr(oracle.CSR_SUM, src, indptr)
+    torch.testing.assert_close(ops.segment_sum_csr(s, ip).cpu(), torch.from_numpy(want), rtol=1e-4, atol=1e-2)
+    want, _ = oracle.segment_csr(oracle.CSR_MEAN, src, indptr)
+    torch.testing.assert_close(ops.segment_mean_csr(s, ip).cpu(), torch.from_numpy(want), rtol=1e-4, atol=1e-5)
+    for op, code in (('min', oracle.CSR_MIN), ('max', oracle.CSR_MAX)):
+        want, warg = oracle.segment_csr(code, src, indptr)
+        val, arg = getattr(ops, f'segment_{op}_csr')(s, ip)
+        assert torch.equal(val.cpu(), torch.from_numpy(want)) and torch.equal(arg.cpu(), torch.from_numpy(warg))
+    # ties across lanes: the first position must win
+    src[:] = 1.0
+    val, arg = ops.segment_min_csr(torch.from_numpy(src).to(DEV), ip)
+    assert torch.equal(arg.cpu()[:, 0], torch.tensor([0, int(indptr[-1]), 50_000, 170_000, 170_003]))
+
+
+def test_softmax_long_groups_and_oracle():
+    rng = np.random.default_rng(23)
+    ptr = np.array([0, 40_000, 40_001, 40_001, 100_000], dtype=np.int64)
+    src = (rng.standard_normal((100_000, 2)) * 5).astype(np.float32)
+    out = ops.softmax_csr(torch.from_numpy(src).to(DEV), torch.from_numpy(ptr).to(DEV), 0)
+    want = oracle.softmax_csr(src, ptr, 0)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(want), rtol=1e-4, atol=1e-9)
+    assert torch.equal(out[40_000].cpu(), torch.ones(2))
+
+
+def test_autograd_matches_dense_formulas():
+    torch.manual_seed(0)
+    indptr = torch.tensor([0, 2, 5, 5, 6], device=DEV)
+    src = torch.randn(6, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 3, device=DEV, dtype=torch.float64)
+    index = torch.tensor([0, 0, 1, 1, 1, 3], device=DEV)
+    for name in ('sum', 'mean', 'min', 'max'):
+        res = getattr(ops, f'segment_{name}_csr')(src, indptr)
+        val = res[0] if name in ('min', 'max') else res
+        (g,) = torch.autograd.grad((val * w).sum(), src)
+        ref = torch.zeros(4, 3, device=DEV, dtype=torch.float64).index_reduce_(
+            0, index, src, {'sum': 'mean', 'mean': 'mean', 'min': 'amin', 'max': 'amax'}[name], include_self=False)
+        if name == 'sum':
+            ref = torch.zeros(4, 3, device=DEV, dtype=torch.float64).index_add_(0, index, src)
+        (gr,) = torch.autograd.grad((ref * w).sum(), src)
+        torch.testing.assert_close(g, gr)
+    ww = w.clone().requires_grad_()
+    (gg,) = torch.autograd.grad((ops.gather_csr(ww, indptr) * src.detach()).sum(), ww)
+    torch.testing.assert_close(gg, torch.zeros_like(w).index_add_(0, index, src.detach()))
+    # softmax_csr backward against autograd through torch.softmax per group
+    x = torch.randn(6, 2, device=DEV, requires_grad=True)
+    ptr = torch.tensor([0, 2, 6], device=DEV)
+    y = ops.softmax_csr(x, ptr, 0)
+    yr = torch.cat([torch.softmax(x[:2], 0), torch.softmax(x[2:], 0)])
+    c = torch.randn(6, 2, device=DEV)
+    (ga,) = torch.autograd.grad((y * c).sum(), x)
+    (gb,) = torch.autograd.grad((yr * c).sum(), x)
+    torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_mirror_the_reference():
+    src = torch.randn(6, 2, device=DEV)
+    with pytest.raises(RuntimeError, match='same device'):
+        ops.segment_sum_csr(src, torch.tensor([0, 6]))
+    with pytest.raises(RuntimeError, match='src.dim'):
+        ops.segment_sum_csr(torch.randn(6, device=DEV), torch.zeros(2, 3, dtype=torch.long, device=DEV))
+    with pytest.raises(RuntimeError, match='not implemented'):
+        ops.segment_mean_csr(torch.arange(6, device=DEV), torch.tensor([0, 6], device=DEV))
+    with pytest.raises(RuntimeError, match='out.size'):
+        ops.segment_sum_csr(src, torch.tensor([0, 6], device=DEV), torch.zeros(3, 2, device=DEV))
+    with pytest.raises(ValueError):
+        ops.segment_csr(src, torch.tensor([0, 6], device=DEV), reduce='prod')
