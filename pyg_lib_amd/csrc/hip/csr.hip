@@ -146,28 +146,25 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   *reinterpret_cast<P*>(op) = res;
 }
 
-// out[slice, e, :] = src[slice, r, :] for the row r that covers position e (if any).
-template <typename T, int V>
+// out[slice, e, :] = src[slice, r, :] for every position e of row r: the mirror image of the sum kernel
+// (one thread per (row, 16-byte slice), L lanes per item for long rows).  Positions covered by no row
+// are never written.
+template <typename T, int V, int L>
 __global__ __launch_bounds__(256) void gather_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
                                                          T* __restrict__ out, CsrShape s) {
   using P = Pack<T, V>;
   const int64_t kv = s.K / V;
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= s.leading * s.E * kv) return;
+  const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / L;
+  const int lane = threadIdx.x & (L - 1);
+  if (t >= s.leading * s.rows * kv) return;
+  const int64_t n = t / kv;
   const int64_t c = (t % kv) * V;
-  const int64_t pe = t / kv;
-  const int64_t slice = pe / s.E, e = pe % s.E;
-  const int64_t* ip = indptr + slice * s.indptr_stride;
-  // last r in [0, rows] with ip[r] <= e
-  int64_t lo = 0, hi = s.rows + 1;  // first r with ip[r] > e
-  while (lo < hi) {
-    const int64_t mid = lo + ((hi - lo) >> 1);
-    if (ip[mid] > e) hi = mid; else lo = mid + 1;
-  }
-  const int64_t r = lo - 1;
-  if (r < 0 || r >= s.rows) return;  // before the first / after the last row: left untouched
-  *reinterpret_cast<P*>(out + (slice * s.E + e) * s.K + c) =
-      *reinterpret_cast<const P*>(src + (slice * s.rows + r) * s.K + c);
+  const int64_t slice = n / s.rows, row = n % s.rows;
+  const int64_t a = indptr[slice * s.indptr_stride + row];
+  const int64_t b = indptr[slice * s.indptr_stride + row + 1];
+  const P v = *reinterpret_cast<const P*>(src + n * s.K + c);
+  T* op = out + slice * s.E * s.K + c;
+  for (int64_t e = a + lane; e < b; e += L) *reinterpret_cast<P*>(op + e * s.K) = v;
 }
 
 // ---- softmax over CSR groups (float / double) ------------------------------------------------------
@@ -276,21 +273,26 @@ int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64
 #undef PYG_CSR_OP
 }
 
+template <typename T, int V>
+int launch_gather(const void* src, const int64_t* indptr, void* out, const CsrShape& s, hipStream_t stream) {
+  const int64_t items = s.leading * s.rows * (s.K / V);
+  const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
+#define PYG_CSR_LAUNCH(LL)                                                                                  \
+  hipLaunchKernelGGL((gather_csr_kernel<T, V, LL>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), 0, \
+                     stream, static_cast<const T*>(src), indptr, static_cast<T*>(out), s)
+  if (L == 64) PYG_CSR_LAUNCH(64);
+  else if (L == 8) PYG_CSR_LAUNCH(8);
+  else PYG_CSR_LAUNCH(1);
+#undef PYG_CSR_LAUNCH
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
 template <typename T>
 int run_gather_csr(const void* src, const int64_t* indptr, void* out, const CsrShape& s, hipStream_t stream) {
   constexpr int VMAX = 16 / (int)sizeof(T);
   const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  if (vec) {
-    const int64_t total = s.leading * s.E * (s.K / VMAX);
-    hipLaunchKernelGGL((gather_csr_kernel<T, VMAX>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const T*>(src), indptr, static_cast<T*>(out), s);
-  } else {
-    const int64_t total = s.leading * s.E * s.K;
-    hipLaunchKernelGGL((gather_csr_kernel<T, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const T*>(src), indptr, static_cast<T*>(out), s);
-  }
-  PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return vec ? launch_gather<T, VMAX>(src, indptr, out, s, stream) : launch_gather<T, 1>(src, indptr, out, s, stream);
 }
 
 template <typename T, bool BACKWARD>
