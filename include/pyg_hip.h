@@ -282,11 +282,14 @@ typedef enum {
  *             initial `out` and untouched buckets keep their value.
  *   index_sorted  != 0 promises an ascending index along e (the COO contract): interior runs are then
  *             reduced without atomics.
- *   workspace optional scratch of pyg_hip_scatter_workspace_size(E) bytes; with it, large unsorted
+ *   workspace optional scratch of pyg_hip_scatter_workspace_size(B, E, N) bytes; with it, large unsorted
  *             float sums sort their indices first (deterministic up to chunk boundaries, ~3x faster
- *             than one atomic per element); without it the atomic kernel runs.
+ *             than one atomic per element), and min / max with an index broadcast along k run
+ *             atomic-free: buckets become CSR rows (directly for a sorted index, after an index sort
+ *             for one large unsorted index vector) reduced in source order -- no CAS loops, no second
+ *             arg pass, same exact values and first-match arg.  Without it the atomic kernels run.
  */
-PYG_HIP_API size_t pyg_hip_scatter_workspace_size(int64_t E);
+PYG_HIP_API size_t pyg_hip_scatter_workspace_size(int64_t B, int64_t E, int64_t N);
 PYG_HIP_API int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index,
                                 int64_t index_stride_b, int64_t index_stride_e,
                                 int64_t index_stride_k, void* out, int64_t* arg_out,

@@ -154,9 +154,12 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
   }
   // scratch for the sort-based sum (large unsorted float scatters only; see pyg_hip_scatter)
   Tensor ws;
-  if (op == OP_SUM && !coo && l.B == 1 && l.isk == 0 && l.ise == 1 && l.E >= (1 << 15) &&
-      at::isFloatingType(src_c.scalar_type()) && l.K * (int64_t)src_c.element_size() >= 64)
-    ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.E)}, src_c.options().dtype(at::kByte));
+  const bool sort_sum = op == OP_SUM && !coo && l.B == 1 && l.isk == 0 && l.ise == 1 && l.E >= (1 << 15) &&
+                        at::isFloatingType(src_c.scalar_type()) && l.K * (int64_t)src_c.element_size() >= 64;
+  // min / max: atomic-free CSR walk for a sorted (COO) index or one large unsorted index vector
+  const bool csr_minmax = minmax && l.isk == 0 && (coo || (l.B == 1 && l.ise == 1 && l.E >= (1 << 15)));
+  if (sort_sum || csr_minmax)
+    ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.B, l.E, l.N)}, src_c.options().dtype(at::kByte));
   check_status(pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk,
                                out.data_ptr(), minmax ? arg.data_ptr<int64_t>() : nullptr,
                                init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N, coo ? 1 : 0,

@@ -52,10 +52,12 @@ struct CsrShape {
 };
 
 // OP: CSR_SUM / CSR_MEAN / CSR_MIN / CSR_MAX.  V elements (16 bytes, or 1) per thread, L lanes per item.
-template <typename T, int OP, int V, int L>
+// PERM: row positions are read through perm[e] (scatter_min/max after an index sort; perm is ascending
+// inside a row, so "first match" is still the smallest source position).
+template <typename T, int OP, int V, int L, bool PERM>
 __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
-                                                          T* __restrict__ out, int64_t* __restrict__ arg,
-                                                          int fresh, CsrShape s) {
+                                                          const int64_t* __restrict__ perm, T* __restrict__ out,
+                                                          int64_t* __restrict__ arg, int fresh, CsrShape s) {
   using acc_t = typename Math<T>::acc_t;
   using P = Pack<T, V>;
   const int64_t kv = s.K / V;
@@ -93,16 +95,17 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   }
   if (live) {
     for (int64_t e = a + lane; e < b; e += L) {
-      const P x = *reinterpret_cast<const P*>(sp + e * s.K);
+      const int64_t p = PERM ? perm[e] : e;
+      const P x = *reinterpret_cast<const P*>(sp + p * s.K);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const acc_t v = Math<T>::up(x.v[i]);
         if constexpr (OP == CSR_SUM || OP == CSR_MEAN) {
           acc[i] += v;
         } else if constexpr (OP == CSR_MIN) {
-          if (v < acc[i]) { acc[i] = v; best[i] = e; }
+          if (v < acc[i]) { acc[i] = v; best[i] = p; }
         } else {
-          if (v > acc[i]) { acc[i] = v; best[i] = e; }
+          if (v > acc[i]) { acc[i] = v; best[i] = p; }
         }
       }
     }
@@ -235,16 +238,16 @@ int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
   return 1;
 }
 
-template <typename T, int OP, int V>
-int launch_segment(const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
-                   hipStream_t stream) {
+template <typename T, int OP, int V, bool PERM = false>
+int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, void* out, int64_t* arg, int fresh,
+                   const CsrShape& s, hipStream_t stream) {
   const int64_t items = s.leading * s.rows * (s.K / V);
   const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
   const T* sp = static_cast<const T*>(src);
   T* op = static_cast<T*>(out);
 #define PYG_CSR_LAUNCH(LL)                                                                                   \
-  hipLaunchKernelGGL((segment_csr_kernel<T, OP, V, LL>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), 0, \
-                     stream, sp, indptr, op, arg, fresh, s)
+  hipLaunchKernelGGL((segment_csr_kernel<T, OP, V, LL, PERM>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), \
+                     0, stream, sp, indptr, perm, op, arg, fresh, s)
   if (L == 64) PYG_CSR_LAUNCH(64);
   else if (L == 8) PYG_CSR_LAUNCH(8);
   else PYG_CSR_LAUNCH(1);
@@ -259,8 +262,8 @@ int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64
   constexpr int VMAX = 16 / (int)sizeof(T);
   const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
 #define PYG_CSR_OP(OPC)                                                                              \
-  return vec ? launch_segment<T, OPC, VMAX>(src, indptr, out, arg, fresh, s, stream)                 \
-             : launch_segment<T, OPC, 1>(src, indptr, out, arg, fresh, s, stream)
+  return vec ? launch_segment<T, OPC, VMAX>(src, indptr, nullptr, out, arg, fresh, s, stream)        \
+             : launch_segment<T, OPC, 1>(src, indptr, nullptr, out, arg, fresh, s, stream)
   switch (op) {
     case CSR_SUM: PYG_CSR_OP(CSR_SUM);
     case CSR_MEAN:
@@ -312,7 +315,29 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
   return PYG_HIP_OK;
 }
 
+template <typename T>
+int run_minmax_perm(int is_min, const void* src, const int64_t* indptr, const int64_t* perm, void* out, int64_t* arg,
+                    int fresh, const CsrShape& s, hipStream_t stream) {
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+#define PYG_MM(OPC, VV)                                                                                  \
+  (perm ? launch_segment<T, OPC, VV, true>(src, indptr, perm, out, arg, fresh, s, stream)                \
+        : launch_segment<T, OPC, VV, false>(src, indptr, nullptr, out, arg, fresh, s, stream))
+  if (is_min) return vec ? PYG_MM(CSR_MIN, VMAX) : PYG_MM(CSR_MIN, 1);
+  return vec ? PYG_MM(CSR_MAX, VMAX) : PYG_MM(CSR_MAX, 1);
+#undef PYG_MM
+}
+
 }  // namespace
+
+int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,
+                       const int64_t* perm, void* out, int64_t* arg, int fresh, int64_t leading, int64_t rows,
+                       int64_t E, int64_t K, hipStream_t stream) {
+  if (leading * rows * K == 0) return PYG_HIP_OK;
+  const CsrShape s{leading, rows, E, K, indptr_stride};
+  PYG_DISPATCH_ALL(dtype, (run_minmax_perm<scalar_t>(is_min, src, indptr, perm, out, arg, fresh, s, stream)));
+}
+
 }  // namespace pyg_hip
 
 using namespace pyg_hip;

@@ -367,6 +367,37 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline size_t scatter_sort_ws_bytes(int64_t E) {
   return 2 * align_up(sizeof(int64_t) * (size_t)(E > 0 ? E : 1), 256) + index_sort_ws_bytes_i64(E);
 }
+// ... followed by the CSR pointer of the (sorted) index: B * (N + 1) offsets
+inline size_t scatter_indptr_bytes(int64_t B, int64_t N) {
+  return align_up(sizeof(int64_t) * (size_t)(B > 0 ? B : 1) * (size_t)(N + 1), 256);
+}
+
+// indptr[b, r] = first position e of row b with index[b, e] >= r (index ascending along e)
+__global__ void coo_indptr_kernel(const int64_t* __restrict__ index, int64_t isb, int64_t ise, int64_t B, int64_t E,
+                                  int64_t N, int64_t* __restrict__ indptr) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= B * (N + 1)) return;
+  const int64_t b = t / (N + 1), r = t % (N + 1);
+  const int64_t* ip = index + b * isb;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (ip[mid * ise] < r) lo = mid + 1; else hi = mid;
+  }
+  indptr[t] = lo;
+}
+
+template <typename T>
+constexpr int dtype_of();
+template <> constexpr int dtype_of<float>() { return PYG_F32; }
+template <> constexpr int dtype_of<double>() { return PYG_F64; }
+template <> constexpr int dtype_of<f16_t>() { return PYG_F16; }
+template <> constexpr int dtype_of<bf16_t>() { return PYG_BF16; }
+template <> constexpr int dtype_of<int8_t>() { return PYG_I8; }
+template <> constexpr int dtype_of<uint8_t>() { return PYG_U8; }
+template <> constexpr int dtype_of<int16_t>() { return PYG_I16; }
+template <> constexpr int dtype_of<int32_t>() { return PYG_I32; }
+template <> constexpr int dtype_of<int64_t>() { return PYG_I64; }
 
 template <typename T>
 int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int64_t* arg, const void* init_,
@@ -422,6 +453,38 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
     hipLaunchKernelGGL((scatter_elem_kernel<T, OP_MUL>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
   } else if (op == OP_MIN || op == OP_MAX) {
     PYG_HIP_REQUIRE(arg != nullptr, "scatter_min/max: 'arg_out' is NULL");
+    // Atomic-free path: with the index ascending along e (the COO contract), or after sorting one
+    // index vector, buckets are CSR rows -- one thread per (bucket, 16-byte slice) walks its row in
+    // source order with the reference's strict compare (values and first-match arg exact, no CAS
+    // loops, no second pass).  Needs an index broadcast along k and the caller's workspace.
+    if (s.isk == 0 && ws) {
+      char* w = static_cast<char*>(ws);
+      const size_t ip_bytes = scatter_indptr_bytes(s.B, s.N);
+      if (sorted && ws_bytes >= ip_bytes) {
+        int64_t* indptr = reinterpret_cast<int64_t*>(w);
+        const int64_t n = s.B * (s.N + 1);
+        hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, index, s.isb,
+                           s.ise, s.B, s.E, s.N, indptr);
+        PYG_HIP_CHECK(hipGetLastError());
+        return segment_csr_minmax(op == OP_MIN, dtype_of<T>(), src, indptr, s.N + 1, nullptr, out, arg, init ? 0 : 1,
+                                  s.B, s.N, s.E, s.K, stream);
+      }
+      const size_t sort_bytes = scatter_sort_ws_bytes(s.E);
+      if (!sorted && s.B == 1 && s.ise == 1 && s.E >= (1 << 15) && ws_bytes >= sort_bytes + scatter_indptr_bytes(1, s.N)) {
+        int64_t* keys = reinterpret_cast<int64_t*>(w);
+        int64_t* perm = reinterpret_cast<int64_t*>(w + align_up(sizeof(int64_t) * (size_t)s.E, 256));
+        void* sws = w + 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256);
+        int64_t* indptr = reinterpret_cast<int64_t*>(w + sort_bytes);
+        int rc = index_sort_i64(index, s.E, s.N > 0 ? s.N - 1 : 0, keys, perm, sws,
+                                sort_bytes - 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256), stream);
+        if (rc != PYG_HIP_OK) return rc;
+        hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((s.N + 1 + 255) / 256)), dim3(256), 0, stream,
+                           (const int64_t*)keys, (int64_t)0, (int64_t)1, (int64_t)1, s.E, s.N, indptr);
+        PYG_HIP_CHECK(hipGetLastError());
+        return segment_csr_minmax(op == OP_MIN, dtype_of<T>(), src, indptr, s.N + 1, perm, out, arg, init ? 0 : 1, 1,
+                                  s.N, s.E, s.K, stream);
+      }
+    }
     hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, stream, arg, outn,
                        s.E);
     if (op == OP_MIN) {
@@ -482,7 +545,9 @@ using namespace pyg_hip;
 
 extern "C" {
 
-size_t pyg_hip_scatter_workspace_size(int64_t E) { return scatter_sort_ws_bytes(E < 0 ? 0 : E); }
+size_t pyg_hip_scatter_workspace_size(int64_t B, int64_t E, int64_t N) {
+  return scatter_sort_ws_bytes(E < 0 ? 0 : E) + scatter_indptr_bytes(B < 1 ? 1 : B, N < 0 ? 0 : N);
+}
 
 int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index, int64_t index_stride_b,
                     int64_t index_stride_e, int64_t index_stride_k, void* out, int64_t* arg_out,
