@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--no-sampler', action='store_true')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--debug-one-device', action='store_true',
+                    help='debug only: all ranks share cuda:0 over gloo (exercises the N>1 code path on a 1-GPU box)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -106,11 +108,16 @@ def main():
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     import torch.distributed as dist
     distributed = world > 1
+    if args.debug_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if args.debug_one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     import pyg_lib_amd
     from pyg_lib_amd import ops, _capi
