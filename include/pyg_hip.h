@@ -116,6 +116,21 @@ PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_ho
  * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 
+/*
+ * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]
+ * (input [N, K], grad_out [N, M], grad_other [B, K, M]; fp32 accumulation, one rounding).  Replaces the
+ * per-relation loop of SegmentMatmul::backward (ops/autograd/matmul_kernel.cpp:92-107: B x
+ * at::matmul(input_i^T, grad_out_i) + at::stack) with one persistent launch.  bf16 / fp16 with
+ * K in {64, 128, 256} and M % 64 == 0; other cases return PYG_HIP_ERR_UNSUPPORTED (the caller keeps the
+ * reference formula).  `workspace`: pyg_hip_segment_matmul_dw_workspace_size(B, K, M) bytes of device
+ * scratch (tile plan + fp32 accumulators).  Never synchronises.
+ */
+PYG_HIP_API size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M);
+PYG_HIP_API int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,
+                                          const void* grad_out, void* grad_other, int64_t N, int64_t K,
+                                          int64_t M, int64_t B, void* workspace, size_t workspace_bytes,
+                                          void* stream);
+
 /* ---- neighbor_sample / hetero_neighbor_sample ---------------------------------------------- */
 
 /* Host services the sampler needs from its caller (the torch binding supplies the PyTorch

@@ -174,6 +174,26 @@ static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& p
   return op.call(input, ptr, other);
 }
 
+// dW through the C-ABI; returns an undefined tensor when the device kernel does not cover the case.
+static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, const Tensor& other) {
+  const auto st = input.scalar_type();
+  if (st != at::kBFloat16 && st != at::kHalf) return Tensor();
+  const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
+  if (!(K == 64 || K == 128 || K == 256) || M % 64 != 0 || B == 0) return Tensor();
+  DeviceGuard guard(input.device());
+  auto x = input.contiguous();
+  auto gy = grad_out.contiguous();
+  auto p = ptr.contiguous();
+  auto out = at::empty({B, K, M}, other.options());
+  auto ws = at::empty({(int64_t)pyg_hip_segment_matmul_dw_workspace_size(B, K, M)}, x.options().dtype(at::kByte));
+  const int rc = pyg_hip_segment_matmul_dw(dtype_code(st), x.data_ptr(), p.data_ptr<int64_t>(), p.is_cuda() ? 1 : 0,
+                                           gy.data_ptr(), out.data_ptr(), x.size(0), K, M, B, ws.data_ptr(),
+                                           (size_t)ws.numel(), current_stream(x));
+  if (rc == PYG_HIP_ERR_UNSUPPORTED) return Tensor();
+  check_status(rc);
+  return out;
+}
+
 class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
  public:
   static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx,
@@ -196,7 +216,11 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
       input_grad = segment_matmul_below_autograd(grad_out, ptr, other.transpose(-2, -1));
     }
     if (torch::autograd::any_variable_requires_grad({other})) {
-      // dW[b] = X_b^T @ dY_b
+      // dW[b] = X_b^T @ dY_b: one persistent MFMA launch for the 16-bit types (csrc/hip/matmul_dw.hip) ...
+      other_grad = segment_matmul_dw(input, ptr, grad_out, other);
+    }
+    if (torch::autograd::any_variable_requires_grad({other}) && !other_grad.defined()) {
+      // ... the reference's per-relation formula elsewhere (fp32 / fp64 / unsupported shapes)
       const auto size = (ptr.narrow(0, 1, ptr.numel() - 1) - ptr.narrow(0, 0, ptr.numel() - 1)).cpu();
       const auto sizes = at::IntArrayRef(size.data_ptr<int64_t>(), (size_t)size.numel());
       const auto xs = input.split_with_sizes(sizes, 0);

@@ -1,0 +1,334 @@
+// Weight gradient of segment_matmul for gfx950 (MI355X):  dW[b] = X_b^T @ dY_b  for every relation b.
+//
+// Replaces the reference's B-iteration backward (pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:92-107:
+// one at::matmul per relation + at::stack) with one persistent launch.  HBM-bound
+// like the forward: X and dY are read exactly once (2 N F s bytes), the B small K x M results are
+// accumulated in fp32.
+//
+//   * Same tiling as the forward: 128-row tiles that never cross a relation, every workgroup walks a
+//     contiguous tile range, so it meets ~1.3 relations and flushes its accumulators only then.
+//   * Each of the 4 waves owns 32 rows of a tile and a FULL K x MC fp32 accumulator block in
+//     registers ((K/32) x (MC/32) MFMA blocks x 16 = 256 accumulators; 1 wave / SIMD): the waves never
+//     exchange data and there is no workgroup barrier in the loop.
+//   * The contraction runs over ROWS, so both MFMA operands are "8 rows of one column" -- transposed
+//     with respect to the row-major tensors.  Rows are loaded with fully coalesced 1 KiB wave
+//     accesses, parked in a wave-private row-major LDS image, and read back through gfx950's LDS
+//     transpose read (ds_read_b64_tr_b16: every 16-lane group turns a 4 x 16 block into per-lane
+//     4-row columns): 2 reads per MFMA operand instead of 8 two-byte reads.  The image pitch is
+//     16 (mod 64) dwords, which keeps the two 16-lane groups of a 32-lane service group and the 4 rows
+//     of a block on disjoint banks.
+//   * Accumulators are flushed with native global_atomic_add_f32 into an fp32 [B, K, M] scratch
+//     (43 M atomics for C2, L2-resident) and rounded once to the storage type by a tiny epilogue.
+#include "common.h"
+
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace pyg_hip {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef short v8i16 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 128;  // rows per workgroup tile (4 waves x 32)
+
+struct bf16_tag {};
+struct f16_tag {};
+
+__device__ __forceinline__ f32x16 mfma16(bf16_tag, v8i16 a, v8i16 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16_tag, v8i16 a, v8i16 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// pitch (bytes) of a row-major [32][cols] 16-bit LDS image: >= the row, == 16 (mod 64) dwords
+constexpr int pitch_bytes(int cols) {
+  const int dw = cols / 2;
+  const int extra = dw > 16 ? (dw - 16 + 63) / 64 : 0;
+  return (16 + 64 * extra) * 4;
+}
+
+// tile prefix of the relations: tile_start[b] = sum_{b' < b} ceil(rows_b' / 128)
+__global__ void dw_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ tile_start) {
+  __shared__ int64_t part[256];
+  const int tid = threadIdx.x;
+  const int64_t per = (B + 255) / 256;
+  const int64_t beg = min((int64_t)tid * per, B), end = min(beg + per, B);
+  int64_t t = 0;
+  for (int64_t b = beg; b < end; ++b) {
+    const int64_t r = ptr[b + 1] - ptr[b];
+    t += r > 0 ? (r + kTile - 1) / kTile : 0;
+  }
+  part[tid] = t;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t v = part[i];
+      part[i] = acc;
+      acc += v;
+    }
+    tile_start[B] = (int32_t)acc;
+  }
+  __syncthreads();
+  t = part[tid];
+  for (int64_t b = beg; b < end; ++b) {
+    tile_start[b] = (int32_t)t;
+    const int64_t r = ptr[b + 1] - ptr[b];
+    t += r > 0 ? (r + kTile - 1) / kTile : 0;
+  }
+}
+
+template <typename Tag, int K, int MC>
+__global__ __launch_bounds__(256, 1) void seg_dw_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
+                                                         const int64_t* __restrict__ ptr,
+                                                         const int32_t* __restrict__ tile_start, int B, int M,
+                                                         float* __restrict__ acc_out) {
+  constexpr int IB = K / 32, JB = MC / 32;
+  constexpr int PX = pitch_bytes(K), PY = pitch_bytes(MC);
+  constexpr int CX = K / 8, CY = MC / 8;          // 16-byte chunks per row
+  constexpr int NX = 32 * CX / 64, NY = 32 * CY / 64;  // chunk loads per lane and tile
+  static_assert(IB * JB <= 16, "accumulators must fit the register file");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* xs = smem + wave * 32 * (PX + PY);
+  char* ys = xs + 32 * PX;
+  const int col0 = blockIdx.y * MC;
+
+  const int total = tile_start[B];
+  const int G = gridDim.x;
+  const int t_beg = (int)((int64_t)blockIdx.x * total / G);
+  const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
+  if (t_beg >= t_end) return;
+  int g = 0;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_beg) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+
+  f32x16 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  int acc_g = -1;  // relation the accumulators belong to
+
+  auto flush = [&]() {
+    if (acc_g < 0) return;
+    float* base = acc_out + ((int64_t)acc_g * K) * M + col0;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = j * 32 + (lane & 31);
+          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][r] = 0.0f;
+        }
+  };
+
+  // software pipeline: rows of tile t+1 travel to registers while tile t is multiplied
+  u32x4 xr[NX], yr[NY];
+  int n_g = g;
+  auto prefetch = [&](int t) {
+    while (t >= tile_start[n_g + 1]) ++n_g;
+    const int64_t seg0 = ptr[n_g], seg1 = ptr[n_g + 1];
+    const int64_t row0 = seg0 + (int64_t)(t - tile_start[n_g]) * kTile + wave * 32;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int p = it * 64 + lane;
+      const int64_t row = row0 + p / CX;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < seg1) v = *reinterpret_cast<const u32x4*>(X + row * K + (p % CX) * 8);
+      xr[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int p = it * 64 + lane;
+      const int64_t row = row0 + p / CY;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < seg1) v = *reinterpret_cast<const u32x4*>(dY + row * M + col0 + (p % CY) * 8);
+      yr[it] = v;
+    }
+  };
+
+  // lane constants of the transpose reads: lane q of a 16-lane group supplies row (q >> 2), columns
+  // (q & 3) * 4 of a 4 x 16 block and receives column q; group = (column half, row half kb)
+  const int q = lane & 15, half = (lane >> 4) & 1, kb = lane >> 5;
+  const int a_off = (kb * 8 + (q >> 2)) * PX + (half * 16 + (q & 3) * 4) * 2;
+  const int b_off = (kb * 8 + (q >> 2)) * PY + (half * 16 + (q & 3) * 4) * 2;
+  typedef __attribute__((address_space(3))) v4i16* lds_v4;
+
+  prefetch(t_beg);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int cur_g = n_g;  // relation of the tile held in xr / yr
+    if (cur_g != acc_g) {
+      flush();
+      acc_g = cur_g;
+    }
+    // park the tile in the wave-private LDS image (row-major)
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int p = it * 64 + lane;
+      *reinterpret_cast<u32x4*>(xs + (p / CX) * PX + (p % CX) * 16) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int p = it * 64 + lane;
+      *reinterpret_cast<u32x4*>(ys + (p / CY) * PY + (p % CY) * 16) = yr[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (t + 1 < t_end) prefetch(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v8i16 af[IB], bf[JB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const char* p = xs + a_off + ks * 16 * PX + i * 64;
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * PX));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const char* p = ys + b_off + ks * 16 * PY + j * 64;
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * PY));
+        bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = mfma16(Tag{}, af[i], bf[j], acc[i][j]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  flush();
+}
+
+// dW[b, k, m] = round(acc[b, k, m])
+template <typename Tag>
+__global__ void dw_round_kernel(const float* __restrict__ acc, uint16_t* __restrict__ out, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if constexpr (sizeof(Tag) && __is_same(Tag, bf16_tag)) out[i] = __builtin_bit_cast(uint16_t, (__bf16)acc[i]);
+  else out[i] = __builtin_bit_cast(uint16_t, (_Float16)acc[i]);
+}
+
+struct DwWorkspace {
+  int64_t* ptr_dev;
+  int32_t* tile_start;
+  float* acc;
+};
+
+inline size_t dw_ws_bytes(int64_t B, int64_t K, int64_t M) {
+  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + align_up(sizeof(int32_t) * (size_t)(B + 1), 256) +
+         align_up(sizeof(float) * (size_t)B * (size_t)K * (size_t)M, 256);
+}
+
+template <typename Tag, int K, int MC>
+int launch_dw(const void* X, const void* dY, const int64_t* ptr, const int32_t* tile_start, int64_t B, int64_t M,
+              int64_t tiles_upper, float* acc, hipStream_t stream) {
+  constexpr int lds = 4 * 32 * (pitch_bytes(K) + pitch_bytes(MC));
+  const void* kern = reinterpret_cast<const void*>(&seg_dw_kernel<Tag, K, MC>);
+  static thread_local bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int64_t cus = device_info().num_cus;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus));
+  hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), lds, stream,
+                     static_cast<const uint16_t*>(X), static_cast<const uint16_t*>(dY), ptr, tile_start, (int)B, (int)M,
+                     acc);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename Tag>
+int run_dw(const void* X, const void* dY, const int64_t* ptr, const int32_t* tile_start, int64_t B, int64_t K, int64_t M,
+           int64_t tiles_upper, float* acc, hipStream_t stream) {
+  if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 64 == 0) return launch_dw<Tag, 64, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 256 && M % 64 == 0) return launch_dw<Tag, 256, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+  return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: K=%lld, M=%lld has no MFMA kernel (K in {64,128,256}, M %% 64 == 0)",
+              (long long)K, (long long)M);
+}
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" {
+
+size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M) {
+  return dw_ws_bytes(B < 0 ? 0 : B, K < 0 ? 0 : K, M < 0 ? 0 : M);
+}
+
+int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, int ptr_on_device, const void* grad_out,
+                              void* grad_other, int64_t N, int64_t K, int64_t M, int64_t B, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(N >= 0 && K >= 0 && M >= 0 && B >= 0, "segment_matmul_dw: negative size");
+  if (B * K * M == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(ptr && grad_other && (N == 0 || (input && grad_out)), "segment_matmul_dw: NULL tensor");
+  if (dtype != PYG_BF16 && dtype != PYG_F16)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: 16-bit floating types only (dtype %d)", dtype);
+  PYG_HIP_REQUIRE(((uintptr_t)input % 16 == 0) && ((uintptr_t)grad_out % 16 == 0), "segment_matmul_dw: tensors must be 16-byte aligned");
+  if (workspace == nullptr || workspace_bytes < dw_ws_bytes(B, K, M))
+    return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul_dw: workspace of %zu bytes needed, got %zu", dw_ws_bytes(B, K, M),
+                workspace_bytes);
+  char* w = static_cast<char*>(workspace);
+  int64_t* ptr_dev = reinterpret_cast<int64_t*>(w);
+  int32_t* tile_start = reinterpret_cast<int32_t*>(w + align_up(sizeof(int64_t) * (size_t)(B + 1), 256));
+  float* acc = reinterpret_cast<float*>(w + align_up(sizeof(int64_t) * (size_t)(B + 1), 256) +
+                                        align_up(sizeof(int32_t) * (size_t)(B + 1), 256));
+  const int64_t* dptr = ptr;
+  if (!ptr_on_device) {
+    void* staged = nullptr;
+    int rc = pinned_stage().acquire(sizeof(int64_t) * (size_t)(B + 1), &staged);
+    if (rc != PYG_HIP_OK) return rc;
+    ::memcpy(staged, ptr, sizeof(int64_t) * (size_t)(B + 1));
+    PYG_HIP_CHECK(hipMemcpyAsync(ptr_dev, staged, sizeof(int64_t) * (size_t)(B + 1), hipMemcpyHostToDevice, stream));
+    rc = pinned_stage().commit(stream);
+    if (rc != PYG_HIP_OK) return rc;
+    dptr = ptr_dev;
+  }
+  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)B * (size_t)K * (size_t)M, stream));
+  hipLaunchKernelGGL(dw_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, tile_start);
+  PYG_HIP_CHECK(hipGetLastError());
+  const int64_t tiles_upper = (N + kTile - 1) / kTile + B;
+  int rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(input, grad_out, dptr, tile_start, B, K, M, tiles_upper, acc, stream)
+                             : run_dw<f16_tag>(input, grad_out, dptr, tile_start, B, K, M, tiles_upper, acc, stream);
+  if (rc != PYG_HIP_OK) return rc;
+  const int64_t n = B * K * M;
+  if (dtype == PYG_BF16)
+    hipLaunchKernelGGL(dw_round_kernel<bf16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
+                       static_cast<uint16_t*>(grad_other), n);
+  else
+    hipLaunchKernelGGL(dw_round_kernel<f16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
+                       static_cast<uint16_t*>(grad_other), n);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+}  // extern "C"

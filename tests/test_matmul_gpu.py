@@ -260,3 +260,53 @@ def test_full_size_c2_properties():
         total += float(out[s:e].double().sum() - exp.double().sum())
     assert bad == 0
     assert abs(total) < 1e-6
+
+
+# ---- weight gradient kernel (csrc/hip/matmul_dw.hip) ---------------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('K,M', [(128, 128), (64, 64), (128, 64), (64, 128), (256, 256), (128, 256)])
+def test_segment_matmul_weight_gradient_kernel(dtype, K, M):
+    # ragged relations incl. empty ones, sizes that are not tile multiples, one relation > many tiles
+    sizes = [0, 37, 128, 129, 1000, 0, 5000, 31, 257]
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    N, B = int(ptr[-1]), len(sizes)
+    g = torch.Generator().manual_seed(K * 1000 + M)
+    x = torch.randn(N, K, generator=g).to(dtype)
+    w = (torch.randn(B, K, M, generator=g) / K ** 0.5).to(dtype)
+    gy = torch.randn(N, M, generator=g).to(dtype)
+    xd = x.cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    y = ops.segment_matmul(xd, ptr, wd)
+    gx, gw = torch.autograd.grad(y, [xd, wd], gy.cuda())
+    # float64 reference from the stored values: dW[b] = X_b^T dY_b, dX = dY W^T
+    want_w = torch.stack([x[ptr[b]:ptr[b + 1]].double().t() @ gy[ptr[b]:ptr[b + 1]].double() for b in range(B)])
+    want_x = torch.cat([gy[ptr[b]:ptr[b + 1]].double() @ w[b].double().t() for b in range(B)])
+    eps = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    scale_w = want_w.abs().max().item()
+    assert (gw.double().cpu() - want_w).abs().max().item() <= eps * scale_w * 1.01 + 1e-6
+    assert (gx.double().cpu() - want_x).abs().max().item() <= eps * want_x.abs().max().item() * 1.01 + 1e-6
+    assert gw.shape == w.shape and gw.dtype == dtype
+    # device-resident ptr takes the same path (fp32 partials meet in atomic order: equal up to rounding)
+    y2 = ops.segment_matmul(xd, ptr.cuda(), wd)
+    (gw2,) = torch.autograd.grad(y2, [wd], gy.cuda())
+    assert (gw2.double() - gw.double()).abs().max().item() <= eps * scale_w * 1.01 + 1e-6
+
+
+def test_weight_gradient_is_transpose_detecting_and_linear():
+    # asymmetric one-hot inputs: dW[k, m] must pick up exactly (row with x[:, k] = 1) . dY[:, m]
+    K = M = 128
+    ptr = torch.tensor([0, 200, 456])
+    x = torch.zeros(456, K)
+    gy = torch.zeros(456, M)
+    x[7, 3] = 1.0
+    gy[7, 100] = 2.0
+    x[300, 127] = 1.0
+    gy[300, 0] = -4.0
+    xd = x.to(torch.bfloat16).cuda()
+    wd = torch.zeros(2, K, M, dtype=torch.bfloat16, device='cuda', requires_grad=True)
+    y = ops.segment_matmul(xd, ptr, wd)
+    (gw,) = torch.autograd.grad(y, [wd], gy.to(torch.bfloat16).cuda())
+    want = torch.zeros(2, K, M)
+    want[0, 3, 100] = 2.0
+    want[1, 127, 0] = -4.0
+    assert torch.equal(gw.float().cpu(), want)
