@@ -126,6 +126,12 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  * scratch (tile plan + fp32 accumulators).  Never synchronises.
  */
 PYG_HIP_API size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M);
+/* Grouped form (the others_grad of GroupedMatmul.backward, pyg_lib/ops/__init__.py:88-94): for every
+ * group i, out_pool[i] = input_i^T @ other_i with input_i [rows_i, k] and other_i [rows_i, m] row-major
+ * (uniform k, m; `out`/`other_trans` of pyg_hip_group are ignored); out_pool is one [G, k, m] block.
+ * Same kernel, same workspace formula (B = G). */
+PYG_HIP_API int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* groups, int64_t G, void* out_pool,
+                                          void* workspace, size_t workspace_bytes, void* stream);
 PYG_HIP_API int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,
                                           const void* grad_out, void* grad_other, int64_t N, int64_t K,
                                           int64_t M, int64_t B, void* workspace, size_t workspace_bytes,

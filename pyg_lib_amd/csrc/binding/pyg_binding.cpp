@@ -125,6 +125,42 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
   std::vector<Tensor> keep;
   keep.reserve(2 * G);
   outs.reserve(G);
+  // Weight-gradient pattern of GroupedMatmul.backward (pyg_lib/ops/__init__.py:88-94): every input is
+  // the transposed view X_i^T of a row-major X_i [rows_i, K] and the contraction runs over rows_i.
+  // One persistent launch of the dW kernel (csrc/hip/matmul_dw.hip) instead of a transposing copy of
+  // every X_i and G skinny GEMMs.
+  {
+    const auto st = input[0].scalar_type();
+    bool dw = (st == at::kBFloat16 || st == at::kHalf);
+    const int64_t K = input[0].size(0), M = other[0].size(1);
+    dw = dw && (K == 64 || K == 128 || K == 256) && M % 64 == 0;
+    for (size_t i = 0; dw && i < G; ++i)
+      dw = input[i].size(0) == K && other[i].size(1) == M && !input[i].is_contiguous() &&
+           input[i].t().is_contiguous() && other[i].is_contiguous() && (uintptr_t)input[i].data_ptr() % 16 == 0 &&
+           (uintptr_t)other[i].data_ptr() % 16 == 0;
+    if (dw) {
+      for (size_t i = 0; i < G; ++i) {
+        groups[i].input = input[i].data_ptr();  // X_i, row-major [rows_i, K]
+        groups[i].other = other[i].data_ptr();  // dY_i [rows_i, M]
+        groups[i].out = nullptr;
+        groups[i].rows = input[i].size(1);
+        groups[i].k = (int32_t)K;
+        groups[i].m = (int32_t)M;
+        groups[i].other_trans = 0;
+        groups[i].reserved = 0;
+      }
+      auto pool = at::empty({(int64_t)G, K, M}, input[0].options());
+      auto ws = at::empty({(int64_t)pyg_hip_segment_matmul_dw_workspace_size((int64_t)G, K, M)},
+                          input[0].options().dtype(at::kByte));
+      const int rc = pyg_hip_grouped_matmul_dw(dtype_code(st), groups.data(), (int64_t)G, pool.data_ptr(), ws.data_ptr(),
+                                               (size_t)ws.numel(), current_stream(input[0]));
+      if (rc == PYG_HIP_OK) {
+        for (size_t i = 0; i < G; ++i) outs.push_back(pool.select(0, (int64_t)i));
+        return outs;
+      }
+      TORCH_CHECK(rc == PYG_HIP_ERR_UNSUPPORTED, pyg_hip_last_error());
+    }
+  }
   // One allocation for all outputs (the reference makes G of them, matmul_kernel.cpp:296-298); each
   // output is a 16-byte aligned view into it.
   const int64_t elt = (int64_t)input[0].element_size();

@@ -55,8 +55,17 @@ constexpr int pitch_bytes(int cols) {
   return (16 + 64 * extra) * 4;
 }
 
-// tile prefix of the relations: tile_start[b] = sum_{b' < b} ceil(rows_b' / 128)
-__global__ void dw_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ tile_start) {
+// One relation / group: `rows` rows of X [rows, K] and dY [rows, M] (row-major, M = row pitch of dY).
+struct DwGroup {
+  const uint16_t* x;
+  const uint16_t* dy;
+  int64_t rows;
+};
+
+// segment form: descriptors + tile prefix from ptr; tile_start[b] = sum_{b' < b} ceil(rows_b' / 128)
+__global__ void dw_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, const uint16_t* X, const uint16_t* dY,
+                               int64_t K, int64_t M, DwGroup* __restrict__ groups,
+                               int32_t* __restrict__ tile_start) {
   __shared__ int64_t part[256];
   const int tid = threadIdx.x;
   const int64_t per = (B + 255) / 256;
@@ -81,14 +90,19 @@ __global__ void dw_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, int32
   t = part[tid];
   for (int64_t b = beg; b < end; ++b) {
     tile_start[b] = (int32_t)t;
-    const int64_t r = ptr[b + 1] - ptr[b];
+    const int64_t p0 = ptr[b];
+    const int64_t r = ptr[b + 1] - p0;
+    DwGroup d;
+    d.x = X + p0 * K;
+    d.dy = dY + p0 * M;
+    d.rows = r > 0 ? r : 0;
+    groups[b] = d;
     t += r > 0 ? (r + kTile - 1) / kTile : 0;
   }
 }
 
 template <typename Tag, int K, int MC>
-__global__ __launch_bounds__(256, 1) void seg_dw_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
-                                                         const int64_t* __restrict__ ptr,
+__global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restrict__ groups,
                                                          const int32_t* __restrict__ tile_start, int B, int M,
                                                          float* __restrict__ acc_out) {
   constexpr int IB = K / 32, JB = MC / 32;
@@ -145,16 +159,19 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const uint16_t* __restri
   // software pipeline: rows of tile t+1 travel to registers while tile t is multiplied
   u32x4 xr[NX], yr[NY];
   int n_g = g;
+  DwGroup gd = groups[g];
   auto prefetch = [&](int t) {
-    while (t >= tile_start[n_g + 1]) ++n_g;
-    const int64_t seg0 = ptr[n_g], seg1 = ptr[n_g + 1];
-    const int64_t row0 = seg0 + (int64_t)(t - tile_start[n_g]) * kTile + wave * 32;
+    while (t >= tile_start[n_g + 1]) {
+      ++n_g;
+      gd = groups[n_g];
+    }
+    const int64_t row0 = (int64_t)(t - tile_start[n_g]) * kTile + wave * 32;
 #pragma unroll
     for (int it = 0; it < NX; ++it) {
       const int p = it * 64 + lane;
       const int64_t row = row0 + p / CX;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < seg1) v = *reinterpret_cast<const u32x4*>(X + row * K + (p % CX) * 8);
+      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.x + row * K + (p % CX) * 8);
       xr[it] = v;
     }
 #pragma unroll
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const uint16_t* __restri
       const int p = it * 64 + lane;
       const int64_t row = row0 + p / CY;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < seg1) v = *reinterpret_cast<const u32x4*>(dY + row * M + col0 + (p % CY) * 8);
+      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.dy + row * M + col0 + (p % CY) * 8);
       yr[it] = v;
     }
   };
@@ -231,20 +248,16 @@ __global__ void dw_round_kernel(const float* __restrict__ acc, uint16_t* __restr
   else out[i] = __builtin_bit_cast(uint16_t, (_Float16)acc[i]);
 }
 
-struct DwWorkspace {
-  int64_t* ptr_dev;
-  int32_t* tile_start;
-  float* acc;
-};
-
+inline size_t dw_groups_bytes(int64_t B) { return align_up(sizeof(DwGroup) * (size_t)(B > 0 ? B : 1), 256); }
+inline size_t dw_tiles_bytes(int64_t B) { return align_up(sizeof(int32_t) * (size_t)(B + 1), 256); }
 inline size_t dw_ws_bytes(int64_t B, int64_t K, int64_t M) {
-  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + align_up(sizeof(int32_t) * (size_t)(B + 1), 256) +
+  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + dw_groups_bytes(B) + dw_tiles_bytes(B) +
          align_up(sizeof(float) * (size_t)B * (size_t)K * (size_t)M, 256);
 }
 
 template <typename Tag, int K, int MC>
-int launch_dw(const void* X, const void* dY, const int64_t* ptr, const int32_t* tile_start, int64_t B, int64_t M,
-              int64_t tiles_upper, float* acc, hipStream_t stream) {
+int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* acc,
+              hipStream_t stream) {
   constexpr int lds = 4 * 32 * (pitch_bytes(K) + pitch_bytes(MC));
   const void* kern = reinterpret_cast<const void*>(&seg_dw_kernel<Tag, K, MC>);
   static thread_local bool attr_set = false;  // per instantiation
@@ -254,23 +267,33 @@ int launch_dw(const void* X, const void* dY, const int64_t* ptr, const int32_t* 
   }
   const int64_t cus = device_info().num_cus;
   const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus));
-  hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), lds, stream,
-                     static_cast<const uint16_t*>(X), static_cast<const uint16_t*>(dY), ptr, tile_start, (int)B, (int)M,
-                     acc);
+  hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), lds, stream, groups,
+                     tile_start, (int)B, (int)M, acc);
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
 }
 
 template <typename Tag>
-int run_dw(const void* X, const void* dY, const int64_t* ptr, const int32_t* tile_start, int64_t B, int64_t K, int64_t M,
-           int64_t tiles_upper, float* acc, hipStream_t stream) {
-  if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 64 == 0) return launch_dw<Tag, 64, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 256 && M % 64 == 0) return launch_dw<Tag, 256, 64>(X, dY, ptr, tile_start, B, M, tiles_upper, acc, stream);
+int run_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
+           float* acc, hipStream_t stream) {
+  if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 64 == 0) return launch_dw<Tag, 64, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 256 && M % 64 == 0) return launch_dw<Tag, 256, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
   return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: K=%lld, M=%lld has no MFMA kernel (K in {64,128,256}, M %% 64 == 0)",
               (long long)K, (long long)M);
+}
+
+int round_out(int dtype, const float* acc, void* out, int64_t n, hipStream_t stream) {
+  if (dtype == PYG_BF16)
+    hipLaunchKernelGGL(dw_round_kernel<bf16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
+                       static_cast<uint16_t*>(out), n);
+  else
+    hipLaunchKernelGGL(dw_round_kernel<f16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
+                       static_cast<uint16_t*>(out), n);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
 }
 
 }  // namespace
@@ -299,9 +322,12 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
                 workspace_bytes);
   char* w = static_cast<char*>(workspace);
   int64_t* ptr_dev = reinterpret_cast<int64_t*>(w);
-  int32_t* tile_start = reinterpret_cast<int32_t*>(w + align_up(sizeof(int64_t) * (size_t)(B + 1), 256));
-  float* acc = reinterpret_cast<float*>(w + align_up(sizeof(int64_t) * (size_t)(B + 1), 256) +
-                                        align_up(sizeof(int32_t) * (size_t)(B + 1), 256));
+  w += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  DwGroup* groups = reinterpret_cast<DwGroup*>(w);
+  w += dw_groups_bytes(B);
+  int32_t* tile_start = reinterpret_cast<int32_t*>(w);
+  w += dw_tiles_bytes(B);
+  float* acc = reinterpret_cast<float*>(w);
   const int64_t* dptr = ptr;
   if (!ptr_on_device) {
     void* staged = nullptr;
@@ -314,21 +340,68 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
     dptr = ptr_dev;
   }
   PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)B * (size_t)K * (size_t)M, stream));
-  hipLaunchKernelGGL(dw_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, tile_start);
+  hipLaunchKernelGGL(dw_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, static_cast<const uint16_t*>(input),
+                     static_cast<const uint16_t*>(grad_out), K, M, groups, tile_start);
   PYG_HIP_CHECK(hipGetLastError());
   const int64_t tiles_upper = (N + kTile - 1) / kTile + B;
-  int rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(input, grad_out, dptr, tile_start, B, K, M, tiles_upper, acc, stream)
-                             : run_dw<f16_tag>(input, grad_out, dptr, tile_start, B, K, M, tiles_upper, acc, stream);
+  int rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream)
+                             : run_dw<f16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream);
   if (rc != PYG_HIP_OK) return rc;
-  const int64_t n = B * K * M;
-  if (dtype == PYG_BF16)
-    hipLaunchKernelGGL(dw_round_kernel<bf16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(grad_other), n);
-  else
-    hipLaunchKernelGGL(dw_round_kernel<f16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(grad_other), n);
-  PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return round_out(dtype, acc, grad_other, B * K * M, stream);
+}
+
+int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64_t G, void* out_pool, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(G >= 0 && G < (1LL << 31), "grouped_matmul_dw: bad group count");
+  if (G == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(host_groups && out_pool, "grouped_matmul_dw: NULL argument");
+  if (dtype != PYG_BF16 && dtype != PYG_F16)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: 16-bit floating types only (dtype %d)", dtype);
+  const int64_t K = host_groups[0].k, M = host_groups[0].m;
+  int64_t tiles = 0;
+  for (int64_t i = 0; i < G; ++i) {
+    const pyg_hip_group& g = host_groups[i];
+    if (g.k != K || g.m != M) return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: groups must share (K, M)");
+    PYG_HIP_REQUIRE(g.rows >= 0 && (g.rows == 0 || (g.input && g.other)), "grouped_matmul_dw: NULL tensor in group %lld",
+                    (long long)i);
+    if (((uintptr_t)g.input | (uintptr_t)g.other) % 16 != 0)
+      return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: operands must be 16-byte aligned");
+    tiles += (g.rows + kTile - 1) / kTile;
+  }
+  if (K * M == 0) return PYG_HIP_OK;
+  if (workspace == nullptr || workspace_bytes < dw_ws_bytes(G, K, M))
+    return fail(PYG_HIP_ERR_WORKSPACE, "grouped_matmul_dw: workspace of %zu bytes needed, got %zu", dw_ws_bytes(G, K, M),
+                workspace_bytes);
+  char* w = static_cast<char*>(workspace) + align_up(sizeof(int64_t) * (size_t)(G + 1), 256);
+  DwGroup* groups = reinterpret_cast<DwGroup*>(w);
+  w += dw_groups_bytes(G);
+  int32_t* tile_start = reinterpret_cast<int32_t*>(w);
+  w += dw_tiles_bytes(G);
+  float* acc = reinterpret_cast<float*>(w);
+  // host-side plan (G is small): descriptors + tile prefix in one pinned H2D copy
+  void* staged = nullptr;
+  int rc = pinned_stage().acquire(dw_groups_bytes(G) + dw_tiles_bytes(G), &staged);
+  if (rc != PYG_HIP_OK) return rc;
+  DwGroup* hg = static_cast<DwGroup*>(staged);
+  int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + dw_groups_bytes(G));
+  int64_t t = 0;
+  for (int64_t i = 0; i < G; ++i) {
+    hg[i].x = static_cast<const uint16_t*>(host_groups[i].input);
+    hg[i].dy = static_cast<const uint16_t*>(host_groups[i].other);
+    hg[i].rows = host_groups[i].rows;
+    ht[i] = (int32_t)t;
+    t += (host_groups[i].rows + kTile - 1) / kTile;
+  }
+  ht[G] = (int32_t)t;
+  PYG_HIP_CHECK(hipMemcpyAsync(groups, staged, dw_groups_bytes(G) + dw_tiles_bytes(G), hipMemcpyHostToDevice, stream));
+  rc = pinned_stage().commit(stream);
+  if (rc != PYG_HIP_OK) return rc;
+  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)G * (size_t)K * (size_t)M, stream));
+  rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream)
+                         : run_dw<f16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream);
+  if (rc != PYG_HIP_OK) return rc;
+  return round_out(dtype, acc, out_pool, G * K * M, stream);
 }
 
 }  // extern "C"

@@ -1,4 +1,5 @@
-"""segment_matmul forward + backward timing on C2 (bf16): python tools/bench_backward.py"""
+"""segment_matmul (C2) forward + backward timing, bf16 (C4: tools/c4_parts.py):
+    python tools/bench_backward.py [scale]"""
 import os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +18,7 @@ def fb(gx, gw):
     a = x if gx else x.detach(); b = w if gw else w.detach()
     y = ops.segment_matmul(a, ptr, b)
     torch.autograd.grad(y, [t for t in (a, b) if t.requires_grad], gy)
-r = dict(rows=N, fwd_ms=round(fwd, 3), fwd_bwd_dx_ms=round(T(lambda: fb(True, False)), 3),
+r = dict(workload='C2 segment_matmul', rows=N, fwd_ms=round(fwd, 3), fwd_bwd_dx_ms=round(T(lambda: fb(True, False)), 3),
          fwd_bwd_dw_ms=round(T(lambda: fb(False, True)), 3), fwd_bwd_both_ms=round(T(lambda: fb(True, True)), 3))
 print(json.dumps(r))
+# C4 (grouped_matmul) forward / dX / dW: tools/c4_parts.py
