@@ -181,6 +181,25 @@ def main():
                     traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
                     mfma_tflops=None if achieved is None else round(2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12, 1))
 
+    # context for `frac`: what a plain device copy of the same 1 read : 1 write byte mix reaches on this
+    # box (torch's copy kernel over x -> out-sized buffer), measured right after the timed region
+    if rank == 0 and world == 1:
+        try:
+            dst = torch.empty_like(x)
+            for _ in range(2):
+                dst.copy_(x)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(x)
+            e1.record()
+            torch.cuda.synchronize()
+            roofline['stream_copy_GBps'] = round(2.0 * x.numel() * esz / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9, 1)
+            del dst
+        except Exception:  # noqa: BLE001 - context only
+            roofline['stream_copy_GBps'] = None
+
     allgather = None
     if distributed:
         # RCCL all-gather(v) of the sharded outputs over xGMI, timed on its own (see module docstring)

@@ -158,7 +158,8 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
                         at::isFloatingType(src_c.scalar_type()) && l.K * (int64_t)src_c.element_size() >= 64;
   // min / max: atomic-free CSR walk for a sorted (COO) index or one large unsorted index vector
   const bool csr_minmax = minmax && l.isk == 0 && (coo || (l.B == 1 && l.ise == 1 && l.E >= (1 << 15)));
-  if (sort_sum || csr_minmax)
+  const bool csr_sum = op == OP_SUM && coo && l.isk == 0;  // sorted index: atomic-free CSR row sums
+  if (sort_sum || csr_minmax || csr_sum)
     ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.B, l.E, l.N)}, src_c.options().dtype(at::kByte));
   check_status(pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk,
                                out.data_ptr(), minmax ? arg.data_ptr<int64_t>() : nullptr,

@@ -78,6 +78,9 @@ size_t index_sort_ws_bytes_i64(int64_t n);
 int index_sort_i64(const int64_t* keys, int64_t n, int64_t max_value, int64_t* keys_out, int64_t* idx_out,
                    void* ws, size_t ws_bytes, hipStream_t stream);
 
+// csr.hip: row sums seeded from `out` (the atomic-free, source-order back end of segment_sum_coo).
+int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, void* out, int64_t leading,
+                    int64_t rows, int64_t E, int64_t K, hipStream_t stream);
 // csr.hip: min / max (+ first-match arg) over CSR rows, optionally reading source position perm[e]
 // instead of e -- the atomic-free back end of sorted and sort-based scatter_min/max (reduce.hip).
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,

@@ -228,6 +228,121 @@ __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ 
   }
 }
 
+// ---- small K: rows streamed through LDS ----------------------------------------------------------
+// With K * sizeof(T) below a cache line, one thread per (row, column) reads 2-4 byte elements that lie
+// a whole row apart from its neighbour's (0.35 TB/s at K = 1).  Here a workgroup owns 256 / K consecutive
+// rows: their source range is one contiguous span, which is copied to LDS in chunks with fully coalesced
+// loads; every thread then walks ITS row's part of the chunk in source order -- same operation order
+// as the CPU kernel (bit-exact), HBM traffic = the span once.
+constexpr int kStreamValues = 8192;    // LDS values per chunk (32 KB of fp32)
+constexpr int kSoftmaxValues = 16384;  // softmax: bigger chunks so that typical spans need ONE pass over HBM
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __restrict__ src,
+                                                                 const int64_t* __restrict__ indptr,
+                                                                 T* __restrict__ out, int64_t* __restrict__ arg,
+                                                                 int fresh, CsrShape s, int rpb) {
+  using acc_t = typename Math<T>::acc_t;
+  __shared__ T buf[kStreamValues];
+  const int K = (int)s.K;
+  const int rl = threadIdx.x / K, k = threadIdx.x % K;
+  const int64_t bps = (s.rows + rpb - 1) / rpb;
+  const int64_t slice = blockIdx.x / bps;
+  const int64_t r0 = (blockIdx.x % bps) * rpb;
+  const int64_t rN = r0 + rpb < s.rows ? r0 + rpb : s.rows;
+  const int64_t* ip = indptr + slice * s.indptr_stride;
+  const int64_t a0 = ip[r0], b0 = ip[rN];
+  const int64_t row = r0 + rl;
+  const bool valid = rl < rpb && row < rN;
+  const int64_t a = valid ? ip[row] : 0, b = valid ? ip[row + 1] : 0;
+  const int64_t n = slice * s.rows + row;
+  acc_t acc = acc_t(0);
+  int64_t best = s.E;
+  if (valid && OP != CSR_MEAN) acc = Math<T>::up(out[n * K + k]);
+  const int64_t CE = kStreamValues / K;
+  const T* sp = src + slice * s.E * K;
+  for (int64_t base = a0; base < b0; base += CE) {
+    const int64_t ce = b0 - base < CE ? b0 - base : CE;
+    const int64_t nv = ce * K;
+    for (int64_t i = threadIdx.x; i < nv; i += 256) buf[i] = sp[base * K + i];
+    __syncthreads();
+    const int64_t lo = a > base ? a : base, hi = b < base + ce ? b : base + ce;
+    for (int64_t e = lo; e < hi; ++e) {
+      const acc_t v = Math<T>::up(buf[(e - base) * K + k]);
+      if constexpr (OP == CSR_SUM || OP == CSR_MEAN) acc += v;
+      else if constexpr (OP == CSR_MIN) { if (v < acc) { acc = v; best = e; } }
+      else { if (v > acc) { acc = v; best = e; } }
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+  if constexpr (OP == CSR_MEAN) {
+    const int64_t len = b - a;
+    out[n * K + k] = Math<T>::down(acc / (acc_t)(len > 0 ? len : 1));
+  } else if constexpr (OP == CSR_SUM) {
+    out[n * K + k] = Math<T>::down(acc);
+  } else {
+    out[n * K + k] = (fresh && best == s.E) ? Math<T>::down(acc_t(0)) : Math<T>::down(acc);
+    arg[n * K + k] = best;
+  }
+}
+
+// softmax over groups with small inner size, streamed the same way: when a workgroup's span fits one
+// chunk the three passes (max, exp-sum, normalise) run from LDS -- one HBM read, one write; longer
+// spans stream three times.  Per-head operation order = the CPU kernel's.
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 const int64_t* __restrict__ ptr, T* __restrict__ y,
+                                                                 CsrShape s, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  T* buf = reinterpret_cast<T*>(sm_raw);
+  T* buf2 = buf + kSoftmaxValues;  // backward only
+  const int K = (int)s.K;
+  const int rl = threadIdx.x / K, k = threadIdx.x % K;
+  const int64_t bps = (s.rows + rpb - 1) / rpb;
+  const int64_t slice = blockIdx.x / bps;
+  const int64_t r0 = (blockIdx.x % bps) * rpb;
+  const int64_t rN = r0 + rpb < s.rows ? r0 + rpb : s.rows;
+  const int64_t a0 = ptr[r0], b0 = ptr[rN];
+  const int64_t row = r0 + rl;
+  const bool valid = rl < rpb && row < rN;
+  const int64_t a = valid ? ptr[row] : 0, b = valid ? ptr[row + 1] : 0;
+  const int64_t CE = kSoftmaxValues / K;
+  const T* xp = x + slice * s.E * K;
+  const T* dp = BACKWARD ? dy + slice * s.E * K : nullptr;
+  T* yp = y + slice * s.E * K;
+  const bool single = b0 - a0 <= CE;
+  const bool one = !BACKWARD && b - a == 1;  // single-element groups are exactly 1
+  T mx = type_lowest<T>(), sum = T(0);
+  // pass p: 0 = max (forward only), 1 = sum, 2 = write
+  for (int pass = BACKWARD ? 1 : 0; pass < 3; ++pass) {
+    for (int64_t base = a0; base < b0; base += CE) {
+      const int64_t ce = b0 - base < CE ? b0 - base : CE;
+      const int64_t nv = ce * K;
+      if (!single || pass == (BACKWARD ? 1 : 0)) {
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+          buf[i] = xp[base * K + i];
+          if (BACKWARD) buf2[i] = dp[base * K + i];
+        }
+        __syncthreads();
+      }
+      const int64_t lo = a > base ? a : base, hi = b < base + ce ? b : base + ce;
+      for (int64_t e = lo; e < hi; ++e) {
+        const int64_t j = (e - base) * K + k;
+        if constexpr (BACKWARD) {
+          if (pass == 1) sum += buf[j] * buf2[j];
+          else if (pass == 2) yp[e * K + k] = buf[j] * (buf2[j] - sum);
+        } else {
+          if (pass == 0) { const T v = buf[j]; mx = mx < v ? v : mx; }
+          else if (pass == 1) { if (!one) sum += exp(buf[j] - mx); }
+          else yp[e * K + k] = one ? T(1) : exp(buf[j] - mx) / sum;
+        }
+      }
+    }
+  }
+}
+
 // lanes per item: long rows + too few items to fill the chip
 int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
   if (units <= 0 || items <= 0) return 1;
@@ -256,9 +371,39 @@ int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, 
   return PYG_HIP_OK;
 }
 
+template <typename T, int OP>
+int launch_stream(const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
+                  hipStream_t stream) {
+  const int rpb = 256 / (int)s.K;
+  const int64_t blocks = s.leading * ((s.rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL((segment_csr_stream_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                     static_cast<const T*>(src), indptr, static_cast<T*>(out), arg, fresh, s, rpb);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+// rows of less than 64 bytes that are not very long on average take the LDS-streamed kernel
+template <typename T>
+bool use_stream(const CsrShape& s) {
+  if (s.K < 1 || s.K > 16 || s.K * (int64_t)sizeof(T) >= 64) return false;
+  const int64_t units = s.leading * s.rows;
+  return units > 0 && (s.leading * s.E) / units < 1024 && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
+}
+
 template <typename T>
 int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
                 hipStream_t stream) {
+  if (use_stream<T>(s)) {
+    switch (op) {
+      case CSR_SUM: return launch_stream<T, CSR_SUM>(src, indptr, out, arg, fresh, s, stream);
+      case CSR_MEAN:
+        if constexpr (std::is_integral<T>::value) return fail(PYG_HIP_ERR_INVALID, "segment_mean_csr: floating dtypes only");
+        else return launch_stream<T, CSR_MEAN>(src, indptr, out, arg, fresh, s, stream);
+      case CSR_MIN: return launch_stream<T, CSR_MIN>(src, indptr, out, arg, fresh, s, stream);
+      case CSR_MAX: return launch_stream<T, CSR_MAX>(src, indptr, out, arg, fresh, s, stream);
+      default: return fail(PYG_HIP_ERR_INVALID, "segment_csr: unknown reduction %d", op);
+    }
+  }
   constexpr int VMAX = 16 / (int)sizeof(T);
   const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
 #define PYG_CSR_OP(OPC)                                                                              \
@@ -301,6 +446,24 @@ int run_gather_csr(const void* src, const int64_t* indptr, void* out, const CsrS
 template <typename T, bool BACKWARD>
 int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int64_t outer, int64_t D, int64_t inner,
                 int64_t groups, hipStream_t stream) {
+  {
+    const CsrShape s{outer, groups, D, inner, 0};
+    if (use_stream<T>(s)) {
+      const int rpb = 256 / (int)inner;
+      const int64_t blocks = outer * ((groups + rpb - 1) / rpb);
+      const int lds = (int)(sizeof(T) * kSoftmaxValues * (BACKWARD ? 2 : 1));
+      static thread_local bool attr_set = false;  // per instantiation
+      if (!attr_set) {
+        PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&softmax_csr_stream_kernel<T, BACKWARD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((softmax_csr_stream_kernel<T, BACKWARD>), dim3((unsigned)blocks), dim3(256), lds, stream,
+                         static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), s, rpb);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+  }
   const int64_t items = groups * outer * inner;
   const int L = pick_lanes(items, D * outer * inner, items);
 #define PYG_SM_LAUNCH(LL)                                                                                         \
@@ -330,11 +493,21 @@ int run_minmax_perm(int is_min, const void* src, const int64_t* indptr, const in
 
 }  // namespace
 
+int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, void* out, int64_t leading,
+                    int64_t rows, int64_t E, int64_t K, hipStream_t stream) {
+  if (leading * rows * K == 0) return PYG_HIP_OK;
+  const CsrShape s{leading, rows, E, K, indptr_stride};
+  PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(CSR_SUM, src, indptr, out, nullptr, 0, s, stream)));
+}
+
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,
                        const int64_t* perm, void* out, int64_t* arg, int fresh, int64_t leading, int64_t rows,
                        int64_t E, int64_t K, hipStream_t stream) {
   if (leading * rows * K == 0) return PYG_HIP_OK;
   const CsrShape s{leading, rows, E, K, indptr_stride};
+  if (!perm) {  // plain rows: small K takes the LDS-streamed kernel
+    PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(is_min ? CSR_MIN : CSR_MAX, src, indptr, out, arg, fresh, s, stream)));
+  }
   PYG_DISPATCH_ALL(dtype, (run_minmax_perm<scalar_t>(is_min, src, indptr, perm, out, arg, fresh, s, stream)));
 }
 

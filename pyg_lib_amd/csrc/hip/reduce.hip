@@ -409,6 +409,16 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
   const int64_t outn = s.B * s.N * s.K;
   if (total == 0) return PYG_HIP_OK;
   const unsigned grid = grid_for(total);
+  if (op == OP_SUM && sorted && s.isk == 0 && ws && ws_bytes >= scatter_indptr_bytes(s.B, s.N)) {
+    // COO contract (index ascending along e): buckets are CSR rows -- summed in source order in opmath,
+    // seeded from `out`, no atomics (the run accumulation of segment_coo_kernel.cpp:104-166, bit for bit)
+    int64_t* indptr = reinterpret_cast<int64_t*>(ws);
+    const int64_t n = s.B * (s.N + 1);
+    hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, index, s.isb, s.ise,
+                       s.B, s.E, s.N, indptr);
+    PYG_HIP_CHECK(hipGetLastError());
+    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, out, s.B, s.N, s.E, s.K, stream);
+  }
   if (op == OP_SUM) {
     if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
                   std::is_same<T, f16_t>::value) {
