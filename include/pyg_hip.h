@@ -374,6 +374,20 @@ PYG_HIP_API int pyg_hip_softmax_csr_backward(int dtype, const void* out, const v
                                              const int64_t* ptr, void* in_grad, int64_t outer, int64_t D,
                                              int64_t inner, int64_t groups, void* stream);
 
+/*
+ * Device hash map key -> first position: the kernels behind torch.classes.pyg.CUDAHashMap
+ * (pyg_lib/csrc/classes/cuda/hash_map.cu:36-100, a cuco::static_map wrapper in the reference).
+ * The table is caller-owned: `slots` = pyg_hip_hash_map_slots(n, load_factor) entries (a power of two)
+ * of table_keys (uint64) and table_vals (int64).  Keys are int16 / int32 / int64; INT64_MIN is the empty
+ * sentinel, as in the reference.  `build` leaves the number of distinct keys in *distinct_dev (device
+ * memory); duplicate keys map to their first position.  `get` writes the position or -1 per query.
+ */
+PYG_HIP_API int64_t pyg_hip_hash_map_slots(int64_t n, double load_factor);
+PYG_HIP_API int pyg_hip_hash_map_build(int key_dtype, const void* keys, int64_t n, uint64_t* table_keys,
+                                       int64_t* table_vals, int64_t slots, int64_t* distinct_dev, void* stream);
+PYG_HIP_API int pyg_hip_hash_map_get(int key_dtype, const void* query, int64_t m, const uint64_t* table_keys,
+                                     const int64_t* table_vals, int64_t slots, int64_t* out, void* stream);
+
 /* When enabled (per calling thread), every dominant-kernel launch is bracketed by a pair of HIP
  * events recorded on the stream the kernel is launched on.  pyg_hip_profile_collect waits for the
  * recorded launches, writes up to `capacity` durations (milliseconds, launch order) and returns
