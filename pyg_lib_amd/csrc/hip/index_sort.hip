@@ -8,12 +8,16 @@
 // Same algorithm family (8-bit digits, least significant first, number of passes from the largest
 // key, radix_sort.h:170-176), re-shaped for the chip: every workgroup owns one contiguous slice of
 // the input for the whole pass, so there is one 256-bin histogram per workgroup (not per tile) and
-// the digit-major scan over them is tiny.  Inside a tile the 64-lane wavefronts rank their keys
-// with 8 ballots per digit (a wave64 "match-any"), LDS holds the per-wave digit counters, and
-// the running per-digit output cursors of the workgroup live in LDS across tiles.  Stability follows
-// from processing slices, tiles, rounds, waves and lanes in input order, which makes the result
-// bit-identical to torch.sort(stable=True) -- for negative keys too (sign bit flipped), which the
-// reference's radix path mis-sorts.
+// the digit-major scan over them is tiny.  A tile is 8192 keys: MI355X's 160 KB LDS holds the whole
+// tile's (key, index) pairs, so the tile is first sorted by digit INSIDE LDS and then written out --
+// a digit's keys leave as one run of ~32 consecutive elements (256-byte bursts) instead of one
+// scattered 8-byte write per key.  Ranking: every wave owns 1024 consecutive keys and ranks them in 16
+// rounds of 64 with 8 ballots per round (a wave64 "match-any") against its own running digit counters
+// in LDS -- no workgroup barrier inside the ranking; three barriers per tile in all.  The running
+// per-digit output cursors of the workgroup live in LDS across tiles.  Stability follows from ranking
+// in (slice, tile, wave, round, lane) = input order, which makes the result bit-identical to
+// torch.sort(stable=True) -- for negative keys too (sign bit flipped), which the reference's radix path
+// mis-sorts.
 // HBM-bound: per pass one key read for the histogram, one key+index read and one key+index write.
 #include "common.h"
 #include "scan.h"
@@ -23,10 +27,12 @@
 namespace pyg_hip {
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
-constexpr int kItems = 8;                       // keys per thread per tile
-constexpr int kTile = kThreads * kItems;        // 2048 keys per tile
+constexpr int kThreads = 256;                   // histogram / min-max kernels
+constexpr int kSThreads = 512;                  // scatter kernel: 8 waves
+constexpr int kWaves = kSThreads / 64;
+constexpr int kItems = 16;                      // keys per thread per tile
+constexpr int kTile = kSThreads * kItems;       // 8192 keys per tile: (key, index) pairs fill 128 KB of LDS
+constexpr int kWaveKeys = kTile / kWaves;       // 1024 consecutive keys per wave
 
 template <typename K>
 struct KeyTraits;
@@ -77,16 +83,30 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const K* __restrict__ 
 }
 
 // ---- pass kernels ---------------------------------------------------------------------------------------
-// hist[d * G + g]: number of keys with digit d in the slice of workgroup g
+// hist[d * G + g]: number of keys with digit d in the slice of workgroup g.  Equal digits inside a wave
+// are counted by ONE LDS atomic (match-any leader), so skewed digits (high bytes) do not serialise.
 template <typename K>
 __global__ __launch_bounds__(kThreads) void hist_kernel(const K* __restrict__ keys, int64_t n, int64_t slice,
                                                         int shift, int64_t* __restrict__ hist) {
   __shared__ unsigned int bins[256];
   bins[threadIdx.x] = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int64_t beg = blockIdx.x * slice;
   const int64_t end = min(beg + slice, n);
-  for (int64_t i = beg + threadIdx.x; i < end; i += kThreads) atomicAdd(&bins[digit_of(keys[i], shift)], 1u);
+  for (int64_t i0 = beg; i0 < end; i0 += kThreads) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool valid = i < end;
+    const unsigned d = valid ? digit_of(keys[i], shift) : 0u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    if (valid && (peers & lt_mask) == 0) atomicAdd(&bins[d], (unsigned)__popcll(peers));
+  }
   __syncthreads();
   hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = bins[threadIdx.x];
 }
@@ -102,60 +122,115 @@ struct HistStore {
 
 // Stable scatter of one pass.  FIRST: the index payload is the identity (arange), not read.
 template <typename K, bool FIRST>
-__global__ __launch_bounds__(kThreads) void scatter_kernel(const K* __restrict__ keys_in,
-                                                           const int64_t* __restrict__ idx_in, K* __restrict__ keys_out,
-                                                           int64_t* __restrict__ idx_out, int64_t n, int64_t slice,
-                                                           int shift, const int64_t* __restrict__ offsets) {
-  __shared__ int64_t cursor[256];                // next output position per digit (this workgroup)
-  __shared__ unsigned int wave_cnt[kWaves][256]; // keys per (wave, digit) in the current round
+__global__ __launch_bounds__(kSThreads) void scatter_kernel(const K* __restrict__ keys_in,
+                                                            const int64_t* __restrict__ idx_in, K* __restrict__ keys_out,
+                                                            int64_t* __restrict__ idx_out, int64_t n, int64_t slice,
+                                                            int shift, const int64_t* __restrict__ offsets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t* sidx = reinterpret_cast<int64_t*>(smem);                      // [kTile] tile sorted by digit: payload
+  K* skeys = reinterpret_cast<K*>(smem + sizeof(int64_t) * kTile);        // [kTile]                       keys
+  char* rest = smem + (sizeof(int64_t) + sizeof(K)) * kTile;
+  rest = reinterpret_cast<char*>(((uintptr_t)rest + 15) & ~(uintptr_t)15);
+  int64_t* cursor = reinterpret_cast<int64_t*>(rest);                     // [256] next output position per digit
+  unsigned* wcnt = reinterpret_cast<unsigned*>(rest + 256 * sizeof(int64_t));  // [kWaves][256]
+  unsigned* tile_pref = wcnt + kWaves * 256;                              // [256] first tile slot of a digit
+  unsigned* tile_cnt = tile_pref + 256;                                   // [256]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  cursor[tid] = offsets[(int64_t)tid * gridDim.x + blockIdx.x];
+  if (tid < 256) cursor[tid] = offsets[(int64_t)tid * gridDim.x + blockIdx.x];
   const int64_t beg = blockIdx.x * slice;
   const int64_t end = min(beg + slice, n);
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  unsigned* my_cnt = wcnt + wave * 256;
 
   for (int64_t tile = beg; tile < end; tile += kTile) {
-    // rounds keep input order: element = tile + r * 256 + wave * 64 + lane
-#pragma unroll 1
+    const int64_t tile_n = min((int64_t)kTile, end - tile);
+    // ---- 1. rank: wave w owns keys [w * 1024, (w + 1) * 1024) of the tile, 16 rounds of 64 -----------
+    for (int j = lane; j < 256; j += 64) my_cnt[j] = 0;
+    K key[kItems];
+    int64_t pay[kItems];
+    unsigned short rank[kItems];
+#pragma unroll
     for (int r = 0; r < kItems; ++r) {
-      const int64_t i = tile + (int64_t)r * kThreads + tid;
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
+      key[r] = i < end ? keys_in[i] : K(0);
+      if (!FIRST) pay[r] = i < end ? idx_in[i] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
       const bool valid = i < end;
-      for (int w = 0; w < kWaves; ++w) wave_cnt[w][tid] = 0;
-      __syncthreads();
-      K key = 0;
-      unsigned d = 0;
-      if (valid) {
-        key = keys_in[i];
-        d = digit_of(key, shift);
-      }
-      // wave64 match-any on the 8-bit digit: 8 ballots
+      const unsigned d = valid ? digit_of(key[r], shift) : 0u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const unsigned long long m = __ballot((d >> b) & 1u);
         peers &= ((d >> b) & 1u) ? m : ~m;
       }
-      const unsigned rank_in_wave = (unsigned)__popcll(peers & lt_mask);
-      if (valid && rank_in_wave == 0) wave_cnt[wave][d] = (unsigned)__popcll(peers);
-      __syncthreads();
-      if (valid) {
-        unsigned before = 0;
-        for (int w = 0; w < wave; ++w) before += wave_cnt[w][d];
-        const int64_t pos = cursor[d] + before + rank_in_wave;
-        keys_out[pos] = key;
-        idx_out[pos] = FIRST ? i : idx_in[i];
-      }
-      __syncthreads();
-      {
-        unsigned tot = 0;
-        for (int w = 0; w < kWaves; ++w) tot += wave_cnt[w][tid];
-        cursor[tid] += tot;
-      }
-      __syncthreads();
+      const unsigned before = my_cnt[d];  // keys of this digit in earlier rounds of this wave
+      const unsigned in_round = (unsigned)__popcll(peers & lt_mask);
+      rank[r] = (unsigned short)(before + in_round);
+      __builtin_amdgcn_wave_barrier();    // every lane has read the counter before the leader bumps it
+      if (valid && in_round == 0) my_cnt[d] = before + (unsigned)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
+    // ---- 2. digit totals of the tile, wave offsets, exclusive scan over the 256 digits ---------------
+    if (tid < 256) {
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const unsigned c = wcnt[w * 256 + tid];
+        wcnt[w * 256 + tid] = run;
+        run += c;
+      }
+      tile_cnt[tid] = run;
+      // scan of 256 totals by the first 4 waves: wave shuffle scan + 4 wave totals
+      unsigned incl = run;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, dlt);
+        if (lane >= dlt) incl += up;
+      }
+      tile_pref[tid] = incl - run;  // exclusive inside the wave; wave bases added below
+      if (lane == 63) sidx[wave] = (int64_t)incl;  // borrow 4 slots of the (not yet written) payload array
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += (unsigned)sidx[w];
+      tile_pref[tid] += base;
+    }
+    __syncthreads();
+    // ---- 3. place every (key, payload) at its digit-sorted slot of the tile ---------------------------
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
+      if (i < end) {
+        const unsigned d = digit_of(key[r], shift);
+        const unsigned pos = tile_pref[d] + my_cnt[d] + rank[r];
+        skeys[pos] = key[r];
+        sidx[pos] = FIRST ? i : pay[r];
+      }
+    }
+    __syncthreads();
+    // ---- 4. write out: slot j of digit d goes to cursor[d] + (j - tile_pref[d]); runs are contiguous ---
+    for (int j = tid; j < tile_n; j += kSThreads) {
+      const K k = skeys[j];
+      const unsigned d = digit_of(k, shift);
+      const int64_t dest = cursor[d] + (int64_t)(j - tile_pref[d]);
+      keys_out[dest] = k;
+      idx_out[dest] = sidx[j];
+    }
+    __syncthreads();
+    if (tid < 256) cursor[tid] += tile_cnt[tid];
+    // (the next tile's first barrier orders this update before its use in step 4)
   }
+}
+
+constexpr size_t scatter_lds_bytes(size_t key_size) {
+  return (sizeof(int64_t) + key_size) * kTile + 16 + 256 * sizeof(int64_t) + (kWaves * 256 + 512) * sizeof(unsigned);
 }
 
 template <typename K>
@@ -175,7 +250,7 @@ struct Plan {
 
 Plan make_plan(int64_t n) {
   const int64_t tiles = (n + kTile - 1) / kTile;
-  int64_t groups = std::min<int64_t>(tiles, (int64_t)device_info().num_cus * 8);
+  int64_t groups = std::min<int64_t>(tiles, (int64_t)device_info().num_cus * 4);
   if (groups < 1) groups = 1;
   const int64_t tiles_per = (tiles + groups - 1) / groups;
   Plan p;
@@ -269,11 +344,20 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
     int rc = device_scan<int64_t, SumOp>(HistLoad{hist}, HistStore{offs}, p.groups * 256, scan_tmp,
                                          scan_tmp + ntiles, stream);
     if (rc != PYG_HIP_OK) return rc;
+    constexpr int lds = (int)scatter_lds_bytes(sizeof(K));
+    static thread_local bool attr_set = false;  // per key type
+    if (!attr_set) {
+      PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_kernel<K, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_kernel<K, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
     if (ps == 0)
-      hipLaunchKernelGGL((scatter_kernel<K, true>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, src_k,
+      hipLaunchKernelGGL((scatter_kernel<K, true>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k,
                          (const int64_t*)nullptr, kdst[cur], idst[cur], n, p.slice, shift, offs);
     else
-      hipLaunchKernelGGL((scatter_kernel<K, false>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, src_k,
+      hipLaunchKernelGGL((scatter_kernel<K, false>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k,
                          (const int64_t*)iin, kdst[cur], idst[cur], n, p.slice, shift, offs);
     PYG_HIP_CHECK(hipGetLastError());
     kin = kdst[cur];
