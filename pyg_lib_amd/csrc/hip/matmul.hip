@@ -818,17 +818,25 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
                   hipStream_t stream, bool* handled) {
   static thread_local char name[64];
   *handled = true;
-  const int MC = (M % 128 == 0) ? 128 : 64;
+  const int MC = (M % 128 == 0 && K <= 256) ? 128 : (M % 64 == 0 ? 64 : 32);
   snprintf(name, sizeof(name), "mfma_%s_k%d_mc%d", tname, K, MC);
   g_last_variant = name;
 #define PYG_CASE(KK, MM)            \
   if (K == KK && MC == MM) return launch_mfma<T, KK, MM>(w, B, M, tiles_upper, stream);
+  PYG_CASE(32, 32)
+  PYG_CASE(32, 64)
+  PYG_CASE(32, 128)
+  PYG_CASE(64, 32)
   PYG_CASE(64, 64)
   PYG_CASE(64, 128)
+  PYG_CASE(128, 32)
   PYG_CASE(128, 64)
   PYG_CASE(128, 128)
+  PYG_CASE(256, 32)
   PYG_CASE(256, 64)
   PYG_CASE(256, 128)
+  PYG_CASE(512, 32)
+  PYG_CASE(512, 64)
 #undef PYG_CASE
   *handled = false;
   return PYG_HIP_OK;
@@ -836,8 +844,8 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
 
 bool mfma_shape_ok(int dtype, int64_t K, int64_t M) {
   if (!(dtype == PYG_F32 || dtype == PYG_BF16 || dtype == PYG_F16)) return false;
-  if (!(K == 64 || K == 128 || K == 256)) return false;
-  if (M < 64 || M % 64 != 0 || M > (1 << 20)) return false;
+  if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 512)) return false;
+  if (M < 32 || M % 32 != 0 || M > (1 << 20)) return false;
   if (dtype == PYG_F32 && K == 256 && (M % 128 == 0)) {
     // fp32 K=256 x 128 columns needs 133 KB of LDS; fine on gfx950 (160 KB), 1 block/CU.
   }

@@ -84,8 +84,8 @@ def test_ragged_fp32_mfma_1e5():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize('K', [64, 128, 256])
-@pytest.mark.parametrize('M', [64, 128, 192, 256])
+@pytest.mark.parametrize('K', [32, 64, 128, 256, 512])
+@pytest.mark.parametrize('M', [32, 64, 96, 128, 192, 256])
 def test_mfma_shape_sweep_vs_oracle(dtype, K, M):
     torch.manual_seed(K * 1000 + M)
     sizes = [130, 0, 1, 257, 64]
