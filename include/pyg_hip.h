@@ -120,7 +120,7 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]
  * (input [N, K], grad_out [N, M], grad_other [B, K, M]; fp32 accumulation, one rounding).  Replaces the
  * per-relation loop of SegmentMatmul::backward (ops/autograd/matmul_kernel.cpp:92-107: B x
- * at::matmul(input_i^T, grad_out_i) + at::stack) with one persistent launch.  bf16 / fp16 with
+ * at::matmul(input_i^T, grad_out_i) + at::stack) with one persistent launch.  fp32 / bf16 / fp16 with
  * K in {64, 128, 256} and M % 64 == 0; other cases return PYG_HIP_ERR_UNSUPPORTED (the caller keeps the
  * reference formula).  `workspace`: pyg_hip_segment_matmul_dw_workspace_size(B, K, M) bytes of device
  * scratch (tile plan + fp32 accumulators).  Never synchronises.

@@ -131,7 +131,7 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
   // every X_i and G skinny GEMMs.
   {
     const auto st = input[0].scalar_type();
-    bool dw = (st == at::kBFloat16 || st == at::kHalf);
+    bool dw = (st == at::kBFloat16 || st == at::kHalf || st == at::kFloat);
     const int64_t K = input[0].size(0), M = other[0].size(1);
     dw = dw && (K == 64 || K == 128 || K == 256) && M % 64 == 0;
     for (size_t i = 0; dw && i < G; ++i)
@@ -213,7 +213,7 @@ static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& p
 // dW through the C-ABI; returns an undefined tensor when the device kernel does not cover the case.
 static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, const Tensor& other) {
   const auto st = input.scalar_type();
-  if (st != at::kBFloat16 && st != at::kHalf) return Tensor();
+  if (st != at::kBFloat16 && st != at::kHalf && st != at::kFloat) return Tensor();
   const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
   if (!(K == 64 || K == 128 || K == 256) || M % 64 != 0 || B == 0) return Tensor();
   DeviceGuard guard(input.device());

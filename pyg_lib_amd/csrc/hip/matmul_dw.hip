@@ -239,6 +239,87 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
   flush();
 }
 
+// fp32: v_mfma_f32_32x32x2_f32 takes ONE value per lane (lane (i, kk) = A[i][kk]), so the "column of
+// rows" operand is simply a row-major load -- lane (i, kk) reads X[row 2s + kk][col i]: two coalesced
+// 128-byte segments per wave instruction, no LDS and no transposition.  Exact fp32 FMA chains (gfx950 has
+// no TF32); bound by the fp32 MFMA rate (157 TFLOP/s: C2 >= 4.4 ms), not by HBM.
+template <int K, int MC>
+__global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __restrict__ groups,
+                                                             const int32_t* __restrict__ tile_start, int B, int M,
+                                                             float* __restrict__ acc_out) {
+  constexpr int IB = K / 32, JB = MC / 32;
+  static_assert(IB * JB <= 16, "accumulators must fit the register file");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kk = lane >> 5;
+  const int col0 = blockIdx.y * MC;
+  const int total = tile_start[B];
+  const int G = gridDim.x;
+  const int t_beg = (int)((int64_t)blockIdx.x * total / G);
+  const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
+  if (t_beg >= t_end) return;
+  int g = 0;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_beg) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  f32x16 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  int acc_g = -1;
+  auto flush = [&]() {
+    if (acc_g < 0) return;
+    float* base = acc_out + ((int64_t)acc_g * K) * M + col0;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = j * 32 + (lane & 31);
+          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][r] = 0.0f;
+        }
+  };
+  DwGroup gd = groups[g];
+  for (int t = t_beg; t < t_end; ++t) {
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      gd = groups[g];
+    }
+    if (g != acc_g) {
+      flush();
+      acc_g = g;
+    }
+    const float* xp = reinterpret_cast<const float*>(gd.x);
+    const float* yp = reinterpret_cast<const float*>(gd.dy);
+    const int64_t row0 = (int64_t)(t - tile_start[g]) * kTile + wave * 32;
+#pragma unroll 4
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int64_t row = row0 + 2 * s2 + kk;
+      const bool ok = row < gd.rows;
+      float a[IB], b[JB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) a[i] = ok ? xp[row * K + i * 32 + li] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < JB; ++j) b[j] = ok ? yp[row * M + col0 + j * 32 + li] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  flush();
+}
+
 // dW[b, k, m] = round(acc[b, k, m])
 template <typename Tag>
 __global__ void dw_round_kernel(const float* __restrict__ acc, uint16_t* __restrict__ out, int64_t n) {
@@ -285,7 +366,33 @@ int run_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t 
               (long long)K, (long long)M);
 }
 
+template <int K, int MC>
+int launch_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* acc,
+                  hipStream_t stream) {
+  const int64_t cus = device_info().num_cus;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus));
+  hipLaunchKernelGGL((seg_dw_f32_kernel<K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), 0, stream, groups, tile_start,
+                     (int)B, (int)M, acc);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+int run_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
+               float* acc, hipStream_t stream) {
+  if (K == 128 && M % 128 == 0) return launch_dw_f32<128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 128 && M % 64 == 0) return launch_dw_f32<128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 128 == 0) return launch_dw_f32<64, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 64 && M % 64 == 0) return launch_dw_f32<64, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  if (K == 256 && M % 64 == 0) return launch_dw_f32<256, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+  return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: K=%lld, M=%lld has no MFMA kernel (K in {64,128,256}, M %% 64 == 0)",
+              (long long)K, (long long)M);
+}
+
 int round_out(int dtype, const float* acc, void* out, int64_t n, hipStream_t stream) {
+  if (dtype == PYG_F32) {  // the accumulators ARE the result
+    PYG_HIP_CHECK(hipMemcpyAsync(out, acc, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    return PYG_HIP_OK;
+  }
   if (dtype == PYG_BF16)
     hipLaunchKernelGGL(dw_round_kernel<bf16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
                        static_cast<uint16_t*>(out), n);
@@ -314,8 +421,8 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
   PYG_HIP_REQUIRE(N >= 0 && K >= 0 && M >= 0 && B >= 0, "segment_matmul_dw: negative size");
   if (B * K * M == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(ptr && grad_other && (N == 0 || (input && grad_out)), "segment_matmul_dw: NULL tensor");
-  if (dtype != PYG_BF16 && dtype != PYG_F16)
-    return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: 16-bit floating types only (dtype %d)", dtype);
+  if (dtype != PYG_BF16 && dtype != PYG_F16 && dtype != PYG_F32)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: float32 / bfloat16 / float16 only (dtype %d)", dtype);
   PYG_HIP_REQUIRE(((uintptr_t)input % 16 == 0) && ((uintptr_t)grad_out % 16 == 0), "segment_matmul_dw: tensors must be 16-byte aligned");
   if (workspace == nullptr || workspace_bytes < dw_ws_bytes(B, K, M))
     return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul_dw: workspace of %zu bytes needed, got %zu", dw_ws_bytes(B, K, M),
@@ -340,12 +447,15 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
     dptr = ptr_dev;
   }
   PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)B * (size_t)K * (size_t)M, stream));
+  // descriptors address the tensors in 2-byte units: an fp32 row is 2 K of them
+  const int64_t u = dtype == PYG_F32 ? 2 : 1;
   hipLaunchKernelGGL(dw_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, static_cast<const uint16_t*>(input),
-                     static_cast<const uint16_t*>(grad_out), K, M, groups, tile_start);
+                     static_cast<const uint16_t*>(grad_out), K * u, M * u, groups, tile_start);
   PYG_HIP_CHECK(hipGetLastError());
   const int64_t tiles_upper = (N + kTile - 1) / kTile + B;
-  int rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream)
-                             : run_dw<f16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream);
+  int rc = dtype == PYG_F32    ? run_dw_f32(groups, tile_start, B, K, M, tiles_upper, acc, stream)
+           : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream)
+                               : run_dw<f16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream);
   if (rc != PYG_HIP_OK) return rc;
   return round_out(dtype, acc, grad_other, B * K * M, stream);
 }
@@ -356,8 +466,8 @@ int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64
   PYG_HIP_REQUIRE(G >= 0 && G < (1LL << 31), "grouped_matmul_dw: bad group count");
   if (G == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(host_groups && out_pool, "grouped_matmul_dw: NULL argument");
-  if (dtype != PYG_BF16 && dtype != PYG_F16)
-    return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: 16-bit floating types only (dtype %d)", dtype);
+  if (dtype != PYG_BF16 && dtype != PYG_F16 && dtype != PYG_F32)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: float32 / bfloat16 / float16 only (dtype %d)", dtype);
   const int64_t K = host_groups[0].k, M = host_groups[0].m;
   int64_t tiles = 0;
   for (int64_t i = 0; i < G; ++i) {
@@ -398,8 +508,9 @@ int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;
   PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)G * (size_t)K * (size_t)M, stream));
-  rc = dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream)
-                         : run_dw<f16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream);
+  rc = dtype == PYG_F32    ? run_dw_f32(groups, tile_start, G, K, M, tiles + 1, acc, stream)
+       : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream)
+                           : run_dw<f16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream);
   if (rc != PYG_HIP_OK) return rc;
   return round_out(dtype, acc, out_pool, G * K * M, stream);
 }

@@ -263,7 +263,7 @@ def test_full_size_c2_properties():
 
 
 # ---- weight gradient kernel (csrc/hip/matmul_dw.hip) ---------------------------------
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize('K,M', [(128, 128), (64, 64), (128, 64), (64, 128), (256, 256), (128, 256)])
 def test_segment_matmul_weight_gradient_kernel(dtype, K, M):
     # ragged relations incl. empty ones, sizes that are not tile multiples, one relation > many tiles
@@ -281,7 +281,7 @@ def test_segment_matmul_weight_gradient_kernel(dtype, K, M):
     # float64 reference from the stored values: dW[b] = X_b^T dY_b, dX = dY W^T
     want_w = torch.stack([x[ptr[b]:ptr[b + 1]].double().t() @ gy[ptr[b]:ptr[b + 1]].double() for b in range(B)])
     want_x = torch.cat([gy[ptr[b]:ptr[b + 1]].double() @ w[b].double().t() for b in range(B)])
-    eps = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    eps = {torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11, torch.float32: 1e-5}[dtype]
     scale_w = want_w.abs().max().item()
     assert (gw.double().cpu() - want_w).abs().max().item() <= eps * scale_w * 1.01 + 1e-6
     assert (gx.double().cpu() - want_x).abs().max().item() <= eps * want_x.abs().max().item() * 1.01 + 1e-6
@@ -312,7 +312,7 @@ def test_weight_gradient_is_transpose_detecting_and_linear():
     assert torch.equal(gw.float().cpu(), want)
 
 
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 def test_grouped_matmul_backward_uses_weight_gradient_kernel(dtype):
     # C4-shaped (F=256) and F=128 groups of ragged sizes; others_grad goes through grouped_matmul(X_i^T, dY_i)
     for F in (128, 256):
@@ -325,7 +325,7 @@ def test_grouped_matmul_backward_uses_weight_gradient_kernel(dtype):
         wd = [w.cuda().requires_grad_(True) for w in ws]
         outs = ops.grouped_matmul(xd, wd)
         grads = torch.autograd.grad(outs, xd + wd, [t.cuda() for t in gs])
-        eps = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+        eps = {torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11, torch.float32: 1e-5}[dtype]
         for i, n in enumerate(sizes):
             want_x = gs[i].double() @ ws[i].double().t()
             want_w = xs[i].double().t() @ gs[i].double()
