@@ -304,16 +304,32 @@ struct CountLoad {
   }
 };
 
+// Device-resident engine position and per-node-type list sizes: the relations of a hop are queued
+// back to back (each one starts where the previous one ended) and the host reads the results of the
+// whole hop with ONE synchronisation.
+struct ChainState {
+  int64_t word;   // engine position: linear word index
+  int32_t units;  //                  16-bit units left in that word
+  int32_t abort;  // sticky: a relation of this hop lacked random words -> everything after it is a no-op
+};
+struct TypeState {
+  int64_t size;      // length of the node list of this type
+  int64_t distinct;  // Mapper::curr
+};
+
 struct CountStore {
   int64_t* edge_off;
   int64_t* rng_word;
   int32_t* rng_units;
-  int64_t word0;   // hop start state
+  int64_t word0;   // hop start state (chain == nullptr)
   int32_t units0;
+  const ChainState* chain;  // device-resident start state, or nullptr
   __device__ void operator()(int64_t i, const CountAgg& prefix, const CountAgg&) const {
+    const int64_t w0 = chain ? chain->word : word0;
+    const int u0 = chain ? chain->units : units0;
     edge_off[i] = prefix.edges;
-    rng_word[i] = word0 + tab_dw(prefix.tab, units0);
-    rng_units[i] = tab_nb(prefix.tab, units0);
+    rng_word[i] = w0 + tab_dw(prefix.tab, u0);
+    rng_units[i] = tab_nb(prefix.tab, u0);
   }
 };
 
@@ -330,7 +346,8 @@ struct HopArgs {
   // run-ahead mode (info != nullptr): the kernel is launched before the host knows the count-scan
   // total; it checks on its own that every random word it may read has been generated
   HopInfo* info = nullptr;
-  int64_t word0 = 0;          // engine position at the start of the hop
+  ChainState* chain = nullptr;  // device-resident engine position (start of this relation), sticky abort
+  int64_t word0 = 0;          // engine position at the start of the hop (chain == nullptr)
   int units0 = 4;
   int64_t avail_blocks = 0;   // 128-word blocks readable by this launch
   const int64_t* nodes;       // src node list (positions are the emitted `row`)
@@ -399,9 +416,16 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
 // that do not exist yet; the host then generates them and repeats the hop.
 __device__ __forceinline__ bool hop_overflow(const HopArgs& a) {
   if (!a.info) return false;
-  const int64_t end_word = a.word0 + tab_dw(a.info->tot.tab, a.units0);
-  const bool over = a.info->tot.edges > 0 && end_word / 128 + 1 > a.avail_blocks;
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.info->overflow = over ? 1 : 0;
+  const int64_t w0 = a.chain ? a.chain->word : a.word0;
+  const int u0 = a.chain ? a.chain->units : a.units0;
+  const int64_t end_word = w0 + tab_dw(a.info->tot.tab, u0);
+  // an earlier relation of the hop already gave up: its engine position is not final, so neither is ours
+  const bool aborted = a.chain && a.chain->abort;
+  const bool over = aborted || (a.info->tot.edges > 0 && end_word / 128 + 1 > a.avail_blocks);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.info->overflow = over ? (aborted ? 2 : 1) : 0;
+    if (over && a.chain) a.chain->abort = 1;
+  }
   return over;
 }
 
@@ -562,27 +586,55 @@ struct AssignStore {
   const int64_t* e_batch;
   int64_t* nodes;      // dst node list
   int64_t* batch;      // dst batch list (disjoint) or nullptr
-  int64_t size_base;   // dst list size before this hop-relation
+  int64_t size_base;   // dst list size before this hop-relation  (ts == nullptr)
   int64_t id_base;     // dst mapper `curr` before this hop-relation
   int write_nodes;
+  const TypeState* ts; // device-resident bases, or nullptr
   __device__ void operator()(int64_t p, const int64_t& rank, const int64_t& flag) const {
     if (!flag) return;
-    vals[slots[p]] = (u64)(id_base + rank);
+    const int64_t sb = ts ? ts->size : size_base;
+    const int64_t ib = ts ? ts->distinct : id_base;
+    vals[slots[p]] = (u64)(ib + rank);
     if (write_nodes) {
-      nodes[size_base + rank] = e_node[p];
-      if (batch) batch[size_base + rank] = e_batch[p];
+      nodes[sb + rank] = e_node[p];
+      if (batch) batch[sb + rank] = e_batch[p];
     }
   }
 };
 
+// Local ids of every emitted edge.  Thread 0 also closes the relation: publishes its totals to pinned host
+// memory and advances the device-resident engine position and node-list sizes for the next relation.
 __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __restrict__ vals,
                                 int64_t n, int64_t* __restrict__ out_col, const HopInfo* __restrict__ info,
-                                HopInfo* __restrict__ publish) {
+                                HopInfo* __restrict__ publish, ChainState* __restrict__ chain,
+                                TypeState* __restrict__ ts) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (p == 0 && publish) *publish = *info;  // pinned host memory: read by the host after the hop's sync
+  if (p == 0 && publish) {
+    *publish = *info;  // pinned host memory: read by the host after the hop's sync
+    if (chain && !info->overflow) {
+      if (info->tot.edges > 0) {
+        const int u0 = chain->units;
+        chain->word += tab_dw(info->tot.tab, u0);
+        chain->units = tab_nb(info->tot.tab, u0);
+      }
+      ts->size += info->uniq;
+      ts->distinct += info->uniq;
+    }
+  }
   if (info && (p >= info->tot.edges || info->overflow)) return;
   if (p < n) out_col[p] = (int64_t)vals[slots[p]];
 }
+
+__global__ void set_chain_kernel(ChainState* c, int64_t word, int units) {
+  c->word = word;
+  c->units = units;
+  c->abort = 0;
+}
+__global__ void set_type_kernel(TypeState* t, int64_t size, int64_t distinct) {
+  t->size = size;
+  t->distinct = distinct;
+}
+__global__ void clear_abort_kernel(ChainState* c) { c->abort = 0; }
 
 __global__ void interleave_kernel(const int64_t* __restrict__ batch,
                                   const int64_t* __restrict__ node, int64_t n,
@@ -816,14 +868,16 @@ struct DevVec {
   int64_t* p = nullptr;
   int64_t size = 0;
   int64_t cap = 0;
+  int64_t live = 0;  // elements that may hold data of relations not yet committed by the host (>= size)
   // `hint`: expected final size (later hops included), so that one allocation usually lasts the call
   int reserve(Ctx& c, int64_t n, int64_t hint = 0) {
     if (n <= cap) return PYG_HIP_OK;
     const int64_t ncap = std::max<int64_t>(std::max<int64_t>(n, hint), std::max<int64_t>(2 * cap, 1024));
     int64_t* np;
     PYG_ALLOC(np, int64_t*, c, sizeof(int64_t) * (size_t)ncap);
-    if (size > 0)
-      PYG_HIP_CHECK(hipMemcpyAsync(np, p, sizeof(int64_t) * (size_t)size, hipMemcpyDeviceToDevice,
+    const int64_t keep = std::min<int64_t>(std::max(size, live), cap);
+    if (keep > 0)
+      PYG_HIP_CHECK(hipMemcpyAsync(np, p, sizeof(int64_t) * (size_t)keep, hipMemcpyDeviceToDevice,
                                    c.stream));
     c.release(p);
     p = np;
@@ -1138,7 +1192,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
   void* pinned = nullptr;
   {
-    int rc = get_pinned(&pinned, 4096);
+    int rc = get_pinned(&pinned, 1024 + sizeof(HopInfo) * (size_t)std::max(num_relations, 96));  // scratch + one HopInfo per relation
     if (rc != PYG_HIP_OK) return rc;
   }
 
@@ -1249,199 +1303,299 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   pt.lap(0);
 
   // ---- hops ----
+  // Engine position and node-list sizes live on the device (ChainState / TypeState): the relations of a
+  // hop are queued back to back -- count scan, sample, dedup scan, finalize, each starting where the
+  // previous one ended -- and the host synchronises ONCE per hop to read every relation's totals.
+  // A relation is "committed" when the host has folded its totals into its own bookkeeping.
+  volatile HopInfo* info_host = reinterpret_cast<volatile HopInfo*>(static_cast<char*>(pinned) + 1024);
   HopInfo* info_dev;
-  PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo));
-  for (int ell = 0; ell < L; ++ell) {
-    for (int e = 0; e < num_relations; ++e) {
-      const pyg_hip_relation& r = rels[e];
-      const int src = !csc ? r.src_type : r.dst_type;
+  ChainState* chain;
+  TypeState* tstate;
+  PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo) * (size_t)std::max(num_relations, 1));
+  PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
+  PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
+  hipLaunchKernelGGL(set_chain_kernel, dim3(1), dim3(1), 0, stream, chain, rng.word, rng.units);
+  for (int t = 0; t < num_node_types; ++t)
+    hipLaunchKernelGGL(set_type_kernel, dim3(1), dim3(1), 0, stream, tstate + t, ns[(size_t)t].nodes.size,
+                       ns[(size_t)t].distinct);
+  PYG_HIP_CHECK(hipGetLastError());
+
+  struct Pending {
+    int e = 0;
+    int64_t F = 0, Eb = 0, count = 0;
+    RangeCtx range;
+    CountAgg* tile_buf = nullptr;
+    int64_t* edge_off = nullptr;
+    int64_t* rng_word = nullptr;
+    int32_t* rng_units = nullptr;
+    int64_t* e_node = nullptr;
+    int64_t* e_batch = nullptr;
+    u64* e_slot = nullptr;
+    int64_t* ftile = nullptr;
+  };
+  std::vector<Pending> pend;
+  auto free_pending = [&](Pending& q) {
+    c.release(q.tile_buf);
+    c.release(q.edge_off);
+    c.release(q.rng_word);
+    c.release(q.rng_units);
+    c.release(q.e_node);
+    if (q.e_batch) c.release(q.e_batch);
+    c.release(q.e_slot);
+    c.release(q.ftile);
+  };
+
+  // queues sample + dedup scan + finalize of one relation behind its count scan
+  auto enqueue_tail = [&](Pending& q, int64_t avail_blocks) -> int {
+    const pyg_hip_relation& r = rels[q.e];
+    const int src = !csc ? r.src_type : r.dst_type;
+    const int dst = !csc ? r.dst_type : r.src_type;
+    NodeSet& sn = ns[(size_t)src];
+    NodeSet& dn = ns[(size_t)dst];
+    RelState& st = rs[(size_t)q.e];
+    HopArgs a;
+    a.info = info_dev + q.e;
+    a.chain = chain;
+    a.avail_blocks = avail_blocks;
+    a.nodes = sn.nodes.p;
+    a.batch = disjoint ? sn.batch.p : nullptr;
+    a.begin = sn.slice_b;
+    a.frontier = q.F;
+    q.range.batch = a.batch;  // a reserve may have moved the list (src type == dst type)
+    a.range = q.range;
+    a.col = r.col;
+    a.count = q.count;
+    a.replace = replace;
+    a.num_batches = num_batches;
+    a.edge_off = q.edge_off;
+    a.rng_word = q.rng_word;
+    a.rng_units = q.rng_units;
+    a.words = rng.dev;
+    a.e_row = st.row.p + st.row.size;
+    a.e_node = q.e_node;
+    a.e_batch = q.e_batch;
+    a.e_eid = st.eid.p + st.eid.size;
+    a.e_slot = q.e_slot;
+    a.table = dn.table;
+    launch_sample(a, q.F, stream);
+    PYG_HIP_CHECK(hipGetLastError());
+    // first occurrences -> ranks -> new local ids / appended nodes
+    FlagLoad fl{q.e_slot, dn.table.vals, info_dev + q.e};
+    AssignStore as{q.e_slot, dn.table.vals, q.e_node, q.e_batch, dn.nodes.p,
+                   disjoint ? dn.batch.p : (int64_t*)nullptr, 0, 0, 1, tstate + dst};
+    int rc = device_scan<int64_t, SumOp>(fl, as, q.Eb, q.ftile, &info_dev[q.e].uniq, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    // local ids of every emitted edge; publishes the totals and advances the device state
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((q.Eb + 255) / 256)), dim3(256), 0, stream, q.e_slot,
+                       dn.table.vals, q.Eb, st.col.p + st.col.size, info_dev + q.e,
+                       const_cast<HopInfo*>(info_host) + q.e, chain, tstate + dst);
+    PYG_HIP_CHECK(hipGetLastError());
+    return PYG_HIP_OK;
+  };
+
+  // Synchronises and commits the queued relations in order.  Returns the index (into `pend`) of the
+  // first relation that must be re-queued from scratch, or -1: a relation that ran out of random words
+  // (draws wider than 16 bits, or beyond what the speculation may run ahead) is repeated right here with
+  // exactly the words it needs; the relations queued behind it did nothing (sticky abort) and start over.
+  auto commit = [&](int* restart) -> int {
+    *restart = -1;
+    if (pend.empty()) return PYG_HIP_OK;
+    pt.lap(4);
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    pt.lap(5);
+    if (temporal)
+      PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0, "Found invalid non-sorted temporal neighborhood");
+    for (size_t k = 0; k < pend.size(); ++k) {
+      Pending& q = pend[k];
+      const pyg_hip_relation& r = rels[q.e];
       const int dst = !csc ? r.dst_type : r.src_type;
-      NodeSet& sn = ns[(size_t)src];
       NodeSet& dn = ns[(size_t)dst];
-      RelState& st = rs[(size_t)e];
-      const int64_t count = r.num_neighbors_host[ell];
-      const int64_t F = sn.slice_e - sn.slice_b;
-      st.edges_per_hop.push_back(0);
-      if (F <= 0 || count == 0 || r.num_cols == 0) continue;
-
-      // 1. per-node edge counts + RNG transition tables -> exclusive scan (total -> info_dev->tot)
-      const int64_t ntiles = (F + kScanTile - 1) / kScanTile;
-      CountAgg* tile_buf;
-      PYG_ALLOC(tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
-      int64_t* edge_off;
-      int64_t* rng_word;
-      int32_t* rng_units;
-      PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
-      PYG_ALLOC(rng_word, int64_t*, c, sizeof(int64_t) * (size_t)F);
-      PYG_ALLOC(rng_units, int32_t*, c, sizeof(int32_t) * (size_t)F);
-      // edge-level time wins over node-level time of the destination type (neighbor_kernel.cpp:746-789)
-      RangeCtx range;
-      range.rowptr = r.rowptr;
-      range.col = r.col;
-      range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
-      range.edge_level = r.edge_time ? 1 : 0;
-      range.last = temporal_last;
-      range.seed_times = seed_times;
-      range.batch = disjoint ? sn.batch.p : nullptr;
-      range.error = err_flag;
-      CountLoad cl{sn.nodes.p, sn.slice_b, range, count, replace};
-      CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
-      int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev->tot, stream);
-      if (rc != PYG_HIP_OK) return rc;
-
-      // Run-ahead: with a bounded fan-out the hop's kernels are queued behind the count scan without
-      // waiting for its total -- buffers are sized for the bound F * count, the kernels read the exact
-      // edge count from `info_dev`, and the words the hop may read (16-bit draws) are already being
-      // generated.  One synchronisation per hop instead of two.  Unbounded / large fan-outs and the
-      // host-callback word source (which must draw exactly what is consumed) learn the total first.
-      volatile HopInfo* info_host = static_cast<volatile HopInfo*>(pinned);
-      const bool presync = count < 0 || count > 64 || !rng.engine;
-      int64_t Eb = presync ? 0 : F * count;
-      int64_t avail_blocks = 0;
-      if (presync) {
-        PYG_HIP_CHECK(hipMemcpyAsync(pinned, info_dev, sizeof(HopInfo), hipMemcpyDeviceToHost, stream));
-        PYG_HIP_CHECK(hipStreamSynchronize(stream));
-        if (range.time)
-          PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
-                          "Found invalid non-sorted temporal neighborhood");
-        Eb = info_host->tot.edges;
-        pt.lap(1);
-        if (Eb == 0) {
-          c.release(tile_buf);
-          c.release(edge_off);
-          c.release(rng_word);
-          c.release(rng_units);
-          continue;
-        }
-        // 2. make the consumed random words resident (drawn by the caller's generator)
-        const int64_t end_word = rng.word + tab_dw(info_host->tot.tab, rng.units);
-        if (rng.engine) rc = rng_wait(c, rng, end_word, &avail_blocks);
-        else rc = rng_ensure(c, rng, end_word);
-        if (rc != PYG_HIP_OK) return rc;
-        if (!rng.engine) avail_blocks = rng.blocks;
-      } else {
-        rc = rng_wait(c, rng, rng.word + (F * count + 3) / 4 + 1, &avail_blocks);
-        if (rc != PYG_HIP_OK) return rc;
-      }
-      pt.lap(2);
-
-      // 3. sample + insert
-      // Expected growth over the remaining hops (this relation's own fan-outs, every node expanding
-      // fully): sizes the outputs and the hash table once instead of copying / rehashing them per hop.
-      double mult = 1.0, term = 1.0;
-      for (int l2 = ell + 1; l2 < L && r.num_neighbors_host[l2] > 0; ++l2) {
-        term *= (double)r.num_neighbors_host[l2];
-        mult += term;
-      }
-      const int64_t grow = (int64_t)std::min<double>((double)Eb * mult, 16.0 * 1024 * 1024);
-      rc = st.row.reserve(c, st.row.size + Eb, st.row.size + grow);
-      if (rc != PYG_HIP_OK) return rc;
-      rc = st.col.reserve(c, st.col.size + Eb, st.col.size + grow);
-      if (rc != PYG_HIP_OK) return rc;
-      // edge ids are always produced: they double as the chosen-set history of large fan-outs
-      rc = st.eid.reserve(c, st.eid.size + Eb, st.eid.size + grow);
-      if (rc != PYG_HIP_OK) return rc;
-      rc = dn.nodes.reserve(c, dn.nodes.size + Eb, dn.nodes.size + grow);
-      if (rc != PYG_HIP_OK) return rc;
-      if (disjoint) {
-        rc = dn.batch.reserve(c, dn.batch.size + Eb, dn.batch.size + grow);
-        if (rc != PYG_HIP_OK) return rc;
-      }
-      rc = table_reserve(c, dn, Eb, dn.entries_bound + grow);
-      if (rc != PYG_HIP_OK) return rc;
-      int64_t* e_node;
-      int64_t* e_batch = nullptr;
-      u64* e_slot;
-      PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)Eb);
-      if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)Eb);
-      PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)Eb);
-      const int64_t etiles = (Eb + kScanTile - 1) / kScanTile;
-      int64_t* ftile;
-      PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
-      pt.lap(3);
-      int64_t E = 0, U = 0;
-      for (int attempt = 0;; ++attempt) {
-        HopArgs a;
-        a.info = info_dev;
-        a.word0 = rng.word;
-        a.units0 = rng.units;
-        a.avail_blocks = avail_blocks;
-        a.nodes = sn.nodes.p;
-        a.batch = disjoint ? sn.batch.p : nullptr;
-        a.begin = sn.slice_b;
-        a.frontier = F;
-        range.batch = a.batch;  // the reserve above may have moved the list (src type == dst type)
-        a.range = range;
-        a.col = r.col;
-        a.count = count;
-        a.replace = replace;
-        a.num_batches = num_batches;
-        a.edge_off = edge_off;
-        a.rng_word = rng_word;
-        a.rng_units = rng_units;
-        a.words = rng.dev;
-        a.e_row = st.row.p + st.row.size;
-        a.e_node = e_node;
-        a.e_batch = e_batch;
-        a.e_eid = st.eid.p + st.eid.size;
-        a.e_slot = e_slot;
-        a.table = dn.table;
-        launch_sample(a, F, stream);
-        PYG_HIP_CHECK(hipGetLastError());
-
-        // 4. first occurrences -> ranks -> new local ids / appended nodes
-        FlagLoad fl{e_slot, dn.table.vals, info_dev};
-        AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
-                       disjoint ? dn.batch.p : (int64_t*)nullptr, dn.nodes.size, dn.distinct, 1};
-        rc = device_scan<int64_t, SumOp>(fl, as, Eb, ftile, &info_dev->uniq, stream);
-        if (rc != PYG_HIP_OK) return rc;
-        // 5. local ids of every emitted edge; publishes the hop's totals to the host
-        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Eb + 255) / 256)), dim3(256), 0, stream,
-                           e_slot, dn.table.vals, Eb, st.col.p + st.col.size, info_dev,
-                           static_cast<HopInfo*>(pinned));
-        PYG_HIP_CHECK(hipGetLastError());
-        pt.lap(4);
-        PYG_HIP_CHECK(hipStreamSynchronize(stream));
-        pt.lap(5);
-        if (range.time)
-          PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
-                          "Found invalid non-sorted temporal neighborhood");
-        E = info_host->tot.edges;
-        U = info_host->uniq;
-        const RngTab tab = info_host->tot.tab;
-        const int64_t end_word = rng.word + tab_dw(tab, rng.units);
-        if (info_host->overflow) {
-          // rare: draws wider than 16 bits, or more words than the speculation may run ahead --
-          // nothing was sampled; generate what the hop really needs and repeat it
-          PYG_HIP_REQUIRE(attempt == 0 && rng.engine, "sampler: random words missing after regeneration");
-          rc = rng_wait(c, rng, end_word, &avail_blocks);
-          if (rc != PYG_HIP_OK) return rc;
-          continue;
-        }
-        if (E > 0) {
-          if (rng.engine) rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
-          rng.word = end_word;
-          rng.units = tab_nb(tab, rng.units);
-        }
+      RelState& st = rs[(size_t)q.e];
+      volatile HopInfo* hi = info_host + q.e;
+      if (hi->overflow == 2) {  // aborted behind an earlier relation: start over
+        *restart = (int)k;
         break;
+      }
+      RngTab tab = hi->tot.tab;
+      int64_t end_word = rng.word + tab_dw(tab, rng.units);
+      if (hi->overflow == 1) {
+        PYG_HIP_REQUIRE(rng.engine, "sampler: random words missing");
+        int64_t avail = 0;
+        int rc = rng_wait(c, rng, end_word, &avail);
+        if (rc != PYG_HIP_OK) return rc;
+        hipLaunchKernelGGL(clear_abort_kernel, dim3(1), dim3(1), 0, stream, chain);
+        rc = enqueue_tail(q, avail);
+        if (rc != PYG_HIP_OK) return rc;
+        PYG_HIP_CHECK(hipStreamSynchronize(stream));
+        PYG_HIP_REQUIRE(hi->overflow == 0, "sampler: random words missing after regeneration");
+        if (k + 1 < pend.size()) *restart = (int)(k + 1);
+      }
+      const int64_t E = hi->tot.edges, U = hi->uniq;
+      if (E > 0) {
+        if (rng.engine) rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
+        rng.word = end_word;
+        rng.units = tab_nb(tab, rng.units);
       }
       dn.nodes.size += U;
       if (disjoint) dn.batch.size += U;
       dn.distinct += U;
-      dn.entries_bound = dn.entries_bound - Eb + U;
+      dn.entries_bound = dn.entries_bound - q.Eb + U;
       st.row.size += E;
       st.col.size += E;
       st.eid.size += E;
       st.edges_per_hop.back() = E;
-      c.release(tile_buf);
-      c.release(edge_off);
-      c.release(rng_word);
-      c.release(rng_units);
-      c.release(e_node);
-      if (e_batch) c.release(e_batch);
-      c.release(e_slot);
-      c.release(ftile);
-      pt.lap(6);
+      if (*restart >= 0) break;
+    }
+    // relations that start over: undo their bound-based reservations
+    for (size_t k = (*restart < 0 ? pend.size() : (size_t)*restart); k < pend.size(); ++k) {
+      const pyg_hip_relation& r = rels[pend[k].e];
+      NodeSet& dn = ns[(size_t)(!csc ? r.dst_type : r.src_type)];
+      dn.entries_bound -= pend[k].Eb;
+    }
+    for (Pending& q : pend) free_pending(q);
+    for (int t = 0; t < num_node_types; ++t) {
+      ns[(size_t)t].nodes.live = ns[(size_t)t].nodes.size;
+      ns[(size_t)t].batch.live = ns[(size_t)t].batch.size;
+    }
+    pt.lap(6);
+    return PYG_HIP_OK;
+  };
+
+  for (int ell = 0; ell < L; ++ell) {
+    std::vector<int> order;
+    for (int e = 0; e < num_relations; ++e) {
+      const pyg_hip_relation& r = rels[e];
+      const NodeSet& sn = ns[(size_t)(!csc ? r.src_type : r.dst_type)];
+      rs[(size_t)e].edges_per_hop.push_back(0);
+      if (sn.slice_e - sn.slice_b <= 0 || r.num_neighbors_host[ell] == 0 || r.num_cols == 0) continue;
+      order.push_back(e);
+    }
+    int64_t spec_word = rng.word;  // upper bound of the engine position behind the queued relations
+    size_t pos = 0;
+    while (pos < order.size() || !pend.empty()) {
+      bool flush = pos >= order.size();
+      if (!flush) {
+        const int e = order[pos];
+        const pyg_hip_relation& r = rels[e];
+        const int src = !csc ? r.src_type : r.dst_type;
+        const int dst = !csc ? r.dst_type : r.src_type;
+        NodeSet& sn = ns[(size_t)src];
+        NodeSet& dn = ns[(size_t)dst];
+        RelState& st = rs[(size_t)e];
+        const int64_t count = r.num_neighbors_host[ell];
+        const int64_t F = sn.slice_e - sn.slice_b;
+        // Unbounded / large fan-outs and the host-callback word source (which must draw exactly what is
+        // consumed) need the count-scan total on the host before anything can be sized: they run alone.
+        const bool presync = count < 0 || count > 64 || !rng.engine;
+        if (presync && !pend.empty()) {
+          flush = true;
+        } else {
+          Pending q;
+          q.e = e;
+          q.F = F;
+          q.count = count;
+          // 1. per-node edge counts + RNG transition tables -> exclusive scan (total -> info_dev[e].tot)
+          const int64_t ntiles = (F + kScanTile - 1) / kScanTile;
+          PYG_ALLOC(q.tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
+          PYG_ALLOC(q.edge_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
+          PYG_ALLOC(q.rng_word, int64_t*, c, sizeof(int64_t) * (size_t)F);
+          PYG_ALLOC(q.rng_units, int32_t*, c, sizeof(int32_t) * (size_t)F);
+          // edge-level time wins over node-level time of the destination type (neighbor_kernel.cpp:746-789)
+          q.range.rowptr = r.rowptr;
+          q.range.col = r.col;
+          q.range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
+          q.range.edge_level = r.edge_time ? 1 : 0;
+          q.range.last = temporal_last;
+          q.range.seed_times = seed_times;
+          q.range.batch = disjoint ? sn.batch.p : nullptr;
+          q.range.error = err_flag;
+          CountLoad cl{sn.nodes.p, sn.slice_b, q.range, count, replace};
+          CountStore cs{q.edge_off, q.rng_word, q.rng_units, 0, 4, chain};
+          int rc = device_scan<CountAgg, CountOp>(cl, cs, F, q.tile_buf, &info_dev[e].tot, stream);
+          if (rc != PYG_HIP_OK) return rc;
+
+          int64_t avail_blocks = 0;
+          q.Eb = presync ? 0 : F * count;
+          if (presync) {
+            PYG_HIP_CHECK(hipMemcpyAsync(const_cast<HopInfo*>(info_host) + e, info_dev + e, sizeof(HopInfo),
+                                         hipMemcpyDeviceToHost, stream));
+            PYG_HIP_CHECK(hipStreamSynchronize(stream));
+            if (q.range.time)
+              PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0,
+                              "Found invalid non-sorted temporal neighborhood");
+            q.Eb = info_host[e].tot.edges;
+            pt.lap(1);
+            if (q.Eb == 0) {
+              free_pending(q);
+              ++pos;
+              continue;
+            }
+            // make the consumed random words resident (drawn by the caller's generator)
+            const int64_t end_word = rng.word + tab_dw(info_host[e].tot.tab, rng.units);
+            if (rng.engine) rc = rng_wait(c, rng, end_word, &avail_blocks);
+            else rc = rng_ensure(c, rng, end_word);
+            if (rc != PYG_HIP_OK) return rc;
+            if (!rng.engine) avail_blocks = rng.blocks;
+          } else {
+            // run-ahead: the words this relation MAY read (16-bit draws) are already being generated
+            spec_word += (F * count + 3) / 4 + 1;
+            rc = rng_wait(c, rng, spec_word, &avail_blocks);
+            if (rc != PYG_HIP_OK) return rc;
+          }
+          pt.lap(2);
+
+          // 2. size outputs / node list / hash table for the bound Eb.  Expected growth over the remaining
+          // hops (this relation's own fan-outs, every node expanding fully) sizes them once instead of
+          // copying / rehashing them per hop.
+          double mult = 1.0, term = 1.0;
+          for (int l2 = ell + 1; l2 < L && r.num_neighbors_host[l2] > 0; ++l2) {
+            term *= (double)r.num_neighbors_host[l2];
+            mult += term;
+          }
+          const int64_t grow = (int64_t)std::min<double>((double)q.Eb * mult, 16.0 * 1024 * 1024);
+          rc = st.row.reserve(c, st.row.size + q.Eb, st.row.size + grow);
+          if (rc != PYG_HIP_OK) return rc;
+          rc = st.col.reserve(c, st.col.size + q.Eb, st.col.size + grow);
+          if (rc != PYG_HIP_OK) return rc;
+          // edge ids are always produced: they double as the chosen-set history of large fan-outs
+          rc = st.eid.reserve(c, st.eid.size + q.Eb, st.eid.size + grow);
+          if (rc != PYG_HIP_OK) return rc;
+          // the node list may already hold uncommitted nodes of relations queued before this one
+          dn.nodes.live = std::max(dn.nodes.live, dn.nodes.size);
+          rc = dn.nodes.reserve(c, dn.nodes.live + q.Eb, dn.nodes.live + grow);
+          if (rc != PYG_HIP_OK) return rc;
+          dn.nodes.live += q.Eb;
+          if (disjoint) {
+            dn.batch.live = std::max(dn.batch.live, dn.batch.size);
+            rc = dn.batch.reserve(c, dn.batch.live + q.Eb, dn.batch.live + grow);
+            if (rc != PYG_HIP_OK) return rc;
+            dn.batch.live += q.Eb;
+          }
+          rc = table_reserve(c, dn, q.Eb, dn.entries_bound + grow);
+          if (rc != PYG_HIP_OK) return rc;
+          PYG_ALLOC(q.e_node, int64_t*, c, sizeof(int64_t) * (size_t)q.Eb);
+          if (disjoint) PYG_ALLOC(q.e_batch, int64_t*, c, sizeof(int64_t) * (size_t)q.Eb);
+          PYG_ALLOC(q.e_slot, u64*, c, sizeof(u64) * (size_t)q.Eb);
+          const int64_t etiles = (q.Eb + kScanTile - 1) / kScanTile;
+          PYG_ALLOC(q.ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
+          pt.lap(3);
+          // 3. sample + insert, dedup scan, finalize
+          rc = enqueue_tail(q, avail_blocks);
+          if (rc != PYG_HIP_OK) return rc;
+          pend.push_back(q);
+          ++pos;
+          if (presync) flush = true;
+        }
+      }
+      if (flush) {
+        int restart = -1;
+        const size_t first_pending = pos - pend.size();
+        int rc = commit(&restart);
+        if (rc != PYG_HIP_OK) return rc;
+        if (restart >= 0) pos = first_pending + (size_t)restart;
+        pend.clear();
+        spec_word = rng.word;
+      }
     }
     for (int t = 0; t < num_node_types; ++t) {
       NodeSet& n = ns[(size_t)t];
