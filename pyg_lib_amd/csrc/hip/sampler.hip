@@ -1420,6 +1420,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       int64_t end_word = rng.word + tab_dw(tab, rng.units);
       if (hi->overflow == 1) {
         PYG_HIP_REQUIRE(rng.engine, "sampler: random words missing");
+        if (pt.on)
+          fprintf(stderr, "[pyg_hip sampler] relation %d repeated after a word top-up, %zu queued behind it start over\n",
+                  q.e, pend.size() - k - 1);
         int64_t avail = 0;
         int rc = rng_wait(c, rng, end_word, &avail);
         if (rc != PYG_HIP_OK) return rc;

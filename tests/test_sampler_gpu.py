@@ -269,3 +269,41 @@ def test_dist_random_graph_matches_oracle(variant):
     assert torch.equal(edge.cpu(), torch.from_numpy(redge))
     assert cumsum == rcumsum
     assert after == int(oracle.mt19937_words(5, info['rng_blocks'] * 128 + 1)[-1])
+
+
+def test_hetero_hub_forces_word_top_up_and_requeue():
+    # A hub row of degree >= 2^16 makes its draws 32 bits wide: the first relation of the hop needs more
+    # random words than the 16-bit speculation provided, raises the sticky abort, is repeated after a
+    # top-up, and the relations queued behind it in the same hop start over (sampler.hip, commit()).
+    rng = np.random.default_rng(12)
+    na, nb = 1200, 70_000
+    ets = [('a', 'r1', 'b'), ('a', 'r2', 'a'), ('b', 'r3', 'a'), ('b', 'r4', 'b')]
+    deg = rng.poisson(6, na).astype(np.int64)
+    deg[7] = 69_000  # the hub
+    rp1 = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    cl1 = rng.integers(0, nb, int(rp1[-1]), dtype=np.int64)
+    cl1[rp1[7]:rp1[8]] = rng.permutation(nb)[:69_000]
+    rp, cl = {ets[0]: rp1}, {ets[0]: cl1}
+    for et, (ns, nd) in zip(ets[1:], [(na, na), (nb, na), (nb, nb)]):
+        d = rng.poisson(4, ns).astype(np.int64)
+        rp[et] = np.concatenate([[0], np.cumsum(d)]).astype(np.int64)
+        cl[et] = rng.integers(0, nd, int(d.sum()), dtype=np.int64)
+    # 400 copies of the hub: 2400 32-bit draws = 1200 words, twice what the 16-bit speculation generates
+    seeds = {'a': np.array([3, 7, 11, 500] + [7] * 400, dtype=np.int64), 'b': np.array([5, 69_999], dtype=np.int64)}
+    fan = {e: [6, 3] for e in ets}
+    fan[ets[1]] = [0, 3]  # keeps the hop's speculative chunk (868 words) below the 1212 the hub needs
+    for replace in (False, True):
+        torch.manual_seed(77)
+        out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                             {k: dev(v) for k, v in seeds.items()}, fan, replace=replace)
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        ref = oracle.hetero_neighbor_sample(['a', 'b'], ets, rp, cl, seeds, fan, replace=replace, rng_seed=77)
+        for e in ets:
+            assert torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e])), (e, replace)
+            assert torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
+            assert torch.equal(out[3][e].cpu(), torch.from_numpy(ref[3][e]))
+        for t in ('a', 'b'):
+            assert torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t]))
+        # the global CPU generator advanced by exactly the reference's number of 128-word prefetches
+        assert after == int(oracle.mt19937_words(77, ref[6]['rng_blocks'] * 128 + 1)[-1])
+        assert sum(sum(v) for v in ref[5].values()) > 100
