@@ -78,6 +78,14 @@ size_t index_sort_ws_bytes_i64(int64_t n);
 int index_sort_i64(const int64_t* keys, int64_t n, int64_t max_value, int64_t* keys_out, int64_t* idx_out,
                    void* ws, size_t ws_bytes, hipStream_t stream);
 
+// mt_jump.hip: jump-ahead tables of MT19937 for the sampler's parallel word generation.  The stream is
+// cut into segments of kMtSeg raw values; list k holds the set coefficient positions of
+// x^(k * kMtSeg) mod phi on the current device (immutable, created on first use); `max_span` = the
+// largest window of raw values one of `parts` equal shares of the list touches.
+constexpr int kMtSeg = 20480;
+constexpr int kMtMaxSeg = 64;
+int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* max_span);
+
 // csr.hip: row sums seeded from `out` (the atomic-free, source-order back end of segment_sum_coo).
 int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, void* out, int64_t leading,
                     int64_t rows, int64_t E, int64_t K, hipStream_t stream);

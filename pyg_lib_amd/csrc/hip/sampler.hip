@@ -711,82 +711,76 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
 // whose newest operand lies 454 positions back: 454 new values per step (one per thread), the
 // same numbers in the same order, 2.7x fewer dependent steps than array-at-a-time.  x[n-454] is the
 // value the same thread produced one step earlier (a register); the others come from a 2048-word
-// circular LDS window.  The kernel is issue/latency-bound on one CU, so the step barrier only waits
-// for LDS (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads() would also drain the global stores.
-// One launch continues from array A_from (held in `window`, or in `init` for A_0) and produces arrays
-// A_from+1 .. A_from+m, leaving A_from+m in `window`; the first two steps use the plain recurrence
-// because only 624 values of history exist.  The kernel runs on a side stream ahead of the sampling
-// kernels (speculatively: the exact consumption of a hop is only known after its count scan);
-// `stop` (pinned host memory) lets the host cancel what nobody will read.
+// circular LDS window.  A generating workgroup is issue/latency-bound on one CU, so the step barrier
+// only waits for LDS (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads() would also drain the global
+// stores.
+//
+// One serial recurrence is still the critical path of a sampling call (0.33 ms for a C3 batch), so the
+// stream is generated by MANY workgroups: it is linear over GF(2), and with g_J = x^J mod phi (phi = the
+// generator's characteristic polynomial, mt_jump.hip)
+//       r[1 + J + w] = XOR_{i : bit i of g_J set} r[1 + i + w],
+// i.e. the 624-word window that starts segment k (J = k * kMtSeg raw values further on) is an XOR of
+// windows of the first 19937 + 624 values.  A round is three launches on the side stream:
+//   1. mt_prefix_kernel : one workgroup generates segment 0 (which contains those 20561 values),
+//   2. mt_jump_kernel   : (K-1) x 16 workgroups XOR the start windows of segments 1 .. K-1 together,
+//   3. mt_segment_kernel: K-1 workgroups generate their segments concurrently.
+// Raw coordinates of a round: r[0..623] = the base window (the engine's array, or the last 624 values
+// of the previous round); raw position t is engine output o_r0 + t.  Rounds run speculatively ahead of
+// the sampling kernels (the exact consumption of a hop is only known after its count scan); `stop`
+// (pinned host memory) lets the host cancel what nobody will read.
 constexpr int kMtThreads = 512;
 constexpr int kMtStep = 454;
+constexpr int kMtJumpParts = 16;
 
 __device__ __forceinline__ void mt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev init, uint32_t* __restrict__ window,
-                                                                 uint32_t* __restrict__ out32, int64_t from,
-                                                                 int64_t m, const int* stop) {
-  // x-stream index n lives at x[n & 2047]; x[0..623] = array A_from.  x[2048] mirrors x[0] so that the
-  // operand pairs (x[k], x[k+1]) are always adjacent (one ds_read2_b32 each).
-  __shared__ uint32_t x[2048 + 1];
-  __shared__ int stop_s;
+// little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
+__device__ __forceinline__ void mt_emit(uint32_t* __restrict__ out32, int64_t o, uint32_t raw) {
+  const uint32_t y = mt_temper(raw);
+  if ((o & 1) == 0) out32[o + 1] = y ^ 0x80000000u;
+  else out32[o - 1] = y;
+}
+__device__ __forceinline__ uint32_t mt_raw_at(const uint32_t* __restrict__ out32, int64_t o) {
+  const uint32_t y = (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
+  return mt_untemper(y);
+}
+
+// Generates raw positions [t0, t1) of a stream whose previous 624 values sit in x[] (position t at slot
+// t & 2047, x[2048] mirrors x[0] so that operand pairs are adjacent: one ds_read2_b32 each), emitting
+// output o_r0 + t for each.  Returns false when cancelled.
+__device__ __forceinline__ bool mt_run(uint32_t* x, int* stop_s, uint32_t t0, uint32_t t1,
+                                       uint32_t* __restrict__ out32, int64_t o_r0, const int* stop) {
   const int tid = threadIdx.x;
-  const int64_t a0 = (int64_t)init.left - 1;
-  const int64_t o_base = a0 + 624 * from - 624;  // output index of x-stream position n is o_base + n
-  uint32_t* const obase = out32 + o_base;
-  const uint32_t par = (uint32_t)(o_base & 1);
-  // little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
-  auto emit = [&](uint32_t n, uint32_t raw) {
-    const uint32_t odd = (n + par) & 1u;
-    obase[(int64_t)n + 1 - 2 * (int64_t)odd] = mt_temper(raw) ^ (odd ? 0u : 0x80000000u);
-  };
   auto put = [&](uint32_t slot, uint32_t v) {
     x[slot] = v;
     if (slot == 0) x[2048] = v;
   };
-  if (from == 0) {
-    for (int i = tid; i < 624; i += kMtThreads) put(i, init.state[i]);
-    __syncthreads();
-    // the a0 outputs still held by the caller's current array: output q <- state[next + q]
-    for (int64_t q = tid; q < a0; q += kMtThreads) {
-      const uint32_t y = mt_temper(x[init.next + q]);
-      if ((q & 1) == 0) out32[q + 1] = y ^ 0x80000000u;
-      else out32[q - 1] = y;
-    }
-  } else {
-    for (int i = tid; i < 624; i += kMtThreads) put(i, window[i]);
-    __syncthreads();
-  }
-  if (m <= 0) {
-    if (from == 0) for (int i = tid; i < 624; i += kMtThreads) window[i] = x[i];
-    return;
-  }
-  const uint32_t gen_end = (uint32_t)(624 * (m + 1));  // produce x[624 .. gen_end)
   // two plain steps of 227: history grows to 1078 values
-  uint32_t n0 = 624;
+  uint32_t n0 = t0;
   for (int k = 0; k < 2; ++k, n0 += 227) {
     const uint32_t n = n0 + tid;
-    if (tid < 227 && n < gen_end) {
+    if (tid < 227 && n < t1) {
       const uint32_t v = x[(n - 227) & 2047] ^ mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
       put(n & 2047, v);
-      emit(n, v);
+      mt_emit(out32, o_r0 + n, v);
     }
     mt_lds_barrier();
   }
   // main loop: the step is even, so each thread keeps its slot arithmetic, output parity and pointer
   uint32_t slot = (n0 + tid) & 2047;
   uint32_t prev = x[(slot + 2048 - kMtStep) & 2047];  // x[n - 454] of this thread's element
-  const uint32_t odd = (n0 + tid + par) & 1u;
+  const int64_t o_mine = o_r0 + n0 + tid;
+  const uint32_t odd = (uint32_t)(o_mine & 1);
   const uint32_t flip = odd ? 0u : 0x80000000u;
-  uint32_t* op = obase + ((int64_t)(n0 + tid) + 1 - 2 * (int64_t)odd);
+  uint32_t* op = out32 + (o_mine + 1 - 2 * (int64_t)odd);
   int step = 0;
-  for (; n0 < gen_end; n0 += kMtStep, ++step) {
+  for (; n0 < t1; n0 += kMtStep, ++step) {
     if ((step & 63) == 63) {
-      if (tid == 0) stop_s = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid == 0) *stop_s = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __syncthreads();
-      if (stop_s) return;  // cancelled: nothing past the consumed words is ever read
+      if (*stop_s) return false;  // cancelled: nothing past the consumed words is ever read
     }
-    const uint32_t left = gen_end - n0;
+    const uint32_t left = t1 - n0;
     const uint32_t lim = left < (uint32_t)kMtStep ? left : (uint32_t)kMtStep;
     if ((uint32_t)tid < lim) {
       const uint32_t s1 = (slot + (2048 - 851)) & 2047;
@@ -800,7 +794,100 @@ __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const MtDev ini
     op += kMtStep;
     mt_lds_barrier();
   }
-  for (int i = tid; i < 624; i += kMtThreads) window[i] = x[(624 * (uint32_t)m + i) & 2047];
+  return true;
+}
+
+// Segment 0 of a round: base window from `init` (first round: the caller's engine) or `window`; keeps a
+// raw copy of the base window for the jump kernel, emits the outputs the base window still owes
+// (first round) and generates `count` values.  `window_out`: where to leave the last 624 raw values.
+__global__ __launch_bounds__(kMtThreads) void mt_prefix_kernel(const MtDev init, int use_init,
+                                                               const uint32_t* __restrict__ window,
+                                                               uint32_t* __restrict__ base_raw,
+                                                               uint32_t* __restrict__ out32, int64_t o_r0,
+                                                               uint32_t count, uint32_t* __restrict__ window_out,
+                                                               const int* stop) {
+  __shared__ uint32_t x[2048 + 1];
+  __shared__ int stop_s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 624; i += kMtThreads) {
+    const uint32_t v = use_init ? init.state[i] : window[i];
+    x[i] = v;
+    if (i == 0) x[2048] = v;
+    base_raw[i] = v;
+  }
+  __syncthreads();
+  if (use_init)  // outputs still held by the caller's current array: raw position t is output o_r0 + t >= 0
+    for (int t = tid; t < 624; t += kMtThreads)
+      if (o_r0 + t >= 0) mt_emit(out32, o_r0 + t, x[t]);
+  if (!mt_run(x, &stop_s, 624, 624 + count, out32, o_r0, stop)) return;
+  if (window_out)
+    for (int i = tid; i < 624; i += kMtThreads) window_out[i] = x[(count + i) & 2047];
+}
+
+struct MtJumpLists {
+  const uint16_t* idx[kMtMaxSeg];
+  int count[kMtMaxSeg];
+};
+
+// windows[k-1][w] ^= XOR over this workgroup's share of the set coefficients i of g_k of r[1 + i + w]
+__global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict__ base_raw,
+                                                      const uint32_t* __restrict__ out32, int64_t o_r0,
+                                                      MtJumpLists lists, uint32_t* __restrict__ windows) {
+  extern __shared__ uint32_t r_lds[];
+  const int k = blockIdx.x + 1;
+  const uint16_t* idx = lists.idx[k];
+  const int n = lists.count[k];
+  const int j0 = (int)((int64_t)blockIdx.y * n / kMtJumpParts);
+  const int j1 = (int)((int64_t)(blockIdx.y + 1) * n / kMtJumpParts);
+  if (j0 >= j1) return;
+  const int imin = idx[j0], imax = idx[j1 - 1];
+  const int span = imax - imin + 624;  // raw positions 1 + imin .. 1 + imax + 623
+  // this share of the coefficient list sits behind the raw values in LDS (a dependent global load per
+  // term would cost ~0.2 us each)
+  uint16_t* off_lds = reinterpret_cast<uint16_t*>(r_lds + span);
+  for (int p = threadIdx.x; p < span; p += 256) {
+    const int t = 1 + imin + p;
+    r_lds[p] = t < 624 ? base_raw[t] : mt_raw_at(out32, o_r0 + t);
+  }
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) off_lds[j - j0] = (uint16_t)(idx[j] - imin);
+  __syncthreads();
+  uint32_t acc[3] = {0u, 0u, 0u};
+  const int w0 = threadIdx.x, w1 = threadIdx.x + 256, w2 = threadIdx.x + 512;
+  const bool has2 = w2 < 624;
+#pragma unroll 4
+  for (int j = 0; j < j1 - j0; ++j) {
+    const int off = off_lds[j];
+    acc[0] ^= r_lds[off + w0];
+    acc[1] ^= r_lds[off + w1];
+    if (has2) acc[2] ^= r_lds[off + w2];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int w = threadIdx.x + 256 * q;
+    if (w < 624) atomicXor(&windows[(k - 1) * 624 + w], acc[q]);
+  }
+}
+
+// Segments 1 .. K-1: workgroup b continues from windows[b] = r[1 + k seg .. 1 + k seg + 623], k = b + 1.
+__global__ __launch_bounds__(kMtThreads) void mt_segment_kernel(const uint32_t* __restrict__ windows,
+                                                                uint32_t* __restrict__ out32, int64_t o_r0,
+                                                                uint32_t seg, uint32_t* __restrict__ window_out,
+                                                                const int* stop) {
+  __shared__ uint32_t x[2048 + 1];
+  __shared__ int stop_s;
+  const int tid = threadIdx.x;
+  const uint32_t k = blockIdx.x + 1;
+  const uint32_t tk = 1 + k * seg;  // raw position of the window's first value
+  for (int i = tid; i < 624; i += kMtThreads) {
+    const uint32_t slot = (tk + i) & 2047;
+    const uint32_t v = windows[blockIdx.x * 624 + i];
+    x[slot] = v;
+    if (slot == 0) x[2048] = v;
+  }
+  __syncthreads();
+  if (!mt_run(x, &stop_s, tk + 624, tk + 624 + seg, out32, o_r0, stop)) return;
+  if (window_out && blockIdx.x == gridDim.x - 1)
+    for (int i = tid; i < 624; i += kMtThreads) window_out[i] = x[(tk + seg + i) & 2047];
 }
 
 // Engine state after consuming n32 > a0 outputs: the array that holds the last consumed output, fully
@@ -905,7 +992,7 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   }
   const int64_t want = std::max<int64_t>(need, std::min<int64_t>(hint, 1ll << 20));
   u64 ncap = 1024;
-  while (ncap < 4 * (u64)need || ncap < 2 * (u64)want) ncap <<= 1;
+  while (ncap < 2 * (u64)need || ncap < 2 * (u64)want) ncap <<= 1;  // load factor <= 0.5
   HashTable nt;
   PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * 2 * ncap);
   nt.vals = nt.keys + ncap;
@@ -986,9 +1073,11 @@ struct RngHost {
   bool engine = false;
   MtDev init;                 // the caller's engine at call start
   int64_t a0 = 0;             // outputs left in its current array
-  int64_t arrays = 0;         // regenerated arrays launched so far: a0 + 624 * arrays outputs exist
-  bool started = false;
-  uint32_t* window = nullptr; // device: raw values of the newest array
+  int64_t o_r0 = 0;           // engine output index of raw position 0 of the current base window
+  bool started = false;       // a round has been launched: the base window lives in `window`
+  uint32_t* window = nullptr; // device: the last 624 raw values generated (base window of the next round)
+  uint32_t* base_raw = nullptr;   // device: raw copy of a round's base window (jump kernel input)
+  uint32_t* windows = nullptr;    // device: start windows of segments 1 .. kMtMaxSeg-1
   volatile int* stop = nullptr;
   SideStream* side = nullptr;
   struct Mark {
@@ -997,53 +1086,88 @@ struct RngHost {
   };
   std::vector<Mark> marks;
   size_t waited = 0;          // marks[0 .. waited) are already ordered before the main stream
-  int64_t generated32() const { return started ? a0 + 624 * arrays : 0; }
+  // outputs [0, generated32) exist once the last launched round has finished
+  int64_t generated32() const { return started ? o_r0 + 624 : 0; }
 };
 
-constexpr int64_t kSpecCapWords = 1ll << 20;  // speculation never runs more than 8 MB ahead
+constexpr int64_t kSpecCapWords = (int64_t)kMtMaxSeg * kMtSeg / 2;  // one round: 655 k words (5 MB)
 
-// Launches generation on the side stream until at least `target32` outputs exist.
+// Launches rounds on the side stream until at least `target32` outputs exist.
 int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
-  if (r.started && r.generated32() >= target32) return PYG_HIP_OK;
-  const int64_t m = std::max<int64_t>(0, (target32 - (r.a0 + 624 * r.arrays) + 623) / 624);
-  const int64_t new_gen = r.a0 + 624 * (r.arrays + m);
-  const int64_t need_cap = (new_gen + 2 + 255) / 256;
-  if (need_cap > r.dev_cap_blocks) {
-    const int64_t ncap = std::max<int64_t>(need_cap, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
-    u64* nd;
-    PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
-    if (r.started) {  // rare: the speculation cap was too small -- move what exists, in main-stream order
-      PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks.back().ev, 0));
-      r.waited = r.marks.size();
-      PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(uint32_t) * (size_t)(r.generated32() + 1),
-                                   hipMemcpyDeviceToDevice, c.stream));
+  while (!r.started || r.generated32() < target32) {
+    // this round: segments 0 .. K-1 of kMtSeg values (segment 0 one more), raw positions [624, 625 + K seg)
+    int64_t K = (target32 - (r.o_r0 + 625) + kMtSeg - 1) / kMtSeg;
+    K = std::max<int64_t>(1, std::min<int64_t>(K, kMtMaxSeg));
+    const int64_t t_end = 625 + K * kMtSeg;
+    const int64_t new_gen = r.o_r0 + t_end;
+    const int64_t need_cap = (new_gen + 2 + 255) / 256;
+    if (need_cap > r.dev_cap_blocks) {
+      const int64_t ncap = std::max<int64_t>(need_cap, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
+      u64* nd;
+      PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
+      if (r.started) {  // rare: more words than the first round produced -- move what exists, in main-stream order
+        PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks.back().ev, 0));
+        r.waited = r.marks.size();
+        PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(uint32_t) * (size_t)(r.generated32() + 1),
+                                     hipMemcpyDeviceToDevice, c.stream));
+      }
+      // the block may be recycled from main-stream work that is still in flight
+      hipEvent_t ev;
+      int rc = r.side->next_event(&ev);
+      if (rc != PYG_HIP_OK) return rc;
+      PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
+      PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
+      c.release(r.dev);
+      r.dev = nd;
+      r.dev_cap_blocks = ncap;
     }
-    // the block may be recycled from main-stream work that is still in flight
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(r.dev);
+    hipStream_t ss = r.side->stream;
+    hipLaunchKernelGGL(mt_prefix_kernel, dim3(1), dim3(kMtThreads), 0, ss, r.init, r.started ? 0 : 1, r.window,
+                       r.base_raw, out32, r.o_r0, (uint32_t)(kMtSeg + 1), K == 1 ? r.window : (uint32_t*)nullptr,
+                       const_cast<const int*>(r.stop));
+    PYG_HIP_CHECK(hipGetLastError());
     hipEvent_t ev;
     int rc = r.side->next_event(&ev);
     if (rc != PYG_HIP_OK) return rc;
-    PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
-    PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
-    c.release(r.dev);
-    r.dev = nd;
-    r.dev_cap_blocks = ncap;
+    PYG_HIP_CHECK(hipEventRecord(ev, ss));
+    r.marks.push_back({r.o_r0 + 625 + kMtSeg, ev});
+    if (K > 1) {
+      MtJumpLists lists;
+      int max_span = 0;
+      for (int k = 1; k < (int)K; ++k) {
+        int span = 0;
+        rc = mt_jump_list(k, kMtJumpParts, &lists.idx[k], &lists.count[k], &span);
+        if (rc != PYG_HIP_OK) return rc;
+        max_span = std::max(max_span, span);
+      }
+      PYG_HIP_CHECK(hipMemsetAsync(r.windows, 0, sizeof(uint32_t) * 624 * (size_t)(K - 1), ss));
+      // raw values of a share + its coefficient offsets (at most 19937 / kMtJumpParts + 1 of them)
+      const int jump_lds = (int)sizeof(uint32_t) * (max_span + 8) + (int)sizeof(uint16_t) * (19937 / kMtJumpParts + 8);
+      static thread_local int attr_lds = 0;
+      if (jump_lds > attr_lds) {
+        PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mt_jump_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, jump_lds));
+        attr_lds = jump_lds;
+      }
+      hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(K - 1), kMtJumpParts), dim3(256), jump_lds, ss, r.base_raw,
+                         out32, r.o_r0, lists, r.windows);
+      hipLaunchKernelGGL(mt_segment_kernel, dim3((unsigned)(K - 1)), dim3(kMtThreads), 0, ss, r.windows, out32, r.o_r0,
+                         (uint32_t)kMtSeg, r.window, const_cast<const int*>(r.stop));
+      PYG_HIP_CHECK(hipGetLastError());
+      rc = r.side->next_event(&ev);
+      if (rc != PYG_HIP_OK) return rc;
+      PYG_HIP_CHECK(hipEventRecord(ev, ss));
+      r.marks.push_back({new_gen, ev});
+    }
+    r.o_r0 += t_end - 624;
+    r.started = true;
   }
-  hipLaunchKernelGGL(mt_generate_kernel, dim3(1), dim3(kMtThreads), 0, r.side->stream, r.init, r.window,
-                     reinterpret_cast<uint32_t*>(r.dev), r.arrays, m, const_cast<const int*>(r.stop));
-  PYG_HIP_CHECK(hipGetLastError());
-  hipEvent_t ev;
-  int rc = r.side->next_event(&ev);
-  if (rc != PYG_HIP_OK) return rc;
-  PYG_HIP_CHECK(hipEventRecord(ev, r.side->stream));
-  r.arrays += m;
-  r.started = true;
-  r.marks.push_back({r.generated32(), ev});
   return PYG_HIP_OK;
 }
 
-// Adopts the caller's engine and starts generating on the side stream: `spec_words[h]` is the
-// cumulative number of words hop h may consume at most (16-bit draws), one launch per entry so that
-// early hops need not wait for the words of late ones.
+// Adopts the caller's engine and starts generating on the side stream: `spec_words` = the number of words
+// the call may consume at most (16-bit draws); one round of up to kMtMaxSeg concurrent segments.
 int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec_words) {
   const pyg_hip_mt19937* e = c.host->mt19937;
   PYG_HIP_REQUIRE(e->left > 0 && e->left <= 624 && e->next <= 624 && (int64_t)e->next + e->left <= 625,
@@ -1052,6 +1176,7 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
   ::memcpy(&r.init, e, sizeof(MtDev));
   r.engine = true;
   r.a0 = (int64_t)r.init.left - 1;
+  r.o_r0 = r.a0 - 624;  // raw position t of the caller's array is output t - (624 - a0)
   int rc = get_side_stream(&r.side);
   if (rc != PYG_HIP_OK) return rc;
   r.stop = reinterpret_cast<volatile int*>(static_cast<char*>(pinned) + 512);
@@ -1059,11 +1184,14 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
   c.side = r.side->stream;
   c.side_stop = r.stop;
   PYG_ALLOC(r.window, uint32_t*, c, sizeof(uint32_t) * 624);
-  // one allocation for everything the speculation may write
+  PYG_ALLOC(r.base_raw, uint32_t*, c, sizeof(uint32_t) * 624);
+  PYG_ALLOC(r.windows, uint32_t*, c, sizeof(uint32_t) * 624 * (size_t)kMtMaxSeg);
   int64_t top = 128;
   for (int64_t w : spec_words) top = std::max(top, std::min(w, kSpecCapWords));
   {
-    const int64_t cap = (2 * top + 624 + r.a0 + 2 + 255) / 256 + 1;
+    // one allocation for everything the first round may write
+    const int64_t segs = std::max<int64_t>(1, std::min<int64_t>((2 * top + kMtSeg - 1) / kMtSeg + 1, kMtMaxSeg));
+    const int64_t cap = (r.o_r0 + 625 + segs * kMtSeg + 2 + 255) / 256 + 1;
     PYG_ALLOC(r.dev, u64*, c, sizeof(u64) * 128 * (size_t)cap);
     r.dev_cap_blocks = cap;
     hipEvent_t ev;  // order the side stream after whatever used these blocks before
@@ -1072,16 +1200,8 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
     PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
     PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
   }
-  int64_t prev = 0;
-  for (int64_t w : spec_words) {
-    w = std::min(w, kSpecCapWords);
-    if (w <= prev) continue;
-    rc = rng_generate(c, r, 2 * w);
-    if (rc != PYG_HIP_OK) return rc;
-    prev = w;
-  }
   // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
-  rc = rng_generate(c, r, 256);
+  rc = rng_generate(c, r, std::max<int64_t>(2 * top, 256));
   if (rc != PYG_HIP_OK) return rc;
   r.blocks = 1;
   return PYG_HIP_OK;
@@ -1092,7 +1212,7 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
 // No consumption accounting: also used for words a hop MAY read.
 int rng_wait(Ctx& c, RngHost& r, int64_t last_word, int64_t* avail_blocks) {
   const int64_t need32 = (last_word / 128 + 1) * 256;
-  if (r.generated32() < need32) {  // beyond the speculation: top up with some slack
+  if (r.generated32() < need32) {  // beyond the speculation: another round, with some slack
     int rc = rng_generate(c, r, need32 + need32 / 4);
     if (rc != PYG_HIP_OK) return rc;
   }
@@ -1151,11 +1271,18 @@ int rng_finish(Ctx& c, RngHost& r) {
     e->next = (uint32_t)(r.init.next + n32);
     return PYG_HIP_OK;
   }
-  // every consumed block was waited for, and launches produce whole arrays: the final array exists
+  // the engine is left holding the whole 624-array that contains the last consumed output: make sure
+  // all of it has been generated, and that the launches producing it are not cancelled below
+  const int64_t k_arr = (n32 - r.a0 + 623) / 624;
+  const int64_t end32 = r.a0 + 624 * k_arr;
+  if (r.generated32() < end32) {
+    int rc = rng_generate(c, r, end32);
+    if (rc != PYG_HIP_OK) return rc;
+  }
   size_t k = 0;
-  while (r.marks[k].upto32 < n32) ++k;
-  // the launch that produces the last consumed words must not be cancelled below
+  while (r.marks[k].upto32 < end32) ++k;
   PYG_HIP_CHECK(hipEventSynchronize(r.marks[k].ev));
+  if (k >= r.waited) PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
   MtDev* out;
   PYG_ALLOC(out, MtDev*, c, sizeof(MtDev));
   hipLaunchKernelGGL(mt_finish_kernel, dim3(1), dim3(256), 0, c.stream,
