@@ -630,10 +630,14 @@ __global__ void set_chain_kernel(ChainState* c, int64_t word, int units) {
   c->units = units;
   c->abort = 0;
 }
-__global__ void set_type_kernel(TypeState* t, int64_t size, int64_t distinct) {
-  t->size = size;
-  t->distinct = distinct;
+__global__ void init_types_kernel(TypeState* t, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    t[i].size = 0;
+    t[i].distinct = 0;
+  }
 }
+__global__ void set_type_size_kernel(TypeState* t, int64_t size) { t->size = size; }
 __global__ void clear_abort_kernel(ChainState* c) { c->abort = 0; }
 
 __global__ void interleave_kernel(const int64_t* __restrict__ batch,
@@ -833,7 +837,7 @@ struct MtJumpLists {
 __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict__ base_raw,
                                                       const uint32_t* __restrict__ out32, int64_t o_r0,
                                                       MtJumpLists lists, uint32_t* __restrict__ windows) {
-  extern __shared__ uint32_t r_lds[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t r_lds[];
   const int k = blockIdx.x + 1;
   const uint16_t* idx = lists.idx[k];
   const int n = lists.count[k];
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict
   const int span = imax - imin + 624;  // raw positions 1 + imin .. 1 + imax + 623
   // this share of the coefficient list sits behind the raw values in LDS (a dependent global load per
   // term would cost ~0.2 us each)
-  uint16_t* off_lds = reinterpret_cast<uint16_t*>(r_lds + span);
+  uint16_t* off_lds = reinterpret_cast<uint16_t*>(r_lds + ((span + 3) & ~3));
   for (int p = threadIdx.x; p < span; p += 256) {
     const int t = 1 + imin + p;
     r_lds[p] = t < 624 ? base_raw[t] : mt_raw_at(out32, o_r0 + t);
@@ -854,8 +858,28 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict
   uint32_t acc[3] = {0u, 0u, 0u};
   const int w0 = threadIdx.x, w1 = threadIdx.x + 256, w2 = threadIdx.x + 512;
   const bool has2 = w2 < 624;
-#pragma unroll 4
-  for (int j = 0; j < j1 - j0; ++j) {
+  // 8 terms per round: one 16-byte read of offsets, then 24 independent LDS reads in flight
+  const int nterms = j1 - j0;
+  int j = 0;
+  for (; j + 8 <= nterms; j += 8) {
+    const uint4 o4 = *reinterpret_cast<const uint4*>(off_lds + j);
+    const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
+    uint32_t v0[8], v1[8], v2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int off = (int)((ow[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+      v0[q] = r_lds[off + w0];
+      v1[q] = r_lds[off + w1];
+      v2[q] = has2 ? r_lds[off + w2] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[0] ^= v0[q];
+      acc[1] ^= v1[q];
+      acc[2] ^= v2[q];
+    }
+  }
+  for (; j < nterms; ++j) {
     const int off = off_lds[j];
     acc[0] ^= r_lds[off + w0];
     acc[1] ^= r_lds[off + w1];
@@ -1143,7 +1167,7 @@ int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
       }
       PYG_HIP_CHECK(hipMemsetAsync(r.windows, 0, sizeof(uint32_t) * 624 * (size_t)(K - 1), ss));
       // raw values of a share + its coefficient offsets (at most 19937 / kMtJumpParts + 1 of them)
-      const int jump_lds = (int)sizeof(uint32_t) * (max_span + 8) + (int)sizeof(uint16_t) * (19937 / kMtJumpParts + 8);
+      const int jump_lds = (int)sizeof(uint32_t) * (max_span + 8) + (int)sizeof(uint16_t) * (19937 / kMtJumpParts + 16);
       static thread_local int attr_lds = 0;
       if (jump_lds > attr_lds) {
         PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mt_jump_kernel),
@@ -1373,6 +1397,16 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     *err_flag = 0;
   }
 
+  // device-resident engine position and node-list sizes (see the hop loop)
+  ChainState* chain;
+  TypeState* tstate;
+  PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
+  PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
+  hipLaunchKernelGGL(set_chain_kernel, dim3(1), dim3(1), 0, stream, chain, rng.word, rng.units);
+  hipLaunchKernelGGL(init_types_kernel, dim3((unsigned)((num_node_types + 63) / 64)), dim3(64), 0, stream, tstate,
+                     num_node_types);
+  PYG_HIP_CHECK(hipGetLastError());
+
   // ---- seeds ----
   int64_t batch0 = 0;
   for (int s = 0; s < num_seed_sets; ++s) {
@@ -1415,11 +1449,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
     FlagLoad fl{slots, n.table.vals};
     AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    // scan totals land directly in pinned host memory (device-visible): no D2H copy to launch
-    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, static_cast<int64_t*>(pinned), stream);
+    // the number of distinct seeds (Mapper::curr) goes straight into the device-resident type state: the
+    // host never needs it, so the seeds cost no synchronisation
+    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &tstate[ss.node_type].distinct, stream);
     if (rc != PYG_HIP_OK) return rc;
-    PYG_HIP_CHECK(hipStreamSynchronize(stream));
-    n.distinct = *static_cast<volatile int64_t*>(pinned);
+    hipLaunchKernelGGL(set_type_size_kernel, dim3(1), dim3(1), 0, stream, tstate + ss.node_type, S);
+    PYG_HIP_CHECK(hipGetLastError());
     n.nodes.size = S;
     if (disjoint) n.batch.size = S;
     c.release(slots);
@@ -1436,16 +1471,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   // A relation is "committed" when the host has folded its totals into its own bookkeeping.
   volatile HopInfo* info_host = reinterpret_cast<volatile HopInfo*>(static_cast<char*>(pinned) + 1024);
   HopInfo* info_dev;
-  ChainState* chain;
-  TypeState* tstate;
   PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo) * (size_t)std::max(num_relations, 1));
-  PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
-  PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
-  hipLaunchKernelGGL(set_chain_kernel, dim3(1), dim3(1), 0, stream, chain, rng.word, rng.units);
-  for (int t = 0; t < num_node_types; ++t)
-    hipLaunchKernelGGL(set_type_kernel, dim3(1), dim3(1), 0, stream, tstate + t, ns[(size_t)t].nodes.size,
-                       ns[(size_t)t].distinct);
-  PYG_HIP_CHECK(hipGetLastError());
 
   struct Pending {
     int e = 0;
