@@ -191,15 +191,34 @@ __global__ void rehash_kernel(HashTable oldt, HashTable newt) {
   }
 }
 
+// Device-resident engine position and per-node-type list sizes: the relations of a hop are queued
+// back to back (each one starts where the previous one ended) and the host reads the results of the
+// whole hop with ONE synchronisation.
+struct ChainState {
+  int64_t word;   // engine position: linear word index
+  int32_t units;  //                  16-bit units left in that word
+  int32_t abort;  // sticky: a relation of this hop lacked random words -> everything after it is a no-op
+};
+struct TypeState {
+  int64_t size;      // length of the node list of this type
+  int64_t distinct;  // Mapper::curr
+  int64_t slice_b;   // frontier of the current hop = nodes [slice_b, slice_e) (fully queued mode)
+  int64_t slice_e;
+};
+
 // ---- seeds -----------------------------------------------------------------------------------------
 // mapper.fill(seed) / per-seed insert (neighbor_kernel.cpp:409-416, 667-683): emission position =
 // seed index within its type; value = min position.
 __global__ void seed_insert_kernel(const int64_t* __restrict__ seed, int64_t n, int64_t batch0,
                                    int disjoint, int64_t num_batches, HashTable t,
                                    int64_t* __restrict__ nodes, int64_t* __restrict__ batch,
-                                   u64* __restrict__ slots) {
+                                   u64* __restrict__ slots, TypeState* __restrict__ ts) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (i == 0) {  // the seeds are the node list so far and the frontier of hop 0
+    ts->size = n;
+    ts->slice_e = n;
+  }
   const int64_t v = seed[i];
   const int64_t b = disjoint ? batch0 + i : 0;
   nodes[i] = v;
@@ -261,12 +280,21 @@ struct CountLoad {
   RangeCtx range;
   int64_t count;          // fan-out (may be negative)
   int replace;
+  const TypeState* fs;    // device-resident frontier [slice_b, slice_e) of the src type, or nullptr
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
     r.tab = rng_identity();
-    const int64_t v = nodes[begin + i];
+    int64_t b = begin;
+    if (fs) {  // launched for an upper bound of the frontier size
+      b = fs->slice_b;
+      if (i >= fs->slice_e - b) {
+        r.edges = 0;
+        return r;
+      }
+    }
+    const int64_t v = nodes[b + i];
     int64_t rs, re;
-    range(v, begin + i, count, &rs, &re);
+    range(v, b + i, count, &rs, &re);
     const int64_t deg = re - rs;
     if (deg <= 0 || count == 0) {
       r.edges = 0;
@@ -304,19 +332,6 @@ struct CountLoad {
   }
 };
 
-// Device-resident engine position and per-node-type list sizes: the relations of a hop are queued
-// back to back (each one starts where the previous one ended) and the host reads the results of the
-// whole hop with ONE synchronisation.
-struct ChainState {
-  int64_t word;   // engine position: linear word index
-  int32_t units;  //                  16-bit units left in that word
-  int32_t abort;  // sticky: a relation of this hop lacked random words -> everything after it is a no-op
-};
-struct TypeState {
-  int64_t size;      // length of the node list of this type
-  int64_t distinct;  // Mapper::curr
-};
-
 struct CountStore {
   int64_t* edge_off;
   int64_t* rng_word;
@@ -347,6 +362,9 @@ struct HopArgs {
   // total; it checks on its own that every random word it may read has been generated
   HopInfo* info = nullptr;
   ChainState* chain = nullptr;  // device-resident engine position (start of this relation), sticky abort
+  const TypeState* fs = nullptr;      // device-resident frontier of the src type (overrides begin / frontier)
+  const int64_t* rel_size = nullptr;  // device-resident number of edges this relation has emitted so far
+                                      // (offset of e_row / e_eid), or nullptr
   int64_t word0 = 0;          // engine position at the start of the hop (chain == nullptr)
   int units0 = 4;
   int64_t avail_blocks = 0;   // 128-word blocks readable by this launch
@@ -429,9 +447,23 @@ __device__ __forceinline__ bool hop_overflow(const HopArgs& a) {
   return over;
 }
 
+// fully queued mode: frontier and output offsets come from device memory
+__device__ __forceinline__ void resolve_device_state(HopArgs& a) {
+  if (a.fs) {
+    a.begin = a.fs->slice_b;
+    a.frontier = a.fs->slice_e - a.fs->slice_b;
+  }
+  if (a.rel_size) {
+    const int64_t o = *a.rel_size;
+    a.e_row += o;
+    if (a.e_eid) a.e_eid += o;
+  }
+}
+
 // One wave per frontier node (_sample, neighbor_kernel.cpp:177-243).
 __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
   if (hop_overflow(a)) return;
+  resolve_device_state(a);
   const int lane = threadIdx.x & 63;
   const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (i >= a.frontier) return;
@@ -497,6 +529,7 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
 template <int G>
 __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
   if (hop_overflow(a)) return;
+  resolve_device_state(a);
   const int lane = threadIdx.x & 63;
   const int g = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
@@ -607,8 +640,11 @@ struct AssignStore {
 __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __restrict__ vals,
                                 int64_t n, int64_t* __restrict__ out_col, const HopInfo* __restrict__ info,
                                 HopInfo* __restrict__ publish, ChainState* __restrict__ chain,
-                                TypeState* __restrict__ ts) {
+                                TypeState* __restrict__ ts, const int64_t* __restrict__ rel_size,
+                                int64_t* __restrict__ rel_size_next) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t col_off = rel_size ? *rel_size : 0;  // fully queued mode: edges this relation emitted before
+  if (p == 0 && rel_size_next) *rel_size_next = col_off + (info->overflow ? 0 : info->tot.edges);
   if (p == 0 && publish) {
     *publish = *info;  // pinned host memory: read by the host after the hop's sync
     if (chain && !info->overflow) {
@@ -622,22 +658,35 @@ __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __rest
     }
   }
   if (info && (p >= info->tot.edges || info->overflow)) return;
-  if (p < n) out_col[p] = (int64_t)vals[slots[p]];
+  if (p < n) out_col[col_off + p] = (int64_t)vals[slots[p]];
 }
 
-__global__ void set_chain_kernel(ChainState* c, int64_t word, int units) {
-  c->word = word;
-  c->units = units;
-  c->abort = 0;
-}
-__global__ void init_types_kernel(TypeState* t, int n) {
+// Hop boundary (fully queued mode): the nodes appended during the hop become the next frontier, and every
+// relation's output offset is carried over to the next hop's slot (finalize_kernel overwrites it for the
+// relations that run in that hop).  rel_sizes is [hops + 1][num_rel].
+__global__ void hop_boundary_kernel(TypeState* t, int n, int advance, int64_t* rel_sizes, int num_rel, int next_hop) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (advance && i < n) {
+    t[i].slice_b = t[i].slice_e;
+    t[i].slice_e = t[i].size;
+  }
+  if (i < num_rel) rel_sizes[(int64_t)(next_hop + 1) * num_rel + i] = rel_sizes[(int64_t)next_hop * num_rel + i];
+}
+
+__global__ void init_state_kernel(ChainState* c, int64_t word, int units, TypeState* t, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    c->word = word;
+    c->units = units;
+    c->abort = 0;
+  }
   if (i < n) {
     t[i].size = 0;
     t[i].distinct = 0;
+    t[i].slice_b = 0;
+    t[i].slice_e = 0;
   }
 }
-__global__ void set_type_size_kernel(TypeState* t, int64_t size) { t->size = size; }
 __global__ void clear_abort_kernel(ChainState* c) { c->abort = 0; }
 
 __global__ void interleave_kernel(const int64_t* __restrict__ batch,
@@ -1317,6 +1366,8 @@ int rng_finish(Ctx& c, RngHost& r) {
   return PYG_HIP_OK;
 }
 
+constexpr int kNeedSlow = 1000;  // internal: repeat the call in the synchronising mode
+
 struct RelState {
   DevVec row, col, eid;
   std::vector<int64_t> edges_per_hop;
@@ -1325,7 +1376,7 @@ struct RelState {
 int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* rels,
                 int num_seed_sets, const pyg_hip_seed_set* seeds, const int64_t* const* node_time,
                 int temporal_last, int L, int csc, int replace, int disjoint, int return_edge_id,
-                Ctx& c, pyg_hip_sample_result* res) {
+                Ctx& c, pyg_hip_sample_result* res, bool allow_fast) {
   hipStream_t stream = c.stream;
   std::vector<NodeSet> ns((size_t)num_node_types);
   std::vector<RelState> rs((size_t)num_relations);
@@ -1343,10 +1394,123 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
   void* pinned = nullptr;
   {
-    int rc = get_pinned(&pinned, 1024 + sizeof(HopInfo) * (size_t)std::max(num_relations, 96));  // scratch + one HopInfo per relation
+    int rc = get_pinned(&pinned, 1024 + sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 96));  // scratch + one HopInfo per (hop, relation)
     if (rc != PYG_HIP_OK) return rc;
   }
 
+  // temporal sampling: one seed time per disjoint subgraph (batch id)
+  bool temporal = false;
+  for (int t = 0; t < num_node_types && node_time; ++t) temporal = temporal || node_time[t] != nullptr;
+  for (int e = 0; e < num_relations; ++e) temporal = temporal || rels[e].edge_time != nullptr;
+  int64_t* seed_times = nullptr;
+  int* err_flag = nullptr;
+  if (temporal) {
+    PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
+    PYG_ALLOC(seed_times, int64_t*, c, sizeof(int64_t) * (size_t)num_batches);
+    // kernels raise the flag straight in pinned host memory: no copy, no extra synchronisation
+    err_flag = reinterpret_cast<int*>(static_cast<char*>(pinned) + 256);
+    *err_flag = 0;
+  }
+
+  // device-resident engine position and node-list sizes (see the hop loop)
+  ChainState* chain;
+  TypeState* tstate;
+  PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
+  PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
+  hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((num_node_types + 63) / 64)), dim3(64), 0, stream, chain,
+                     rng.word, rng.units, tstate, num_node_types);
+  PYG_HIP_CHECK(hipGetLastError());
+
+  // Upper bounds from the seeds and the fan-out products: frontier size per (hop, type), emitted edges per
+  // (hop, relation).  With bounded fan-outs they size everything up front (fully queued mode below).
+  bool fast = allow_fast && c.host->mt19937 != nullptr && L > 0 && num_relations > 0;
+  std::vector<std::vector<int64_t>> eb((size_t)L, std::vector<int64_t>((size_t)num_relations, 0));
+  std::vector<std::vector<int64_t>> fbh((size_t)L, std::vector<int64_t>((size_t)num_node_types, 0));
+  std::vector<int64_t> node_bound((size_t)num_node_types, 0), rel_bound((size_t)num_relations, 0);
+  if (fast) {
+    std::vector<int64_t> fb((size_t)num_node_types, 0);
+    for (int s = 0; s < num_seed_sets; ++s)
+      if (seeds[s].node_type >= 0 && seeds[s].node_type < num_node_types)
+        fb[(size_t)seeds[s].node_type] += seeds[s].num_seed;
+    int64_t total = 0;
+    for (int ell = 0; ell < L && fast; ++ell) {
+      fbh[(size_t)ell] = fb;
+      std::vector<int64_t> nf((size_t)num_node_types, 0);
+      for (int e = 0; e < num_relations; ++e) {
+        const int src = !csc ? rels[e].src_type : rels[e].dst_type;
+        const int dst = !csc ? rels[e].dst_type : rels[e].src_type;
+        const int64_t count = rels[e].num_neighbors_host[ell];
+        if (count < 0 || count > 64) fast = false;
+        if (count <= 0 || fb[(size_t)src] == 0 || rels[e].num_cols == 0) continue;
+        const int64_t b = fb[(size_t)src] * count;
+        eb[(size_t)ell][(size_t)e] = b;
+        nf[(size_t)dst] += b;
+        node_bound[(size_t)dst] += b;
+        rel_bound[(size_t)e] += b;
+        total += b;
+        if (total > (24ll << 20)) fast = false;  // bounds too loose to pre-size everything
+      }
+      fb.swap(nf);
+    }
+  }
+
+  // ---- seeds ----
+  int64_t batch0 = 0;
+  for (int s = 0; s < num_seed_sets; ++s) {
+    const pyg_hip_seed_set& ss = seeds[s];
+    PYG_HIP_REQUIRE(ss.node_type >= 0 && ss.node_type < num_node_types, "sampler: bad seed type");
+    NodeSet& n = ns[(size_t)ss.node_type];
+    PYG_HIP_REQUIRE(n.nodes.size == 0, "sampler: node type seeded twice");
+    const int64_t S = ss.num_seed;
+    n.slice_b = 0;
+    n.slice_e = S;
+    if (S == 0) continue;
+    // fully queued mode: the list and the table are created at their final (bound) size right away
+    const int64_t nb = fast ? node_bound[(size_t)ss.node_type] : 0;
+    int rc = n.nodes.reserve(c, S, S + nb);
+    if (rc != PYG_HIP_OK) return rc;
+    if (disjoint) {
+      rc = n.batch.reserve(c, S, S + nb);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    rc = table_reserve(c, n, S, S + nb);
+    if (rc != PYG_HIP_OK) return rc;
+    u64* slots;
+    PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
+    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
+                       disjoint ? n.batch.p : (int64_t*)nullptr, slots, tstate + ss.node_type);
+    PYG_HIP_CHECK(hipGetLastError());
+    if (temporal) {
+      const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
+      if (ss.seed_time || nt) {
+        hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                           ss.seed, ss.seed_time, nt, S, batch0, seed_times);
+        PYG_HIP_CHECK(hipGetLastError());
+      } else {
+        // the reference would index an empty seed_times vector here (undefined behaviour)
+        return fail(PYG_HIP_ERR_INVALID, "Seed time needs to be specified");
+      }
+    }
+    // ranks of first occurrences = local ids (duplicates keep their first id)
+    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
+    int64_t* tile_buf;
+    PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
+    FlagLoad fl{slots, n.table.vals};
+    AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    // the number of distinct seeds (Mapper::curr) goes straight into the device-resident type state: the
+    // host never needs it, so the seeds cost no synchronisation
+    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &tstate[ss.node_type].distinct, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    n.nodes.size = S;
+    if (disjoint) n.batch.size = S;
+    c.release(slots);
+    c.release(tile_buf);
+    batch0 += S;
+  }
+  // The word generation is queued behind the seed kernels (which do not need it; its launches would
+  // otherwise sit in front of them on the host).
+  auto start_rng = [&]() -> int {
   if (c.host->mt19937) {
     // upper bounds of the words each hop can consume: every frontier node draws `count` 16-bit numbers
     std::vector<int64_t> spec;
@@ -1383,83 +1547,11 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (rc != PYG_HIP_OK) return rc;
   }
 
-  // temporal sampling: one seed time per disjoint subgraph (batch id)
-  bool temporal = false;
-  for (int t = 0; t < num_node_types && node_time; ++t) temporal = temporal || node_time[t] != nullptr;
-  for (int e = 0; e < num_relations; ++e) temporal = temporal || rels[e].edge_time != nullptr;
-  int64_t* seed_times = nullptr;
-  int* err_flag = nullptr;
-  if (temporal) {
-    PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
-    PYG_ALLOC(seed_times, int64_t*, c, sizeof(int64_t) * (size_t)num_batches);
-    // kernels raise the flag straight in pinned host memory: no copy, no extra synchronisation
-    err_flag = reinterpret_cast<int*>(static_cast<char*>(pinned) + 256);
-    *err_flag = 0;
-  }
-
-  // device-resident engine position and node-list sizes (see the hop loop)
-  ChainState* chain;
-  TypeState* tstate;
-  PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
-  PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
-  hipLaunchKernelGGL(set_chain_kernel, dim3(1), dim3(1), 0, stream, chain, rng.word, rng.units);
-  hipLaunchKernelGGL(init_types_kernel, dim3((unsigned)((num_node_types + 63) / 64)), dim3(64), 0, stream, tstate,
-                     num_node_types);
-  PYG_HIP_CHECK(hipGetLastError());
-
-  // ---- seeds ----
-  int64_t batch0 = 0;
-  for (int s = 0; s < num_seed_sets; ++s) {
-    const pyg_hip_seed_set& ss = seeds[s];
-    PYG_HIP_REQUIRE(ss.node_type >= 0 && ss.node_type < num_node_types, "sampler: bad seed type");
-    NodeSet& n = ns[(size_t)ss.node_type];
-    PYG_HIP_REQUIRE(n.nodes.size == 0, "sampler: node type seeded twice");
-    const int64_t S = ss.num_seed;
-    n.slice_b = 0;
-    n.slice_e = S;
-    if (S == 0) continue;
-    int rc = n.nodes.reserve(c, S);
+    return PYG_HIP_OK;
+  };
+  {
+    int rc = start_rng();
     if (rc != PYG_HIP_OK) return rc;
-    if (disjoint) {
-      rc = n.batch.reserve(c, S);
-      if (rc != PYG_HIP_OK) return rc;
-    }
-    rc = table_reserve(c, n, S);
-    if (rc != PYG_HIP_OK) return rc;
-    u64* slots;
-    PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
-    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
-                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
-                       disjoint ? n.batch.p : (int64_t*)nullptr, slots);
-    PYG_HIP_CHECK(hipGetLastError());
-    if (temporal) {
-      const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
-      if (ss.seed_time || nt) {
-        hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
-                           ss.seed, ss.seed_time, nt, S, batch0, seed_times);
-        PYG_HIP_CHECK(hipGetLastError());
-      } else {
-        // the reference would index an empty seed_times vector here (undefined behaviour)
-        return fail(PYG_HIP_ERR_INVALID, "Seed time needs to be specified");
-      }
-    }
-    // ranks of first occurrences = local ids (duplicates keep their first id)
-    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
-    int64_t* tile_buf;
-    PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
-    FlagLoad fl{slots, n.table.vals};
-    AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    // the number of distinct seeds (Mapper::curr) goes straight into the device-resident type state: the
-    // host never needs it, so the seeds cost no synchronisation
-    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &tstate[ss.node_type].distinct, stream);
-    if (rc != PYG_HIP_OK) return rc;
-    hipLaunchKernelGGL(set_type_size_kernel, dim3(1), dim3(1), 0, stream, tstate + ss.node_type, S);
-    PYG_HIP_CHECK(hipGetLastError());
-    n.nodes.size = S;
-    if (disjoint) n.batch.size = S;
-    c.release(slots);
-    c.release(tile_buf);
-    batch0 += S;
   }
   for (int t = 0; t < num_node_types; ++t) nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size);
   pt.lap(0);
@@ -1471,7 +1563,187 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   // A relation is "committed" when the host has folded its totals into its own bookkeeping.
   volatile HopInfo* info_host = reinterpret_cast<volatile HopInfo*>(static_cast<char*>(pinned) + 1024);
   HopInfo* info_dev;
-  PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo) * (size_t)std::max(num_relations, 1));
+  PYG_ALLOC(info_dev, HopInfo*, c, sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 1));
+
+  // ---- fully queued mode -------------------------------------------------------------------------------
+  // With bounded fan-outs everything is sized from the upper bounds computed above, the frontier of every
+  // hop is read from device memory, and ALL hops are queued without a single intermediate
+  // synchronisation; the host reads every (hop, relation) total at the end.  Scratch comes from ONE
+  // allocation (the host is the bottleneck of this mode: ~40 allocator calls and ~45 launches otherwise).
+  // A relation that lacks random words (draws wider than 16 bits) aborts the rest of the queue untouched
+  // and the call is repeated in the synchronising mode below (kNeedSlow).
+  bool done_fast = false;
+  if (fast) {
+    struct Queued {
+      int ell, e;
+    };
+    std::vector<Queued> queued;
+    size_t arena_bytes = align_up(sizeof(int64_t) * (size_t)(L + 1) * (size_t)num_relations, 256);
+    auto tiles = [](int64_t n) { return (n + kScanTile - 1) / kScanTile + 1; };
+    for (int ell = 0; ell < L; ++ell)
+      for (int e = 0; e < num_relations; ++e) {
+        const int64_t Eb = eb[(size_t)ell][(size_t)e];
+        if (Eb == 0) continue;
+        const int src = !csc ? rels[e].src_type : rels[e].dst_type;
+        const int64_t Fb = fbh[(size_t)ell][(size_t)src];
+        arena_bytes += align_up(sizeof(CountAgg) * (size_t)tiles(Fb), 256) + 2 * align_up(8 * (size_t)Fb, 256) +
+                       align_up(4 * (size_t)Fb, 256) + (disjoint ? 3 : 2) * align_up(8 * (size_t)Eb, 256) +
+                       align_up(8 * (size_t)tiles(Eb), 256);
+      }
+    char* arena;
+    PYG_ALLOC(arena, char*, c, arena_bytes);
+    auto carve = [&](size_t bytes) {
+      char* p = arena;
+      arena += align_up(bytes, 256);
+      return p;
+    };
+    int64_t* rel_sizes = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (size_t)(L + 1) * (size_t)num_relations));
+    PYG_HIP_CHECK(hipMemsetAsync(rel_sizes, 0, sizeof(int64_t) * (size_t)num_relations, stream));
+    for (int t = 0; t < num_node_types; ++t) {
+      NodeSet& n = ns[(size_t)t];
+      if (node_bound[(size_t)t] == 0) continue;
+      n.nodes.live = n.nodes.size;
+      int rc = n.nodes.reserve(c, n.nodes.size + node_bound[(size_t)t]);
+      if (rc != PYG_HIP_OK) return rc;
+      if (disjoint) {
+        n.batch.live = n.batch.size;
+        rc = n.batch.reserve(c, n.batch.size + node_bound[(size_t)t]);
+        if (rc != PYG_HIP_OK) return rc;
+      }
+      rc = table_reserve(c, n, node_bound[(size_t)t]);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    for (int e = 0; e < num_relations; ++e) {
+      RelState& st = rs[(size_t)e];
+      if (rel_bound[(size_t)e] == 0) continue;
+      int rc = st.row.reserve(c, rel_bound[(size_t)e]);
+      if (rc == PYG_HIP_OK) rc = st.col.reserve(c, rel_bound[(size_t)e]);
+      if (rc == PYG_HIP_OK) rc = st.eid.reserve(c, rel_bound[(size_t)e]);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    int64_t avail_blocks = 0;
+    int64_t spec_word = rng.word;
+    for (int ell = 0; ell < L; ++ell) {
+      hipLaunchKernelGGL(hop_boundary_kernel, dim3((unsigned)((std::max(num_node_types, num_relations) + 63) / 64)),
+                         dim3(64), 0, stream, tstate, num_node_types, ell > 0 ? 1 : 0, rel_sizes, num_relations, ell);
+      PYG_HIP_CHECK(hipGetLastError());
+      for (int e = 0; e < num_relations; ++e) {
+        const int64_t Eb = eb[(size_t)ell][(size_t)e];
+        if (Eb == 0) continue;
+        const pyg_hip_relation& r = rels[e];
+        const int src = !csc ? r.src_type : r.dst_type;
+        const int dst = !csc ? r.dst_type : r.src_type;
+        NodeSet& sn = ns[(size_t)src];
+        NodeSet& dn = ns[(size_t)dst];
+        RelState& st = rs[(size_t)e];
+        const int64_t count = r.num_neighbors_host[ell];
+        const int64_t Fb = fbh[(size_t)ell][(size_t)src];
+        const int slot = ell * num_relations + e;
+        CountAgg* tile_buf = reinterpret_cast<CountAgg*>(carve(sizeof(CountAgg) * (size_t)tiles(Fb)));
+        int64_t* edge_off = reinterpret_cast<int64_t*>(carve(8 * (size_t)Fb));
+        int64_t* rng_word = reinterpret_cast<int64_t*>(carve(8 * (size_t)Fb));
+        int32_t* rng_units = reinterpret_cast<int32_t*>(carve(4 * (size_t)Fb));
+        int64_t* e_node = reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb));
+        int64_t* e_batch = disjoint ? reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb)) : nullptr;
+        u64* e_slot = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
+        int64_t* ftile = reinterpret_cast<int64_t*>(carve(8 * (size_t)tiles(Eb)));
+        RangeCtx range;
+        range.rowptr = r.rowptr;
+        range.col = r.col;
+        range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
+        range.edge_level = r.edge_time ? 1 : 0;
+        range.last = temporal_last;
+        range.seed_times = seed_times;
+        range.batch = disjoint ? sn.batch.p : nullptr;
+        range.error = err_flag;
+        CountLoad cl{sn.nodes.p, 0, range, count, replace, tstate + src};
+        CountStore cs{edge_off, rng_word, rng_units, 0, 4, chain};
+        int rc = device_scan<CountAgg, CountOp>(cl, cs, Fb, tile_buf, &info_dev[slot].tot, stream);
+        if (rc != PYG_HIP_OK) return rc;
+        // order the words this relation may read (16-bit draws, cumulative bound) before its sample kernel:
+        // the first hops only wait for the first segment of the round, not for all of it
+        spec_word += (Eb + 3) / 4 + 1;
+        rc = rng_wait(c, rng, spec_word, &avail_blocks);
+        if (rc != PYG_HIP_OK) return rc;
+        HopArgs a;
+        a.info = info_dev + slot;
+        a.chain = chain;
+        a.fs = tstate + src;
+        a.rel_size = rel_sizes + (int64_t)ell * num_relations + e;
+        a.avail_blocks = avail_blocks;
+        a.nodes = sn.nodes.p;
+        a.batch = disjoint ? sn.batch.p : nullptr;
+        a.begin = 0;
+        a.frontier = Fb;
+        a.range = range;
+        a.col = r.col;
+        a.count = count;
+        a.replace = replace;
+        a.num_batches = num_batches;
+        a.edge_off = edge_off;
+        a.rng_word = rng_word;
+        a.rng_units = rng_units;
+        a.words = rng.dev;
+        a.e_row = st.row.p;
+        a.e_node = e_node;
+        a.e_batch = e_batch;
+        a.e_eid = st.eid.p;
+        a.e_slot = e_slot;
+        a.table = dn.table;
+        launch_sample(a, Fb, stream);
+        PYG_HIP_CHECK(hipGetLastError());
+        FlagLoad fl{e_slot, dn.table.vals, info_dev + slot};
+        AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
+                       disjoint ? dn.batch.p : (int64_t*)nullptr, 0, 0, 1, tstate + dst};
+        rc = device_scan<int64_t, SumOp>(fl, as, Eb, ftile, &info_dev[slot].uniq, stream);
+        if (rc != PYG_HIP_OK) return rc;
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Eb + 255) / 256)), dim3(256), 0, stream, e_slot,
+                           dn.table.vals, Eb, st.col.p, info_dev + slot, const_cast<HopInfo*>(info_host) + slot, chain,
+                           tstate + dst, (const int64_t*)a.rel_size, rel_sizes + (int64_t)(ell + 1) * num_relations + e);
+        PYG_HIP_CHECK(hipGetLastError());
+        queued.push_back({ell, e});
+      }
+    }
+    pt.lap(4);
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    pt.lap(5);
+    if (temporal)
+      PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0, "Found invalid non-sorted temporal neighborhood");
+    for (const Queued& q : queued)
+      if (info_host[q.ell * num_relations + q.e].overflow) return kNeedSlow;
+    // fold the totals into the host's bookkeeping, hop by hop
+    size_t qi = 0;
+    for (int ell = 0; ell < L; ++ell) {
+      for (int e = 0; e < num_relations; ++e) rs[(size_t)e].edges_per_hop.push_back(0);
+      std::vector<int64_t> before((size_t)num_node_types);
+      for (int t = 0; t < num_node_types; ++t) before[(size_t)t] = ns[(size_t)t].nodes.size;
+      for (; qi < queued.size() && queued[qi].ell == ell; ++qi) {
+        const int e = queued[qi].e;
+        volatile HopInfo* hi = info_host + (ell * num_relations + e);
+        const pyg_hip_relation& r = rels[e];
+        NodeSet& dn = ns[(size_t)(!csc ? r.dst_type : r.src_type)];
+        RelState& st = rs[(size_t)e];
+        const int64_t E = hi->tot.edges, U = hi->uniq;
+        if (E > 0) {
+          const RngTab tab = hi->tot.tab;
+          const int64_t end_word = rng.word + tab_dw(tab, rng.units);
+          rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
+          rng.word = end_word;
+          rng.units = tab_nb(tab, rng.units);
+        }
+        dn.nodes.size += U;
+        if (disjoint) dn.batch.size += U;
+        st.row.size += E;
+        st.col.size += E;
+        st.eid.size += E;
+        st.edges_per_hop.back() = E;
+      }
+      for (int t = 0; t < num_node_types; ++t)
+        nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size - before[(size_t)t]);
+    }
+    done_fast = true;
+  }
+  if (!done_fast) {
 
   struct Pending {
     int e = 0;
@@ -1541,7 +1813,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     // local ids of every emitted edge; publishes the totals and advances the device state
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((q.Eb + 255) / 256)), dim3(256), 0, stream, q.e_slot,
                        dn.table.vals, q.Eb, st.col.p + st.col.size, info_dev + q.e,
-                       const_cast<HopInfo*>(info_host) + q.e, chain, tstate + dst);
+                       const_cast<HopInfo*>(info_host) + q.e, chain, tstate + dst, (const int64_t*)nullptr,
+                       (int64_t*)nullptr);
     PYG_HIP_CHECK(hipGetLastError());
     return PYG_HIP_OK;
   };
@@ -1760,6 +2033,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       nodes_per_hop[(size_t)t].push_back(n.slice_e - n.slice_b);
     }
   }
+
+  }  // synchronising mode
 
   // ---- hand the results over ----
   for (int t = 0; t < num_node_types; ++t) {
@@ -1996,8 +2271,18 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   Ctx c;
   c.host = host;
   c.stream = static_cast<hipStream_t>(stream_);
+  const bool allow_fast = getenv("PYG_HIP_SAMPLER_SYNC_MODE") == nullptr;  // experiment / test knob
   int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time,
-                       temporal_last, L, csc, replace, disjoint, return_edge_id, c, result);
+                       temporal_last, L, csc, replace, disjoint, return_edge_id, c, result, allow_fast);
+  if (rc == kNeedSlow) {
+    // a hub row made its draws wider than the speculation assumed: nothing was handed out and the
+    // caller's engine is untouched -- start over in the synchronising mode
+    c.quiesce_side();
+    (void)hipStreamSynchronize(c.stream);
+    c.release_all();
+    rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time, temporal_last, L,
+                     csc, replace, disjoint, return_edge_id, c, result, false);
+  }
   c.quiesce_side();
   if (rc != PYG_HIP_OK) {
     (void)hipStreamSynchronize(c.stream);
