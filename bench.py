@@ -60,7 +60,7 @@ def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
     return x, lptr, w, (N, B, F)
 
 
-def cpu_baseline_segment_matmul(sample_rows=120_000):
+def cpu_baseline_segment_matmul(sample_rows=480_000):
     """Oracle (kind "port") on a bounded sample of the same workload: the first relations of C2
     truncated to `sample_rows` rows, bf16, F=128."""
     import oracle
@@ -75,7 +75,7 @@ def cpu_baseline_segment_matmul(sample_rows=120_000):
     best = None
     t_all = time.perf_counter()
     reps = 0
-    while reps < 3 and time.perf_counter() - t_all < 25.0:
+    while reps < 30 and time.perf_counter() - t_all < 12.0:
         t0 = time.perf_counter()
         oracle.segment_matmul(x, ptr, w, dtype=oracle.BF16)
         dt = time.perf_counter() - t0
