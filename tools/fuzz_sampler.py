@@ -9,93 +9,99 @@ import oracle
 from pyg_lib_amd import sampler
 I64_MIN, I64_MAX = -2 ** 63, 2 ** 63 - 1
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=200, seed=0):
+    rng = np.random.default_rng(seed)
 
 
-def csr(rows, cols, mean):
-    deg = rng.poisson(mean, rows).astype(np.int64)
-    deg[rng.random(rows) < 0.15] = 0
-    if rng.random() < 0.2 and rows > 3:
-        deg[rng.integers(0, rows)] = min(cols * 3, 400)  # a hub
-    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
-    return rp, rng.integers(0, max(cols, 1), int(rp[-1]), dtype=np.int64)
+    def csr(rows, cols, mean):
+        deg = rng.poisson(mean, rows).astype(np.int64)
+        deg[rng.random(rows) < 0.15] = 0
+        if rng.random() < 0.2 and rows > 3:
+            deg[rng.integers(0, rows)] = min(cols * 3, 400)  # a hub
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        return rp, rng.integers(0, max(cols, 1), int(rp[-1]), dtype=np.int64)
 
 
-def fanout(L):
-    return [int(rng.choice([-1, 0, 1, 2, 3, 5, 8, 17, 40, 70], p=[.06, .06, .12, .14, .14, .16, .12, .1, .06, .04]))
-            for _ in range(L)]
+    def fanout(L):
+        return [int(rng.choice([-1, 0, 1, 2, 3, 5, 8, 17, 40, 70], p=[.06, .06, .12, .14, .14, .16, .12, .1, .06, .04]))
+                for _ in range(L)]
 
 
-t0 = time.time()
-nh = nt = 0
-for it in range(cases):
-    seed = int(rng.integers(0, 2 ** 31))
-    replace, disjoint = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-    L = int(rng.integers(1, 4))
-    if rng.random() < 0.55:  # homogeneous, possibly temporal
-        n = int(rng.integers(1, 2500))
-        rp, cl = csr(n, n, float(rng.choice([1.5, 6, 20])))
-        seeds = rng.integers(0, n, int(rng.integers(0, 60)))
-        kw = dict(replace=replace, disjoint=disjoint)
-        if rng.random() < 0.35 and seeds.size:
-            kw['disjoint'] = True
-            kw['temporal_strategy'] = str(rng.choice(['uniform', 'last']))
-            if rng.random() < 0.5:
-                nt_ = rng.integers(0, 50, n, dtype=np.int64)
-                for v in range(n):
-                    a, b = rp[v], rp[v + 1]
-                    cl[a:b] = cl[a:b][np.argsort(nt_[cl[a:b]], kind='stable')]
-                kw['node_time'] = nt_
+    t0 = time.time()
+    nh = nt = 0
+    for it in range(cases):
+        seed = int(rng.integers(0, 2 ** 31))
+        replace, disjoint = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        L = int(rng.integers(1, 4))
+        if rng.random() < 0.55:  # homogeneous, possibly temporal
+            n = int(rng.integers(1, 2500))
+            rp, cl = csr(n, n, float(rng.choice([1.5, 6, 20])))
+            seeds = rng.integers(0, n, int(rng.integers(0, 60)))
+            kw = dict(replace=replace, disjoint=disjoint)
+            if rng.random() < 0.35 and seeds.size:
+                kw['disjoint'] = True
+                kw['temporal_strategy'] = str(rng.choice(['uniform', 'last']))
                 if rng.random() < 0.5:
+                    nt_ = rng.integers(0, 50, n, dtype=np.int64)
+                    for v in range(n):
+                        a, b = rp[v], rp[v + 1]
+                        cl[a:b] = cl[a:b][np.argsort(nt_[cl[a:b]], kind='stable')]
+                    kw['node_time'] = nt_
+                    if rng.random() < 0.5:
+                        kw['seed_time'] = rng.integers(0, 60, seeds.size, dtype=np.int64)
+                else:
+                    et = rng.integers(0, 50, cl.size, dtype=np.int64)
+                    for v in range(n):
+                        et[rp[v]:rp[v + 1]] = np.sort(et[rp[v]:rp[v + 1]])
+                    kw['edge_time'] = et
                     kw['seed_time'] = rng.integers(0, 60, seeds.size, dtype=np.int64)
-            else:
-                et = rng.integers(0, 50, cl.size, dtype=np.int64)
-                for v in range(n):
-                    et[rp[v]:rp[v + 1]] = np.sort(et[rp[v]:rp[v + 1]])
-                kw['edge_time'] = et
-                kw['seed_time'] = rng.integers(0, 60, seeds.size, dtype=np.int64)
-            nt += 1
-        fan = fanout(L)
-        torch.manual_seed(seed)
-        dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
-        out = sampler.neighbor_sample(dev(rp), dev(cl), dev(seeds.astype(np.int64)), fan, **dkw)
-        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
-        ref = oracle.neighbor_sample(rp, cl, seeds.astype(np.int64), fan, rng_seed=seed, **kw)
-        ok = all(torch.equal(out[i].cpu(), torch.from_numpy(ref[i])) for i in range(4)) and out[4] == ref[4] and out[5] == ref[5]
-        info = ref[6]
-    else:
-        T = int(rng.integers(2, 5))
-        types = [f't{i}' for i in range(T)]
-        sizes = {t: int(rng.integers(1, 1500)) for t in types}
-        R = int(rng.integers(1, 8))
-        ets = []
-        for r in range(R):
-            ets.append((types[int(rng.integers(0, T))], f'r{r}', types[int(rng.integers(0, T))]))
-        rp, cl = {}, {}
-        for (s_, r_, d_) in ets:
-            rp[(s_, r_, d_)], cl[(s_, r_, d_)] = csr(sizes[s_], sizes[d_], float(rng.choice([2, 7])))
-        seed_types = [t for t in types if rng.random() < 0.6] or [types[0]]
-        seeds = {t: rng.integers(0, sizes[t], int(rng.integers(1, 40))).astype(np.int64) for t in seed_types}
-        fan = {e: fanout(L) for e in ets}
-        torch.manual_seed(seed)
-        out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
-                                             {k: dev(v) for k, v in seeds.items()}, fan, replace=replace, disjoint=disjoint)
-        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
-        ref = oracle.hetero_neighbor_sample(types, ets, rp, cl, seeds, fan, replace=replace, disjoint=disjoint, rng_seed=seed)
-        ok = True
-        for e in ets:
-            ok = ok and torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e])) and torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
-            ok = ok and torch.equal(out[3][e].cpu(), torch.from_numpy(ref[3][e])) and out[5][e] == ref[5][e]
-        for t in types:
-            if t in out[2]:
-                ok = ok and torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t])) and out[4][t] == ref[4][t]
-            else:  # the wrapper only knows node types named by an edge type or a seed set
-                ok = ok and ref[2][t].size == 0
-        info = ref[6]
-        nh += 1
-    ok = ok and after == int(oracle.mt19937_words(seed, info['rng_blocks'] * 128 + 1)[-1])
-    if not ok:
-        print('MISMATCH at case', it, 'seed', seed, 'replace', replace, 'disjoint', disjoint, 'L', L)
-        sys.exit(1)
-print(f'{cases} cases ({nh} hetero, {nt} temporal) match the oracle bit for bit in {time.time() - t0:.1f}s')
+                nt += 1
+            fan = fanout(L)
+            torch.manual_seed(seed)
+            dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+            out = sampler.neighbor_sample(dev(rp), dev(cl), dev(seeds.astype(np.int64)), fan, **dkw)
+            after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+            ref = oracle.neighbor_sample(rp, cl, seeds.astype(np.int64), fan, rng_seed=seed, **kw)
+            ok = all(torch.equal(out[i].cpu(), torch.from_numpy(ref[i])) for i in range(4)) and out[4] == ref[4] and out[5] == ref[5]
+            info = ref[6]
+        else:
+            T = int(rng.integers(2, 5))
+            types = [f't{i}' for i in range(T)]
+            sizes = {t: int(rng.integers(1, 1500)) for t in types}
+            R = int(rng.integers(1, 8))
+            ets = []
+            for r in range(R):
+                ets.append((types[int(rng.integers(0, T))], f'r{r}', types[int(rng.integers(0, T))]))
+            rp, cl = {}, {}
+            for (s_, r_, d_) in ets:
+                rp[(s_, r_, d_)], cl[(s_, r_, d_)] = csr(sizes[s_], sizes[d_], float(rng.choice([2, 7])))
+            seed_types = [t for t in types if rng.random() < 0.6] or [types[0]]
+            seeds = {t: rng.integers(0, sizes[t], int(rng.integers(1, 40))).astype(np.int64) for t in seed_types}
+            fan = {e: fanout(L) for e in ets}
+            torch.manual_seed(seed)
+            out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                                 {k: dev(v) for k, v in seeds.items()}, fan, replace=replace, disjoint=disjoint)
+            after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+            ref = oracle.hetero_neighbor_sample(types, ets, rp, cl, seeds, fan, replace=replace, disjoint=disjoint, rng_seed=seed)
+            ok = True
+            for e in ets:
+                ok = ok and torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e])) and torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
+                ok = ok and torch.equal(out[3][e].cpu(), torch.from_numpy(ref[3][e])) and out[5][e] == ref[5][e]
+            for t in types:
+                if t in out[2]:
+                    ok = ok and torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t])) and out[4][t] == ref[4][t]
+                else:  # the wrapper only knows node types named by an edge type or a seed set
+                    ok = ok and ref[2][t].size == 0
+            info = ref[6]
+            nh += 1
+        ok = ok and after == int(oracle.mt19937_words(seed, info['rng_blocks'] * 128 + 1)[-1])
+        if not ok:
+            print('MISMATCH at case', it, 'seed', seed, 'replace', replace, 'disjoint', disjoint, 'L', L)
+            return False
+    print(f'{cases} cases ({nh} hetero, {nt} temporal) match the oracle bit for bit in {time.time() - t0:.1f}s')
+    return True
+
+
+if __name__ == '__main__':
+    ok = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    sys.exit(0 if ok else 1)
