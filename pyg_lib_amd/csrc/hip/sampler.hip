@@ -145,7 +145,7 @@ struct CountOp {
 
 // ---- hash table ------------------------------------------------------------------------------------
 struct HashTable {
-  u64* keys;
+  u64* keys;  // slot s: keys[2 s], vals[2 s] with vals == keys + 1 (interleaved pairs)
   u64* vals;
   u64 mask;  // capacity - 1
 };
@@ -159,18 +159,20 @@ __device__ __forceinline__ u64 hash64(u64 x) {
   return x;
 }
 
-// Find-or-claim the slot of `key`; returns the slot index.
+// Find-or-claim the slot of `key`.  Key and value of a slot are interleaved (16 bytes: one memory sector
+// per probe + value update instead of two); the returned handle is 2 * slot, to be used as
+// t.keys[handle] / t.vals[handle] (vals = keys + 1).
 __device__ __forceinline__ u64 table_slot(const HashTable& t, u64 key) {
   u64 s = hash64(key) & t.mask;
   while (true) {
-    u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) return s;
+    u64 k = __hip_atomic_load(&t.keys[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return 2 * s;
     if (k == kEmpty) {
       u64 expected = kEmpty;
-      if (__hip_atomic_compare_exchange_strong(&t.keys[s], &expected, key, __ATOMIC_RELAXED,
+      if (__hip_atomic_compare_exchange_strong(&t.keys[2 * s], &expected, key, __ATOMIC_RELAXED,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        return s;
-      if (expected == key) return s;
+        return 2 * s;
+      if (expected == key) return 2 * s;
     }
     s = (s + 1) & t.mask;
   }
@@ -184,10 +186,10 @@ __device__ __forceinline__ u64 make_key(int64_t node, int64_t batch, int64_t num
 __global__ void rehash_kernel(HashTable oldt, HashTable newt) {
   const u64 n = oldt.mask + 1;
   for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-    const u64 k = oldt.keys[i];
+    const u64 k = oldt.keys[2 * i];
     if (k == kEmpty) continue;
     const u64 s = table_slot(newt, k);
-    newt.vals[s] = oldt.vals[i];
+    newt.vals[s] = oldt.vals[2 * i];
   }
 }
 
@@ -1068,7 +1070,7 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   while (ncap < 2 * (u64)need || ncap < 2 * (u64)want) ncap <<= 1;  // load factor <= 0.5
   HashTable nt;
   PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * 2 * ncap);
-  nt.vals = nt.keys + ncap;
+  nt.vals = nt.keys + 1;  // interleaved slots: (key, value) pairs
   nt.mask = ncap - 1;
   PYG_HIP_CHECK(hipMemsetAsync(nt.keys, 0xFF, sizeof(u64) * 2 * ncap, c.stream));
   if (ns.table.keys) {
