@@ -209,7 +209,7 @@ __device__ __forceinline__ void store16(float*, char* dst, const float (&v)[16])
 template <typename T, int K, int MC, int NW>
 __global__ __launch_bounds__(NW * 64) void mfma_rows_kernel(const DevGroup* __restrict__ descs,
                                                             const int32_t* __restrict__ tile_start,
-                                                            int B) {
+                                                            int B, int ncol) {
   constexpr int SZ = Elem<T>::kSize;
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int NCH = (K / 2) / EPC;           // 16-byte chunks per lane (half row)
@@ -224,11 +224,14 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_kernel(const DevGroup* __re
   const int wave = tid >> 6;
   const int x = lane & 31;
   const int h = lane >> 5;
-  const int col0 = blockIdx.y * MC;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
 
   const int total = tile_start[B];
-  const int t0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
-  const int t1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+  const int G = (int)gridDim.x / ncol;
+  const int t0 = (int)((int64_t)bx * total / G);
+  const int t1 = (int)((int64_t)(bx + 1) * total / G);
   if (t0 >= t1) return;
 
   // group of the first tile: largest g with tile_start[g] <= t0
@@ -379,7 +382,7 @@ __device__ __forceinline__ u32x4 pack_chunk(float, const float* v) {
 
 template <typename T, int K, int MC, int NW, int FLAGS = 3>
 __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
-    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk) {
+    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk, int ncol) {
   constexpr bool NT_LOAD = (FLAGS & 1) != 0;
   constexpr bool NT_STORE = (FLAGS & 2) != 0;
   constexpr int SZ = Elem<T>::kSize;
@@ -403,24 +406,29 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   const int wave = tid >> 6;
   const int x = lane & 31;
   const int h = lane >> 5;
-  const int col0 = blockIdx.y * MC;
+  // XCD-aware workgroup decode (1-D grid of G * ncol workgroups): consecutive workgroup ids go to
+  // consecutive XCDs, so the `ncol` column-chunk workgroups of one tile range get ids 8 apart -- same
+  // XCD, same L2 -- and the X tiles they both read come from HBM once.
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
   char* stage = smem + WBYTES + wave * STAGE;
 
   // Tile schedule: workgroup b owns the tile chunks b, b + G, b + 2G, ... of `chunk` consecutive
   // tiles each (chunk <= 0: one contiguous range per workgroup).  Local tile i of this workgroup is
   // global tile tile_of(i).
   const int total = tile_start[B];
-  const int G = gridDim.x;
+  const int G = (int)gridDim.x / ncol;
   int nloc, cbase = 0;
   if (chunk <= 0) {
-    cbase = (int)((int64_t)blockIdx.x * total / G);
-    nloc = (int)((int64_t)(blockIdx.x + 1) * total / G) - cbase;
+    cbase = (int)((int64_t)bx * total / G);
+    nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
   } else {
     const int nchunks = (total + chunk - 1) / chunk;
-    const int mine = nchunks > (int)blockIdx.x ? (nchunks - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const int mine = nchunks > bx ? (nchunks - 1 - bx) / G + 1 : 0;
     nloc = mine * chunk;
     if (mine > 0) {
-      const int last_chunk = (mine - 1) * G + blockIdx.x;  // may be the ragged final chunk
+      const int last_chunk = (mine - 1) * G + bx;  // may be the ragged final chunk
       const int over = (last_chunk + 1) * chunk - total;
       if (over > 0) nloc -= over;
     }
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   auto tile_of = [&](int i) -> int {
     if (chunk <= 0) return cbase + i;
     const int j = i / chunk;
-    return (j * G + (int)blockIdx.x) * chunk + (i - j * chunk);
+    return (j * G + bx) * chunk + (i - j * chunk);
   };
   const int t0 = 0, t1 = nloc;  // local tile indices
 
@@ -784,7 +792,13 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   if (const char* e = getenv("PYG_HIP_MM_CHUNK")) chunk = atoi(e);
   if (const char* e = getenv("PYG_HIP_MM_WGS")) per_cu = std::max(1, atoi(e));
   int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
-  dim3 grid((unsigned)gx, (unsigned)(M / MC), 1);
+  const int ncol = M / MC;
+  if (ncol > 1) {
+    // the column-chunk workgroups of a tile range share the X tiles: 1-D grid, XCD-aware decode in the
+    // kernel (workgroup ids 8 apart = same XCD); keep the chip's resident workgroup count
+    gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus * per_cu / ncol) + 7) / 8 * 8);
+  }
+  dim3 grid((unsigned)(gx * ncol), 1, 1);
   {
     ProfScope prof(stream);
     if constexpr (use_v2) {
@@ -797,17 +811,17 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
           PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
           attr2 = true;
         }
-        if (flags == 0) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 0>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
-        else if (flags == 1) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 1>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
-        else if (flags == 2) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 2>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
-        else hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 3>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk);
+        if (flags == 0) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 0>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
+        else if (flags == 1) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 1>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
+        else if (flags == 2) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 2>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
+        else hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 3>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
       } else {
         hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
-                           w.descs, w.tile_start, B, chunk);
+                           w.descs, w.tile_start, B, chunk, ncol);
       }
     } else
       hipLaunchKernelGGL((mfma_rows_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
-                         w.descs, w.tile_start, B);
+                         w.descs, w.tile_start, B, ncol);
   }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;

@@ -114,12 +114,17 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* xs = smem + wave * 32 * (PX + PY);
   char* ys = xs + 32 * PX;
-  const int col0 = blockIdx.y * MC;
+  // XCD-aware decode of the 1-D grid: the M / MC column-chunk workgroups of one tile range get ids 8 apart
+  // (same XCD, same L2), so the X rows they all read come from HBM once
+  const int ncol = M / MC;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
 
   const int total = tile_start[B];
-  const int G = gridDim.x;
-  const int t_beg = (int)((int64_t)blockIdx.x * total / G);
-  const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
+  const int G = (int)gridDim.x / ncol;
+  const int t_beg = (int)((int64_t)bx * total / G);
+  const int t_end = (int)((int64_t)(bx + 1) * total / G);
   if (t_beg >= t_end) return;
   int g = 0;
   {
@@ -251,11 +256,14 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
   static_assert(IB * JB <= 16, "accumulators must fit the register file");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kk = lane >> 5;
-  const int col0 = blockIdx.y * MC;
+  const int ncol = M / MC;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
   const int total = tile_start[B];
-  const int G = gridDim.x;
-  const int t_beg = (int)((int64_t)blockIdx.x * total / G);
-  const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
+  const int G = (int)gridDim.x / ncol;
+  const int t_beg = (int)((int64_t)bx * total / G);
+  const int t_end = (int)((int64_t)(bx + 1) * total / G);
   if (t_beg >= t_end) return;
   int g = 0;
   {
@@ -347,8 +355,10 @@ int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64
     attr_set = true;
   }
   const int64_t cus = device_info().num_cus;
-  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus));
-  hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), lds, stream, groups,
+  const int64_t ncol = M / MC;
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
+  if (ncol > 1) gx = (gx + 7) / 8 * 8;  // the kernel's XCD-aware decode works on groups of 8 ids
+  hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3((unsigned)(gx * ncol)), dim3(256), lds, stream, groups,
                      tile_start, (int)B, (int)M, acc);
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
@@ -370,8 +380,10 @@ template <int K, int MC>
 int launch_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* acc,
                   hipStream_t stream) {
   const int64_t cus = device_info().num_cus;
-  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus));
-  hipLaunchKernelGGL((seg_dw_f32_kernel<K, MC>), dim3(gx, (unsigned)(M / MC)), dim3(256), 0, stream, groups, tile_start,
+  const int64_t ncol = M / MC;
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
+  if (ncol > 1) gx = (gx + 7) / 8 * 8;
+  hipLaunchKernelGGL((seg_dw_f32_kernel<K, MC>), dim3((unsigned)(gx * ncol)), dim3(256), 0, stream, groups, tile_start,
                      (int)B, (int)M, acc);
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
