@@ -254,6 +254,32 @@ PYG_HIP_API int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_
                                              int64_t** edge_id, int64_t* num_edges,
                                              int64_t* cumsum_host, void* stream);
 
+/*
+ * Distributed-sampling helpers (homogeneous forms).
+ *
+ * pyg_hip_relabel_neighborhood replaces pyg::relabel_neighborhood (schema sampler/dist_relabel.cpp:71-76; CPU
+ * sampler/cpu/dist_relabel_kernel.cpp:30-94): local ids in insertion order -- the seeds first (a duplicate
+ * seed keeps the id of its first occurrence; disjoint: key (i, seed[i])), then the externally sampled
+ * sequence `sampled` (disjoint: key (batch[j], sampled[j])).  col_out[j] = id of sampled[j]; row_out[j] = the
+ * source node i with count_prefix[i] <= j < count_prefix[i + 1] (count_prefix: device array of num_src + 1
+ * offsets, the running sum of num_sampled_neighbors_per_node).  The csc swap is the caller's.
+ * `workspace`: pyg_hip_relabel_workspace_size(num_seed, num_sampled) bytes.
+ *
+ * pyg_hip_segment_concat is the device part of pyg::merge_sampler_outputs (schema
+ * sampler/dist_merge_outputs.cpp:51-55; CPU sampler/cpu/dist_merge_outputs_kernel.cpp:17-138): out = the
+ * segments bases[part[j]][begin[j] ...) of length dst_off[j+1] - dst_off[j], concatenated in j order; with
+ * `fill`, out[i] = fill[j] for the positions of segment j instead (the batch vector).  All arrays are device
+ * arrays; `bases` is a device array of device pointers.
+ */
+PYG_HIP_API size_t pyg_hip_relabel_workspace_size(int64_t num_seed, int64_t num_sampled);
+PYG_HIP_API int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_seed, const int64_t* sampled,
+                                             int64_t num_sampled, const int64_t* count_prefix, int64_t num_src,
+                                             const int64_t* batch, int disjoint, int64_t* row_out, int64_t* col_out,
+                                             void* workspace, size_t workspace_bytes, void* stream);
+PYG_HIP_API int pyg_hip_segment_concat(const int64_t* const* bases, const int64_t* part, const int64_t* begin,
+                                       const int64_t* dst_off, int64_t n, const int64_t* fill, int64_t* out,
+                                       int64_t total, void* stream);
+
 /* ---- index_sort ---------------------------------------------------------------------------- */
 
 PYG_HIP_API size_t pyg_hip_index_sort_workspace_size(int dtype, int64_t n);

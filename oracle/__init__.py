@@ -559,3 +559,44 @@ def softmax_csr_backward(out, out_grad, ptr, dim=0):
     gin = np.empty_like(out)
     L.oracle_softmax_csr_backward(_ptr(out), _ptr(out_grad), _ptr(ptr), _ptr(gin), outer, D, inner, ptr.size - 1)
     return gin
+
+
+# ---- distributed-sampling helpers (dist_relabel / dist_merge_outputs, homogeneous forms) ----------------
+def relabel_neighborhood(seed, sampled_nodes_with_duplicates, num_sampled_neighbors_per_node, num_nodes=None,
+                         batch=None, csc=False, disjoint=False):
+    """pyg::relabel_neighborhood (pyg_lib/csrc/sampler/cpu/dist_relabel_kernel.cpp:30-94): Mapper ids in
+    insertion order -- seeds first (`fill`: id = position of the first occurrence among distinct seeds;
+    disjoint: key (i, seed[i])), then the sampled nodes in sequence; row = index of the source node."""
+    seed = np.asarray(seed, dtype=np.int64)
+    nodes = np.asarray(sampled_nodes_with_duplicates, dtype=np.int64)
+    ids = {}
+    for i, v in enumerate(seed.tolist()):
+        ids.setdefault((i, v) if disjoint else v, len(ids))
+    rows, cols = [], []
+    j = 0
+    for i, c in enumerate(num_sampled_neighbors_per_node):
+        for _ in range(int(c)):
+            key = (int(batch[j]), int(nodes[j])) if disjoint else int(nodes[j])
+            cols.append(ids.setdefault(key, len(ids)))
+            rows.append(i)
+            j += 1
+    row, col = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    return (col, row) if csc else (row, col)
+
+
+def merge_sampler_outputs(node_ids, edge_ids, cumsum_neighbors_per_node, partition_ids, partition_orders,
+                          num_partitions, num_neighbors, batch=None, disjoint=False):
+    """pyg::merge_sampler_outputs (pyg_lib/csrc/sampler/cpu/dist_merge_outputs_kernel.cpp:17-138): the
+    sampled neighbours of node j live in partition partition_ids[j] at order partition_orders[j]; outputs are
+    the per-node segments concatenated in j order."""
+    out_n, out_e, out_b, counts = [], [], [], []
+    for j, (p, o) in enumerate(zip(partition_ids, partition_orders)):
+        cs = cumsum_neighbors_per_node[p]
+        bn, en = cs[o], cs[o + 1]
+        out_n.append(np.asarray(node_ids[p], dtype=np.int64)[bn:en])
+        out_e.append(np.asarray(edge_ids[p], dtype=np.int64)[bn - cs[0]:en - cs[0]])
+        if disjoint:
+            out_b.append(np.full(en - bn, int(batch[j]), dtype=np.int64))
+        counts.append(en - bn)
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64)
+    return cat(out_n), cat(out_e), (cat(out_b) if disjoint else None), counts

@@ -2241,6 +2241,55 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   return PYG_HIP_OK;
 }
 
+// ---- distributed-sampling helpers ---------------------------------------------------------------------
+// relabel_neighborhood (sampler/cpu/dist_relabel_kernel.cpp:30-94): the Mapper's insertion-ordered ids for
+// seeds + an externally sampled node sequence -- the sampler's own first-occurrence machinery without
+// sampling.  `emit` of position j: hash insert with atomicMin(j).
+__global__ void relabel_insert_kernel(const int64_t* __restrict__ nodes, const int64_t* __restrict__ batch, int64_t n,
+                                      int64_t num_batches, HashTable t, u64* __restrict__ slots) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const u64 s = table_slot(t, make_key(nodes[j], batch ? batch[j] : 0, num_batches));
+  slots[j] = s;
+  __hip_atomic_fetch_min(&t.vals[s], kProvisional + (u64)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// row[j] = the source node whose neighbour list contains position j: prefix[i] <= j < prefix[i + 1]
+__global__ void expand_rows_kernel(const int64_t* __restrict__ prefix, int64_t n, int64_t total, int64_t* __restrict__ row) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= total) return;
+  int64_t lo = 0, hi = n;  // first i with prefix[i + 1] > j
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (prefix[mid + 1] > j) hi = mid; else lo = mid + 1;
+  }
+  row[j] = lo;
+}
+
+// merge_sampler_outputs (sampler/cpu/dist_merge_outputs_kernel.cpp:17-138): out = the segments
+// bases[part[j]][begin[j] .. begin[j] + len_j) concatenated in j order (dst_off = prefix of the lengths);
+// with `fill`, out[i] = fill[j] instead (the batch vector of disjoint sampling).
+__global__ void segment_concat_kernel(const int64_t* const* __restrict__ bases, const int64_t* __restrict__ part,
+                                      const int64_t* __restrict__ begin, const int64_t* __restrict__ dst_off, int64_t n,
+                                      const int64_t* __restrict__ fill, int64_t* __restrict__ out, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int64_t lo = 0, hi = n;  // first j with dst_off[j + 1] > i
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (dst_off[mid + 1] > i) hi = mid; else lo = mid + 1;
+  }
+  out[i] = fill ? fill[lo] : bases[part[lo]][begin[lo] + (i - dst_off[lo])];
+}
+
+inline size_t relabel_ws_bytes(int64_t S, int64_t E) {
+  u64 cap = 1024;
+  while (cap < 2 * (u64)(S + E)) cap <<= 1;
+  const int64_t tiles = (std::max(S, E) + kScanTile - 1) / kScanTile + 2;
+  return align_up(sizeof(u64) * 2 * cap, 256) + align_up(sizeof(u64) * (size_t)(3 * S + E + 1), 256) +
+         align_up(sizeof(int64_t) * (size_t)tiles, 256) + align_up(sizeof(TypeState), 256);
+}
+
 }  // namespace
 }  // namespace pyg_hip
 
@@ -2312,4 +2361,81 @@ extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t
   if (rc != PYG_HIP_OK) (void)hipStreamSynchronize(c.stream);
   c.release_all();
   return rc;
+}
+
+extern "C" size_t pyg_hip_relabel_workspace_size(int64_t num_seed, int64_t num_sampled) {
+  return relabel_ws_bytes(num_seed < 0 ? 0 : num_seed, num_sampled < 0 ? 0 : num_sampled);
+}
+
+extern "C" int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_seed, const int64_t* sampled,
+                                            int64_t num_sampled, const int64_t* count_prefix, int64_t num_src,
+                                            const int64_t* batch, int disjoint, int64_t* row_out, int64_t* col_out,
+                                            void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t S = num_seed, E = num_sampled;
+  PYG_HIP_REQUIRE(S >= 0 && E >= 0 && num_src >= 0, "relabel_neighborhood: negative size");
+  if (E == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE((S == 0 || seed) && sampled && count_prefix && row_out && col_out, "relabel_neighborhood: NULL argument");
+  PYG_HIP_REQUIRE(!disjoint || batch, "Batch needs to be specified to create disjoint subgraphs");
+  if (workspace == nullptr || workspace_bytes < relabel_ws_bytes(S, E))
+    return fail(PYG_HIP_ERR_WORKSPACE, "relabel_neighborhood: workspace of %zu bytes needed, got %zu", relabel_ws_bytes(S, E),
+                workspace_bytes);
+  const int64_t num_batches = disjoint ? std::max<int64_t>(S, 1) : 1;
+  PYG_HIP_REQUIRE(num_batches < (1ll << 22), "relabel_neighborhood: too many seeds for disjoint relabelling");
+  u64 cap = 1024;
+  while (cap < 2 * (u64)(S + E)) cap <<= 1;
+  char* w = static_cast<char*>(workspace);
+  HashTable t;
+  t.keys = reinterpret_cast<u64*>(w);
+  t.vals = t.keys + 1;
+  t.mask = cap - 1;
+  w += align_up(sizeof(u64) * 2 * cap, 256);
+  u64* seed_slots = reinterpret_cast<u64*>(w);                 // [S] slots of the seeds
+  int64_t* seed_copy = reinterpret_cast<int64_t*>(w) + S;       // [S] seed_insert_kernel also writes the node list
+  int64_t* seed_batch = reinterpret_cast<int64_t*>(w) + 2 * S;  // [S] ... and its batch list (disjoint)
+  u64* slots = reinterpret_cast<u64*>(w) + 3 * S;               // [E] slots of the sampled sequence
+  w += align_up(sizeof(u64) * (size_t)(3 * S + E + 1), 256);
+  int64_t* tile_buf = reinterpret_cast<int64_t*>(w);
+  w += align_up(sizeof(int64_t) * (size_t)((std::max(S, E) + kScanTile - 1) / kScanTile + 2), 256);
+  TypeState* ts = reinterpret_cast<TypeState*>(w);
+  PYG_HIP_CHECK(hipMemsetAsync(t.keys, 0xFF, sizeof(u64) * 2 * cap, stream));
+  PYG_HIP_CHECK(hipMemsetAsync(ts, 0, sizeof(TypeState), stream));
+  if (S > 0) {
+    // seeds: mapper.fill(seed) / insert({i, seed[i]}) -- ids of first occurrences in position order
+    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, seed, S, (int64_t)0,
+                       disjoint, num_batches, t, seed_copy, seed_batch, seed_slots, ts);
+    PYG_HIP_CHECK(hipGetLastError());
+    FlagLoad fl{seed_slots, t.vals};
+    AssignStore as{seed_slots, t.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    int rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &ts->distinct, stream);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  // the sampled sequence: ids continue from the number of distinct seeds (device-resident)
+  hipLaunchKernelGGL(relabel_insert_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, sampled,
+                     disjoint ? batch : (const int64_t*)nullptr, E, num_batches, t, slots);
+  PYG_HIP_CHECK(hipGetLastError());
+  FlagLoad fl{slots, t.vals};
+  AssignStore as{slots, t.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, ts};
+  int rc = device_scan<int64_t, SumOp>(fl, as, E, tile_buf, tile_buf + (E + kScanTile - 1) / kScanTile + 1, stream);
+  if (rc != PYG_HIP_OK) return rc;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, slots, t.vals, E, col_out,
+                     (const HopInfo*)nullptr, (HopInfo*)nullptr, (ChainState*)nullptr, (TypeState*)nullptr,
+                     (const int64_t*)nullptr, (int64_t*)nullptr);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, count_prefix, num_src, E,
+                     row_out);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+extern "C" int pyg_hip_segment_concat(const int64_t* const* bases, const int64_t* part, const int64_t* begin,
+                                      const int64_t* dst_off, int64_t n, const int64_t* fill, int64_t* out, int64_t total,
+                                      void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(n >= 0 && total >= 0, "segment_concat: negative size");
+  if (total == 0 || n == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(dst_off && out && (fill || (bases && part && begin)), "segment_concat: NULL argument");
+  hipLaunchKernelGGL(segment_concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, bases, part, begin,
+                     dst_off, n, fill, out, total);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
 }

@@ -91,3 +91,30 @@ DIST_CASES = [
                      temporal_strategy='uniform'),
          node=[[0, 2], [1, 3], [0, 1], [1, 2]], edge=[4, 6], cumsum=[2, 3, 4]),
 ]
+
+
+# test/csrc/sampler/test_dist_merge_outputs.cpp (:7-49, :51-93, :95-132): merge_sampler_outputs
+MERGE_CASES = [
+    dict(name='merge_basic', node_ids=[[2, 7, 8], [0, 1, 4, 5, 6], [3, 9, 10]], edge_ids=[[17, 18], [14, 15, 16], [19, 20]],
+         cumsum=[[1, 3], [2, 4, 5], [1, 3]], partition_ids=[1, 1, 0, 2], partition_orders=[0, 1, 0, 0], num_partitions=3,
+         num_neighbors=2, batch=None, disjoint=False,
+         nodes=[4, 5, 6, 7, 8, 9, 10], edges=[14, 15, 16, 17, 18, 19, 20], out_batch=None, counts=[2, 1, 2, 2]),
+    dict(name='merge_all_neighbors', node_ids=[[2, 7, 8], [0, 1, 4, 5, 6], [3, 9, 10, 11]],
+         edge_ids=[[17, 18], [14, 15, 16], [19, 20, 21]], cumsum=[[1, 3], [2, 4, 5], [1, 4]],
+         partition_ids=[1, 1, 0, 2], partition_orders=[0, 1, 0, 0], num_partitions=3, num_neighbors=-1, batch=None,
+         disjoint=False, nodes=[4, 5, 6, 7, 8, 9, 10, 11], edges=[14, 15, 16, 17, 18, 19, 20, 21], out_batch=None,
+         counts=[2, 1, 2, 3]),
+    dict(name='merge_disjoint', node_ids=[[2, 7, 8], [0, 1, 4, 5, 6], [3, 9, 10]], edge_ids=[[17, 18], [14, 15, 16], [19, 20]],
+         cumsum=[[1, 3], [2, 4, 5], [1, 3]], partition_ids=[1, 1, 0, 2], partition_orders=[0, 1, 0, 0], num_partitions=3,
+         num_neighbors=2, batch=[0, 1, 2, 3], disjoint=True,
+         nodes=[4, 5, 6, 7, 8, 9, 10], edges=[14, 15, 16, 17, 18, 19, 20], out_batch=[0, 0, 1, 2, 2, 3, 3],
+         counts=[2, 1, 2, 2]),
+]
+
+# test/csrc/sampler/test_dist_relabel.cpp (:9-37, :39-79): relabel_neighborhood
+RELABEL_CASES = [
+    dict(name='relabel_basic', seed=[2, 3], sampled=[1, 3, 2, 4], counts=[2, 2], num_nodes=6, batch=None, disjoint=False,
+         row=[0, 0, 1, 1], col=[2, 1, 0, 3]),
+    dict(name='relabel_disjoint', seed=[2, 3], sampled=[1, 3, 2, 4], counts=[2, 2], num_nodes=6, batch=[0, 0, 1, 1],
+         disjoint=True, row=[0, 0, 1, 1], col=[2, 3, 4, 5]),
+]

@@ -62,3 +62,19 @@ def test_dist_reference_golden_vectors(case):
     assert node.tolist() == case['node']
     assert edge.tolist() == case['edge']
     assert cumsum == case['cumsum']
+
+
+@pytest.mark.parametrize('case', G.MERGE_CASES, ids=[c['name'] for c in G.MERGE_CASES])
+def test_merge_sampler_outputs_golden(case):
+    n, e, b, cnt = oracle.merge_sampler_outputs(case['node_ids'], case['edge_ids'], case['cumsum'], case['partition_ids'],
+                                                case['partition_orders'], case['num_partitions'], case['num_neighbors'],
+                                                case['batch'], case['disjoint'])
+    assert n.tolist() == case['nodes'] and e.tolist() == case['edges'] and cnt == case['counts']
+    assert (b is None) == (case['out_batch'] is None) and (b is None or b.tolist() == case['out_batch'])
+
+
+@pytest.mark.parametrize('case', G.RELABEL_CASES, ids=[c['name'] for c in G.RELABEL_CASES])
+def test_relabel_neighborhood_golden(case):
+    row, col = oracle.relabel_neighborhood(case['seed'], case['sampled'], case['counts'], case['num_nodes'], case['batch'],
+                                           False, case['disjoint'])
+    assert row.tolist() == case['row'] and col.tolist() == case['col']
