@@ -572,8 +572,19 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         // keep the order "issue the next step's LDS reads, then this step's MFMAs": left alone, the
         // scheduler sinks every ds_read to just before its MFMA (lgkmcnt(0) x32 per tile)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SZ == 4) {
+          // fp32: a 16-byte chunk feeds four 32x32x2 MFMAs per column block; interleave the column blocks
+          // so that back-to-back MFMAs never wait on each other's accumulator
+          const f32x4 xf = __builtin_bit_cast(f32x4, xa);
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma_chunk(T{}, wa[tt], xa, acc[tt]);
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+              acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, wa[tt])[e], xf[e], acc[tt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma_chunk(T{}, wa[tt], xa, acc[tt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < NI) {
           xa = xb;
@@ -797,6 +808,26 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
     // the column-chunk workgroups of a tile range share the X tiles: 1-D grid, XCD-aware decode in the
     // kernel (workgroup ids 8 apart = same XCD); keep the chip's resident workgroup count
     gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus * per_cu / ncol) + 7) / 8 * 8);
+  }
+  if constexpr (SZ == 4 && use_v2) {
+    static const bool direct = getenv("PYG_HIP_MM_DIRECT") != nullptr;
+    if (direct) {
+      const void* dk = reinterpret_cast<const void*>(&mfma_rows_kernel<T, K, MC, NW>);
+      static thread_local bool dattr = false;
+      if (!dattr) {
+        PYG_HIP_CHECK(hipFuncSetAttribute(dk, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes));
+        dattr = true;
+      }
+      int pc = std::max(1, std::min(4, (160 * 1024) / wbytes));
+      if (const char* e = getenv("PYG_HIP_MM_WGS")) pc = std::max(1, atoi(e));
+      int64_t g2 = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * pc);
+      if (ncol > 1) g2 = std::max<int64_t>(8, (std::min<int64_t>(g2, (int64_t)di.num_cus * pc / ncol) + 7) / 8 * 8);
+      ProfScope prof(stream);
+      hipLaunchKernelGGL((mfma_rows_kernel<T, K, MC, NW>), dim3((unsigned)(g2 * ncol)), dim3(NW * 64), wbytes, stream,
+                         w.descs, w.tile_start, B, ncol);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
   }
   dim3 grid((unsigned)(gx * ncol), 1, 1);
   {
