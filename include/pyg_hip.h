@@ -180,6 +180,12 @@ typedef struct {
   int32_t dst_type;
   const int64_t* num_neighbors_host; /* L fan-outs, host */
   const int64_t* edge_time;          /* device, per edge, or NULL (edge-level temporal sampling) */
+  /* Biased sampling (neighbor_kernel.cpp:39-56,245-285; hetero :732-745): per-edge weights on the device, or
+   * NULL.  edge_weight_dtype is PYG_F32 or PYG_F64 (the dtype decides how many generator outputs a draw
+   * takes, see pyg_hip_hetero_neighbor_sample).  Needs host->mt19937 and replace == 0. */
+  const void* edge_weight;
+  int32_t edge_weight_dtype;
+  int32_t reserved;
 } pyg_hip_relation;
 
 /* Seeds of one node type, in seed_dict iteration order. */
@@ -222,7 +228,16 @@ typedef struct {
  * requires disjoint): node_time_by_type is a host array of num_node_types device pointers (entries
  * or the array itself may be NULL), relation.edge_time takes precedence; temporal_last selects the
  * "last" strategy.  A neighbourhood that is not time-sorted fails with the reference's message.
- * Biased sampling (edge_weight) is not available on the device path.
+ * Biased sampling (relation.edge_weight; _biased_sample, neighbor_kernel.cpp:245-285): a row with more
+ * neighbours than the fan-out draws one uniform number per neighbour STRAIGHT from the generator (one
+ * 32-bit output per float32 weight, 24 bits kept; two per float64 weight, 53 bits kept -- Tensor.uniform_),
+ * key = log(u) / weight, and takes the `count` largest keys in Tensor.topk order (ties as libstdc++'s
+ * partial_sort / nth_element + sort leave them, ATen/native/TopKImpl.h).  The device path reproduces that
+ * stream and that order; `log` is the correctly rounded logarithm where libtorch calls MKL's (<1 ulp, closed
+ * source: 15,372 of the 2^24 possible float32 arguments round differently), so a selection can differ from
+ * the reference's only if two keys of one row lie within one ulp of each other.  Needs host->mt19937,
+ * replace == 0, no temporal arguments, and every sampled relation weighted; anything else fails with
+ * PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
@@ -234,6 +249,12 @@ PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relat
                                                int disjoint, int return_edge_id,
                                                const pyg_hip_sampler_host* host,
                                                pyg_hip_sample_result* result, void* stream);
+
+/*
+ * The float32 logarithm biased sampling evaluates (key = log(u) / weight), element-wise over device arrays.
+ * Exposed so that it can be pinned on every argument Tensor.uniform_ can produce (k * 2^-24).
+ */
+PYG_HIP_API int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, void* stream);
 
 /*
  * One-hop sampling WITHOUT relabelling for PyG's distributed sampler.

@@ -22,7 +22,8 @@ F32, F64, F16, BF16 = 0, 1, 2, 3
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (a few seconds)."""
     so = osp.join(_HERE, 'liboracle.so')
-    srcs = [osp.join(_HERE, f) for f in sorted(os.listdir(_HERE)) if f.startswith('oracle_') and f.endswith('.c')]
+    srcs = [osp.join(_HERE, f) for f in sorted(os.listdir(_HERE))
+            if f.startswith('oracle_') and (f.endswith('.c') or f.endswith('.cpp'))]
     if force or not osp.exists(so) or any(osp.getmtime(s) > osp.getmtime(so) for s in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle.so'])
     return so
@@ -50,6 +51,10 @@ def _declare(L):
                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     L.oracle_mt19937_words.restype = None
     L.oracle_mt19937_words.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64]
+    L.oracle_mt19937_word_after.restype = ctypes.c_int64
+    L.oracle_mt19937_word_after.argtypes = [ctypes.c_uint64, ctypes.c_int64]
+    L.oracle_biased_log_f32.restype = None
+    L.oracle_biased_log_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     L.oracle_hetero_neighbor_sample.restype = ctypes.c_void_p
     L.oracle_hetero_neighbor_sample.argtypes = [
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,  # types, et_src, et_dst
@@ -59,12 +64,20 @@ def _declare(L):
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,  # node_time**, edge_time**, seed_time**
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,  # csc, replace, disjoint, last
         ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    L.oracle_hetero_neighbor_sample_w.restype = ctypes.c_void_p
+    L.oracle_hetero_neighbor_sample_w.argtypes = (
+        L.oracle_hetero_neighbor_sample.argtypes[:15] + [ctypes.c_void_p, ctypes.c_void_p] +  # weight**, is_f64*
+        L.oracle_hetero_neighbor_sample.argtypes[15:])
+    L.oracle_topk_desc_f32.restype = None
+    L.oracle_topk_desc_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.oracle_topk_desc_f64.restype = None
+    L.oracle_topk_desc_f64.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     L.oracle_sample_free.restype = None
     L.oracle_sample_free.argtypes = [ctypes.c_void_p]
     for name in ('oracle_sample_num_nodes', 'oracle_sample_num_edges'):
         getattr(L, name).restype = ctypes.c_int64
         getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_int]
-    for name in ('oracle_sample_rng_blocks', 'oracle_sample_rng_draws'):
+    for name in ('oracle_sample_rng_blocks', 'oracle_sample_rng_draws', 'oracle_sample_rng_raw_draws'):
         getattr(L, name).restype = ctypes.c_int64
         getattr(L, name).argtypes = [ctypes.c_void_p]
     L.oracle_sample_copy_nodes.restype = None
@@ -151,6 +164,28 @@ def mt19937_words(seed: int, n: int) -> np.ndarray:
 
 # ---- sampler -----------------------------------------------------------------------------------
 
+def mt19937_word_after(seed: int, skip32: int) -> int:
+    """torch.randint(INT64_MIN, INT64_MAX, (1,)) after manual_seed(seed) and `skip32` 32-bit outputs."""
+    return int(lib().oracle_mt19937_word_after(seed & 0xFFFFFFFFFFFFFFFF, int(skip32)))
+
+
+def biased_log_f32(u: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    out = np.empty_like(u)
+    lib().oracle_biased_log_f32(_ptr(u), _ptr(out), u.size)
+    return out
+
+
+def topk_desc(keys: np.ndarray, k: int) -> np.ndarray:
+    """Indices of Tensor.topk(k) (largest, sorted) of a 1-D float32 / float64 array, libtorch's tie order."""
+    keys = np.ascontiguousarray(keys)
+    idx = np.empty(k, dtype=np.int64)
+    fn = lib().oracle_topk_desc_f64 if keys.dtype == np.float64 else lib().oracle_topk_desc_f32
+    assert keys.dtype in (np.float32, np.float64)
+    fn(_ptr(keys), keys.size, int(k), _ptr(idx))
+    return idx
+
+
 def _pp(arrs):
     """array of pointers (NULL for None)"""
     t = (ctypes.c_void_p * max(len(arrs), 1))()
@@ -166,8 +201,11 @@ def _c64(a):
 def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_dict, num_neighbors_dict,
                            node_time_dict=None, edge_time_dict=None, seed_time_dict=None, csc=False,
                            replace=False, disjoint=False, temporal_strategy='uniform', return_edge_id=True,
-                           rng_seed=0, fill=None):
+                           rng_seed=0, fill=None, edge_weight_dict=None):
     """Restates pyg::hetero_neighbor_sample (single-threaded order).
+
+    `edge_weight_dict`: float32 / float64 per-edge weights of the relations to sample with bias
+    (replace=False only).
 
     Dict keys: node types are strings, edge types are (src, rel, dst) tuples.  Returns
     (row_dict, col_dict, node_id_dict, edge_id_dict|None, num_nodes_per_hop_dict,
@@ -190,6 +228,18 @@ def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_d
     ntimes = [_c64(node_time_dict.get(t)) if node_time_dict else None for t in node_types]
     etimes = [_c64(edge_time_dict.get(e)) if edge_time_dict else None for e in edge_types]
     stimes = [_c64(seed_time_dict.get(k)) if seed_time_dict else None for k in seed_keys]
+    weights = [None] * E
+    w64 = np.zeros(max(E, 1), dtype=np.int32)
+    if edge_weight_dict:
+        if node_time_dict or edge_time_dict:
+            raise RuntimeError('Biased temporal sampling not yet supported')
+        for i, e in enumerate(edge_types):
+            w = edge_weight_dict.get(e)
+            if w is not None:
+                w = np.ascontiguousarray(w)
+                assert w.dtype in (np.float32, np.float64)
+                weights[i] = w
+                w64[i] = int(w.dtype == np.float64)
     status = ctypes.c_int(0)
     cb = None
     if fill is not None:
@@ -198,12 +248,15 @@ def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_d
             fill(arr)
         cb = _FILL(_cb)
     L_ = lib()
-    h = L_.oracle_hetero_neighbor_sample(
+    h = L_.oracle_hetero_neighbor_sample_w(
         len(node_types), E, _ptr(et_src), _ptr(et_dst), _pp(rowptrs), _pp(cols), len(seed_keys), _ptr(seed_types),
-        _pp(seeds), _ptr(seed_len), _ptr(nn), L, _pp(ntimes), _pp(etimes), _pp(stimes), int(csc), int(replace),
+        _pp(seeds), _ptr(seed_len), _ptr(nn), L, _pp(ntimes), _pp(etimes), _pp(stimes), _pp(weights), _ptr(w64),
+        int(csc), int(replace),
         int(disjoint), int(temporal_strategy == 'last'), rng_seed & 0xFFFFFFFFFFFFFFFF,
         ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None, ctypes.byref(status))
     try:
+        if status.value == -2:
+            raise NotImplementedError('biased sampling with replacement / an external word source is not restated')
         if status.value != 0:
             raise RuntimeError('Found invalid non-sorted temporal neighborhood')
         rows, colsd, eids, nodes, nhops, ehops = {}, {}, {}, {}, {}, {}
@@ -227,7 +280,8 @@ def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_d
             hops = np.zeros(L, dtype=np.int64)
             L_.oracle_sample_copy_hops(h, i, 1, _ptr(hops))
             ehops[e] = hops.tolist()
-        info = {'rng_blocks': L_.oracle_sample_rng_blocks(h), 'rng_draws': L_.oracle_sample_rng_draws(h)}
+        info = {'rng_blocks': L_.oracle_sample_rng_blocks(h), 'rng_draws': L_.oracle_sample_rng_draws(h),
+                'rng_raw_draws': L_.oracle_sample_rng_raw_draws(h)}
     finally:
         L_.oracle_sample_free(h)
     return rows, colsd, nodes, (eids if return_edge_id else None), nhops, ehops, info
@@ -235,7 +289,7 @@ def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_d
 
 def neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_time=None, seed_time=None, csc=False,
                     replace=False, directed=True, disjoint=False, temporal_strategy='uniform',
-                    return_edge_id=True, rng_seed=0, fill=None):
+                    return_edge_id=True, rng_seed=0, fill=None, edge_weight=None):
     """Restates pyg::neighbor_sample. Returns (row, col, node_id, edge_id|None, nodes_per_hop,
     edges_per_hop, info)."""
     if not directed:
@@ -249,7 +303,8 @@ def neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_time=
         edge_time_dict=None if edge_time is None else {et: edge_time},
         seed_time_dict=None if seed_time is None else {'n': seed_time},
         csc=csc, replace=replace, disjoint=disjoint, temporal_strategy=temporal_strategy,
-        return_edge_id=return_edge_id, rng_seed=rng_seed, fill=fill)
+        return_edge_id=return_edge_id, rng_seed=rng_seed, fill=fill,
+        edge_weight_dict=None if edge_weight is None else {et: edge_weight})
     rows, cols, nodes, eids, nh, eh, info = out
     return rows[et], cols[et], nodes['n'], (eids[et] if eids is not None else None), nh['n'], eh[et], info
 

@@ -30,14 +30,28 @@
  * test/csrc/sampler/test_neighbor.cpp (biased cases excepted: they consume at::multinomial /
  * uniform_ and are outside this path) -- see tests/golden/sampler_reference_vectors.py.
  *
- * Biased sampling (edge_weight) is not restated.
+ * Biased sampling (edge_weight, neighbor_kernel.cpp:39-56,245-285), `replace == false` only: per row
+ * `rand = empty_like(weight).uniform_(); key = rand.log() / weight; index = key.topk(count)`.  The uniform
+ * draws come straight from the generator (NOT from the prefetched engine): one 32-bit output per float
+ * (24 bits kept), one 64-bit draw per double (53 bits kept) -- ATen/core/DistributionsHelper.h:80-95,
+ * TransformationHelper.h:85-93.  top-k: oracle_topk.cpp.  `log`: libtorch evaluates it with MKL's vsLn/vdLn
+ * (closed source, <1 ulp); it is restated here as the CORRECTLY ROUNDED logarithm, which differs from
+ * libtorch's on 15,372 of the 2^24 possible float inputs by one ulp (measured,
+ * tests/golden/make_biased_golden.py) -- a selection only changes if two keys of one row lie within that
+ * ulp.  Pinned by tests/golden/biased_golden.npz, generated with the real torch ops.  With replacement
+ * (at::multinomial) is not restated.
  *
  * dist_neighbor_sample (neighbor_kernel.cpp:957-978, the `distributed` template flag :296-303,
  * 386-388,446-447): one hop, no relabelling -- see oracle_dist_neighbor_sample at the end.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* oracle_topk.cpp */
+void oracle_topk_desc_f32(const float* keys, int64_t n, int64_t k, int64_t* idx);
+void oracle_topk_desc_f64(const double* keys, int64_t n, int64_t k, int64_t* idx);
 
 /* ---------------------------------------------------------------------------------------------
  * mt19937 exactly as at::mt19937 (ATen/core/MT19937RNGEngine.h): standard MT with 32-bit seed.
@@ -100,6 +114,21 @@ void oracle_mt19937_words(uint64_t seed, int64_t* out, int64_t n) {
   for (int64_t i = 0; i < n; ++i) out[i] = torch_randint_full(&g);
 }
 
+/* The word torch.randint(INT64_MIN, INT64_MAX, (1,)) yields after torch.manual_seed(seed) and `skip32`
+ * 32-bit engine outputs (tests: how far did a call advance the generator?). */
+int64_t oracle_mt19937_word_after(uint64_t seed, int64_t skip32) {
+  mt19937_t g;
+  mt19937_seed(&g, seed);
+  for (int64_t i = 0; i < skip32; ++i) (void)mt19937_u32(&g);
+  return torch_randint_full(&g);
+}
+
+/* (float)log((double)u): the float32 logarithm as the biased-sampling restatement defines it (tests pin the
+ * device's evaluation against this on all 2^24 arguments uniform_ can produce). */
+void oracle_biased_log_f32(const float* in, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = (float)log((double)in[i]);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * RandintEngine / PrefetchedRandint (rand_engine.h:41-92).
  * ------------------------------------------------------------------------------------------- */
@@ -114,6 +143,7 @@ typedef struct {
   void* user;
   int64_t blocks;         /* number of 128-word prefetches so far */
   int64_t draws;
+  int64_t raw_draws;      /* 32-bit outputs taken directly by biased sampling (uniform_) */
 } engine_t;
 
 static void engine_prefetch(engine_t* e) {
@@ -329,6 +359,43 @@ static void sampler_sample(sampler_t* s, int64_t row_start, int64_t row_end, int
   }
 }
 
+/* _biased_sample (neighbor_kernel.cpp:245-285), replace == false.  weight_f64: 0 = float32 weights,
+ * 1 = float64.  Returns 0, or -2 for the (not restated) with-replacement case. */
+static int sampler_biased(sampler_t* s, int64_t row_start, int64_t row_end, int64_t count, int replace,
+                          int64_t src_batch, int64_t local_src, nodeset_t* dst, int disjoint,
+                          engine_t* eng, const void* weight, int weight_f64) {
+  const int64_t population = row_end - row_start;
+  if (count < 0 || (!replace && count >= population)) {
+    for (int64_t e = row_start; e < row_end; ++e) sampler_add(s, e, src_batch, local_src, dst, disjoint);
+    return 0;
+  }
+  if (replace || eng->fill) return -2;
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
+  if (!weight_f64) {
+    const float* w = (const float*)weight + row_start;
+    float* key = (float*)malloc(sizeof(float) * (size_t)population);
+    for (int64_t j = 0; j < population; ++j) {
+      const float u = (float)(mt19937_u32(&eng->gen) & 0xffffffu) * 0x1p-24f; /* uniform_real<float>: 24 bits */
+      key[j] = (float)log((double)u) / w[j];
+    }
+    oracle_topk_desc_f32(key, population, count, idx);
+    free(key);
+  } else {
+    const double* w = (const double*)weight + row_start;
+    double* key = (double*)malloc(sizeof(double) * (size_t)population);
+    for (int64_t j = 0; j < population; ++j) {
+      const double u = (double)(mt19937_u64(&eng->gen) & ((1ull << 53) - 1)) * 0x1p-53; /* 53 bits */
+      key[j] = log(u) / w[j];
+    }
+    oracle_topk_desc_f64(key, population, count, idx);
+    free(key);
+  }
+  eng->raw_draws += population * (weight_f64 ? 2 : 1);
+  for (int64_t i = 0; i < count; ++i) sampler_add(s, row_start + idx[i], src_batch, local_src, dst, disjoint);
+  free(idx);
+  return 0;
+}
+
 /* upper_bound helpers for temporal sampling (neighbor_kernel.cpp:74-144) */
 static int64_t ub_node_time(const int64_t* col, int64_t b, int64_t e, int64_t seed_time,
                             const int64_t* time) {
@@ -381,7 +448,7 @@ typedef struct {
   int num_node_types, num_edge_types, L, disjoint;
   nodeset_t* ns;
   sampler_t* sm;
-  int64_t rng_blocks, rng_draws;
+  int64_t rng_blocks, rng_draws, rng_raw_draws;
 } oracle_result;
 
 static void nodeset_init(nodeset_t* n) {
@@ -412,6 +479,7 @@ int64_t oracle_sample_num_nodes(const oracle_result* r, int t) { return r->ns[t]
 int64_t oracle_sample_num_edges(const oracle_result* r, int e) { return r->sm[e].rows.n; }
 int64_t oracle_sample_rng_blocks(const oracle_result* r) { return r->rng_blocks; }
 int64_t oracle_sample_rng_draws(const oracle_result* r) { return r->rng_draws; }
+int64_t oracle_sample_rng_raw_draws(const oracle_result* r) { return r->rng_raw_draws; }
 
 /* node ids: [n] or, when disjoint, [n, 2] = (batch, node) pairs (from_vector of pairs). */
 void oracle_sample_copy_nodes(const oracle_result* r, int t, int64_t* out) {
@@ -451,12 +519,15 @@ void oracle_sample_copy_hops(const oracle_result* r, int t_or_e, int is_edge, in
  *  num_neighbors     [num_edge_types, L]
  *  node_time[t] / edge_time[e] / seed_time (per seed type) may be NULL.
  * ------------------------------------------------------------------------------------------- */
-oracle_result* oracle_hetero_neighbor_sample(
+/* edge_weight[e]: NULL or the relation's per-edge weights (float32, or float64 where weight_f64[e]); a
+ * weighted relation is sampled with biased_sample (neighbor_kernel.cpp:732-745; homogeneous :436-447). */
+oracle_result* oracle_hetero_neighbor_sample_w(
     int num_node_types, int num_edge_types, const int* et_src, const int* et_dst,
     const int64_t* const* rowptr, const int64_t* const* col, int num_seed_types,
     const int* seed_types, const int64_t* const* seed, const int64_t* seed_len,
     const int64_t* num_neighbors, int L, const int64_t* const* node_time,
-    const int64_t* const* edge_time, const int64_t* const* seed_time, int csc, int replace,
+    const int64_t* const* edge_time, const int64_t* const* seed_time,
+    const void* const* edge_weight, const int* weight_f64, int csc, int replace,
     int disjoint, int temporal_last, uint64_t rng_seed, oracle_fill_fn fill, void* user,
     int* status) {
   oracle_result* r = (oracle_result*)calloc(1, sizeof(oracle_result));
@@ -513,6 +584,19 @@ oracle_result* oracle_hetero_neighbor_sample(
       const int64_t* nt = (node_time && node_time[dst]) ? node_time[dst] : NULL;
       const int64_t* et = (edge_time && edge_time[e]) ? edge_time[e] : NULL;
       const int64_t b = sn->slice_b, en = sn->slice_e; /* fixed at hop start (:725) */
+      if (edge_weight && edge_weight[e]) {
+        for (int64_t i = b; i < en; ++i) {
+          const int64_t v = sn->node.d[i];
+          const int64_t rs = s->rowptr[v], re = s->rowptr[v + 1];
+          if (re - rs == 0 || count == 0) continue;
+          if (sampler_biased(s, rs, re, count, replace, disjoint ? sn->batch.d[i] : 0, i, dn, disjoint, &eng,
+                             edge_weight[e], weight_f64[e]) != 0) {
+            *status = -2;
+            break;
+          }
+        }
+        continue;
+      }
       for (int64_t i = b; i < en; ++i) {
         const int64_t v = sn->node.d[i];
         const int64_t sb = disjoint ? sn->batch.d[i] : 0;
@@ -533,9 +617,24 @@ oracle_result* oracle_hetero_neighbor_sample(
   }
   r->rng_blocks = eng.blocks;
   r->rng_draws = eng.draws;
+  r->rng_raw_draws = eng.raw_draws;
   free(trk.slot);
   free(seed_times.d);
   return r;
+}
+
+oracle_result* oracle_hetero_neighbor_sample(
+    int num_node_types, int num_edge_types, const int* et_src, const int* et_dst,
+    const int64_t* const* rowptr, const int64_t* const* col, int num_seed_types,
+    const int* seed_types, const int64_t* const* seed, const int64_t* seed_len,
+    const int64_t* num_neighbors, int L, const int64_t* const* node_time,
+    const int64_t* const* edge_time, const int64_t* const* seed_time, int csc, int replace,
+    int disjoint, int temporal_last, uint64_t rng_seed, oracle_fill_fn fill, void* user,
+    int* status) {
+  return oracle_hetero_neighbor_sample_w(num_node_types, num_edge_types, et_src, et_dst, rowptr, col,
+                                         num_seed_types, seed_types, seed, seed_len, num_neighbors, L, node_time,
+                                         edge_time, seed_time, NULL, NULL, csc, replace, disjoint, temporal_last,
+                                         rng_seed, fill, user, status);
 }
 
 /* Homogeneous entry (neighbor_kernel.cpp:332-514): one node type, one edge type.  `csc` only

@@ -415,9 +415,17 @@ static void check_modes(bool has_node_time, bool has_edge_time, bool has_seed_ti
   TORCH_CHECK(!(has_node_time && has_weight), "Biased node temporal sampling not yet supported");
   TORCH_CHECK(!(has_edge_time && has_weight), "Biased edge temporal sampling not yet supported");
   TORCH_CHECK(directed, "Undirected subgraphs not yet supported");
-  TORCH_CHECK(!has_weight,
-              "pyg (HIP): biased sampling is not implemented on the device path yet; refusing to fall back "
-              "to a CPU kernel");
+}
+
+// biased sampling: per-edge weights of one relation (neighbor_kernel.cpp:52 narrows them per row)
+static void set_weight(pyg_hip_relation& rel, const Tensor& w, int64_t num_cols) {
+  TORCH_CHECK(w.is_cuda(), "pyg (HIP): 'edge_weight' must live on a HIP device");
+  TORCH_CHECK(w.is_contiguous(), "Non-contiguous 'edge_weight'");
+  TORCH_CHECK(w.dim() == 1 && w.numel() == num_cols, "pyg (HIP): 'edge_weight' needs one entry per edge");
+  TORCH_CHECK(w.scalar_type() == at::kFloat || w.scalar_type() == at::kDouble,
+              "pyg (HIP): 'edge_weight' must be float32 or float64");
+  rel.edge_weight = w.data_ptr();
+  rel.edge_weight_dtype = w.scalar_type() == at::kDouble ? PYG_F64 : PYG_F32;
 }
 
 static const int64_t* time_ptr(const Tensor& t, const char* what) {
@@ -447,6 +455,10 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   rels[0].dst_type = 0;
   rels[0].num_neighbors_host = num_neighbors.data();
   rels[0].edge_time = edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr;
+  rels[0].edge_weight = nullptr;
+  rels[0].edge_weight_dtype = 0;
+  rels[0].reserved = 0;
+  if (edge_weight.has_value()) set_weight(rels[0], edge_weight.value(), col.numel());
   std::vector<pyg_hip_seed_set> seeds(1);
   seeds[0].node_type = 0;
   seeds[0].reserved = 0;
@@ -506,6 +518,11 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     rels[e].edge_time = nullptr;
     if (edge_time_dict.has_value() && edge_time_dict.value().contains(rel))
       rels[e].edge_time = time_ptr(edge_time_dict.value().at(rel), "edge_time");
+    rels[e].edge_weight = nullptr;
+    rels[e].edge_weight_dtype = 0;
+    rels[e].reserved = 0;
+    if (edge_weight_dict.has_value() && edge_weight_dict.value().contains(rel))
+      set_weight(rels[e], edge_weight_dict.value().at(rel), col.numel());
   }
   for (size_t e = 0; e < edge_types.size(); ++e) {
     TORCH_CHECK(fanouts[e].size() == L, "hetero_neighbor_sample: all relations must list ", L, " hops");
@@ -565,6 +582,9 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
     bool directed, bool disjoint, std::string temporal_strategy) {
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(), directed,
               disjoint, temporal_strategy);
+  TORCH_CHECK(!edge_weight.has_value(),
+              "pyg (HIP): biased dist_neighbor_sample is not implemented on the device path; refusing to fall back "
+              "to a CPU kernel");
   check_index(rowptr, "rowptr");
   check_index(col, "col");
   check_index(seed, "seed");

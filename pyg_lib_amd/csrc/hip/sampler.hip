@@ -984,6 +984,393 @@ __global__ __launch_bounds__(256) void mt_finish_kernel(const uint32_t* __restri
   }
 }
 
+// ---- biased sampling (edge_weight) -------------------------------------------------------------------
+// _biased_sample (neighbor_kernel.cpp:245-285), replace == false: a row with more neighbours than the
+// fan-out draws `rand = empty_like(weight).uniform_()` straight from the generator, forms
+// key = rand.log() / weight and takes `key.topk(count)` -- the sampled edges in descending key order.
+//   * uniform_ (serial CPU kernel): float32 -> one engine output, 24 bits kept; float64 -> random64() (two
+//     outputs, first = high half), 53 bits kept (ATen/core/DistributionsHelper.h, TransformationHelper.h).
+//     Row i of the frontier reads the outputs [raw_off[i], raw_off[i] + deg * outputs_per_draw): an
+//     exclusive scan over the frontier (the prefetched RandintEngine is not touched).
+//   * log: libtorch evaluates it with MKL (<1 ulp, closed source); here the correctly rounded logarithm
+//     (float32: the f64 log rounded once; float64: the f64 log itself) -- see include/pyg_hip.h.
+//   * topk (ATen/native/TopKImpl.h:30-96): comparator "NaN first, then greater" on (key, index) pairs,
+//     std::partial_sort if count * 64 <= deg, else std::nth_element + std::sort of the first count - 1.
+//     Keys are mapped to unsigned integers whose order is that comparator's.  Without equal keys among the
+//     selected ones and at the selection boundary the result is simply the `count` largest in descending
+//     order: one wave per row finds the count-th largest key bit by bit and ranks the selection by
+//     counting.  Rows WITH such ties (zero weights -> -inf keys; equal weights with equal 24-bit draws) are
+//     re-done by biased_exact_kernel, which performs libstdc++'s algorithms step for step.
+__device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ out32, int64_t o) {
+  return (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];  // mt_emit's layout
+}
+
+// float32 logarithm of the biased path: the f64 log rounded once (pinned on all 2^24 arguments uniform_ can
+// produce through pyg_hip_biased_log_f32, tests/test_biased_sampler_gpu.py)
+__device__ __forceinline__ float biased_log_f32(float u) { return (float)log((double)u); }
+__global__ void biased_log_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = biased_log_f32(in[i]);
+}
+
+template <bool F64> struct BiasedKey;
+template <> struct BiasedKey<false> {
+  typedef uint32_t K;
+  typedef float W;
+  static constexpr int kOutputs = 1;
+  static constexpr int kBits = 32;
+  __device__ static K make(const uint32_t* __restrict__ out32, int64_t o, float w) {
+    const float u = (float)(mt_output_at(out32, o) & 0xffffffu) * 0x1p-24f;
+    const float key = __fdiv_rn(biased_log_f32(u), w);
+    uint32_t b = __float_as_uint(key);
+    if (key != key) return ~0u;
+    if (key == 0.f) b = 0u;  // -0 and +0 compare equal
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  }
+};
+template <> struct BiasedKey<true> {
+  typedef uint64_t K;
+  typedef double W;
+  static constexpr int kOutputs = 2;
+  static constexpr int kBits = 64;
+  __device__ static K make(const uint32_t* __restrict__ out32, int64_t o, double w) {
+    const uint64_t v = ((uint64_t)mt_output_at(out32, o) << 32) | mt_output_at(out32, o + 1);
+    const double u = (double)(v & ((1ull << 53) - 1)) * 0x1p-53;
+    const double key = log(u) / w;
+    uint64_t b = (uint64_t)__double_as_longlong(key);
+    if (key != key) return ~0ull;
+    if (key == 0.0) b = 0ull;
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+  }
+};
+
+struct BiasedCountLoad {
+  const int64_t* nodes;
+  int64_t begin;
+  const int64_t* rowptr;
+  int64_t count;
+  int outputs;  // engine outputs per draw
+  __device__ CountAgg operator()(int64_t i) const {
+    CountAgg r;
+    r.tab = rng_identity();
+    r.edges = 0;
+    const int64_t v = nodes[begin + i];
+    const int64_t deg = rowptr[v + 1] - rowptr[v];
+    if (deg <= 0 || count == 0) return r;
+    if (count < 0 || count >= deg) {
+      r.edges = deg;
+      return r;
+    }
+    r.edges = count;
+    r.tab |= (u64)(deg * outputs) << 20;  // identity transitions compose additively in the word field
+    return r;
+  }
+};
+
+template <typename K>
+struct BiasedArgs {
+  HopArgs h;              // nodes, batch, begin, frontier, range.rowptr, col, count, edge_off, rng_word (= the
+                          // row's first engine output), emission buffers, table
+  HopInfo* info;          // tot.tab is reset to the identity (the engine does not move), overflow cleared
+  const void* weight;
+  const uint32_t* out32;  // generated engine outputs
+  int64_t out_base;       // engine output behind key slot 0
+  K* skey;                // [draws] keys of every drawing row, in draw order
+  int32_t* sidx;          // [draws] rank scratch / index half of the exact path's pairs
+  K* selkey;              // [edges] keys of the selected neighbours, in index order
+  int32_t* selidx;        // [edges]
+  int32_t* flag;          // [frontier] 1 = the row has ties and is left to biased_exact_kernel
+};
+
+__device__ __forceinline__ void wave_mem_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool F64>
+__global__ __launch_bounds__(256) void biased_sample_kernel(BiasedArgs<typename BiasedKey<F64>::K> a) {
+  typedef BiasedKey<F64> BK;
+  typedef typename BK::K K;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.info->tot.tab = rng_identity();
+    a.info->overflow = 0;
+  }
+  if (i >= a.h.frontier) return;
+  const int64_t src_pos = a.h.begin + i;
+  const int64_t v = a.h.nodes[src_pos];
+  const int64_t batch = a.h.batch ? a.h.batch[src_pos] : 0;
+  const int64_t rs = a.h.range.rowptr[v];
+  const int64_t n = a.h.range.rowptr[v + 1] - rs;
+  const int64_t k = a.h.count;
+  if (lane == 0) a.flag[i] = 0;
+  if (n <= 0 || k == 0) return;
+  const int64_t eo = a.h.edge_off[i];
+  if (k < 0 || k >= n) {  // the full neighbourhood, no draws (:257-262)
+    for (int64_t j = lane; j < n; j += 64) emit(a.h, eo + j, rs + j, src_pos, batch);
+    return;
+  }
+  const int64_t o0 = a.h.rng_word[i];
+  const int64_t ko = (o0 - a.out_base) / BK::kOutputs;
+  K* sk = a.skey + ko;
+  const typename BK::W* w = static_cast<const typename BK::W*>(a.weight) + rs;
+  for (int64_t j = lane; j < n; j += 64) sk[j] = BK::make(a.out32, o0 + j * BK::kOutputs, w[j]);
+  wave_mem_sync();
+  // T = the k-th largest key
+  K T = 0;
+  for (int b = BK::kBits - 1; b >= 0; --b) {
+    const K cand = T | ((K)1 << b);
+    int c = 0;
+    for (int64_t j = lane; j < n; j += 64) c += sk[j] >= cand ? 1 : 0;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s, 64);
+    if (c >= k) T = cand;
+  }
+  // selection = keys >= T, compacted in index order; more than k of them = a tie at the boundary
+  int64_t sel = 0;
+  for (int64_t j0 = 0; j0 < n; j0 += 64) {
+    const int64_t j = j0 + lane;
+    const K x = j < n ? sk[j] : (K)0;
+    const bool in = j < n && x >= T;
+    const u64 m = __ballot(in);
+    const int64_t p = sel + __popcll(m & ((1ull << lane) - 1));
+    if (in && p < k) {
+      a.selkey[eo + p] = x;
+      a.selidx[eo + p] = (int32_t)j;
+    }
+    sel += __popcll(m);
+  }
+  bool tie = sel > k;
+  wave_mem_sync();
+  if (!tie) {
+    // rank by counting; equal keys inside the selection are ties as well
+    bool dup = false;
+    for (int64_t p = lane; p < k; p += 64) {
+      const K x = a.selkey[eo + p];
+      int32_t rank = 0, same = 0;
+      for (int64_t q = 0; q < k; ++q) {
+        const K y = a.selkey[eo + q];
+        rank += y > x ? 1 : 0;
+        same += y == x ? 1 : 0;
+      }
+      dup = dup || same > 1;
+      a.sidx[ko + p] = rank;
+    }
+    tie = __ballot(dup) != 0;
+  }
+  if (tie) {
+    if (lane == 0) a.flag[i] = 1;
+    return;
+  }
+  for (int64_t p = lane; p < k; p += 64) emit(a.h, eo + a.sidx[ko + p], rs + a.selidx[eo + p], src_pos, batch);
+}
+
+// libstdc++'s heap / introselect / introsort on (key, index) pairs held in two arrays, with the comparator
+// "x before y  <=>  key(x) > key(y)" (bits/stl_heap.h, bits/stl_algo.h of GCC 11; the algorithms have not
+// changed in a decade).  Sequential by nature: one thread per row, for the rare rows with tied keys.
+template <typename K>
+struct PairSeq {
+  K* k;
+  int32_t* v;
+  struct V {
+    K k;
+    int32_t v;
+  };
+  __device__ V at(int64_t i) const { return V{k[i], v[i]}; }
+  __device__ void put(int64_t i, V x) const {
+    k[i] = x.k;
+    v[i] = x.v;
+  }
+  __device__ void swp(int64_t i, int64_t j) const {
+    const V t = at(i);
+    put(i, at(j));
+    put(j, t);
+  }
+  __device__ static bool lt(const V& x, const V& y) { return x.k > y.k; }
+  __device__ static int lg(int64_t n) { return 63 - __clzll((unsigned long long)n); }
+
+  __device__ void push_heap(int64_t first, int64_t hole, int64_t top, V value) const {
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && lt(at(first + parent), value)) {
+      put(first + hole, at(first + parent));
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    put(first + hole, value);
+  }
+  __device__ void adjust_heap(int64_t first, int64_t hole, int64_t len, V value) const {
+    const int64_t top = hole;
+    int64_t child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (lt(at(first + child), at(first + (child - 1)))) child--;
+      put(first + hole, at(first + child));
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      put(first + hole, at(first + (child - 1)));
+      hole = child - 1;
+    }
+    push_heap(first, hole, top, value);
+  }
+  __device__ void make_heap(int64_t first, int64_t last) const {
+    const int64_t len = last - first;
+    if (len < 2) return;
+    int64_t parent = (len - 2) / 2;
+    for (;;) {
+      adjust_heap(first, parent, len, at(first + parent));
+      if (parent == 0) return;
+      parent--;
+    }
+  }
+  __device__ void pop_heap(int64_t first, int64_t last, int64_t result) const {
+    const V value = at(result);
+    put(result, at(first));
+    adjust_heap(first, 0, last - first, value);
+  }
+  __device__ void heap_select(int64_t first, int64_t middle, int64_t last) const {
+    make_heap(first, middle);
+    for (int64_t i = middle; i < last; ++i)
+      if (lt(at(i), at(first))) pop_heap(first, middle, i);
+  }
+  __device__ void sort_heap(int64_t first, int64_t last) const {
+    while (last - first > 1) {
+      --last;
+      pop_heap(first, last, last);
+    }
+  }
+  __device__ void partial_sort(int64_t first, int64_t middle, int64_t last) const {
+    heap_select(first, middle, last);
+    sort_heap(first, middle);
+  }
+  __device__ void move_median_to_first(int64_t result, int64_t a, int64_t b, int64_t c) const {
+    if (lt(at(a), at(b))) {
+      if (lt(at(b), at(c))) swp(result, b);
+      else if (lt(at(a), at(c))) swp(result, c);
+      else swp(result, a);
+    } else if (lt(at(a), at(c))) swp(result, a);
+    else if (lt(at(b), at(c))) swp(result, c);
+    else swp(result, b);
+  }
+  __device__ int64_t unguarded_partition(int64_t first, int64_t last, int64_t pivot) const {
+    for (;;) {
+      while (lt(at(first), at(pivot))) ++first;
+      --last;
+      while (lt(at(pivot), at(last))) --last;
+      if (!(first < last)) return first;
+      swp(first, last);
+      ++first;
+    }
+  }
+  __device__ int64_t unguarded_partition_pivot(int64_t first, int64_t last) const {
+    const int64_t mid = first + (last - first) / 2;
+    move_median_to_first(first, first + 1, mid, last - 1);
+    return unguarded_partition(first + 1, last, first);
+  }
+  __device__ void unguarded_linear_insert(int64_t last) const {
+    const V val = at(last);
+    int64_t next = last - 1;
+    while (lt(val, at(next))) {
+      put(last, at(next));
+      last = next;
+      --next;
+    }
+    put(last, val);
+  }
+  __device__ void insertion_sort(int64_t first, int64_t last) const {
+    if (first == last) return;
+    for (int64_t i = first + 1; i != last; ++i) {
+      if (lt(at(i), at(first))) {
+        const V val = at(i);
+        for (int64_t j = i; j > first; --j) put(j, at(j - 1));
+        put(first, val);
+      } else {
+        unguarded_linear_insert(i);
+      }
+    }
+  }
+  __device__ void nth_element(int64_t first, int64_t nth, int64_t last) const {
+    if (first == last || nth == last) return;
+    int depth = lg(last - first) * 2;
+    while (last - first > 3) {
+      if (depth == 0) {
+        heap_select(first, nth + 1, last);
+        swp(first, nth);
+        return;
+      }
+      --depth;
+      const int64_t cut = unguarded_partition_pivot(first, last);
+      if (cut <= nth) first = cut;
+      else last = cut;
+    }
+    insertion_sort(first, last);
+  }
+  __device__ void sort(int64_t first, int64_t last) const {
+    if (first == last) return;
+    // __introsort_loop recurses into the right part and loops on the left one; the parts are disjoint, so
+    // an explicit stack of pending right parts yields the same arrangement
+    int64_t sf[130], sl[130];
+    int sd[130];
+    int top = 0;
+    sf[0] = first;
+    sl[0] = last;
+    sd[0] = lg(last - first) * 2;
+    top = 1;
+    while (top > 0) {
+      --top;
+      int64_t f = sf[top], l = sl[top];
+      int d = sd[top];
+      while (l - f > 16) {
+        if (d == 0) {
+          partial_sort(f, l, l);
+          break;
+        }
+        --d;
+        const int64_t cut = unguarded_partition_pivot(f, l);
+        sf[top] = cut;
+        sl[top] = l;
+        sd[top] = d;
+        ++top;
+        l = cut;
+      }
+    }
+    if (last - first > 16) {
+      insertion_sort(first, first + 16);
+      for (int64_t i = first + 16; i != last; ++i) unguarded_linear_insert(i);
+    } else {
+      insertion_sort(first, last);
+    }
+  }
+};
+
+template <bool F64>
+__global__ __launch_bounds__(64) void biased_exact_kernel(BiasedArgs<typename BiasedKey<F64>::K> a) {
+  typedef BiasedKey<F64> BK;
+  typedef typename BK::K K;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= a.h.frontier || !a.flag[i]) return;
+  const int64_t src_pos = a.h.begin + i;
+  const int64_t v = a.h.nodes[src_pos];
+  const int64_t batch = a.h.batch ? a.h.batch[src_pos] : 0;
+  const int64_t rs = a.h.range.rowptr[v];
+  const int64_t n = a.h.range.rowptr[v + 1] - rs;
+  const int64_t k = a.h.count;
+  const int64_t eo = a.h.edge_off[i];
+  const int64_t ko = (a.h.rng_word[i] - a.out_base) / BK::kOutputs;
+  PairSeq<K> s{a.skey + ko, a.sidx + ko};
+  for (int64_t j = 0; j < n; ++j) s.v[j] = (int32_t)j;
+  if (k * 64 <= n) {
+    s.partial_sort(0, k, n);
+  } else {
+    s.nth_element(0, k - 1, n);
+    s.sort(0, k - 1);
+  }
+  for (int64_t p = 0; p < k; ++p) emit(a.h, eo + p, rs + s.v[p], src_pos, batch);
+}
+
 // ---- host driver -----------------------------------------------------------------------------------
 struct Ctx {
   const pyg_hip_sampler_host* host;
@@ -1144,6 +1531,8 @@ struct RngHost {
   int64_t dev_cap_blocks = 0;
   int64_t word = 0;           // engine state: linear word index
   int units = 4;              //               16-bit units left in that word
+  int64_t raw_used = 0;       // generator outputs consumed directly (biased sampling's uniform_), behind the
+                              // engine's blocks -- only ever non-zero while the engine holds its first block
   // device continuation of the caller's mt19937 (fast path)
   bool engine = false;
   MtDev init;                 // the caller's engine at call start
@@ -1285,8 +1674,12 @@ int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec
 // Device engine only: orders the words up to `last_word` (and whatever else the same launch produced)
 // before work submitted to the main stream afterwards; `avail_blocks` = whole 128-word blocks covered.
 // No consumption accounting: also used for words a hop MAY read.
+int rng_wait32(Ctx& c, RngHost& r, int64_t need32, int64_t* avail_blocks);
 int rng_wait(Ctx& c, RngHost& r, int64_t last_word, int64_t* avail_blocks) {
-  const int64_t need32 = (last_word / 128 + 1) * 256;
+  return rng_wait32(c, r, (last_word / 128 + 1) * 256, avail_blocks);
+}
+// the same for engine outputs [0, need32)
+int rng_wait32(Ctx& c, RngHost& r, int64_t need32, int64_t* avail_blocks) {
   if (r.generated32() < need32) {  // beyond the speculation: another round, with some slack
     int rc = rng_generate(c, r, need32 + need32 / 4);
     if (rc != PYG_HIP_OK) return rc;
@@ -1337,7 +1730,7 @@ int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
 // Hands the advanced engine back (queued on the main stream; the caller synchronises it).
 int rng_finish(Ctx& c, RngHost& r) {
   if (!r.engine) return PYG_HIP_OK;
-  const int64_t n32 = r.blocks * 256;
+  const int64_t n32 = r.blocks * 256 + r.raw_used;
   pyg_hip_mt19937* e = c.host->mt19937;
   if (n32 <= r.a0) {
     PYG_HIP_CHECK(hipEventSynchronize(r.marks[0].ev));
@@ -1426,6 +1819,26 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   // Upper bounds from the seeds and the fan-out products: frontier size per (hop, type), emitted edges per
   // (hop, relation).  With bounded fan-outs they size everything up front (fully queued mode below).
   bool fast = allow_fast && c.host->mt19937 != nullptr && L > 0 && num_relations > 0;
+  bool any_biased = false;
+  for (int e = 0; e < num_relations; ++e) any_biased = any_biased || rels[e].edge_weight != nullptr;
+  if (any_biased) {
+    // reference checks (neighbor_kernel.cpp:377-380,579-582)
+    PYG_HIP_REQUIRE(!temporal, "Biased temporal sampling not yet supported");
+    if (replace) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling with replacement (at::multinomial) is not available on the device path");
+    if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
+    for (int e = 0; e < num_relations; ++e) {
+      if (rels[e].edge_weight) {
+        PYG_HIP_REQUIRE(rels[e].edge_weight_dtype == PYG_F32 || rels[e].edge_weight_dtype == PYG_F64,
+                        "sampler: edge_weight must be float32 or float64");
+        continue;
+      }
+      bool samples = false;
+      for (int ell = 0; ell < L; ++ell) samples = samples || rels[e].num_neighbors_host[ell] != 0;
+      if (samples && rels[e].num_cols > 0)
+        return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: mixing weighted and unweighted relations in one call is not available on the device path");
+    }
+    fast = false;  // the draws of a hop are only known after its degree scan
+  }
   std::vector<std::vector<int64_t>> eb((size_t)L, std::vector<int64_t>((size_t)num_relations, 0));
   std::vector<std::vector<int64_t>> fbh((size_t)L, std::vector<int64_t>((size_t)num_node_types, 0));
   std::vector<int64_t> node_bound((size_t)num_node_types, 0), rel_bound((size_t)num_relations, 0);
@@ -1892,6 +2305,157 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     return PYG_HIP_OK;
   };
 
+  // One weighted relation of one hop (biased_sample, neighbor_kernel.cpp:39-56,245-285): degree scan ->
+  // host (emitted edges, generator outputs drawn) -> keys + top-k per row -> the usual dedup tail.
+  auto run_biased = [&](int e, int64_t F, int64_t count) -> int {
+    const pyg_hip_relation& r = rels[e];
+    const int src = !csc ? r.src_type : r.dst_type;
+    const int dst = !csc ? r.dst_type : r.src_type;
+    NodeSet& sn = ns[(size_t)src];
+    NodeSet& dn = ns[(size_t)dst];
+    RelState& st = rs[(size_t)e];
+    const bool f64 = r.edge_weight_dtype == PYG_F64;
+    const int outputs = f64 ? 2 : 1;
+    const int64_t ntiles = (F + kScanTile - 1) / kScanTile;
+    CountAgg* tile_buf;
+    int64_t *edge_off, *raw_off;
+    int32_t* flag;
+    PYG_ALLOC(tile_buf, CountAgg*, c, sizeof(CountAgg) * (size_t)(ntiles + 1));
+    PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
+    PYG_ALLOC(raw_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
+    PYG_ALLOC(flag, int32_t*, c, sizeof(int32_t) * (size_t)F);
+    const int64_t out_base = rng.blocks * 256 + rng.raw_used;
+    BiasedCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, outputs};
+    CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
+    int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipMemcpyAsync(const_cast<HopInfo*>(info_host) + e, info_dev + e, sizeof(HopInfo),
+                                 hipMemcpyDeviceToHost, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t E = info_host[e].tot.edges;
+    const int64_t W = (int64_t)(info_host[e].tot.tab >> 20);  // generator outputs drawn by this relation
+    auto cleanup = [&]() {
+      c.release(tile_buf);
+      c.release(edge_off);
+      c.release(raw_off);
+      c.release(flag);
+    };
+    if (E == 0) {
+      cleanup();
+      return PYG_HIP_OK;
+    }
+    PYG_HIP_REQUIRE(r.num_cols < (1ll << 31) || W == 0, "sampler: biased sampling supports rows below 2^31 neighbours");
+    if (W > 0) {
+      rc = rng_wait32(c, rng, out_base + W, nullptr);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    double mult = 1.0, term = 1.0;
+    for (int l2 = (int)st.edges_per_hop.size(); l2 < L && r.num_neighbors_host[l2] > 0; ++l2) {
+      term *= (double)r.num_neighbors_host[l2];
+      mult += term;
+    }
+    const int64_t grow = (int64_t)std::min<double>((double)E * mult, 16.0 * 1024 * 1024);
+    rc = st.row.reserve(c, st.row.size + E, st.row.size + grow);
+    if (rc != PYG_HIP_OK) return rc;
+    rc = st.col.reserve(c, st.col.size + E, st.col.size + grow);
+    if (rc != PYG_HIP_OK) return rc;
+    rc = st.eid.reserve(c, st.eid.size + E, st.eid.size + grow);
+    if (rc != PYG_HIP_OK) return rc;
+    dn.nodes.live = std::max(dn.nodes.live, dn.nodes.size);
+    rc = dn.nodes.reserve(c, dn.nodes.live + E, dn.nodes.live + grow);
+    if (rc != PYG_HIP_OK) return rc;
+    if (disjoint) {
+      dn.batch.live = std::max(dn.batch.live, dn.batch.size);
+      rc = dn.batch.reserve(c, dn.batch.live + E, dn.batch.live + grow);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    rc = table_reserve(c, dn, E, dn.entries_bound + grow);
+    if (rc != PYG_HIP_OK) return rc;
+    int64_t *e_node, *e_batch = nullptr, *ftile;
+    u64* e_slot;
+    PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
+    if (disjoint) PYG_ALLOC(e_batch, int64_t*, c, sizeof(int64_t) * (size_t)E);
+    PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
+    const int64_t etiles = (E + kScanTile - 1) / kScanTile;
+    PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
+    const int64_t draws = W / outputs;
+    const size_t ksz = f64 ? 8 : 4;
+    void *skey, *selkey;
+    int32_t *sidx, *selidx;
+    PYG_ALLOC(skey, void*, c, ksz * (size_t)std::max<int64_t>(draws, 1));
+    PYG_ALLOC(sidx, int32_t*, c, 4 * (size_t)std::max<int64_t>(draws, 1));
+    PYG_ALLOC(selkey, void*, c, ksz * (size_t)E);
+    PYG_ALLOC(selidx, int32_t*, c, 4 * (size_t)E);
+
+    HopArgs a;
+    a.nodes = sn.nodes.p;
+    a.batch = disjoint ? sn.batch.p : nullptr;
+    a.begin = sn.slice_b;
+    a.frontier = F;
+    a.range.rowptr = r.rowptr;
+    a.range.col = r.col;
+    a.range.time = nullptr;
+    a.col = r.col;
+    a.count = count;
+    a.replace = 0;
+    a.num_batches = num_batches;
+    a.edge_off = edge_off;
+    a.rng_word = raw_off;
+    a.rng_units = nullptr;
+    a.words = nullptr;
+    a.e_row = st.row.p + st.row.size;
+    a.e_node = e_node;
+    a.e_batch = e_batch;
+    a.e_eid = st.eid.p + st.eid.size;
+    a.e_slot = e_slot;
+    a.table = dn.table;
+    const unsigned wg = (unsigned)((F + 3) / 4), xg = (unsigned)((F + 63) / 64);
+    if (f64) {
+      BiasedArgs<uint64_t> b{a, info_dev + e, r.edge_weight, reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                             static_cast<uint64_t*>(skey), sidx, static_cast<uint64_t*>(selkey), selidx, flag};
+      hipLaunchKernelGGL(biased_sample_kernel<true>, dim3(wg), dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(biased_exact_kernel<true>, dim3(xg), dim3(64), 0, stream, b);
+    } else {
+      BiasedArgs<uint32_t> b{a, info_dev + e, r.edge_weight, reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                             static_cast<uint32_t*>(skey), sidx, static_cast<uint32_t*>(selkey), selidx, flag};
+      hipLaunchKernelGGL(biased_sample_kernel<false>, dim3(wg), dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(biased_exact_kernel<false>, dim3(xg), dim3(64), 0, stream, b);
+    }
+    PYG_HIP_CHECK(hipGetLastError());
+    FlagLoad fl{e_slot, dn.table.vals, info_dev + e};
+    AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p, disjoint ? dn.batch.p : (int64_t*)nullptr,
+                   0, 0, 1, tstate + dst};
+    rc = device_scan<int64_t, SumOp>(fl, as, E, ftile, &info_dev[e].uniq, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, e_slot,
+                       dn.table.vals, E, st.col.p + st.col.size, info_dev + e, const_cast<HopInfo*>(info_host) + e,
+                       chain, tstate + dst, (const int64_t*)nullptr, (int64_t*)nullptr);
+    PYG_HIP_CHECK(hipGetLastError());
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t U = info_host[e].uniq;
+    rng.raw_used += W;
+    dn.nodes.size += U;
+    if (disjoint) dn.batch.size += U;
+    dn.distinct += U;
+    dn.entries_bound = dn.entries_bound - E + U;
+    dn.nodes.live = dn.nodes.size;
+    dn.batch.live = dn.batch.size;
+    st.row.size += E;
+    st.col.size += E;
+    st.eid.size += E;
+    st.edges_per_hop.back() = E;
+    cleanup();
+    c.release(e_node);
+    if (e_batch) c.release(e_batch);
+    c.release(e_slot);
+    c.release(ftile);
+    c.release(skey);
+    c.release(sidx);
+    c.release(selkey);
+    c.release(selidx);
+    return PYG_HIP_OK;
+  };
+
   for (int ell = 0; ell < L; ++ell) {
     std::vector<int> order;
     for (int e = 0; e < num_relations; ++e) {
@@ -1915,6 +2479,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         RelState& st = rs[(size_t)e];
         const int64_t count = r.num_neighbors_host[ell];
         const int64_t F = sn.slice_e - sn.slice_b;
+        if (r.edge_weight) {  // biased: runs alone (any_biased => nothing is ever pending)
+          int rc = run_biased(e, F, count);
+          if (rc != PYG_HIP_OK) return rc;
+          ++pos;
+          continue;
+        }
         // Unbounded / large fan-outs and the host-callback word source (which must draw exactly what is
         // consumed) need the count-scan total on the host before anything can be sized: they run alone.
         const bool presync = count < 0 || count > 64 || !rng.engine;
@@ -2340,6 +2910,15 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   }
   c.release_all();  // scratch (and, on failure, everything)
   return rc;
+}
+
+extern "C" int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, void* stream) {
+  using namespace pyg_hip;
+  if (n <= 0) return PYG_HIP_OK;
+  hipLaunchKernelGGL(biased_log_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     in, out, n);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
 }
 
 extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, const int64_t* seed,

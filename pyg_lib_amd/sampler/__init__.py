@@ -45,8 +45,9 @@ def neighbor_sample(
             iteration. If an entry is set to :obj:`-1`, all neighbors will be
             included.
         node_time, edge_time, seed_time: Temporal sampling (requires
-            :obj:`disjoint=True`); not available on the device path yet.
-        edge_weight: Biased sampling; not available on the device path yet.
+            :obj:`disjoint=True`).
+        edge_weight: Per-edge float32 / float64 weights for biased sampling
+            (without replacement only on the device path).
         csc: If set to :obj:`True`, assumes that the graph is given in CSC
             format :obj:`(colptr, row)`.
         replace: If set to :obj:`True`, will sample with replacement.
