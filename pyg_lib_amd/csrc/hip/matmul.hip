@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace pyg_hip {
@@ -481,7 +482,9 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         const int c = cs ^ (r & XM);
         int64_t row = n_row0 + r;
         if (row >= n_rows) row = n_rows - 1;
-        const u32x4* src = reinterpret_cast<const u32x4*>(dn.a + row * (K * SZ) + c * 16);
+        // global_* (a flat access also counts on lgkmcnt and makes every LDS wait conservative)
+        typedef __attribute__((address_space(1))) u32x4 GU32x4;
+        const GU32x4* src = (const GU32x4*)(dn.a + row * (K * SZ) + c * 16);
         xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
       }
     }
@@ -560,6 +563,10 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       for (int tt = 0; tt < NT; ++tt) wa[tt] = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW);
 #pragma unroll
       for (int s = 0; s < NI; ++s) {
+        // wait for this step's fragments (issued a whole step ago) before the next step's reads go out:
+        // otherwise the compiler's wait in front of the MFMAs is an lgkmcnt(0) that covers those too
+        asm volatile("" : "+v"(wa[NT - 1]));
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 xb = xa;
         u32x4 wb[NT];
         if (s + 1 < NI) {
@@ -641,10 +648,371 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         const int cs = p % CPO;
         const int c = cs ^ (r & OM);
         if (row0_out + r < rows_out) {
-          u32x4* dst = reinterpret_cast<u32x4*>(obase + (int64_t)r * M * SZ + c * 16);
+          typedef __attribute__((address_space(1))) u32x4 GU32x4;
+          GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + c * 16);
           if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
         }
       }
+    }
+  }
+}
+
+// ---- fp32 variant with a pipelined epilogue ---------------------------------------------------------
+// fp32 at K = 128 is bound by the MFMA rate (AI = 32 flop/B), and the weight image + X stages leave room for
+// one 4-wave workgroup per CU: with one wave per SIMD nothing hides a tile's epilogue (accumulators ->
+// row order -> HBM), which mfma_rows_lds_kernel runs after the tile's last MFMA.  Here the accumulators are
+// double-buffered and the epilogue of tile t-1 is cut into single instructions that are issued BETWEEN the
+// MFMA groups of tile t (the wave issues in order: anything placed behind a block of MFMAs waits for all
+// of them to issue).  The output goes through its own 4 KB per-wave stage, one 32-column block at a time:
+//   step s of the K loop (NI steps, 4 MFMA groups each)  ->  block tt = s / (NI/NT):
+//     first step  : 4 x ds_write_b128 (accumulator fragments, + bias)
+//     second step : 4 x ds_read_b128  (row order)
+//     third step  : 4 x global_store_dwordx4 (two 64-byte runs per row and instruction)
+// X staging and the loads of tile t+2 stay between the tiles, as in mfma_rows_lds_kernel.
+template <int K, int MC, int NW, int DBG = 0>  // DBG (timing experiments only): 1 = no HBM loads, 2 = no stores, 4 = no MFMAs
+__global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
+    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk, int ncol) {
+  // global_* instructions (a flat access would also count on lgkmcnt and make every LDS wait conservative)
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  typedef __attribute__((address_space(1))) float GF32;
+  constexpr int SZ = 4;
+  constexpr int NT = MC / 32;
+  constexpr int LDW = K * SZ + 16;
+  constexpr int BM = NW * 32;
+  static_assert(BM == kTileRows, "tile table is built for 128-row tiles");
+  constexpr int CPR = K * SZ / 16;
+  constexpr int NI = CPR / 2;
+  constexpr int XM = (CPR < 16 ? CPR : 16) - 1;
+  constexpr int STAGE = 32 * 16 * CPR;
+  constexpr int OSTAGE = 32 * 128;
+  constexpr int WBYTES = MC * LDW;
+  constexpr int SPT = NI / NT;  // K steps per output block
+  static_assert(NI % NT == 0 && SPT >= 3, "epilogue pieces need three K steps per output block");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int x = lane & 31;
+  const int h = lane >> 5;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
+  char* stage = smem + WBYTES + wave * STAGE;
+  char* ostage = smem + WBYTES + NW * STAGE + wave * OSTAGE;
+
+  const int total = tile_start[B];
+  const int G = (int)gridDim.x / ncol;
+  int nloc, cbase = 0;
+  if (chunk <= 0) {
+    cbase = (int)((int64_t)bx * total / G);
+    nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
+  } else {
+    const int nchunks = (total + chunk - 1) / chunk;
+    const int mine = nchunks > bx ? (nchunks - 1 - bx) / G + 1 : 0;
+    nloc = mine * chunk;
+    if (mine > 0) {
+      const int last_chunk = (mine - 1) * G + bx;
+      const int over = (last_chunk + 1) * chunk - total;
+      if (over > 0) nloc -= over;
+    }
+  }
+  if (nloc <= 0) return;
+  auto tile_of = [&](int i) -> int {
+    if (chunk <= 0) return cbase + i;
+    const int j = i / chunk;
+    return (j * G + bx) * chunk + (i - j * chunk);
+  };
+  const int t1 = nloc;
+
+  int lo = 0, hi = B;
+  {
+    const int first = tile_of(0);
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= first) lo = mid; else hi = mid;
+    }
+  }
+  int g = lo;
+  int staged = -1;
+
+  const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
+  const char* wfrag = smem + crow0 * LDW + (K / 2) * h * SZ;
+
+  u32x4 xr[NI];
+  uint32_t xoff[NI];  // byte offset of this lane's 16 bytes of load i inside a whole 32-row tile
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = i * 64 + lane;
+    const int r = p / CPR;
+    xoff[i] = (uint32_t)(r * (K * SZ) + (((p % CPR) ^ (r & XM)) * 16));
+  }
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  auto prefetch = [&](int ti) {
+    const int t = tile_of(ti);
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+      if (n_row0 + 32 <= n_rows) {
+        // whole tile: wave-uniform base in SGPRs + the per-lane offsets computed once (no address math here)
+        const uint64_t base = (uint64_t)(dn.a + n_row0 * (K * SZ));
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+        // v_readfirstlane writes the SGPRs; a VMEM instruction may read them only 5 wait states later, and the
+        // compiler's hazard recogniser does not look inside inline asm
+        asm volatile("s_nop 5" : "+s"(sbase));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if constexpr ((DBG & 1) == 0)
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(xr[i]) : "v"(xoff[i]), "s"(sbase) : "memory");
+          else
+            asm volatile("v_mov_b32 %0, %1" : "=v"(xr[i][0]) : "v"(xoff[i]));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int p = i * 64 + lane;
+          const int r = p / CPR;
+          const int cs = p % CPR;
+          const int c = cs ^ (r & XM);
+          int64_t row = n_row0 + r;
+          if (row >= n_rows) row = n_rows - 1;
+          // Issued through inline asm so that the WAIT for these loads is placed by hand (stage_x below): stores
+          // count on vmcnt too, and the compiler -- which cannot see across this loop's branches that exactly
+          // the 16 stores of the overlapped epilogue are younger -- would wait for those stores as well
+          // (vmcnt(0): several microseconds of store latency per tile).
+          asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(xr[i]) : "v"(dn.a + row * (K * SZ) + c * 16) : "memory");
+        }
+      }
+    }
+  };
+  // `younger16`: exactly the 16 unpredicated stores of an overlapped epilogue were issued after the loads
+  auto stage_x = [&](bool younger16) {
+    if (younger16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+  };
+
+  // the tile whose accumulators wait for their epilogue
+  bool p_valid = false;
+  char* p_obase = nullptr;
+  int64_t p_left = 0;    // rows of the tile that exist
+  int64_t p_pitch = 0;   // output row pitch in bytes
+  const GF32* p_bias = nullptr;
+  bool p_full = false;   // all 32 rows exist: stores need no predicate
+
+  // one epilogue instruction: part e (0..3) of K step s, for the pending tile's accumulators
+  u32x4 ov[4];
+  auto piece = [&](const f32x16 (&acc)[NT], int s, int e, auto full_tile) {
+    constexpr bool FULL = decltype(full_tile)::value;
+    const int tt = s / SPT;
+    const int sub = s - tt * SPT;
+    if (sub == 0) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[tt][4 * e + j];
+      if (!FULL && p_bias) {  // (tiles with a bias take the predicated path)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += p_bias[(MC / 2) * h + 16 * tt + 4 * e + j];
+      }
+      *reinterpret_cast<f32x4*>(ostage + (x * 8 + ((h * 4 + e) ^ ((x >> 1) & 7))) * 16) = v;
+    } else if (sub == 1) {
+      ov[e] = *reinterpret_cast<const u32x4*>(ostage + (e * 64 + lane) * 16);
+    } else if (sub == 2) {
+      const int p = e * 64 + lane;
+      const int r = p >> 3;
+      const int c = (p & 7) ^ ((r >> 1) & 7);
+      if (FULL || r < p_left) {
+        GU32x4* dst = (GU32x4*)(p_obase + (int64_t)r * p_pitch + ((MC / 2) * (c >> 2) + 16 * tt + 4 * (c & 3)) * SZ);
+        if constexpr ((DBG & 2) == 0) __builtin_nontemporal_store(ov[e], dst);
+        else if (ov[e][0] == 0x12345678u && ov[e][1] == 0x9abcdef0u) *dst = ov[e];
+      }
+    }
+  };
+  auto flush = [&](const f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int s = 0; s < NI; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) piece(acc, s, e, std::false_type{});
+  };
+
+  auto multiply = [&](f32x16 (&accC)[NT], const f32x16 (&accP)[NT], auto has_prev) {
+    constexpr bool HAS_PREV = decltype(has_prev)::value;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accC[i][r] = 0.f;
+    u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h) ^ (x & XM))) * 16);
+    u32x4 wa[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) wa[tt] = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW);
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      // Wait for this step's fragments BEFORE the next step's reads are issued: they were issued a whole
+      // step (16 MFMAs) ago, so this costs nothing -- whereas the wait the compiler would place in front
+      // of the first MFMA is an lgkmcnt(0) that also covers the reads issued just before it.
+      asm volatile("" : "+v"(wa[NT - 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 xb = xa;
+      u32x4 wb[NT];
+      if (s + 1 < NI) {
+        const int c = NI * h + s + 1;
+        xb = *reinterpret_cast<const u32x4*>(stage + (x * CPR + (c ^ (x & XM))) * 16);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          wb[tt] = *reinterpret_cast<const u32x4*>(wfrag + tt * 16 * LDW + (s + 1) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 xf = __builtin_bit_cast(f32x4, xa);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          if constexpr ((DBG & 4) == 0)
+            accC[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, wa[tt])[e], xf[e], accC[tt], 0, 0, 0);
+          else
+            accC[tt][e] += __builtin_bit_cast(f32x4, wa[tt])[e] * xf[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HAS_PREV) {
+          piece(accP, s, e, std::true_type{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (s + 1 < NI) {
+        xa = xb;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) wa[tt] = wb[tt];
+      }
+    }
+  };
+
+  prefetch(0);
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+  if (valid) stage_x(false);
+  if (1 < t1) prefetch(1);
+
+  int t = 0;
+  uint64_t dbg_t[4] = {0, 0, 0, 0};
+  uint64_t dbg_start = 0;
+  if constexpr ((DBG & 8) != 0) dbg_start = __builtin_readcyclecounter();
+  auto one = [&](f32x16 (&accC)[NT], f32x16 (&accP)[NT]) {
+    if (cg != staged) {
+      __syncthreads();
+      const char* w = d.w;
+      const int M = d.m;
+      if (!d.trans) {
+        constexpr int CW = MC / 4;
+        for (int idx = tid; idx < K * CW; idx += NW * 64) {
+          const int k = idx / CW;
+          const int cc = (idx - k * CW) * 4;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * M + col0 + cc) * SZ);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(smem + (cc + e) * LDW + k * 4) = v[e];
+        }
+      } else {
+        constexpr int CW = K / 4;
+        for (int idx = tid; idx < MC * CW; idx += NW * 64) {
+          const int c = idx / CW;
+          const int kk = (idx - c * CW) * 4;
+          *reinterpret_cast<u32x4*>(smem + c * LDW + kk * SZ) =
+              *reinterpret_cast<const u32x4*>(w + ((int64_t)(col0 + c) * K + kk) * SZ);
+        }
+      }
+      __syncthreads();
+      staged = cg;
+    }
+    // the overlapped epilogue is the unpredicated one (whole 32-row tiles without bias); the last tile of a
+    // group / biased outputs are flushed on their own
+    bool flushed = false;
+    if (p_valid && !(valid && p_full)) {
+      flush(accP);
+      p_valid = false;
+      flushed = true;
+    }
+    bool overlapped = false;
+    uint64_t c0 = 0;
+    if constexpr ((DBG & 8) != 0) c0 = __builtin_readcyclecounter();
+    if (valid) {
+      if (p_valid) {
+        multiply(accC, accP, std::true_type{});
+        overlapped = true;
+      } else {
+        multiply(accC, accP, std::false_type{});
+      }
+    }
+    if constexpr ((DBG & 8) != 0) {
+      const uint64_t c1 = __builtin_readcyclecounter();
+      dbg_t[0] += c1 - c0;
+      c0 = c1;
+    }
+    // this tile's accumulators are the pending ones now
+    p_valid = valid;
+    if (valid) {
+      p_pitch = (int64_t)d.m * SZ;
+      p_obase = d.c + row0 * p_pitch + (int64_t)col0 * SZ;
+      p_left = rows - row0;
+      p_bias = d.bias ? (const GF32*)(reinterpret_cast<const float*>(d.bias) + col0) : nullptr;
+      p_full = p_left >= 32 && !d.bias;
+    }
+    if (t + 1 < t1) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+      if constexpr ((DBG & 8) != 0) {
+        const uint64_t c1 = __builtin_readcyclecounter();
+        dbg_t[1] += c1 - c0;
+        c0 = c1;
+      }
+      if (valid) stage_x(overlapped && !flushed);
+      if constexpr ((DBG & 8) != 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t c1 = __builtin_readcyclecounter();
+        dbg_t[2] += c1 - c0;
+        c0 = c1;
+      }
+      if (t + 2 < t1) prefetch(t + 2);
+      if constexpr ((DBG & 8) != 0) {
+        const uint64_t c1 = __builtin_readcyclecounter();
+        dbg_t[3] += c1 - c0;
+        c0 = c1;
+      }
+    }
+  };
+
+  f32x16 acc0[NT], acc1[NT];
+  for (;;) {
+    one(acc0, acc1);
+    if (++t >= t1) {
+      if (p_valid) flush(acc0);
+      break;
+    }
+    one(acc1, acc0);
+    if (++t >= t1) {
+      if (p_valid) flush(acc1);
+      break;
+    }
+  }
+  if constexpr ((DBG & 8) != 0) {
+    if (blockIdx.x == 17 && tid == 64) {
+      const uint64_t tot = __builtin_readcyclecounter() - dbg_start;
+      printf("[pipe dbg] tiles %d total %llu | multiply %llu bookkeeping %llu stage_x %llu prefetch %llu (cycles)\n", t1,
+             (unsigned long long)tot, (unsigned long long)dbg_t[0], (unsigned long long)dbg_t[1],
+             (unsigned long long)dbg_t[2], (unsigned long long)dbg_t[3]);
     }
   }
 }
@@ -825,6 +1193,43 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
       ProfScope prof(stream);
       hipLaunchKernelGGL((mfma_rows_kernel<T, K, MC, NW>), dim3((unsigned)(g2 * ncol)), dim3(NW * 64), wbytes, stream,
                          w.descs, w.tile_start, B, ncol);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+  }
+  if constexpr (SZ == 4 && K == 128 && (MC == 128 || MC == 64 || MC == 32)) {
+    static const bool nopipe = getenv("PYG_HIP_MM_NOPIPE") != nullptr;
+    if (!nopipe) {
+      constexpr int plds = wbytes + NW * (32 * K * SZ) + NW * 4096;
+      static_assert(plds <= 160 * 1024, "pipelined fp32 kernel: LDS");
+      const void* pk = reinterpret_cast<const void*>(&mfma_rows_f32_pipe_kernel<K, MC, NW>);
+      static thread_local bool pattr = false;
+      if (!pattr) {
+        PYG_HIP_CHECK(hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+        pattr = true;
+      }
+      int pc = std::max(1, std::min(2, (160 * 1024) / plds));
+      if (const char* e = getenv("PYG_HIP_MM_WGS")) pc = std::max(1, atoi(e));
+      int64_t g2 = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * pc);
+      if (ncol > 1) g2 = std::max<int64_t>(8, (std::min<int64_t>(g2, (int64_t)di.num_cus * pc / ncol) + 7) / 8 * 8);
+      ProfScope prof(stream);
+      if constexpr (MC == 128) {
+        static const int dbg = getenv("PYG_HIP_MM_DBG") ? atoi(getenv("PYG_HIP_MM_DBG")) : 0;
+        if (dbg) {  // timing experiments (wrong results by construction)
+          const void* dk = dbg == 1 ? (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 1>
+                         : dbg == 2 ? (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 2>
+                         : dbg == 3 ? (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 3>
+                         : dbg == 4 ? (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 4>
+                         : dbg == 8 ? (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 8>
+                                    : (const void*)&mfma_rows_f32_pipe_kernel<K, MC, NW, 7>;
+          PYG_HIP_CHECK(hipFuncSetAttribute(dk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+          void* args[] = {(void*)&w.descs, (void*)&w.tile_start, (void*)&B, (void*)&chunk, (void*)&ncol};
+          PYG_HIP_CHECK(hipLaunchKernel(dk, dim3((unsigned)(g2 * ncol)), dim3(NW * 64), args, plds, stream));
+          return PYG_HIP_OK;
+        }
+      }
+      hipLaunchKernelGGL((mfma_rows_f32_pipe_kernel<K, MC, NW>), dim3((unsigned)(g2 * ncol)), dim3(NW * 64), plds, stream,
+                         w.descs, w.tile_start, B, chunk, ncol);
       PYG_HIP_CHECK(hipGetLastError());
       return PYG_HIP_OK;
     }

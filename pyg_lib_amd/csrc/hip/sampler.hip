@@ -1088,6 +1088,75 @@ __device__ __forceinline__ void wave_mem_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// A row of up to 64 R neighbours: keys stay in registers (R per lane).
+template <bool F64, int R>
+__device__ __forceinline__ void biased_row_in_registers(const BiasedArgs<typename BiasedKey<F64>::K>& a, int64_t i,
+                                                        int lane, int64_t n, int64_t k, int64_t rs, int64_t eo,
+                                                        int64_t o0, typename BiasedKey<F64>::K* sk,
+                                                        const typename BiasedKey<F64>::W* w, int64_t src_pos,
+                                                        int64_t batch) {
+  typedef BiasedKey<F64> BK;
+  typedef typename BK::K K;
+  K x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t j = lane + 64 * r;
+    x[r] = 0;  // absent slot: below every real key (the smallest, -inf, maps to 0x007f...f)
+    if (j < n) {
+      x[r] = BK::make(a.out32, o0 + j * BK::kOutputs, w[j]);
+      sk[j] = x[r];  // the exact path reads the keys from memory
+    }
+  }
+  // T = the k-th largest key, bit by bit; absent slots hold 0 and candidates are > 0
+  K T = 0;
+  for (int b = BK::kBits - 1; b >= 0; --b) {
+    const K cand = T | ((K)1 << b);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += __popcll(__ballot(x[r] >= cand && lane + 64 * r < n));
+    if (c >= k) T = cand;
+  }
+  int sel = 0, gt = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    sel += __popcll(__ballot(x[r] >= T && lane + 64 * r < n));
+    gt += __popcll(__ballot(x[r] > T && lane + 64 * r < n));
+  }
+  // exactly k keys >= T, and the boundary key T is unique: otherwise a tie
+  bool tie = sel != k || sel - gt != 1;
+  // rank of every selected key = number of selected keys above it; equal selected keys = tie
+  int rank[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) rank[r] = 0;
+  if (!tie) {
+    bool dup = false;
+#pragma unroll
+    for (int r2 = 0; r2 < R; ++r2) {
+      u64 m = __ballot(x[r2] >= T && lane + 64 * r2 < n);
+      while (m) {
+        const int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const K y = __shfl(x[r2], q, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          rank[r] += y > x[r] ? 1 : 0;
+          dup = dup || (y == x[r] && (q != lane || r2 != r) && x[r] >= T && lane + 64 * r < n);
+        }
+      }
+    }
+    tie = __ballot(dup) != 0;
+  }
+  if (tie) {
+    if (lane == 0) a.flag[i] = 1;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t j = lane + 64 * r;
+    if (j < n && x[r] >= T) emit(a.h, eo + rank[r], rs + j, src_pos, batch);
+  }
+}
+
 template <bool F64>
 __global__ __launch_bounds__(256) void biased_sample_kernel(BiasedArgs<typename BiasedKey<F64>::K> a) {
   typedef BiasedKey<F64> BK;
@@ -1116,18 +1185,61 @@ __global__ __launch_bounds__(256) void biased_sample_kernel(BiasedArgs<typename 
   const int64_t ko = (o0 - a.out_base) / BK::kOutputs;
   K* sk = a.skey + ko;
   const typename BK::W* w = static_cast<const typename BK::W*>(a.weight) + rs;
+  if (n <= 64) {
+    biased_row_in_registers<F64, 1>(a, i, lane, n, k, rs, eo, o0, sk, w, src_pos, batch);
+    return;
+  }
+  if (n <= 256) {
+    biased_row_in_registers<F64, 4>(a, i, lane, n, k, rs, eo, o0, sk, w, src_pos, batch);
+    return;
+  }
   for (int64_t j = lane; j < n; j += 64) sk[j] = BK::make(a.out32, o0 + j * BK::kOutputs, w[j]);
   wave_mem_sync();
-  // T = the k-th largest key
+  // T = the k-th largest key: radix select, one pass over the row per 8-bit digit (per-wave LDS histogram)
+  __shared__ uint32_t hist_all[4][256];
+  uint32_t* hist = hist_all[threadIdx.x >> 6];
   K T = 0;
-  for (int b = BK::kBits - 1; b >= 0; --b) {
-    const K cand = T | ((K)1 << b);
-    int c = 0;
-    for (int64_t j = lane; j < n; j += 64) c += sk[j] >= cand ? 1 : 0;
+  int64_t krem = k;  // the krem-th largest of the keys that share the digits fixed so far
+  uint32_t c_eq = 0;
+  for (int shift = BK::kBits - 8; shift >= 0; shift -= 8) {
+    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    wave_mem_sync();
+    const K hi_mask = shift + 8 >= BK::kBits ? (K)0 : (~(K)0) << (shift + 8);
+    for (int64_t j = lane; j < n; j += 64) {
+      const K x = sk[j];
+      if ((x & hi_mask) == T) atomicAdd(&hist[(uint32_t)(x >> shift) & 255u], 1u);
+    }
+    wave_mem_sync();
+    uint32_t h[4];
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s, 64);
-    if (c >= k) T = cand;
+    for (int q = 0; q < 4; ++q) h[q] = hist[4 * lane + q];
+    const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
+    uint32_t t = s4;  // -> sum over lanes >= lane (higher lanes hold higher digits)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_down(t, off, 64);
+      if (lane + off < 64) t += v;
+    }
+    uint32_t above = t - s4;  // keys with a digit above this lane's four
+    int digit = -1;
+    uint32_t need = 0, cnt = 0;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {
+      if (digit < 0 && (int64_t)above < krem && krem <= (int64_t)above + h[q]) {
+        digit = 4 * lane + q;
+        need = (uint32_t)(krem - above);
+        cnt = h[q];
+      }
+      above += h[q];
+    }
+    const u64 m = __ballot(digit >= 0);
+    const int src = __ffsll((long long)m) - 1;  // exactly one lane finds it
+    digit = __shfl(digit, src, 64);
+    krem = __shfl(need, src, 64);
+    c_eq = __shfl(cnt, src, 64);
+    T |= (K)(uint32_t)digit << shift;
   }
+  // exactly k keys are >= T iff the boundary key is unique (c_eq == krem == 1)
   // selection = keys >= T, compacted in index order; more than k of them = a tie at the boundary
   int64_t sel = 0;
   for (int64_t j0 = 0; j0 < n; j0 += 64) {
@@ -1142,7 +1254,7 @@ __global__ __launch_bounds__(256) void biased_sample_kernel(BiasedArgs<typename 
     }
     sel += __popcll(m);
   }
-  bool tie = sel > k;
+  bool tie = sel > k || c_eq != 1 || krem != 1;
   wave_mem_sync();
   if (!tie) {
     // rank by counting; equal keys inside the selection are ties as well
