@@ -348,6 +348,29 @@ static void check_index(const Tensor& t, const char* what) {
   TORCH_CHECK(t.scalar_type() == at::kLong, "pyg (HIP): '", what, "' must be int64 on the device path");
 }
 
+// The reference dispatches the sampler on the seeds' integral type (neighbor_kernel.cpp:893,930) and returns
+// that type.  The HIP kernels are int64: an int32 graph is widened ON THE DEVICE for the call (one copy of
+// rowptr / col / seed per call) and the results are narrowed back -- same values, same generator stream.
+struct IndexArgs {
+  at::ScalarType dtype = at::kLong;
+  std::vector<Tensor> keep;  // widened copies stay alive until the call returns
+  const int64_t* ptr(const Tensor& t, const char* what) {
+    TORCH_CHECK(t.is_contiguous(), "Non-contiguous '", what, "'");
+    TORCH_CHECK(t.is_cuda(), "pyg (HIP): '", what, "' must live on a HIP device");
+    TORCH_CHECK(t.scalar_type() == dtype, "pyg (HIP): '", what, "' must have the seeds' dtype (", dtype, ")");
+    if (dtype == at::kLong) return t.data_ptr<int64_t>();
+    keep.push_back(t.to(at::kLong));
+    return keep.back().data_ptr<int64_t>();
+  }
+  Tensor narrow(const Tensor& t) const { return dtype == at::kLong ? t : t.to(dtype); }
+};
+
+static at::ScalarType index_dtype(const Tensor& seed) {
+  TORCH_CHECK(seed.scalar_type() == at::kLong || seed.scalar_type() == at::kInt,
+              "pyg (HIP): indices must be int64 or int32");
+  return seed.scalar_type();
+}
+
 struct SampleOutput {
   std::vector<Tensor> node_id, row, col, edge_id;
   std::vector<std::vector<int64_t>> nodes_per_hop, edges_per_hop;
@@ -443,13 +466,12 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
                        bool disjoint, std::string temporal_strategy, bool return_edge_id) {
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(),
               directed, disjoint, temporal_strategy);
-  check_index(rowptr, "rowptr");
-  check_index(col, "col");
-  check_index(seed, "seed");
+  IndexArgs ix;
+  ix.dtype = index_dtype(seed);
   std::vector<pyg_hip_relation> rels(1);
-  rels[0].rowptr = rowptr.data_ptr<int64_t>();
+  rels[0].rowptr = ix.ptr(rowptr, "rowptr");
   rels[0].num_rows = rowptr.numel() - 1;
-  rels[0].col = col.data_ptr<int64_t>();
+  rels[0].col = ix.ptr(col, "col");
   rels[0].num_cols = col.numel();
   rels[0].src_type = 0;
   rels[0].dst_type = 0;
@@ -462,7 +484,7 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   std::vector<pyg_hip_seed_set> seeds(1);
   seeds[0].node_type = 0;
   seeds[0].reserved = 0;
-  seeds[0].seed = seed.data_ptr<int64_t>();
+  seeds[0].seed = ix.ptr(seed, "seed");
   seeds[0].num_seed = seed.numel();
   seeds[0].seed_time = seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr;
   std::vector<const int64_t*> ntime;
@@ -470,9 +492,9 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   auto out = run_sampler(rels, seeds, ntime, temporal_strategy == "last", 1, (int)num_neighbors.size(), csc,
                          replace, disjoint, return_edge_id, rowptr.device());
   c10::optional<Tensor> eid = c10::nullopt;
-  if (return_edge_id) eid = out.edge_id[0];
-  return std::make_tuple(out.row[0], out.col[0], out.node_id[0], eid, out.nodes_per_hop[0],
-                         out.edges_per_hop[0]);
+  if (return_edge_id) eid = ix.narrow(out.edge_id[0]);
+  return std::make_tuple(ix.narrow(out.row[0]), ix.narrow(out.col[0]), ix.narrow(out.node_id[0]), eid,
+                         out.nodes_per_hop[0], out.edges_per_hop[0]);
 }
 
 std::tuple<c10::Dict<rel_type, Tensor>, c10::Dict<rel_type, Tensor>, c10::Dict<node_type, Tensor>,
@@ -494,6 +516,9 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
   std::unordered_map<std::string, int> nt_index;
   for (size_t i = 0; i < node_types.size(); ++i) nt_index[node_types[i]] = (int)i;
   size_t L = 0;
+  IndexArgs ix;
+  TORCH_CHECK(seed_dict.size() > 0, "hetero_neighbor_sample: no seeds given");
+  ix.dtype = index_dtype(seed_dict.begin()->value());  // neighbor_kernel.cpp:930
   std::vector<pyg_hip_relation> rels(edge_types.size());
   std::vector<std::vector<int64_t>> fanouts(edge_types.size());
   c10::optional<at::Device> device;
@@ -502,16 +527,14 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     const auto rel = to_rel_type(k);
     const Tensor& rowptr = rowptr_dict.at(rel);
     const Tensor& col = col_dict.at(rel);
-    check_index(rowptr, "rowptr");
-    check_index(col, "col");
     if (!device.has_value()) device = rowptr.device();
     fanouts[e] = num_neighbors_dict.at(rel);
     L = std::max(L, fanouts[e].size());
     TORCH_CHECK(nt_index.count(std::get<0>(k)) && nt_index.count(std::get<2>(k)),
                 "hetero_neighbor_sample: edge type names an unknown node type");
-    rels[e].rowptr = rowptr.data_ptr<int64_t>();
+    rels[e].rowptr = ix.ptr(rowptr, "rowptr");
     rels[e].num_rows = rowptr.numel() - 1;
-    rels[e].col = col.data_ptr<int64_t>();
+    rels[e].col = ix.ptr(col, "col");
     rels[e].num_cols = col.numel();
     rels[e].src_type = nt_index[std::get<0>(k)];
     rels[e].dst_type = nt_index[std::get<2>(k)];
@@ -531,13 +554,12 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
   std::vector<pyg_hip_seed_set> seeds;
   for (const auto& kv : seed_dict) {  // c10::Dict iterates in insertion order, as the reference relies on
     const Tensor& seed = kv.value();
-    check_index(seed, "seed");
     if (!device.has_value()) device = seed.device();
     TORCH_CHECK(nt_index.count(kv.key()), "hetero_neighbor_sample: seed type '", kv.key(), "' is not a node type");
     pyg_hip_seed_set s;
     s.node_type = nt_index[kv.key()];
     s.reserved = 0;
-    s.seed = seed.data_ptr<int64_t>();
+    s.seed = ix.ptr(seed, "seed");
     s.num_seed = seed.numel();
     s.seed_time = nullptr;
     if (seed_time_dict.has_value()) s.seed_time = time_ptr(seed_time_dict.value().at(kv.key()), "seed_time");
@@ -561,15 +583,15 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
   c10::Dict<node_type, std::vector<int64_t>> out_nph;
   c10::Dict<rel_type, std::vector<int64_t>> out_eph;
   for (size_t t = 0; t < node_types.size(); ++t) {
-    out_node.insert(node_types[t], out.node_id[t]);
+    out_node.insert(node_types[t], ix.narrow(out.node_id[t]));
     out_nph.insert(node_types[t], out.nodes_per_hop[t]);
   }
   for (size_t e = 0; e < edge_types.size(); ++e) {
     const auto rel = to_rel_type(edge_types[e]);
-    out_row.insert(rel, out.row[e]);
-    out_col.insert(rel, out.col[e]);
+    out_row.insert(rel, ix.narrow(out.row[e]));
+    out_col.insert(rel, ix.narrow(out.col[e]));
     out_eph.insert(rel, out.edges_per_hop[e]);
-    if (return_edge_id) out_eid.value().insert(rel, out.edge_id[e]);
+    if (return_edge_id) out_eid.value().insert(rel, ix.narrow(out.edge_id[e]));
   }
   return std::make_tuple(out_row, out_col, out_node, out_eid, out_nph, out_eph);
 }

@@ -205,6 +205,34 @@ def test_temporal_unsorted_neighbourhood_raises():
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0]), [2], node_time=dev(node_time), disjoint=True)
 
 
+def test_int32_graphs_match_int64_and_keep_their_dtype():
+    """The reference dispatches on the seeds' integral type (neighbor_kernel.cpp:893,930): int32 graphs give the
+    same samples, the same generator advance, and int32 outputs."""
+    rowptr, col = random_csr(3000, 12, 4)
+    seed = np.arange(0, 300, 3, dtype=np.int64)
+    for kw in (dict(), dict(replace=True), dict(disjoint=True)):
+        torch.manual_seed(77)
+        ref = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seed), [6, 3], **kw)
+        a64 = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        torch.manual_seed(77)
+        out = sampler.neighbor_sample(dev(rowptr).int(), dev(col).int(), dev(seed).int(), [6, 3], **kw)
+        a32 = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        assert a32 == a64
+        for o, r in zip(out[:4], ref[:4]):
+            assert o.dtype == torch.int32
+            assert torch.equal(o.long(), r)
+        assert out[4] == ref[4] and out[5] == ref[5]
+    et = ('n', 'to', 'n')
+    torch.manual_seed(5)
+    h64 = sampler.hetero_neighbor_sample({et: dev(rowptr)}, {et: dev(col)}, {'n': dev(seed)}, {et: [4, 2]})
+    torch.manual_seed(5)
+    h32 = sampler.hetero_neighbor_sample({et: dev(rowptr).int()}, {et: dev(col).int()}, {'n': dev(seed).int()}, {et: [4, 2]})
+    assert h32[0][et].dtype == torch.int32 and torch.equal(h32[0][et].long(), h64[0][et])
+    assert torch.equal(h32[2]['n'].long(), h64[2]['n']) and torch.equal(h32[3][et].long(), h64[3][et])
+    with pytest.raises(RuntimeError, match="seeds' dtype"):
+        sampler.neighbor_sample(dev(rowptr), dev(col).int(), dev(seed), [2])
+
+
 def test_unsupported_modes_fail_loudly():
     rowptr, col = dev(G.ROWPTR), dev(G.COL)
     with pytest.raises(RuntimeError):
