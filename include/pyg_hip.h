@@ -276,6 +276,25 @@ PYG_HIP_API int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_
                                              int64_t* cumsum_host, void* stream);
 
 /*
+ * Building blocks of pyg::hetero_relabel_neighborhood (schema sampler/dist_relabel.cpp:77-83; CPU
+ * sampler/cpu/dist_relabel_kernel.cpp:96-262): there every node type has ONE Mapper and consumes its
+ * `sampled_nodes_with_duplicates` list strictly in order, so the local id of list position j is a per-type
+ * quantity (pyg_hip_relabel_nodes), and an edge type's rows / cols are segments of source indices
+ * (pyg_hip_expand_rows) / of the destination type's local ids.
+ *   pyg_hip_relabel_nodes: local_out[j] = Mapper id of sampled[j] after the seeds (ids of first occurrences;
+ *     disjoint: keys (batch, node), the seeds carry batch ids seed_batch0, seed_batch0 + 1, ..., all batch ids
+ *     < num_batches).  Workspace: pyg_hip_relabel_workspace_size(num_seed, num_sampled).
+ *   pyg_hip_expand_rows: row_out[j] = i for count_prefix[i] <= j < count_prefix[i + 1] (device prefix of
+ *     num_src + 1 entries), j < total.
+ */
+PYG_HIP_API int pyg_hip_relabel_nodes(const int64_t* seed, int64_t num_seed, int64_t seed_batch0,
+                                      int64_t num_batches, const int64_t* sampled, int64_t num_sampled,
+                                      const int64_t* batch, int disjoint, int64_t* local_out,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+PYG_HIP_API int pyg_hip_expand_rows(const int64_t* count_prefix, int64_t num_src, int64_t total,
+                                    int64_t* row_out, void* stream);
+
+/*
  * Distributed-sampling helpers (homogeneous forms).
  *
  * pyg_hip_relabel_neighborhood replaces pyg::relabel_neighborhood (schema sampler/dist_relabel.cpp:71-76; CPU

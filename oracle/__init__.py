@@ -639,6 +639,54 @@ def relabel_neighborhood(seed, sampled_nodes_with_duplicates, num_sampled_neighb
     return (col, row) if csc else (row, col)
 
 
+def hetero_relabel_neighborhood(node_types, edge_types, seed_dict, sampled_nodes_with_duplicates_dict,
+                                num_sampled_neighbors_per_node_dict, num_nodes_dict=None, batch_dict=None,
+                                csc=False, disjoint=False):
+    """pyg::hetero_relabel_neighborhood (pyg_lib/csrc/sampler/cpu/dist_relabel_kernel.cpp:96-262, the
+    single-threaded order): one Mapper per node type (seeds first; disjoint: batch ids run on across the seed
+    types, :181-192); per layer, per edge type (in `edge_types` order), per source node i of that layer's range
+    (:199-236) the next `count` nodes of the DESTINATION type's list are inserted; row = i.  The source ranges
+    of the next layer start behind the largest range end of the edge types sharing the source type (:239-255).
+    `num_sampled_neighbors_per_node_dict[edge_type]` is a list (layers) of lists (counts per source node)."""
+    ids = {t: {} for t in node_types}
+    b = 0
+    for t, seed in seed_dict.items():
+        for v in np.asarray(seed, dtype=np.int64).tolist():
+            ids[t].setdefault((b, v) if disjoint else v, len(ids[t]))
+            b += 1
+    nodes = {t: np.asarray(sampled_nodes_with_duplicates_dict[t], dtype=np.int64) for t in node_types}
+    pos = {t: 0 for t in node_types}
+    rows = {k: [] for k in edge_types}
+    cols = {k: [] for k in edge_types}
+    counts = num_sampled_neighbors_per_node_dict
+    slices = {k: (0, len(counts[k][0])) for k in edge_types}
+    src_off = {t: 0 for t in node_types}
+    num_layers = len(counts[edge_types[0]])
+    for ell in range(num_layers):
+        for k in edge_types:
+            dst = k[2] if not csc else k[0]
+            lo, hi = slices[k]
+            for i in range(lo, hi):
+                for _ in range(int(counts[k][ell][i - lo])):
+                    j = pos[dst]
+                    key = (int(batch_dict[dst][j]), int(nodes[dst][j])) if disjoint else int(nodes[dst][j])
+                    cols[k].append(ids[dst].setdefault(key, len(ids[dst])))
+                    rows[k].append(i)
+                    pos[dst] = j + 1
+        if ell < num_layers - 1:
+            for k in edge_types:
+                src = k[0] if not csc else k[2]
+                src_off[src] = max(src_off[src], slices[k][1])
+            for k in edge_types:
+                src = k[0] if not csc else k[2]
+                slices[k] = (src_off[src], src_off[src] + len(counts[k][ell + 1]))
+    out_row, out_col = {}, {}
+    for k in edge_types:
+        r, c = np.asarray(rows[k], dtype=np.int64), np.asarray(cols[k], dtype=np.int64)
+        out_row[k], out_col[k] = (c, r) if csc else (r, c)
+    return out_row, out_col
+
+
 def merge_sampler_outputs(node_ids, edge_ids, cumsum_neighbors_per_node, partition_ids, partition_orders,
                           num_partitions, num_neighbors, batch=None, disjoint=False):
     """pyg::merge_sampler_outputs (pyg_lib/csrc/sampler/cpu/dist_merge_outputs_kernel.cpp:17-138): the

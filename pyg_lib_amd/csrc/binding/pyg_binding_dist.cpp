@@ -1,5 +1,5 @@
-// torch::Library binding of the distributed-sampling helpers pyg::relabel_neighborhood and
-// pyg::merge_sampler_outputs (homogeneous forms).  Schemas byte-identical to
+// torch::Library binding of the distributed-sampling helpers pyg::relabel_neighborhood,
+// pyg::hetero_relabel_neighborhood and pyg::merge_sampler_outputs.  Schemas byte-identical to
 // pyg_lib/csrc/sampler/dist_relabel.cpp:71-76 and sampler/dist_merge_outputs.cpp:51-55; argument checks follow
 // sampler/cpu/dist_relabel_kernel.cpp:37-48.  Kernels: csrc/hip/sampler.hip through the C-ABI.
 #include <torch/library.h>
@@ -120,6 +120,158 @@ std::tuple<Tensor, Tensor, std::optional<Tensor>, std::vector<int64_t>> merge_sa
 }  // namespace
 
 // sampler/dist_relabel.cpp:71-76, sampler/dist_merge_outputs.cpp:51-55
+typedef std::string node_type;
+typedef std::string rel_type;
+typedef std::tuple<std::string, std::string, std::string> edge_type;
+inline rel_type rel_of(const edge_type& k) { return std::get<0>(k) + "__" + std::get<1>(k) + "__" + std::get<2>(k); }
+
+// pyg::hetero_relabel_neighborhood (sampler/cpu/dist_relabel_kernel.cpp:96-262).  Every node type has one
+// Mapper and its sampled list is consumed strictly in order, so the local ids are computed per node type
+// (pyg_hip_relabel_nodes) and every (edge type, layer) is a segment: rows = the layer's source range expanded
+// by the per-source counts, cols = the next slice of the destination type's local ids.
+std::tuple<c10::Dict<rel_type, Tensor>, c10::Dict<rel_type, Tensor>> hetero_relabel_neighborhood_kernel(
+    const std::vector<node_type>& node_types, const std::vector<edge_type>& edge_types,
+    const c10::Dict<node_type, Tensor>& seed_dict, const c10::Dict<node_type, Tensor>& sampled_nodes_with_duplicates_dict,
+    const c10::Dict<rel_type, std::vector<std::vector<int64_t>>>& num_sampled_neighbors_per_node_dict,
+    const c10::Dict<node_type, int64_t>& num_nodes_dict, const std::optional<c10::Dict<node_type, Tensor>>& batch_dict,
+    bool csc, bool disjoint) {
+  (void)num_nodes_dict;  // capacity hints of the reference's Mappers
+  TORCH_CHECK(!edge_types.empty(), "hetero_relabel_neighborhood: no edge types");
+  if (disjoint) TORCH_CHECK(batch_dict.has_value(), "Batch needs to be specified to create disjoint subgraphs");
+  std::optional<at::Device> device;
+  int64_t total_seeds = 0;
+  for (const auto& kv : seed_dict) total_seeds += kv.value().numel();
+  // per node type: local ids of the whole sampled list
+  std::unordered_map<std::string, Tensor> local;
+  std::unordered_map<std::string, int64_t> seed_batch0;
+  {
+    int64_t b = 0;
+    for (const auto& kv : seed_dict) {  // batch ids run on across the seed types (:181-192)
+      seed_batch0[kv.key()] = b;
+      b += kv.value().numel();
+    }
+  }
+  for (const auto& t : node_types) {
+    TORCH_CHECK(sampled_nodes_with_duplicates_dict.contains(t), "hetero_relabel_neighborhood: no sampled nodes for type '", t, "'");
+    const Tensor& nodes = sampled_nodes_with_duplicates_dict.at(t);
+    TORCH_CHECK(nodes.is_cuda(), "hetero_relabel_neighborhood: tensors must live on a HIP device");
+    TORCH_CHECK(nodes.scalar_type() == at::kLong, "hetero_relabel_neighborhood: int64 node ids expected on the device path");
+    TORCH_CHECK(nodes.is_contiguous(), "Non-contiguous 'sampled_nodes_with_duplicates'");
+    if (!device.has_value()) device = nodes.device();
+    DeviceGuard guard(nodes.device());
+    const int64_t E = nodes.numel();
+    Tensor seed;
+    if (seed_dict.contains(t)) {
+      seed = seed_dict.at(t);
+      TORCH_CHECK(seed.is_cuda() && seed.scalar_type() == at::kLong && seed.is_contiguous(),
+                  "hetero_relabel_neighborhood: contiguous int64 device 'seed' expected");
+    }
+    const int64_t S = seed.defined() ? seed.numel() : 0;
+    const int64_t* batch = nullptr;
+    if (disjoint) {
+      TORCH_CHECK(batch_dict.value().contains(t), "hetero_relabel_neighborhood: no batch vector for type '", t, "'");
+      const Tensor& bt = batch_dict.value().at(t);
+      TORCH_CHECK(bt.is_cuda() && bt.scalar_type() == at::kLong && bt.is_contiguous() && bt.numel() == E,
+                  "hetero_relabel_neighborhood: 'batch' must be a contiguous int64 device tensor, one entry per node");
+      batch = bt.data_ptr<int64_t>();
+    }
+    auto out = at::empty({E}, nodes.options());
+    if (E > 0) {
+      auto ws = at::empty({(int64_t)pyg_hip_relabel_workspace_size(S, E)}, nodes.options().dtype(at::kByte));
+      check_status(pyg_hip_relabel_nodes(S ? seed.data_ptr<int64_t>() : nullptr, S, S ? seed_batch0[t] : 0,
+                                         std::max<int64_t>(total_seeds, 1), nodes.data_ptr<int64_t>(), E, batch,
+                                         disjoint ? 1 : 0, out.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(),
+                                         current_stream(nodes)));
+    }
+    local[t] = out;
+  }
+  TORCH_CHECK(device.has_value(), "hetero_relabel_neighborhood: no node types");
+  DeviceGuard guard(device.value());
+  const auto opts = at::TensorOptions().dtype(at::kLong).device(device.value());
+  const size_t num_layers = num_sampled_neighbors_per_node_dict.at(rel_of(edge_types[0])).size();
+  // host walk of the (layer, edge type) segments (:194-256)
+  std::unordered_map<std::string, int64_t> dst_pos, src_off;
+  for (const auto& t : node_types) {
+    dst_pos[t] = 0;
+    src_off[t] = 0;
+  }
+  struct Seg {
+    int64_t src_begin, dst_begin, edges;
+    const std::vector<int64_t>* counts;
+  };
+  std::vector<std::vector<Seg>> segs(edge_types.size());
+  std::vector<std::pair<int64_t, int64_t>> slice(edge_types.size());
+  for (size_t e = 0; e < edge_types.size(); ++e)
+    slice[e] = {0, (int64_t)num_sampled_neighbors_per_node_dict.at(rel_of(edge_types[e]))[0].size()};
+  // the Dict hands out copies: keep them alive while Seg points into them
+  std::vector<std::vector<std::vector<int64_t>>> counts_keep(edge_types.size());
+  for (size_t e = 0; e < edge_types.size(); ++e) counts_keep[e] = num_sampled_neighbors_per_node_dict.at(rel_of(edge_types[e]));
+  for (size_t ell = 0; ell < num_layers; ++ell) {
+    for (size_t e = 0; e < edge_types.size(); ++e) {
+      const auto& k = edge_types[e];
+      const std::string& dst = !csc ? std::get<2>(k) : std::get<0>(k);
+      TORCH_CHECK(counts_keep[e].size() > ell, "hetero_relabel_neighborhood: edge types list different numbers of layers");
+      const auto& cnt = counts_keep[e][ell];
+      TORCH_CHECK((int64_t)cnt.size() == slice[e].second - slice[e].first, "hetero_relabel_neighborhood: layer size mismatch");
+      int64_t n = 0;
+      for (int64_t c : cnt) n += c;
+      TORCH_CHECK(dst_pos.count(dst), "hetero_relabel_neighborhood: edge type names an unknown node type");
+      TORCH_CHECK(dst_pos[dst] + n <= local[dst].numel(), "hetero_relabel_neighborhood: more sampled neighbours announced than nodes given");
+      segs[e].push_back({slice[e].first, dst_pos[dst], n, &cnt});
+      dst_pos[dst] += n;
+    }
+    if (ell + 1 < num_layers) {
+      for (size_t e = 0; e < edge_types.size(); ++e) {
+        const std::string& src = !csc ? std::get<0>(edge_types[e]) : std::get<2>(edge_types[e]);
+        src_off[src] = std::max(src_off[src], slice[e].second);
+      }
+      for (size_t e = 0; e < edge_types.size(); ++e) {
+        const std::string& src = !csc ? std::get<0>(edge_types[e]) : std::get<2>(edge_types[e]);
+        slice[e] = {src_off[src], src_off[src] + (int64_t)counts_keep[e][ell + 1].size()};
+      }
+    }
+  }
+  c10::Dict<rel_type, Tensor> out_row, out_col;
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    const auto& k = edge_types[e];
+    const std::string& dst = !csc ? std::get<2>(k) : std::get<0>(k);
+    int64_t E = 0, nsrc = 0;
+    for (const Seg& sg : segs[e]) {
+      E += sg.edges;
+      nsrc += (int64_t)sg.counts->size();
+    }
+    // one prefix over all layers' sources: the expanded index is the position in that list; its source id is
+    // src_begin(layer) + position inside the layer -> a second small table maps list position to source id
+    auto meta_cpu = at::empty({2 * nsrc + 1}, at::TensorOptions().dtype(at::kLong));
+    int64_t* prefix = meta_cpu.data_ptr<int64_t>();
+    int64_t* src_id = prefix + nsrc + 1;
+    prefix[0] = 0;
+    int64_t q = 0;
+    for (const Seg& sg : segs[e])
+      for (size_t i = 0; i < sg.counts->size(); ++i, ++q) {
+        prefix[q + 1] = prefix[q] + (*sg.counts)[i];
+        src_id[q] = sg.src_begin + (int64_t)i;
+      }
+    auto row = at::empty({E}, opts);
+    std::vector<Tensor> parts;
+    for (const Seg& sg : segs[e]) parts.push_back(local[dst].narrow(0, sg.dst_begin, sg.edges));
+    Tensor col = parts.empty() ? at::empty({0}, opts) : at::cat(parts);
+    if (E > 0) {
+      auto meta = meta_cpu.to(device.value());
+      check_status(pyg_hip_expand_rows(meta.data_ptr<int64_t>(), nsrc, E, row.data_ptr<int64_t>(), current_stream(row)));
+      row = meta.narrow(0, nsrc + 1, nsrc).index_select(0, row);  // list position -> source id
+    }
+    if (!csc) {
+      out_row.insert(rel_of(k), row);
+      out_col.insert(rel_of(k), col);
+    } else {
+      out_row.insert(rel_of(k), col);
+      out_col.insert(rel_of(k), row);
+    }
+  }
+  return std::make_tuple(out_row, out_col);
+}
+
 TORCH_LIBRARY_FRAGMENT(pyg, m) {
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::relabel_neighborhood(Tensor seed, Tensor sampled_nodes_with_duplicates, int[] "
@@ -129,11 +281,22 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
       "pyg::merge_sampler_outputs(Tensor[] node_ids, Tensor[] edge_ids, int[][] cumsum_neighbors_per_node, int[] "
       "partition_ids, int[] partition_orders, int num_partitions, int num_neighbors, Tensor? batch, bool disjoint) -> "
       "(Tensor, Tensor, Tensor?, int[])"));
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::hetero_relabel_neighborhood(str[] node_types, (str, str, str)[] edge_types, Dict(str, Tensor) seed_dict, "
+      "Dict(str, Tensor) sampled_nodes_with_duplicates_dict, Dict(str, int[][]) num_sampled_neighbors_per_node_dict, "
+      "Dict(str, int) num_nodes_dict, Dict(str, Tensor)? batch_dict = None, bool csc = False, bool disjoint = False) -> "
+      "(Dict(str, Tensor), Dict(str, Tensor))"));
 }
 
 TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::relabel_neighborhood"), TORCH_FN(relabel_neighborhood_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::merge_sampler_outputs"), TORCH_FN(merge_sampler_outputs_kernel));
+}
+
+// Tensors inside Dicts cannot drive dispatch (the reference registers this op under BackendSelect too,
+// sampler/cpu/dist_relabel_kernel.cpp:315-318): the kernel checks the device itself.
+TORCH_LIBRARY_IMPL(pyg, BackendSelect, m) {
+  m.impl(TORCH_SELECTIVE_NAME("pyg::hetero_relabel_neighborhood"), TORCH_FN(hetero_relabel_neighborhood_kernel));
 }
 
 }  // namespace pyg_amd

@@ -3058,21 +3058,20 @@ extern "C" size_t pyg_hip_relabel_workspace_size(int64_t num_seed, int64_t num_s
   return relabel_ws_bytes(num_seed < 0 ? 0 : num_seed, num_sampled < 0 ? 0 : num_sampled);
 }
 
-extern "C" int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_seed, const int64_t* sampled,
-                                            int64_t num_sampled, const int64_t* count_prefix, int64_t num_src,
-                                            const int64_t* batch, int disjoint, int64_t* row_out, int64_t* col_out,
-                                            void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int64_t S = num_seed, E = num_sampled;
-  PYG_HIP_REQUIRE(S >= 0 && E >= 0 && num_src >= 0, "relabel_neighborhood: negative size");
+// Local ids (Mapper order) of an externally sampled node sequence: the seeds first (batch ids seed_batch0,
+// seed_batch0 + 1, ... when disjoint), then the sequence; local_out[j] = id of sampled[j].
+static int relabel_nodes_impl(const int64_t* seed, int64_t S, int64_t seed_batch0, int64_t num_batches,
+                              const int64_t* sampled, int64_t E, const int64_t* batch, int disjoint, int64_t* local_out,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  using namespace pyg_hip;
+  PYG_HIP_REQUIRE(S >= 0 && E >= 0, "relabel: negative size");
   if (E == 0) return PYG_HIP_OK;
-  PYG_HIP_REQUIRE((S == 0 || seed) && sampled && count_prefix && row_out && col_out, "relabel_neighborhood: NULL argument");
+  PYG_HIP_REQUIRE((S == 0 || seed) && sampled && local_out, "relabel: NULL argument");
   PYG_HIP_REQUIRE(!disjoint || batch, "Batch needs to be specified to create disjoint subgraphs");
   if (workspace == nullptr || workspace_bytes < relabel_ws_bytes(S, E))
-    return fail(PYG_HIP_ERR_WORKSPACE, "relabel_neighborhood: workspace of %zu bytes needed, got %zu", relabel_ws_bytes(S, E),
-                workspace_bytes);
-  const int64_t num_batches = disjoint ? std::max<int64_t>(S, 1) : 1;
-  PYG_HIP_REQUIRE(num_batches < (1ll << 22), "relabel_neighborhood: too many seeds for disjoint relabelling");
+    return fail(PYG_HIP_ERR_WORKSPACE, "relabel: workspace of %zu bytes needed, got %zu", relabel_ws_bytes(S, E), workspace_bytes);
+  if (!disjoint) num_batches = 1;
+  PYG_HIP_REQUIRE(num_batches >= 1 && num_batches < (1ll << 22), "relabel: too many seeds for disjoint relabelling");
   u64 cap = 1024;
   while (cap < 2 * (u64)(S + E)) cap <<= 1;
   char* w = static_cast<char*>(workspace);
@@ -3093,7 +3092,7 @@ extern "C" int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_see
   PYG_HIP_CHECK(hipMemsetAsync(ts, 0, sizeof(TypeState), stream));
   if (S > 0) {
     // seeds: mapper.fill(seed) / insert({i, seed[i]}) -- ids of first occurrences in position order
-    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, seed, S, (int64_t)0,
+    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, seed, S, seed_batch0,
                        disjoint, num_batches, t, seed_copy, seed_batch, seed_slots, ts);
     PYG_HIP_CHECK(hipGetLastError());
     FlagLoad fl{seed_slots, t.vals};
@@ -3109,9 +3108,43 @@ extern "C" int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_see
   AssignStore as{slots, t.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, ts};
   int rc = device_scan<int64_t, SumOp>(fl, as, E, tile_buf, tile_buf + (E + kScanTile - 1) / kScanTile + 1, stream);
   if (rc != PYG_HIP_OK) return rc;
-  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, slots, t.vals, E, col_out,
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, slots, t.vals, E, local_out,
                      (const HopInfo*)nullptr, (HopInfo*)nullptr, (ChainState*)nullptr, (TypeState*)nullptr,
                      (const int64_t*)nullptr, (int64_t*)nullptr);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+extern "C" int pyg_hip_relabel_nodes(const int64_t* seed, int64_t num_seed, int64_t seed_batch0, int64_t num_batches,
+                                     const int64_t* sampled, int64_t num_sampled, const int64_t* batch, int disjoint,
+                                     int64_t* local_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return relabel_nodes_impl(seed, num_seed, seed_batch0, num_batches, sampled, num_sampled, batch, disjoint, local_out,
+                            workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pyg_hip_expand_rows(const int64_t* count_prefix, int64_t num_src, int64_t total, int64_t* row_out, void* stream) {
+  using namespace pyg_hip;
+  if (total <= 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(count_prefix && row_out && num_src >= 0, "expand_rows: bad argument");
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     count_prefix, num_src, total, row_out);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+extern "C" int pyg_hip_relabel_neighborhood(const int64_t* seed, int64_t num_seed, const int64_t* sampled,
+                                            int64_t num_sampled, const int64_t* count_prefix, int64_t num_src,
+                                            const int64_t* batch, int disjoint, int64_t* row_out, int64_t* col_out,
+                                            void* workspace, size_t workspace_bytes, void* stream_) {
+  using namespace pyg_hip;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t S = num_seed, E = num_sampled;
+  PYG_HIP_REQUIRE(S >= 0 && E >= 0 && num_src >= 0, "relabel_neighborhood: negative size");
+  if (E == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(count_prefix && row_out && col_out, "relabel_neighborhood: NULL argument");
+  int rc = relabel_nodes_impl(seed, S, 0, std::max<int64_t>(S, 1), sampled, E, batch, disjoint, col_out, workspace,
+                              workspace_bytes, stream);
+  if (rc != PYG_HIP_OK) return rc;
   hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, count_prefix, num_src, E,
                      row_out);
   PYG_HIP_CHECK(hipGetLastError());

@@ -118,3 +118,15 @@ RELABEL_CASES = [
     dict(name='relabel_disjoint', seed=[2, 3], sampled=[1, 3, 2, 4], counts=[2, 2], num_nodes=6, batch=[0, 0, 1, 1],
          disjoint=True, row=[0, 0, 1, 1], col=[2, 3, 4, 5]),
 ]
+
+
+# test/csrc/sampler/test_dist_relabel.cpp:81-275 -- hetero_relabel_neighborhood on the cycle graph, one node
+# type "paper", one edge type; num_sampled_neighbors_per_node = 2 layers x [2]
+HETERO_RELABEL_CASES = [
+    dict(name='hetero_relabel', kwargs={}, seed=[2, 3], sampled=[1, 3, 2, 4], counts=[[2], [2]],
+         row=[0, 0, 1, 1], col=[2, 1, 0, 3]),                                    # :81-138
+    dict(name='hetero_relabel_csc', kwargs=dict(csc=True), seed=[2, 3], sampled=[1, 3, 2, 4], counts=[[2], [2]],
+         row=[2, 1, 0, 3], col=[0, 0, 1, 1]),                                    # :140-204
+    dict(name='hetero_relabel_disjoint', kwargs=dict(disjoint=True), seed=[2, 3], sampled=[1, 3, 2, 4],
+         counts=[[2], [2]], batch=[0, 0, 1, 1], row=[0, 0, 1, 1], col=[2, 3, 4, 5]),  # :206-275
+]
