@@ -1,6 +1,6 @@
 """Differential fuzzing of the HIP sampler against the oracle: random homogeneous / heterogeneous graphs,
-fan-outs (incl. 0, -1, > 64), duplicate seeds, replace / disjoint / temporal modes; every output and the
-generator state must match bit for bit.    python tools/fuzz_sampler.py [cases] [seed]"""
+fan-outs (incl. 0, -1, > 64), duplicate seeds, replace / disjoint / temporal / biased (edge_weight) modes, int32
+graphs; every output and the generator state must match bit for bit.    python tools/fuzz_sampler.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -27,8 +27,21 @@ def run(cases=200, seed=0):
                 for _ in range(L)]
 
 
+    def weights(n):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            w = rng.random(n) + 0.01
+        elif kind == 1:
+            w = np.ones(n)
+        elif kind == 2:
+            w = (rng.random(n) < 0.4).astype(np.float64)  # zero weights: -inf keys, ties
+        else:
+            w = rng.integers(1, 3, n).astype(np.float64)
+        return w.astype(np.float32 if rng.random() < 0.6 else np.float64)
+
+
     t0 = time.time()
-    nh = nt = 0
+    nh = nt = nb = 0
     for it in range(cases):
         seed = int(rng.integers(0, 2 ** 31))
         replace, disjoint = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -56,9 +69,23 @@ def run(cases=200, seed=0):
                     kw['edge_time'] = et
                     kw['seed_time'] = rng.integers(0, 60, seeds.size, dtype=np.int64)
                 nt += 1
+            biased = 'temporal_strategy' not in kw and rng.random() < 0.3
+            if biased:
+                kw['replace'] = False
+                kw['edge_weight'] = weights(cl.size)
+                nb += 1
             fan = fanout(L)
             torch.manual_seed(seed)
             dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+            if not biased and rng.random() < 0.15:  # int32 graph: same samples, int32 outputs
+                o32 = sampler.neighbor_sample(dev(rp).int(), dev(cl).int(), dev(seeds.astype(np.int64)).int(), fan, **dkw)
+                assert all(o32[i].dtype == torch.int32 for i in range(4))
+                torch.manual_seed(seed)
+                o64 = sampler.neighbor_sample(dev(rp), dev(cl), dev(seeds.astype(np.int64)), fan, **dkw)
+                if not all(torch.equal(o32[i].long(), o64[i]) for i in range(4)):
+                    print('MISMATCH int32 vs int64 at case', it, 'seed', seed)
+                    return False
+                torch.manual_seed(seed)
             out = sampler.neighbor_sample(dev(rp), dev(cl), dev(seeds.astype(np.int64)), fan, **dkw)
             after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
             ref = oracle.neighbor_sample(rp, cl, seeds.astype(np.int64), fan, rng_seed=seed, **kw)
@@ -78,11 +105,18 @@ def run(cases=200, seed=0):
             seed_types = [t for t in types if rng.random() < 0.6] or [types[0]]
             seeds = {t: rng.integers(0, sizes[t], int(rng.integers(1, 40))).astype(np.int64) for t in seed_types}
             fan = {e: fanout(L) for e in ets}
+            wd = None
+            if rng.random() < 0.3:  # biased: every relation weighted
+                replace = False
+                wd = {e: weights(cl[e].size) for e in ets}
+                nb += 1
             torch.manual_seed(seed)
             out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
-                                                 {k: dev(v) for k, v in seeds.items()}, fan, replace=replace, disjoint=disjoint)
+                                                 {k: dev(v) for k, v in seeds.items()}, fan, replace=replace, disjoint=disjoint,
+                                                 edge_weight_dict=None if wd is None else {e: dev(v) for e, v in wd.items()})
             after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
-            ref = oracle.hetero_neighbor_sample(types, ets, rp, cl, seeds, fan, replace=replace, disjoint=disjoint, rng_seed=seed)
+            ref = oracle.hetero_neighbor_sample(types, ets, rp, cl, seeds, fan, replace=replace, disjoint=disjoint, rng_seed=seed,
+                                                edge_weight_dict=wd)
             ok = True
             for e in ets:
                 ok = ok and torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e])) and torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
@@ -94,11 +128,11 @@ def run(cases=200, seed=0):
                     ok = ok and ref[2][t].size == 0
             info = ref[6]
             nh += 1
-        ok = ok and after == int(oracle.mt19937_words(seed, info['rng_blocks'] * 128 + 1)[-1])
+        ok = ok and after == oracle.mt19937_word_after(seed, info['rng_blocks'] * 256 + info['rng_raw_draws'])
         if not ok:
             print('MISMATCH at case', it, 'seed', seed, 'replace', replace, 'disjoint', disjoint, 'L', L)
             return False
-    print(f'{cases} cases ({nh} hetero, {nt} temporal) match the oracle bit for bit in {time.time() - t0:.1f}s')
+    print(f'{cases} cases ({nh} hetero, {nt} temporal, {nb} biased) match the oracle bit for bit in {time.time() - t0:.1f}s')
     return True
 
 
