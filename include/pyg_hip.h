@@ -235,9 +235,10 @@ typedef struct {
  * partial_sort / nth_element + sort leave them, ATen/native/TopKImpl.h).  The device path reproduces that
  * stream and that order; `log` is the correctly rounded logarithm where libtorch calls MKL's (<1 ulp, closed
  * source: 15,372 of the 2^24 possible float32 arguments round differently), so a selection can differ from
- * the reference's only if two keys of one row lie within one ulp of each other.  Needs host->mt19937,
- * replace == 0, no temporal arguments, and every sampled relation weighted; anything else fails with
- * PYG_HIP_ERR_UNSUPPORTED.
+ * the reference's only if two keys of one row lie within one ulp of each other.  Weighted and unweighted
+ * relations may be mixed (the engine's later 128-word blocks then lie behind the weighted relations' draws in
+ * the generator stream, as in the reference).  Needs host->mt19937, replace == 0 and no temporal arguments;
+ * anything else fails with PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,

@@ -350,6 +350,39 @@ struct CountStore {
   }
 };
 
+// tempered engine output o of the device-generated stream (mt_emit's layout: little-endian u64 words, even
+// output = high half with bit 63 flipped)
+__device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ out32, int64_t o) {
+  return (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
+}
+
+// Where the engine's 128-word blocks lie in the generated stream.  Normally block b = outputs [256 b, 256 b + 256);
+// when weighted (biased) relations of the same call have drawn `shift` outputs straight from the generator
+// before a block was fetched, that block lies `shift` outputs further on: blocks up to b0 (fetched before this
+// relation started) at shift_old, later ones at shift_new.
+struct WordSrc {
+  const u64* words;
+  int64_t b0;
+  int64_t shift_old, shift_new;
+  __device__ u64 at(int64_t word) const {
+    const int64_t b = word >> 7;
+    const int j = 127 - (int)(word & 127);
+    const int64_t shift = b <= b0 ? shift_old : shift_new;
+    u64 w;
+    if (shift == 0) {
+      w = words[b * 128 + j];
+    } else {
+      const uint32_t* o32 = reinterpret_cast<const uint32_t*>(words);
+      const int64_t o = 256 * b + shift + 2 * j;
+      w = ((u64)(mt_output_at(o32, o) ^ 0x80000000u) << 32) | mt_output_at(o32, o + 1);
+    }
+    // uniform_int_from_to's `x % (2^64 - 1)` differs from x only for x == 2^64 - 1 (-> 0); the device
+    // generator stores x + INT64_MIN un-reduced (so the stream stays invertible, mt_finish_kernel)
+    if (w == 0x7fffffffffffffffull) w = 0x8000000000000000ull;
+    return w;
+  }
+};
+
 // Device-resident results of one hop of one relation; published to pinned host memory by the hop's
 // last kernel so that the host needs ONE synchronisation per hop.
 struct HopInfo {
@@ -383,6 +416,9 @@ struct HopArgs {
   const int64_t* rng_word;
   const int32_t* rng_units;
   const u64* words;           // all prefetched RNG words, block-major
+  int64_t word_b0 = INT64_MAX;  // WordSrc: blocks <= word_b0 lie at shift_old, later ones at shift_new
+  int64_t shift_old = 0, shift_new = 0;
+  __device__ WordSrc word_src() const { return WordSrc{words, word_b0, shift_old, shift_new}; }
   // emission buffers of this hop
   int64_t* e_row;
   int64_t* e_node;            // global dst node id
@@ -395,7 +431,7 @@ struct HopArgs {
 struct RngCursor {
   int64_t word;
   int units;
-  const u64* words;
+  WordSrc words;
   // rand_engine.h:41-76 with the buffer laid out block-major: linear word index W lives at
   // words[(W / 128) * 128 + (127 - W % 128)] (the reference consumes each 128-word block from
   // its tail).
@@ -405,10 +441,7 @@ struct RngCursor {
       ++word;
       units = 4;
     }
-    u64 w = words[(word >> 7) * 128 + (127 - (word & 127))];
-    // uniform_int_from_to's `x % (2^64 - 1)` differs from x only for x == 2^64 - 1 (-> 0); the device
-    // generator stores x + INT64_MIN un-reduced (so the stream stays invertible, mt_finish_kernel)
-    if (w == 0x7fffffffffffffffull) w = 0x8000000000000000ull;
+    const u64 w = words.at(word);
     const int shift = (4 - units) * 16;
     u64 v = w >> shift;
     if (n == 1) v &= 0xffffull;
@@ -484,7 +517,7 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
     return;
   }
 
-  RngCursor rng{a.rng_word[i], a.rng_units[i], a.words};
+  RngCursor rng{a.rng_word[i], a.rng_units[i], a.word_src()};
   if (a.replace) {
     // `count` independent draws from [0, deg) (:196-210); lanes take turns holding a draw
     int64_t mine = 0;
@@ -574,8 +607,7 @@ __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
         word = w0 + 1 + t / per;
         unit = (t % per) * n;
       }
-      u64 w = a.words[(word >> 7) * 128 + (127 - (word & 127))];
-      if (w == 0x7fffffffffffffffull) w = 0x8000000000000000ull;
+      const u64 w = a.word_src().at(word);
       val = w >> (unit * 16);
       if (n == 1) val &= 0xffffull;
       else if (n == 2) val &= 0xffffffffull;
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
       else val = val % range;
     } else {
       // the draw width changes inside this node's sequence (degree straddles 2^16 / 2^32): walk it
-      RngCursor rng{w0, u0, a.words};
+      RngCursor rng{w0, u0, a.word_src()};
       val = 0;
       for (int t = 0; t <= g; ++t) val = rng.next((u64)(deg - count + t) + 1);
     }
@@ -1001,9 +1033,6 @@ __global__ __launch_bounds__(256) void mt_finish_kernel(const uint32_t* __restri
 //     order: one wave per row finds the count-th largest key bit by bit and ranks the selection by
 //     counting.  Rows WITH such ties (zero weights -> -inf keys; equal weights with equal 24-bit draws) are
 //     re-done by biased_exact_kernel, which performs libstdc++'s algorithms step for step.
-__device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ out32, int64_t o) {
-  return (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];  // mt_emit's layout
-}
 
 // float32 logarithm of the biased path: the f64 log rounded once (pinned on all 2^24 arguments uniform_ can
 // produce through pyg_hip_biased_log_f32, tests/test_biased_sampler_gpu.py)
@@ -1643,8 +1672,8 @@ struct RngHost {
   int64_t dev_cap_blocks = 0;
   int64_t word = 0;           // engine state: linear word index
   int units = 4;              //               16-bit units left in that word
-  int64_t raw_used = 0;       // generator outputs consumed directly (biased sampling's uniform_), behind the
-                              // engine's blocks -- only ever non-zero while the engine holds its first block
+  int64_t raw_used = 0;       // generator outputs consumed directly so far (biased sampling's uniform_)
+  int64_t cur_shift = 0;      // raw_used at the time the engine's CURRENT block was fetched (WordSrc)
   // device continuation of the caller's mt19937 (fast path)
   bool engine = false;
   MtDev init;                 // the caller's engine at call start
@@ -1939,15 +1968,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (replace) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling with replacement (at::multinomial) is not available on the device path");
     if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
     for (int e = 0; e < num_relations; ++e) {
-      if (rels[e].edge_weight) {
+      if (rels[e].edge_weight)
         PYG_HIP_REQUIRE(rels[e].edge_weight_dtype == PYG_F32 || rels[e].edge_weight_dtype == PYG_F64,
                         "sampler: edge_weight must be float32 or float64");
-        continue;
-      }
-      bool samples = false;
-      for (int ell = 0; ell < L; ++ell) samples = samples || rels[e].num_neighbors_host[ell] != 0;
-      if (samples && rels[e].num_cols > 0)
-        return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: mixing weighted and unweighted relations in one call is not available on the device path");
     }
     fast = false;  // the draws of a hop are only known after its degree scan
   }
@@ -2323,6 +2346,11 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     a.rng_word = q.rng_word;
     a.rng_units = q.rng_units;
     a.words = rng.dev;
+    if (any_biased) {  // blocks may lie behind outputs that weighted relations drew in between (WordSrc)
+      a.word_b0 = rng.word >> 7;
+      a.shift_old = rng.cur_shift;
+      a.shift_new = rng.raw_used;
+    }
     a.e_row = st.row.p + st.row.size;
     a.e_node = q.e_node;
     a.e_batch = q.e_batch;
@@ -2389,6 +2417,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       const int64_t E = hi->tot.edges, U = hi->uniq;
       if (E > 0) {
         if (rng.engine) rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
+        if ((end_word >> 7) > (rng.word >> 7)) rng.cur_shift = rng.raw_used;  // the current block is a new one
         rng.word = end_word;
         rng.units = tab_nb(tab, rng.units);
       }
@@ -2599,7 +2628,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         }
         // Unbounded / large fan-outs and the host-callback word source (which must draw exactly what is
         // consumed) need the count-scan total on the host before anything can be sized: they run alone.
-        const bool presync = count < 0 || count > 64 || !rng.engine;
+        // (with weighted relations in the call the engine's block positions depend on what ran before: alone too)
+        const bool presync = count < 0 || count > 64 || !rng.engine || any_biased;
         if (presync && !pend.empty()) {
           flush = true;
         } else {
@@ -2645,8 +2675,14 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
             }
             // make the consumed random words resident (drawn by the caller's generator)
             const int64_t end_word = rng.word + tab_dw(info_host[e].tot.tab, rng.units);
-            if (rng.engine) rc = rng_wait(c, rng, end_word, &avail_blocks);
-            else rc = rng_ensure(c, rng, end_word);
+            if (any_biased) {
+              rc = rng_wait32(c, rng, (end_word / 128 + 1) * 256 + rng.raw_used, nullptr);
+              avail_blocks = end_word / 128 + 1;  // exactly the words this relation reads
+            } else if (rng.engine) {
+              rc = rng_wait(c, rng, end_word, &avail_blocks);
+            } else {
+              rc = rng_ensure(c, rng, end_word);
+            }
             if (rc != PYG_HIP_OK) return rc;
             if (!rng.engine) avail_blocks = rng.blocks;
           } else {

@@ -180,6 +180,45 @@ def test_tie_rows_follow_libstdcxx_order(dtype):
             assert torch.equal(out[1].cpu(), torch.from_numpy(ref[1])), (kind, k)
 
 
+@pytest.mark.parametrize('disjoint', [False, True])
+def test_mixed_weighted_and_uniform_relations(disjoint):
+    """Only some relations weighted (neighbor_kernel.cpp:732-760): the weighted ones draw straight from the
+    generator BETWEEN the engine's 128-word prefetches, so later prefetched blocks lie further on in the stream."""
+    rng = np.random.default_rng(23)
+    sizes = {'a': 3000, 'b': 2000}
+    ets = [('a', 'u1', 'b'), ('b', 'w1', 'a'), ('a', 'w2', 'a'), ('b', 'u2', 'b')]
+    rowptr, col, w = {}, {}, {}
+    for e in ets:
+        deg = rng.poisson(14, sizes[e[0]]).astype(np.int64)
+        deg[rng.integers(0, deg.size, 2)] = 1500
+        rowptr[e] = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        col[e] = rng.integers(0, sizes[e[2]], int(rowptr[e][-1]), dtype=np.int64)
+    w[ets[1]] = (rng.random(col[ets[1]].size) + 0.1).astype(np.float32)
+    w[ets[2]] = rng.integers(0, 3, col[ets[2]].size).astype(np.float64)
+    seeds = {'a': rng.choice(3000, 150, replace=False).astype(np.int64), 'b': rng.choice(2000, 90, replace=False).astype(np.int64)}
+    refills = []
+    for fan in ({ets[0]: [6, 4, 3], ets[1]: [5, 3, 2], ets[2]: [3, 5, 2], ets[3]: [4, 2, 4]},
+                {ets[0]: [70, -1], ets[1]: [2, 2], ets[2]: [1, 80], ets[3]: [3, 0]}):
+        torch.manual_seed(31)
+        out = sampler.hetero_neighbor_sample({e: dev(rowptr[e]) for e in ets}, {e: dev(col[e]) for e in ets},
+                                             {t: dev(s) for t, s in seeds.items()}, fan,
+                                             edge_weight_dict={e: wdev(v) for e, v in w.items()}, disjoint=disjoint)
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        ref = oracle.hetero_neighbor_sample(['a', 'b'], ets, rowptr, col, seeds, fan, rng_seed=31, edge_weight_dict=w,
+                                            disjoint=disjoint)
+        info = ref[6]
+        assert info['rng_raw_draws'] > 0
+        refills.append(info['rng_blocks'])
+        for e in ets:
+            assert torch.equal(out[3][e].cpu(), torch.from_numpy(ref[3][e])), e
+            assert torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e]))
+            assert torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e]))
+        for t in ('a', 'b'):
+            assert torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t]))
+        assert after == oracle.mt19937_word_after(31, 256 * info['rng_blocks'] + info['rng_raw_draws'])
+    assert max(refills) > 10  # the engine refilled many times between the weighted relations' draws
+
+
 def test_log_f32_matches_on_every_uniform_argument():
     lib = _capi.lib()
     lib.pyg_hip_biased_log_f32.restype = ctypes.c_int
@@ -200,9 +239,5 @@ def test_unsupported_modes_fail_loudly():
     w = wdev(np.ones(12, dtype=np.float32))
     with pytest.raises(RuntimeError, match='replacement'):
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w, replace=True)
-    e1, e2 = ('n', 'a', 'n'), ('n', 'b', 'n')
-    with pytest.raises(RuntimeError, match='mixing'):
-        sampler.hetero_neighbor_sample({e1: dev(rowptr), e2: dev(rowptr)}, {e1: dev(col), e2: dev(col)},
-                                       {'n': dev([0, 1])}, {e1: [1], e2: [1]}, edge_weight_dict={e1: w})
     with pytest.raises(RuntimeError, match='float32 or float64'):
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w.half())

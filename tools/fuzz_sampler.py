@@ -106,9 +106,12 @@ def run(cases=200, seed=0):
             seeds = {t: rng.integers(0, sizes[t], int(rng.integers(1, 40))).astype(np.int64) for t in seed_types}
             fan = {e: fanout(L) for e in ets}
             wd = None
-            if rng.random() < 0.3:  # biased: every relation weighted
+            if rng.random() < 0.35:  # biased: all or some of the relations weighted
                 replace = False
-                wd = {e: weights(cl[e].size) for e in ets}
+                some = rng.random() < 0.5
+                wd = {e: weights(cl[e].size) for e in ets if not some or rng.random() < 0.5}
+                if not wd:
+                    wd = {ets[0]: weights(cl[ets[0]].size)}
                 nb += 1
             torch.manual_seed(seed)
             out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
