@@ -265,12 +265,14 @@ PYG_HIP_API int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, v
  *                [S+E, 2] (batch, node) pairs when disjoint), from host->alloc
  *   edge_id   -> E sampled edge ids, from host->alloc
  *   cumsum_host  caller array of S + 1 entries: [S, size after seed 0, size after seed 1, ...]
- * Random words, temporal arguments and error behaviour as in pyg_hip_hetero_neighbor_sample.
+ * Random words, temporal arguments, biased sampling (edge_weight: device pointer or NULL, edge_weight_dtype
+ * PYG_F32 / PYG_F64) and error behaviour as in pyg_hip_hetero_neighbor_sample.
  */
 PYG_HIP_API int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col,
                                              const int64_t* seed, int64_t num_seed,
                                              int64_t num_neighbors, const int64_t* node_time,
                                              const int64_t* edge_time, const int64_t* seed_time,
+                                             const void* edge_weight, int edge_weight_dtype,
                                              int temporal_last, int replace, int disjoint,
                                              const pyg_hip_sampler_host* host, int64_t** node_id,
                                              int64_t** edge_id, int64_t* num_edges,

@@ -498,30 +498,37 @@ def index_sort(keys):
 
 
 def dist_neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_time=None, seed_time=None, csc=False,
-                         replace=False, directed=True, disjoint=False, temporal_strategy='uniform', rng_seed=0):
+                         replace=False, directed=True, disjoint=False, temporal_strategy='uniform', rng_seed=0,
+                         edge_weight=None):
     """Restates pyg::dist_neighbor_sample. Returns (node_id, edge_id, cumsum_neighbors_per_node, info)."""
     if (node_time is not None or edge_time is not None) and not disjoint:
         raise RuntimeError('Temporal sampling needs to create disjoint subgraphs')
     L = lib()
     c = ctypes
-    L.oracle_dist_neighbor_sample.restype = c.c_int64
-    L.oracle_dist_neighbor_sample.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p,
-                                              c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_uint64,
-                                              c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    L.oracle_dist_neighbor_sample_w.restype = c.c_int64
+    L.oracle_dist_neighbor_sample_w.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p,
+                                                c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int,
+                                                c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     rowptr, col, seed = _c64(rowptr), _c64(col), _c64(seed)
     nt, et, st = _c64(node_time), _c64(edge_time), _c64(seed_time)
+    w = None if edge_weight is None else np.ascontiguousarray(edge_weight)
+    assert w is None or w.dtype in (np.float32, np.float64)
     S = seed.size
-    args = (_ptr(rowptr), _ptr(col), _ptr(seed), S, int(num_neighbors), _ptr(nt), _ptr(et), _ptr(st), int(replace),
-            int(disjoint), int(temporal_strategy == 'last'), rng_seed & 0xFFFFFFFFFFFFFFFF)
-    E = L.oracle_dist_neighbor_sample(*args, None, None, None, None)
+    args = (_ptr(rowptr), _ptr(col), _ptr(seed), S, int(num_neighbors), _ptr(nt), _ptr(et), _ptr(st), _ptr(w),
+            int(w is not None and w.dtype == np.float64), int(replace), int(disjoint), int(temporal_strategy == 'last'),
+            rng_seed & 0xFFFFFFFFFFFFFFFF)
+    E = L.oracle_dist_neighbor_sample_w(*args, None, None, None, None, None)
+    if E == -2:
+        raise NotImplementedError('biased sampling with replacement is not restated')
     if E < 0:
         raise RuntimeError('Found invalid non-sorted temporal neighborhood')
     nodes = np.zeros((S + E, 2) if disjoint else (S + E,), dtype=np.int64)
     edges = np.zeros(E, dtype=np.int64)
     cumsum = np.zeros(S + 1, dtype=np.int64)
     blocks = ctypes.c_int64(0)
-    L.oracle_dist_neighbor_sample(*args, _ptr(nodes), _ptr(edges), _ptr(cumsum), ctypes.byref(blocks))
-    return nodes, edges, cumsum.tolist(), {'rng_blocks': blocks.value}
+    raw = ctypes.c_int64(0)
+    L.oracle_dist_neighbor_sample_w(*args, _ptr(nodes), _ptr(edges), _ptr(cumsum), ctypes.byref(blocks), ctypes.byref(raw))
+    return nodes, edges, cumsum.tolist(), {'rng_blocks': blocks.value, 'rng_raw_draws': raw.value}
 
 
 # ---- CSR family (segment_*_csr, gather_csr, softmax_csr) ----------------------------------------------

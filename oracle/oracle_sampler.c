@@ -667,11 +667,28 @@ oracle_result* oracle_neighbor_sample(const int64_t* rowptr, const int64_t* col,
  * out_nodes: [(S+E)] or [(S+E), 2] when disjoint; out_edges: [E]; cumsum: [S+1].
  * Returns E (>= 0) or -1; call with out_* == NULL first to size the buffers.
  * ------------------------------------------------------------------------------------------- */
+int64_t oracle_dist_neighbor_sample_w(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S,
+                                      int64_t count, const int64_t* node_time, const int64_t* edge_time,
+                                      const int64_t* seed_time, const void* weight, int weight_f64, int replace,
+                                      int disjoint, int temporal_last, uint64_t rng_seed, int64_t* out_nodes,
+                                      int64_t* out_edges, int64_t* cumsum, int64_t* rng_blocks, int64_t* rng_raw_draws);
+
 int64_t oracle_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S,
                                     int64_t count, const int64_t* node_time, const int64_t* edge_time,
                                     const int64_t* seed_time, int replace, int disjoint, int temporal_last,
                                     uint64_t rng_seed, int64_t* out_nodes, int64_t* out_edges, int64_t* cumsum,
                                     int64_t* rng_blocks) {
+  return oracle_dist_neighbor_sample_w(rowptr, col, seed, S, count, node_time, edge_time, seed_time, NULL, 0, replace,
+                                       disjoint, temporal_last, rng_seed, out_nodes, out_edges, cumsum, rng_blocks, NULL);
+}
+
+/* `weight`: per-edge weights (biased_sample in distributed mode, neighbor_kernel.cpp:436-447 with :296-303), replace
+ * == false only; returns -2 otherwise. */
+int64_t oracle_dist_neighbor_sample_w(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S,
+                                      int64_t count, const int64_t* node_time, const int64_t* edge_time,
+                                      const int64_t* seed_time, const void* weight, int weight_f64, int replace,
+                                      int disjoint, int temporal_last, uint64_t rng_seed, int64_t* out_nodes,
+                                      int64_t* out_edges, int64_t* cumsum, int64_t* rng_blocks, int64_t* rng_raw_draws) {
   engine_t eng;
   engine_init(&eng, rng_seed, NULL, NULL);
   tracker_t trk = {0, 0};
@@ -697,6 +714,31 @@ int64_t oracle_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, c
       const int64_t pop = re - rs;
       if (count < 0 || (!replace && count >= pop)) {
         for (int64_t e = rs; e < re; ++e) { vpush(&eids, e); vpush(&nodes, col[e]); vpush(&batches, i); }
+      } else if (weight) {
+        if (replace) { rc = -2; break; }
+        int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
+        if (!weight_f64) {
+          const float* w = (const float*)weight + rs;
+          float* key = (float*)malloc(sizeof(float) * (size_t)pop);
+          for (int64_t j = 0; j < pop; ++j) {
+            const float u = (float)(mt19937_u32(&eng.gen) & 0xffffffu) * 0x1p-24f;
+            key[j] = (float)log((double)u) / w[j];
+          }
+          oracle_topk_desc_f32(key, pop, count, idx);
+          free(key);
+        } else {
+          const double* w = (const double*)weight + rs;
+          double* key = (double*)malloc(sizeof(double) * (size_t)pop);
+          for (int64_t j = 0; j < pop; ++j) {
+            const double u = (double)(mt19937_u64(&eng.gen) & ((1ull << 53) - 1)) * 0x1p-53;
+            key[j] = log(u) / w[j];
+          }
+          oracle_topk_desc_f64(key, pop, count, idx);
+          free(key);
+        }
+        eng.raw_draws += pop * (weight_f64 ? 2 : 1);
+        for (int64_t j = 0; j < count; ++j) { vpush(&eids, rs + idx[j]); vpush(&nodes, col[rs + idx[j]]); vpush(&batches, i); }
+        free(idx);
       } else if (replace) {
         for (int64_t j = 0; j < count; ++j) {
           const int64_t e = rs + (int64_t)engine_next(&eng, (uint64_t)pop);
@@ -726,9 +768,10 @@ int64_t oracle_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, c
   }
   if (rc == 0 && out_edges) memcpy(out_edges, eids.d, sizeof(int64_t) * (size_t)E);
   if (rng_blocks) *rng_blocks = eng.blocks;
+  if (rng_raw_draws) *rng_raw_draws = eng.raw_draws;
   free(eids.d);
   free(nodes.d);
   free(batches.d);
   free(trk.slot);
-  return rc == 0 ? E : -1;
+  return rc == 0 ? E : rc;
 }

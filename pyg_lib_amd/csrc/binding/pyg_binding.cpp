@@ -604,9 +604,6 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
     bool directed, bool disjoint, std::string temporal_strategy) {
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(), directed,
               disjoint, temporal_strategy);
-  TORCH_CHECK(!edge_weight.has_value(),
-              "pyg (HIP): biased dist_neighbor_sample is not implemented on the device path; refusing to fall back "
-              "to a CPU kernel");
   check_index(rowptr, "rowptr");
   check_index(col, "col");
   check_index(seed, "seed");
@@ -621,12 +618,15 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
   int64_t* node_ptr = nullptr;
   int64_t* edge_ptr = nullptr;
   int64_t E = 0;
+  pyg_hip_relation wrel{};  // only carries the weights (set_weight checks them)
+  if (edge_weight.has_value()) set_weight(wrel, edge_weight.value(), col.numel());
   const int rc = pyg_hip_dist_neighbor_sample(
       rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), seed.data_ptr<int64_t>(), S, num_neighbors,
       node_time.has_value() ? time_ptr(node_time.value(), "node_time") : nullptr,
       edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr,
-      seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr, temporal_strategy == "last",
-      replace, disjoint, &cb, &node_ptr, &edge_ptr, &E, cumsum.data(), host.stream);
+      seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr, wrel.edge_weight,
+      wrel.edge_weight_dtype, temporal_strategy == "last", replace, disjoint, &cb, &node_ptr, &edge_ptr, &E,
+      cumsum.data(), host.stream);
   if (rc == PYG_HIP_OK) loan.commit();
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);

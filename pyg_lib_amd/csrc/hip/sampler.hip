@@ -2828,8 +2828,8 @@ __global__ void dist_nodes_kernel(const int64_t* __restrict__ seed, int64_t S, c
 // dist_neighbor_sample (neighbor_kernel.cpp:957-978): one hop over the seeds, no relabelling.
 int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S, int64_t count,
                      const int64_t* node_time, const int64_t* edge_time, const int64_t* seed_time,
-                     int temporal_last, int replace, int disjoint, Ctx& c, int64_t** out_node, int64_t** out_edge,
-                     int64_t* num_edges, int64_t* cumsum_host) {
+                     const void* weight, int weight_dtype, int temporal_last, int replace, int disjoint, Ctx& c,
+                     int64_t** out_node, int64_t** out_edge, int64_t* num_edges, int64_t* cumsum_host) {
   hipStream_t stream = c.stream;
   RngHost rng;
   void* pinned = nullptr;
@@ -2840,9 +2840,15 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   const bool temporal = node_time || edge_time;
   if (temporal) PYG_HIP_REQUIRE(disjoint, "Temporal sampling needs to create disjoint subgraphs");
   if (edge_time) PYG_HIP_REQUIRE(seed_time != nullptr, "Seed time needs to be specified");
+  if (weight) {  // biased_sample in distributed mode (neighbor_kernel.cpp:436-447, 296-303)
+    PYG_HIP_REQUIRE(!temporal, "Biased temporal sampling not yet supported");
+    PYG_HIP_REQUIRE(weight_dtype == PYG_F32 || weight_dtype == PYG_F64, "sampler: edge_weight must be float32 or float64");
+    if (replace) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling with replacement (at::multinomial) is not available on the device path");
+    if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
+  }
   if (c.host->mt19937) {
     std::vector<int64_t> spec;
-    if (count > 0) spec.push_back(std::min<int64_t>(kSpecCapWords, 256 + (int64_t)((double)S * (double)count / 4.0)));
+    if (count > 0 && !weight) spec.push_back(std::min<int64_t>(kSpecCapWords, 256 + (int64_t)((double)S * (double)count / 4.0)));
     int rc = rng_begin(c, rng, pinned, spec);
     if (rc != PYG_HIP_OK) return rc;
   } else {
@@ -2888,9 +2894,18 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     PYG_ALLOC(edge_off, int64_t*, c, sizeof(int64_t) * (size_t)S);
     PYG_ALLOC(rng_word, int64_t*, c, sizeof(int64_t) * (size_t)S);
     PYG_ALLOC(rng_units, int32_t*, c, sizeof(int32_t) * (size_t)S);
-    CountLoad cl{seed, 0, range, count, replace};
-    CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
-    int rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    const bool f64 = weight_dtype == PYG_F64;
+    const int64_t out_base = rng.blocks * 256;  // the uniform_ draws follow the engine's first block
+    int rc;
+    if (weight) {
+      BiasedCountLoad cl{seed, 0, rowptr, count, f64 ? 2 : 1};
+      CountStore cs{edge_off, rng_word, rng_units, out_base, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    } else {
+      CountLoad cl{seed, 0, range, count, replace};
+      CountStore cs{edge_off, rng_word, rng_units, rng.word, rng.units};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    }
     if (rc != PYG_HIP_OK) return rc;
     PYG_HIP_CHECK(hipMemcpyAsync(pinned, tile_buf + ntiles, sizeof(CountAgg), hipMemcpyDeviceToHost, stream));
     // per-seed prefix of emitted neighbours -> cumsum_neighbors_per_node (:386-388,446-447)
@@ -2906,8 +2921,13 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     for (int64_t i = 0; i + 1 < S; ++i) cumsum_host[1 + i] = S + cumsum_host[2 + i];
     cumsum_host[S] = S + E;
     if (E > 0) {
-      const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
-      rc = rng_ensure(c, rng, end_word);
+      const int64_t W = weight ? (int64_t)(tot.tab >> 20) : 0;  // generator outputs drawn by uniform_
+      if (weight) {
+        if (W > 0) rc = rng_wait32(c, rng, out_base + W, nullptr);
+      } else {
+        const int64_t end_word = rng.word + tab_dw(tot.tab, rng.units);
+        rc = rng_ensure(c, rng, end_word);
+      }
       if (rc != PYG_HIP_OK) return rc;
       PYG_ALLOC(e_node, int64_t*, c, sizeof(int64_t) * (size_t)E);
       PYG_ALLOC(e_eid, int64_t*, c, sizeof(int64_t) * (size_t)E);
@@ -2934,7 +2954,33 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
       a.e_eid = e_eid;
       a.e_slot = nullptr;
       a.table = HashTable{nullptr, nullptr, 0};
-      launch_sample(a, S, stream);
+      if (!weight) {
+        launch_sample(a, S, stream);
+      } else {
+        const int64_t draws = W / (f64 ? 2 : 1);
+        const size_t ksz = f64 ? 8 : 4;
+        void *skey, *selkey;
+        int32_t *sidx, *selidx;
+        HopInfo* info;
+        PYG_ALLOC(skey, void*, c, ksz * (size_t)std::max<int64_t>(draws, 1));
+        PYG_ALLOC(sidx, int32_t*, c, 4 * (size_t)std::max<int64_t>(draws, 1));
+        PYG_ALLOC(selkey, void*, c, ksz * (size_t)E);
+        PYG_ALLOC(selidx, int32_t*, c, 4 * (size_t)E);
+        PYG_ALLOC(info, HopInfo*, c, sizeof(HopInfo));
+        const unsigned wg = (unsigned)((S + 3) / 4), xg = (unsigned)((S + 63) / 64);
+        if (f64) {
+          BiasedArgs<uint64_t> b{a, info, weight, reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                                 static_cast<uint64_t*>(skey), sidx, static_cast<uint64_t*>(selkey), selidx, rng_units};
+          hipLaunchKernelGGL(biased_sample_kernel<true>, dim3(wg), dim3(256), 0, stream, b);
+          hipLaunchKernelGGL(biased_exact_kernel<true>, dim3(xg), dim3(64), 0, stream, b);
+        } else {
+          BiasedArgs<uint32_t> b{a, info, weight, reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                                 static_cast<uint32_t*>(skey), sidx, static_cast<uint32_t*>(selkey), selidx, rng_units};
+          hipLaunchKernelGGL(biased_sample_kernel<false>, dim3(wg), dim3(256), 0, stream, b);
+          hipLaunchKernelGGL(biased_exact_kernel<false>, dim3(xg), dim3(64), 0, stream, b);
+        }
+        rng.raw_used += W;
+      }
       PYG_HIP_CHECK(hipGetLastError());
     }
   }
@@ -3071,7 +3117,8 @@ extern "C" int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, vo
 
 extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col, const int64_t* seed,
                                             int64_t num_seed, int64_t num_neighbors, const int64_t* node_time,
-                                            const int64_t* edge_time, const int64_t* seed_time, int temporal_last,
+                                            const int64_t* edge_time, const int64_t* seed_time,
+                                            const void* edge_weight, int edge_weight_dtype, int temporal_last,
                                             int replace, int disjoint, const pyg_hip_sampler_host* host,
                                             int64_t** node_id, int64_t** edge_id, int64_t* num_edges,
                                             int64_t* cumsum_host, void* stream_) {
@@ -3082,8 +3129,9 @@ extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t
   Ctx c;
   c.host = host;
   c.stream = static_cast<hipStream_t>(stream_);
-  int rc = run_dist_sampler(rowptr, col, seed, num_seed, num_neighbors, node_time, edge_time, seed_time,
-                            temporal_last, replace, disjoint, c, node_id, edge_id, num_edges, cumsum_host);
+  int rc = run_dist_sampler(rowptr, col, seed, num_seed, num_neighbors, node_time, edge_time, seed_time, edge_weight,
+                            edge_weight_dtype, temporal_last, replace, disjoint, c, node_id, edge_id, num_edges,
+                            cumsum_host);
   c.quiesce_side();
   if (rc != PYG_HIP_OK) (void)hipStreamSynchronize(c.stream);
   c.release_all();

@@ -241,3 +241,24 @@ def test_unsupported_modes_fail_loudly():
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w, replace=True)
     with pytest.raises(RuntimeError, match='float32 or float64'):
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w.half())
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('disjoint', [False, True])
+def test_biased_dist_neighbor_sample(dtype, disjoint):
+    # biased_sample in distributed mode (neighbor_kernel.cpp:436-447 with :296-303): one hop, no relabelling
+    rowptr, col, rng = big_graph(9, n=6000, avg=20, hubs=(900, 5000))
+    w = rng.integers(0, 3, col.size).astype(dtype) if disjoint else (rng.random(col.size) + 0.05).astype(dtype)
+    seeds = rng.choice(6000, 400, replace=False).astype(np.int64)
+    seeds[:2] = np.argsort(np.diff(rowptr))[-2:]
+    for fan in (5, 64, -1):
+        torch.manual_seed(8)
+        node, edge, cumsum = torch.ops.pyg.dist_neighbor_sample(dev(rowptr), dev(col), dev(seeds), fan, None, None, None,
+                                                                wdev(w), True, False, True, disjoint, 'uniform')
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        rnode, redge, rcumsum, info = oracle.dist_neighbor_sample(rowptr, col, seeds, fan, rng_seed=8, edge_weight=w,
+                                                                  disjoint=disjoint)
+        assert torch.equal(edge.cpu(), torch.from_numpy(redge))
+        assert torch.equal(node.cpu(), torch.from_numpy(rnode))
+        assert cumsum == rcumsum
+        assert after == oracle.mt19937_word_after(8, 256 * info['rng_blocks'] + info['rng_raw_draws'])
