@@ -485,7 +485,9 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         // global_* (a flat access also counts on lgkmcnt and makes every LDS wait conservative)
         typedef __attribute__((address_space(1))) u32x4 GU32x4;
         const GU32x4* src = (const GU32x4*)(dn.a + row * (K * SZ) + c * 16);
-        xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+        // with several column-chunk readers the tile must STAY in L2 for the others: no streaming hint (with it
+        // C4's X came from HBM 1.86 times, PMC FETCH_SIZE; without it 1.01 times)
+        xr[i] = (NT_LOAD && ncol == 1) ? __builtin_nontemporal_load(src) : *src;
       }
     }
   };
@@ -651,6 +653,277 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
           typedef __attribute__((address_space(1))) u32x4 GU32x4;
           GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + c * 16);
           if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+        }
+      }
+    }
+  }
+}
+
+// ---- 16-bit, K = 256, 256 output columns per workgroup -------------------------------------------------
+// With 128-column chunks an F = 256 layer needs two workgroups per tile range, i.e. every X tile travels
+// through two CUs' load paths (C4: the kernel then moves 1.5x the algorithmic bytes at the same per-CU
+// streaming rate as C2 and lands at 3.3 TB/s of useful traffic).  Here ONE workgroup owns all 256 columns:
+// the whole weight matrix (128 KB) stays in LDS as two K-halves [256 columns][128 k] WITHOUT padding -- the
+// 16-byte chunks of a row are XOR-swizzled with (row & 15) instead, which keeps the fragment reads
+// conflict-free -- and the remaining 32 KB are four 8 KB stages.  A tile is two K-half passes into the same
+// 8 x (32x32) accumulators (each pass = the K = 128 kernel's inner loop), X is read from HBM once, and the
+// output leaves in two rounds of 4 column blocks through the stage (full 128-byte lines per row).
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void mfma_rows_wide256_kernel(
+    const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk, int ncol) {
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  constexpr int SZ = 2;
+  constexpr int K = 256, KH = 128, MC = 256;
+  constexpr int NT = MC / 32;          // 8 accumulator blocks
+  constexpr int BM = NW * 32;
+  static_assert(BM == kTileRows, "tile table is built for 128-row tiles");
+  constexpr int CPR = KH * SZ / 16;    // 16 chunks per half row
+  constexpr int NI = CPR / 2;          // 8 loads / K steps per half
+  constexpr int WROW = KH * SZ;        // 256 bytes per image row
+  constexpr int WIMG = MC * WROW;      // 64 KB per K-half
+  constexpr int STAGE = 32 * 256;      // 8 KB per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int x = lane & 31;
+  const int h = lane >> 5;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
+  char* stage = smem + 2 * WIMG + wave * STAGE;
+
+  const int total = tile_start[B];
+  const int G = (int)gridDim.x / ncol;
+  int nloc, cbase = 0;
+  if (chunk <= 0) {
+    cbase = (int)((int64_t)bx * total / G);
+    nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
+  } else {
+    const int nchunks = (total + chunk - 1) / chunk;
+    const int mine = nchunks > bx ? (nchunks - 1 - bx) / G + 1 : 0;
+    nloc = mine * chunk;
+    if (mine > 0) {
+      const int last_chunk = (mine - 1) * G + bx;
+      const int over = (last_chunk + 1) * chunk - total;
+      if (over > 0) nloc -= over;
+    }
+  }
+  if (nloc <= 0) return;
+  auto tile_of = [&](int i) -> int {
+    if (chunk <= 0) return cbase + i;
+    const int j = i / chunk;
+    return (j * G + bx) * chunk + (i - j * chunk);
+  };
+  const int t1 = nloc;
+  int lo = 0, hi = B;
+  {
+    const int first = tile_of(0);
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= first) lo = mid; else hi = mid;
+    }
+  }
+  int g = lo;
+  int staged = -1;
+
+  // image row (= output column) of lane x for accumulator block tt: crow0 + 16 tt; its swizzle is crow0 & 15
+  const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
+  const int wsw = crow0 & 15;
+  const char* wrow = smem + crow0 * WROW;
+
+  u32x4 xr[2][NI];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  // plan(ti): which group / rows local tile ti covers for this wave; load_half(kh): its K-half into xr[kh]
+  auto plan = [&](int ti) {
+    const int t = tile_of(ti);
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    n_valid = n_row0 < n_rows;
+  };
+  // The X loads are issued through inline asm and their vmcnt wait is placed by hand (wait_half): stores count
+  // on vmcnt as well, and the wait the compiler would insert in front of the stage writes is a vmcnt(0) that
+  // also waits for the output stores issued a moment earlier (microseconds per tile).  since[kh] = a LOWER bound
+  // of the vector-memory instructions issued after the loads into xr[kh] (memory operations retire in order).
+  int since[2] = {0, 0};
+  auto load_half = [&](int kh) {
+    if (!n_valid) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = i * 64 + lane;
+      const int r = p / CPR;
+      const int c = (p % CPR) ^ (r & 15);
+      int64_t row = n_row0 + r;
+      if (row >= n_rows) row = n_rows - 1;
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(xr[kh][i])
+                   : "v"(dn.a + row * (K * SZ) + kh * (KH * SZ) + c * 16) : "memory");
+    }
+    since[kh] = 0;
+    since[kh ^ 1] += NI;
+  };
+  auto wait_half = [&](int kh) {
+    const int n = since[kh];
+    if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  plan(0);
+  load_half(0);
+  load_half(1);
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+
+  for (int t = 0; t < t1; ++t) {
+    if (cg != staged) {
+      __syncthreads();
+      const char* w = d.w;
+      const int M = d.m;
+      if (!d.trans) {
+        // W[k][m] row-major: 8 columns per 16-byte load, scattered as 2-byte stores into the swizzled image
+        constexpr int CW = MC / 8;
+        for (int idx = tid; idx < K * CW; idx += NW * 64) {
+          const int k = idx / CW;
+          const int cc = (idx - k * CW) * 8;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * M + col0 + cc) * SZ);
+          char* img = smem + (k >= KH ? WIMG : 0);
+          const int kk = k & (KH - 1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int m = cc + e;
+            const uint16_t sv = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            *reinterpret_cast<uint16_t*>(img + m * WROW + (((kk >> 3) ^ (m & 15)) * 16) + (kk & 7) * 2) = sv;
+          }
+        }
+      } else {
+        // W^T[m][k] row-major: whole chunks
+        constexpr int CW = K / 8;
+        for (int idx = tid; idx < MC * CW; idx += NW * 64) {
+          const int m = idx / CW;
+          const int kc = idx - m * CW;  // chunk of 8 k
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)(col0 + m) * K + kc * 8) * SZ);
+          char* img = smem + (kc >= CPR ? WIMG : 0);
+          *reinterpret_cast<u32x4*>(img + m * WROW + (((kc & (CPR - 1)) ^ (m & 15)) * 16)) = v;
+        }
+      }
+      __syncthreads();
+      staged = cg;
+    }
+
+    // the next tile's loads go out as soon as the registers of a half are free: right after that half has been
+    // written to the stage, a whole tile before they are needed
+    const bool have_next = t + 1 < t1;
+    if (have_next) plan(t + 1);
+    f32x16 acc[NT];
+    if (!valid && have_next) {
+      load_half(0);
+      load_half(1);
+    }
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        // this half of the tile -> stage (row order -> swizzled rows), then the K steps
+        wait_half(kh);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[kh][i];
+        if (have_next) load_half(kh);
+        const char* img = wrow + kh * WIMG;
+        u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h) ^ (x & 15))) * 16);
+        u32x4 wa[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          wa[tt] = *reinterpret_cast<const u32x4*>(img + tt * 16 * WROW + (((NI * h) ^ wsw) * 16));
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
+          asm volatile("" : "+v"(wa[NT - 1]));  // wait for this step's fragments before the next reads go out
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 xb = xa;
+          u32x4 wb[NT];
+          if (s + 1 < NI) {
+            const int c = NI * h + s + 1;
+            xb = *reinterpret_cast<const u32x4*>(stage + (x * CPR + (c ^ (x & 15))) * 16);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+              wb[tt] = *reinterpret_cast<const u32x4*>(img + tt * 16 * WROW + ((c ^ wsw) * 16));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma_chunk(T{}, wa[tt], xa, acc[tt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < NI) {
+            xa = xb;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) wa[tt] = wb[tt];
+          }
+        }
+      }
+    }
+
+    const DevGroup d_out = d;
+    const int64_t row0_out = row0, rows_out = rows;
+    const bool valid_out = valid;
+    if (have_next) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+    }
+
+    if (valid_out) {
+      const int M = d_out.m;
+      char* obase = d_out.c + (row0_out * M + col0) * SZ;
+      const bool full_out = row0_out + 32 <= rows_out;  // all 16 stores below are issued
+      if (full_out) {
+        since[0] += 16;
+        since[1] += 16;
+      }
+      const T* bp = d_out.bias ? reinterpret_cast<const T*>(d_out.bias) + col0 + (MC / 2) * h : nullptr;
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {  // column blocks 4 rd .. 4 rd + 3 of both lane halves
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int tt = 4 * rd + q;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+          if (bp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c = 8 * h + 2 * q + j;  // 16 chunks per stage row: [half 0: 8 chunks | half 1: 8 chunks]
+            *reinterpret_cast<u32x4*>(stage + (x * 16 + (c ^ (x & 15))) * 16) = pack_chunk(T{}, v + 8 * j);
+          }
+        }
+        u32x4 ov[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int p = i * 64 + lane;
+          const int r = p >> 4;
+          const int c = (p & 15) ^ (r & 15);
+          if (full_out || row0_out + r < rows_out) {
+            // columns (MC/2) * half + 64 rd + 8 * (c & 7)
+            GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + ((MC / 2) * (c >> 3) + 64 * rd + 8 * (c & 7)) * SZ);
+            __builtin_nontemporal_store(ov[i], dst);
+          }
         }
       }
     }
@@ -1268,11 +1541,43 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
                   hipStream_t stream, bool* handled) {
   static thread_local char name[64];
   *handled = true;
-  const int MC = (M % 128 == 0 && K <= 256) ? 128 : (M % 64 == 0 ? 64 : 32);
+  if constexpr (Elem<T>::kSize == 2) {
+    static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+    if (K == 256 && M % 256 == 0 && !nowide) {
+      snprintf(name, sizeof(name), "mfma_%s_k256_wide256", tname);
+      g_last_variant = name;
+      constexpr int NW = 4;
+      constexpr int lds = 2 * 256 * 256 + NW * 32 * 256;  // 128 KB weights + 4 x 8 KB stages = 160 KB
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_wide256_kernel<T, NW>);
+      static thread_local bool attr = false;
+      if (!attr) {
+        PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+      }
+      const DeviceInfo& di = device_info();
+      const int ncol = M / 256;
+      int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus);
+      if (ncol > 1) gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus / ncol) + 7) / 8 * 8);
+      ProfScope prof(stream);
+      hipLaunchKernelGGL((mfma_rows_wide256_kernel<T, NW>), dim3((unsigned)(gx * ncol)), dim3(NW * 64), lds, stream,
+                         w.descs, w.tile_start, B, 0, ncol);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+  }
+  int MC = (M % 128 == 0 && K <= 256) ? 128 : (M % 64 == 0 ? 64 : 32);
+  if constexpr (Elem<T>::kSize == 2) {
+    // 16-bit, K <= 128: one workgroup can own 256 columns (weights + stages fit), X is read by one CU only
+    static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+    if (K == 128 && M % 256 == 0 && !nowide) MC = 256;
+  }
   snprintf(name, sizeof(name), "mfma_%s_k%d_mc%d", tname, K, MC);
   g_last_variant = name;
 #define PYG_CASE(KK, MM)            \
   if (K == KK && MC == MM) return launch_mfma<T, KK, MM>(w, B, M, tiles_upper, stream);
+  if constexpr (Elem<T>::kSize == 2) {
+    PYG_CASE(128, 256)
+  }
   PYG_CASE(32, 32)
   PYG_CASE(32, 64)
   PYG_CASE(32, 128)
