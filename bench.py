@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.0  # dense v_mfma_f32_32x32x2_f32 peak at 2.4 GHz (MI355X_MICROARCH.md)
 
 C2 = dict(B=154, N=21_111_007, F=128)
 
@@ -176,10 +177,18 @@ def main():
             traffic = int(json.load(open(pmc))['hbm_traffic_bytes'])
         except Exception:  # noqa: BLE001
             traffic = None
-    roofline = dict(bound='hbm', achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
-                    mfma_tflops=None if achieved is None else round(2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12, 1))
+    tflops = None if achieved is None else 2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12
+    if args.dtype == 'f32':
+        # fp32, F = 128: AI = 32 flop/B is above the fp32 ridge (157 TF / 8 TB/s = 20): bound by the fp32 MFMA rate
+        roofline = dict(bound='mfma', achieved=None if tflops is None else round(tflops, 1), peak=F32_MFMA_PEAK_TFLOPS,
+                        unit='TFLOP/s', frac=None if tflops is None else round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+                        traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
+                        hbm_GBps=None if achieved is None else round(achieved, 1))
+    else:
+        roofline = dict(bound='hbm', achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS,
+                        unit='GB/s', frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
+                        mfma_tflops=None if tflops is None else round(tflops, 1))
 
     # context for `frac`: what a plain device copy of the same 1 read : 1 write byte mix reaches on this
     # box (torch's copy kernel over x -> out-sized buffer), measured right after the timed region

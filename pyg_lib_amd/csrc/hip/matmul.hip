@@ -1023,7 +1023,15 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
   DevGroup dn = descs[g];
   int64_t n_row0 = 0, n_rows = 0;
   bool n_valid = false;
-  auto prefetch = [&](int ti) {
+  // plan(ti): group / rows of local tile ti for this wave (scalar work); the loads themselves are issued either
+  // between the first MFMA groups of the tile computed meanwhile (issue_in_loop: whole tiles, tile base + the
+  // per-lane offsets computed once) or all at once (issue_all).  They go through inline asm so that their WAIT
+  // is placed by hand (stage_x): stores count on vmcnt too, and the compiler -- which cannot see across this
+  // loop's branches that exactly the 16 stores of the overlapped epilogue are younger -- would wait for those
+  // stores as well (vmcnt(0): several microseconds of store latency per tile).
+  const char* n_base = nullptr;  // first byte of a whole tile (+ the per-lane offsets computed once)
+  bool n_whole = false;
+  auto plan = [&](int ti) {
     const int t = tile_of(ti);
     while (t >= tile_start[g + 1]) {
       ++g;
@@ -1032,38 +1040,30 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
     n_rows = dn.rows;
     n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
     n_valid = n_row0 < n_rows;
-    if (n_valid) {
-      if (n_row0 + 32 <= n_rows) {
-        // whole tile: wave-uniform base in SGPRs + the per-lane offsets computed once (no address math here)
-        const uint64_t base = (uint64_t)(dn.a + n_row0 * (K * SZ));
-        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-        uint64_t sbase = ((uint64_t)bhi << 32) | blo;
-        // v_readfirstlane writes the SGPRs; a VMEM instruction may read them only 5 wait states later, and the
-        // compiler's hazard recogniser does not look inside inline asm
-        asm volatile("s_nop 5" : "+s"(sbase));
+    n_whole = n_valid && n_row0 + 32 <= n_rows;
+    n_base = dn.a + n_row0 * (K * SZ);
+  };
+  auto issue_in_loop = [&](int i) {
+    if constexpr ((DBG & 1) == 0)
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(xr[i]) : "v"(n_base + xoff[i]) : "memory");
+    else
+      asm volatile("v_mov_b32 %0, %1" : "=v"(xr[i][0]) : "v"(xoff[i]));
+  };
+  auto issue_all = [&]() {
+    if (!n_valid) return;
+    if (n_whole) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          if constexpr ((DBG & 1) == 0)
-            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(xr[i]) : "v"(xoff[i]), "s"(sbase) : "memory");
-          else
-            asm volatile("v_mov_b32 %0, %1" : "=v"(xr[i][0]) : "v"(xoff[i]));
-        }
-      } else {
+      for (int i = 0; i < NI; ++i) issue_in_loop(i);
+    } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int p = i * 64 + lane;
-          const int r = p / CPR;
-          const int cs = p % CPR;
-          const int c = cs ^ (r & XM);
-          int64_t row = n_row0 + r;
-          if (row >= n_rows) row = n_rows - 1;
-          // Issued through inline asm so that the WAIT for these loads is placed by hand (stage_x below): stores
-          // count on vmcnt too, and the compiler -- which cannot see across this loop's branches that exactly
-          // the 16 stores of the overlapped epilogue are younger -- would wait for those stores as well
-          // (vmcnt(0): several microseconds of store latency per tile).
-          asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(xr[i]) : "v"(dn.a + row * (K * SZ) + c * 16) : "memory");
-        }
+      for (int i = 0; i < NI; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPR;
+        const int cs = p % CPR;
+        const int c = cs ^ (r & XM);
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(xr[i]) : "v"(dn.a + row * (K * SZ) + c * 16) : "memory");
       }
     }
   };
@@ -1118,7 +1118,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
       for (int e = 0; e < 4; ++e) piece(acc, s, e, std::false_type{});
   };
 
-  auto multiply = [&](f32x16 (&accC)[NT], const f32x16 (&accP)[NT], auto has_prev) {
+  constexpr int LPG = (NI + 7) / 8;  // loads per MFMA group when the next tile's loads ride in K steps 0 and 1
+  auto multiply = [&](f32x16 (&accC)[NT], const f32x16 (&accP)[NT], auto has_prev, bool loads) {
     constexpr bool HAS_PREV = decltype(has_prev)::value;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -1156,6 +1157,12 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
             accC[tt][e] += __builtin_bit_cast(f32x4, wa[tt])[e] * xf[e];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (s < 2 && loads) {  // all of them before the first stores (K step 2) of the overlapped epilogue
+#pragma unroll
+          for (int q = 0; q < LPG; ++q)
+            if ((s * 4 + e) * LPG + q < NI) issue_in_loop((s * 4 + e) * LPG + q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (HAS_PREV) {
           piece(accP, s, e, std::true_type{});
           __builtin_amdgcn_sched_barrier(0);
@@ -1169,13 +1176,18 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
     }
   };
 
-  prefetch(0);
+  plan(0);
+  issue_all();
   DevGroup d = dn;
   int cg = g;
   int64_t row0 = n_row0, rows = n_rows;
   bool valid = n_valid;
   if (valid) stage_x(false);
-  if (1 < t1) prefetch(1);
+  bool pending = false;  // a planned tile whose loads have not been issued yet
+  if (1 < t1) {
+    plan(1);
+    pending = true;
+  }
 
   int t = 0;
   uint64_t dbg_t[4] = {0, 0, 0, 0};
@@ -1218,12 +1230,16 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
     bool overlapped = false;
     uint64_t c0 = 0;
     if constexpr ((DBG & 8) != 0) c0 = __builtin_readcyclecounter();
+    // the planned tile's loads: inside this tile's K loop when both are whole tiles, else right here
+    const bool loads_in_loop = pending && valid && n_whole;
+    if (pending && !loads_in_loop) issue_all();
+    pending = false;
     if (valid) {
       if (p_valid) {
-        multiply(accC, accP, std::true_type{});
+        multiply(accC, accP, std::true_type{}, loads_in_loop);
         overlapped = true;
       } else {
-        multiply(accC, accP, std::false_type{});
+        multiply(accC, accP, std::false_type{}, loads_in_loop);
       }
     }
     if constexpr ((DBG & 8) != 0) {
@@ -1251,14 +1267,19 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
         dbg_t[1] += c1 - c0;
         c0 = c1;
       }
-      if (valid) stage_x(overlapped && !flushed);
+      // younger than the staged tile's loads: exactly the 16 stores of the overlapped epilogue -- unless those
+      // loads were issued before this iteration's flush / restage traffic (then every older access has to land)
+      if (valid) stage_x(overlapped && !flushed && loads_in_loop);
       if constexpr ((DBG & 8) != 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint64_t c1 = __builtin_readcyclecounter();
         dbg_t[2] += c1 - c0;
         c0 = c1;
       }
-      if (t + 2 < t1) prefetch(t + 2);
+      if (t + 2 < t1) {
+        plan(t + 2);
+        pending = true;
+      }
       if constexpr ((DBG & 8) != 0) {
         const uint64_t c1 = __builtin_readcyclecounter();
         dbg_t[3] += c1 - c0;
