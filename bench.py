@@ -61,24 +61,27 @@ def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
     return x, lptr, w, (N, B, F)
 
 
-def cpu_baseline_segment_matmul(sample_rows=480_000):
+def cpu_baseline_segment_matmul(sample_rows=480_000, dtype='bf16'):
     """Oracle (kind "port") on a bounded sample of the same workload: the first relations of C2
-    truncated to `sample_rows` rows, bf16, F=128."""
+    truncated to `sample_rows` rows, F=128, in the dtype of the run."""
     import oracle
     B, F = 8, C2['F']
     rng = np.random.default_rng(0)
     sizes = np.full(B, sample_rows // B)
     ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n = int(ptr[-1])
-    x = oracle.f32_to_bf16_bits(rng.standard_normal((n, F), dtype=np.float32))
-    w = oracle.f32_to_bf16_bits(rng.standard_normal((B, F, F), dtype=np.float32) / F ** 0.5)
-    oracle.segment_matmul(x[:1024], np.array([0, 1024]), w[:1], dtype=oracle.BF16)  # warm up / build
+    x = rng.standard_normal((n, F), dtype=np.float32)
+    w = rng.standard_normal((B, F, F), dtype=np.float32) / F ** 0.5
+    code = oracle.F32
+    if dtype == 'bf16':
+        x, w, code = oracle.f32_to_bf16_bits(x), oracle.f32_to_bf16_bits(w), oracle.BF16
+    oracle.segment_matmul(x[:1024], np.array([0, 1024]), w[:1], dtype=code)  # warm up / build
     best = None
     t_all = time.perf_counter()
     reps = 0
     while reps < 30 and time.perf_counter() - t_all < 12.0:
         t0 = time.perf_counter()
-        oracle.segment_matmul(x, ptr, w, dtype=oracle.BF16)
+        oracle.segment_matmul(x, ptr, w, dtype=code)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         reps += 1
@@ -86,7 +89,7 @@ def cpu_baseline_segment_matmul(sample_rows=480_000):
     threads = int(os.environ.get('OMP_NUM_THREADS', cores))
     return dict(value=round(2.0 * n * F * F / best / 1e9, 2), unit='GFLOP/s', cores=threads, kind='port',
                 sample=f'oracle/oracle_matmul.c segment_matmul, {B} relations x {sample_rows // B} rows, '
-                       f'F=128 bf16, best of {reps}, OpenMP')
+                       f'F=128 {dtype}, best of {reps}, OpenMP')
 
 
 def main():
@@ -258,7 +261,7 @@ def main():
         except ImportError:
             result['sampler'] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline_segment_matmul()
+        result['cpu_baseline'] = cpu_baseline_segment_matmul(dtype=args.dtype)
     elif rank == 0:
         result['cpu_baseline'] = None
     if rank == 0:
