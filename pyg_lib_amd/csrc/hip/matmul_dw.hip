@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -244,6 +245,171 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
   flush();
 }
 
+// K = 256, 256 output columns per workgroup: the four waves SHARE every 32-row slab of X and dY and split the
+// COLUMNS of dW instead of the rows (wave w owns dW[:, 64 w .. 64 w + 63]: 8 x 2 accumulator blocks, the same
+// 256 registers as above).  With row-split waves a 256-wide dW needs four column-chunk workgroups that each
+// stream the whole X again (C4: 4.6 ms); here X and dY pass through one CU once.  The slab lives in a
+// workgroup-shared, double-buffered row-major LDS image (same pitch rule, same transpose reads); every wave
+// loads a quarter of the next slab while the current one is multiplied, one barrier per slab:
+//   iteration s:  registers (slab s+1) -> image[(s+1) & 1];  issue loads of slab s+2;  MFMAs on image[s & 1];  barrier.
+template <typename Tag>
+__global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* __restrict__ groups,
+                                                                const int32_t* __restrict__ tile_start, int B, int M,
+                                                                float* __restrict__ acc_out) {
+  constexpr int K = 256, MC = 256, IB = K / 32, JB = 2;
+  constexpr int PX = pitch_bytes(K), PY = pitch_bytes(MC);
+  constexpr int CX = K / 8, CY = MC / 8;                 // 16-byte chunks per row
+  constexpr int NX = 32 * CX / 256, NY = 32 * CY / 256;  // chunk loads per THREAD and slab
+  constexpr int IMG = 32 * (PX + PY);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncol = M / MC;
+  const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
+  const int col0 = by * MC;
+
+  const int total = tile_start[B];
+  const int G = (int)gridDim.x / ncol;
+  const int t_beg = (int)((int64_t)bx * total / G);
+  const int t_end = (int)((int64_t)(bx + 1) * total / G);
+  if (t_beg >= t_end) return;
+  int g = 0;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_beg) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+
+  f32x16 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  int acc_g = -1;
+  auto flush = [&]() {
+    if (acc_g < 0) return;
+    float* base = acc_out + ((int64_t)acc_g * K) * M + col0 + 64 * wave;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = j * 32 + (lane & 31);
+          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][r] = 0.0f;
+        }
+  };
+
+  // slab index space: 4 slabs of 32 rows per 128-row tile
+  const int s_beg = t_beg * 4, s_end = t_end * 4;
+  u32x4 xr[NX], yr[NY];
+  int n_g = g;
+  DwGroup gd = groups[g];
+  auto prefetch = [&](int sl) {  // this thread's share of slab sl (group n_g after the call)
+    const int t = sl >> 2;
+    while (t >= tile_start[n_g + 1]) {
+      ++n_g;
+      gd = groups[n_g];
+    }
+    const int64_t row0 = (int64_t)(t - tile_start[n_g]) * kTile + (sl & 3) * 32;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int p = it * 256 + tid;
+      const int64_t row = row0 + p / CX;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.x + row * K + (p % CX) * 8);
+      xr[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int p = it * 256 + tid;
+      const int64_t row = row0 + p / CY;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.dy + row * M + col0 + (p % CY) * 8);
+      yr[it] = v;
+    }
+  };
+  auto park = [&](int buf) {
+    char* xs = smem + buf * IMG;
+    char* ys = xs + 32 * PX;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int p = it * 256 + tid;
+      *reinterpret_cast<u32x4*>(xs + (p / CX) * PX + (p % CX) * 16) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int p = it * 256 + tid;
+      *reinterpret_cast<u32x4*>(ys + (p / CY) * PY + (p % CY) * 16) = yr[it];
+    }
+  };
+
+  const int q = lane & 15, half = (lane >> 4) & 1, kb = lane >> 5;
+  const int a_off = (kb * 8 + (q >> 2)) * PX + (half * 16 + (q & 3) * 4) * 2;
+  const int b_off = (kb * 8 + (q >> 2)) * PY + (half * 16 + (q & 3) * 4) * 2 + wave * 128;  // this wave's 64 columns
+  typedef __attribute__((address_space(3))) v4i16* lds_v4;
+
+  // group of the slab held in the registers / of each image
+  prefetch(s_beg);
+  int g_img[2];
+  g_img[0] = n_g;
+  park(0);
+  g_img[1] = n_g;
+  if (s_beg + 1 < s_end) prefetch(s_beg + 1);
+  int g_regs = n_g;
+  __syncthreads();
+
+  for (int sl = s_beg; sl < s_end; ++sl) {
+    const int cur = (sl - s_beg) & 1;
+    if (sl + 1 < s_end) {
+      park(cur ^ 1);  // slab sl + 1 (in registers since the previous iteration)
+      g_img[cur ^ 1] = g_regs;
+      if (sl + 2 < s_end) {
+        prefetch(sl + 2);
+        g_regs = n_g;
+      }
+    }
+    const int cur_g = g_img[cur];
+    if (cur_g != acc_g) {
+      flush();
+      acc_g = cur_g;
+    }
+    const char* xs = smem + cur * IMG;
+    const char* ys = xs + 32 * PX;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v8i16 af[IB], bf[JB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const char* p = xs + a_off + ks * 16 * PX + i * 64;
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * PX));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const char* p = ys + b_off + ks * 16 * PY + j * 64;
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * PY));
+        bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = mfma16(Tag{}, af[i], bf[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  flush();
+}
+
 // fp32: v_mfma_f32_32x32x2_f32 takes ONE value per lane (lane (i, kk) = A[i][kk]), so the "column of
 // rows" operand is simply a row-major load -- lane (i, kk) reads X[row 2s + kk][col i]: two coalesced
 // 128-byte segments per wave instruction, no LDS and no transposition.  Exact fp32 FMA chains (gfx950 has
@@ -365,8 +531,30 @@ int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64
 }
 
 template <typename Tag>
+int launch_dw_wide256(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper,
+                      float* acc, hipStream_t stream) {
+  constexpr int lds = 2 * 32 * (pitch_bytes(256) + pitch_bytes(256));
+  const void* kern = reinterpret_cast<const void*>(&seg_dw_wide256_kernel<Tag>);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int64_t cus = device_info().num_cus;
+  const int64_t ncol = M / 256;
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
+  if (ncol > 1) gx = (gx + 7) / 8 * 8;
+  hipLaunchKernelGGL((seg_dw_wide256_kernel<Tag>), dim3((unsigned)(gx * ncol)), dim3(256), lds, stream, groups, tile_start,
+                     (int)B, (int)M, acc);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename Tag>
 int run_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
            float* acc, hipStream_t stream) {
+  static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+  if (K == 256 && M % 256 == 0 && !nowide) return launch_dw_wide256<Tag>(groups, tile_start, B, M, tiles_upper, acc, stream);
   if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
   if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
   if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
