@@ -420,6 +420,11 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
                                                              float* __restrict__ acc_out) {
   constexpr int IB = K / 32, JB = MC / 32;
   static_assert(IB * JB <= 16, "accumulators must fit the register file");
+  // The MFMA wants ONE value per lane and block, but nothing ties block i to the columns 32 i .. 32 i + 31:
+  // lane li loads VA (up to 4) CONSECUTIVE floats of its row in one instruction and feeds them to VA
+  // different blocks (block VA h + e = columns 32 VA h + VA li + e) -- 16-byte instead of 4-byte accesses,
+  // whole 512-byte rows per wave instruction; the permutation is undone when the accumulators are flushed.
+  constexpr int VA = IB >= 4 ? 4 : IB, VB = JB >= 4 ? 4 : JB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kk = lane >> 5;
   const int ncol = M / MC;
@@ -457,38 +462,71 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
       for (int j = 0; j < JB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int col = j * 32 + (lane & 31);
+          // block i = VA h + e holds the X columns 32 VA h + VA * (MFMA row) + e (see the loads below)
+          const int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int row = 32 * VA * (i / VA) + VA * mrow + (i % VA);
+          const int col = 32 * VB * (j / VB) + VB * (lane & 31) + (j % VB);
           __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           acc[i][j][r] = 0.0f;
         }
   };
-  DwGroup gd = groups[g];
-  for (int t = t_beg; t < t_end; ++t) {
-    while (t >= tile_start[g + 1]) {
-      ++g;
-      gd = groups[g];
+  // Software pipeline over the flattened (tile, row pair) sequence: the operands of step it + D are requested
+  // while step it is multiplied (one wave per SIMD and 16 MFMAs = 1 k cycles per step: without the ring an HBM
+  // round trip of ~5 k cycles is exposed every few steps).  D slots of (a, b, group) with static indices.
+  constexpr int D = 8;
+  const int n_it = (t_end - t_beg) * 16;
+  float pa[D][IB], pb[D][JB];
+  int pg[D];
+  int lg = g;  // group walk of the load side
+  DwGroup ld = groups[lg];
+  auto request = [&](int it, float (&a)[IB], float (&b)[JB], int& grp) {
+    const int t = t_beg + (it >> 4);
+    while (t >= tile_start[lg + 1]) {
+      ++lg;
+      ld = groups[lg];
     }
-    if (g != acc_g) {
+    grp = lg;
+    const float* xp = reinterpret_cast<const float*>(ld.x);
+    const float* yp = reinterpret_cast<const float*>(ld.dy);
+    const int64_t row = (int64_t)(t - tile_start[lg]) * kTile + wave * 32 + 2 * (it & 15) + kk;
+    const bool ok = row < ld.rows;
+#pragma unroll
+    for (int h = 0; h < IB / VA; ++h) {
+      typedef float vecA __attribute__((ext_vector_type(VA)));
+      vecA v;
+#pragma unroll
+      for (int e = 0; e < VA; ++e) v[e] = 0.0f;
+      if (ok) v = *reinterpret_cast<const vecA*>(xp + row * K + 32 * VA * h + VA * li);
+#pragma unroll
+      for (int e = 0; e < VA; ++e) a[VA * h + e] = v[e];
+    }
+#pragma unroll
+    for (int h = 0; h < JB / VB; ++h) {
+      typedef float vecB __attribute__((ext_vector_type(VB)));
+      vecB v;
+#pragma unroll
+      for (int e = 0; e < VB; ++e) v[e] = 0.0f;
+      if (ok) v = *reinterpret_cast<const vecB*>(yp + row * M + col0 + 32 * VB * h + VB * li);
+#pragma unroll
+      for (int e = 0; e < VB; ++e) b[VB * h + e] = v[e];
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < D; ++k) request(k, pa[k], pb[k], pg[k]);  // n_it is a multiple of 16
+  // D divides the 16 steps of a tile and tiles never cross a relation: a chunk of D steps has ONE relation
+  static_assert(16 % D == 0, "a chunk of D steps must stay inside one tile");
+  for (int it0 = 0; it0 < n_it; it0 += D) {
+    if (pg[0] != acc_g) {
       flush();
-      acc_g = g;
+      acc_g = pg[0];
     }
-    const float* xp = reinterpret_cast<const float*>(gd.x);
-    const float* yp = reinterpret_cast<const float*>(gd.dy);
-    const int64_t row0 = (int64_t)(t - tile_start[g]) * kTile + wave * 32;
-#pragma unroll 4
-    for (int s2 = 0; s2 < 16; ++s2) {
-      const int64_t row = row0 + 2 * s2 + kk;
-      const bool ok = row < gd.rows;
-      float a[IB], b[JB];
 #pragma unroll
-      for (int i = 0; i < IB; ++i) a[i] = ok ? xp[row * K + i * 32 + li] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < JB; ++j) b[j] = ok ? yp[row * M + col0 + j * 32 + li] : 0.0f;
+    for (int k = 0; k < D; ++k) {
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k][i], pb[k][j], acc[i][j], 0, 0, 0);
+      if (it0 + k + D < n_it) request(it0 + k + D, pa[k], pb[k], pg[k]);
     }
   }
   flush();
