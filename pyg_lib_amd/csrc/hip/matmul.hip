@@ -1471,6 +1471,7 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
     // kernel (workgroup ids 8 apart = same XCD); keep the chip's resident workgroup count
     gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus * per_cu / ncol) + 7) / 8 * 8);
   }
+#ifdef PYG_HIP_MM_EXPERIMENTS
   if constexpr (SZ == 4 && use_v2) {
     static const bool direct = getenv("PYG_HIP_MM_DIRECT") != nullptr;
     if (direct) {
@@ -1491,6 +1492,7 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
       return PYG_HIP_OK;
     }
   }
+#endif
   if constexpr (SZ == 4 && K == 128 && (MC == 128 || MC == 64 || MC == 32)) {
     static const bool nopipe = getenv("PYG_HIP_MM_NOPIPE") != nullptr;
     if (!nopipe) {
@@ -1507,6 +1509,7 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
       int64_t g2 = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * pc);
       if (ncol > 1) g2 = std::max<int64_t>(8, (std::min<int64_t>(g2, (int64_t)di.num_cus * pc / ncol) + 7) / 8 * 8);
       ProfScope prof(stream);
+#ifdef PYG_HIP_MM_EXPERIMENTS  // ablation / phase-counter variants: never part of the shipped library
       if constexpr (MC == 128) {
         static const int dbg = getenv("PYG_HIP_MM_DBG") ? atoi(getenv("PYG_HIP_MM_DBG")) : 0;
         if (dbg) {  // timing experiments (wrong results by construction)
@@ -1522,6 +1525,7 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
           return PYG_HIP_OK;
         }
       }
+#endif
       hipLaunchKernelGGL((mfma_rows_f32_pipe_kernel<K, MC, NW>), dim3((unsigned)(g2 * ncol)), dim3(NW * 64), plds, stream,
                          w.descs, w.tile_start, B, chunk, ncol);
       PYG_HIP_CHECK(hipGetLastError());
