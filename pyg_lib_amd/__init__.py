@@ -7,32 +7,28 @@ this file registers the reference's ``pyg::*`` operator schemas, and ``pyg_lib_a
 of ``include/pyg_hip.h`` (``libpyg_hip.so``).  There is no CPU path and no Triton path: without
 the libraries the import fails loudly.
 """
-import importlib.machinery
 import os.path as osp
 
 import torch
 
 __version__ = '0.9.0+amd.r1'
 
-
-def load_library(lib_name: str) -> None:
-    # same discovery as pyg_lib/__init__.py:17-33, but a missing library is an error, not a warning
-    loader_details = (
-        importlib.machinery.ExtensionFileLoader,
-        importlib.machinery.EXTENSION_SUFFIXES,
-    )
-    path = osp.dirname(osp.abspath(__file__))
-    ext_finder = importlib.machinery.FileFinder(path, loader_details)
-    spec = ext_finder.find_spec(lib_name)
-    if spec is None:
-        raise ImportError(
-            f"pyg_lib_amd: could not find shared library '{lib_name}' in {path}. Build it with "
-            f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950); "
-            f"there is no CPU fallback.")
-    torch.ops.load_library(spec.origin)
+_HERE = osp.dirname(osp.abspath(__file__))
 
 
-load_library('libpyg')
+def _load(name: str) -> None:
+    """Registers the ``pyg::*`` operators: ``<name>.so`` is built in-tree, next to this file (the reference
+    searches its package directory and only warns when the library is missing, pyg_lib/__init__.py:17-33;
+    here a missing library is an error -- there is nothing to fall back to)."""
+    so = osp.join(_HERE, name + '.so')
+    if not osp.isfile(so):
+        raise ImportError(f"pyg_lib_amd: {so} is missing.  Build it with "
+                          f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950); "
+                          f"there is no CPU fallback.")
+    torch.ops.load_library(so)
+
+
+_load('libpyg')
 
 from pyg_lib_amd import _capi  # noqa: E402
 import pyg_lib_amd.ops  # noqa: E402,F401

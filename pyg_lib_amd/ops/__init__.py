@@ -18,31 +18,13 @@ def segment_matmul(
     other: Tensor,
     bias: Optional[Tensor] = None,
 ) -> Tensor:
-    r"""Performs dense-dense matrix multiplication according to segments along
-    the first dimension of :obj:`inputs` as given by :obj:`ptr`
-    (same contract as :func:`pyg_lib.ops.segment_matmul`, pyg_lib/ops/__init__.py:137-172).
+    """``out[ptr[b]:ptr[b + 1]] = inputs[ptr[b]:ptr[b + 1]] @ other[b] (+ bias[b])`` for every segment ``b`` --
+    one persistent MFMA launch for all segments (interface of the reference's
+    ``pyg_lib.ops.segment_matmul``, pyg_lib/ops/__init__.py:137-172).
 
-    .. code-block:: python
-
-        inputs = torch.randn(8, 16, device='cuda')
-        ptr = torch.tensor([0, 5, 8])
-        other = torch.randn(2, 16, 32, device='cuda')
-
-        out = pyg_lib_amd.ops.segment_matmul(inputs, ptr, other)
-        assert out.size() == (8, 32)
-        assert out[0:5] == inputs[0:5] @ other[0]
-        assert out[5:8] == inputs[5:8] @ other[1]
-
-    Args:
-        inputs: The left operand 2D matrix of shape :obj:`[N, K]`.
-        ptr: Compressed vector of shape :obj:`[B + 1]`, holding the boundaries
-            of segments. May live on the host or on the device; neither
-            placement synchronises.
-        other: The right operand 3D tensor of shape :obj:`[B, K, M]`.
-        bias: The bias term of shape :obj:`[B, M]`.
-
-    Returns:
-        The 2D output matrix of shape :obj:`[N, M]`.
+    ``inputs`` is ``[N, K]`` on a HIP device, ``ptr`` the ``B + 1`` row boundaries (host or device; neither
+    placement synchronises), ``other`` ``[B, K, M]``, ``bias`` optionally ``[B, M]``.  Returns ``[N, M]``.
+    Differentiable in ``inputs``, ``other`` and ``bias``.
     """
     needs_grad = torch.is_grad_enabled() and (inputs.requires_grad or other.requires_grad or
                                               (bias is not None and bias.requires_grad))
@@ -93,16 +75,9 @@ def grouped_matmul(
     others: List[Tensor],
     biases: Optional[List[Tensor]] = None,
 ) -> List[Tensor]:
-    r"""Performs dense-dense matrix multiplication according to groups
-    (same contract as :func:`pyg_lib.ops.grouped_matmul`, pyg_lib/ops/__init__.py:99-134).
-
-    Args:
-        inputs: List of left operand 2D matrices of shapes :obj:`[N_i, K_i]`.
-        others: List of right operand 2D matrices of shapes :obj:`[K_i, M_i]`.
-        biases: Optional bias terms to apply for each element.
-
-    Returns:
-        List of 2D output matrices of shapes :obj:`[N_i, M_i]`.
+    """``outs[i] = inputs[i] @ others[i] (+ biases[i])`` for lists of independent 2-D operands
+    (``[N_i, K_i]`` x ``[K_i, M_i]``) in one launch (interface of the reference's
+    ``pyg_lib.ops.grouped_matmul``, pyg_lib/ops/__init__.py:99-134).  Differentiable.
     """
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in list(inputs) + list(others))
     if needs_grad:
@@ -123,25 +98,11 @@ def index_sort(
     inputs: Tensor,
     max_value: Optional[int] = None,
 ) -> Tuple[Tensor, Tensor]:
-    r"""Sorts the elements of the :obj:`inputs` tensor in ascending order
-    (same contract as :func:`pyg_lib.ops.index_sort`, pyg_lib/ops/__init__.py:295-321).
-    It is expected that :obj:`inputs` is one-dimensional and that it only
-    contains positive integer values. If :obj:`max_value` is given, it can be
-    used by the underlying algorithm for better performance.
-
-    Unlike the reference, device tensors are *not* handed to :func:`torch.sort`
-    (:319-320): they run the LDS radix sort of this library; the result equals
-    ``torch.sort(inputs, stable=True)``.
-
-    Args:
-        inputs: A vector with positive integer values.
-        max_value: The maximum value stored inside :obj:`inputs`. This value
-            can be an estimation, but needs to be greater than or equal to the
-            real maximum.
-
-    Returns:
-        A tuple containing sorted values and indices of the elements in the
-        original :obj:`input` tensor.
+    """Stable ascending sort of a 1-D tensor of non-negative integers; returns ``(sorted values,
+    permutation)`` and equals ``torch.sort(inputs, stable=True)`` (interface of the reference's
+    ``pyg_lib.ops.index_sort``, pyg_lib/ops/__init__.py:295-321).  ``max_value`` -- any upper bound of the
+    keys -- limits the number of radix passes.  The reference hands device tensors to ``torch.sort``
+    (:319-320); here they run this library's LDS radix sort.
     """
     return torch.ops.pyg.index_sort(inputs, max_value)
 
