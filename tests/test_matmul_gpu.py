@@ -108,6 +108,43 @@ def test_mfma_shape_sweep_vs_oracle(dtype, K, M):
         assert (bits(out) == ref).mean() > 0.99
 
 
+@pytest.mark.parametrize('dtype,K,M', [
+    (torch.bfloat16, 256, 256), (torch.bfloat16, 256, 512), (torch.bfloat16, 128, 256), (torch.bfloat16, 128, 512),
+    (torch.float16, 256, 256), (torch.float32, 128, 128), (torch.float32, 128, 256), (torch.float32, 128, 64),
+    (torch.bfloat16, 256, 128), (torch.bfloat16, 64, 256)])
+@pytest.mark.parametrize('with_bias', [False, True])
+def test_many_tiles_per_workgroup_vs_oracle(dtype, K, M, with_bias):
+    """~300 tiles per workgroup-sized grid would be too slow for the oracle; 150 k rows over 37 ragged segments
+    still give every persistent workgroup several tiles, relation changes and partial tiles -- the pipelined
+    paths (next-tile loads in flight, hand-placed waits, double-buffered accumulators, 256-column workgroups)."""
+    rng = np.random.default_rng(K + M)
+    sizes = rng.integers(0, 9000, 37)
+    sizes[5] = 0
+    sizes[11] = 1
+    sizes[20] = 128 * 40  # exact tile multiple
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    g = torch.Generator().manual_seed(K * 7 + M)
+    x = torch.randn(n, K, generator=g).to(dtype)
+    w = (torch.randn(len(sizes), K, M, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(len(sizes), M, generator=g).to(dtype) if with_bias else None
+    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV), None if b is None else b.to(DEV))
+    assert ops.matmul_last_variant().startswith('mfma_'), ops.matmul_last_variant()
+    if dtype == torch.float32:
+        ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy(), None if b is None else b.numpy())
+        assert rel_fro(out.cpu().numpy(), ref) <= 1e-5
+    elif dtype == torch.float16:
+        ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy(), None if b is None else b.numpy())
+        np.testing.assert_allclose(out.cpu().float().numpy(), ref.astype(np.float32), rtol=2 ** -9, atol=2e-3)
+    else:
+        ref = oracle.segment_matmul(bits(x), ptr.numpy(), bits(w), None if b is None else bits(b), dtype=oracle.BF16)
+        got = oracle.bf16_bits_to_f32(bits(out))
+        np.testing.assert_allclose(got, oracle.bf16_bits_to_f32(ref), rtol=2 ** -6, atol=2e-2)
+        assert (bits(out) == ref).mean() > 0.98
+    # rows of empty segments / behind the last one do not exist; every row was written
+    assert torch.isfinite(out.float()).all()
+
+
 def test_asymmetric_weight_detects_transposes():
     # A = I picks rows of W; an asymmetric W catches row/col swaps in the MFMA C-layout.
     K = M = 128
@@ -264,7 +301,7 @@ def test_full_size_c2_properties():
 
 # ---- weight gradient kernel (csrc/hip/matmul_dw.hip) ---------------------------------
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize('K,M', [(128, 128), (64, 64), (128, 64), (64, 128), (256, 256), (128, 256)])
+@pytest.mark.parametrize('K,M', [(128, 128), (64, 64), (128, 64), (64, 128), (256, 256), (128, 256), (256, 512)])
 def test_segment_matmul_weight_gradient_kernel(dtype, K, M):
     # ragged relations incl. empty ones, sizes that are not tile multiples, one relation > many tiles
     sizes = [0, 37, 128, 129, 1000, 0, 5000, 31, 257]
