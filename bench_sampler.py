@@ -36,9 +36,10 @@ def run(device, batches=20, warmup=3, cpu_batches=2):
         sampler.neighbor_sample(rowptr, col, seeds[b], FANOUT)
     torch.cuda.synchronize()
     edges = 0
+    # (the generator is seeded once: a data loader does not reseed per batch; every batch continues the stream)
+    torch.manual_seed(12345)
     t0 = time.perf_counter()
     for b in range(warmup, warmup + batches):
-        torch.manual_seed(12345)
         out = sampler.neighbor_sample(rowptr, col, seeds[b], FANOUT)
         edges += sum(out[5])
     torch.cuda.synchronize()
