@@ -1016,6 +1016,40 @@ __global__ __launch_bounds__(256) void mt_finish_kernel(const uint32_t* __restri
   }
 }
 
+// The same, queued BEHIND the last hop without the host in between (fully queued mode): the number of
+// consumed blocks comes from the device-resident engine position.  status: 0 = state written; 1 = the final
+// 624-array is not fully generated yet; 2 = the position is still inside the caller's own array (the host
+// adjusts left / next itself).  The host cross-checks n32 against its own bookkeeping before trusting it.
+struct MtHandBack {
+  MtDev st;
+  int64_t n32;
+  int32_t status;
+  int32_t pad;
+};
+__global__ __launch_bounds__(256) void mt_finish_chain_kernel(const uint32_t* __restrict__ out32, int64_t a0,
+                                                              const ChainState* __restrict__ chain, int64_t generated32,
+                                                              MtHandBack* __restrict__ hb) {
+  const int64_t n32 = (chain->word / 128 + 1) * 256;
+  int status = 0;
+  const int64_t mp = n32 - a0;
+  const int64_t k = (mp + 623) / 624;
+  if (n32 <= a0) status = 2;
+  else if (a0 + 624 * k > generated32) status = 1;
+  if (status == 0) {
+    const int64_t o0 = a0 + 624 * (k - 1);
+    for (int i = threadIdx.x; i < 624; i += 256) hb->st.state[i] = mt_untemper(mt_output_at(out32, o0 + i));
+    if (threadIdx.x == 0) {
+      const int64_t nx = mp - 624 * (k - 1);
+      hb->st.next = (uint32_t)nx;
+      hb->st.left = (int32_t)(625 - nx);
+    }
+  }
+  if (threadIdx.x == 0) {
+    hb->n32 = n32;
+    hb->status = status;
+  }
+}
+
 // ---- biased sampling (edge_weight) -------------------------------------------------------------------
 // _biased_sample (neighbor_kernel.cpp:245-285), replace == false: a row with more neighbours than the
 // fan-out draws `rand = empty_like(weight).uniform_()` straight from the generator, forms
@@ -1918,6 +1952,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   std::vector<RelState> rs((size_t)num_relations);
   std::vector<std::vector<int64_t>> nodes_per_hop((size_t)num_node_types);
   RngHost rng;
+  MtHandBack* hand_back = nullptr;  // pinned: engine state written by mt_finish_chain_kernel (fully queued mode)
   PhaseTimer pt;
 
   int64_t num_batches = 1;
@@ -1928,9 +1963,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_HIP_REQUIRE(num_batches < (1ll << 22), "sampler: too many seeds for disjoint sampling");
   }
 
+  const size_t hand_back_offset =
+      align_up(1024 + sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 96), 64);
   void* pinned = nullptr;
   {
-    int rc = get_pinned(&pinned, 1024 + sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 96));  // scratch + one HopInfo per (hop, relation)
+    // scratch + one HopInfo per (hop, relation) + the engine hand-back of the fully queued mode
+    int rc = get_pinned(&pinned, hand_back_offset + sizeof(MtHandBack));
     if (rc != PYG_HIP_OK) return rc;
   }
 
@@ -2252,6 +2290,29 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                            tstate + dst, (const int64_t*)a.rel_size, rel_sizes + (int64_t)(ell + 1) * num_relations + e);
         PYG_HIP_CHECK(hipGetLastError());
         queued.push_back({ell, e});
+      }
+    }
+    // the engine hand-back rides behind the last hop: its position is on the device, so no host round trip is
+    // needed to know how many blocks were consumed (verified against the host's bookkeeping below)
+    if (rng.engine) {
+      // outputs that must exist: everything the hops may have read (spec_word bounds it) + the rest of the
+      // 624-array the engine is left in; only a launch that is already under way is waited for
+      const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
+      size_t k = 0;
+      while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
+      if (k < rng.marks.size()) {
+        MtHandBack* hb_dev;
+        PYG_ALLOC(hb_dev, MtHandBack*, c, sizeof(MtHandBack));
+        hand_back = reinterpret_cast<MtHandBack*>(static_cast<char*>(pinned) + hand_back_offset);
+        hand_back->status = -1;
+        if (k >= rng.waited) {
+          PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
+          rng.waited = k + 1;
+        }
+        hipLaunchKernelGGL(mt_finish_chain_kernel, dim3(1), dim3(256), 0, stream,
+                           reinterpret_cast<const uint32_t*>(rng.dev), rng.a0, chain, rng.marks[k].upto32, hb_dev);
+        PYG_HIP_CHECK(hipGetLastError());
+        PYG_HIP_CHECK(hipMemcpyAsync(hand_back, hb_dev, sizeof(MtHandBack), hipMemcpyDeviceToHost, stream));
       }
     }
     pt.lap(4);
@@ -2797,7 +2858,11 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     for (int l = 0; l < L; ++l) res->edges_per_hop_host[(size_t)e * L + l] = st.edges_per_hop[(size_t)l];
   }
   res->rng_blocks = rng.blocks;
-  {
+  if (hand_back && hand_back->status == 0 && hand_back->n32 == rng.blocks * 256 + rng.raw_used) {
+    // already on the host (it arrived with the hop totals): nothing left to wait for
+    ::memcpy(c.host->mt19937, &hand_back->st, sizeof(MtDev));
+    c.quiesce_side();
+  } else {
     int rc = rng_finish(c, rng);  // hand the advanced engine back
     if (rc != PYG_HIP_OK) return rc;
   }
