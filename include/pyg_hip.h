@@ -182,7 +182,7 @@ typedef struct {
   const int64_t* edge_time;          /* device, per edge, or NULL (edge-level temporal sampling) */
   /* Biased sampling (neighbor_kernel.cpp:39-56,245-285; hetero :732-745): per-edge weights on the device, or
    * NULL.  edge_weight_dtype is PYG_F32 or PYG_F64 (the dtype decides how many generator outputs a draw
-   * takes, see pyg_hip_hetero_neighbor_sample).  Needs host->mt19937 and replace == 0. */
+   * takes, see pyg_hip_hetero_neighbor_sample).  Needs host->mt19937. */
   const void* edge_weight;
   int32_t edge_weight_dtype;
   int32_t reserved;
@@ -237,8 +237,12 @@ typedef struct {
  * source: 15,372 of the 2^24 possible float32 arguments round differently), so a selection can differ from
  * the reference's only if two keys of one row lie within one ulp of each other.  Weighted and unweighted
  * relations may be mixed (the engine's later 128-word blocks then lie behind the weighted relations' draws in
- * the generator stream, as in the reference).  Needs host->mt19937, replace == 0 and no temporal arguments;
- * anything else fails with PYG_HIP_ERR_UNSUPPORTED.
+ * the generator stream, as in the reference).  With replace != 0 the reference calls
+ * at::multinomial(weight, count, true): for count > 1 that is a sequential cumulative sum in the weights' type,
+ * a division by the sum, and one 53-bit double per sample located by binary search -- reproduced exactly
+ * (PYG_HIP_ERR_INVALID "invalid multinomial distribution" for rows at::multinomial rejects); count == 1 goes
+ * through exponential_ and MKL's own generator inside at::multinomial and fails with PYG_HIP_ERR_UNSUPPORTED,
+ * as do temporal arguments and a missing host->mt19937.
  * Synchronises `stream` (output sizes are data dependent).
  */
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,

@@ -256,7 +256,10 @@ def hetero_neighbor_sample(node_types, edge_types, rowptr_dict, col_dict, seed_d
         ctypes.cast(cb, ctypes.c_void_p) if cb is not None else None, None, ctypes.byref(status))
     try:
         if status.value == -2:
-            raise NotImplementedError('biased sampling with replacement / an external word source is not restated')
+            raise NotImplementedError('biased sampling with replacement and one draw per node (at::multinomial\'s '
+                                      'exponential_ path) / with an external word source is not restated')
+        if status.value == -3:
+            raise RuntimeError('invalid multinomial distribution')
         if status.value != 0:
             raise RuntimeError('Found invalid non-sorted temporal neighborhood')
         rows, colsd, eids, nodes, nhops, ehops = {}, {}, {}, {}, {}, {}

@@ -359,6 +359,71 @@ static void sampler_sample(sampler_t* s, int64_t row_start, int64_t row_end, int
   }
 }
 
+/* at::multinomial(weight, count, replacement = true) for count > 1, as libtorch 2.10 computes it on the CPU
+ * (ATen/native/cpu/MultinomialKernel.cpp, multinomial_with_replacement_apply): the cumulative distribution is
+ * summed SEQUENTIALLY in the weights' own type, every entry divided by the sum, the last one set to 1; each sample
+ * draws one double from the generator (random64, 53 bits kept) and binary-searches the first entry that is not
+ * below it.  Pinned against torch.multinomial itself (tests/golden/make_biased_golden.py).  count == 1 takes a
+ * different route inside at::multinomial (exponential_ through MKL's own generator): not restated (-2).
+ * Returns -3 for the distributions at::multinomial rejects (negative / non-finite weights, zero sum). */
+static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t population, int64_t count,
+                                  int64_t src_batch, int64_t local_src, nodeset_t* dst, int disjoint, engine_t* eng,
+                                  const void* weight, int weight_f64) {
+  if (count == 1) return -2;
+  int rc = 0;
+  if (!weight_f64) {
+    const float* w = (const float*)weight + row_start;
+    float* cum = (float*)malloc(sizeof(float) * (size_t)population);
+    float sum = 0.0f;
+    for (int64_t j = 0; j < population; ++j) {
+      if (!(w[j] >= 0.0f) || !isfinite(w[j])) rc = -3;
+      sum += w[j];
+      cum[j] = sum;
+    }
+    if (!(sum > 0.0f)) rc = -3;
+    if (rc == 0) {
+      for (int64_t j = 0; j < population; ++j) cum[j] /= sum;
+      for (int64_t i = 0; i < count; ++i) {
+        const double u = (double)(mt19937_u64(&eng->gen) & ((1ull << 53) - 1)) * 0x1p-53;
+        cum[population - 1] = 1.0f;
+        int64_t lo = 0, hi = population;
+        while (hi - lo > 0) {
+          const int64_t mid = lo + (hi - lo) / 2;
+          if ((double)cum[mid] < u) lo = mid + 1; else hi = mid;
+        }
+        sampler_add(s, row_start + lo, src_batch, local_src, dst, disjoint);
+      }
+    }
+    free(cum);
+  } else {
+    const double* w = (const double*)weight + row_start;
+    double* cum = (double*)malloc(sizeof(double) * (size_t)population);
+    double sum = 0.0;
+    for (int64_t j = 0; j < population; ++j) {
+      if (!(w[j] >= 0.0) || !isfinite(w[j])) rc = -3;
+      sum += w[j];
+      cum[j] = sum;
+    }
+    if (!(sum > 0.0)) rc = -3;
+    if (rc == 0) {
+      for (int64_t j = 0; j < population; ++j) cum[j] /= sum;
+      for (int64_t i = 0; i < count; ++i) {
+        const double u = (double)(mt19937_u64(&eng->gen) & ((1ull << 53) - 1)) * 0x1p-53;
+        cum[population - 1] = 1.0;
+        int64_t lo = 0, hi = population;
+        while (hi - lo > 0) {
+          const int64_t mid = lo + (hi - lo) / 2;
+          if (cum[mid] < u) lo = mid + 1; else hi = mid;
+        }
+        sampler_add(s, row_start + lo, src_batch, local_src, dst, disjoint);
+      }
+    }
+    free(cum);
+  }
+  if (rc == 0) eng->raw_draws += 2 * count;
+  return rc;
+}
+
 /* _biased_sample (neighbor_kernel.cpp:245-285), replace == false.  weight_f64: 0 = float32 weights,
  * 1 = float64.  Returns 0, or -2 for the (not restated) with-replacement case. */
 static int sampler_biased(sampler_t* s, int64_t row_start, int64_t row_end, int64_t count, int replace,
@@ -369,7 +434,9 @@ static int sampler_biased(sampler_t* s, int64_t row_start, int64_t row_end, int6
     for (int64_t e = row_start; e < row_end; ++e) sampler_add(s, e, src_batch, local_src, dst, disjoint);
     return 0;
   }
-  if (replace || eng->fill) return -2;
+  if (eng->fill) return -2;
+  if (replace) return sampler_biased_replace(s, row_start, population, count, src_batch, local_src, dst, disjoint, eng,
+                                             weight, weight_f64);
   int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
   if (!weight_f64) {
     const float* w = (const float*)weight + row_start;
@@ -589,9 +656,10 @@ oracle_result* oracle_hetero_neighbor_sample_w(
           const int64_t v = sn->node.d[i];
           const int64_t rs = s->rowptr[v], re = s->rowptr[v + 1];
           if (re - rs == 0 || count == 0) continue;
-          if (sampler_biased(s, rs, re, count, replace, disjoint ? sn->batch.d[i] : 0, i, dn, disjoint, &eng,
-                             edge_weight[e], weight_f64[e]) != 0) {
-            *status = -2;
+          const int brc = sampler_biased(s, rs, re, count, replace, disjoint ? sn->batch.d[i] : 0, i, dn, disjoint, &eng,
+                                         edge_weight[e], weight_f64[e]);
+          if (brc != 0) {
+            *status = brc;
             break;
           }
         }

@@ -1546,6 +1546,94 @@ __global__ __launch_bounds__(64) void biased_exact_kernel(BiasedArgs<typename Bi
   for (int64_t p = 0; p < k; ++p) emit(a.h, eo + p, rs + s.v[p], src_pos, batch);
 }
 
+// With replacement (neighbor_kernel.cpp:267-270): index = at::multinomial(weight, count, true).  For count > 1
+// libtorch's CPU kernel (ATen/native/cpu/MultinomialKernel.cpp) sums the cumulative distribution SEQUENTIALLY in the
+// weights' type, divides every entry by the sum, sets the last one to 1, and for each sample draws one double
+// (random64, 53 bits) and binary-searches the first entry that is not below it.  One wave per row: lane 0 runs the
+// sequential sum (bit-exactness leaves no choice), the division and the `count` searches are spread over the lanes.
+// Every emitting row draws 2 count outputs and emits count edges, so its first output is out_base + 2 edge_off.
+// A distribution at::multinomial rejects raises info->overflow = 3.  (count == 1 goes through exponential_ with
+// MKL's own generator inside at::multinomial: refused by the host.)
+struct BiasedReplaceCountLoad {
+  const int64_t* nodes;
+  int64_t begin;
+  const int64_t* rowptr;
+  int64_t count;
+  __device__ CountAgg operator()(int64_t i) const {
+    CountAgg r;
+    r.tab = rng_identity();
+    r.edges = 0;
+    const int64_t v = nodes[begin + i];
+    const int64_t deg = rowptr[v + 1] - rowptr[v];
+    if (deg <= 0 || count == 0) return r;
+    if (count < 0) {
+      r.edges = deg;
+      return r;
+    }
+    r.edges = count;
+    r.tab |= (u64)deg << 20;  // scratch entries of the cumulative distribution
+    return r;
+  }
+};
+
+template <typename W>
+__global__ __launch_bounds__(256) void biased_replace_kernel(HopArgs a, HopInfo* info, const W* __restrict__ weight,
+                                                             const uint32_t* __restrict__ out32, int64_t out_base,
+                                                             W* __restrict__ cum_all) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) info->tot.tab = rng_identity();
+  if (i >= a.frontier) return;
+  const int64_t src_pos = a.begin + i;
+  const int64_t v = a.nodes[src_pos];
+  const int64_t batch = a.batch ? a.batch[src_pos] : 0;
+  const int64_t rs = a.range.rowptr[v];
+  const int64_t n = a.range.rowptr[v + 1] - rs;
+  const int64_t k = a.count;
+  if (n <= 0 || k == 0) return;
+  const int64_t eo = a.edge_off[i];
+  if (k < 0) {
+    for (int64_t j = lane; j < n; j += 64) emit(a, eo + j, rs + j, src_pos, batch);
+    return;
+  }
+  W* cum = cum_all + a.rng_word[i];
+  const W* w = weight + rs;
+  W sum = 0;
+  int bad = 0;
+  if (lane == 0) {
+    for (int64_t j = 0; j < n; ++j) {
+      const W x = w[j];
+      if (!(x >= (W)0) || isinf(x)) bad = 1;
+      sum += x;
+      cum[j] = sum;
+    }
+    if (!(sum > (W)0)) bad = 1;
+  }
+  bad = __shfl(bad, 0, 64);
+  if (bad) {
+    if (lane == 0) info->overflow = 3;
+    return;
+  }
+  sum = __shfl(sum, 0, 64);
+  wave_mem_sync();
+  for (int64_t j = lane; j < n; j += 64) cum[j] = cum[j] / sum;
+  wave_mem_sync();
+  if (lane == 0) cum[n - 1] = (W)1;
+  wave_mem_sync();
+  for (int64_t s = lane; s < k; s += 64) {
+    const int64_t o = out_base + 2 * (eo + s);
+    const uint64_t r64 = ((uint64_t)mt_output_at(out32, o) << 32) | mt_output_at(out32, o + 1);
+    const double u = (double)(r64 & ((1ull << 53) - 1)) * 0x1p-53;
+    int64_t lo = 0, hi = n;
+    while (hi - lo > 0) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if ((double)cum[mid] < u) lo = mid + 1;
+      else hi = mid;
+    }
+    emit(a, eo + s, rs + lo, src_pos, batch);
+  }
+}
+
 // ---- host driver -----------------------------------------------------------------------------------
 struct Ctx {
   const pyg_hip_sampler_host* host;
@@ -2003,7 +2091,6 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   if (any_biased) {
     // reference checks (neighbor_kernel.cpp:377-380,579-582)
     PYG_HIP_REQUIRE(!temporal, "Biased temporal sampling not yet supported");
-    if (replace) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling with replacement (at::multinomial) is not available on the device path");
     if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
     for (int e = 0; e < num_relations; ++e) {
       if (rels[e].edge_weight)
@@ -2527,15 +2614,31 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(raw_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
     PYG_ALLOC(flag, int32_t*, c, sizeof(int32_t) * (size_t)F);
     const int64_t out_base = rng.blocks * 256 + rng.raw_used;
-    BiasedCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, outputs};
-    CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
-    int rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
+    if (replace && count == 1)
+      return fail(PYG_HIP_ERR_UNSUPPORTED,
+                  "sampler: biased sampling with replacement and a fan-out of 1 is not available on the device path "
+                  "(at::multinomial draws a single sample through exponential_ and MKL's own generator)");
+    int rc;
+    if (replace) {
+      // the word field of the scan carries the cumulative-distribution scratch offset (in weights)
+      BiasedReplaceCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count};
+      CountStore cs{edge_off, raw_off, flag, 0, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
+    } else {
+      BiasedCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, outputs};
+      CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
+    }
     if (rc != PYG_HIP_OK) return rc;
+    PYG_HIP_CHECK(hipMemsetAsync(&info_dev[e].overflow, 0, sizeof(int32_t), stream));
     PYG_HIP_CHECK(hipMemcpyAsync(const_cast<HopInfo*>(info_host) + e, info_dev + e, sizeof(HopInfo),
                                  hipMemcpyDeviceToHost, stream));
     PYG_HIP_CHECK(hipStreamSynchronize(stream));
     const int64_t E = info_host[e].tot.edges;
-    const int64_t W = (int64_t)(info_host[e].tot.tab >> 20);  // generator outputs drawn by this relation
+    const int64_t scratch_w = replace ? (int64_t)(info_host[e].tot.tab >> 20) : 0;  // cumulative-distribution entries
+    // generator outputs drawn by this relation: one uniform_ value per neighbour of every drawing row, or one
+    // double per sampled edge (with replacement)
+    const int64_t W = replace ? (count > 0 ? 2 * E : 0) : (int64_t)(info_host[e].tot.tab >> 20);
     auto cleanup = [&]() {
       c.release(tile_buf);
       c.release(edge_off);
@@ -2580,7 +2683,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
     const int64_t etiles = (E + kScanTile - 1) / kScanTile;
     PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
-    const int64_t draws = W / outputs;
+    const int64_t draws = replace ? scratch_w : W / outputs;
     const size_t ksz = f64 ? 8 : 4;
     void *skey, *selkey;
     int32_t *sidx, *selidx;
@@ -2612,7 +2715,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     a.e_slot = e_slot;
     a.table = dn.table;
     const unsigned wg = (unsigned)((F + 3) / 4), xg = (unsigned)((F + 63) / 64);
-    if (f64) {
+    if (replace) {
+      a.replace = 1;
+      if (f64)
+        hipLaunchKernelGGL(biased_replace_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info_dev + e,
+                           static_cast<const double*>(r.edge_weight), reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                           static_cast<double*>(skey));
+      else
+        hipLaunchKernelGGL(biased_replace_kernel<float>, dim3(wg), dim3(256), 0, stream, a, info_dev + e,
+                           static_cast<const float*>(r.edge_weight), reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                           static_cast<float*>(skey));
+    } else if (f64) {
       BiasedArgs<uint64_t> b{a, info_dev + e, r.edge_weight, reinterpret_cast<const uint32_t*>(rng.dev), out_base,
                              static_cast<uint64_t*>(skey), sidx, static_cast<uint64_t*>(selkey), selidx, flag};
       hipLaunchKernelGGL(biased_sample_kernel<true>, dim3(wg), dim3(256), 0, stream, b);
@@ -2634,6 +2747,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                        chain, tstate + dst, (const int64_t*)nullptr, (int64_t*)nullptr);
     PYG_HIP_CHECK(hipGetLastError());
     PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (info_host[e].overflow == 3)  // at::multinomial's checks (negative / non-finite weights, zero sum)
+      return fail(PYG_HIP_ERR_INVALID, "invalid multinomial distribution (a sampled row has negative or non-finite weights, or they sum to zero)");
     const int64_t U = info_host[e].uniq;
     rng.raw_used += W;
     dn.nodes.size += U;

@@ -11,7 +11,9 @@ def load():
     cases = []
     for c in range(int(z['num_cases'][0])):
         pre = f'c{c}_'
-        hetero, disjoint, f64, manual_seed, n_rel = [int(x) for x in z[pre + 'meta']]
+        meta = [int(x) for x in z[pre + 'meta']]
+        hetero, disjoint, f64, manual_seed, n_rel = meta[:5]
+        replace = bool(meta[5]) if len(meta) > 5 else False
         if hetero:
             node_types = ['a', 'b']
             edge_types = [('a', 'x', 'b'), ('b', 'y', 'a'), ('a', 'z', 'a')]
@@ -19,7 +21,7 @@ def load():
             node_types = ['n']
             edge_types = [('n', 'to', 'n')]
         assert n_rel == len(edge_types)
-        case = dict(id=c, hetero=bool(hetero), disjoint=bool(disjoint), f64=bool(f64), manual_seed=manual_seed,
+        case = dict(id=c, hetero=bool(hetero), disjoint=bool(disjoint), f64=bool(f64), manual_seed=manual_seed, replace=replace,
                     node_types=node_types, edge_types=edge_types,
                     rowptr={e: z[pre + f'rowptr{j}'] for j, e in enumerate(edge_types)},
                     col={e: z[pre + f'col{j}'] for j, e in enumerate(edge_types)},

@@ -3,7 +3,8 @@ libtorch CPU ops the reference calls -- pyg_lib/csrc/sampler/cpu/neighbor_kernel
 
     rand  = at::empty_like(weight).uniform_()         # global CPU generator
     key   = rand.log() / weight
-    index = std::get<1>(key.topk(count))
+    index = std::get<1>(key.topk(count))              # replace == false
+    index = at::multinomial(weight, count, true)      # replace == true (cases with count > 1)
 
 around a Python transcription of the (single-threaded) hop loop (:332-514 homogeneous, :518-841
 heterogeneous; Mapper = first-occurrence dict).  The engine constructor's prefetch
@@ -25,7 +26,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 I64_MIN, I64_MAX = -2**63, 2**63 - 1
 
 
-def torch_biased(node_types, edge_types, rowptr, col, weight, seed_dict, fanouts, manual_seed, disjoint=False, csc=False):
+def torch_biased(node_types, edge_types, rowptr, col, weight, seed_dict, fanouts, manual_seed, disjoint=False, csc=False,
+                 replace=False):
     torch.manual_seed(manual_seed)
     torch.randint(I64_MIN, I64_MAX, (128,))  # RandintEngine constructor prefetch
     nodes = {t: [] for t in node_types}       # (batch, node) or node
@@ -65,8 +67,11 @@ def torch_biased(node_types, edge_types, rowptr, col, weight, seed_dict, fanouts
                 rs, re = int(rp[v]), int(rp[v + 1])
                 if re - rs == 0 or count == 0:
                     continue
-                if count < 0 or count >= re - rs:
+                if count < 0 or (not replace and count >= re - rs):
                     picked = list(range(rs, re))
+                elif replace:
+                    # neighbor_kernel.cpp:267-270 (count > 1: the with-replacement kernel of at::multinomial)
+                    picked = (rs + torch.multinomial(w[rs:re], count, True)).tolist()
                 else:
                     ww = w[rs:re]
                     rand = torch.empty_like(ww).uniform_()
@@ -180,6 +185,55 @@ def main():
                             out[pre + f'nhops_{t}'] = np.array(ref[4][t], dtype=np.int64)
                         cases.append((kind, str(dtype), disjoint, hetero, trial))
                         cid += 1
+    # with replacement (at::multinomial, count > 1): strictly positive weights (an all-zero row is an error)
+    for kind in ('random', 'small_ints'):
+        for dtype in (torch.float32, torch.float64):
+            for hetero in (False, True):
+                for disjoint in (False, True):
+                    ms = 1000 + cid
+                    if not hetero:
+                        nt, ets = ['n'], [('n', 'to', 'n')]
+                        n = 300
+                        rp, cl = random_csr(g, n, n, 9, hub=300)
+                        rowptr, col = {ets[0]: rp}, {ets[0]: cl}
+                        fan = {ets[0]: [4, 3, 2]}
+                        seeds = {'n': torch.randperm(n, generator=g)[:7]}
+                    else:
+                        nt = ['a', 'b']
+                        ets = [('a', 'x', 'b'), ('b', 'y', 'a'), ('a', 'z', 'a')]
+                        sizes = {'a': 200, 'b': 120}
+                        rowptr, col = {}, {}
+                        for e in ets:
+                            rowptr[e], col[e] = random_csr(g, sizes[e[0]], sizes[e[2]], 7, hub=500)
+                        fan = {ets[0]: [3, 2], ets[1]: [2, 4], ets[2]: [6, 2]}
+                        seeds = {'a': torch.randperm(200, generator=g)[:5], 'b': torch.randperm(120, generator=g)[:3]}
+                    weight = {e: make_weight(g, col[e].numel(), kind, dtype) for e in ets}
+                    ref = torch_biased(nt, ets, rowptr, col, weight, seeds, fan, ms, disjoint=disjoint, replace=True)
+                    got = oracle.hetero_neighbor_sample(
+                        nt, ets, {e: rowptr[e].numpy() for e in ets}, {e: col[e].numpy() for e in ets},
+                        {t: s.numpy() for t, s in seeds.items()}, fan, disjoint=disjoint, rng_seed=ms, replace=True,
+                        edge_weight_dict={e: weight[e].numpy() for e in ets})
+                    ok = all(got[3][e].tolist() == ref[3][e] and got[1][e].tolist() == ref[1][e] for e in ets)
+                    n_rows += sum(len(v) for v in ref[0].values())
+                    if not ok:
+                        n_mismatch += 1
+                        print('oracle != torch transcription (replace):', kind, dtype, disjoint, hetero)
+                    pre = f'c{cid}_'
+                    out[pre + 'meta'] = np.array([int(hetero), int(disjoint), int(dtype == torch.float64), ms, len(ets), 1])
+                    for j, e in enumerate(ets):
+                        out[pre + f'rowptr{j}'] = rowptr[e].numpy()
+                        out[pre + f'col{j}'] = col[e].numpy()
+                        out[pre + f'weight{j}'] = weight[e].numpy()
+                        out[pre + f'fan{j}'] = np.array(fan[e])
+                        out[pre + f'row_out{j}'] = np.array(ref[0][e], dtype=np.int64)
+                        out[pre + f'col_out{j}'] = np.array(ref[1][e], dtype=np.int64)
+                        out[pre + f'edge_out{j}'] = np.array(ref[3][e], dtype=np.int64)
+                        out[pre + f'ehops{j}'] = np.array(ref[5][e], dtype=np.int64)
+                    for t in nt:
+                        out[pre + f'seed_{t}'] = seeds[t].numpy()
+                        out[pre + f'node_{t}'] = np.array(ref[2][t], dtype=np.int64)
+                        out[pre + f'nhops_{t}'] = np.array(ref[4][t], dtype=np.int64)
+                    cid += 1
     out['num_cases'] = np.array([cid])
     np.savez_compressed(os.path.join(HERE, 'biased_golden.npz'), **out)
     print(f'{cid} cases, {n_rows} sampled edges, oracle mismatches: {n_mismatch}')

@@ -39,13 +39,14 @@ def test_torch_vectors(case):
         e = ets[0]
         row, col, node, eid, nh, eh = sampler.neighbor_sample(
             dev(case['rowptr'][e]), dev(case['col'][e]), dev(case['seed']['n']), case['fan'][e],
-            edge_weight=wdev(case['weight'][e]), disjoint=case['disjoint'])
+            edge_weight=wdev(case['weight'][e]), disjoint=case['disjoint'], replace=case['replace'])
         rows, cols, nodes, eids, nhs, ehs = {e: row}, {e: col}, {'n': node}, {e: eid}, {'n': nh}, {e: eh}
     else:
         rows, cols, nodes, eids, nhs, ehs = sampler.hetero_neighbor_sample(
             {e: dev(case['rowptr'][e]) for e in ets}, {e: dev(case['col'][e]) for e in ets},
             {t: dev(s) for t, s in case['seed'].items()}, case['fan'],
-            edge_weight_dict={e: wdev(case['weight'][e]) for e in ets}, disjoint=case['disjoint'])
+            edge_weight_dict={e: wdev(case['weight'][e]) for e in ets}, disjoint=case['disjoint'],
+            replace=case['replace'])
     for e in ets:
         assert rows[e].cpu().tolist() == case['row_out'][e].tolist()
         assert cols[e].cpu().tolist() == case['col_out'][e].tolist()
@@ -262,3 +263,36 @@ def test_biased_dist_neighbor_sample(dtype, disjoint):
         assert torch.equal(node.cpu(), torch.from_numpy(rnode))
         assert cumsum == rcumsum
         assert after == oracle.mt19937_word_after(8, 256 * info['rng_blocks'] + info['rng_raw_draws'])
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_biased_with_replacement_against_oracle(dtype):
+    """replace=True: at::multinomial(weight, count, true) for count > 1 (sequential cumulative sum in the weights'
+    type, one double per sample); a fan-out of 1 and invalid distributions fail loudly."""
+    rowptr, col, rng = big_graph(31, n=8000, avg=25, hubs=(2000, 30000))
+    w = (rng.random(col.size) ** 3 + 1e-3).astype(dtype)
+    w[rng.random(col.size) < 0.2] = 0  # zero weights are fine as long as a row keeps a positive one
+    deg = np.diff(rowptr)
+    for v in range(deg.size):  # ... so give every row one
+        if deg[v]:
+            w[rowptr[v]] = max(w[rowptr[v]], dtype(0.5))
+    seeds = rng.choice(8000, 300, replace=False).astype(np.int64)
+    seeds[:2] = np.argsort(deg)[-2:]
+    for fan, disjoint in (([6, 3, 2], False), ([40, 2], True), ([-1, 5], False), ([200], False)):
+        torch.manual_seed(77)
+        out = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), fan, edge_weight=wdev(w), replace=True,
+                                      disjoint=disjoint)
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        ref = oracle.neighbor_sample(rowptr, col, seeds, fan, edge_weight=w, replace=True, disjoint=disjoint, rng_seed=77)
+        for k in range(4):
+            assert torch.equal(out[k].cpu(), torch.from_numpy(ref[k])), (fan, k)
+        assert out[4] == ref[4] and out[5] == ref[5]
+        assert after == oracle.mt19937_word_after(77, 256 * ref[6]['rng_blocks'] + ref[6]['rng_raw_draws'])
+    with pytest.raises(RuntimeError, match='fan-out of 1'):
+        sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), [3, 1], edge_weight=wdev(w), replace=True)
+    bad = w.copy()
+    bad[rowptr[seeds[5]]:rowptr[seeds[5] + 1]] = 0  # one sampled row without any positive weight
+    with pytest.raises(RuntimeError, match='invalid multinomial distribution'):
+        sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), [3], edge_weight=wdev(bad), replace=True)
+    with pytest.raises(RuntimeError, match='invalid multinomial distribution'):
+        oracle.neighbor_sample(rowptr, col, seeds, [3], edge_weight=bad, replace=True)

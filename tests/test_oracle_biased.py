@@ -14,7 +14,7 @@ CASES = biased_cases.load()
 @pytest.mark.parametrize('case', CASES, ids=[f"c{c['id']}" for c in CASES])
 def test_oracle_matches_torch_vectors(case):
     out = oracle.hetero_neighbor_sample(case['node_types'], case['edge_types'], case['rowptr'], case['col'],
-                                        case['seed'], case['fan'], disjoint=case['disjoint'],
+                                        case['seed'], case['fan'], disjoint=case['disjoint'], replace=case['replace'],
                                         rng_seed=case['manual_seed'], edge_weight_dict=case['weight'])
     rows, cols, nodes, eids, nh, eh, info = out
     for e in case['edge_types']:

@@ -70,11 +70,13 @@ def run(cases=200, seed=0):
                     kw['seed_time'] = rng.integers(0, 60, seeds.size, dtype=np.int64)
                 nt += 1
             biased = 'temporal_strategy' not in kw and rng.random() < 0.3
-            if biased:
-                kw['replace'] = False
-                kw['edge_weight'] = weights(cl.size)
-                nb += 1
             fan = fanout(L)
+            if biased:
+                kw['edge_weight'] = weights(cl.size)
+                if kw['replace']:  # at::multinomial: strictly positive weights, no single draws
+                    kw['edge_weight'] = np.abs(kw['edge_weight']) + kw['edge_weight'].dtype.type(0.25)
+                    fan = [2 if f == 1 else f for f in fan]
+                nb += 1
             torch.manual_seed(seed)
             dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
             if not biased and rng.random() < 0.15:  # int32 graph: same samples, int32 outputs
