@@ -522,7 +522,9 @@ def dist_neighbor_sample(rowptr, col, seed, num_neighbors, node_time=None, edge_
             rng_seed & 0xFFFFFFFFFFFFFFFF)
     E = L.oracle_dist_neighbor_sample_w(*args, None, None, None, None, None)
     if E == -2:
-        raise NotImplementedError('biased sampling with replacement is not restated')
+        raise NotImplementedError('biased sampling with replacement and one draw per node is not restated')
+    if E == -3:
+        raise RuntimeError('invalid multinomial distribution')
     if E < 0:
         raise RuntimeError('Found invalid non-sorted temporal neighborhood')
     nodes = np.zeros((S + E, 2) if disjoint else (S + E,), dtype=np.int64)

@@ -366,9 +366,8 @@ static void sampler_sample(sampler_t* s, int64_t row_start, int64_t row_end, int
  * below it.  Pinned against torch.multinomial itself (tests/golden/make_biased_golden.py).  count == 1 takes a
  * different route inside at::multinomial (exponential_ through MKL's own generator): not restated (-2).
  * Returns -3 for the distributions at::multinomial rejects (negative / non-finite weights, zero sum). */
-static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t population, int64_t count,
-                                  int64_t src_batch, int64_t local_src, nodeset_t* dst, int disjoint, engine_t* eng,
-                                  const void* weight, int weight_f64) {
+static int multinomial_replace(engine_t* eng, const void* weight, int weight_f64, int64_t row_start,
+                               int64_t population, int64_t count, int64_t* idx) {
   if (count == 1) return -2;
   int rc = 0;
   if (!weight_f64) {
@@ -391,7 +390,7 @@ static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t popul
           const int64_t mid = lo + (hi - lo) / 2;
           if ((double)cum[mid] < u) lo = mid + 1; else hi = mid;
         }
-        sampler_add(s, row_start + lo, src_batch, local_src, dst, disjoint);
+        idx[i] = lo;
       }
     }
     free(cum);
@@ -415,12 +414,24 @@ static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t popul
           const int64_t mid = lo + (hi - lo) / 2;
           if (cum[mid] < u) lo = mid + 1; else hi = mid;
         }
-        sampler_add(s, row_start + lo, src_batch, local_src, dst, disjoint);
+        idx[i] = lo;
       }
     }
     free(cum);
   }
   if (rc == 0) eng->raw_draws += 2 * count;
+  return rc;
+}
+
+static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t population, int64_t count,
+                                  int64_t src_batch, int64_t local_src, nodeset_t* dst, int disjoint, engine_t* eng,
+                                  const void* weight, int weight_f64) {
+  if (count == 1) return -2;
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
+  const int rc = multinomial_replace(eng, weight, weight_f64, row_start, population, count, idx);
+  if (rc == 0)
+    for (int64_t i = 0; i < count; ++i) sampler_add(s, row_start + idx[i], src_batch, local_src, dst, disjoint);
+  free(idx);
   return rc;
 }
 
@@ -782,8 +793,14 @@ int64_t oracle_dist_neighbor_sample_w(const int64_t* rowptr, const int64_t* col,
       const int64_t pop = re - rs;
       if (count < 0 || (!replace && count >= pop)) {
         for (int64_t e = rs; e < re; ++e) { vpush(&eids, e); vpush(&nodes, col[e]); vpush(&batches, i); }
+      } else if (weight && replace) {
+        int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
+        const int mrc = multinomial_replace(&eng, weight, weight_f64, rs, pop, count, idx);
+        if (mrc == 0)
+          for (int64_t j = 0; j < count; ++j) { vpush(&eids, rs + idx[j]); vpush(&nodes, col[rs + idx[j]]); vpush(&batches, i); }
+        free(idx);
+        if (mrc != 0) { rc = mrc; break; }
       } else if (weight) {
-        if (replace) { rc = -2; break; }
         int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
         if (!weight_f64) {
           const float* w = (const float*)weight + rs;

@@ -3023,7 +3023,10 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   if (weight) {  // biased_sample in distributed mode (neighbor_kernel.cpp:436-447, 296-303)
     PYG_HIP_REQUIRE(!temporal, "Biased temporal sampling not yet supported");
     PYG_HIP_REQUIRE(weight_dtype == PYG_F32 || weight_dtype == PYG_F64, "sampler: edge_weight must be float32 or float64");
-    if (replace) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling with replacement (at::multinomial) is not available on the device path");
+    if (replace && count == 1)
+      return fail(PYG_HIP_ERR_UNSUPPORTED,
+                  "sampler: biased sampling with replacement and a fan-out of 1 is not available on the device path "
+                  "(at::multinomial draws a single sample through exponential_ and MKL's own generator)");
     if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
   }
   if (c.host->mt19937) {
@@ -3077,7 +3080,11 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     const bool f64 = weight_dtype == PYG_F64;
     const int64_t out_base = rng.blocks * 256;  // the uniform_ draws follow the engine's first block
     int rc;
-    if (weight) {
+    if (weight && replace) {
+      BiasedReplaceCountLoad cl{seed, 0, rowptr, count};
+      CountStore cs{edge_off, rng_word, rng_units, 0, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    } else if (weight) {
       BiasedCountLoad cl{seed, 0, rowptr, count, f64 ? 2 : 1};
       CountStore cs{edge_off, rng_word, rng_units, out_base, 4, nullptr};
       rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
@@ -3101,7 +3108,9 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     for (int64_t i = 0; i + 1 < S; ++i) cumsum_host[1 + i] = S + cumsum_host[2 + i];
     cumsum_host[S] = S + E;
     if (E > 0) {
-      const int64_t W = weight ? (int64_t)(tot.tab >> 20) : 0;  // generator outputs drawn by uniform_
+      // generator outputs drawn directly: uniform_ values per neighbour, or one double per sampled edge
+      const int64_t scratch_w = (weight && replace) ? (int64_t)(tot.tab >> 20) : 0;
+      const int64_t W = !weight ? 0 : replace ? (count > 0 ? 2 * E : 0) : (int64_t)(tot.tab >> 20);
       if (weight) {
         if (W > 0) rc = rng_wait32(c, rng, out_base + W, nullptr);
       } else {
@@ -3136,6 +3145,28 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
       a.table = HashTable{nullptr, nullptr, 0};
       if (!weight) {
         launch_sample(a, S, stream);
+      } else if (replace) {
+        HopInfo* info;
+        void* cum;
+        PYG_ALLOC(info, HopInfo*, c, sizeof(HopInfo));
+        PYG_ALLOC(cum, void*, c, (f64 ? 8 : 4) * (size_t)std::max<int64_t>(scratch_w, 1));
+        PYG_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(HopInfo), stream));
+        a.replace = 1;
+        const unsigned wg = (unsigned)((S + 3) / 4);
+        if (f64)
+          hipLaunchKernelGGL(biased_replace_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info,
+                             static_cast<const double*>(weight), reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                             static_cast<double*>(cum));
+        else
+          hipLaunchKernelGGL(biased_replace_kernel<float>, dim3(wg), dim3(256), 0, stream, a, info,
+                             static_cast<const float*>(weight), reinterpret_cast<const uint32_t*>(rng.dev), out_base,
+                             static_cast<float*>(cum));
+        PYG_HIP_CHECK(hipGetLastError());
+        PYG_HIP_CHECK(hipMemcpyAsync(pinned, info, sizeof(HopInfo), hipMemcpyDeviceToHost, stream));
+        PYG_HIP_CHECK(hipStreamSynchronize(stream));
+        if (static_cast<HopInfo*>(pinned)->overflow == 3)
+          return fail(PYG_HIP_ERR_INVALID, "invalid multinomial distribution (a sampled row has negative or non-finite weights, or they sum to zero)");
+        rng.raw_used += W;
       } else {
         const int64_t draws = W / (f64 ? 2 : 1);
         const size_t ksz = f64 ? 8 : 4;

@@ -296,3 +296,19 @@ def test_biased_with_replacement_against_oracle(dtype):
         sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), [3], edge_weight=wdev(bad), replace=True)
     with pytest.raises(RuntimeError, match='invalid multinomial distribution'):
         oracle.neighbor_sample(rowptr, col, seeds, [3], edge_weight=bad, replace=True)
+
+
+def test_biased_dist_neighbor_sample_with_replacement():
+    rowptr, col, rng = big_graph(4, n=5000, avg=15, hubs=(3000,))
+    w = (rng.random(col.size) + 0.05).astype(np.float32)
+    seeds = rng.choice(5000, 300, replace=False).astype(np.int64)
+    for fan, disjoint in ((4, False), (70, True)):
+        torch.manual_seed(9)
+        node, edge, cumsum = torch.ops.pyg.dist_neighbor_sample(dev(rowptr), dev(col), dev(seeds), fan, None, None, None,
+                                                                wdev(w), True, True, True, disjoint, 'uniform')
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        rnode, redge, rcumsum, info = oracle.dist_neighbor_sample(rowptr, col, seeds, fan, rng_seed=9, edge_weight=w,
+                                                                  replace=True, disjoint=disjoint)
+        assert torch.equal(edge.cpu(), torch.from_numpy(redge)) and torch.equal(node.cpu(), torch.from_numpy(rnode))
+        assert cumsum == rcumsum
+        assert after == oracle.mt19937_word_after(9, 256 * info['rng_blocks'] + info['rng_raw_draws'])
