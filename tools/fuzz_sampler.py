@@ -109,11 +109,13 @@ def run(cases=200, seed=0):
             fan = {e: fanout(L) for e in ets}
             wd = None
             if rng.random() < 0.35:  # biased: all or some of the relations weighted
-                replace = False
                 some = rng.random() < 0.5
                 wd = {e: weights(cl[e].size) for e in ets if not some or rng.random() < 0.5}
                 if not wd:
                     wd = {ets[0]: weights(cl[ets[0]].size)}
+                if replace:  # at::multinomial: strictly positive weights, no single draws on weighted relations
+                    wd = {e: np.abs(v) + v.dtype.type(0.25) for e, v in wd.items()}
+                    fan = {e: ([2 if f == 1 else f for f in fl] if e in wd else fl) for e, fl in fan.items()}
                 nb += 1
             torch.manual_seed(seed)
             out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
