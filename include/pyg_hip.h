@@ -240,9 +240,10 @@ typedef struct {
  * the generator stream, as in the reference).  With replace != 0 the reference calls
  * at::multinomial(weight, count, true): for count > 1 that is a sequential cumulative sum in the weights' type,
  * a division by the sum, and one 53-bit double per sample located by binary search -- reproduced exactly
- * (PYG_HIP_ERR_INVALID "invalid multinomial distribution" for rows at::multinomial rejects); count == 1 goes
- * through exponential_ and MKL's own generator inside at::multinomial and fails with PYG_HIP_ERR_UNSUPPORTED,
- * as do temporal arguments and a missing host->mt19937.
+ * (PYG_HIP_ERR_INVALID "invalid multinomial distribution" for rows at::multinomial rejects); for count == 1
+ * at::multinomial takes argmax(weight / exponential_()) instead, where libtorch 2.10 draws one 53-bit double
+ * per neighbour and evaluates -log1p(-u) -- reproduced too (first of equal maxima).  Temporal arguments and a
+ * missing host->mt19937 fail with PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,

@@ -366,9 +366,48 @@ static void sampler_sample(sampler_t* s, int64_t row_start, int64_t row_end, int
  * below it.  Pinned against torch.multinomial itself (tests/golden/make_biased_golden.py).  count == 1 takes a
  * different route inside at::multinomial (exponential_ through MKL's own generator): not restated (-2).
  * Returns -3 for the distributions at::multinomial rejects (negative / non-finite weights, zero sum). */
+/* count == 1: at::multinomial's single-draw route (ATen/native/Distributions.cpp, "gumbel" fast path):
+ * q = empty_like(weight).exponential_(1); index = argmax(weight / q).  libtorch 2.10.0 (this image) evaluates
+ * exponential_ on the CPU element by element as -log1p(-u), u = one 53-bit double per element (random64, also for
+ * float32 tensors; the result is then rounded to the tensor's type) -- measured: bit-identical to this
+ * restatement on float32, within an ulp of log1p on float64; argmax takes the first of equal maxima and treats
+ * NaN as the maximum.  Pinned against torch.multinomial(w, 1, True) (tests/golden/make_biased_golden.py). */
+static int multinomial_single(engine_t* eng, const void* weight, int weight_f64, int64_t row_start,
+                              int64_t population, int64_t* idx) {
+  int rc = 0;
+  int64_t best = -1;
+  int best_nan = 0;
+  double best_key = 0.0, sum = 0.0;
+  for (int64_t j = 0; j < population; ++j) {
+    const double u = (double)(mt19937_u64(&eng->gen) & ((1ull << 53) - 1)) * 0x1p-53;
+    const double q64 = -log1p(-u);
+    double key, wj;
+    if (!weight_f64) {
+      const float wf = ((const float*)weight)[row_start + j];
+      wj = (double)wf;
+      key = (double)(wf / (float)q64);
+    } else {
+      wj = ((const double*)weight)[row_start + j];
+      key = wj / q64;
+    }
+    if (!(wj >= 0.0) || !isfinite(wj)) rc = -3;
+    sum += wj;
+    const int is_nan = key != key;
+    if (best < 0 || (!best_nan && (is_nan || key > best_key))) {
+      best = j;
+      best_key = key;
+      best_nan = is_nan;
+    }
+  }
+  if (!(sum > 0.0)) rc = -3;
+  eng->raw_draws += 2 * population;
+  idx[0] = best;
+  return rc;
+}
+
 static int multinomial_replace(engine_t* eng, const void* weight, int weight_f64, int64_t row_start,
                                int64_t population, int64_t count, int64_t* idx) {
-  if (count == 1) return -2;
+  if (count == 1) return multinomial_single(eng, weight, weight_f64, row_start, population, idx);
   int rc = 0;
   if (!weight_f64) {
     const float* w = (const float*)weight + row_start;
@@ -426,7 +465,6 @@ static int multinomial_replace(engine_t* eng, const void* weight, int weight_f64
 static int sampler_biased_replace(sampler_t* s, int64_t row_start, int64_t population, int64_t count,
                                   int64_t src_batch, int64_t local_src, nodeset_t* dst, int disjoint, engine_t* eng,
                                   const void* weight, int weight_f64) {
-  if (count == 1) return -2;
   int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)count);
   const int rc = multinomial_replace(eng, weight, weight_f64, row_start, population, count, idx);
   if (rc == 0)

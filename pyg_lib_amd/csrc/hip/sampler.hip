@@ -1634,6 +1634,94 @@ __global__ __launch_bounds__(256) void biased_replace_kernel(HopArgs a, HopInfo*
   }
 }
 
+// at::multinomial(weight, 1, true): the single-draw route (ATen/native/Distributions.cpp) -- q =
+// empty_like(weight).exponential_(1), index = argmax(weight / q).  libtorch 2.10.0 evaluates exponential_ on the
+// CPU as -log1p(-u) with ONE 53-bit double per element (random64, also for float32 tensors; the value is then
+// rounded to the tensor's type), argmax returns the first of equal maxima and treats NaN as the maximum.  One wave
+// per row: every row draws 2 deg outputs (offset = the scan's word field), lanes keep (best key, index).
+struct BiasedSingleCountLoad {
+  const int64_t* nodes;
+  int64_t begin;
+  const int64_t* rowptr;
+  __device__ CountAgg operator()(int64_t i) const {
+    CountAgg r;
+    r.tab = rng_identity();
+    r.edges = 0;
+    const int64_t v = nodes[begin + i];
+    const int64_t deg = rowptr[v + 1] - rowptr[v];
+    if (deg <= 0) return r;
+    r.edges = 1;
+    r.tab |= (u64)(2 * deg) << 20;
+    return r;
+  }
+};
+
+template <typename W>
+__global__ __launch_bounds__(256) void biased_single_kernel(HopArgs a, HopInfo* info, const W* __restrict__ weight,
+                                                            const uint32_t* __restrict__ out32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) info->tot.tab = rng_identity();
+  if (i >= a.frontier) return;
+  const int64_t src_pos = a.begin + i;
+  const int64_t v = a.nodes[src_pos];
+  const int64_t batch = a.batch ? a.batch[src_pos] : 0;
+  const int64_t rs = a.range.rowptr[v];
+  const int64_t n = a.range.rowptr[v + 1] - rs;
+  if (n <= 0) return;
+  const int64_t o0 = a.rng_word[i];
+  const W* w = weight + rs;
+  // order: NaN above everything, then by value; ties keep the smaller index
+  int64_t best = -1;
+  int best_nan = 0;
+  double best_key = 0.0;
+  double sum = 0.0;
+  int bad = 0;
+  for (int64_t j = lane; j < n; j += 64) {
+    const uint64_t r64 = ((uint64_t)mt_output_at(out32, o0 + 2 * j) << 32) | mt_output_at(out32, o0 + 2 * j + 1);
+    const double u = (double)(r64 & ((1ull << 53) - 1)) * 0x1p-53;
+    const double q64 = -log1p(-u);
+    const W wj = w[j];
+    double key;
+    if (sizeof(W) == 4) key = (double)__fdiv_rn((float)wj, (float)q64);
+    else key = (double)wj / q64;
+    if (!(wj >= (W)0) || isinf(wj)) bad = 1;
+    sum += (double)wj;
+    const int is_nan = key != key;
+    if (best < 0 || (!best_nan && (is_nan || key > best_key))) {
+      best = j;
+      best_key = key;
+      best_nan = is_nan;
+    }
+  }
+  // wave reduction of (nan, key, index) with the same order; lanes without elements hold best = -1
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const int64_t ob = __shfl_xor(best, d, 64);
+    const int on = __shfl_xor(best_nan, d, 64);
+    const double ok = __shfl_xor(best_key, d, 64);
+    sum += __shfl_xor(sum, d, 64);
+    bad |= __shfl_xor(bad, d, 64);
+    bool take = false;
+    if (ob >= 0) {
+      if (best < 0) take = true;
+      else if (on != best_nan) take = on > best_nan;
+      else if (!on && ok != best_key) take = ok > best_key;
+      else take = ob < best;
+    }
+    if (take) {
+      best = ob;
+      best_nan = on;
+      best_key = ok;
+    }
+  }
+  if (bad || !(sum > 0.0)) {
+    if (lane == 0) info->overflow = 3;
+    return;
+  }
+  if (lane == 0) emit(a, a.edge_off[i], rs + best, src_pos, batch);
+}
+
 // ---- host driver -----------------------------------------------------------------------------------
 struct Ctx {
   const pyg_hip_sampler_host* host;
@@ -2614,12 +2702,13 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(raw_off, int64_t*, c, sizeof(int64_t) * (size_t)F);
     PYG_ALLOC(flag, int32_t*, c, sizeof(int32_t) * (size_t)F);
     const int64_t out_base = rng.blocks * 256 + rng.raw_used;
-    if (replace && count == 1)
-      return fail(PYG_HIP_ERR_UNSUPPORTED,
-                  "sampler: biased sampling with replacement and a fan-out of 1 is not available on the device path "
-                  "(at::multinomial draws a single sample through exponential_ and MKL's own generator)");
+    const bool single = replace && count == 1;  // at::multinomial's single-draw route
     int rc;
-    if (replace) {
+    if (single) {
+      BiasedSingleCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr};
+      CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
+    } else if (replace) {
       // the word field of the scan carries the cumulative-distribution scratch offset (in weights)
       BiasedReplaceCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count};
       CountStore cs{edge_off, raw_off, flag, 0, 4, nullptr};
@@ -2635,10 +2724,10 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                                  hipMemcpyDeviceToHost, stream));
     PYG_HIP_CHECK(hipStreamSynchronize(stream));
     const int64_t E = info_host[e].tot.edges;
-    const int64_t scratch_w = replace ? (int64_t)(info_host[e].tot.tab >> 20) : 0;  // cumulative-distribution entries
-    // generator outputs drawn by this relation: one uniform_ value per neighbour of every drawing row, or one
-    // double per sampled edge (with replacement)
-    const int64_t W = replace ? (count > 0 ? 2 * E : 0) : (int64_t)(info_host[e].tot.tab >> 20);
+    const int64_t scratch_w = (replace && !single) ? (int64_t)(info_host[e].tot.tab >> 20) : 0;  // cumulative-distribution entries
+    // generator outputs drawn by this relation: one uniform_ value per neighbour of every drawing row, one double
+    // per sampled edge (with replacement, count > 1), or one double per neighbour (single draw)
+    const int64_t W = (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)(info_host[e].tot.tab >> 20);
     auto cleanup = [&]() {
       c.release(tile_buf);
       c.release(edge_off);
@@ -2683,7 +2772,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     PYG_ALLOC(e_slot, u64*, c, sizeof(u64) * (size_t)E);
     const int64_t etiles = (E + kScanTile - 1) / kScanTile;
     PYG_ALLOC(ftile, int64_t*, c, sizeof(int64_t) * (size_t)(etiles + 1));
-    const int64_t draws = replace ? scratch_w : W / outputs;
+    const int64_t draws = single ? 0 : (replace ? scratch_w : W / outputs);
     const size_t ksz = f64 ? 8 : 4;
     void *skey, *selkey;
     int32_t *sidx, *selidx;
@@ -2715,7 +2804,15 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     a.e_slot = e_slot;
     a.table = dn.table;
     const unsigned wg = (unsigned)((F + 3) / 4), xg = (unsigned)((F + 63) / 64);
-    if (replace) {
+    if (single) {
+      a.replace = 1;
+      if (f64)
+        hipLaunchKernelGGL(biased_single_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info_dev + e,
+                           static_cast<const double*>(r.edge_weight), reinterpret_cast<const uint32_t*>(rng.dev));
+      else
+        hipLaunchKernelGGL(biased_single_kernel<float>, dim3(wg), dim3(256), 0, stream, a, info_dev + e,
+                           static_cast<const float*>(r.edge_weight), reinterpret_cast<const uint32_t*>(rng.dev));
+    } else if (replace) {
       a.replace = 1;
       if (f64)
         hipLaunchKernelGGL(biased_replace_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info_dev + e,
@@ -3023,12 +3120,9 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
   if (weight) {  // biased_sample in distributed mode (neighbor_kernel.cpp:436-447, 296-303)
     PYG_HIP_REQUIRE(!temporal, "Biased temporal sampling not yet supported");
     PYG_HIP_REQUIRE(weight_dtype == PYG_F32 || weight_dtype == PYG_F64, "sampler: edge_weight must be float32 or float64");
-    if (replace && count == 1)
-      return fail(PYG_HIP_ERR_UNSUPPORTED,
-                  "sampler: biased sampling with replacement and a fan-out of 1 is not available on the device path "
-                  "(at::multinomial draws a single sample through exponential_ and MKL's own generator)");
     if (!c.host->mt19937) return fail(PYG_HIP_ERR_UNSUPPORTED, "sampler: biased sampling needs the mt19937 engine state (host->mt19937)");
   }
+  const bool single = weight && replace && count == 1;  // at::multinomial's single-draw route
   if (c.host->mt19937) {
     std::vector<int64_t> spec;
     if (count > 0 && !weight) spec.push_back(std::min<int64_t>(kSpecCapWords, 256 + (int64_t)((double)S * (double)count / 4.0)));
@@ -3080,7 +3174,11 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     const bool f64 = weight_dtype == PYG_F64;
     const int64_t out_base = rng.blocks * 256;  // the uniform_ draws follow the engine's first block
     int rc;
-    if (weight && replace) {
+    if (single) {
+      BiasedSingleCountLoad cl{seed, 0, rowptr};
+      CountStore cs{edge_off, rng_word, rng_units, out_base, 4, nullptr};
+      rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
+    } else if (weight && replace) {
       BiasedReplaceCountLoad cl{seed, 0, rowptr, count};
       CountStore cs{edge_off, rng_word, rng_units, 0, 4, nullptr};
       rc = device_scan<CountAgg, CountOp>(cl, cs, S, tile_buf, tile_buf + ntiles, stream);
@@ -3109,8 +3207,8 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     cumsum_host[S] = S + E;
     if (E > 0) {
       // generator outputs drawn directly: uniform_ values per neighbour, or one double per sampled edge
-      const int64_t scratch_w = (weight && replace) ? (int64_t)(tot.tab >> 20) : 0;
-      const int64_t W = !weight ? 0 : replace ? (count > 0 ? 2 * E : 0) : (int64_t)(tot.tab >> 20);
+      const int64_t scratch_w = (weight && replace && !single) ? (int64_t)(tot.tab >> 20) : 0;
+      const int64_t W = !weight ? 0 : (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)(tot.tab >> 20);
       if (weight) {
         if (W > 0) rc = rng_wait32(c, rng, out_base + W, nullptr);
       } else {
@@ -3153,7 +3251,13 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
         PYG_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(HopInfo), stream));
         a.replace = 1;
         const unsigned wg = (unsigned)((S + 3) / 4);
-        if (f64)
+        if (single && f64)
+          hipLaunchKernelGGL(biased_single_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info,
+                             static_cast<const double*>(weight), reinterpret_cast<const uint32_t*>(rng.dev));
+        else if (single)
+          hipLaunchKernelGGL(biased_single_kernel<float>, dim3(wg), dim3(256), 0, stream, a, info,
+                             static_cast<const float*>(weight), reinterpret_cast<const uint32_t*>(rng.dev));
+        else if (f64)
           hipLaunchKernelGGL(biased_replace_kernel<double>, dim3(wg), dim3(256), 0, stream, a, info,
                              static_cast<const double*>(weight), reinterpret_cast<const uint32_t*>(rng.dev), out_base,
                              static_cast<double*>(cum));

@@ -4,7 +4,7 @@ libtorch CPU ops the reference calls -- pyg_lib/csrc/sampler/cpu/neighbor_kernel
     rand  = at::empty_like(weight).uniform_()         # global CPU generator
     key   = rand.log() / weight
     index = std::get<1>(key.topk(count))              # replace == false
-    index = at::multinomial(weight, count, true)      # replace == true (cases with count > 1)
+    index = at::multinomial(weight, count, true)      # replace == true (count > 1 and the single-draw route)
 
 around a Python transcription of the (single-threaded) hop loop (:332-514 homogeneous, :518-841
 heterogeneous; Mapper = first-occurrence dict).  The engine constructor's prefetch
@@ -196,7 +196,7 @@ def main():
                         n = 300
                         rp, cl = random_csr(g, n, n, 9, hub=300)
                         rowptr, col = {ets[0]: rp}, {ets[0]: cl}
-                        fan = {ets[0]: [4, 3, 2]}
+                        fan = {ets[0]: [4, 1, 2]}  # a fan-out of 1 takes at::multinomial's single-draw route
                         seeds = {'n': torch.randperm(n, generator=g)[:7]}
                     else:
                         nt = ['a', 'b']
@@ -205,7 +205,7 @@ def main():
                         rowptr, col = {}, {}
                         for e in ets:
                             rowptr[e], col[e] = random_csr(g, sizes[e[0]], sizes[e[2]], 7, hub=500)
-                        fan = {ets[0]: [3, 2], ets[1]: [2, 4], ets[2]: [6, 2]}
+                        fan = {ets[0]: [3, 1], ets[1]: [1, 4], ets[2]: [6, 2]}
                         seeds = {'a': torch.randperm(200, generator=g)[:5], 'b': torch.randperm(120, generator=g)[:3]}
                     weight = {e: make_weight(g, col[e].numel(), kind, dtype) for e in ets}
                     ref = torch_biased(nt, ets, rowptr, col, weight, seeds, fan, ms, disjoint=disjoint, replace=True)

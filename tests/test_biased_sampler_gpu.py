@@ -238,8 +238,6 @@ def test_log_f32_matches_on_every_uniform_argument():
 def test_unsupported_modes_fail_loudly():
     rowptr, col = cycle_graph(6)
     w = wdev(np.ones(12, dtype=np.float32))
-    with pytest.raises(RuntimeError, match='replacement'):
-        sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w, replace=True)
     with pytest.raises(RuntimeError, match='float32 or float64'):
         sampler.neighbor_sample(dev(rowptr), dev(col), dev([0, 1]), [1], edge_weight=w.half())
 
@@ -288,8 +286,15 @@ def test_biased_with_replacement_against_oracle(dtype):
             assert torch.equal(out[k].cpu(), torch.from_numpy(ref[k])), (fan, k)
         assert out[4] == ref[4] and out[5] == ref[5]
         assert after == oracle.mt19937_word_after(77, 256 * ref[6]['rng_blocks'] + ref[6]['rng_raw_draws'])
-    with pytest.raises(RuntimeError, match='fan-out of 1'):
-        sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), [3, 1], edge_weight=wdev(w), replace=True)
+    # a fan-out of 1: at::multinomial's single-draw route (exponential_ + argmax)
+    for fan in ([1], [3, 1, 1], [1, 4]):
+        torch.manual_seed(78)
+        out = sampler.neighbor_sample(dev(rowptr), dev(col), dev(seeds), fan, edge_weight=wdev(w), replace=True)
+        after = int(torch.randint(I64_MIN, I64_MAX, (1,)).item())
+        ref = oracle.neighbor_sample(rowptr, col, seeds, fan, edge_weight=w, replace=True, rng_seed=78)
+        for k in range(4):
+            assert torch.equal(out[k].cpu(), torch.from_numpy(ref[k])), (fan, k)
+        assert after == oracle.mt19937_word_after(78, 256 * ref[6]['rng_blocks'] + ref[6]['rng_raw_draws'])
     bad = w.copy()
     bad[rowptr[seeds[5]]:rowptr[seeds[5] + 1]] = 0  # one sampled row without any positive weight
     with pytest.raises(RuntimeError, match='invalid multinomial distribution'):

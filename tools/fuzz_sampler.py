@@ -73,9 +73,8 @@ def run(cases=200, seed=0):
             fan = fanout(L)
             if biased:
                 kw['edge_weight'] = weights(cl.size)
-                if kw['replace']:  # at::multinomial: strictly positive weights, no single draws
+                if kw['replace']:  # at::multinomial: every sampled row needs a positive weight
                     kw['edge_weight'] = np.abs(kw['edge_weight']) + kw['edge_weight'].dtype.type(0.25)
-                    fan = [2 if f == 1 else f for f in fan]
                 nb += 1
             torch.manual_seed(seed)
             dkw = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
@@ -113,9 +112,8 @@ def run(cases=200, seed=0):
                 wd = {e: weights(cl[e].size) for e in ets if not some or rng.random() < 0.5}
                 if not wd:
                     wd = {ets[0]: weights(cl[ets[0]].size)}
-                if replace:  # at::multinomial: strictly positive weights, no single draws on weighted relations
+                if replace:  # at::multinomial: every sampled row needs a positive weight
                     wd = {e: np.abs(v) + v.dtype.type(0.25) for e, v in wd.items()}
-                    fan = {e: ([2 if f == 1 else f for f in fl] if e in wd else fl) for e, fl in fan.items()}
                 nb += 1
             torch.manual_seed(seed)
             out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
