@@ -84,6 +84,7 @@ int index_sort_i64(const int64_t* keys, int64_t n, int64_t max_value, int64_t* k
 // largest window of raw values one of `parts` equal shares of the list touches.
 constexpr int kMtSeg = 20480;
 constexpr int kMtMaxSeg = 64;
+constexpr int kMtStride = 4;  // long rounds: the jump segments start kMtStride * kMtSeg apart (and are that long)
 int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* max_span);
 
 // csr.hip: row sums seeded from `out` (the atomic-free, source-order back end of segment_sum_coo).

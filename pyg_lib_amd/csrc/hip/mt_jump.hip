@@ -88,6 +88,7 @@ struct Tables {
   Poly phi_low;            // phi = x^19937 + sum_j phi_low[j] x^j
   Poly g1;                 // x^kMtSeg mod phi
   std::vector<Poly> g;     // g[k] = x^(k * kMtSeg) mod phi, grown on demand (g[0] unused)
+  std::vector<Poly> gs;    // strided: gs[b] = x^((1 + b * kMtStride) * kMtSeg) mod phi (long rounds)
   struct DevList {
     uint16_t* idx = nullptr;
     int count = 0;
@@ -159,7 +160,8 @@ int init_tables(Tables& t) {
 
 }  // namespace
 
-// Device-resident list of the set coefficient positions of g_k = x^(k * kMtSeg) mod phi (1 <= k < kMtMaxSeg).
+// Device-resident list of the set coefficient positions of g_k = x^(k * kMtSeg) mod phi (1 <= k < kMtMaxSeg, or
+// k = 1 + b * kMtStride for the long rounds).
 int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* max_span) {
   Tables& t = tables();
   std::lock_guard<std::mutex> lock(t.mu);
@@ -171,8 +173,21 @@ int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* ma
       return rc;
     }
   }
-  PYG_HIP_REQUIRE(k >= 1 && k < kMtMaxSeg, "mt19937 jump: segment %d out of range", k);
-  while ((int)t.g.size() <= k) t.g.push_back(mulmod(t.g1, t.g.back(), t.phi_low));
+  PYG_HIP_REQUIRE(k >= 1 && k <= 1 + (kMtMaxSeg - 2) * kMtStride, "mt19937 jump: segment %d out of range", k);
+  // k < kMtMaxSeg: the unit chain g[k] = g1 * g[k-1]; larger k (long rounds): only k = 1 + b * kMtStride, through the
+  // chain gs[b] = g[kMtStride] * gs[b-1] (one multiplication per list either way, each list built on first use)
+  const Poly* poly = nullptr;
+  if (k < kMtMaxSeg) {
+    while ((int)t.g.size() <= k) t.g.push_back(mulmod(t.g1, t.g.back(), t.phi_low));
+    poly = &t.g[(size_t)k];
+  } else {
+    PYG_HIP_REQUIRE((k - 1) % kMtStride == 0, "mt19937 jump: segment %d is not on the long-round grid", k);
+    const int b = (k - 1) / kMtStride;
+    while ((int)t.g.size() <= kMtStride) t.g.push_back(mulmod(t.g1, t.g.back(), t.phi_low));
+    if (t.gs.empty()) t.gs.push_back(t.g[1]);
+    while ((int)t.gs.size() <= b) t.gs.push_back(mulmod(t.g[(size_t)kMtStride], t.gs.back(), t.phi_low));
+    poly = &t.gs[(size_t)b];
+  }
   int dev = 0;
   PYG_HIP_CHECK(hipGetDevice(&dev));
   if ((int)t.dev.size() <= dev) t.dev.resize((size_t)dev + 1);
@@ -181,7 +196,7 @@ int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* ma
   if (!dl.idx) {
     std::vector<uint16_t> host;
     for (int i = 0; i < kDeg; ++i)
-      if (get_bit(t.g[(size_t)k], i)) host.push_back((uint16_t)i);
+      if (get_bit(*poly, i)) host.push_back((uint16_t)i);
     uint16_t* p = nullptr;
     PYG_HIP_CHECK(hipMalloc(&p, sizeof(uint16_t) * std::max<size_t>(host.size(), 1)));
     // immutable table, uploaded once per device; synchronous on purpose (first use only)

@@ -978,13 +978,16 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict
 // Segments 1 .. K-1: workgroup b continues from windows[b] = r[1 + k seg .. 1 + k seg + 623], k = b + 1.
 __global__ __launch_bounds__(kMtThreads) void mt_segment_kernel(const uint32_t* __restrict__ windows,
                                                                 uint32_t* __restrict__ out32, int64_t o_r0,
-                                                                uint32_t seg, uint32_t* __restrict__ window_out,
+                                                                uint32_t unit, uint32_t stride, uint32_t* __restrict__ window_out,
                                                                 const int* stop) {
   __shared__ uint32_t x[2048 + 1];
   __shared__ int stop_s;
   const int tid = threadIdx.x;
-  const uint32_t k = blockIdx.x + 1;
-  const uint32_t tk = 1 + k * seg;  // raw position of the window's first value
+  // workgroup b continues from the window of raw position 1 + (1 + b * stride) * unit and generates stride * unit
+  // values (stride == 1: the segments k = 1, 2, ... of `unit` values each)
+  const uint32_t k = 1 + blockIdx.x * stride;
+  const uint32_t seg = stride * unit;
+  const uint32_t tk = 1 + k * unit;  // raw position of the window's first value
   for (int i = tid; i < 624; i += kMtThreads) {
     const uint32_t slot = (tk + i) & 2047;
     const uint32_t v = windows[blockIdx.x * 624 + i];
@@ -1911,9 +1914,13 @@ constexpr int64_t kSpecCapWords = (int64_t)kMtMaxSeg * kMtSeg / 2;  // one round
 int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
   while (!r.started || r.generated32() < target32) {
     // this round: segments 0 .. K-1 of kMtSeg values (segment 0 one more), raw positions [624, 625 + K seg)
-    int64_t K = (target32 - (r.o_r0 + 625) + kMtSeg - 1) / kMtSeg;
+    // K workgroups: segment 0 (kMtSeg + 1 values, the prefix kernel) and K - 1 jump segments of stride * kMtSeg
+    // values each; requests beyond one unit round (64 x 20480) use the long grid: 4x fewer jump windows per output
+    const int64_t units = (target32 - (r.o_r0 + 625) + kMtSeg - 1) / kMtSeg;  // kMtSeg-sized pieces wanted
+    const int64_t stride = units > kMtMaxSeg ? kMtStride : 1;
+    int64_t K = 1 + (std::max<int64_t>(units, 1) - 1 + stride - 1) / stride;
     K = std::max<int64_t>(1, std::min<int64_t>(K, kMtMaxSeg));
-    const int64_t t_end = 625 + K * kMtSeg;
+    const int64_t t_end = 625 + (1 + (K - 1) * stride) * kMtSeg;
     const int64_t new_gen = r.o_r0 + t_end;
     const int64_t need_cap = (new_gen + 2 + 255) / 256;
     if (need_cap > r.dev_cap_blocks) {
@@ -1950,9 +1957,9 @@ int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
     if (K > 1) {
       MtJumpLists lists;
       int max_span = 0;
-      for (int k = 1; k < (int)K; ++k) {
+      for (int k = 1; k < (int)K; ++k) {  // slot k holds the list of segment 1 + (k - 1) * stride
         int span = 0;
-        rc = mt_jump_list(k, kMtJumpParts, &lists.idx[k], &lists.count[k], &span);
+        rc = mt_jump_list(1 + (k - 1) * (int)stride, kMtJumpParts, &lists.idx[k], &lists.count[k], &span);
         if (rc != PYG_HIP_OK) return rc;
         max_span = std::max(max_span, span);
       }
@@ -1968,7 +1975,7 @@ int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
       hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(K - 1), kMtJumpParts), dim3(256), jump_lds, ss, r.base_raw,
                          out32, r.o_r0, lists, r.windows);
       hipLaunchKernelGGL(mt_segment_kernel, dim3((unsigned)(K - 1)), dim3(kMtThreads), 0, ss, r.windows, out32, r.o_r0,
-                         (uint32_t)kMtSeg, r.window, const_cast<const int*>(r.stop));
+                         (uint32_t)kMtSeg, (uint32_t)stride, r.window, const_cast<const int*>(r.stop));
       PYG_HIP_CHECK(hipGetLastError());
       rc = r.side->next_event(&ev);
       if (rc != PYG_HIP_OK) return rc;
