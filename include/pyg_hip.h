@@ -116,6 +116,15 @@ PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_ho
  * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 
+/* Tile schedule of the 16-bit K = M = 128 segment/grouped matmul kernels (process wide):
+ *   0  automatic (default): the cyclic schedule once every CU has several 256-row tiles to sweep,
+ *      contiguous ranges below that;
+ *   1  contiguous tile range per workgroup (mfma_rows_lds_kernel): fastest when the allocator happened to
+ *      place input and output favourably (up to 6.1 TB/s on C2), 5.0 TB/s otherwise;
+ *   2  cyclic (mfma_rows_cyc_kernel): the chip sweeps one narrow window, 5.4 - 5.9 TB/s on either placement.
+ * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
+PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
+
 /*
  * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]
  * (input [N, K], grad_out [N, M], grad_other [B, K, M]; fp32 accumulation, one rounding).  Replaces the

@@ -95,7 +95,11 @@ Tensor segment_matmul_bias_kernel(const Tensor& input, const Tensor& ptr, const 
   return segment_matmul_impl(input, ptr, other, bias);
 }
 
-std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::TensorList other) {
+// `caller_pool` (this build's pyg::grouped_matmul_pool): a contiguous [sum of rows, M] tensor that receives the
+// outputs as consecutive row ranges -- the sharded driver passes its slot of the all-gather buffer
+// (pyg_lib_amd/sharding.py), so the results are produced where the collective reads them.
+static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const at::TensorList other,
+                                               const c10::optional<Tensor>& caller_pool) {
   TORCH_CHECK(input.size() == other.size(),
               "Number of 'input' tensors must match number of 'other' tensors");
   const size_t G = input.size();
@@ -133,7 +137,7 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
     const auto st = input[0].scalar_type();
     bool dw = (st == at::kBFloat16 || st == at::kHalf || st == at::kFloat);
     const int64_t K = input[0].size(0), M = other[0].size(1);
-    dw = dw && (K == 64 || K == 128 || K == 256) && M % 64 == 0;
+    dw = dw && !caller_pool.has_value() && (K == 64 || K == 128 || K == 256) && M % 64 == 0;
     for (size_t i = 0; dw && i < G; ++i)
       dw = input[i].size(0) == K && other[i].size(1) == M && !input[i].is_contiguous() &&
            input[i].t().is_contiguous() && other[i].is_contiguous() && (uintptr_t)input[i].data_ptr() % 16 == 0 &&
@@ -155,6 +159,9 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
       const int rc = pyg_hip_grouped_matmul_dw(dtype_code(st), groups.data(), (int64_t)G, pool.data_ptr(), ws.data_ptr(),
                                                (size_t)ws.numel(), current_stream(input[0]));
       if (rc == PYG_HIP_OK) {
+        // plain aliases of the pool, not tracked views: the reference returns G independent tensors, and
+        // outputs that are "views of a multi-output function" could not be modified in place by the caller
+        at::AutoDispatchBelowADInplaceOrView untracked;
         for (size_t i = 0; i < G; ++i) outs.push_back(pool.select(0, (int64_t)i));
         return outs;
       }
@@ -172,7 +179,30 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
     const int64_t n = input[i].size(0) * other[i].size(-1);
     total += (n + align - 1) / align * align;
   }
-  auto pool = at::empty({std::max<int64_t>(total, 1)}, input[0].options());
+  Tensor pool;
+  if (caller_pool.has_value()) {
+    pool = caller_pool.value();
+    const int64_t M0 = other[0].size(-1);
+    int64_t rows = 0;
+    for (size_t i = 0; i < G; ++i) {
+      TORCH_CHECK(other[i].size(-1) == M0, "grouped_matmul_pool: every 'other' must have the same number of columns");
+      rows += input[i].size(0);
+    }
+    TORCH_CHECK(pool.dim() == 2 && pool.size(0) == rows && pool.size(1) == M0 && pool.is_contiguous() &&
+                    pool.scalar_type() == input[0].scalar_type() && pool.device() == input[0].device(),
+                "grouped_matmul_pool: expected a contiguous 'pool' of shape [", rows, ", ", M0, "] like 'input'");
+    TORCH_CHECK((M0 * elt) % 16 == 0 || G == 1, "grouped_matmul_pool: rows of 'pool' must be 16-byte multiples");
+    total = 0;
+    for (size_t i = 0; i < G; ++i) {
+      offs[i] = total;
+      total += input[i].size(0) * M0;
+    }
+    pool = pool.view({-1});
+  } else {
+    pool = at::empty({std::max<int64_t>(total, 1)}, input[0].options());
+  }
+  // aliases of the pool that are NOT tracked as views (see above)
+  at::AutoDispatchBelowADInplaceOrView untracked;
   for (size_t i = 0; i < G; ++i) {
     auto a = input[i].contiguous();
     Tensor o = other[i];
@@ -201,6 +231,14 @@ std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::
   check_status(pyg_hip_grouped_matmul(dtype_code(input[0].scalar_type()), groups.data(), (int64_t)G,
                                       ws.data_ptr(), (size_t)ws.numel(), current_stream(input[0])));
   return outs;
+}
+
+std::vector<Tensor> grouped_matmul_kernel(const at::TensorList input, const at::TensorList other) {
+  return grouped_matmul_impl(input, other, c10::nullopt);
+}
+
+std::vector<Tensor> grouped_matmul_pool_kernel(const at::TensorList input, const at::TensorList other, Tensor pool) {
+  return grouped_matmul_impl(input, other, pool);
 }
 
 // Autograd, mirroring SegmentMatmul (pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:68-111).
@@ -648,6 +686,9 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   // this build only: bias as a fused epilogue
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::segment_matmul_bias(Tensor input, Tensor ptr, Tensor other, Tensor bias) -> Tensor"));
+  // this build only: grouped_matmul writing into a caller-provided [sum rows, M] pool (sharded driver)
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::grouped_matmul_pool(Tensor[] input, Tensor[] other, Tensor(a!) pool) -> Tensor[]"));
   // pyg_lib/csrc/sampler/neighbor.cpp:129-147
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::neighbor_sample(Tensor rowptr, Tensor col, Tensor seed, int[] "
@@ -680,6 +721,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul"), TORCH_FN(grouped_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul_pool"), TORCH_FN(grouped_matmul_pool_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::dist_neighbor_sample"), TORCH_FN(dist_neighbor_sample_kernel));
 }

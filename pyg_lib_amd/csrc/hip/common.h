@@ -55,10 +55,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Device properties, cached per device index (the reference keeps un-keyed process globals,
 // pyg_lib/csrc/ops/cuda/matmul_kernel.cu:19,118-119 -- not replicated).
 struct DeviceInfo {
+  int device;
   int num_cus;
   int max_lds_per_block;
 };
 const DeviceInfo& device_info();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kern` on the CURRENT device, applied once per (device, kernel)
+// for the whole process (the attribute is per device: a per-thread "done" flag would skip the second GPU).
+int ensure_dynamic_lds(const void* kern, int bytes);
 
 // Pinned host staging buffer (thread local) used for small asynchronous H2D descriptor copies.
 // `acquire` waits for the previous copy that used the buffer before handing it out again.

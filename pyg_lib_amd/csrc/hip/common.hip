@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace pyg_hip {
@@ -13,13 +15,14 @@ char* last_error_buffer() {
 
 const DeviceInfo& device_info() {
   static std::mutex mu;
-  static std::vector<DeviceInfo> cache(64, DeviceInfo{0, 0});
+  static std::vector<DeviceInfo> cache(64, DeviceInfo{0, 0, 0});
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
   std::lock_guard<std::mutex> lock(mu);
   if (cache[dev].num_cus == 0) {
     hipDeviceProp_t prop;
+    cache[dev].device = dev;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
       cache[dev].num_cus = prop.multiProcessorCount;
       cache[dev].max_lds_per_block = (int)prop.sharedMemPerBlock;
@@ -29,6 +32,18 @@ const DeviceInfo& device_info() {
     }
   }
   return cache[dev];
+}
+
+int ensure_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  PYG_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kern})) return PYG_HIP_OK;
+  PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kern});
+  return PYG_HIP_OK;
 }
 
 int PinnedStage::acquire(size_t bytes, void** out) {
@@ -56,8 +71,12 @@ int PinnedStage::commit(hipStream_t stream) {
 }
 
 PinnedStage& pinned_stage() {
-  static thread_local PinnedStage st;
-  return st;
+  // one staging buffer + event per (thread, device): an event belongs to the device it was created on
+  static thread_local std::vector<PinnedStage> st(64);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  return st[dev];
 }
 
 }  // namespace pyg_hip

@@ -452,12 +452,7 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
       const int rpb = 256 / (int)inner;
       const int64_t blocks = outer * ((groups + rpb - 1) / rpb);
       const int lds = (int)(sizeof(T) * kSoftmaxValues * (BACKWARD ? 2 : 1));
-      static thread_local bool attr_set = false;  // per instantiation
-      if (!attr_set) {
-        PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&softmax_csr_stream_kernel<T, BACKWARD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-      }
+      if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&softmax_csr_stream_kernel<T, BACKWARD>), lds)) return rc_;
       hipLaunchKernelGGL((softmax_csr_stream_kernel<T, BACKWARD>), dim3((unsigned)blocks), dim3(256), lds, stream,
                          static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), s, rpb);
       PYG_HIP_CHECK(hipGetLastError());

@@ -345,14 +345,8 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
                                          scan_tmp + ntiles, stream);
     if (rc != PYG_HIP_OK) return rc;
     constexpr int lds = (int)scatter_lds_bytes(sizeof(K));
-    static thread_local bool attr_set = false;  // per key type
-    if (!attr_set) {
-      PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_kernel<K, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_kernel<K, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_set = true;
-    }
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_kernel<K, true>), lds)) return rc_;
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_kernel<K, false>), lds)) return rc_;
     if (ps == 0)
       hipLaunchKernelGGL((scatter_kernel<K, true>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k,
                          (const int64_t*)nullptr, kdst[cur], idst[cur], n, p.slice, shift, offs);

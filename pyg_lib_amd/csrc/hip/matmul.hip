@@ -64,38 +64,44 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
                                      const char* w, char* c, const char* bias, int64_t K,
                                      int64_t M, int elt, DevGroup* __restrict__ descs,
                                      int32_t* __restrict__ tile_start,
-                                     int64_t* __restrict__ row_start) {
+                                     int64_t* __restrict__ row_start, int32_t* __restrict__ tile_start2) {
   // Single block; B is the number of relations (hundreds): a serial-per-chunk scan is plenty.
   __shared__ int64_t s_tiles[256];
+  __shared__ int64_t s_tiles2[256];
   __shared__ int64_t s_rows[256];
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
   const int64_t per = (B + nthr - 1) / nthr;
   const int64_t beg = min((int64_t)tid * per, B), end = min(beg + per, B);
-  int64_t tiles = 0, rows = 0;
+  int64_t tiles = 0, tiles2 = 0, rows = 0;
   for (int64_t b = beg; b < end; ++b) {
     int64_t r = ptr[b + 1] - ptr[b];
     if (r < 0) r = 0;
     rows += r;
     tiles += (r + kTileRows - 1) / kTileRows;
+    tiles2 += (r + 2 * kTileRows - 1) / (2 * kTileRows);
   }
   s_tiles[tid] = tiles;
+  s_tiles2[tid] = tiles2;
   s_rows[tid] = rows;
   __syncthreads();
   if (tid == 0) {
-    int64_t t = 0, r = 0;
+    int64_t t = 0, t2 = 0, r = 0;
     for (int i = 0; i < nthr; ++i) {
-      int64_t tt = s_tiles[i], rr = s_rows[i];
+      int64_t tt = s_tiles[i], tt2 = s_tiles2[i], rr = s_rows[i];
       s_tiles[i] = t;
+      s_tiles2[i] = t2;
       s_rows[i] = r;
       t += tt;
+      t2 += tt2;
       r += rr;
     }
     tile_start[B] = (int32_t)t;
+    tile_start2[B] = (int32_t)t2;
     row_start[B] = r;
   }
   __syncthreads();
-  int64_t t = s_tiles[tid], rs = s_rows[tid];
+  int64_t t = s_tiles[tid], t2 = s_tiles2[tid], rs = s_rows[tid];
   for (int64_t b = beg; b < end; ++b) {
     const int64_t p0 = ptr[b];
     int64_t r = ptr[b + 1] - p0;
@@ -112,8 +118,10 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
     d.pad = 0;
     descs[b] = d;
     tile_start[b] = (int32_t)t;
+    tile_start2[b] = (int32_t)t2;
     row_start[b] = rs;
     t += (r + kTileRows - 1) / kTileRows;
+    t2 += (r + 2 * kTileRows - 1) / (2 * kTileRows);
     rs += r;
   }
 }
@@ -652,6 +660,210 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         if (row0_out + r < rows_out) {
           typedef __attribute__((address_space(1))) u32x4 GU32x4;
           GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + c * 16);
+          if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+        }
+      }
+    }
+  }
+}
+
+
+// ---- 16-bit, K = 128, 128 output columns: cyclic schedule, W by LDS-DMA in its native layout ---------------------
+// The contiguous-range kernel above keeps ~1000 independent read / write streams alive (one per wave); how fast the
+// HBM side serves that depends on where the caching allocator happened to place `input` and `out` (measured on one
+// box, same launch, six candidate output buffers: 5.0 ... 6.1 TB/s, ~3 of 4 allocations at the low end).  Here every
+// workgroup (8 waves, 256-row tile) takes the tiles b, b + G, b + 2G, ... so the chip sweeps ONE narrow window of
+// `input` / `out` front to back (5.4 - 5.9 TB/s on the same buffers).  A workgroup then changes relation every other
+// tile, so the weight switch must be free:
+//   * W[g] is copied [K][M] as it lies in memory by LDS-DMA (global_load_lds_dwordx4, 8 waves x 4 KiB); the 16-byte
+//     chunks of every 1 KiB block (4 k-rows) are permuted on the SOURCE side so that
+//   * the MFMA "A" fragments (8 consecutive k of one output column) come out of gfx950's transposing LDS read
+//     (ds_read_b64_tr_b16, two per fragment) without bank conflicts: a 32-lane service group touches
+//     4 k-rows x {chunks 2tt, 2tt+1, 8+2tt, 9+2tt}, which the permutation places in one 256-byte line;
+//   * two W buffers: the next relation of this workgroup's tile sequence is in flight while the current one is
+//     multiplied; ONE workgroup barrier per relation change (everybody is done with the buffer that is refilled next,
+//     and everybody's part of the new W has landed -- each wave has waited for its own DMAs because they are older
+//     than the X tile it has just staged).
+// X staging, fragment order, epilogue and store order are those of mfma_rows_lds_kernel.
+template <typename T, int FLAGS = 3>
+__global__ __launch_bounds__(512) void mfma_rows_cyc_kernel(const DevGroup* __restrict__ descs,
+                                                            const int32_t* __restrict__ tile_start, int B) {
+  constexpr bool NT_LOAD = (FLAGS & 1) != 0;
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int K = 128, MC = 128, SZ = 2, NWV = 8;
+  constexpr int NT = 4, NI = 8, NO = 8, CPR = 16;
+  constexpr int BM = NWV * 32;
+  static_assert(BM == 2 * kTileRows, "tile_start2 is built for 256-row tiles");
+  constexpr int WB = K * MC * SZ;  // 32 KB per W buffer
+  constexpr int BLK_PER_WAVE = (K / 4) / NWV;
+  typedef __attribute__((address_space(3))) void LDSV;
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, h = lane >> 5;
+  const int bx = blockIdx.x, G = gridDim.x;
+  char* stage = smem + 2 * WB + wave * 8192;
+  const int total = tile_start[B];
+  if (bx >= total) return;
+  const int nloc = (total - 1 - bx) / G + 1;
+
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= bx) lo = mid; else hi = mid;
+  }
+  int g = lo;  // group of the tile being prefetched
+
+  // DMA side: lane i of a block's instruction fills LDS position i (16 bytes) of the 1 KiB block
+  const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+  const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+  const int dma_src_off = dma_r * (MC * SZ) + dma_c * 16;
+  auto issue_w = [&](int grp_id, int buf) {
+    const char* w = descs[grp_id].w;
+#pragma unroll
+    for (int j = 0; j < BLK_PER_WAVE; ++j) {
+      const int kb = wave * BLK_PER_WAVE + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                       (LDSV*)(smem + buf * WB + kb * 1024), 16, 0, 0);
+    }
+  };
+  // group of the first tile of this workgroup's sequence behind group `gc` (-1: none)
+  auto next_group = [&](int gc) -> int {
+    const int ts = tile_start[gc + 1];
+    if (ts >= total) return -1;
+    const int j = ts > bx ? (ts - bx + G - 1) / G : 0;
+    const int t = bx + j * G;
+    if (t >= total) return -1;
+    int gg = gc + 1;
+    while (tile_start[gg + 1] <= t) ++gg;
+    return gg;
+  };
+  // reader side (transposing read): lane q of a 16-lane group supplies k-row (q >> 2), piece (q & 3)
+  const int q = lane & 15, grp16 = lane >> 4;
+  const int a_lane_off = 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+
+  u32x4 xr[NI];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  auto prefetch = [&](int ti) {
+    const int t = bx + ti * G;
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPR;
+        const int cs = p % CPR;
+        const int c = cs ^ (r & 15);
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        const GU32x4* src = (const GU32x4*)(dn.a + row * (K * SZ) + c * 16);
+        xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+
+  int wcur = g, wbuf = 0;
+  issue_w(wcur, 0);
+  int wnext = next_group(wcur);
+  if (wnext >= 0) issue_w(wnext, 1);
+  prefetch(0);
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+  }
+  if (1 < nloc) prefetch(1);
+
+  for (int t = 0; t < nloc; ++t) {
+    u32x4 ov[NO];
+    if (valid) {
+      f32x16 acc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      const char* wb = smem + wbuf * WB + a_lane_off;
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h + s) ^ (x & 15))) * 16);
+        u32x4 wa[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + tt * 256));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + tt * 256));
+          wa[tt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma_chunk(T{}, wa[tt], xa, acc[tt]);
+      }
+      const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + (MC / 2) * h : nullptr;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+        if (bp) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = NO * h + 2 * tt + j;
+          *reinterpret_cast<u32x4*>(stage + (x * 16 + (c ^ (x & 15))) * 16) = pack8(T{}, v + 8 * j);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+    }
+    const DevGroup d_out = d;
+    const int64_t row0_out = row0, rows_out = rows;
+    const bool valid_out = valid;
+    if (t + 1 < nloc) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+      }
+      if (cg != wcur) {
+        // relation change (same tile index in every wave of the workgroup)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        wcur = cg;
+        wbuf ^= 1;
+        wnext = next_group(wcur);
+        if (wnext >= 0) issue_w(wnext, wbuf ^ 1);
+      }
+      if (t + 2 < nloc) prefetch(t + 2);
+    }
+    if (valid_out) {
+      char* obase = d_out.c + (row0_out * MC) * SZ;
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / 16;
+        const int cs = p % 16;
+        const int c = cs ^ (r & 15);
+        if (row0_out + r < rows_out) {
+          GU32x4* dst = (GU32x4*)(obase + (int64_t)r * MC * SZ + c * 16);
           if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
         }
       }
@@ -1386,6 +1598,8 @@ thread_local const char* g_last_variant = "";
 // Optional per-launch timing of the dominant kernel (bench.py roofline leg): when enabled, a pair of
 // HIP events brackets the main kernel on the stream it is launched on.
 struct ProfPair { hipEvent_t a, b; };
+// tile schedule of the 16-bit K = M = 128 kernels: 0 = automatic, 1 = contiguous ranges, 2 = cyclic
+int g_schedule = 0;
 thread_local bool g_prof_on = false;
 thread_local std::vector<ProfPair> g_prof;
 
@@ -1412,6 +1626,9 @@ struct Workspace {
   int32_t* tile_start;
   int64_t* row_start;   // also reused as out_start by the naive path
   int64_t* ptr_copy;
+  int32_t* tile_start2;  // prefix of 256-row workgroup tiles (cyclic-schedule kernel)
+  bool any_trans = false;  // host-side note: some group reads a transposed `other`
+  int64_t rows_upper = 0;  // host-side note: upper bound of the rows of the call
 };
 
 size_t workspace_bytes(int64_t B) {
@@ -1420,6 +1637,7 @@ size_t workspace_bytes(int64_t B) {
   n += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
   n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
   n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  n += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
   return n;
 }
 
@@ -1433,6 +1651,8 @@ Workspace carve(void* ws, int64_t B) {
   w.row_start = reinterpret_cast<int64_t*>(p);
   p += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
   w.ptr_copy = reinterpret_cast<int64_t*>(p);
+  p += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
+  w.tile_start2 = reinterpret_cast<int32_t*>(p);
   return w;
 }
 
@@ -1450,20 +1670,18 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   const void* kern;
   if constexpr (use_v2) kern = reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW>);
   else kern = reinterpret_cast<const void*>(&mfma_rows_kernel<T, K, MC, NW>);
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const DeviceInfo& di = device_info();
   int per_cu = std::max(1, std::min(use_v2 ? 2 : 4, (160 * 1024) / lds));
-  // experiment knobs (tools/mm_variants.py): PYG_HIP_MM_FLAGS (bit0 nt loads, bit1 nt stores),
-  // PYG_HIP_MM_WGS (workgroups per CU in the persistent grid)
-  int flags = 3;
-  int chunk = 0;
+  int flags = 3;  // nt loads + nt stores
+  int chunk = 0;  // contiguous tile range per workgroup
+#ifdef PYG_HIP_MM_EXPERIMENTS
+  // experiment knobs (tools/mm_variants.py), experiment builds only: PYG_HIP_MM_FLAGS (bit0 nt loads, bit1 nt
+  // stores), PYG_HIP_MM_CHUNK (blocked-cyclic tile schedule), PYG_HIP_MM_WGS (workgroups per CU)
   if (const char* e = getenv("PYG_HIP_MM_FLAGS")) flags = atoi(e) & 3;
   if (const char* e = getenv("PYG_HIP_MM_CHUNK")) chunk = atoi(e);
   if (const char* e = getenv("PYG_HIP_MM_WGS")) per_cu = std::max(1, atoi(e));
+#endif
   int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * per_cu);
   const int ncol = M / MC;
   if (ncol > 1) {
@@ -1476,11 +1694,7 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
     static const bool direct = getenv("PYG_HIP_MM_DIRECT") != nullptr;
     if (direct) {
       const void* dk = reinterpret_cast<const void*>(&mfma_rows_kernel<T, K, MC, NW>);
-      static thread_local bool dattr = false;
-      if (!dattr) {
-        PYG_HIP_CHECK(hipFuncSetAttribute(dk, hipFuncAttributeMaxDynamicSharedMemorySize, wbytes));
-        dattr = true;
-      }
+      if (int rc_ = ensure_dynamic_lds(dk, wbytes)) return rc_;
       int pc = std::max(1, std::min(4, (160 * 1024) / wbytes));
       if (const char* e = getenv("PYG_HIP_MM_WGS")) pc = std::max(1, atoi(e));
       int64_t g2 = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * pc);
@@ -1494,18 +1708,20 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   }
 #endif
   if constexpr (SZ == 4 && K == 128 && (MC == 128 || MC == 64 || MC == 32)) {
+#ifdef PYG_HIP_MM_EXPERIMENTS
     static const bool nopipe = getenv("PYG_HIP_MM_NOPIPE") != nullptr;
+#else
+    constexpr bool nopipe = false;
+#endif
     if (!nopipe) {
       constexpr int plds = wbytes + NW * (32 * K * SZ) + NW * 4096;
       static_assert(plds <= 160 * 1024, "pipelined fp32 kernel: LDS");
       const void* pk = reinterpret_cast<const void*>(&mfma_rows_f32_pipe_kernel<K, MC, NW>);
-      static thread_local bool pattr = false;
-      if (!pattr) {
-        PYG_HIP_CHECK(hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
-        pattr = true;
-      }
+      if (int rc_ = ensure_dynamic_lds(pk, plds)) return rc_;
       int pc = std::max(1, std::min(2, (160 * 1024) / plds));
+#ifdef PYG_HIP_MM_EXPERIMENTS
       if (const char* e = getenv("PYG_HIP_MM_WGS")) pc = std::max(1, atoi(e));
+#endif
       int64_t g2 = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus * pc);
       if (ncol > 1) g2 = std::max<int64_t>(8, (std::min<int64_t>(g2, (int64_t)di.num_cus * pc / ncol) + 7) / 8 * 8);
       ProfScope prof(stream);
@@ -1536,20 +1752,19 @@ int launch_mfma(const Workspace& w, int B, int M, int64_t tiles_upper, hipStream
   {
     ProfScope prof(stream);
     if constexpr (use_v2) {
+#ifdef PYG_HIP_MM_EXPERIMENTS
       if constexpr (K == 128 && MC == 128) {
         // the headline shape carries the experiment variants
-        static thread_local bool attr2 = false;
-        if (!attr2) {
-          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-          PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-          attr2 = true;
-        }
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 0>), lds)) return rc_;
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 1>), lds)) return rc_;
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, K, MC, NW, 2>), lds)) return rc_;
         if (flags == 0) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 0>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
         else if (flags == 1) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 1>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
         else if (flags == 2) hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 2>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
         else hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW, 3>), grid, dim3(NW * 64), lds, stream, w.descs, w.tile_start, B, chunk, ncol);
-      } else {
+      } else
+#endif
+      {
         hipLaunchKernelGGL((mfma_rows_lds_kernel<T, K, MC, NW>), grid, dim3(NW * 64), lds, stream,
                            w.descs, w.tile_start, B, chunk, ncol);
       }
@@ -1567,18 +1782,18 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
   static thread_local char name[64];
   *handled = true;
   if constexpr (Elem<T>::kSize == 2) {
+#ifdef PYG_HIP_MM_EXPERIMENTS
     static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+#else
+    constexpr bool nowide = false;
+#endif
     if (K == 256 && M % 256 == 0 && !nowide) {
       snprintf(name, sizeof(name), "mfma_%s_k256_wide256", tname);
       g_last_variant = name;
       constexpr int NW = 4;
       constexpr int lds = 2 * 256 * 256 + NW * 32 * 256;  // 128 KB weights + 4 x 8 KB stages = 160 KB
       const void* kern = reinterpret_cast<const void*>(&mfma_rows_wide256_kernel<T, NW>);
-      static thread_local bool attr = false;
-      if (!attr) {
-        PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-      }
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
       const DeviceInfo& di = device_info();
       const int ncol = M / 256;
       int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus);
@@ -1590,10 +1805,34 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
       return PYG_HIP_OK;
     }
   }
+  if constexpr (Elem<T>::kSize == 2) {
+    // the headline shape (K = M = 128, 16-bit): cyclic-schedule kernel when there is enough work for every CU to
+    // sweep several 256-row tiles and no group reads a transposed weight (the dX pass keeps the kernel below)
+    const DeviceInfo& di = device_info();
+    const int sched = g_schedule;
+    const bool big = w.rows_upper >= (int64_t)di.num_cus * 256 * 4;
+    if (K == 128 && M == 128 && !w.any_trans && (sched == 2 || (sched == 0 && big))) {
+      snprintf(name, sizeof(name), "mfma_%s_k128_mc128_cyc", tname);
+      g_last_variant = name;
+      constexpr int lds = 2 * 128 * 128 * 2 + 8 * 8192;  // two W buffers + 8 stages = 128 KB
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_cyc_kernel<T>);
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+      const int64_t tiles2_upper = (w.rows_upper + 255) / 256 + B;
+      const int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles2_upper, 1), (int64_t)di.num_cus);
+      ProfScope prof(stream);
+      hipLaunchKernelGGL((mfma_rows_cyc_kernel<T>), dim3((unsigned)gx), dim3(512), lds, stream, w.descs, w.tile_start2, B);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+  }
   int MC = (M % 128 == 0 && K <= 256) ? 128 : (M % 64 == 0 ? 64 : 32);
   if constexpr (Elem<T>::kSize == 2) {
     // 16-bit, K <= 128: one workgroup can own 256 columns (weights + stages fit), X is read by one CU only
+#ifdef PYG_HIP_MM_EXPERIMENTS
     static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+#else
+    constexpr bool nowide = false;
+#endif
     if (K == 128 && M % 256 == 0 && !nowide) MC = 256;
   }
   snprintf(name, sizeof(name), "mfma_%s_k%d_mc%d", tname, K, MC);
@@ -1696,6 +1935,8 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
+void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode == 1 || mode == 2) ? mode : 0; }
+
 void pyg_hip_profile_enable(int on) {
   g_prof_on = on != 0;
   if (!g_prof_on) {
@@ -1762,8 +2003,9 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
   hipLaunchKernelGGL(plan_segments_kernel, dim3(1), dim3(256), 0, stream, dptr, B,
                      static_cast<const char*>(input), static_cast<const char*>(other),
                      static_cast<char*>(out), static_cast<const char*>(bias), K, M, (int)elt,
-                     w.descs, w.tile_start, w.row_start);
+                     w.descs, w.tile_start, w.row_start, w.tile_start2);
   PYG_HIP_CHECK(hipGetLastError());
+  w.rows_upper = N;
   if (K == 0) {
     // empty contraction: out = 0 (+ bias), handled by the generic kernel
     return dispatch_naive(dtype, w, (int)B, N * M, stream);
@@ -1791,10 +2033,12 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   const size_t descs_b = align_up(sizeof(DevGroup) * (size_t)G, 256);
   const size_t tiles_b = align_up(sizeof(int32_t) * (size_t)(G + 1), 256);
   void* staged = nullptr;
-  int rc = pinned_stage().acquire(descs_b + tiles_b, &staged);
+  int rc = pinned_stage().acquire(descs_b + 2 * tiles_b, &staged);
   if (rc != PYG_HIP_OK) return rc;
   DevGroup* hd = static_cast<DevGroup*>(staged);
   int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b);
+  int32_t* ht2 = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b + tiles_b);
+  int64_t tiles2 = 0, rows_total = 0;
   bool uniform = true, any_trans = false;
   int64_t tiles = 0, out_elems = 0;
   for (int64_t i = 0; i < G; ++i) {
@@ -1815,15 +2059,22 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
     if (!aligned16(gr.input) || !aligned16(gr.other) || !aligned16(gr.out)) uniform = false;
     if (gr.other_trans) any_trans = true;
     ht[i] = (int32_t)tiles;
+    ht2[i] = (int32_t)tiles2;
+    tiles2 += (hd[i].rows + 2 * kTileRows - 1) / (2 * kTileRows);
+    rows_total += hd[i].rows;
     tiles += (hd[i].rows + kTileRows - 1) / kTileRows;
     out_elems += hd[i].rows * gr.m;
     PYG_HIP_REQUIRE(tiles < (1LL << 31), "grouped_matmul: too many row tiles");
   }
-  (void)any_trans;
+  w.any_trans = any_trans;
+  w.rows_upper = rows_total;
   ht[G] = (int32_t)tiles;
+  ht2[G] = (int32_t)tiles2;
   PYG_HIP_CHECK(hipMemcpyAsync(w.descs, hd, sizeof(DevGroup) * (size_t)G, hipMemcpyHostToDevice,
                                stream));
   PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start, ht, sizeof(int32_t) * (size_t)(G + 1),
+                               hipMemcpyHostToDevice, stream));
+  PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start2, ht2, sizeof(int32_t) * (size_t)(G + 1),
                                hipMemcpyHostToDevice, stream));
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;

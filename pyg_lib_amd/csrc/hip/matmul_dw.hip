@@ -553,11 +553,7 @@ int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64
               hipStream_t stream) {
   constexpr int lds = 4 * 32 * (pitch_bytes(K) + pitch_bytes(MC));
   const void* kern = reinterpret_cast<const void*>(&seg_dw_kernel<Tag, K, MC>);
-  static thread_local bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const int64_t cus = device_info().num_cus;
   const int64_t ncol = M / MC;
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
@@ -573,11 +569,7 @@ int launch_dw_wide256(const DwGroup* groups, const int32_t* tile_start, int64_t 
                       float* acc, hipStream_t stream) {
   constexpr int lds = 2 * 32 * (pitch_bytes(256) + pitch_bytes(256));
   const void* kern = reinterpret_cast<const void*>(&seg_dw_wide256_kernel<Tag>);
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    PYG_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const int64_t cus = device_info().num_cus;
   const int64_t ncol = M / 256;
   int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
@@ -591,7 +583,11 @@ int launch_dw_wide256(const DwGroup* groups, const int32_t* tile_start, int64_t 
 template <typename Tag>
 int run_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
            float* acc, hipStream_t stream) {
+#ifdef PYG_HIP_MM_EXPERIMENTS
   static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
+#else
+  constexpr bool nowide = false;
+#endif
   if (K == 256 && M % 256 == 0 && !nowide) return launch_dw_wide256<Tag>(groups, tile_start, B, M, tiles_upper, acc, stream);
   if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
   if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);

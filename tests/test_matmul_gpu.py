@@ -145,6 +145,65 @@ def test_many_tiles_per_workgroup_vs_oracle(dtype, K, M, with_bias):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.fixture
+def cyclic_schedule():
+    ops.set_matmul_schedule('cyclic')
+    yield
+    ops.set_matmul_schedule('auto')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('with_bias', [False, True])
+@pytest.mark.parametrize('ptr_on_device', [False, True])
+def test_cyclic_schedule_kernel_vs_oracle(cyclic_schedule, dtype, with_bias, ptr_on_device):
+    """mfma_rows_cyc_kernel (256-row workgroup tiles taken cyclically, W by LDS-DMA + transposing LDS reads, one
+    barrier per relation change) forced onto a ragged problem the oracle finishes quickly: empty relations, single
+    rows, exact tile multiples, runs of tiny relations (several weight switches inside one workgroup's sequence,
+    relations a workgroup skips entirely) and a tail shorter than one wave."""
+    rng = np.random.default_rng(7 + int(with_bias))
+    sizes = rng.integers(0, 6000, 61)
+    sizes[[3, 4, 17]] = 0
+    sizes[8] = 1
+    sizes[9] = 31
+    sizes[10] = 33
+    sizes[25] = 256 * 9
+    sizes[30:40] = rng.integers(1, 300, 10)
+    sizes[60] = 5
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 128, generator=g).to(dtype)
+    w = (torch.randn(len(sizes), 128, 128, generator=g) / 128 ** 0.5).to(dtype)
+    b = torch.randn(len(sizes), 128, generator=g).to(dtype) if with_bias else None
+    p = ptr.to(DEV) if ptr_on_device else ptr
+    out = ops.segment_matmul(x.to(DEV), p, w.to(DEV), None if b is None else b.to(DEV))
+    name = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128_cyc'
+    if dtype == torch.float16:
+        ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy(), None if b is None else b.numpy())
+        np.testing.assert_allclose(out.cpu().float().numpy(), ref.astype(np.float32), rtol=2 ** -9, atol=2e-3)
+    else:
+        ref = oracle.segment_matmul(bits(x), ptr.numpy(), bits(w), None if b is None else bits(b), dtype=oracle.BF16)
+        np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -6,
+                                   atol=2e-2)
+        assert (bits(out) == ref).mean() > 0.98
+    # the contiguous-range kernel must give the very same bits (same MFMA order per output element)
+    ops.set_matmul_schedule('contiguous')
+    out2 = ops.segment_matmul(x.to(DEV), p, w.to(DEV), None if b is None else b.to(DEV))
+    assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128'
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+
+
+def test_cyclic_schedule_one_relation_and_fewer_tiles_than_workgroups(cyclic_schedule):
+    for rows in (1, 255, 256, 257, 40_000):
+        x = torch.randn(rows, 128, device=DEV).bfloat16()
+        w = (torch.randn(1, 128, 128, device=DEV) / 11).bfloat16()
+        out = ops.segment_matmul(x, torch.tensor([0, rows]), w)
+        assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128_cyc'
+        ref = (x.float() @ w[0].float()).bfloat16()
+        torch.testing.assert_close(out.float(), ref.float(), rtol=2 ** -6, atol=2e-2)
+
+
 def test_asymmetric_weight_detects_transposes():
     # A = I picks rows of W; an asymmetric W catches row/col swaps in the MFMA C-layout.
     K = M = 128
@@ -248,6 +307,64 @@ def test_grouped_matmul_mfma_uniform_groups(dtype, trans):
                                        rtol=2 ** -7, atol=1e-4)
 
 
+def test_grouped_matmul_outputs_can_be_modified_in_place():
+    """The reference returns G independent tensors (ops/cpu/matmul_kernel.cpp:296-298); here they alias one pool but
+    must not be tracked as views of a multi-output function -- in-place ops on an output of a differentiable call
+    are legal there."""
+    ins = [torch.randn(5, 16, device=DEV, requires_grad=True), torch.randn(6, 9, device=DEV, requires_grad=True)]
+    oth = [torch.randn(16, 48, device=DEV, requires_grad=True), torch.randn(9, 42, device=DEV, requires_grad=True)]
+    outs = ops.grouped_matmul(ins, oth)
+    ref0 = (ins[0].detach() @ oth[0].detach()).relu()
+    outs[0].relu_()
+    outs[1] += 1.0
+    torch.testing.assert_close(outs[0].detach(), ref0, atol=1e-4, rtol=1e-4)
+    (outs[0].sum() + outs[1].sum()).backward()
+    assert ins[0].grad is not None and oth[1].grad is not None
+    mask = (ins[0].detach() @ oth[0].detach() > 0).float()
+    torch.testing.assert_close(ins[0].grad, mask @ oth[0].detach().t(), atol=1e-4, rtol=1e-4)
+    # ... and without autograd
+    outs = ops.grouped_matmul([a.detach() for a in ins], [o.detach() for o in oth])
+    outs[1].mul_(2.0)
+    torch.testing.assert_close(outs[0], ins[0].detach() @ oth[0].detach(), atol=1e-4, rtol=1e-4)
+
+
+def test_grouped_matmul_pool_writes_into_the_callers_buffer():
+    torch.manual_seed(3)
+    rows = [300, 0, 129, 512, 7]
+    ins = [torch.randn(r, 256, device=DEV).bfloat16() for r in rows]
+    oth = [(torch.randn(256, 256, device=DEV) / 16).bfloat16() for _ in rows]
+    pool = torch.full((sum(rows) + 3, 256), 7.0, device=DEV, dtype=torch.bfloat16)
+    outs = torch.ops.pyg.grouped_matmul_pool(ins, oth, pool[:sum(rows)])
+    ref = ops.grouped_matmul(ins, oth)
+    pos = 0
+    for r, o, e in zip(rows, outs, ref):
+        assert o.data_ptr() == pool[pos:].data_ptr() and o.shape == (r, 256)
+        assert torch.equal(o, e)
+        pos += r
+    assert bool((pool[sum(rows):] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        torch.ops.pyg.grouped_matmul_pool(ins, oth, pool)  # wrong number of rows
+
+
+@pytest.mark.parametrize('sched', ['cyclic', 'contiguous'])
+def test_grouped_matmul_k128_both_schedules(sched):
+    """grouped_matmul with uniform K = M = 128 reaches the same two kernels through the host-built tile tables."""
+    torch.manual_seed(5)
+    rows = [700, 1, 0, 256, 513, 90, 1024, 33]
+    ins = [torch.randn(r, 128).bfloat16() for r in rows]
+    oth = [(torch.randn(128, 128) / 11).bfloat16() for _ in rows]
+    ops.set_matmul_schedule(sched)
+    try:
+        outs = ops.grouped_matmul([a.to(DEV) for a in ins], [o.to(DEV) for o in oth])
+    finally:
+        ops.set_matmul_schedule('auto')
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128' + ('_cyc' if sched == 'cyclic' else '')
+    for a, o, out in zip(ins, oth, outs):
+        ref = oracle.matmul(bits(a), bits(o), dtype=oracle.BF16)
+        np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -7,
+                                   atol=1e-4)
+
+
 def test_grouped_matmul_backward_shapes():
     # test/ops/test_matmul.py:77-93
     ins = [torch.randn(5, 16, device=DEV, requires_grad=True), torch.randn(6, 9, device=DEV, requires_grad=True)]
@@ -282,21 +399,29 @@ def test_full_size_c2_properties():
     scale = 2.0 ** (torch.arange(B) % 5 - 2).float()
     w = torch.zeros(B, F, F)
     w[torch.arange(B)[:, None], perm, torch.arange(F)[None, :]] = sign * scale[:, None]
-    out = ops.segment_matmul(x, ptr, w.bfloat16().to(DEV))
-    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128'
-    # expected: out[r, j] = sign[b, j] * scale[b] * x[r, perm[b, j]]
+    wd = w.bfloat16().to(DEV)
     seg = torch.repeat_interleave(torch.arange(B, device=DEV), sizes.to(DEV))
-    total = 0.0
-    bad = 0
-    step = 2_000_000
-    for s in range(0, N, step):
-        e = min(s + step, N)
-        sb = seg[s:e]
-        exp = torch.gather(x[s:e].float(), 1, perm.to(DEV)[sb]) * (sign * scale[:, None]).to(DEV)[sb]
-        bad += int((exp.bfloat16() != out[s:e]).sum())
-        total += float(out[s:e].double().sum() - exp.double().sum())
-    assert bad == 0
-    assert abs(total) < 1e-6
+    # both tile schedules (the automatic choice at this size is the cyclic kernel)
+    for mode, variant in (('auto', 'mfma_bf16_k128_mc128_cyc'), ('contiguous', 'mfma_bf16_k128_mc128')):
+        ops.set_matmul_schedule(mode)
+        try:
+            out = ops.segment_matmul(x, ptr, wd)
+        finally:
+            ops.set_matmul_schedule('auto')
+        assert ops.matmul_last_variant() == variant
+        # expected: out[r, j] = sign[b, j] * scale[b] * x[r, perm[b, j]]
+        total = 0.0
+        bad = 0
+        step = 2_000_000
+        for s in range(0, N, step):
+            e = min(s + step, N)
+            sb = seg[s:e]
+            exp = torch.gather(x[s:e].float(), 1, perm.to(DEV)[sb]) * (sign * scale[:, None]).to(DEV)[sb]
+            bad += int((exp.bfloat16() != out[s:e]).sum())
+            total += float(out[s:e].double().sum() - exp.double().sum())
+        assert bad == 0
+        assert abs(total) < 1e-6
+        del out
 
 
 # ---- weight gradient kernel (csrc/hip/matmul_dw.hip) ---------------------------------

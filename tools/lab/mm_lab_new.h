@@ -1,0 +1,772 @@
+// candidate designs (included by mm_lab.hip after Ctx / bench)
+
+// ------------------------------------------------------------------------------------------------
+// v3: NWV waves per workgroup (WG tile = NWV*32 rows), cyclic WG-tile schedule (tile b, b + G, ...: the
+//     chip sweeps one narrow window of X / out), W kept in LDS in its NATIVE [K][M] layout: copied by
+//     LDS-DMA (global_load_lds_dwordx4, chunk order permuted inside every 1 KiB block so the transposing
+//     reads are bank-conflict free), double buffered (the next relation's W is in flight while this one is
+//     multiplied, one barrier per relation change), A fragments through ds_read_b64_tr_b16.
+// ------------------------------------------------------------------------------------------------
+template <int FLAGS, int NWV, int DBG, int WDB = 1, int SCHED = 0>
+__global__ __launch_bounds__(NWV * 64) void v3_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start,
+                                                      int B) {
+  constexpr bool NT_LOAD = (FLAGS & 1) != 0;
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int NT = 4, NI = 8, NO = 8, CPR = 16;
+  constexpr int BM = NWV * 32;
+  constexpr int WB = K * MC * 2;  // 32 KB per W buffer
+  constexpr int BLK_PER_WAVE = (K / 4) / NWV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, h = lane >> 5;
+  const int bx = blockIdx.x, G = gridDim.x;
+  char* stage = smem + (WDB ? 2 : 1) * WB + wave * 8192;
+  const int total = tile_start[B];
+  int nloc, cbase = 0;
+  if (SCHED == 0) {
+    if (bx >= total) return;
+    nloc = (total - 1 - bx) / G + 1;
+  } else {
+    cbase = (int)((int64_t)bx * total / G);
+    nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
+    if (nloc <= 0) return;
+  }
+  auto tile_of = [&](int j) -> int { return SCHED == 0 ? bx + j * G : cbase + j; };
+
+  // group of the first tile
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= tile_of(0)) lo = mid; else hi = mid;
+  }
+  int g = lo;  // group of the tile being prefetched
+
+  // --- W buffers -----------------------------------------------------------------------------------
+  // DMA side: lane i of a block's instruction fills LDS position i of the 1 KiB block
+  const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+  const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+  const int dma_src_off = dma_r * 256 + dma_c * 16;
+  auto issue_w = [&](int grp_id, int buf) {
+    const char* w = descs[grp_id].w;
+#pragma unroll
+    for (int j = 0; j < BLK_PER_WAVE; ++j) {
+      const int kb = wave * BLK_PER_WAVE + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                       (LDSV*)(smem + buf * WB + kb * 1024), 16, 0, 0);
+    }
+  };
+  // first tile of this workgroup's sequence in a group after `gc` (-1: none), and its group
+  auto next_group = [&](int gc) -> int {
+    const int ts = tile_start[gc + 1];
+    if (ts >= total) return -1;
+    int t;
+    if (SCHED == 0) {
+      const int j = ts > bx ? (ts - bx + G - 1) / G : 0;
+      t = bx + j * G;
+      if (t >= total) return -1;
+    } else {
+      t = ts > cbase ? ts : cbase;
+      if (t >= cbase + nloc) return -1;
+    }
+    int gg = gc + 1;
+    while (tile_start[gg + 1] <= t) ++gg;
+    return gg;
+  };
+  // reader side
+  const int q = lane & 15, grp16 = lane >> 4;
+  const int a_lane_off = 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+
+  u32x4 xr[NI];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  auto prefetch = [&](int ti) {
+    const int t = tile_of(ti);
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPR;
+        const int cs = p % CPR;
+        const int c = cs ^ (r & 15);
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        const GU32x4* src = (const GU32x4*)(dn.a + row * (K * SZ) + c * 16);
+        xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+
+  int wcur = g, wbuf = 0;
+  issue_w(wcur, 0);
+  int wnext = -1;
+  if (WDB) {
+    wnext = next_group(wcur);
+    if (wnext >= 0) issue_w(wnext, 1);
+  }
+  prefetch(0);
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+  }
+  if (1 < nloc) prefetch(1);
+
+  for (int t = 0; t < nloc; ++t) {
+    u32x4 ov[NO];
+    if (valid) {
+      f32x16 acc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      const char* wb = smem + wbuf * WB + a_lane_off;
+      if (!(DBG & 1)) {
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
+          const u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h + s) ^ (x & 15))) * 16);
+          bf16x8 wa[NT];
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + tt * 256));
+            const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + tt * 256));
+            wa[tt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tt], __builtin_bit_cast(bf16x8, xa), acc[tt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = NO * h + 2 * tt + j;
+          *reinterpret_cast<u32x4*>(stage + (x * 16 + (c ^ (x & 15))) * 16) = pack8(v + 8 * j);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+    }
+    const DevGroup d_out = d;
+    const int64_t row0_out = row0, rows_out = rows;
+    const bool valid_out = valid;
+    if (t + 1 < nloc) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+      }
+      if (cg != wcur) {
+        // relation change: everything this wave has in flight (its part of the next W included) is older than
+        // the X tile it has just staged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        wcur = cg;
+        if (WDB) {
+          wbuf ^= 1;
+          wnext = next_group(wcur);
+          if (wnext >= 0) issue_w(wnext, wbuf ^ 1);
+        } else {
+          issue_w(wcur, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+      }
+      if (t + 2 < nloc) prefetch(t + 2);
+    }
+    if (valid_out) {
+      char* obase = d_out.c + (row0_out * MC) * SZ;
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / 16;
+        const int cs = p % 16;
+        const int c = cs ^ (r & 15);
+        if (row0_out + r < rows_out) {
+          GU32x4* dst = (GU32x4*)(obase + (int64_t)r * MC * SZ + c * 16);
+          if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// copyq: persistent pipelined copy with the features of the base kernel added one at a time
+//   MODE 0  flat: workgroup b copies WG-tiles [b*T/G, (b+1)*T/G) of a flat buffer (hbm_copy's pat1 pipe1)
+//   MODE 1  segment aware: tile walk over descs / tile_start, clamped rows, per-row store predicates
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void copyq_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B,
+                                                    const u32x4* __restrict__ in, u32x4* __restrict__ out, long flat_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x, G = gridDim.x;
+  if (smem && tid == 100000) smem[0] = 1;
+  if (MODE == 0) {
+    const long b0 = (long)bx * flat_tiles / G, b1 = (long)(bx + 1) * flat_tiles / G;
+    u32x4 v[8], nx[8];
+    if (b0 < b1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + ((b0 * 4 + wave) * 8 + q) * 64 + lane));
+    }
+    for (long t = b0; t < b1; ++t) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = nx[q];
+      if (t + 1 < b1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (((t + 1) * 4 + wave) * 8 + q) * 64 + lane));
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + ((t * 4 + wave) * 8 + q) * 64 + lane));
+    }
+    return;
+  }
+  const int total = tile_start[B];
+  const int cbase = (int)((int64_t)bx * total / G);
+  const int nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
+  if (nloc <= 0) return;
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= cbase) lo = mid; else hi = mid;
+  }
+  int g = lo;
+  u32x4 xr[8];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  auto prefetch = [&](int ti) {
+    const int t = cbase + ti;
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * 128 + wave * 32;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / 16, cs = p % 16;
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        xr[i] = __builtin_nontemporal_load((const GU32x4*)(dn.a + row * 256 + cs * 16));
+      }
+    }
+  };
+  prefetch(0);
+  for (int t = 0; t < nloc; ++t) {
+    u32x4 ov[8];
+    const DevGroup d_out = dn;
+    const int64_t row0_out = n_row0, rows_out = n_rows;
+    const bool valid_out = n_valid;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ov[i] = xr[i];
+    if (t + 1 < nloc) prefetch(t + 1);
+    if (valid_out) {
+      char* obase = d_out.c + (row0_out * 128) * 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / 16, cs = p % 16;
+        if (row0_out + r < rows_out) __builtin_nontemporal_store(ov[i], (GU32x4*)(obase + (int64_t)r * 256 + cs * 16));
+      }
+    }
+  }
+}
+
+
+// plain cyclic read / write / copy over named buffers (is one of the buffers "slow memory"?)
+template <int MODE>  // 0 read, 1 write, 2 copy
+__global__ __launch_bounds__(256) void rw_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long W = (long)gridDim.x * 4;
+  u32x4 acc = {0, 0, 0, 0};
+  for (long t = (long)blockIdx.x * 4 + wave; t < ntiles; t += W) {
+    u32x4 v[8];
+    if (MODE != 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * 8 + q) * 64 + lane));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = u32x4{(uint32_t)lane, 1, 2, 3};
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc ^= v[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * 8 + q) * 64 + lane));
+    }
+  }
+  if (MODE == 0 && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) out[0] = acc;
+}
+
+
+// non-persistent copy, one U KiB tile per wave, occupancy limited through the dynamic LDS size
+template <int U>
+__global__ __launch_bounds__(256) void bigc_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const long t = (long)blockIdx.x * 4 + wave;
+  if (t >= ntiles) return;
+  u32x4 v[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+  for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+}
+
+// persistent copy with DYNAMIC tile assignment: every wave pulls its next 8 KiB tile from one of 8 counters
+// (counter = workgroup id % 8, i.e. per XCD; tile = 8 * ticket + counter), one tile ahead of the copy
+__global__ __launch_bounds__(256) void dync_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
+                                                   unsigned int* __restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const int q8 = blockIdx.x & 7;
+  auto pull = [&]() -> long {
+    unsigned int k = 0;
+    if (lane == 0) k = atomicAdd(&ctr[q8 * 32], 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    return (long)k * 8 + q8;
+  };
+  u32x4 v[8], nx[8];
+  long t = pull();
+  if (t < ntiles) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * 8 + q) * 64 + lane));
+  }
+  while (t < ntiles) {
+    const long t2 = pull();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = nx[q];
+    if (t2 < ntiles) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t2 * 8 + q) * 64 + lane));
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * 8 + q) * 64 + lane));
+    t = t2;
+  }
+}
+
+
+// persistent pipelined copy whose loads are inline asm (invisible to the compiler's waitcnt pass) and whose wait
+// is an explicit vmcnt(8): the 8 stores issued after the loads stay in flight.  SCHED 0: contiguous WG ranges,
+// 1: cyclic wave tiles.
+template <int SCHED, int WAITN, int ILV = 0, int TLBPF = 0>
+__global__ __launch_bounds__(256) void copyv_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long flat_tiles) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x, G = gridDim.x;
+  long j0, j1, step;  // wave tile index sequence j0, j0 + step, ... < j1 (8 KiB wave tiles)
+  const long wtiles = flat_tiles * 4;
+  if (SCHED == 0) {
+    const long b0 = (long)bx * flat_tiles / G, b1 = (long)(bx + 1) * flat_tiles / G;
+    j0 = b0 * 4 + wave; j1 = b1 * 4; step = 4;
+  } else {
+    j0 = (long)bx * 4 + wave; j1 = wtiles; step = (long)G * 4;
+  }
+  u32x4 nx[8];
+  auto issue = [&](long j) {
+    const u32x4* p = in + j * 512 + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(nx[q]) : "v"(p + q * 64) : "memory");
+  };
+  if (j0 < j1) issue(j0);
+  for (long j = j0; j < j1; j += step) {
+    u32x4 v[8];
+    if (WAITN == 8 && j != j0)  // steady state: 8 loads, then the previous tile's 8 stores
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(nx[4]), "+v"(nx[5]), "+v"(nx[6]), "+v"(nx[7])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(nx[4]), "+v"(nx[5]), "+v"(nx[6]), "+v"(nx[7])::"memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = nx[q];
+    u32x4* o = out + j * 512 + lane;
+    if (TLBPF) {
+      // translation prefetch: one dword from the X tile TLBPF rounds ahead and from the out tile of the next round
+      const long ja = j + (long)TLBPF * step, jo = j + step;
+      uint32_t dummy;
+      if (ja < j1) asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"((const char*)in + ja * 8192) : "memory");
+      if (jo < j1) asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"((const char*)out + jo * 8192) : "memory");
+    }
+    if (ILV && j + step < j1) {
+      // loads of the next tile and stores of this one alternate, 1 KiB each
+      const u32x4* p = in + (j + step) * 512 + lane;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(nx[q]) : "v"(p + q * 64) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o + q * 64), "v"(v[q]) : "memory");
+      }
+    } else {
+      if (j + step < j1) issue(j + step);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o + q * 64), "v"(v[q]) : "memory");
+    }
+  }
+}
+
+
+// memory-behaviour proxy of a NON-persistent matmul: one workgroup per NW*RPW-row tile; every wave DMAs its
+// RPW rows of X (256 B each) and its share of a 32 KB weight (L2 resident) into LDS, barrier, reads X back and
+// stores it as the "output".  No MFMAs: what would the memory system give such a kernel?
+template <int NW, int RPW, int WLOAD>
+__global__ __launch_bounds__(NW * 64) void proxy_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, const char* __restrict__ w,
+                                                        long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XI = RPW * 256 / 1024;        // 1 KiB DMA instructions per wave for X
+  constexpr int WI = 32768 / (NW * 1024);     // ... for the weight share
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long t = blockIdx.x;
+  if (t >= ntiles) return;
+  char* xs = smem + 32768 + wave * (RPW * 256);
+  const char* src = (const char*)in + (t * NW + wave) * (RPW * 256);
+#pragma unroll
+  for (int q = 0; q < XI; ++q)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024 + lane * 16), (LDSV*)(xs + q * 1024), 16, 0, 2);
+  if (WLOAD) {
+    const char* wsrc = w + ((t * 7) % 154) * 32768 + wave * (WI * 1024);
+#pragma unroll
+    for (int q = 0; q < WI; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + q * 1024 + lane * 16), (LDSV*)(smem + wave * (WI * 1024) + q * 1024), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  u32x4 v[XI];
+#pragma unroll
+  for (int q = 0; q < XI; ++q) v[q] = *reinterpret_cast<const u32x4*>(xs + q * 1024 + lane * 16);
+  if (WLOAD) v[0][0] ^= *reinterpret_cast<const uint32_t*>(smem + ((lane * 516 + wave * 36) & 32764)) & 1u;
+  char* dst = (char*)out + (t * NW + wave) * (RPW * 256);
+#pragma unroll
+  for (int q = 0; q < XI; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(dst + q * 1024 + lane * 16));
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v4: NON-persistent.  One workgroup (4 waves x 32 rows) per 128-row tile, dispatched in tile order by the
+//     hardware (the chip sweeps X / out linearly with a narrow window of tiles in flight).  X tile and the
+//     relation's W (native layout) arrive by LDS-DMA, A fragments through ds_read_b64_tr_b16; 64 KB of LDS,
+//     two workgroups per CU cover each other's load phase.
+// ------------------------------------------------------------------------------------------------
+struct TileRec {
+  const char* a;   // first row of the tile
+  const char* w;
+  char* c;
+  int32_t rows;    // valid rows in this tile (1..128)
+  int32_t pad;
+};
+
+template <int FLAGS, int DBG>
+__global__ __launch_bounds__(256) void v4_kernel(const TileRec* __restrict__ recs, int ntiles) {
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int XAUX = (FLAGS & 1) ? 2 : 0;
+  constexpr int NT = 4, NI = 8, NO = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, h = lane >> 5;
+  const TileRec rec = recs[blockIdx.x];
+  const int row0 = wave * 32;
+  const bool valid = row0 < rec.rows;
+  char* xs = smem + 32768 + wave * 8192;
+  // W: this wave's 8 blocks (4 k-rows each), chunk order permuted inside every block (see v3)
+  {
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const char* wsrc = rec.w + dma_r * 256 + dma_c * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kb = wave * 8 + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024), (LDSV*)(smem + kb * 1024), 16, 0, 0);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = i * 64 + lane;
+      const int r = p >> 4, cs = p & 15;
+      const int c = cs ^ (r & 15);
+      int row = row0 + r;
+      if (row >= rec.rows) row = rec.rows - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec.a + row * 256 + c * 16), (LDSV*)(xs + i * 1024), 16, 0, XAUX);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!valid) return;
+  const int q = lane & 15, grp16 = lane >> 4;
+  const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  if (!(DBG & 1)) {
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (x * 16 + ((NI * h + s) ^ (x & 15))) * 16);
+      bf16x8 wa[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + tt * 256));
+        const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + tt * 256));
+        wa[tt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tt], __builtin_bit_cast(bf16x8, xa), acc[tt], 0, 0, 0);
+    }
+  } else {
+    acc[0][0] = __builtin_bit_cast(float, *reinterpret_cast<const uint32_t*>(xs + lane * 16));
+  }
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[tt][r];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = NO * h + 2 * tt + j;
+      *reinterpret_cast<u32x4*>(xs + (x * 16 + (c ^ (x & 15))) * 16) = pack8(v + 8 * j);
+    }
+  }
+  u32x4 ov[NO];
+#pragma unroll
+  for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(xs + (i * 64 + lane) * 16);
+  char* obase = rec.c + row0 * 256;
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int p = i * 64 + lane;
+    const int r = p >> 4, cs = p & 15;
+    const int c = cs ^ (r & 15);
+    if (row0 + r < rec.rows) {
+      GU32x4* dst = (GU32x4*)(obase + r * 256 + c * 16);
+      if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+    }
+  }
+}
+
+static bool run_new(const Ctx& c, const std::string& spec, const std::string& name, std::map<std::string, int>& o) {
+  auto opt = [&](const char* k, int dflt) { return o.count(k) ? o[k] : dflt; };
+
+  if (name == "copyq") {
+    const int mode = opt("mode", 0), lds = opt("lds", 0), wgs = opt("wgs", 2);
+    const long ooff = (long)opt("ooff", 0) * 1024;  // shift of the output buffer (bytes), mode 0 only
+    const int grid = c.cus * wgs;
+    const long flat_tiles = c.rows * 256 / 32768;
+    if (mode == 0) {
+      CK(hipFuncSetAttribute((const void*)&copyq_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      bench(c, spec, [&] { hipLaunchKernelGGL((copyq_kernel<0>), dim3(grid), dim3(256), lds, 0, c.descs, c.tile128, c.B, (const u32x4*)c.x, (u32x4*)((opt("dst", 0) ? (char*)c.out : (char*)c.out2) + ooff), flat_tiles); });
+    } else {
+      CK(hipFuncSetAttribute((const void*)&copyq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      bench(c, spec, [&] { hipLaunchKernelGGL((copyq_kernel<1>), dim3(grid), dim3(256), lds, 0, c.descs, c.tile128, c.B, (const u32x4*)c.x, (u32x4*)c.out, flat_tiles); });
+    }
+    return true;
+  }
+
+
+  if (name == "big" || name == "dyn") {
+    const int u = opt("u", 8), lds = opt("lds", 0), wgs = opt("wgs", 2);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / (u * 1024);
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    if (lds) {
+      CK(hipFuncSetAttribute((const void*)&bigc_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      CK(hipFuncSetAttribute((const void*)&bigc_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      CK(hipFuncSetAttribute((const void*)&bigc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      CK(hipFuncSetAttribute((const void*)&bigc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      CK(hipFuncSetAttribute((const void*)&dync_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      if (name == "dyn") CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
+      CK(hipEventRecord(e0));
+      const unsigned gb = (unsigned)((ntiles + 3) / 4);
+      if (name == "dyn") hipLaunchKernelGGL(dync_kernel, dim3(c.cus * wgs), dim3(256), lds, 0, in, out, nbytes / 8192, ctr);
+      else if (u == 8) hipLaunchKernelGGL((bigc_kernel<8>), dim3(gb), dim3(256), lds, 0, in, out, ntiles);
+      else if (u == 4) hipLaunchKernelGGL((bigc_kernel<4>), dim3(gb), dim3(256), lds, 0, in, out, ntiles);
+      else if (u == 2) hipLaunchKernelGGL((bigc_kernel<2>), dim3(gb), dim3(256), lds, 0, in, out, ntiles);
+      else hipLaunchKernelGGL((bigc_kernel<1>), dim3(gb), dim3(256), lds, 0, in, out, ntiles);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "copyv") {
+    const int sched = opt("sched", 0), waitn = opt("wait", 8), wgs = opt("wgs", 2), ilv = opt("ilv", 0), pf = opt("pf", 0);
+    const int grid = c.cus * wgs;
+    const long flat_tiles = c.rows * 256 / 32768;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+#define CV(S, W, I, P) if (sched == S && waitn == W && ilv == I && pf == P) { bench(c, spec, [&] { hipLaunchKernelGGL((copyv_kernel<S, W, I, P>), dim3(grid), dim3(256), 0, 0, in, out, flat_tiles); }); return true; }
+    CV(0, 8, 0, 0) CV(0, 0, 0, 0) CV(1, 8, 0, 0) CV(1, 0, 0, 0) CV(0, 0, 1, 0) CV(1, 0, 1, 0)
+    CV(1, 0, 0, 2) CV(1, 0, 0, 3) CV(1, 0, 0, 4) CV(0, 0, 0, 8)
+#undef CV
+    return true;
+  }
+
+  if (name == "proxy") {
+    const int nw = opt("nw", 8), rpw = opt("rpw", 16), wl = opt("w", 1), pad = opt("pad", 0);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / ((long)nw * rpw * 256);
+    const int lds = 32768 + nw * rpw * 256 + pad;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipEventRecord(e0));
+#define PX(N, R, W) if (nw == N && rpw == R && wl == W) { CK(hipFuncSetAttribute((const void*)&proxy_kernel<N, R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((proxy_kernel<N, R, W>), dim3((unsigned)ntiles), dim3(N * 64), lds, 0, in, out, (const char*)c.w, ntiles); }
+      PX(8, 16, 1) PX(8, 16, 0) PX(4, 32, 1) PX(4, 32, 0) PX(4, 16, 1) PX(8, 32, 1) PX(8, 8, 1) PX(16, 8, 1) PX(16, 16, 1) PX(2, 32, 1) PX(8, 4, 1) PX(16, 4, 1)
+#undef PX
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s  (lds %d)\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9, lds);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "v4") {
+    const int flags = opt("flags", 3), dbg = opt("dbg", 0), pad = opt("pad", 0);
+    static TileRec* drec = nullptr;
+    static int ntiles = 0;
+    if (!drec) {
+      std::vector<TileRec> hr;
+      for (int b = 0; b < c.B; ++b) {
+        const int64_t n = c.ptr[b + 1] - c.ptr[b];
+        for (int64_t r0 = 0; r0 < n; r0 += 128) {
+          TileRec t;
+          t.a = (const char*)c.x + (c.ptr[b] + r0) * 256;
+          t.w = (const char*)c.w + (size_t)b * 32768;
+          t.c = (char*)c.out + (c.ptr[b] + r0) * 256;
+          t.rows = (int32_t)std::min<int64_t>(128, n - r0);
+          t.pad = 0;
+          hr.push_back(t);
+        }
+      }
+      ntiles = (int)hr.size();
+      CK(hipMalloc(&drec, hr.size() * sizeof(TileRec)));
+      CK(hipMemcpy(drec, hr.data(), hr.size() * sizeof(TileRec), hipMemcpyHostToDevice));
+    }
+    const int lds = 65536 + pad;
+    bool done = false;
+#define V4_CASE(F, D)                                                                                          \
+  if (flags == F && dbg == D) {                                                                                \
+    CK(hipFuncSetAttribute((const void*)&v4_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));   \
+    bench(c, spec, [&] { hipLaunchKernelGGL((v4_kernel<F, D>), dim3(ntiles), dim3(256), lds, 0, drec, ntiles); }); \
+    done = true;                                                                                               \
+  }
+    V4_CASE(3, 0) V4_CASE(2, 0) V4_CASE(1, 0) V4_CASE(0, 0) V4_CASE(3, 1)
+#undef V4_CASE
+    if (!done && g_round == 0) printf("%s: no such v4 variant\n", spec.c_str());
+    return true;
+  }
+  if (name == "rw") {
+    // src / dst: 0 = x, 1 = out, 2 = out2, 3 = out2 + 32 MB
+    const int mode = opt("mode", 2), src = opt("src", 0), dst = opt("dst", 1), wgs = opt("wgs", 8);
+    char* bufs[4] = {(char*)c.x, (char*)c.out, c.out2, c.out2 + (32u << 20)};
+    const long ntiles = c.rows * 256 / 8192;
+    const u32x4* in = (const u32x4*)bufs[src];
+    u32x4* out = (u32x4*)bufs[dst];
+    const int grid = c.cus * wgs;
+    // timing only (the data check of bench() is meaningless here)
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipEventRecord(e0));
+      if (mode == 0) hipLaunchKernelGGL((rw_kernel<0>), dim3(grid), dim3(256), 0, 0, in, out, ntiles);
+      else if (mode == 1) hipLaunchKernelGGL((rw_kernel<1>), dim3(grid), dim3(256), 0, 0, in, out, ntiles);
+      else hipLaunchKernelGGL((rw_kernel<2>), dim3(grid), dim3(256), 0, 0, in, out, ntiles);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = (mode == 2 ? 2.0 : 1.0) * c.rows * 256;
+    printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+  if (name == "v3") {
+    const int nwv = opt("nw", 8), flags = opt("flags", 3), wgs = opt("wgs", 1), dbg = opt("dbg", 0);
+    const int wdb = opt("wdb", 1), sched = opt("sched", 0);
+    const int bm = nwv * 32;
+    // tile table for bm-row workgroup tiles
+    std::vector<int32_t> ht(c.B + 1);
+    long tiles = 0;
+    for (int b = 0; b < c.B; ++b) {
+      ht[b] = (int32_t)tiles;
+      tiles += (c.ptr[b + 1] - c.ptr[b] + bm - 1) / bm;
+    }
+    ht[c.B] = (int32_t)tiles;
+    int32_t* dt;
+    CK(hipMalloc(&dt, (c.B + 1) * 4));
+    CK(hipMemcpy(dt, ht.data(), (c.B + 1) * 4, hipMemcpyHostToDevice));
+    const int lds = (wdb ? 2 : 1) * 32768 + nwv * 8192;
+    const int grid = c.cus * wgs;
+    bool done = false;
+#define V3_CASE(F, N, D, W, S)                                                                                       \
+  if (flags == F && nwv == N && dbg == D && wdb == W && sched == S) {                                                \
+    CK(hipFuncSetAttribute((const void*)&v3_kernel<F, N, D, W, S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    bench(c, spec, [&] { hipLaunchKernelGGL((v3_kernel<F, N, D, W, S>), dim3(grid), dim3(N * 64), lds, 0, c.descs, dt, c.B); }); \
+    done = true;                                                                                                     \
+  }
+    V3_CASE(3, 8, 0, 1, 0) V3_CASE(0, 8, 0, 1, 0) V3_CASE(3, 4, 0, 1, 0) V3_CASE(3, 8, 1, 1, 0)
+    V3_CASE(3, 8, 0, 1, 1) V3_CASE(3, 8, 0, 0, 0) V3_CASE(3, 4, 0, 0, 0) V3_CASE(3, 4, 0, 0, 1) V3_CASE(3, 2, 0, 0, 0)
+    V3_CASE(1, 8, 0, 1, 0) V3_CASE(2, 8, 0, 1, 0)
+#undef V3_CASE
+    CK(hipFree(dt));
+    if (!done) printf("%s: no such v3 variant\n", spec.c_str());
+    return true;
+  }
+  return false;
+}
