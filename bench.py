@@ -5,21 +5,28 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
-``segment_matmul`` on BASELINE.json configs[1] (154 relations, 21,111,007 rows, F=128, bf16;
-SURVEY.md 8(d) C2).  `value` is whole-job GFLOP/s (2*N*K*M flop per step / wall time).  With
-N > 1 ranks the relation list is sharded contiguously by rows (pyg_lib_amd/sharding.py), each rank
-multiplies its shard, and the timed region is compute-only with the outputs left sharded -- no
-data-path collective.  Default "scaling": "weak": the job is the C2 relation list with every
-relation N x as many rows, so each rank's shard is one C2-sized launch (per-GPU work fixed);
-``--scaling strong`` shards the fixed C2 job instead (0.25 ms launches at N=8).  The RCCL all-gather
-of the outputs that BASELINE's north_star names is timed separately and reported under "allgather"
-(it is xGMI-bound and ~26x slower than the HBM-bound shard compute, so folding it
-in would only measure the links).
+``segment_matmul`` on BASELINE.json configs[1] (154 relations, 21,111,007 rows, F=128, bf16).
+`value` is whole-job GFLOP/s (2*N*K*M flop per step / wall time, max over ranks).
 
-The JSON line also carries `roofline` (dominant kernel vs the HBM roofline, durations measured
-with HIP events on the launch stream through pyg_hip_profile_*), `cpu_baseline` (the oracle timed
-on the host cores on a bounded sample, rank 0 / N=1 only) and `sampler` (neighbor_sample
-sampled-edges/s on the C3-shaped synthetic graph, when the HIP sampler is built).
+N > 1 ranks: STRONG scaling -- the same fixed C2 job, its relation list cut at row boundaries into N contiguous
+shards (pyg_lib_amd/sharding.py), every rank multiplies its shard, outputs left sharded: the timed region has no
+data-path collective (north_star's ">= 6x at 8 GPUs" refers to this compute-only figure; SURVEY.md 8(e) shows the
+all-gather of the outputs is xGMI-bound and ~26x slower than the HBM-bound shard compute).  The all-gather is timed
+on its own and reported under "allgather"; BASELINE config C4 (grouped_matmul, 512 groups, relation-sharded by LPT,
+in-place RCCL all-gather) is the "c4" object with `compute_only` and `incl_allgather` side by side.
+(``--scaling weak`` grows the job with N instead: debugging only.)
+
+The JSON line also carries
+  roofline      dominant kernel vs the HBM roofline: algorithmic bytes / HIP-event kernel time on the launch stream
+                (pyg_hip_profile_*), plus `achievable`: what hand-written device copies of the same 1 read : 1 write
+                byte mix reach on this box on the same two buffers (pyg_hip_stream_copy: fine-grained sweep = the best
+                copy known on this hardware; contiguous / cyclic = the kernel's two tile schedules without the
+                arithmetic)
+  cpu_baseline  the reference's CPU arithmetic -- one at::matmul per relation (ops/cpu/matmul_kernel.cpp:195-201)
+                -- as per-segment torch.matmul on CPU tensors of the same dtype, all host threads; `cpu_port` is the
+                oracle's own C restatement (test infrastructure) on a smaller sample
+  sampler       neighbor_sample sampled-edges/s on the C3-shaped synthetic graph (single GPU by design)
+  c4, c5, index_sort, scatter_sum, segment_matmul_backward   the other configs / ops (bench_legs.py)
 """
 import argparse
 import ctypes
@@ -41,13 +48,17 @@ F32_MFMA_PEAK_TFLOPS = 157.0  # dense v_mfma_f32_32x32x2_f32 peak at 2.4 GHz (MI
 C2 = dict(B=154, N=21_111_007, F=128)
 
 
-def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
-    B, N, F = C2['B'], int(C2['N'] * scale), C2['F']
+def c2_ptr(N, B):
     g = torch.Generator(device='cpu').manual_seed(0)
     frac = torch.rand(B, generator=g)
     sizes = torch.floor(frac / frac.sum() * N).long()
     sizes[-1] += N - sizes.sum()
-    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    return torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+
+
+def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
+    B, N, F = C2['B'], int(C2['N'] * scale), C2['F']
+    ptr = c2_ptr(N, B)
     # contiguous row shard of this rank, ptr clipped to it (pyg_lib_amd/sharding.py)
     from pyg_lib_amd import sharding
     r0, r1, lptr = sharding.shard_ptr(ptr, rank, world)
@@ -61,9 +72,40 @@ def make_c2(device, rank, world, dtype=torch.bfloat16, scale=1.0):
     return x, lptr, w, (N, B, F)
 
 
-def cpu_baseline_segment_matmul(sample_rows=480_000, dtype='bf16'):
-    """Oracle (kind "port") on a bounded sample of the same workload: the first relations of C2
-    truncated to `sample_rows` rows, F=128, in the dtype of the run."""
+def cpu_baseline_aten(dtype='bf16', rows=4_194_304, budget_s=25.0):
+    """The reference's CPU path for this op is a loop of at::matmul_out over the relations
+    (ops/cpu/matmul_kernel.cpp:195-201, 428-434): the same arithmetic as per-segment torch.matmul on CPU tensors.
+    Sample: the C2 relation list scaled to `rows` rows, all host threads, best of up to 6 passes."""
+    B, F = C2['B'], C2['F']
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    ptr = c2_ptr(rows, B).tolist()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, F, generator=g).to(tdt)
+    w = (torch.randn(B, F, F, generator=g) / F ** 0.5).to(tdt)
+    out = torch.empty(rows, F, dtype=tdt)
+
+    def run():
+        for b in range(B):
+            if ptr[b + 1] > ptr[b]:
+                torch.matmul(x[ptr[b]:ptr[b + 1]], w[b], out=out[ptr[b]:ptr[b + 1]])
+
+    run()
+    best, reps, t_all = None, 0, time.perf_counter()
+    while reps < 6 and time.perf_counter() - t_all < budget_s:
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return dict(value=round(2.0 * rows * F * F / best / 1e9, 2), unit='GFLOP/s', cores=torch.get_num_threads(),
+                kind='aten-per-segment',
+                sample=f'per-relation torch.matmul on CPU {dtype} tensors (= at::matmul_out per segment, '
+                       f'ops/cpu/matmul_kernel.cpp:195-201): C2 relation list scaled to {rows} rows, F=128, '
+                       f'best of {reps} passes, {torch.get_num_threads()} threads')
+
+
+def cpu_port_segment_matmul(sample_rows=480_000, dtype='bf16'):
+    """The oracle's C restatement (kind "port", test infrastructure) on a bounded sample."""
     import oracle
     B, F = 8, C2['F']
     rng = np.random.default_rng(0)
@@ -76,10 +118,8 @@ def cpu_baseline_segment_matmul(sample_rows=480_000, dtype='bf16'):
     if dtype == 'bf16':
         x, w, code = oracle.f32_to_bf16_bits(x), oracle.f32_to_bf16_bits(w), oracle.BF16
     oracle.segment_matmul(x[:1024], np.array([0, 1024]), w[:1], dtype=code)  # warm up / build
-    best = None
-    t_all = time.perf_counter()
-    reps = 0
-    while reps < 30 and time.perf_counter() - t_all < 12.0:
+    best, reps, t_all = None, 0, time.perf_counter()
+    while reps < 10 and time.perf_counter() - t_all < 5.0:
         t0 = time.perf_counter()
         oracle.segment_matmul(x, ptr, w, dtype=code)
         dt = time.perf_counter() - t0
@@ -92,6 +132,28 @@ def cpu_baseline_segment_matmul(sample_rows=480_000, dtype='bf16'):
                        f'F=128 {dtype}, best of {reps}, OpenMP')
 
 
+def stream_copy_rates(L, x, reps=5):
+    """Hand-written copies of x into an out-sized buffer (1 read : 1 write, the kernel's byte mix)."""
+    dst = torch.empty_like(x)
+    nbytes = x.numel() * x.element_size()
+    stream = torch.cuda.current_stream().cuda_stream
+    rates = {}
+    for name, mode in (('fine_sweep', 0), ('contiguous_ranges', 1), ('cyclic', 2)):
+        for _ in range(2):
+            L.pyg_hip_stream_copy(x.data_ptr(), dst.data_ptr(), nbytes, mode, stream)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.pyg_hip_stream_copy(x.data_ptr(), dst.data_ptr(), nbytes, mode, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        rates[name] = round(2.0 * nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9, 1)
+    ok = bool(torch.equal(dst.view(torch.int16)[-4096:], x.view(torch.int16)[-4096:]))
+    del dst
+    return rates, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -100,8 +162,11 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sampler', action='store_true')
+    ap.add_argument('--no-legs', action='store_true', help='skip the c4 / c5 / index_sort / scatter / backward legs')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
+    ap.add_argument('--schedule', default='auto', choices=['auto', 'contiguous', 'cyclic'],
+                    help='tile schedule of the bf16 kernel (pyg_hip_matmul_set_schedule)')
     ap.add_argument('--debug-one-device', action='store_true',
                     help='debug only: all ranks share cuda:0 over gloo (exercises the N>1 code path on a 1-GPU box)')
     args = ap.parse_args()
@@ -116,8 +181,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    backend = None
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'gloo' if args.debug_one_device else 'nccl'
         if args.debug_one_device:
             dist.init_process_group('gloo')
         else:
@@ -129,6 +196,9 @@ def main():
     L.pyg_hip_profile_enable.argtypes = [ctypes.c_int]
     L.pyg_hip_profile_collect.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.pyg_hip_profile_collect.restype = ctypes.c_int
+    L.pyg_hip_stream_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    L.pyg_hip_stream_copy.restype = ctypes.c_int
+    ops.set_matmul_schedule(args.schedule)
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     job_scale = args.scale * (world if args.scaling == 'weak' else 1)
@@ -171,15 +241,21 @@ def main():
     n_local = x.size(0)
     alg_bytes = esz * (n_local * F + n_local * F + B * F * F) + 8 * (B + 1)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
-    # HBM bytes from PMC (FETCH_SIZE/WRITE_SIZE, separate --pmc passes of this command, corrected as
-    # MI355X_MICROARCH.md prescribes): recorded in profiles/, valid for the full single-GPU C2 launch
+    # HBM bytes from PMC (FETCH_SIZE / WRITE_SIZE, separate --pmc passes of this command, corrected as
+    # MI355X_MICROARCH.md prescribes): recorded in profiles/ per kernel variant, valid for the full single-GPU launch
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r1_segment_matmul_c2_pmc.json')
-    if world == 1 and args.scale == 1.0 and args.dtype == 'bf16' and os.path.exists(pmc):
-        try:
-            traffic = int(json.load(open(pmc))['hbm_traffic_bytes'])
-        except Exception:  # noqa: BLE001
-            traffic = None
+    if world == 1 and args.scale == 1.0 and args.dtype == 'bf16':
+        for name in ('r2_segment_matmul_c2_pmc.json', 'r1_segment_matmul_c2_pmc.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if not os.path.exists(pmc):
+                continue
+            try:
+                rec = json.load(open(pmc))
+                if rec.get('kernel_variant', 'mfma_bf16_k128_mc128') == variant:
+                    traffic = int(rec['hbm_traffic_bytes'])
+                    break
+            except Exception:  # noqa: BLE001
+                pass
     tflops = None if achieved is None else 2.0 * n_local * F * F / (kernel_ms * 1e-3) / 1e12
     if args.dtype == 'f32':
         # fp32, F = 128: AI = 32 flop/B is above the fp32 ridge (157 TF / 8 TB/s = 20): bound by the fp32 MFMA rate
@@ -193,24 +269,16 @@ def main():
                         traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
                         mfma_tflops=None if tflops is None else round(tflops, 1))
 
-    # context for `frac`: what a plain device copy of the same 1 read : 1 write byte mix reaches on this
-    # box (torch's copy kernel over x -> out-sized buffer), measured right after the timed region
-    if rank == 0 and world == 1:
+    # context for `frac`: hand-written copies of the same byte mix on this box, right after the timed region
+    if rank == 0 and world == 1 and args.dtype == 'bf16':
         try:
-            dst = torch.empty_like(x)
-            for _ in range(2):
-                dst.copy_(x)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                dst.copy_(x)
-            e1.record()
-            torch.cuda.synchronize()
-            roofline['stream_copy_GBps'] = round(2.0 * x.numel() * esz / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9, 1)
-            del dst
-        except Exception:  # noqa: BLE001 - context only
-            roofline['stream_copy_GBps'] = None
+            rates, ok = stream_copy_rates(L, x)
+            roofline['achievable'] = dict(GBps=max(rates.values()), copies_GBps=rates, verified=ok,
+                                          what='pyg_hip_stream_copy of x into an out-sized buffer (1 read : 1 write)')
+            if achieved is not None:
+                roofline['frac_of_achievable'] = round(achieved / max(rates.values()), 4)
+        except Exception as e:  # noqa: BLE001 - context only
+            roofline['achievable'] = dict(error=repr(e)[:200])
 
     allgather = None
     if distributed:
@@ -231,7 +299,7 @@ def main():
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
             ag_ms = float(tg.item()) * 1e3
             allgather = dict(ms=round(ag_ms, 3), bytes_per_rank_received=int((N - n_local) * F * esz),
-                             value_incl_allgather=round(flops / ((ms_per_step + ag_ms) * 1e-3) / 1e9, 1))
+                             value_incl_allgather=round(flops / ((ms_per_step + ag_ms) * 1e-3) / 1e9, 1), backend=backend)
             del full
         except Exception as e:  # noqa: BLE001 - the headline line must survive a collective failure
             allgather = dict(error=repr(e)[:200])
@@ -246,13 +314,40 @@ def main():
             'config': {'workload': 'segment_matmul ogbn-mag-shaped: 154 relations, 21,111,007 rows, '
                                    'F_in=F_out=128 (BASELINE.json configs[1])',
                        'relations': B, 'rows': N, 'rows_per_gpu': N // world, 'F': F, 'scale': args.scale,
-                       'sharding': f'contiguous row shards x{world}, outputs left sharded'},
+                       'sharding': f'contiguous row shards x{world}, outputs left sharded (compute only)'},
             'roofline': roofline,
         }
         if allgather is not None:
             result['allgather'] = allgather
 
     del out
+    # C4 (grouped_matmul, relation-sharded): runs on every rank
+    if not args.no_legs and args.dtype == 'bf16':
+        import bench_legs
+        try:
+            c4 = bench_legs.leg_c4(device, rank, world)
+        except Exception as e:  # noqa: BLE001
+            c4 = dict(error=repr(e)[:300])
+        if rank == 0:
+            result['c4'] = c4
+    if rank == 0 and world == 1 and not args.no_legs and args.dtype == 'bf16':
+        import bench_legs
+        for key, fn in (('segment_matmul_backward', lambda: bench_legs.leg_backward(device, x, ptr, w)),):
+            try:
+                result[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                result[key] = dict(error=repr(e)[:300])
+    del x
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_legs and args.dtype == 'bf16':
+        for key, fn in (('c5', lambda: bench_legs.leg_c5(device)),
+                        ('index_sort', lambda: bench_legs.leg_index_sort(device)),
+                        ('scatter_sum', lambda: bench_legs.leg_scatter_sum(device))):
+            try:
+                result[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                result[key] = dict(error=repr(e)[:300])
+            torch.cuda.empty_cache()
     # secondary metric: sampled-edges/s of the HIP neighbour sampler (single GPU by design)
     if rank == 0 and not args.no_sampler:
         try:
@@ -261,7 +356,11 @@ def main():
         except ImportError:
             result['sampler'] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline_segment_matmul(dtype=args.dtype)
+        result['cpu_baseline'] = cpu_baseline_aten(dtype=args.dtype)
+        try:
+            result['cpu_port'] = cpu_port_segment_matmul(dtype=args.dtype)
+        except Exception as e:  # noqa: BLE001
+            result['cpu_port'] = dict(error=repr(e)[:200])
     elif rank == 0:
         result['cpu_baseline'] = None
     if rank == 0:

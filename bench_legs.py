@@ -1,0 +1,235 @@
+"""Secondary legs of bench.py: the other BASELINE configs and hot-path ops, each as one small JSON object with its
+algorithmic bytes (SURVEY.md 8(d) formulas), the measured time per call (HIP events on the launch stream, inputs
+resident in HBM) and the fraction of the 8 TB/s HBM peak that makes.  Rank 0 / one GPU unless stated otherwise.
+
+Every leg is bounded (a few launches of a fixed synthetic workload) so that the default `python bench.py` run still
+finishes within a few minutes.
+"""
+import math
+import time
+
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _event_ms(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _rate(alg_bytes, ms):
+    gbps = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(alg_bytes=int(alg_bytes), ms=round(ms, 4), GBps=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBS, 4))
+
+
+# ---------------------------------------------------------------------------------------------------
+# C4: grouped_matmul, 512 variable-size groups, K = M = 256, bf16 (BASELINE.json configs[3])
+# ---------------------------------------------------------------------------------------------------
+
+def c4_group_rows(num_groups=512, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.exp(torch.rand(num_groups, generator=g) * (math.log(65536.0) - math.log(256.0)) +
+                     math.log(256.0)).long().tolist()
+
+
+def leg_c4(device, rank, world, iters=10, F=256, dtype=torch.bfloat16):
+    """The fixed 512-group job, relation-sharded over `world` ranks by greedy LPT on the row counts
+    (pyg_lib_amd/sharding.py).  `compute_only`: every rank multiplies its groups, outputs left in its slot of the
+    pool; `incl_allgather`: plus the in-place RCCL all_gather_into_tensor that completes the pool on every rank.
+    Both are max-over-ranks times of the same fixed job (strong scaling)."""
+    import torch.distributed as dist
+    from pyg_lib_amd import ops, sharding
+    rows = c4_group_rows()
+    plan = sharding.GroupPlan(rows, world)
+    mine = plan.local_groups(rank)
+    gd = torch.Generator(device=device).manual_seed(10 + rank)
+    xs = [torch.randn(rows[i], F, device=device, generator=gd).to(dtype) for i in mine]
+    ws = [(torch.randn(F, F, device=device, generator=gd) / F ** 0.5).to(dtype) for _ in mine]
+    esz = xs[0].element_size()
+    total_rows = sum(rows)
+    flops = 2.0 * total_rows * F * F
+    alg_total = esz * (2 * total_rows * F + len(rows) * F * F)   # whole job
+    alg_local = esz * (2 * plan.load[rank] * F + len(mine) * F * F)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / n], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3
+
+    # the reference's operator signature (list in, list out): what a PyG caller runs on one GPU
+    op_ms = timed(lambda: ops.grouped_matmul(xs, ws), iters)
+    variant = ops.matmul_last_variant()
+    kernel_ms = _event_ms(lambda: sharding.grouped_matmul_sharded(xs, ws, plan, rank, gather=False), iters)
+    comp_ms = timed(lambda: sharding.grouped_matmul_sharded(xs, ws, plan, rank, gather=False), iters)
+    res = dict(workload='grouped_matmul: 512 groups, rows log-uniform [256, 65536], K=M=256 (BASELINE.json configs[3])',
+               groups=len(rows), rows=total_rows, F=F, dtype='bf16', n_gpus=world, kernel=variant,
+               sharding=f'LPT by rows over {world} ranks, imbalance {plan.imbalance:.4f}',
+               operator_ms=round(op_ms, 4),
+               compute_only=dict(ms=round(comp_ms, 4), GFLOPs=round(flops / (comp_ms * 1e-3) / 1e9, 1),
+                                 **{k: v for k, v in _rate(alg_total, comp_ms).items() if k != 'ms'}),
+               rank0_launch=_rate(alg_local, kernel_ms))
+    if world > 1:
+        ag_ms = timed(lambda: sharding.grouped_matmul_sharded(xs, ws, plan, rank, gather=True), max(3, iters // 3))
+        res['incl_allgather'] = dict(ms=round(ag_ms, 4), GFLOPs=round(flops / (ag_ms * 1e-3) / 1e9, 1),
+                                     bytes_received_per_rank=int(esz * (total_rows - plan.load[rank]) * F))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# C5: hetero_neighbor_sample + R-GCN layer on a MAG-shaped graph (BASELINE.json configs[4])
+# ---------------------------------------------------------------------------------------------------
+
+MAG_SIZES = {'paper': 736_389, 'author': 1_134_649, 'institution': 8_740, 'field_of_study': 59_965}
+MAG_RELS = [('paper', 'cites', 'paper', 10_832_542), ('author', 'writes', 'paper', 7_145_660),
+            ('paper', 'rev_writes', 'author', 7_145_660), ('author', 'affiliated_with', 'institution', 1_043_998),
+            ('institution', 'rev_affiliated_with', 'author', 1_043_998),
+            ('paper', 'has_topic', 'field_of_study', 7_505_078), ('field_of_study', 'rev_has_topic', 'paper', 7_505_078)]
+
+
+def make_mag_graph(device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    rp, cl = {}, {}
+    for s, r, d, e in MAG_RELS:
+        src = torch.randint(0, MAG_SIZES[s], (e,), device=device, generator=g)
+        deg = torch.bincount(src, minlength=MAG_SIZES[s])
+        rp[(s, r, d)] = torch.cat([deg.new_zeros(1), deg.cumsum(0)])
+        cl[(s, r, d)] = torch.randint(0, MAG_SIZES[d], (e,), device=device, generator=g)
+    return rp, cl
+
+
+def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
+    from pyg_lib_amd import sampler, rgcn
+    types = list(MAG_SIZES)
+    ets = [(s, r, d) for s, r, d, _ in MAG_RELS]
+    rp, cl = make_mag_graph(device)
+    feat = {t: torch.randn(MAG_SIZES[t], F, device=device).to(dtype) for t in types}
+    W = (torch.randn(len(ets), F, F, device=device) / F ** 0.5).to(dtype)
+    fan = {e: [15, 10] for e in ets}
+    gs = torch.Generator().manual_seed(1)
+    seeds = [torch.randperm(MAG_SIZES['paper'], generator=gs)[:batch].to(device) for _ in range(iters + 3)]
+    layer = getattr(rgcn, 'rgcn_layer_fused', None) or rgcn.rgcn_layer
+    state = {}
+
+    def sample(i):
+        return sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds[i]}, fan)
+
+    def one(i):
+        out = sample(i)
+        row_d, col_d, node_d = out[0], out[1], out[2]
+        off = rgcn.type_offsets({t: node_d[t].numel() for t in types}, types)
+        x = torch.cat([feat[t][node_d[t]] for t in types])
+        y = layer(x, off, row_d, col_d, ets, W)
+        state['last'] = (out, x, off)
+        return out, y
+
+    torch.manual_seed(100)
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(3, 3 + iters):
+        out, y = one(i)
+        edges += sum(v.numel() for v in out[0].values())
+    torch.cuda.synchronize()
+    total_ms = (time.perf_counter() - t0) / iters * 1e3
+    t0 = time.perf_counter()
+    for i in range(3, 3 + iters):
+        sample(i)
+    torch.cuda.synchronize()
+    samp_ms = (time.perf_counter() - t0) / iters * 1e3
+    out, x, off = state['last']
+    layer_ms = _event_ms(lambda: layer(x, off, out[0], out[1], ets, W), iters)
+    e = sum(v.numel() for v in out[0].values())
+    n = x.size(0)
+    esz = x.element_size()
+    # layer: per edge one gathered source row in (+ 16 B of indices), per node one output row written
+    alg = e * (F * esz + 16) + n * F * esz + len(ets) * F * F * esz
+    return dict(workload='hetero_neighbor_sample + R-GCN layer, MAG-shaped graph (4 node types, 7 relations, ~42 M '
+                         'entries), batch 1024 papers, fanout [15, 10], F=128 bf16 (BASELINE.json configs[4])',
+                layer_impl=layer.__name__, edges_per_batch=edges // iters, nodes_last_batch=n,
+                ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
+                layer=_rate(alg, layer_ms))
+
+
+# ---------------------------------------------------------------------------------------------------
+# index_sort, scatter_sum, segment_matmul backward
+# ---------------------------------------------------------------------------------------------------
+
+def leg_index_sort(device, n=100_000_000, max_value=2_449_029, iters=5):
+    from pyg_lib_amd import ops
+    g = torch.Generator(device=device).manual_seed(3)
+    keys = torch.randint(0, max_value, (n,), device=device, generator=g, dtype=torch.long)
+    ms = _event_ms(lambda: ops.index_sort(keys, max_value), iters)
+    passes = (max(max_value, 1).bit_length() + 7) // 8
+    floor = n * (8 + 16)                 # read keys once, write keys + permutation once
+    res = _rate(floor, ms)
+    res.update(workload=f'index_sort: {n} int64 keys < {max_value} ({passes} radix passes)', keys_per_s=round(n / (ms * 1e-3)),
+               lsd_budget_bytes=int(passes * n * (8 + 16 + 16)))
+    return res
+
+
+def leg_scatter_sum(device, E=20_000_000, N=2_000_000, K=128, dtype=torch.bfloat16, iters=5):
+    from pyg_lib_amd import ops
+    g = torch.Generator(device=device).manual_seed(4)
+    src = torch.randn(E, K, device=device, generator=g, dtype=torch.float32).to(dtype)
+    idx = torch.randint(0, N, (E,), device=device, generator=g, dtype=torch.long)
+    ms = _event_ms(lambda: ops.scatter_sum(src, idx, dim=0, dim_size=N), iters)
+    esz = src.element_size()
+    res = _rate(8 * E + esz * E * K + esz * N * K, ms)
+    res.update(workload=f'scatter_sum: E={E} random (unsorted) indices into N={N} rows, K={K} bf16')
+    idx_sorted = idx.sort().values
+    ms2 = _event_ms(lambda: ops.segment_sum_coo(src, idx_sorted, dim_size=N), iters)
+    res['segment_sum_coo_sorted'] = _rate(8 * E + esz * E * K + esz * N * K, ms2)
+    ms3 = _event_ms(lambda: ops.gather_coo(src[:N], idx_sorted), iters)
+    res['gather_coo'] = _rate(8 * E + 2 * esz * E * K, ms3)
+    return res
+
+
+def leg_backward(device, x, ptr, w, iters=5):
+    """segment_matmul forward + backward (dX through the forward kernel with W^T read in place, dW through the
+    split-rows weight-gradient kernel) on the bench's own C2 tensors."""
+    from pyg_lib_amd import ops
+    N, F = x.shape
+    B = w.size(0)
+    esz = x.element_size()
+    xg = x.detach().requires_grad_()
+    wg = w.detach().requires_grad_()
+    go = torch.ones(N, F, device=device, dtype=x.dtype)
+
+    def fb():
+        out = ops.segment_matmul(xg, ptr, wg)
+        out.backward(go)
+        xg.grad = None
+        wg.grad = None
+
+    ms_fb = _event_ms(fb, iters)
+    ms_f = _event_ms(lambda: ops.segment_matmul(x, ptr, w), iters)
+    # backward alone: dX reads dY + writes dX, dW reads X + dY and writes fp32 accumulators + B*K*M
+    alg_bwd = esz * (2 * N * F) + esz * (2 * N * F) + 4 * B * F * F
+    res = _rate(alg_bwd, ms_fb - ms_f)
+    res.update(workload='segment_matmul backward (dX + dW) on C2', ms_forward=round(ms_f, 4), ms_forward_backward=round(ms_fb, 4),
+               flops=2 * 2.0 * N * F * F)
+    return res

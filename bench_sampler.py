@@ -1,8 +1,8 @@
 """bench_sampler.py -- secondary leg of bench.py: sampled-edges/s of the HIP neighbour sampler on BASELINE config C3.
 
 ogbn-products cannot be downloaded here, so the graph is synthetic with the same scale
-(SURVEY.md 8(d)): N = 2,449,029 nodes, per-node degree ~ log-normal(3.3, 1.0) clipped to
-[1, 17481] (~100 M directed edges), col uniform, int64; batch 1024, fan-out [15, 10, 5],
+(SURVEY.md 8(d)): N = 2,449,029 nodes, per-node degree ~ log-normal(3.42, 1.0) clipped to
+[1, 17481] (~123.7 M directed edges, ogbn-products' count), col uniform, int64; batch 1024, fan-out [15, 10, 5],
 replace=False, directed=True, disjoint=False, return_edge_id=True.
 """
 import time
@@ -17,7 +17,7 @@ BATCH = 1024
 
 def make_graph(device, seed=0):
     g = torch.Generator(device=device).manual_seed(seed)
-    deg = torch.exp(torch.randn(N_NODES, device=device, generator=g) * 1.0 + 3.3).round().clamp_(1, 17481).long()
+    deg = torch.exp(torch.randn(N_NODES, device=device, generator=g) * 1.0 + 3.42).round().clamp_(1, 17481).long()
     rowptr = torch.zeros(N_NODES + 1, dtype=torch.long, device=device)
     torch.cumsum(deg, 0, out=rowptr[1:])
     E = int(rowptr[-1])
@@ -62,6 +62,9 @@ def run(device, batches=20, warmup=3, cpu_batches=2):
             r = oracle.neighbor_sample(rp, cl, seeds[warmup + b].cpu().numpy(), FANOUT, rng_seed=12345)
             ce += sum(r[5])
         cdt = time.perf_counter() - t0
+        # the reference sampler is single threaded by construction (one RNG stream, insertion-ordered relabelling,
+        # sampler/cpu/neighbor_kernel.cpp:332-514); this is the oracle's C restatement of it on ONE core
         res['cpu_baseline'] = dict(value=round(ce / cdt, 1), unit='edges/s', cores=1, kind='port',
-                                   sample=f'oracle/oracle_sampler.c, {cpu_batches} batches of {BATCH} seeds')
+                                   sample=f'oracle/oracle_sampler.c (1 thread: the reference algorithm is sequential), '
+                                          f'{cpu_batches} batches of {BATCH} seeds')
     return res

@@ -478,6 +478,12 @@ PYG_HIP_API int pyg_hip_hash_map_get(int key_dtype, const void* query, int64_t m
 PYG_HIP_API void pyg_hip_profile_enable(int on);
 PYG_HIP_API int pyg_hip_profile_collect(float* ms_out, int capacity);
 
+/* Hand-written device-to-device streaming copy of `bytes` bytes (16-byte aligned buffers), the yardstick
+ * bench.py prints as roofline.achievable: mode 0 = fine-grained non-persistent sweep (the best copy found on
+ * this hardware), 1 = persistent with one contiguous range per workgroup, 2 = persistent cyclic -- the two
+ * segment_matmul tile schedules without the arithmetic.  Measurement support; no operator calls it. */
+PYG_HIP_API int pyg_hip_stream_copy(const void* src, void* dst, size_t bytes, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,7 +338,7 @@ def test_grouped_matmul_pool_writes_into_the_callers_buffer():
     ref = ops.grouped_matmul(ins, oth)
     pos = 0
     for r, o, e in zip(rows, outs, ref):
-        assert o.data_ptr() == pool[pos:].data_ptr() and o.shape == (r, 256)
+        assert (r == 0 or o.data_ptr() == pool[pos:].data_ptr()) and o.shape == (r, 256)
         assert torch.equal(o, e)
         pos += r
     assert bool((pool[sum(rows):] == 7.0).all())
