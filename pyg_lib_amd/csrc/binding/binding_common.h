@@ -6,6 +6,9 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <ATen/record_function.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "pyg_hip.h"
 
 namespace pyg_amd {
@@ -26,6 +29,19 @@ inline int dtype_code(at::ScalarType t) {
     default: TORCH_CHECK(false, "pyg (HIP): unsupported dtype ", t); return -1;
   }
 }
+
+// Op-level tracing: every operator entry shows up as a RECORD_FUNCTION range in the PyTorch
+// profiler and as a roctx range in rocprofv3 --marker-trace, named like the schema ("pyg::segment_matmul").
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+  ~RoctxRange() { roctxRangePop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+};
+#define PYG_TRACE(name)                                                \
+  at::RecordFunction pyg_record_fn_(at::RecordScope::FUNCTION);          \
+  if (pyg_record_fn_.isActive()) pyg_record_fn_.before(name);            \
+  ::pyg_amd::RoctxRange pyg_roctx_range_(name)
 
 inline void check_status(int rc) {
   TORCH_CHECK(rc == PYG_HIP_OK, pyg_hip_last_error());

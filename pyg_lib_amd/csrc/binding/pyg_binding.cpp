@@ -48,6 +48,7 @@ int64_t cuda_version() { return pyg_hip_version(); }
 // ---------------------------------------------------------------------------------------------
 static Tensor segment_matmul_impl(const Tensor& input, const Tensor& ptr, const Tensor& other,
                                   const c10::optional<Tensor>& bias) {
+  PYG_TRACE("pyg::segment_matmul");
   at::TensorArg input_arg{input, "input", 0};
   at::TensorArg ptr_arg{ptr, "ptr", 1};
   at::TensorArg other_arg{other, "other", 2};
@@ -100,6 +101,7 @@ Tensor segment_matmul_bias_kernel(const Tensor& input, const Tensor& ptr, const 
 // (pyg_lib_amd/sharding.py), so the results are produced where the collective reads them.
 static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const at::TensorList other,
                                                const c10::optional<Tensor>& caller_pool) {
+  PYG_TRACE("pyg::grouped_matmul");
   TORCH_CHECK(input.size() == other.size(),
               "Number of 'input' tensors must match number of 'other' tensors");
   const size_t G = input.size();
@@ -251,6 +253,7 @@ static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& p
 
 // dW through the C-ABI; returns an undefined tensor when the device kernel does not cover the case.
 static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, const Tensor& other) {
+  PYG_TRACE("pyg::segment_matmul_backward_dw");
   const auto st = input.scalar_type();
   if (st != at::kBFloat16 && st != at::kHalf && st != at::kFloat) return Tensor();
   const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
@@ -503,6 +506,7 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
                        const c10::optional<Tensor>& edge_time, const c10::optional<Tensor>& seed_time,
                        const c10::optional<Tensor>& edge_weight, bool csc, bool replace, bool directed,
                        bool disjoint, std::string temporal_strategy, bool return_edge_id) {
+  PYG_TRACE("pyg::neighbor_sample");
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(),
               directed, disjoint, temporal_strategy);
   IndexArgs ix;
@@ -550,6 +554,7 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
                               const c10::optional<c10::Dict<rel_type, Tensor>>& edge_weight_dict, bool csc,
                               bool replace, bool directed, bool disjoint, std::string temporal_strategy,
                               bool return_edge_id) {
+  PYG_TRACE("pyg::hetero_neighbor_sample");
   check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), seed_time_dict.has_value(),
               edge_weight_dict.has_value(), directed, disjoint, temporal_strategy);
   std::unordered_map<std::string, int> nt_index;
@@ -641,6 +646,7 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
     const c10::optional<Tensor>& node_time, const c10::optional<Tensor>& edge_time,
     const c10::optional<Tensor>& seed_time, const c10::optional<Tensor>& edge_weight, bool csc, bool replace,
     bool directed, bool disjoint, std::string temporal_strategy) {
+  PYG_TRACE("pyg::dist_neighbor_sample");
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(), directed,
               disjoint, temporal_strategy);
   check_index(rowptr, "rowptr");

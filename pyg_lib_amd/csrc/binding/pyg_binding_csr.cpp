@@ -57,6 +57,7 @@ CsrView csr_view(const char* name, const Tensor& src, const Tensor& indptr) {
 
 std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& src, const Tensor& indptr,
                                        const std::optional<Tensor>& optional_out) {
+  PYG_TRACE("pyg::segment_csr");
   if (optional_out.has_value())
     TORCH_CHECK(src.device() == optional_out.value().device(), name, ": src and out must be on the same device (got src=",
                 src.device(), ", out=", optional_out.value().device(), ")");
@@ -117,6 +118,7 @@ std::tuple<Tensor, Tensor> segment_max_csr_kernel(const Tensor& src, const Tenso
 }
 
 Tensor gather_csr_kernel(const Tensor& src, const Tensor& indptr, const std::optional<Tensor>& optional_out) {
+  PYG_TRACE("pyg::gather_csr");
   const char* name = "gather_csr";
   if (optional_out.has_value())
     TORCH_CHECK(src.device() == optional_out.value().device(), name, ": src and out must be on the same device (got src=",
@@ -174,6 +176,7 @@ SoftmaxShape softmax_shape(const char* name, const Tensor& src, const Tensor& pt
 }
 
 Tensor softmax_csr_kernel(const Tensor& src, const Tensor& ptr, int64_t dim) {
+  PYG_TRACE("pyg::softmax_csr");
   const auto s = softmax_shape("softmax_csr_forward", src, ptr, dim);
   DeviceGuard guard(src.device());
   auto out = at::zeros_like(src);
@@ -183,6 +186,7 @@ Tensor softmax_csr_kernel(const Tensor& src, const Tensor& ptr, int64_t dim) {
 }
 
 Tensor softmax_csr_backward_kernel(const Tensor& out, const Tensor& out_grad, const Tensor& ptr, int64_t dim) {
+  PYG_TRACE("pyg::softmax_csr_backward");
   const auto s = softmax_shape("softmax_csr_backward", out, ptr, dim);
   TORCH_CHECK(out_grad.is_contiguous() && out_grad.sizes() == out.sizes() && out_grad.scalar_type() == out.scalar_type() &&
                   out_grad.device() == out.device(),

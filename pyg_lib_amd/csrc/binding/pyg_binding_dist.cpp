@@ -13,6 +13,7 @@ std::tuple<Tensor, Tensor> relabel_neighborhood_kernel(const Tensor& seed, const
                                                        const std::vector<int64_t>& num_sampled_neighbors_per_node,
                                                        const int64_t num_nodes, const std::optional<Tensor>& batch,
                                                        bool csc, bool disjoint) {
+  PYG_TRACE("pyg::relabel_neighborhood");
   (void)num_nodes;  // only a capacity hint in the reference (Mapper)
   TORCH_CHECK(seed.is_cuda() && sampled_nodes_with_duplicates.is_cuda(), "relabel_neighborhood: tensors must live on a HIP device");
   TORCH_CHECK(seed.scalar_type() == at::kLong && sampled_nodes_with_duplicates.scalar_type() == at::kLong,
@@ -51,6 +52,7 @@ std::tuple<Tensor, Tensor, std::optional<Tensor>, std::vector<int64_t>> merge_sa
     const std::vector<std::vector<int64_t>>& cumsum_neighbors_per_node, const std::vector<int64_t>& partition_ids,
     const std::vector<int64_t>& partition_orders, const int64_t num_partitions, const int64_t num_neighbors,
     const std::optional<Tensor>& batch, bool disjoint) {
+  PYG_TRACE("pyg::merge_sampler_outputs");
   (void)num_neighbors;  // the reference only uses it to size a padded staging buffer
   TORCH_CHECK(num_partitions > 0 && (int64_t)node_ids.size() >= num_partitions && (int64_t)edge_ids.size() >= num_partitions &&
                   (int64_t)cumsum_neighbors_per_node.size() >= num_partitions,
@@ -135,6 +137,7 @@ std::tuple<c10::Dict<rel_type, Tensor>, c10::Dict<rel_type, Tensor>> hetero_rela
     const c10::Dict<rel_type, std::vector<std::vector<int64_t>>>& num_sampled_neighbors_per_node_dict,
     const c10::Dict<node_type, int64_t>& num_nodes_dict, const std::optional<c10::Dict<node_type, Tensor>>& batch_dict,
     bool csc, bool disjoint) {
+  PYG_TRACE("pyg::hetero_relabel_neighborhood");
   (void)num_nodes_dict;  // capacity hints of the reference's Mappers
   TORCH_CHECK(!edge_types.empty(), "hetero_relabel_neighborhood: no edge types");
   if (disjoint) TORCH_CHECK(batch_dict.has_value(), "Batch needs to be specified to create disjoint subgraphs");

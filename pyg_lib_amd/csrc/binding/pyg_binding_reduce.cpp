@@ -21,6 +21,7 @@ using torch::autograd::variable_list;
 // index_sort  (pyg_lib/csrc/ops/index_sort.cpp:9-28, ops/cpu/index_sort_kernel.cpp:14-59)
 // ---------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor> index_sort_kernel(const Tensor& input, const at::optional<int64_t> max) {
+  PYG_TRACE("pyg::index_sort");
   TORCH_CHECK(input.is_contiguous(), "Input should be contiguous.");
   TORCH_CHECK(input.dim() == 1, "Input should be 1-dimensional.");
   TORCH_CHECK(at::isIntegralType(input.scalar_type(), /*includeBool=*/false),
@@ -113,6 +114,7 @@ static const char* op_name(int op, bool coo) {
 static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& src, const Tensor& index_b, int64_t dim,
                                               const std::optional<Tensor>& optional_out,
                                               std::optional<int64_t> dim_size, int64_t inferred_size) {
+  PYG_TRACE("pyg::scatter_or_segment_coo");
   const char* name = op_name(op, coo);
   TORCH_CHECK(src.is_cuda() && index_b.is_cuda(), name, ": tensors must live on a HIP device");
   TORCH_CHECK(index_b.scalar_type() == at::kLong, name, ": index must be int64");
@@ -294,6 +296,7 @@ Tensor segment_mean_coo_kernel(const Tensor& src, const Tensor& index, const std
 }
 
 Tensor gather_coo_kernel(const Tensor& src, const Tensor& index, const std::optional<Tensor>& optional_out) {
+  PYG_TRACE("pyg::gather_coo");
   const char* name = "gather_coo";
   TORCH_CHECK(src.dim() >= index.dim(), name, ": src.dim() must be >= index.dim() (got src.dim()=", src.dim(),
               ", index.dim()=", index.dim(), ")");

@@ -148,6 +148,10 @@ struct HashTable {
   u64* keys;  // slot s: keys[2 s], vals[2 s] with vals == keys + 1 (interleaved pairs)
   u64* vals;
   u64 mask;  // capacity - 1
+  // Direct-address mode (the reference's Mapper does the same when the node count allows it, mapper.h:17-24):
+  // vals[node] for node < the type's node count, no keys, no probing -- one atomic per insert instead of a key
+  // load + CAS + atomic, and a table a third smaller than the hash table of a products-sized batch.
+  int dense;
 };
 
 __device__ __forceinline__ u64 hash64(u64 x) {
@@ -163,6 +167,7 @@ __device__ __forceinline__ u64 hash64(u64 x) {
 // per probe + value update instead of two); the returned handle is 2 * slot, to be used as
 // t.keys[handle] / t.vals[handle] (vals = keys + 1).
 __device__ __forceinline__ u64 table_slot(const HashTable& t, u64 key) {
+  if (t.dense) return key;
   u64 s = hash64(key) & t.mask;
   while (true) {
     u64 k = __hip_atomic_load(&t.keys[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1793,14 +1798,19 @@ struct NodeSet {
   DevVec nodes, batch;
   int64_t distinct = 0;  // Mapper::curr
   int64_t slice_b = 0, slice_e = 0;
-  HashTable table{nullptr, nullptr, 0};
+  HashTable table{nullptr, nullptr, 0, 0};
   int64_t entries_bound = 0;  // upper bound of keys present in the table
+  int64_t dense_n = 0;        // > 0: every id of this type is < dense_n and keys are plain node ids (not disjoint)
 };
 
 // keys and vals share one block (one allocation, one memset); `hint` = entries expected by the end of
 // the call, so that the table is usually built once instead of being rehashed every hop.
 int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   const int64_t need = ns.entries_bound + extra;
+  if (ns.table.keys && ns.table.dense) {
+    ns.entries_bound = need;
+    return PYG_HIP_OK;
+  }
   u64 cap = ns.table.keys ? ns.table.mask + 1 : 0;
   if (cap >= 2 * (u64)need && cap > 0) {
     ns.entries_bound = need;
@@ -1809,7 +1819,20 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   const int64_t want = std::max<int64_t>(need, std::min<int64_t>(hint, 1ll << 20));
   u64 ncap = 1024;
   while (ncap < 2 * (u64)need || ncap < 2 * (u64)want) ncap <<= 1;  // load factor <= 0.5
+  if (!ns.table.keys && ns.dense_n > 0 && (u64)ns.dense_n <= 4 * ncap && ns.dense_n <= (1ll << 27)) {
+    // direct-address table: at most twice the bytes of the hash table it replaces
+    HashTable dt;
+    PYG_ALLOC(dt.keys, u64*, c, sizeof(u64) * (size_t)ns.dense_n);
+    dt.vals = dt.keys;
+    dt.mask = 0;
+    dt.dense = 1;
+    PYG_HIP_CHECK(hipMemsetAsync(dt.keys, 0xFF, sizeof(u64) * (size_t)ns.dense_n, c.stream));
+    ns.table = dt;
+    ns.entries_bound = need;
+    return PYG_HIP_OK;
+  }
   HashTable nt;
+  nt.dense = 0;
   PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * 2 * ncap);
   nt.vals = nt.keys + 1;  // interleaved slots: (key, value) pairs
   nt.mask = ncap - 1;
@@ -2144,6 +2167,15 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     for (int s = 0; s < num_seed_sets; ++s) num_batches += seeds[s].num_seed;
     if (num_batches < 1) num_batches = 1;
     PYG_HIP_REQUIRE(num_batches < (1ll << 22), "sampler: too many seeds for disjoint sampling");
+  } else {
+    // node count of every type that some relation expands (rowptr has one row per node of that type): ids of that
+    // type are < that count -- the precondition of the reference's own dense Mapper (mapper.h:17-24, 609-612) --
+    // so its table can be direct-addressed (table_reserve decides by size)
+    for (int e = 0; e < num_relations; ++e) {
+      const int src = !csc ? rels[e].src_type : rels[e].dst_type;
+      if (src >= 0 && src < num_node_types)
+        ns[(size_t)src].dense_n = std::max<int64_t>(ns[(size_t)src].dense_n, rels[e].num_rows);
+    }
   }
 
   const size_t hand_back_offset =
@@ -2358,7 +2390,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         const int64_t Fb = fbh[(size_t)ell][(size_t)src];
         arena_bytes += align_up(sizeof(CountAgg) * (size_t)tiles(Fb), 256) + 2 * align_up(8 * (size_t)Fb, 256) +
                        align_up(4 * (size_t)Fb, 256) + (disjoint ? 3 : 2) * align_up(8 * (size_t)Eb, 256) +
-                       align_up(8 * (size_t)tiles(Eb), 256);
+                       align_up(8 * (size_t)tiles(Eb), 256) +
+                       align_up(sizeof(CountAgg) * (size_t)Fb, 256) + align_up(8 * (size_t)Eb, 256);  // scan value caches
       }
     char* arena;
     PYG_ALLOC(arena, char*, c, arena_bytes);
@@ -2417,6 +2450,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         int64_t* e_batch = disjoint ? reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb)) : nullptr;
         u64* e_slot = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
         int64_t* ftile = reinterpret_cast<int64_t*>(carve(8 * (size_t)tiles(Eb)));
+        // values of the scans' first pass, kept for the second (their loads are dependent random gathers)
+        CountAgg* count_cache = reinterpret_cast<CountAgg*>(carve(sizeof(CountAgg) * (size_t)Fb));
+        int64_t* flag_cache = reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb));
         RangeCtx range;
         range.rowptr = r.rowptr;
         range.col = r.col;
@@ -2428,7 +2464,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         range.error = err_flag;
         CountLoad cl{sn.nodes.p, 0, range, count, replace, tstate + src};
         CountStore cs{edge_off, rng_word, rng_units, 0, 4, chain};
-        int rc = device_scan<CountAgg, CountOp>(cl, cs, Fb, tile_buf, &info_dev[slot].tot, stream);
+        int rc = device_scan<CountAgg, CountOp>(cl, cs, Fb, tile_buf, &info_dev[slot].tot, stream, count_cache);
         if (rc != PYG_HIP_OK) return rc;
         // order the words this relation may read (16-bit draws, cumulative bound) before its sample kernel:
         // the first hops only wait for the first segment of the round, not for all of it
@@ -2465,7 +2501,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         FlagLoad fl{e_slot, dn.table.vals, info_dev + slot};
         AssignStore as{e_slot, dn.table.vals, e_node, e_batch, dn.nodes.p,
                        disjoint ? dn.batch.p : (int64_t*)nullptr, 0, 0, 1, tstate + dst};
-        rc = device_scan<int64_t, SumOp>(fl, as, Eb, ftile, &info_dev[slot].uniq, stream);
+        rc = device_scan<int64_t, SumOp>(fl, as, Eb, ftile, &info_dev[slot].uniq, stream, flag_cache);
         if (rc != PYG_HIP_OK) return rc;
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Eb + 255) / 256)), dim3(256), 0, stream, e_slot,
                            dn.table.vals, Eb, st.col.p, info_dev + slot, const_cast<HopInfo*>(info_host) + slot, chain,
@@ -3247,7 +3283,7 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
       a.e_batch = e_batch;
       a.e_eid = e_eid;
       a.e_slot = nullptr;
-      a.table = HashTable{nullptr, nullptr, 0};
+      a.table = HashTable{nullptr, nullptr, 0, 0};
       if (!weight) {
         launch_sample(a, S, stream);
       } else if (replace) {
@@ -3485,6 +3521,7 @@ static int relabel_nodes_impl(const int64_t* seed, int64_t S, int64_t seed_batch
   t.keys = reinterpret_cast<u64*>(w);
   t.vals = t.keys + 1;
   t.mask = cap - 1;
+  t.dense = 0;
   w += align_up(sizeof(u64) * 2 * cap, 256);
   u64* seed_slots = reinterpret_cast<u64*>(w);                 // [S] slots of the seeds
   int64_t* seed_copy = reinterpret_cast<int64_t*>(w) + S;       // [S] seed_insert_kernel also writes the node list

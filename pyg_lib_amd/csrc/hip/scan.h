@@ -62,10 +62,11 @@ __device__ T block_exclusive(T agg, T* lds, Op op, T* total) {
   return excl;
 }
 
-// Phase A: per-tile aggregates.
+// Phase A: per-tile aggregates.  `cache` (optional, n entries): the loaded values are kept for phase C, whose
+// Load is then not evaluated a second time (the sampler's loads are dependent random gathers).
 template <typename T, typename Op, typename Load>
 __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, int64_t n,
-                                                                   T* __restrict__ tile_agg) {
+                                                                   T* __restrict__ tile_agg, T* __restrict__ cache) {
   __shared__ T lds[8];
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(Load load, in
   T agg = Op::identity();
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
-    if (base + k < n) agg = op(agg, v[k]);
+    if (base + k < n) {
+      agg = op(agg, v[k]);
+      if (cache) cache[base + k] = v[k];
+    }
   T total;
   (void)block_exclusive<T, Op>(agg, lds, op, &total);
   if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
@@ -107,13 +111,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_spine_kernel(T* __restrict_
 template <typename T, typename Op, typename Load, typename Store, bool SELF_SPINE>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Store store, int64_t n,
                                                                   const T* __restrict__ tile_prefix,
-                                                                  T* __restrict__ total_out) {
+                                                                  T* __restrict__ total_out,
+                                                                  const T* __restrict__ cache = nullptr) {
   __shared__ T lds[8];
   Op op;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   T v[kScanItems];
+  if (cache) {
 #pragma unroll
-  for (int k = 0; k < kScanItems; ++k) v[k] = load(base + k < n ? base + k : n - 1);
+    for (int k = 0; k < kScanItems; ++k) v[k] = cache[base + k < n ? base + k : n - 1];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = load(base + k < n ? base + k : n - 1);
+  }
   T agg = Op::identity();
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
@@ -146,8 +156,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(Load load, Sto
 }
 
 // scratch: ntiles * sizeof(T) + sizeof(T) (total).  Returns device pointer to the total.
+// `cache`: optional scratch of n values of T (see scan_reduce_kernel); ignored for a single tile.
 template <typename T, typename Op, typename Load, typename Store>
-int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hipStream_t stream) {
+int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hipStream_t stream, T* cache = nullptr) {
   if (n <= 0) {
     T id = Op::identity();
     PYG_HIP_CHECK(hipMemcpyAsync(total_dev, &id, sizeof(T), hipMemcpyHostToDevice, stream));
@@ -159,17 +170,17 @@ int device_scan(Load load, Store store, int64_t n, T* tile_buf, T* total_dev, hi
                        stream, load, store, n, (const T*)nullptr, total_dev);
   } else if (ntiles <= 2048) {
     hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
-                       dim3(kScanThreads), 0, stream, load, n, tile_buf);
+                       dim3(kScanThreads), 0, stream, load, n, tile_buf, cache);
     hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store, true>), dim3((unsigned)ntiles),
-                       dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf, total_dev);
+                       dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf, total_dev, (const T*)cache);
   } else {
     hipLaunchKernelGGL((scan_reduce_kernel<T, Op, Load>), dim3((unsigned)ntiles),
-                       dim3(kScanThreads), 0, stream, load, n, tile_buf);
+                       dim3(kScanThreads), 0, stream, load, n, tile_buf, cache);
     hipLaunchKernelGGL((scan_spine_kernel<T, Op>), dim3(1), dim3(kScanThreads), 0, stream, tile_buf,
                        ntiles, total_dev);
     hipLaunchKernelGGL((scan_apply_kernel<T, Op, Load, Store, false>), dim3((unsigned)ntiles),
                        dim3(kScanThreads), 0, stream, load, store, n, (const T*)tile_buf,
-                       (T*)nullptr);
+                       (T*)nullptr, (const T*)cache);
   }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
