@@ -146,6 +146,36 @@ PYG_HIP_API int pyg_hip_segment_matmul_dw(int dtype, const void* input, const in
                                           int64_t M, int64_t B, void* workspace, size_t workspace_bytes,
                                           void* stream);
 
+/* ---- fused relational graph convolution (BASELINE config C5) -------------- */
+
+/* One relation of pyg_hip_rgcn_fused: its sampled edges e in [0, num_edges) read row
+ * gather_index[e] + gather_offset of x and add their message to row scatter_index[e] + scatter_offset of out.
+ * The index vectors are the per-relation `col` / `row` outputs of hetero_neighbor_sample, used in place. */
+typedef struct {
+  const int64_t* gather_index;  /* device */
+  const int64_t* scatter_index; /* device; runs of equal values are summed before they touch memory */
+  int64_t num_edges;
+  int64_t gather_offset;
+  int64_t scatter_offset;
+  const void* weight;           /* device, [K, M] row-major, 16-byte aligned */
+} pyg_hip_rgcn_relation;
+
+PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges);
+
+/*
+ * out[scatter_index_r[e] + scatter_offset_r] += x[gather_index_r[e] + gather_offset_r] @ weight_r  for all r, e.
+ * One launch replacing the chain gather_coo -> segment_matmul -> scatter_sum of the reference ops
+ * (pyg_lib/csrc/ops/cuda/segment_coo_kernel.cu:1316-1360, ops/cuda/matmul_kernel.cu:304-319,
+ * ops/cuda/scatter_kernel.cu:56-71): the gathered rows and the messages never exist in HBM.
+ *   x [num_x_rows, K], out [num_out_rows, M] (ACCUMULATED into: zero it for a plain aggregation), both `dtype`
+ *   (PYG_BF16 / PYG_F16) row-major; K = M = 128 (other shapes: PYG_HIP_ERR_UNSUPPORTED, the caller keeps the
+ *   three-op chain).  Messages are rounded to `dtype` once (as the chain does), runs of equal destination are
+ *   summed in fp32 and added with packed 16-bit atomics.  `relations` is a host array.  Never synchronises.
+ */
+PYG_HIP_API int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* relations,
+                                   int64_t num_relations, void* out, int64_t num_out_rows, int64_t K, int64_t M,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- neighbor_sample / hetero_neighbor_sample ---------------------------------------------- */
 
 /* Host services the sampler needs from its caller (the torch binding supplies the PyTorch

@@ -243,6 +243,51 @@ std::vector<Tensor> grouped_matmul_pool_kernel(const at::TensorList input, const
   return grouped_matmul_impl(input, other, pool);
 }
 
+// This build only: gather -> per-relation matmul -> scatter-add in one launch (csrc/hip/rgcn.hip).  `out` is
+// accumulated into and returned.
+Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, const at::TensorList scatter_index,
+                         at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
+  PYG_TRACE("pyg::rgcn_fused");
+  const size_t R = gather_index.size();
+  TORCH_CHECK(scatter_index.size() == R && gather_offset.size() == R && scatter_offset.size() == R,
+              "rgcn_fused: one gather / scatter index vector and offset per relation expected");
+  TORCH_CHECK(x.is_cuda() && weight.is_cuda() && out.is_cuda() && x.device() == weight.device() && x.device() == out.device(),
+              "rgcn_fused: tensors must live on the same HIP device");
+  TORCH_CHECK(x.dim() == 2 && out.dim() == 2 && weight.dim() == 3 && (size_t)weight.size(0) == R &&
+                  weight.size(1) == x.size(1) && weight.size(2) == out.size(1),
+              "rgcn_fused: expected x [N, K], weight [R, K, M], out [N_out, M]");
+  TORCH_CHECK(x.scalar_type() == weight.scalar_type() && x.scalar_type() == out.scalar_type(), "rgcn_fused: dtype mismatch");
+  TORCH_CHECK(out.is_contiguous(), "rgcn_fused: 'out' must be contiguous");
+  DeviceGuard guard(x.device());
+  const auto xc = x.contiguous();
+  const auto wc = weight.contiguous();
+  std::vector<pyg_hip_rgcn_relation> rels(R);
+  std::vector<Tensor> keep;
+  int64_t E = 0;
+  for (size_t r = 0; r < R; ++r) {
+    TORCH_CHECK(gather_index[r].scalar_type() == at::kLong && scatter_index[r].scalar_type() == at::kLong &&
+                    gather_index[r].dim() == 1 && gather_index[r].sizes() == scatter_index[r].sizes() &&
+                    gather_index[r].is_cuda() && scatter_index[r].is_cuda(),
+                "rgcn_fused: index vectors must be 1-D int64 device tensors of equal length");
+    auto g = gather_index[r].contiguous();
+    auto s = scatter_index[r].contiguous();
+    rels[r].gather_index = g.data_ptr<int64_t>();
+    rels[r].scatter_index = s.data_ptr<int64_t>();
+    rels[r].num_edges = g.numel();
+    rels[r].gather_offset = gather_offset[r];
+    rels[r].scatter_offset = scatter_offset[r];
+    rels[r].weight = static_cast<const char*>(wc.data_ptr()) + (int64_t)r * wc.size(1) * wc.size(2) * wc.element_size();
+    E += g.numel();
+    keep.push_back(g);
+    keep.push_back(s);
+  }
+  auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, x.options().dtype(at::kByte));
+  check_status(pyg_hip_rgcn_fused(dtype_code(x.scalar_type()), xc.data_ptr(), xc.size(0), rels.data(), (int64_t)R,
+                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), ws.data_ptr(), (size_t)ws.numel(),
+                                  current_stream(x)));
+  return out;
+}
+
 // Autograd, mirroring SegmentMatmul (pyg_lib/csrc/ops/autograd/matmul_kernel.cpp:68-111).
 static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& ptr, const Tensor& other) {
   static auto op = c10::Dispatcher::singleton()
@@ -692,6 +737,10 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   // this build only: bias as a fused epilogue
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::segment_matmul_bias(Tensor input, Tensor ptr, Tensor other, Tensor bias) -> Tensor"));
+  // this build only: fused R-GCN aggregation (gather -> per-relation matmul -> scatter-add), csrc/hip/rgcn.hip
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::rgcn_fused(Tensor x, Tensor[] gather_index, Tensor[] scatter_index, int[] gather_offset, "
+      "int[] scatter_offset, Tensor weight, Tensor(a!) out) -> Tensor(a!)"));
   // this build only: grouped_matmul writing into a caller-provided [sum rows, M] pool (sharded driver)
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::grouped_matmul_pool(Tensor[] input, Tensor[] other, Tensor(a!) pool) -> Tensor[]"));
@@ -728,6 +777,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul_pool"), TORCH_FN(grouped_matmul_pool_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused"), TORCH_FN(rgcn_fused_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::dist_neighbor_sample"), TORCH_FN(dist_neighbor_sample_kernel));
 }

@@ -1,0 +1,269 @@
+// Fused relational graph convolution over a sampled neighbourhood (BASELINE.json configs[4]):
+//
+//     out[scatter_index[e] + scatter_offset_r] += x[gather_index[e] + gather_offset_r] @ W_r      for every edge e of
+//                                                                                                 every relation r
+//
+// i.e. the reference-op chain  gather_coo (ops/cuda/segment_coo_kernel.cu:1316-1360) -> segment_matmul
+// (ops/cuda/matmul_kernel.cu:304-319) -> scatter_sum (ops/cuda/scatter_kernel.cu:56-71)  in ONE launch: neither the
+// gathered features [E, K] nor the messages [E, M] ever exist in HBM, and the per-relation index vectors are read
+// where the sampler left them (no concatenation).
+//
+// One workgroup (4 waves x 32 edges) per 128-edge tile of one relation, dispatched in tile order:
+//   * A-operand rows are GATHERED: the X tile arrives by LDS-DMA (global_load_lds_dwordx4) whose per-lane source
+//     address is x + (gather_index[e] + offset) * row_bytes + chunk * 16 -- a whole 256-byte row per 16 lanes --
+//     into the same XOR-swizzled per-wave stage the segment_matmul kernels use;
+//   * W_r is copied in its native [K][M] layout by LDS-DMA and read through ds_read_b64_tr_b16 (see
+//     mfma_rows_cyc_kernel in matmul.hip for the block permutation that keeps those reads conflict free);
+//   * epilogue = SCATTER: the 32 x 128 messages of a wave are rounded to the storage type (exactly what the
+//     unfused chain materialises), parked in the stage, and every lane walks its two columns down the 32 rows,
+//     summing runs of equal destination in fp32 -- the sampler emits a relation's edges grouped by source node, so
+//     runs are ~fan-out long and run boundaries are the same for all lanes (wave-uniform branch) -- and flushes
+//     each run with one packed atomic per lane (global_atomic_pk_add_bf16 / _f16: 64 lanes = one whole 256-byte
+//     output row per instruction).  ~E / fan-out row atomics instead of E, no index sort, no second pass.
+// Rounding: messages are rounded once to T (as in the unfused chain), run sums are exact fp32 and rounded once per
+// flush -- at least as accurate as the reference's element-by-element rounding (ops/cpu/scatter_kernel.cpp:82-110).
+#include "common.h"
+
+#include <vector>
+
+namespace pyg_hip {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void LDSV;
+
+struct RelDev {
+  const int64_t* gather_index;
+  const int64_t* scatter_index;
+  const char* weight;
+  int64_t num_edges;
+  int64_t gather_offset;
+  int64_t scatter_offset;
+};
+
+struct TileDev {
+  int32_t rel;
+  int32_t tile;  // 128-edge tile index inside the relation
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 acc) {
+  if constexpr (BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if constexpr (BF16) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+  } else {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+  }
+}
+
+template <bool BF16>
+__device__ __forceinline__ void unpack2(uint32_t v, float* a, float* b) {
+  if constexpr (BF16) {
+    *a = __builtin_bit_cast(float, v << 16);
+    *b = __builtin_bit_cast(float, v & 0xffff0000u);
+  } else {
+    *a = (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xffffu));
+    *b = (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16));
+  }
+}
+
+template <bool BF16>
+__device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
+  const uint32_t v = pack2<BF16>(a, b);
+  typedef __attribute__((address_space(1))) void GV;
+  if constexpr (BF16)
+    asm volatile("global_atomic_pk_add_bf16 %0, %1, off" ::"v"((GV*)addr), "v"(v) : "memory");
+  else
+    asm volatile("global_atomic_pk_add_f16 %0, %1, off" ::"v"((GV*)addr), "v"(v) : "memory");
+}
+
+// K = M = 128, 16-bit T
+template <bool BF16>
+__global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const TileDev* __restrict__ tiles,
+                                                        const char* __restrict__ x, char* __restrict__ out) {
+  constexpr int NT = 4, NI = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
+  const TileDev td = tiles[blockIdx.x];
+  const RelDev rel = rels[td.rel];
+  const int64_t e0 = (int64_t)td.tile * 128 + wave * 32;   // first edge of this wave inside the relation
+  const int64_t left = rel.num_edges - e0;
+  const int nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+  char* xs = smem + 32768 + wave * 8192;
+  // W: this wave's 8 blocks of 4 k-rows, 16-byte chunks permuted inside a block
+  {
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const char* wsrc = rel.weight + dma_r * 256 + dma_c * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kb = wave * 8 + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
+                                       (LDSV*)(smem + kb * 1024), 16, 0, 0);
+    }
+  }
+  // indices of this wave's edges: lane l < 32 holds edge l (rows past the end repeat the last valid edge)
+  int64_t gi = 0, si = 0;
+  if (nrows > 0) {
+    const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
+    gi = rel.gather_index[e] + rel.gather_offset;
+    si = rel.scatter_index[e] + rel.scatter_offset;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = i * 64 + lane;
+      const int r = p >> 4, cs = p & 15;
+      const int c = cs ^ (r & 15);
+      const int64_t row = __shfl(gi, r);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + row * 256 + c * 16),
+                                       (LDSV*)(xs + i * 1024), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nrows == 0) return;
+  const int q = lane & 15, grp16 = lane >> 4;
+  const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((NI * h + s) ^ (xl & 15))) * 16);
+    u32x4 wa[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + tt * 256));
+      const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + tt * 256));
+      wa[tt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma16<BF16>(wa[tt], xa, acc[tt]);
+  }
+  // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[tt][8 * j + 2 * i], acc[tt][8 * j + 2 * i + 1]);
+      const int c = 8 * h + 2 * tt + j;
+      *reinterpret_cast<u32x4*>(xs + (xl * 16 + (c ^ (xl & 15))) * 16) = pk;
+    }
+  }
+  // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row
+  const int cch = lane >> 2, cdw = lane & 3;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t cur = __shfl(si, 0);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    if (r < nrows) {
+      const int64_t d = __shfl(si, r);
+      if (d != cur) {  // wave-uniform
+        atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+        s0 = 0.f;
+        s1 = 0.f;
+        cur = d;
+      }
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
+      float a, b;
+      unpack2<BF16>(v, &a, &b);
+      s0 += a;
+      s1 += b;
+    }
+  }
+  atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+}
+
+}  // namespace
+}  // namespace pyg_hip
+
+using namespace pyg_hip;
+
+extern "C" {
+
+size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges) {
+  if (num_relations < 0) num_relations = 0;
+  if (num_edges < 0) num_edges = 0;
+  const size_t tiles = (size_t)(num_edges / 128 + num_relations + 1);
+  return align_up(sizeof(RelDev) * (size_t)std::max<int64_t>(num_relations, 1), 256) + align_up(sizeof(TileDev) * tiles, 256);
+}
+
+int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R,
+                       void* out, int64_t num_out_rows, int64_t K, int64_t M, void* workspace, size_t workspace_bytes,
+                       void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16, "rgcn_fused: bfloat16 / float16 only");
+  if (K != 128 || M != 128) return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (got %lld x %lld)", (long long)K, (long long)M);
+  PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
+  PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");
+  if (R == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
+  int64_t E = 0, tiles = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    PYG_HIP_REQUIRE(rels[r].num_edges >= 0, "rgcn_fused: negative edge count");
+    PYG_HIP_REQUIRE(rels[r].num_edges == 0 || (rels[r].gather_index && rels[r].scatter_index && rels[r].weight),
+                    "rgcn_fused: NULL tensor in relation %lld", (long long)r);
+    PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(rels[r].weight) & 15) == 0, "rgcn_fused: weights must be 16-byte aligned");
+    E += rels[r].num_edges;
+    tiles += (rels[r].num_edges + 127) / 128;
+  }
+  if (E == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(x && out, "rgcn_fused: NULL tensor");
+  PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0,
+                  "rgcn_fused: misaligned tensor");
+  PYG_HIP_REQUIRE(tiles < (1LL << 31), "rgcn_fused: too many tiles");
+  if (workspace == nullptr || workspace_bytes < pyg_hip_rgcn_fused_workspace_size(R, E))
+    return fail(PYG_HIP_ERR_WORKSPACE, "rgcn_fused: workspace of %zu bytes needed, got %zu",
+                pyg_hip_rgcn_fused_workspace_size(R, E), workspace_bytes);
+  const size_t rel_b = align_up(sizeof(RelDev) * (size_t)R, 256);
+  const size_t tile_b = align_up(sizeof(TileDev) * (size_t)tiles, 256);
+  void* staged = nullptr;
+  int rc = pinned_stage().acquire(rel_b + tile_b, &staged);
+  if (rc != PYG_HIP_OK) return rc;
+  RelDev* hr = static_cast<RelDev*>(staged);
+  TileDev* ht = reinterpret_cast<TileDev*>(static_cast<char*>(staged) + rel_b);
+  int64_t t = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    hr[r].gather_index = rels[r].gather_index;
+    hr[r].scatter_index = rels[r].scatter_index;
+    hr[r].weight = static_cast<const char*>(rels[r].weight);
+    hr[r].num_edges = rels[r].num_edges;
+    hr[r].gather_offset = rels[r].gather_offset;
+    hr[r].scatter_offset = rels[r].scatter_offset;
+    for (int64_t k = 0; k < (rels[r].num_edges + 127) / 128; ++k) ht[t++] = TileDev{(int32_t)r, (int32_t)k};
+  }
+  char* w = static_cast<char*>(workspace);
+  PYG_HIP_CHECK(hipMemcpyAsync(w, staged, rel_b + tile_b, hipMemcpyHostToDevice, stream));
+  rc = pinned_stage().commit(stream);
+  if (rc != PYG_HIP_OK) return rc;
+  const RelDev* drel = reinterpret_cast<const RelDev*>(w);
+  const TileDev* dtile = reinterpret_cast<const TileDev*>(w + rel_b);
+  constexpr int lds = 32768 + 4 * 8192;
+  if (dtype == PYG_BF16) {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&rgcn_fused_kernel<true>), lds)) return rc_;
+    hipLaunchKernelGGL((rgcn_fused_kernel<true>), dim3((unsigned)tiles), dim3(256), lds, stream, drel, dtile,
+                       static_cast<const char*>(x), static_cast<char*>(out));
+  } else {
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&rgcn_fused_kernel<false>), lds)) return rc_;
+    hipLaunchKernelGGL((rgcn_fused_kernel<false>), dim3((unsigned)tiles), dim3(256), lds, stream, drel, dtile,
+                       static_cast<const char*>(x), static_cast<char*>(out));
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+}  // extern "C"

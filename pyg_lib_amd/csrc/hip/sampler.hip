@@ -68,9 +68,32 @@ constexpr u64 kProvisional = 1ull << 62;  // values >= this are emission positio
 // latency-bound; the first version carried 5 x (int32, int32) tables and ran 3-5x longer).
 typedef u64 RngTab;
 
-__host__ __device__ inline RngTab rng_identity() { return 0x43210ull; }
-__host__ __device__ inline int64_t tab_dw(RngTab t, int u) { return (int64_t)(t >> 20) + (int64_t)((t >> (4 * u + 3)) & 1); }
-__host__ __device__ inline int tab_nb(RngTab t, int u) { return (int)((t >> (4 * u)) & 7); }
+// Almost every frontier node draws 16-bit numbers only (degree < 2^16), and c such draws in a row are described by
+// the single number c (from `u` units left: nothing fetched while c <= u, else ceil((c - u) / 4) fresh words).  Such
+// tables are kept as  kPureTab | c  and compose by ADDITION -- the count scans are latency-bound and their operator
+// sits inside 6 shuffle steps per wave scan; the packed 5-state form above is only built when a draw wider than 16
+// bits appears (a row of degree >= 2^16).
+constexpr u64 kPureTab = 1ull << 63;
+
+__host__ __device__ inline bool tab_is_pure(RngTab t) { return (t & kPureTab) != 0; }
+__host__ __device__ inline RngTab tab_pure(int64_t c) { return kPureTab | (u64)c; }
+__host__ __device__ inline RngTab rng_identity() { return kPureTab; }
+__host__ __device__ inline int64_t tab_dw(RngTab t, int u) {
+  if (tab_is_pure(t)) {
+    const int64_t c = (int64_t)(t & ~kPureTab);
+    return c <= u ? 0 : (c - u + 3) / 4;
+  }
+  return (int64_t)(t >> 20) + (int64_t)((t >> (4 * u + 3)) & 1);
+}
+__host__ __device__ inline int tab_nb(RngTab t, int u) {
+  if (tab_is_pure(t)) {
+    const int64_t c = (int64_t)(t & ~kPureTab);
+    if (c <= u) return u - (int)c;
+    const int64_t c2 = c - u;
+    return (int)(4 * ((c2 + 3) / 4) - c2);
+  }
+  return (int)((t >> (4 * u)) & 7);
+}
 
 __host__ __device__ inline RngTab tab_pack(const int64_t (&dw)[5], const int (&nb)[5]) {
   int64_t d = dw[0];
@@ -82,13 +105,31 @@ __host__ __device__ inline RngTab tab_pack(const int64_t (&dw)[5], const int (&n
   return t;
 }
 
+// packed 5-state form of any table
+__host__ __device__ inline RngTab tab_general(RngTab t) {
+  if (!tab_is_pure(t)) return t;
+  int64_t dw[5];
+  int nb[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    dw[u] = tab_dw(t, u);
+    nb[u] = tab_nb(t, u);
+  }
+  return tab_pack(dw, nb);
+}
+
 __host__ __device__ inline int need_units(u64 range) {
   // rand_engine.h:44-50: 16 bits below 2^16, 32 below 2^32, else 64
   return range < (1ull << 16) ? 1 : (range < (1ull << 32) ? 2 : 4);
 }
 
-// one more draw of n units appended to the table (only rows of degree >= 2^16 take this path)
+// one more draw of n units appended to the table (only rows of degree >= 2^16 take the general path)
 __host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
+  if (n == 1 && tab_is_pure(t)) {
+    t += 1;
+    return;
+  }
+  t = tab_general(t);
   int64_t dw[5];
   int nb[5];
 #pragma unroll
@@ -107,6 +148,9 @@ __host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
 
 // g after f
 __host__ __device__ inline RngTab rng_compose(RngTab f, RngTab g) {
+  if (tab_is_pure(f) && tab_is_pure(g)) return f + (g & ~kPureTab);
+  f = tab_general(f);
+  g = tab_general(g);
   u64 e[5];
   u64 mn = 3;
 #pragma unroll
@@ -313,22 +357,7 @@ struct CountLoad {
     }
     r.edges = count;
     if ((u64)deg < (1ull << 16)) {
-      // all draws take 16 bits: closed form
-      int64_t dwv[5];
-      int nbv[5];
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        if (count <= u) {
-          dwv[u] = 0;
-          nbv[u] = u - (int)count;
-        } else {
-          const int64_t c2 = count - u;
-          const int64_t dw = (c2 + 3) / 4;
-          dwv[u] = dw;
-          nbv[u] = (int)(4 * dw - c2);
-        }
-      }
-      r.tab = tab_pack(dwv, nbv);
+      r.tab = tab_pure(count);  // all draws take 16 bits
     } else if (replace) {
       const int n = need_units((u64)deg);
       for (int64_t j = 0; j < count; ++j) rng_push_draw(r.tab, n);
@@ -2767,10 +2796,10 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
                                  hipMemcpyDeviceToHost, stream));
     PYG_HIP_CHECK(hipStreamSynchronize(stream));
     const int64_t E = info_host[e].tot.edges;
-    const int64_t scratch_w = (replace && !single) ? (int64_t)(info_host[e].tot.tab >> 20) : 0;  // cumulative-distribution entries
+    const int64_t scratch_w = (replace && !single) ? (int64_t)((info_host[e].tot.tab & ~kPureTab) >> 20) : 0;  // cumulative-distribution entries
     // generator outputs drawn by this relation: one uniform_ value per neighbour of every drawing row, one double
     // per sampled edge (with replacement, count > 1), or one double per neighbour (single draw)
-    const int64_t W = (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)(info_host[e].tot.tab >> 20);
+    const int64_t W = (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)((info_host[e].tot.tab & ~kPureTab) >> 20);
     auto cleanup = [&]() {
       c.release(tile_buf);
       c.release(edge_off);
@@ -3250,8 +3279,8 @@ int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* s
     cumsum_host[S] = S + E;
     if (E > 0) {
       // generator outputs drawn directly: uniform_ values per neighbour, or one double per sampled edge
-      const int64_t scratch_w = (weight && replace && !single) ? (int64_t)(tot.tab >> 20) : 0;
-      const int64_t W = !weight ? 0 : (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)(tot.tab >> 20);
+      const int64_t scratch_w = (weight && replace && !single) ? (int64_t)((tot.tab & ~kPureTab) >> 20) : 0;
+      const int64_t W = !weight ? 0 : (replace && !single) ? (count > 0 ? 2 * E : 0) : (int64_t)((tot.tab & ~kPureTab) >> 20);
       if (weight) {
         if (W > 0) rc = rng_wait32(c, rng, out_base + W, nullptr);
       } else {

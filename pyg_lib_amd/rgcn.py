@@ -66,3 +66,26 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     feats = ops.gather_coo(x, gidx)                           # [E, F_in]
     msgs = ops.segment_matmul(feats, ptr, weight)              # [E, F_out]
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
+
+
+def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
+                     col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
+                     csc: bool = False) -> Tensor:
+    r"""Same result as :func:`rgcn_layer` from ONE launch (``pyg::rgcn_fused``, csrc/hip/rgcn.hip): source rows are
+    gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
+    and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
+    index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128``; anything else
+    takes the three-op chain."""
+    total = offsets['__total__']
+    if not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and weight.size(-1) == 128 and x.is_cuda):
+        return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
+    gather, scatter, goff, soff = [], [], [], []
+    for et in edge_types:
+        src, _, dst = et
+        row_t, col_t = (src, dst) if not csc else (dst, src)
+        gather.append(col_dict[et])
+        scatter.append(row_dict[et])
+        goff.append(offsets[col_t])
+        soff.append(offsets[row_t])
+    out = x.new_zeros(total, weight.size(-1))
+    return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)

@@ -79,3 +79,106 @@ def test_rgcn_layer_empty_sample():
     y = rgcn.rgcn_layer(x, rgcn.type_offsets({'a': 4}, ['a']), {ets[0]: e}, {ets[0]: e}, ets,
                         torch.randn(1, 64, 64, device='cuda'))
     assert y.shape == (4, 64) and not y.any()
+
+
+# ---- fused layer (csrc/hip/rgcn.hip) -----------------------------------------------------------------------------
+
+MAG_TYPES = ['paper', 'author', 'institution', 'field_of_study']
+MAG_ETS = [('paper', 'cites', 'paper'), ('author', 'writes', 'paper'), ('paper', 'rev_writes', 'author'),
+           ('author', 'affiliated_with', 'institution'), ('institution', 'rev_affiliated_with', 'author'),
+           ('paper', 'has_topic', 'field_of_study'), ('field_of_study', 'rev_has_topic', 'paper')]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_fused_rgcn_layer_mag_shape_matches_oracle(dtype):
+    """BASELINE config C5's shape in small: 4 node types, the 7 relations of ogbn-mag after ToUndirected, F = 128,
+    batch 1024 papers, fan-out [15, 10] -- sampled by the device sampler (checked against the oracle sampler), layer by
+    pyg::rgcn_fused, compared with a float64 restatement on the ORACLE's sample and with the three-op chain."""
+    import oracle
+    from pyg_lib_amd import sampler, rgcn
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(3)
+    sizes = {'paper': 40_000, 'author': 60_000, 'institution': 900, 'field_of_study': 4_000}
+    rp, cl = build_graph(rng, sizes, MAG_ETS, 12)
+    seeds = {'paper': rng.permutation(sizes['paper'])[:1024].astype(np.int64)}
+    fan = {e: [15, 10] for e in MAG_ETS}
+    F = 128
+    feat = {t: rng.standard_normal((sizes[t], F)).astype(np.float32) for t in MAG_TYPES}
+    W = (rng.standard_normal((len(MAG_ETS), F, F)) / np.sqrt(F)).astype(np.float32)
+
+    torch.manual_seed(9)
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                         {k: dev(v) for k, v in seeds.items()}, fan)
+    row_d, col_d, node_d = out[0], out[1], out[2]
+    ref = oracle.hetero_neighbor_sample(MAG_TYPES, MAG_ETS, rp, cl, seeds, fan, rng_seed=9)
+    for t in MAG_TYPES:
+        assert torch.equal(node_d[t].cpu(), torch.from_numpy(ref[2][t]))
+    for e in MAG_ETS:
+        assert torch.equal(row_d[e].cpu(), torch.from_numpy(ref[0][e])) and torch.equal(col_d[e].cpu(), torch.from_numpy(ref[1][e]))
+    off = rgcn.type_offsets({t: node_d[t].numel() for t in MAG_TYPES}, MAG_TYPES)
+    featd = {t: dev(feat[t]).to(dtype) for t in MAG_TYPES}
+    x = torch.cat([featd[t][node_d[t]] for t in MAG_TYPES])
+    Wd = dev(W).to(dtype)
+    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, Wd)
+    assert y.shape == (off['__total__'], F) and y.dtype == dtype
+    total_edges = sum(v.numel() for v in row_d.values())
+    assert total_edges > 100_000
+
+    xr = x.float().cpu().numpy().astype(np.float64)
+    Wr = Wd.float().cpu().numpy().astype(np.float64)
+    want = np.zeros((off['__total__'], F))
+    for i, (s, r, d) in enumerate(MAG_ETS):
+        row, col = ref[0][(s, r, d)], ref[1][(s, r, d)]
+        msg = torch.from_numpy(xr[col + off[d]] @ Wr[i]).to(dtype).double().numpy()  # messages rounded once to T
+        np.add.at(want, row + off[s], msg)
+    got = y.float().cpu().numpy().astype(np.float64)
+    scale = np.abs(want).max()
+    assert scale > 1.0
+    # every destination row is a sum of <= 15 + ... messages over <= 4 relations, each partial sum rounded once
+    assert np.abs(got - want).max() <= (2e-2 if dtype == torch.bfloat16 else 3e-3) * scale
+    touched = np.zeros(off['__total__'], bool)
+    for e in MAG_ETS:
+        touched[ref[0][e] + off[e[0]]] = True
+    assert not got[~touched].any()
+    # the three-op chain agrees to the same tolerance
+    y3 = rgcn.rgcn_layer(x, off, row_d, col_d, MAG_ETS, Wd).float().cpu().numpy()
+    assert np.abs(got - y3).max() <= (3e-2 if dtype == torch.bfloat16 else 4e-3) * scale
+
+
+def test_fused_rgcn_integer_valued_inputs_are_exact():
+    """Small integers times signed-permutation weights: every message and every partial sum is exactly representable,
+    so the fused layer must equal the float64 result bit for bit -- runs straddling tile and wave boundaries, a
+    relation with fewer than 32 edges, an empty relation, destinations shared by several relations."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(2)
+    n, F = 700, 128
+    x = torch.randint(-4, 5, (n, F), generator=g).float()
+    counts = [1000, 0, 17, 4096 + 33, 129]
+    ets = [('a', f'r{i}', 'a') for i in range(len(counts))]
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in counts])
+    W = torch.zeros(len(counts), F, F)
+    W[torch.arange(len(counts))[:, None], perm, torch.arange(F)[None, :]] = (torch.randint(0, 2, (len(counts), F), generator=g) * 2 - 1).float()
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        r = torch.sort(torch.randint(0, 60, (c,), generator=g)).values  # long runs, few destinations
+        rows[et] = r.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    y = rgcn.rgcn_layer_fused(x.bfloat16().cuda(), off, rows, cols, ets, W.bfloat16().cuda())
+    want = torch.zeros(n, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), x[cols[et].cpu()].double() @ W[i].double())
+    assert want.abs().max() <= 256  # exactly representable in bf16
+    assert torch.equal(y.double().cpu(), want)
+
+
+def test_fused_rgcn_falls_back_for_other_shapes():
+    from pyg_lib_amd import rgcn
+    ets = [('a', 'x', 'a')]
+    x = torch.randn(50, 64, device='cuda')
+    r = torch.sort(torch.randint(0, 50, (300,), device='cuda')).values
+    c = torch.randint(0, 50, (300,), device='cuda')
+    w = torch.randn(1, 64, 64, device='cuda')
+    off = rgcn.type_offsets({'a': 50}, ['a'])
+    torch.testing.assert_close(rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w),
+                               rgcn.rgcn_layer(x, off, {ets[0]: r}, {ets[0]: c}, ets, w))
