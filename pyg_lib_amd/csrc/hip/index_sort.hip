@@ -19,6 +19,12 @@
 // torch.sort(stable=True) -- for negative keys too (sign bit flipped), which the reference's radix path
 // mis-sorts.
 // HBM-bound: per pass one key read for the histogram, one key+index read and one key+index write.
+//
+// PACKED mode (non-negative keys whose significant bits plus the bits of n - 1 fit 64 -- every index vector PyG
+// sorts): key and position travel as ONE 64-bit word (key << index_bits | position) through the passes; the first
+// pass packs while it reads the keys, the last pass splits into the two output vectors.  8 instead of 16 bytes per
+// element per pass in both directions (12 -> 8 GB for 1e8 int64 keys in 3 passes), 64 KB instead of 128 KB of LDS per
+// 8192-key tile (two workgroups per CU).  Same stable order, bit-identical result.
 #include "common.h"
 #include "scan.h"
 
@@ -47,6 +53,7 @@ PYG_KEY(int8_t, uint8_t, 0x80u)
 PYG_KEY(int16_t, uint16_t, 0x8000u)
 PYG_KEY(int32_t, uint32_t, 0x80000000u)
 PYG_KEY(int64_t, uint64_t, 0x8000000000000000ull)
+PYG_KEY(uint64_t, uint64_t, 0)  // packed words
 #undef PYG_KEY
 
 template <typename K>
@@ -229,6 +236,118 @@ __global__ __launch_bounds__(kSThreads) void scatter_kernel(const K* __restrict_
   }
 }
 
+
+// Packed mode: stable scatter of one pass over 64-bit words (key << ib | position).  IN_KEYS: the input is the key
+// vector (first pass: words are formed on the fly), else words.  OUT_SPLIT: the output is (keys, indices) (last pass),
+// else words.  `shift` addresses the digit inside the WORD (ib + 8 * pass).
+template <typename K, bool IN_KEYS, bool OUT_SPLIT>
+__global__ __launch_bounds__(kSThreads) void scatter_packed_kernel(const K* __restrict__ keys_in, const uint64_t* __restrict__ words_in,
+                                                                   uint64_t* __restrict__ words_out, K* __restrict__ keys_out,
+                                                                   int64_t* __restrict__ idx_out, int64_t n, int64_t slice, int shift,
+                                                                   int ib, const int64_t* __restrict__ offsets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* swords = reinterpret_cast<uint64_t*>(smem);                   // [kTile] tile sorted by digit
+  char* rest = smem + sizeof(uint64_t) * kTile;
+  int64_t* cursor = reinterpret_cast<int64_t*>(rest);                     // [256] next output position per digit
+  unsigned* wcnt = reinterpret_cast<unsigned*>(rest + 256 * sizeof(int64_t));  // [kWaves][256]
+  unsigned* tile_pref = wcnt + kWaves * 256;                              // [256] first tile slot of a digit
+  unsigned* tile_cnt = tile_pref + 256;                                   // [256]
+  unsigned* wave_tot = tile_cnt + 256;                                    // [4]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if (tid < 256) cursor[tid] = offsets[(int64_t)tid * gridDim.x + blockIdx.x];
+  const int64_t beg = blockIdx.x * slice;
+  const int64_t end = min(beg + slice, n);
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const uint64_t imask = ib >= 64 ? ~0ull : ((1ull << ib) - 1);
+  unsigned* my_cnt = wcnt + wave * 256;
+
+  for (int64_t tile = beg; tile < end; tile += kTile) {
+    const int64_t tile_n = min((int64_t)kTile, end - tile);
+    for (int j = lane; j < 256; j += 64) my_cnt[j] = 0;
+    uint64_t word[kItems];
+    unsigned short rank[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
+      if (IN_KEYS) word[r] = i < end ? (((uint64_t)keys_in[i] << ib) | (uint64_t)i) : 0ull;
+      else word[r] = i < end ? words_in[i] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
+      const bool valid = i < end;
+      const unsigned d = valid ? (unsigned)((word[r] >> shift) & 0xff) : 0u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+      }
+      const unsigned before = my_cnt[d];
+      const unsigned in_round = (unsigned)__popcll(peers & lt_mask);
+      rank[r] = (unsigned short)(before + in_round);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && in_round == 0) my_cnt[d] = before + (unsigned)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const unsigned c = wcnt[w * 256 + tid];
+        wcnt[w * 256 + tid] = run;
+        run += c;
+      }
+      tile_cnt[tid] = run;
+      unsigned incl = run;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, dlt);
+        if (lane >= dlt) incl += up;
+      }
+      tile_pref[tid] = incl - run;
+      if (lane == 63) wave_tot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += wave_tot[w];
+      tile_pref[tid] += base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+      const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
+      if (i < end) {
+        const unsigned d = (unsigned)((word[r] >> shift) & 0xff);
+        swords[tile_pref[d] + my_cnt[d] + rank[r]] = word[r];
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < tile_n; j += kSThreads) {
+      const uint64_t wv = swords[j];
+      const unsigned d = (unsigned)((wv >> shift) & 0xff);
+      const int64_t dest = cursor[d] + (int64_t)(j - tile_pref[d]);
+      if (OUT_SPLIT) {
+        keys_out[dest] = (K)(wv >> ib);
+        idx_out[dest] = (int64_t)(wv & imask);
+      } else {
+        words_out[dest] = wv;
+      }
+    }
+    __syncthreads();
+    if (tid < 256) cursor[tid] += tile_cnt[tid];
+  }
+}
+
+constexpr size_t scatter_packed_lds_bytes() {
+  return sizeof(uint64_t) * kTile + 256 * sizeof(int64_t) + (kWaves * 256 + 512 + 4) * sizeof(unsigned);
+}
+
+// histogram of the packed FIRST pass: digits of the keys themselves (the word is key << ib | position)
 constexpr size_t scatter_lds_bytes(size_t key_size) {
   return (sizeof(int64_t) + key_size) * kTile + 16 + 256 * sizeof(int64_t) + (kWaves * 256 + 512) * sizeof(unsigned);
 }
@@ -263,8 +382,9 @@ Plan make_plan(int64_t n) {
 size_t ws_bytes(int64_t n, size_t key_size) {
   const Plan p = make_plan(n);
   size_t b = 0;
-  b += align_up((size_t)n * key_size, 256);                       // key ping-pong buffer
-  b += align_up((size_t)n * sizeof(int64_t), 256);                // index ping-pong buffer
+  (void)key_size;
+  b += align_up((size_t)n * sizeof(int64_t), 256);                // key ping-pong buffer / packed words A
+  b += align_up((size_t)n * sizeof(int64_t), 256);                // index ping-pong buffer / packed words B
   b += 2 * align_up((size_t)p.groups * 256 * sizeof(int64_t), 256);  // histograms, offsets
   b += align_up(((size_t)(p.groups * 256 + kScanTile - 1) / kScanTile + 2) * sizeof(int64_t), 256);
   b += 256;                                                       // min/max
@@ -283,7 +403,7 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
   const Plan p = make_plan(n);
   char* w = static_cast<char*>(ws);
   K* kbuf = reinterpret_cast<K*>(w);
-  w += align_up((size_t)n * sizeof(K), 256);
+  w += align_up((size_t)n * sizeof(int64_t), 256);
   int64_t* ibuf = reinterpret_cast<int64_t*>(w);
   w += align_up((size_t)n * sizeof(int64_t), 256);
   int64_t* hist = reinterpret_cast<int64_t*>(w);
@@ -296,6 +416,7 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
 
   // number of 8-bit passes (radix_sort.h:170-176: from the largest key)
   int passes;
+  bool nonneg = true;  // a caller-given max promises keys in [0, max] (the documented precondition)
   constexpr int full = (int)sizeof(K);
   if (has_max) {
     // keys are promised to lie in [0, max_value]
@@ -316,6 +437,7 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
     PYG_HIP_CHECK(hipMemcpyAsync(host_mm, mm, sizeof(host_mm), hipMemcpyDeviceToHost, stream));
     PYG_HIP_CHECK(hipStreamSynchronize(stream));  // the reference syncs here too: input.max().item()
     if (host_mm[0] < 0) {
+      nonneg = false;
       passes = full;  // negative keys: all digits matter (sign bit flipped)
     } else {
       uint64_t m = (uint64_t)host_mm[1];
@@ -325,6 +447,45 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
         m >>= 8;
       }
       passes = std::max(1, std::min(passes, full));
+    }
+  }
+  // ---- packed mode -----------------------------------------------------------------------------------------
+  // non-negative keys < 2^(8 * passes)
+  {
+    int ib = 1;
+    while (ib < 63 && (1ull << ib) < (uint64_t)n) ++ib;  // bits of the largest position n - 1
+    if (nonneg && 8 * passes + ib <= 64) {
+      uint64_t* wbuf[2] = {reinterpret_cast<uint64_t*>(kbuf), reinterpret_cast<uint64_t*>(ibuf)};
+      constexpr int plds = (int)scatter_packed_lds_bytes();
+      const uint64_t* win = nullptr;
+      for (int ps = 0; ps < passes; ++ps) {
+        const bool first = ps == 0, last = ps == passes - 1;
+        if (first)
+          hipLaunchKernelGGL((hist_kernel<K>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, keys, n, p.slice, 0, hist);
+        else
+          hipLaunchKernelGGL((hist_kernel<uint64_t>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, win, n, p.slice,
+                             ib + 8 * ps, hist);
+        PYG_HIP_CHECK(hipGetLastError());
+        const int64_t ntiles = (p.groups * 256 + kScanTile - 1) / kScanTile;
+        int rc = device_scan<int64_t, SumOp>(HistLoad{hist}, HistStore{offs}, p.groups * 256, scan_tmp, scan_tmp + ntiles, stream);
+        if (rc != PYG_HIP_OK) return rc;
+        uint64_t* wout = wbuf[ps & 1];
+        const int shift = ib + 8 * ps;
+#define PYG_PACKED(INK, OUTS)                                                                                              \
+  {                                                                                                                        \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_packed_kernel<K, INK, OUTS>), plds)) return rc_; \
+    hipLaunchKernelGGL((scatter_packed_kernel<K, INK, OUTS>), dim3((unsigned)p.groups), dim3(kSThreads), plds, stream, keys, win, \
+                       wout, keys_out, idx_out, n, p.slice, shift, ib, offs);                                              \
+  }
+        if (first && last) PYG_PACKED(true, true)
+        else if (first) PYG_PACKED(true, false)
+        else if (last) PYG_PACKED(false, true)
+        else PYG_PACKED(false, false)
+#undef PYG_PACKED
+        PYG_HIP_CHECK(hipGetLastError());
+        win = wout;
+      }
+      return PYG_HIP_OK;
     }
   }
   // With fewer than `full` passes the flipped sign bit is never looked at, which is fine: all keys are

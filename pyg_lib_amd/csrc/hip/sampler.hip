@@ -78,6 +78,9 @@ constexpr u64 kPureTab = 1ull << 63;
 __host__ __device__ inline bool tab_is_pure(RngTab t) { return (t & kPureTab) != 0; }
 __host__ __device__ inline RngTab tab_pure(int64_t c) { return kPureTab | (u64)c; }
 __host__ __device__ inline RngTab rng_identity() { return kPureTab; }
+// the identity in the packed 5-state form: the biased-sampling scans carry a plain counter in its word field
+// (identity transitions compose additively there, and tab_dw() returns that counter)
+__host__ __device__ inline RngTab rng_identity_packed() { return 0x43210ull; }
 __host__ __device__ inline int64_t tab_dw(RngTab t, int u) {
   if (tab_is_pure(t)) {
     const int64_t c = (int64_t)(t & ~kPureTab);
@@ -1152,7 +1155,7 @@ struct BiasedCountLoad {
   int outputs;  // engine outputs per draw
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
-    r.tab = rng_identity();
+    r.tab = rng_identity_packed();
     r.edges = 0;
     const int64_t v = nodes[begin + i];
     const int64_t deg = rowptr[v + 1] - rowptr[v];
@@ -1598,7 +1601,7 @@ struct BiasedReplaceCountLoad {
   int64_t count;
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
-    r.tab = rng_identity();
+    r.tab = rng_identity_packed();
     r.edges = 0;
     const int64_t v = nodes[begin + i];
     const int64_t deg = rowptr[v + 1] - rowptr[v];
@@ -1682,7 +1685,7 @@ struct BiasedSingleCountLoad {
   const int64_t* rowptr;
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
-    r.tab = rng_identity();
+    r.tab = rng_identity_packed();
     r.edges = 0;
     const int64_t v = nodes[begin + i];
     const int64_t deg = rowptr[v + 1] - rowptr[v];
