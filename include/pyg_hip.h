@@ -224,7 +224,10 @@ typedef struct {
    * takes, see pyg_hip_hetero_neighbor_sample).  Needs host->mt19937. */
   const void* edge_weight;
   int32_t edge_weight_dtype;
-  int32_t reserved;
+  /* != 0: rowptr and col point at int32 arrays (declared int64_t* for source compatibility) and are read in
+   * place; the reference's int32 instantiation (neighbor_kernel.cpp:893,930).  Seeds, times and all outputs stay
+   * int64 on this interface (they are a few thousand to a million elements; the binding converts them). */
+  int32_t index_is32;
 } pyg_hip_relation;
 
 /* Seeds of one node type, in seed_dict iteration order. */

@@ -436,8 +436,9 @@ static void check_index(const Tensor& t, const char* what) {
 }
 
 // The reference dispatches the sampler on the seeds' integral type (neighbor_kernel.cpp:893,930) and returns
-// that type.  The HIP kernels are int64: an int32 graph is widened ON THE DEVICE for the call (one copy of
-// rowptr / col / seed per call) and the results are narrowed back -- same values, same generator stream.
+// that type.  The kernels read an int32 CSR (rowptr / col, the large arrays) IN PLACE (`graph` below +
+// pyg_hip_relation::index_is32); only the seeds are widened for the call (batch-sized) and the results are
+// narrowed back -- same values, same generator stream.  dist_neighbor_sample still widens its graph.
 struct IndexArgs {
   at::ScalarType dtype = at::kLong;
   std::vector<Tensor> keep;  // widened copies stay alive until the call returns
@@ -449,6 +450,14 @@ struct IndexArgs {
     keep.push_back(t.to(at::kLong));
     return keep.back().data_ptr<int64_t>();
   }
+  // rowptr / col of the sampled graph: raw pointer of either width, no copy
+  const int64_t* graph(const Tensor& t, const char* what) const {
+    TORCH_CHECK(t.is_contiguous(), "Non-contiguous '", what, "'");
+    TORCH_CHECK(t.is_cuda(), "pyg (HIP): '", what, "' must live on a HIP device");
+    TORCH_CHECK(t.scalar_type() == dtype, "pyg (HIP): '", what, "' must have the seeds' dtype (", dtype, ")");
+    return static_cast<const int64_t*>(t.data_ptr());
+  }
+  int32_t is32() const { return dtype == at::kInt ? 1 : 0; }
   Tensor narrow(const Tensor& t) const { return dtype == at::kLong ? t : t.to(dtype); }
 };
 
@@ -557,9 +566,9 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   IndexArgs ix;
   ix.dtype = index_dtype(seed);
   std::vector<pyg_hip_relation> rels(1);
-  rels[0].rowptr = ix.ptr(rowptr, "rowptr");
+  rels[0].rowptr = ix.graph(rowptr, "rowptr");
   rels[0].num_rows = rowptr.numel() - 1;
-  rels[0].col = ix.ptr(col, "col");
+  rels[0].col = ix.graph(col, "col");
   rels[0].num_cols = col.numel();
   rels[0].src_type = 0;
   rels[0].dst_type = 0;
@@ -567,7 +576,7 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   rels[0].edge_time = edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr;
   rels[0].edge_weight = nullptr;
   rels[0].edge_weight_dtype = 0;
-  rels[0].reserved = 0;
+  rels[0].index_is32 = ix.is32();
   if (edge_weight.has_value()) set_weight(rels[0], edge_weight.value(), col.numel());
   std::vector<pyg_hip_seed_set> seeds(1);
   seeds[0].node_type = 0;
@@ -621,9 +630,9 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     L = std::max(L, fanouts[e].size());
     TORCH_CHECK(nt_index.count(std::get<0>(k)) && nt_index.count(std::get<2>(k)),
                 "hetero_neighbor_sample: edge type names an unknown node type");
-    rels[e].rowptr = ix.ptr(rowptr, "rowptr");
+    rels[e].rowptr = ix.graph(rowptr, "rowptr");
     rels[e].num_rows = rowptr.numel() - 1;
-    rels[e].col = ix.ptr(col, "col");
+    rels[e].col = ix.graph(col, "col");
     rels[e].num_cols = col.numel();
     rels[e].src_type = nt_index[std::get<0>(k)];
     rels[e].dst_type = nt_index[std::get<2>(k)];
@@ -632,7 +641,7 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
       rels[e].edge_time = time_ptr(edge_time_dict.value().at(rel), "edge_time");
     rels[e].edge_weight = nullptr;
     rels[e].edge_weight_dtype = 0;
-    rels[e].reserved = 0;
+    rels[e].index_is32 = ix.is32();
     if (edge_weight_dict.has_value() && edge_weight_dict.value().contains(rel))
       set_weight(rels[e], edge_weight_dict.value().at(rel), col.numel());
   }

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const K* __restrict__ 
 // ---- pass kernels ---------------------------------------------------------------------------------------
 // hist[d * G + g]: number of keys with digit d in the slice of workgroup g.  Equal digits inside a wave
 // are counted by ONE LDS atomic (match-any leader), so skewed digits (high bytes) do not serialise.
-template <typename K>
+// RAW (packed mode, non-negative keys): digits of the value itself, no sign-bit flip.
+template <typename K, bool RAW = false>
 __global__ __launch_bounds__(kThreads) void hist_kernel(const K* __restrict__ keys, int64_t n, int64_t slice,
                                                         int shift, int64_t* __restrict__ hist) {
   __shared__ unsigned int bins[256];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const K* __restrict__ ke
   for (int64_t i0 = beg; i0 < end; i0 += kThreads) {
     const int64_t i = i0 + threadIdx.x;
     const bool valid = i < end;
-    const unsigned d = valid ? digit_of(keys[i], shift) : 0u;
+    const unsigned d = !valid ? 0u : RAW ? (unsigned)(((uint64_t)keys[i] >> shift) & 0xff) : digit_of(keys[i], shift);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -461,9 +462,9 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
       for (int ps = 0; ps < passes; ++ps) {
         const bool first = ps == 0, last = ps == passes - 1;
         if (first)
-          hipLaunchKernelGGL((hist_kernel<K>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, keys, n, p.slice, 0, hist);
+          hipLaunchKernelGGL((hist_kernel<K, true>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, keys, n, p.slice, 0, hist);
         else
-          hipLaunchKernelGGL((hist_kernel<uint64_t>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, win, n, p.slice,
+          hipLaunchKernelGGL((hist_kernel<uint64_t, true>), dim3((unsigned)p.groups), dim3(kThreads), 0, stream, win, n, p.slice,
                              ib + 8 * ps, hist);
         PYG_HIP_CHECK(hipGetLastError());
         const int64_t ntiles = (p.groups * 256 + kScanTile - 1) / kScanTile;

@@ -296,9 +296,23 @@ __global__ void seed_time_kernel(const int64_t* __restrict__ seed, const int64_t
 // constraints of node_temporal_sample / edge_temporal_sample (neighbor_kernel.cpp:74-144):
 // upper bound on time <= seed_time (neighbourhoods are time-sorted), and for the "last" strategy
 // the `count` most recent ones.
+// CSR index array of either width (the reference dispatches on the index dtype, neighbor_kernel.cpp:893,930; an
+// int32 graph is read in place -- no widened copy of rowptr / col per call).  The width test is wave-uniform.
+struct IdxArr {
+  const void* p = nullptr;
+  int is32 = 0;
+  IdxArr() = default;
+  __host__ __device__ IdxArr(const int64_t* q) : p(q), is32(0) {}
+  __host__ __device__ IdxArr(const void* q, int narrow) : p(q), is32(narrow) {}
+  __device__ __forceinline__ int64_t operator[](int64_t i) const {
+    return is32 ? (int64_t) static_cast<const int32_t*>(p)[i] : static_cast<const int64_t*>(p)[i];
+  }
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+};
+
 struct RangeCtx {
-  const int64_t* rowptr;
-  const int64_t* col;
+  IdxArr rowptr;
+  IdxArr col;
   const int64_t* time;        // nullptr: no temporal constraint
   int edge_level;             // time indexed by edge (1) or by destination node (0)
   int last;                   // temporal_strategy == "last"
@@ -445,7 +459,7 @@ struct HopArgs {
   int64_t begin;              // frontier begin (position of frontier node 0)
   int64_t frontier;           // frontier size
   RangeCtx range;
-  const int64_t* col;
+  IdxArr col;
   int64_t count;
   int replace;
   int64_t num_batches;
@@ -1150,7 +1164,7 @@ template <> struct BiasedKey<true> {
 struct BiasedCountLoad {
   const int64_t* nodes;
   int64_t begin;
-  const int64_t* rowptr;
+  IdxArr rowptr;
   int64_t count;
   int outputs;  // engine outputs per draw
   __device__ CountAgg operator()(int64_t i) const {
@@ -1597,7 +1611,7 @@ __global__ __launch_bounds__(64) void biased_exact_kernel(BiasedArgs<typename Bi
 struct BiasedReplaceCountLoad {
   const int64_t* nodes;
   int64_t begin;
-  const int64_t* rowptr;
+  IdxArr rowptr;
   int64_t count;
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
@@ -1682,7 +1696,7 @@ __global__ __launch_bounds__(256) void biased_replace_kernel(HopArgs a, HopInfo*
 struct BiasedSingleCountLoad {
   const int64_t* nodes;
   int64_t begin;
-  const int64_t* rowptr;
+  IdxArr rowptr;
   __device__ CountAgg operator()(int64_t i) const {
     CountAgg r;
     r.tab = rng_identity_packed();
@@ -2486,8 +2500,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         CountAgg* count_cache = reinterpret_cast<CountAgg*>(carve(sizeof(CountAgg) * (size_t)Fb));
         int64_t* flag_cache = reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb));
         RangeCtx range;
-        range.rowptr = r.rowptr;
-        range.col = r.col;
+        range.rowptr = IdxArr(r.rowptr, r.index_is32);
+        range.col = IdxArr(r.col, r.index_is32);
         range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
         range.edge_level = r.edge_time ? 1 : 0;
         range.last = temporal_last;
@@ -2514,7 +2528,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         a.begin = 0;
         a.frontier = Fb;
         a.range = range;
-        a.col = r.col;
+        a.col = IdxArr(r.col, r.index_is32);
         a.count = count;
         a.replace = replace;
         a.num_batches = num_batches;
@@ -2649,7 +2663,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     a.frontier = q.F;
     q.range.batch = a.batch;  // a reserve may have moved the list (src type == dst type)
     a.range = q.range;
-    a.col = r.col;
+    a.col = IdxArr(r.col, r.index_is32);
     a.count = q.count;
     a.replace = replace;
     a.num_batches = num_batches;
@@ -2780,16 +2794,16 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     const bool single = replace && count == 1;  // at::multinomial's single-draw route
     int rc;
     if (single) {
-      BiasedSingleCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr};
+      BiasedSingleCountLoad cl{sn.nodes.p, sn.slice_b, IdxArr(r.rowptr, r.index_is32)};
       CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
       rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
     } else if (replace) {
       // the word field of the scan carries the cumulative-distribution scratch offset (in weights)
-      BiasedReplaceCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count};
+      BiasedReplaceCountLoad cl{sn.nodes.p, sn.slice_b, IdxArr(r.rowptr, r.index_is32), count};
       CountStore cs{edge_off, raw_off, flag, 0, 4, nullptr};
       rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
     } else {
-      BiasedCountLoad cl{sn.nodes.p, sn.slice_b, r.rowptr, count, outputs};
+      BiasedCountLoad cl{sn.nodes.p, sn.slice_b, IdxArr(r.rowptr, r.index_is32), count, outputs};
       CountStore cs{edge_off, raw_off, flag, out_base, 4, nullptr};
       rc = device_scan<CountAgg, CountOp>(cl, cs, F, tile_buf, &info_dev[e].tot, stream);
     }
@@ -2861,10 +2875,10 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     a.batch = disjoint ? sn.batch.p : nullptr;
     a.begin = sn.slice_b;
     a.frontier = F;
-    a.range.rowptr = r.rowptr;
-    a.range.col = r.col;
+    a.range.rowptr = IdxArr(r.rowptr, r.index_is32);
+    a.range.col = IdxArr(r.col, r.index_is32);
     a.range.time = nullptr;
-    a.col = r.col;
+    a.col = IdxArr(r.col, r.index_is32);
     a.count = count;
     a.replace = 0;
     a.num_batches = num_batches;
@@ -2992,8 +3006,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
           PYG_ALLOC(q.rng_word, int64_t*, c, sizeof(int64_t) * (size_t)F);
           PYG_ALLOC(q.rng_units, int32_t*, c, sizeof(int32_t) * (size_t)F);
           // edge-level time wins over node-level time of the destination type (neighbor_kernel.cpp:746-789)
-          q.range.rowptr = r.rowptr;
-          q.range.col = r.col;
+          q.range.rowptr = IdxArr(r.rowptr, r.index_is32);
+          q.range.col = IdxArr(r.col, r.index_is32);
           q.range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst] : nullptr);
           q.range.edge_level = r.edge_time ? 1 : 0;
           q.range.last = temporal_last;
