@@ -6,8 +6,10 @@
 // reference's wording, output allocation through the caching allocator, the current HIP stream,
 // the global CPU generator for the sampler's random words, and autograd glue.
 //
-// There is deliberately no CPU registration: a CPU tensor reaches the dispatcher's own
-// "could not run ... with arguments from the 'CPU' backend" error instead of a silent fallback.
+// CPU tensors: the samplers, segment/grouped_matmul and index_sort have their own CPU kernels
+// (pyg_binding_cpu.cpp, dispatch key `CPU`); every other op of this library is device-only and a CPU tensor
+// reaches the dispatcher's "could not run ... with arguments from the 'CPU' backend" error.  A device tensor
+// never takes a CPU path: there is no fallback of any kind.
 #include <ATen/ATen.h>
 #include <ATen/CPUGeneratorImpl.h>
 #include <ATen/core/dispatch/Dispatcher.h>
@@ -300,6 +302,7 @@ static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& p
 static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, const Tensor& other) {
   PYG_TRACE("pyg::segment_matmul_backward_dw");
   const auto st = input.scalar_type();
+  if (!input.is_cuda()) return Tensor();  // CPU tensors: the reference formula below
   if (st != at::kBFloat16 && st != at::kHalf && st != at::kFloat) return Tensor();
   const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
   if (!(K == 64 || K == 128 || K == 256) || M % 64 != 0 || B == 0) return Tensor();
@@ -594,6 +597,21 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
                          out.nodes_per_hop[0], out.edges_per_hop[0]);
 }
 
+// pyg_binding_cpu.cpp
+std::tuple<c10::Dict<std::string, Tensor>, c10::Dict<std::string, Tensor>, c10::Dict<std::string, Tensor>,
+           c10::optional<c10::Dict<std::string, Tensor>>, c10::Dict<std::string, std::vector<int64_t>>,
+           c10::Dict<std::string, std::vector<int64_t>>>
+hetero_neighbor_sample_on_cpu(const std::vector<std::string>& node_types,
+                              const std::vector<std::tuple<std::string, std::string, std::string>>& edge_types,
+                              const c10::Dict<std::string, Tensor>& rowptr_dict, const c10::Dict<std::string, Tensor>& col_dict,
+                              const c10::Dict<std::string, Tensor>& seed_dict,
+                              const c10::Dict<std::string, std::vector<int64_t>>& num_neighbors_dict,
+                              const c10::optional<c10::Dict<std::string, Tensor>>& node_time_dict,
+                              const c10::optional<c10::Dict<std::string, Tensor>>& edge_time_dict,
+                              const c10::optional<c10::Dict<std::string, Tensor>>& seed_time_dict,
+                              const c10::optional<c10::Dict<std::string, Tensor>>& edge_weight_dict, bool csc, bool replace,
+                              bool directed, bool disjoint, std::string temporal_strategy, bool return_edge_id);
+
 std::tuple<c10::Dict<rel_type, Tensor>, c10::Dict<rel_type, Tensor>, c10::Dict<node_type, Tensor>,
            c10::optional<c10::Dict<rel_type, Tensor>>, c10::Dict<node_type, std::vector<int64_t>>,
            c10::Dict<rel_type, std::vector<int64_t>>>
@@ -608,6 +626,17 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
                               const c10::optional<c10::Dict<rel_type, Tensor>>& edge_weight_dict, bool csc,
                               bool replace, bool directed, bool disjoint, std::string temporal_strategy,
                               bool return_edge_id) {
+  // BackendSelect: tensors inside Dicts cannot drive dispatch (sampler/cpu/neighbor_kernel.cpp:985-991) -- a graph
+  // held in CPU tensors goes to the CPU kernel, a device graph to the HIP sampler
+  {
+    bool on_device = false;
+    for (const auto& kv : rowptr_dict) on_device = on_device || kv.value().is_cuda();
+    for (const auto& kv : seed_dict) on_device = on_device || kv.value().is_cuda();
+    if (!on_device)
+      return hetero_neighbor_sample_on_cpu(node_types, edge_types, rowptr_dict, col_dict, seed_dict, num_neighbors_dict,
+                                           node_time_dict, edge_time_dict, seed_time_dict, edge_weight_dict, csc, replace,
+                                           directed, disjoint, temporal_strategy, return_edge_id);
+  }
   PYG_TRACE("pyg::hetero_neighbor_sample");
   check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), seed_time_dict.has_value(),
               edge_weight_dict.has_value(), directed, disjoint, temporal_strategy);

@@ -44,13 +44,15 @@ def test_dtype_codes_match_between_header_oracle_and_python():
     assert codes['PYG_I64'] == _capi.DTYPES[torch.int64]
 
 
-def test_product_has_no_cpu_fallback():
+def test_device_only_ops_refuse_cpu_tensors():
     import torch
     import pyg_lib_amd
-    x = torch.randn(8, 16)
-    # no CPU kernel is registered: the dispatcher itself refuses (NotImplementedError is a RuntimeError)
+    # samplers / matmul / index_sort have their own CPU kernels (tests/test_cpu_key.py); every other op is device-only
+    # and the dispatcher itself refuses a CPU tensor (NotImplementedError is a RuntimeError): nothing falls back
     with pytest.raises(RuntimeError, match="'CPU' backend"):
-        pyg_lib_amd.ops.segment_matmul(x, torch.tensor([0, 5, 8]), torch.randn(2, 16, 32))
+        pyg_lib_amd.ops.scatter_sum(torch.randn(8, 16), torch.zeros(8, dtype=torch.long), dim=0)
+    with pytest.raises(RuntimeError, match="'CPU' backend"):
+        pyg_lib_amd.ops.segment_sum_csr(torch.randn(8, 16), torch.tensor([0, 5, 8]))
 
 
 def test_product_never_imports_the_oracle():
