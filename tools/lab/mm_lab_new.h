@@ -569,6 +569,177 @@ __global__ __launch_bounds__(256) void v4_kernel(const TileRec* __restrict__ rec
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v5: v3 with SIXTEEN waves of 16 rows (1024 threads, 256-row workgroup tiles, one workgroup per CU):
+//     twice as many independent 4 KiB load / store streams per CU -- what the copy proxies say a badly placed
+//     buffer needs -- v_mfma_f32_16x16x32_bf16, W double buffered + LDS-DMA + transposing reads as in v3.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int FLAGS, int DBG>
+__global__ __launch_bounds__(1024) void v5_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B) {
+  constexpr bool NT_LOAD = (FLAGS & 1) != 0;
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int NWV = 16, BM = NWV * 16;
+  constexpr int WB = K * MC * 2;
+  constexpr int BLK_PER_WAVE = (K / 4) / NWV;  // 2
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, g4 = lane >> 4;
+  const int bx = blockIdx.x, G = gridDim.x;
+  char* stage = smem + 2 * WB + wave * 4096;
+  const int total = tile_start[B];
+  if (bx >= total) return;
+  const int nloc = (total - 1 - bx) / G + 1;
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= bx) lo = mid; else hi = mid;
+  }
+  int g = lo;
+  const int pix = (x + 12) & 15;  // row permutation of the stage swizzle (see the service groups of ds_read_b128)
+  // W DMA: LDS position i of a 1 KiB block (4 k-rows): line u = i >> 4, slot v = i & 15 holds row v >> 2, chunk 4 (v & 3) + u
+  const int dma_src_off = ((lane & 15) >> 2) * 256 + (4 * (lane & 3) + (lane >> 4)) * 16;
+  auto issue_w = [&](int grp_id, int buf) {
+    const char* w = descs[grp_id].w;
+#pragma unroll
+    for (int j = 0; j < BLK_PER_WAVE; ++j) {
+      const int kb = wave * BLK_PER_WAVE + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                       (LDSV*)(smem + buf * WB + kb * 1024), 16, 0, 0);
+    }
+  };
+  auto next_group = [&](int gc) -> int {
+    const int ts = tile_start[gc + 1];
+    if (ts >= total) return -1;
+    const int j = ts > bx ? (ts - bx + G - 1) / G : 0;
+    const int t = bx + j * G;
+    if (t >= total) return -1;
+    int gg = gc + 1;
+    while (tile_start[gg + 1] <= t) ++gg;
+    return gg;
+  };
+  const int a_lane_off = 8192 * g4 + 16 * x;
+
+  u32x4 xr[4];
+  DevGroup dn = descs[g];
+  int64_t n_row0 = 0, n_rows = 0;
+  bool n_valid = false;
+  auto prefetch = [&](int ti) {
+    const int t = bx + ti * G;
+    while (t >= tile_start[g + 1]) {
+      ++g;
+      dn = descs[g];
+    }
+    n_rows = dn.rows;
+    n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 16;
+    n_valid = n_row0 < n_rows;
+    if (n_valid) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p >> 4, cs = p & 15;
+        const int c = cs ^ ((r + 12) & 15);
+        int64_t row = n_row0 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        const GU32x4* src = (const GU32x4*)(dn.a + row * 256 + c * 16);
+        xr[i] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+  int wcur = g, wbuf = 0;
+  issue_w(wcur, 0);
+  int wnext = next_group(wcur);
+  if (wnext >= 0) issue_w(wnext, 1);
+  prefetch(0);
+  DevGroup d = dn;
+  int cg = g;
+  int64_t row0 = n_row0, rows = n_rows;
+  bool valid = n_valid;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+  }
+  if (1 < nloc) prefetch(1);
+
+  for (int t = 0; t < nloc; ++t) {
+    u32x4 ov[4];
+    if (valid) {
+      f32x4 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* wb = smem + wbuf * WB + a_lane_off;
+      if (!(DBG & 1)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * 16 + ((4 * g4 + s) ^ pix)) * 16);
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb) {
+            const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4i16*)(wb + 2048 * s + 256 * (cb >> 1) + 8 * (cb & 1)));
+            const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4i16*)(wb + 2048 * s + 1024 + 256 * (cb >> 1) + 8 * (cb & 1)));
+            const bf16x8 wa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, xa), acc[cb], 0, 0, 0);
+          }
+        }
+      } else {
+        acc[0][0] = __builtin_bit_cast(float, *reinterpret_cast<const uint32_t*>(stage + lane * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[2 * j][i];
+          v[4 + i] = acc[2 * j + 1][i];
+        }
+        *reinterpret_cast<u32x4*>(stage + (x * 16 + ((4 * g4 + j) ^ pix)) * 16) = pack8(v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+    }
+    const DevGroup d_out = d;
+    const int64_t row0_out = row0, rows_out = rows;
+    const bool valid_out = valid;
+    if (t + 1 < nloc) {
+      d = dn;
+      cg = g;
+      row0 = n_row0;
+      rows = n_rows;
+      valid = n_valid;
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
+      }
+      if (cg != wcur) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        wcur = cg;
+        wbuf ^= 1;
+        wnext = next_group(wcur);
+        if (wnext >= 0) issue_w(wnext, wbuf ^ 1);
+      }
+      if (t + 2 < nloc) prefetch(t + 2);
+    }
+    if (valid_out) {
+      char* obase = d_out.c + row0_out * 256;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p >> 4, cs = p & 15;
+        const int c = cs ^ ((r + 12) & 15);
+        if (row0_out + r < rows_out) {
+          GU32x4* dst = (GU32x4*)(obase + (int64_t)r * 256 + c * 16);
+          if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+        }
+      }
+    }
+  }
+}
+
 static bool run_new(const Ctx& c, const std::string& spec, const std::string& name, std::map<std::string, int>& o) {
   auto opt = [&](const char* k, int dflt) { return o.count(k) ? o[k] : dflt; };
 
@@ -705,6 +876,35 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     V4_CASE(3, 0) V4_CASE(2, 0) V4_CASE(1, 0) V4_CASE(0, 0) V4_CASE(3, 1)
 #undef V4_CASE
     if (!done && g_round == 0) printf("%s: no such v4 variant\n", spec.c_str());
+    return true;
+  }
+
+  if (name == "v5") {
+    const int flags = opt("flags", 3), dbg = opt("dbg", 0);
+    std::vector<int32_t> ht(c.B + 1);
+    long tiles = 0;
+    for (int b = 0; b < c.B; ++b) {
+      ht[b] = (int32_t)tiles;
+      tiles += (c.ptr[b + 1] - c.ptr[b] + 255) / 256;
+    }
+    ht[c.B] = (int32_t)tiles;
+    static int32_t* dt = nullptr;
+    if (!dt) {
+      CK(hipMalloc(&dt, (c.B + 1) * 4));
+      CK(hipMemcpy(dt, ht.data(), (c.B + 1) * 4, hipMemcpyHostToDevice));
+    }
+    const int lds = 2 * 32768 + 16 * 4096;
+    const int grid = c.cus;
+    bool done = false;
+#define V5_CASE(F, D)                                                                                          \
+  if (flags == F && dbg == D) {                                                                                \
+    CK(hipFuncSetAttribute((const void*)&v5_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));   \
+    bench(c, spec, [&] { hipLaunchKernelGGL((v5_kernel<F, D>), dim3(grid), dim3(1024), lds, 0, c.descs, dt, c.B); }); \
+    done = true;                                                                                               \
+  }
+    V5_CASE(3, 0) V5_CASE(0, 0) V5_CASE(3, 1)
+#undef V5_CASE
+    if (!done && g_round == 0) printf("%s: no such v5 variant\n", spec.c_str());
     return true;
   }
   if (name == "rw") {
