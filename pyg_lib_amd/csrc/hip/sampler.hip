@@ -23,6 +23,7 @@
 // Everything per hop is HBM/latency-bound integer work: 8-byte gathers of col[], 16-byte hash
 // slots, coalesced row/col/edge-id streams.
 #include "common.h"
+#include "sampler_rng.h"
 #include "scan.h"
 
 #include <string.h>
@@ -33,6 +34,8 @@
 
 namespace pyg_hip {
 namespace {
+
+using namespace sampler;
 
 // PYG_HIP_SAMPLER_TRACE=1 prints host wall time per phase of a sampler call (diagnostics only).
 struct PhaseTimer {
@@ -55,7 +58,6 @@ struct PhaseTimer {
   }
 };
 
-typedef unsigned long long u64;
 constexpr u64 kEmpty = ~0ull;           // empty hash key / unset value (memset 0xFF)
 constexpr u64 kProvisional = 1ull << 62;  // values >= this are emission positions, below: final ids
 
@@ -245,14 +247,6 @@ __global__ void rehash_kernel(HashTable oldt, HashTable newt) {
   }
 }
 
-// Device-resident engine position and per-node-type list sizes: the relations of a hop are queued
-// back to back (each one starts where the previous one ended) and the host reads the results of the
-// whole hop with ONE synchronisation.
-struct ChainState {
-  int64_t word;   // engine position: linear word index
-  int32_t units;  //                  16-bit units left in that word
-  int32_t abort;  // sticky: a relation of this hop lacked random words -> everything after it is a no-op
-};
 struct TypeState {
   int64_t size;      // length of the node list of this type
   int64_t distinct;  // Mapper::curr
@@ -401,11 +395,6 @@ struct CountStore {
   }
 };
 
-// tempered engine output o of the device-generated stream (mt_emit's layout: little-endian u64 words, even
-// output = high half with bit 63 flipped)
-__device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ out32, int64_t o) {
-  return (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
-}
 
 // Where the engine's 128-word blocks lie in the generated stream.  Normally block b = outputs [256 b, 256 b + 256);
 // when weighted (biased) relations of the same call have drawn `shift` outputs straight from the generator
@@ -800,1023 +789,9 @@ void launch_sample(const HopArgs& a, int64_t F, hipStream_t stream) {
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, a);
 }
 
-// ---- device-side mt19937 (continues the caller's CPU engine) ---------------------------------------
-// The reference draws its words with at::randint / Tensor.random_ on torch's CPU generator, i.e.
-// at::mt19937 (ATen/core/MT19937RNGEngine.h) + random64() = (hi << 32 | lo) of two consecutive
-// outputs + `% (2^64 - 1) + INT64_MIN` (ATen/core/DistributionsHelper.h:40-56).  Generating the
-// ~2e5 words of a products-scale batch on the host costs more than all sampling kernels together, so
-// the engine state (624 words + left/next) is handed to the device as a kernel argument, the device
-// continues the very same stream, and the advanced engine is handed back to the caller afterwards.
-//
-// Stream coordinates of one call: output o = 0, 1, 2, ... counted from the engine position at call
-// start.  The engine's current array A_0 still holds a0 = left - 1 outputs (o < a0 reads
-// state[next + o]); array A_j (j >= 1, the j-th mt19937_engine::next_state()) covers
-// o in [a0 + 624 (j-1), a0 + 624 j).  Output 2k is the HIGH half of 64-bit word k
-// (CPUGeneratorImpl::random64), INT64_MIN is folded in by flipping bit 63; the words are stored
-// un-reduced (see RngCursor::next), so the raw engine values can be recovered from them.
-struct MtDev {
-  uint32_t state[624];
-  int32_t left;
-  uint32_t next;
-};
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
-}
-
-__device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
-  y ^= y >> 18;
-  y ^= (y << 15) & 0xefc60000u;
-  uint32_t t = y;  // invert y ^= (y << 7) & B: 7 known low bits grow by 7 per round
-  for (int i = 0; i < 4; ++i) t = y ^ ((t << 7) & 0x9d2c5680u);
-  y = t;
-  t = y;           // invert y ^= y >> 11
-  for (int i = 0; i < 2; ++i) t = y ^ (t >> 11);
-  return t;
-}
-
-__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
-  return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
-}
-
-// mt19937_engine::next_state() is the linear recurrence x[n] = x[n-227] ^ T(x[n-624], x[n-623])
-// (T = twist) evaluated in place one 624-array at a time.  Substituting x[n-227] once more gives
-//     x[n] = x[n-454] ^ T(x[n-851], x[n-850]) ^ T(x[n-624], x[n-623]),
-// whose newest operand lies 454 positions back: 454 new values per step (one per thread), the
-// same numbers in the same order, 2.7x fewer dependent steps than array-at-a-time.  x[n-454] is the
-// value the same thread produced one step earlier (a register); the others come from a 2048-word
-// circular LDS window.  A generating workgroup is issue/latency-bound on one CU, so the step barrier
-// only waits for LDS (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads() would also drain the global
-// stores.
-//
-// One serial recurrence is still the critical path of a sampling call (0.33 ms for a C3 batch), so the
-// stream is generated by MANY workgroups: it is linear over GF(2), and with g_J = x^J mod phi (phi = the
-// generator's characteristic polynomial, mt_jump.hip)
-//       r[1 + J + w] = XOR_{i : bit i of g_J set} r[1 + i + w],
-// i.e. the 624-word window that starts segment k (J = k * kMtSeg raw values further on) is an XOR of
-// windows of the first 19937 + 624 values.  A round is three launches on the side stream:
-//   1. mt_prefix_kernel : one workgroup generates segment 0 (which contains those 20561 values),
-//   2. mt_jump_kernel   : (K-1) x 16 workgroups XOR the start windows of segments 1 .. K-1 together,
-//   3. mt_segment_kernel: K-1 workgroups generate their segments concurrently.
-// Raw coordinates of a round: r[0..623] = the base window (the engine's array, or the last 624 values
-// of the previous round); raw position t is engine output o_r0 + t.  Rounds run speculatively ahead of
-// the sampling kernels (the exact consumption of a hop is only known after its count scan); `stop`
-// (pinned host memory) lets the host cancel what nobody will read.
-constexpr int kMtThreads = 512;
-constexpr int kMtStep = 454;
-constexpr int kMtJumpParts = 16;
-
-__device__ __forceinline__ void mt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// little-endian u64: even output = high half (+ INT64_MIN), odd output = low half
-__device__ __forceinline__ void mt_emit(uint32_t* __restrict__ out32, int64_t o, uint32_t raw) {
-  const uint32_t y = mt_temper(raw);
-  if ((o & 1) == 0) out32[o + 1] = y ^ 0x80000000u;
-  else out32[o - 1] = y;
-}
-__device__ __forceinline__ uint32_t mt_raw_at(const uint32_t* __restrict__ out32, int64_t o) {
-  const uint32_t y = (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
-  return mt_untemper(y);
-}
-
-// Generates raw positions [t0, t1) of a stream whose previous 624 values sit in x[] (position t at slot
-// t & 2047, x[2048] mirrors x[0] so that operand pairs are adjacent: one ds_read2_b32 each), emitting
-// output o_r0 + t for each.  Returns false when cancelled.
-__device__ __forceinline__ bool mt_run(uint32_t* x, int* stop_s, uint32_t t0, uint32_t t1,
-                                       uint32_t* __restrict__ out32, int64_t o_r0, const int* stop) {
-  const int tid = threadIdx.x;
-  auto put = [&](uint32_t slot, uint32_t v) {
-    x[slot] = v;
-    if (slot == 0) x[2048] = v;
-  };
-  // two plain steps of 227: history grows to 1078 values
-  uint32_t n0 = t0;
-  for (int k = 0; k < 2; ++k, n0 += 227) {
-    const uint32_t n = n0 + tid;
-    if (tid < 227 && n < t1) {
-      const uint32_t v = x[(n - 227) & 2047] ^ mt_twist(x[(n - 624) & 2047], x[(n - 623) & 2047]);
-      put(n & 2047, v);
-      mt_emit(out32, o_r0 + n, v);
-    }
-    mt_lds_barrier();
-  }
-  // main loop: the step is even, so each thread keeps its slot arithmetic, output parity and pointer
-  uint32_t slot = (n0 + tid) & 2047;
-  uint32_t prev = x[(slot + 2048 - kMtStep) & 2047];  // x[n - 454] of this thread's element
-  const int64_t o_mine = o_r0 + n0 + tid;
-  const uint32_t odd = (uint32_t)(o_mine & 1);
-  const uint32_t flip = odd ? 0u : 0x80000000u;
-  uint32_t* op = out32 + (o_mine + 1 - 2 * (int64_t)odd);
-  int step = 0;
-  for (; n0 < t1; n0 += kMtStep, ++step) {
-    if ((step & 63) == 63) {
-      if (tid == 0) *stop_s = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __syncthreads();
-      if (*stop_s) return false;  // cancelled: nothing past the consumed words is ever read
-    }
-    const uint32_t left = t1 - n0;
-    const uint32_t lim = left < (uint32_t)kMtStep ? left : (uint32_t)kMtStep;
-    if ((uint32_t)tid < lim) {
-      const uint32_t s1 = (slot + (2048 - 851)) & 2047;
-      const uint32_t s2 = (slot + (2048 - 624)) & 2047;
-      const uint32_t v = prev ^ mt_twist(x[s1], x[s1 + 1]) ^ mt_twist(x[s2], x[s2 + 1]);
-      put(slot, v);  // slot of x[n - 2048]: no longer needed by this or any later step
-      prev = v;
-      *op = mt_temper(v) ^ flip;
-    }
-    slot = (slot + kMtStep) & 2047;
-    op += kMtStep;
-    mt_lds_barrier();
-  }
-  return true;
-}
-
-// Segment 0 of a round: base window from `init` (first round: the caller's engine) or `window`; keeps a
-// raw copy of the base window for the jump kernel, emits the outputs the base window still owes
-// (first round) and generates `count` values.  `window_out`: where to leave the last 624 raw values.
-__global__ __launch_bounds__(kMtThreads) void mt_prefix_kernel(const MtDev init, int use_init,
-                                                               const uint32_t* __restrict__ window,
-                                                               uint32_t* __restrict__ base_raw,
-                                                               uint32_t* __restrict__ out32, int64_t o_r0,
-                                                               uint32_t count, uint32_t* __restrict__ window_out,
-                                                               const int* stop) {
-  __shared__ uint32_t x[2048 + 1];
-  __shared__ int stop_s;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 624; i += kMtThreads) {
-    const uint32_t v = use_init ? init.state[i] : window[i];
-    x[i] = v;
-    if (i == 0) x[2048] = v;
-    base_raw[i] = v;
-  }
-  __syncthreads();
-  if (use_init)  // outputs still held by the caller's current array: raw position t is output o_r0 + t >= 0
-    for (int t = tid; t < 624; t += kMtThreads)
-      if (o_r0 + t >= 0) mt_emit(out32, o_r0 + t, x[t]);
-  if (!mt_run(x, &stop_s, 624, 624 + count, out32, o_r0, stop)) return;
-  if (window_out)
-    for (int i = tid; i < 624; i += kMtThreads) window_out[i] = x[(count + i) & 2047];
-}
-
-struct MtJumpLists {
-  const uint16_t* idx[kMtMaxSeg];
-  int count[kMtMaxSeg];
-};
-
-// windows[k-1][w] ^= XOR over this workgroup's share of the set coefficients i of g_k of r[1 + i + w]
-__global__ __launch_bounds__(256) void mt_jump_kernel(const uint32_t* __restrict__ base_raw,
-                                                      const uint32_t* __restrict__ out32, int64_t o_r0,
-                                                      MtJumpLists lists, uint32_t* __restrict__ windows) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t r_lds[];
-  const int k = blockIdx.x + 1;
-  const uint16_t* idx = lists.idx[k];
-  const int n = lists.count[k];
-  const int j0 = (int)((int64_t)blockIdx.y * n / kMtJumpParts);
-  const int j1 = (int)((int64_t)(blockIdx.y + 1) * n / kMtJumpParts);
-  if (j0 >= j1) return;
-  const int imin = idx[j0], imax = idx[j1 - 1];
-  const int span = imax - imin + 624;  // raw positions 1 + imin .. 1 + imax + 623
-  // this share of the coefficient list sits behind the raw values in LDS (a dependent global load per
-  // term would cost ~0.2 us each)
-  uint16_t* off_lds = reinterpret_cast<uint16_t*>(r_lds + ((span + 3) & ~3));
-  for (int p = threadIdx.x; p < span; p += 256) {
-    const int t = 1 + imin + p;
-    r_lds[p] = t < 624 ? base_raw[t] : mt_raw_at(out32, o_r0 + t);
-  }
-  for (int j = j0 + threadIdx.x; j < j1; j += 256) off_lds[j - j0] = (uint16_t)(idx[j] - imin);
-  __syncthreads();
-  uint32_t acc[3] = {0u, 0u, 0u};
-  const int w0 = threadIdx.x, w1 = threadIdx.x + 256, w2 = threadIdx.x + 512;
-  const bool has2 = w2 < 624;
-  // 8 terms per round: one 16-byte read of offsets, then 24 independent LDS reads in flight
-  const int nterms = j1 - j0;
-  int j = 0;
-  for (; j + 8 <= nterms; j += 8) {
-    const uint4 o4 = *reinterpret_cast<const uint4*>(off_lds + j);
-    const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
-    uint32_t v0[8], v1[8], v2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int off = (int)((ow[q >> 1] >> (16 * (q & 1))) & 0xffffu);
-      v0[q] = r_lds[off + w0];
-      v1[q] = r_lds[off + w1];
-      v2[q] = has2 ? r_lds[off + w2] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      acc[0] ^= v0[q];
-      acc[1] ^= v1[q];
-      acc[2] ^= v2[q];
-    }
-  }
-  for (; j < nterms; ++j) {
-    const int off = off_lds[j];
-    acc[0] ^= r_lds[off + w0];
-    acc[1] ^= r_lds[off + w1];
-    if (has2) acc[2] ^= r_lds[off + w2];
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int w = threadIdx.x + 256 * q;
-    if (w < 624) atomicXor(&windows[(k - 1) * 624 + w], acc[q]);
-  }
-}
-
-// Segments 1 .. K-1: workgroup b continues from windows[b] = r[1 + k seg .. 1 + k seg + 623], k = b + 1.
-__global__ __launch_bounds__(kMtThreads) void mt_segment_kernel(const uint32_t* __restrict__ windows,
-                                                                uint32_t* __restrict__ out32, int64_t o_r0,
-                                                                uint32_t unit, uint32_t stride, uint32_t* __restrict__ window_out,
-                                                                const int* stop) {
-  __shared__ uint32_t x[2048 + 1];
-  __shared__ int stop_s;
-  const int tid = threadIdx.x;
-  // workgroup b continues from the window of raw position 1 + (1 + b * stride) * unit and generates stride * unit
-  // values (stride == 1: the segments k = 1, 2, ... of `unit` values each)
-  const uint32_t k = 1 + blockIdx.x * stride;
-  const uint32_t seg = stride * unit;
-  const uint32_t tk = 1 + k * unit;  // raw position of the window's first value
-  for (int i = tid; i < 624; i += kMtThreads) {
-    const uint32_t slot = (tk + i) & 2047;
-    const uint32_t v = windows[blockIdx.x * 624 + i];
-    x[slot] = v;
-    if (slot == 0) x[2048] = v;
-  }
-  __syncthreads();
-  if (!mt_run(x, &stop_s, tk + 624, tk + 624 + seg, out32, o_r0, stop)) return;
-  if (window_out && blockIdx.x == gridDim.x - 1)
-    for (int i = tid; i < 624; i += kMtThreads) window_out[i] = x[(tk + seg + i) & 2047];
-}
-
-// Engine state after consuming n32 > a0 outputs: the array that holds the last consumed output, fully
-// regenerated, with torch's left/next bookkeeping -- rebuilt from the stored words by un-tempering.
-__global__ __launch_bounds__(256) void mt_finish_kernel(const uint32_t* __restrict__ out32, int64_t a0, int64_t n32,
-                                                        MtDev* __restrict__ st) {
-  const int64_t mp = n32 - a0;          // outputs taken from regenerated arrays
-  const int64_t k = (mp + 623) / 624;   // index of the final array
-  const int64_t o0 = a0 + 624 * (k - 1);
-  for (int i = threadIdx.x; i < 624; i += 256) {
-    const int64_t o = o0 + i;
-    const uint32_t y = (o & 1) == 0 ? (out32[o + 1] ^ 0x80000000u) : out32[o - 1];
-    st->state[i] = mt_untemper(y);
-  }
-  if (threadIdx.x == 0) {
-    const int64_t nx = mp - 624 * (k - 1);
-    st->next = (uint32_t)nx;
-    st->left = (int32_t)(625 - nx);
-  }
-}
-
-// The same, queued BEHIND the last hop without the host in between (fully queued mode): the number of
-// consumed blocks comes from the device-resident engine position.  status: 0 = state written; 1 = the final
-// 624-array is not fully generated yet; 2 = the position is still inside the caller's own array (the host
-// adjusts left / next itself).  The host cross-checks n32 against its own bookkeeping before trusting it.
-struct MtHandBack {
-  MtDev st;
-  int64_t n32;
-  int32_t status;
-  int32_t pad;
-};
-__global__ __launch_bounds__(256) void mt_finish_chain_kernel(const uint32_t* __restrict__ out32, int64_t a0,
-                                                              const ChainState* __restrict__ chain, int64_t generated32,
-                                                              MtHandBack* __restrict__ hb) {
-  const int64_t n32 = (chain->word / 128 + 1) * 256;
-  int status = 0;
-  const int64_t mp = n32 - a0;
-  const int64_t k = (mp + 623) / 624;
-  if (n32 <= a0) status = 2;
-  else if (a0 + 624 * k > generated32) status = 1;
-  if (status == 0) {
-    const int64_t o0 = a0 + 624 * (k - 1);
-    for (int i = threadIdx.x; i < 624; i += 256) hb->st.state[i] = mt_untemper(mt_output_at(out32, o0 + i));
-    if (threadIdx.x == 0) {
-      const int64_t nx = mp - 624 * (k - 1);
-      hb->st.next = (uint32_t)nx;
-      hb->st.left = (int32_t)(625 - nx);
-    }
-  }
-  if (threadIdx.x == 0) {
-    hb->n32 = n32;
-    hb->status = status;
-  }
-}
-
-// ---- biased sampling (edge_weight) -------------------------------------------------------------------
-// _biased_sample (neighbor_kernel.cpp:245-285), replace == false: a row with more neighbours than the
-// fan-out draws `rand = empty_like(weight).uniform_()` straight from the generator, forms
-// key = rand.log() / weight and takes `key.topk(count)` -- the sampled edges in descending key order.
-//   * uniform_ (serial CPU kernel): float32 -> one engine output, 24 bits kept; float64 -> random64() (two
-//     outputs, first = high half), 53 bits kept (ATen/core/DistributionsHelper.h, TransformationHelper.h).
-//     Row i of the frontier reads the outputs [raw_off[i], raw_off[i] + deg * outputs_per_draw): an
-//     exclusive scan over the frontier (the prefetched RandintEngine is not touched).
-//   * log: libtorch evaluates it with MKL (<1 ulp, closed source); here the correctly rounded logarithm
-//     (float32: the f64 log rounded once; float64: the f64 log itself) -- see include/pyg_hip.h.
-//   * topk (ATen/native/TopKImpl.h:30-96): comparator "NaN first, then greater" on (key, index) pairs,
-//     std::partial_sort if count * 64 <= deg, else std::nth_element + std::sort of the first count - 1.
-//     Keys are mapped to unsigned integers whose order is that comparator's.  Without equal keys among the
-//     selected ones and at the selection boundary the result is simply the `count` largest in descending
-//     order: one wave per row finds the count-th largest key bit by bit and ranks the selection by
-//     counting.  Rows WITH such ties (zero weights -> -inf keys; equal weights with equal 24-bit draws) are
-//     re-done by biased_exact_kernel, which performs libstdc++'s algorithms step for step.
-
-// float32 logarithm of the biased path: the f64 log rounded once (pinned on all 2^24 arguments uniform_ can
-// produce through pyg_hip_biased_log_f32, tests/test_biased_sampler_gpu.py)
-__device__ __forceinline__ float biased_log_f32(float u) { return (float)log((double)u); }
-__global__ void biased_log_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) out[i] = biased_log_f32(in[i]);
-}
-
-template <bool F64> struct BiasedKey;
-template <> struct BiasedKey<false> {
-  typedef uint32_t K;
-  typedef float W;
-  static constexpr int kOutputs = 1;
-  static constexpr int kBits = 32;
-  __device__ static K make(const uint32_t* __restrict__ out32, int64_t o, float w) {
-    const float u = (float)(mt_output_at(out32, o) & 0xffffffu) * 0x1p-24f;
-    const float key = __fdiv_rn(biased_log_f32(u), w);
-    uint32_t b = __float_as_uint(key);
-    if (key != key) return ~0u;
-    if (key == 0.f) b = 0u;  // -0 and +0 compare equal
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-  }
-};
-template <> struct BiasedKey<true> {
-  typedef uint64_t K;
-  typedef double W;
-  static constexpr int kOutputs = 2;
-  static constexpr int kBits = 64;
-  __device__ static K make(const uint32_t* __restrict__ out32, int64_t o, double w) {
-    const uint64_t v = ((uint64_t)mt_output_at(out32, o) << 32) | mt_output_at(out32, o + 1);
-    const double u = (double)(v & ((1ull << 53) - 1)) * 0x1p-53;
-    const double key = log(u) / w;
-    uint64_t b = (uint64_t)__double_as_longlong(key);
-    if (key != key) return ~0ull;
-    if (key == 0.0) b = 0ull;
-    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
-  }
-};
-
-struct BiasedCountLoad {
-  const int64_t* nodes;
-  int64_t begin;
-  IdxArr rowptr;
-  int64_t count;
-  int outputs;  // engine outputs per draw
-  __device__ CountAgg operator()(int64_t i) const {
-    CountAgg r;
-    r.tab = rng_identity_packed();
-    r.edges = 0;
-    const int64_t v = nodes[begin + i];
-    const int64_t deg = rowptr[v + 1] - rowptr[v];
-    if (deg <= 0 || count == 0) return r;
-    if (count < 0 || count >= deg) {
-      r.edges = deg;
-      return r;
-    }
-    r.edges = count;
-    r.tab |= (u64)(deg * outputs) << 20;  // identity transitions compose additively in the word field
-    return r;
-  }
-};
-
-template <typename K>
-struct BiasedArgs {
-  HopArgs h;              // nodes, batch, begin, frontier, range.rowptr, col, count, edge_off, rng_word (= the
-                          // row's first engine output), emission buffers, table
-  HopInfo* info;          // tot.tab is reset to the identity (the engine does not move), overflow cleared
-  const void* weight;
-  const uint32_t* out32;  // generated engine outputs
-  int64_t out_base;       // engine output behind key slot 0
-  K* skey;                // [draws] keys of every drawing row, in draw order
-  int32_t* sidx;          // [draws] rank scratch / index half of the exact path's pairs
-  K* selkey;              // [edges] keys of the selected neighbours, in index order
-  int32_t* selidx;        // [edges]
-  int32_t* flag;          // [frontier] 1 = the row has ties and is left to biased_exact_kernel
-};
-
-__device__ __forceinline__ void wave_mem_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// A row of up to 64 R neighbours: keys stay in registers (R per lane).
-template <bool F64, int R>
-__device__ __forceinline__ void biased_row_in_registers(const BiasedArgs<typename BiasedKey<F64>::K>& a, int64_t i,
-                                                        int lane, int64_t n, int64_t k, int64_t rs, int64_t eo,
-                                                        int64_t o0, typename BiasedKey<F64>::K* sk,
-                                                        const typename BiasedKey<F64>::W* w, int64_t src_pos,
-                                                        int64_t batch) {
-  typedef BiasedKey<F64> BK;
-  typedef typename BK::K K;
-  K x[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t j = lane + 64 * r;
-    x[r] = 0;  // absent slot: below every real key (the smallest, -inf, maps to 0x007f...f)
-    if (j < n) {
-      x[r] = BK::make(a.out32, o0 + j * BK::kOutputs, w[j]);
-      sk[j] = x[r];  // the exact path reads the keys from memory
-    }
-  }
-  // T = the k-th largest key, bit by bit; absent slots hold 0 and candidates are > 0
-  K T = 0;
-  for (int b = BK::kBits - 1; b >= 0; --b) {
-    const K cand = T | ((K)1 << b);
-    int c = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) c += __popcll(__ballot(x[r] >= cand && lane + 64 * r < n));
-    if (c >= k) T = cand;
-  }
-  int sel = 0, gt = 0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    sel += __popcll(__ballot(x[r] >= T && lane + 64 * r < n));
-    gt += __popcll(__ballot(x[r] > T && lane + 64 * r < n));
-  }
-  // exactly k keys >= T, and the boundary key T is unique: otherwise a tie
-  bool tie = sel != k || sel - gt != 1;
-  // rank of every selected key = number of selected keys above it; equal selected keys = tie
-  int rank[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) rank[r] = 0;
-  if (!tie) {
-    bool dup = false;
-#pragma unroll
-    for (int r2 = 0; r2 < R; ++r2) {
-      u64 m = __ballot(x[r2] >= T && lane + 64 * r2 < n);
-      while (m) {
-        const int q = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const K y = __shfl(x[r2], q, 64);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          rank[r] += y > x[r] ? 1 : 0;
-          dup = dup || (y == x[r] && (q != lane || r2 != r) && x[r] >= T && lane + 64 * r < n);
-        }
-      }
-    }
-    tie = __ballot(dup) != 0;
-  }
-  if (tie) {
-    if (lane == 0) a.flag[i] = 1;
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t j = lane + 64 * r;
-    if (j < n && x[r] >= T) emit(a.h, eo + rank[r], rs + j, src_pos, batch);
-  }
-}
-
-template <bool F64>
-__global__ __launch_bounds__(256) void biased_sample_kernel(BiasedArgs<typename BiasedKey<F64>::K> a) {
-  typedef BiasedKey<F64> BK;
-  typedef typename BK::K K;
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.info->tot.tab = rng_identity();
-    a.info->overflow = 0;
-  }
-  if (i >= a.h.frontier) return;
-  const int64_t src_pos = a.h.begin + i;
-  const int64_t v = a.h.nodes[src_pos];
-  const int64_t batch = a.h.batch ? a.h.batch[src_pos] : 0;
-  const int64_t rs = a.h.range.rowptr[v];
-  const int64_t n = a.h.range.rowptr[v + 1] - rs;
-  const int64_t k = a.h.count;
-  if (lane == 0) a.flag[i] = 0;
-  if (n <= 0 || k == 0) return;
-  const int64_t eo = a.h.edge_off[i];
-  if (k < 0 || k >= n) {  // the full neighbourhood, no draws (:257-262)
-    for (int64_t j = lane; j < n; j += 64) emit(a.h, eo + j, rs + j, src_pos, batch);
-    return;
-  }
-  const int64_t o0 = a.h.rng_word[i];
-  const int64_t ko = (o0 - a.out_base) / BK::kOutputs;
-  K* sk = a.skey + ko;
-  const typename BK::W* w = static_cast<const typename BK::W*>(a.weight) + rs;
-  if (n <= 64) {
-    biased_row_in_registers<F64, 1>(a, i, lane, n, k, rs, eo, o0, sk, w, src_pos, batch);
-    return;
-  }
-  if (n <= 256) {
-    biased_row_in_registers<F64, 4>(a, i, lane, n, k, rs, eo, o0, sk, w, src_pos, batch);
-    return;
-  }
-  for (int64_t j = lane; j < n; j += 64) sk[j] = BK::make(a.out32, o0 + j * BK::kOutputs, w[j]);
-  wave_mem_sync();
-  // T = the k-th largest key: radix select, one pass over the row per 8-bit digit (per-wave LDS histogram)
-  __shared__ uint32_t hist_all[4][256];
-  uint32_t* hist = hist_all[threadIdx.x >> 6];
-  K T = 0;
-  int64_t krem = k;  // the krem-th largest of the keys that share the digits fixed so far
-  uint32_t c_eq = 0;
-  for (int shift = BK::kBits - 8; shift >= 0; shift -= 8) {
-    for (int b = lane; b < 256; b += 64) hist[b] = 0;
-    wave_mem_sync();
-    const K hi_mask = shift + 8 >= BK::kBits ? (K)0 : (~(K)0) << (shift + 8);
-    for (int64_t j = lane; j < n; j += 64) {
-      const K x = sk[j];
-      if ((x & hi_mask) == T) atomicAdd(&hist[(uint32_t)(x >> shift) & 255u], 1u);
-    }
-    wave_mem_sync();
-    uint32_t h[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h[q] = hist[4 * lane + q];
-    const uint32_t s4 = h[0] + h[1] + h[2] + h[3];
-    uint32_t t = s4;  // -> sum over lanes >= lane (higher lanes hold higher digits)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_down(t, off, 64);
-      if (lane + off < 64) t += v;
-    }
-    uint32_t above = t - s4;  // keys with a digit above this lane's four
-    int digit = -1;
-    uint32_t need = 0, cnt = 0;
-#pragma unroll
-    for (int q = 3; q >= 0; --q) {
-      if (digit < 0 && (int64_t)above < krem && krem <= (int64_t)above + h[q]) {
-        digit = 4 * lane + q;
-        need = (uint32_t)(krem - above);
-        cnt = h[q];
-      }
-      above += h[q];
-    }
-    const u64 m = __ballot(digit >= 0);
-    const int src = __ffsll((long long)m) - 1;  // exactly one lane finds it
-    digit = __shfl(digit, src, 64);
-    krem = __shfl(need, src, 64);
-    c_eq = __shfl(cnt, src, 64);
-    T |= (K)(uint32_t)digit << shift;
-  }
-  // exactly k keys are >= T iff the boundary key is unique (c_eq == krem == 1)
-  // selection = keys >= T, compacted in index order; more than k of them = a tie at the boundary
-  int64_t sel = 0;
-  for (int64_t j0 = 0; j0 < n; j0 += 64) {
-    const int64_t j = j0 + lane;
-    const K x = j < n ? sk[j] : (K)0;
-    const bool in = j < n && x >= T;
-    const u64 m = __ballot(in);
-    const int64_t p = sel + __popcll(m & ((1ull << lane) - 1));
-    if (in && p < k) {
-      a.selkey[eo + p] = x;
-      a.selidx[eo + p] = (int32_t)j;
-    }
-    sel += __popcll(m);
-  }
-  bool tie = sel > k || c_eq != 1 || krem != 1;
-  wave_mem_sync();
-  if (!tie) {
-    // rank by counting; equal keys inside the selection are ties as well
-    bool dup = false;
-    for (int64_t p = lane; p < k; p += 64) {
-      const K x = a.selkey[eo + p];
-      int32_t rank = 0, same = 0;
-      for (int64_t q = 0; q < k; ++q) {
-        const K y = a.selkey[eo + q];
-        rank += y > x ? 1 : 0;
-        same += y == x ? 1 : 0;
-      }
-      dup = dup || same > 1;
-      a.sidx[ko + p] = rank;
-    }
-    tie = __ballot(dup) != 0;
-  }
-  if (tie) {
-    if (lane == 0) a.flag[i] = 1;
-    return;
-  }
-  for (int64_t p = lane; p < k; p += 64) emit(a.h, eo + a.sidx[ko + p], rs + a.selidx[eo + p], src_pos, batch);
-}
-
-// libstdc++'s heap / introselect / introsort on (key, index) pairs held in two arrays, with the comparator
-// "x before y  <=>  key(x) > key(y)" (bits/stl_heap.h, bits/stl_algo.h of GCC 11; the algorithms have not
-// changed in a decade).  Sequential by nature: one thread per row, for the rare rows with tied keys.
-template <typename K>
-struct PairSeq {
-  K* k;
-  int32_t* v;
-  struct V {
-    K k;
-    int32_t v;
-  };
-  __device__ V at(int64_t i) const { return V{k[i], v[i]}; }
-  __device__ void put(int64_t i, V x) const {
-    k[i] = x.k;
-    v[i] = x.v;
-  }
-  __device__ void swp(int64_t i, int64_t j) const {
-    const V t = at(i);
-    put(i, at(j));
-    put(j, t);
-  }
-  __device__ static bool lt(const V& x, const V& y) { return x.k > y.k; }
-  __device__ static int lg(int64_t n) { return 63 - __clzll((unsigned long long)n); }
-
-  __device__ void push_heap(int64_t first, int64_t hole, int64_t top, V value) const {
-    int64_t parent = (hole - 1) / 2;
-    while (hole > top && lt(at(first + parent), value)) {
-      put(first + hole, at(first + parent));
-      hole = parent;
-      parent = (hole - 1) / 2;
-    }
-    put(first + hole, value);
-  }
-  __device__ void adjust_heap(int64_t first, int64_t hole, int64_t len, V value) const {
-    const int64_t top = hole;
-    int64_t child = hole;
-    while (child < (len - 1) / 2) {
-      child = 2 * (child + 1);
-      if (lt(at(first + child), at(first + (child - 1)))) child--;
-      put(first + hole, at(first + child));
-      hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-      child = 2 * (child + 1);
-      put(first + hole, at(first + (child - 1)));
-      hole = child - 1;
-    }
-    push_heap(first, hole, top, value);
-  }
-  __device__ void make_heap(int64_t first, int64_t last) const {
-    const int64_t len = last - first;
-    if (len < 2) return;
-    int64_t parent = (len - 2) / 2;
-    for (;;) {
-      adjust_heap(first, parent, len, at(first + parent));
-      if (parent == 0) return;
-      parent--;
-    }
-  }
-  __device__ void pop_heap(int64_t first, int64_t last, int64_t result) const {
-    const V value = at(result);
-    put(result, at(first));
-    adjust_heap(first, 0, last - first, value);
-  }
-  __device__ void heap_select(int64_t first, int64_t middle, int64_t last) const {
-    make_heap(first, middle);
-    for (int64_t i = middle; i < last; ++i)
-      if (lt(at(i), at(first))) pop_heap(first, middle, i);
-  }
-  __device__ void sort_heap(int64_t first, int64_t last) const {
-    while (last - first > 1) {
-      --last;
-      pop_heap(first, last, last);
-    }
-  }
-  __device__ void partial_sort(int64_t first, int64_t middle, int64_t last) const {
-    heap_select(first, middle, last);
-    sort_heap(first, middle);
-  }
-  __device__ void move_median_to_first(int64_t result, int64_t a, int64_t b, int64_t c) const {
-    if (lt(at(a), at(b))) {
-      if (lt(at(b), at(c))) swp(result, b);
-      else if (lt(at(a), at(c))) swp(result, c);
-      else swp(result, a);
-    } else if (lt(at(a), at(c))) swp(result, a);
-    else if (lt(at(b), at(c))) swp(result, c);
-    else swp(result, b);
-  }
-  __device__ int64_t unguarded_partition(int64_t first, int64_t last, int64_t pivot) const {
-    for (;;) {
-      while (lt(at(first), at(pivot))) ++first;
-      --last;
-      while (lt(at(pivot), at(last))) --last;
-      if (!(first < last)) return first;
-      swp(first, last);
-      ++first;
-    }
-  }
-  __device__ int64_t unguarded_partition_pivot(int64_t first, int64_t last) const {
-    const int64_t mid = first + (last - first) / 2;
-    move_median_to_first(first, first + 1, mid, last - 1);
-    return unguarded_partition(first + 1, last, first);
-  }
-  __device__ void unguarded_linear_insert(int64_t last) const {
-    const V val = at(last);
-    int64_t next = last - 1;
-    while (lt(val, at(next))) {
-      put(last, at(next));
-      last = next;
-      --next;
-    }
-    put(last, val);
-  }
-  __device__ void insertion_sort(int64_t first, int64_t last) const {
-    if (first == last) return;
-    for (int64_t i = first + 1; i != last; ++i) {
-      if (lt(at(i), at(first))) {
-        const V val = at(i);
-        for (int64_t j = i; j > first; --j) put(j, at(j - 1));
-        put(first, val);
-      } else {
-        unguarded_linear_insert(i);
-      }
-    }
-  }
-  __device__ void nth_element(int64_t first, int64_t nth, int64_t last) const {
-    if (first == last || nth == last) return;
-    int depth = lg(last - first) * 2;
-    while (last - first > 3) {
-      if (depth == 0) {
-        heap_select(first, nth + 1, last);
-        swp(first, nth);
-        return;
-      }
-      --depth;
-      const int64_t cut = unguarded_partition_pivot(first, last);
-      if (cut <= nth) first = cut;
-      else last = cut;
-    }
-    insertion_sort(first, last);
-  }
-  __device__ void sort(int64_t first, int64_t last) const {
-    if (first == last) return;
-    // __introsort_loop recurses into the right part and loops on the left one; the parts are disjoint, so
-    // an explicit stack of pending right parts yields the same arrangement
-    int64_t sf[130], sl[130];
-    int sd[130];
-    int top = 0;
-    sf[0] = first;
-    sl[0] = last;
-    sd[0] = lg(last - first) * 2;
-    top = 1;
-    while (top > 0) {
-      --top;
-      int64_t f = sf[top], l = sl[top];
-      int d = sd[top];
-      while (l - f > 16) {
-        if (d == 0) {
-          partial_sort(f, l, l);
-          break;
-        }
-        --d;
-        const int64_t cut = unguarded_partition_pivot(f, l);
-        sf[top] = cut;
-        sl[top] = l;
-        sd[top] = d;
-        ++top;
-        l = cut;
-      }
-    }
-    if (last - first > 16) {
-      insertion_sort(first, first + 16);
-      for (int64_t i = first + 16; i != last; ++i) unguarded_linear_insert(i);
-    } else {
-      insertion_sort(first, last);
-    }
-  }
-};
-
-template <bool F64>
-__global__ __launch_bounds__(64) void biased_exact_kernel(BiasedArgs<typename BiasedKey<F64>::K> a) {
-  typedef BiasedKey<F64> BK;
-  typedef typename BK::K K;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= a.h.frontier || !a.flag[i]) return;
-  const int64_t src_pos = a.h.begin + i;
-  const int64_t v = a.h.nodes[src_pos];
-  const int64_t batch = a.h.batch ? a.h.batch[src_pos] : 0;
-  const int64_t rs = a.h.range.rowptr[v];
-  const int64_t n = a.h.range.rowptr[v + 1] - rs;
-  const int64_t k = a.h.count;
-  const int64_t eo = a.h.edge_off[i];
-  const int64_t ko = (a.h.rng_word[i] - a.out_base) / BK::kOutputs;
-  PairSeq<K> s{a.skey + ko, a.sidx + ko};
-  for (int64_t j = 0; j < n; ++j) s.v[j] = (int32_t)j;
-  if (k * 64 <= n) {
-    s.partial_sort(0, k, n);
-  } else {
-    s.nth_element(0, k - 1, n);
-    s.sort(0, k - 1);
-  }
-  for (int64_t p = 0; p < k; ++p) emit(a.h, eo + p, rs + s.v[p], src_pos, batch);
-}
-
-// With replacement (neighbor_kernel.cpp:267-270): index = at::multinomial(weight, count, true).  For count > 1
-// libtorch's CPU kernel (ATen/native/cpu/MultinomialKernel.cpp) sums the cumulative distribution SEQUENTIALLY in the
-// weights' type, divides every entry by the sum, sets the last one to 1, and for each sample draws one double
-// (random64, 53 bits) and binary-searches the first entry that is not below it.  One wave per row: lane 0 runs the
-// sequential sum (bit-exactness leaves no choice), the division and the `count` searches are spread over the lanes.
-// Every emitting row draws 2 count outputs and emits count edges, so its first output is out_base + 2 edge_off.
-// A distribution at::multinomial rejects raises info->overflow = 3.  (count == 1 goes through exponential_ with
-// MKL's own generator inside at::multinomial: refused by the host.)
-struct BiasedReplaceCountLoad {
-  const int64_t* nodes;
-  int64_t begin;
-  IdxArr rowptr;
-  int64_t count;
-  __device__ CountAgg operator()(int64_t i) const {
-    CountAgg r;
-    r.tab = rng_identity_packed();
-    r.edges = 0;
-    const int64_t v = nodes[begin + i];
-    const int64_t deg = rowptr[v + 1] - rowptr[v];
-    if (deg <= 0 || count == 0) return r;
-    if (count < 0) {
-      r.edges = deg;
-      return r;
-    }
-    r.edges = count;
-    r.tab |= (u64)deg << 20;  // scratch entries of the cumulative distribution
-    return r;
-  }
-};
-
-template <typename W>
-__global__ __launch_bounds__(256) void biased_replace_kernel(HopArgs a, HopInfo* info, const W* __restrict__ weight,
-                                                             const uint32_t* __restrict__ out32, int64_t out_base,
-                                                             W* __restrict__ cum_all) {
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) info->tot.tab = rng_identity();
-  if (i >= a.frontier) return;
-  const int64_t src_pos = a.begin + i;
-  const int64_t v = a.nodes[src_pos];
-  const int64_t batch = a.batch ? a.batch[src_pos] : 0;
-  const int64_t rs = a.range.rowptr[v];
-  const int64_t n = a.range.rowptr[v + 1] - rs;
-  const int64_t k = a.count;
-  if (n <= 0 || k == 0) return;
-  const int64_t eo = a.edge_off[i];
-  if (k < 0) {
-    for (int64_t j = lane; j < n; j += 64) emit(a, eo + j, rs + j, src_pos, batch);
-    return;
-  }
-  W* cum = cum_all + a.rng_word[i];
-  const W* w = weight + rs;
-  W sum = 0;
-  int bad = 0;
-  if (lane == 0) {
-    for (int64_t j = 0; j < n; ++j) {
-      const W x = w[j];
-      if (!(x >= (W)0) || isinf(x)) bad = 1;
-      sum += x;
-      cum[j] = sum;
-    }
-    if (!(sum > (W)0)) bad = 1;
-  }
-  bad = __shfl(bad, 0, 64);
-  if (bad) {
-    if (lane == 0) info->overflow = 3;
-    return;
-  }
-  sum = __shfl(sum, 0, 64);
-  wave_mem_sync();
-  for (int64_t j = lane; j < n; j += 64) cum[j] = cum[j] / sum;
-  wave_mem_sync();
-  if (lane == 0) cum[n - 1] = (W)1;
-  wave_mem_sync();
-  for (int64_t s = lane; s < k; s += 64) {
-    const int64_t o = out_base + 2 * (eo + s);
-    const uint64_t r64 = ((uint64_t)mt_output_at(out32, o) << 32) | mt_output_at(out32, o + 1);
-    const double u = (double)(r64 & ((1ull << 53) - 1)) * 0x1p-53;
-    int64_t lo = 0, hi = n;
-    while (hi - lo > 0) {
-      const int64_t mid = lo + (hi - lo) / 2;
-      if ((double)cum[mid] < u) lo = mid + 1;
-      else hi = mid;
-    }
-    emit(a, eo + s, rs + lo, src_pos, batch);
-  }
-}
-
-// at::multinomial(weight, 1, true): the single-draw route (ATen/native/Distributions.cpp) -- q =
-// empty_like(weight).exponential_(1), index = argmax(weight / q).  libtorch 2.10.0 evaluates exponential_ on the
-// CPU as -log1p(-u) with ONE 53-bit double per element (random64, also for float32 tensors; the value is then
-// rounded to the tensor's type), argmax returns the first of equal maxima and treats NaN as the maximum.  One wave
-// per row: every row draws 2 deg outputs (offset = the scan's word field), lanes keep (best key, index).
-struct BiasedSingleCountLoad {
-  const int64_t* nodes;
-  int64_t begin;
-  IdxArr rowptr;
-  __device__ CountAgg operator()(int64_t i) const {
-    CountAgg r;
-    r.tab = rng_identity_packed();
-    r.edges = 0;
-    const int64_t v = nodes[begin + i];
-    const int64_t deg = rowptr[v + 1] - rowptr[v];
-    if (deg <= 0) return r;
-    r.edges = 1;
-    r.tab |= (u64)(2 * deg) << 20;
-    return r;
-  }
-};
-
-template <typename W>
-__global__ __launch_bounds__(256) void biased_single_kernel(HopArgs a, HopInfo* info, const W* __restrict__ weight,
-                                                            const uint32_t* __restrict__ out32) {
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) info->tot.tab = rng_identity();
-  if (i >= a.frontier) return;
-  const int64_t src_pos = a.begin + i;
-  const int64_t v = a.nodes[src_pos];
-  const int64_t batch = a.batch ? a.batch[src_pos] : 0;
-  const int64_t rs = a.range.rowptr[v];
-  const int64_t n = a.range.rowptr[v + 1] - rs;
-  if (n <= 0) return;
-  const int64_t o0 = a.rng_word[i];
-  const W* w = weight + rs;
-  // order: NaN above everything, then by value; ties keep the smaller index
-  int64_t best = -1;
-  int best_nan = 0;
-  double best_key = 0.0;
-  double sum = 0.0;
-  int bad = 0;
-  for (int64_t j = lane; j < n; j += 64) {
-    const uint64_t r64 = ((uint64_t)mt_output_at(out32, o0 + 2 * j) << 32) | mt_output_at(out32, o0 + 2 * j + 1);
-    const double u = (double)(r64 & ((1ull << 53) - 1)) * 0x1p-53;
-    const double q64 = -log1p(-u);
-    const W wj = w[j];
-    double key;
-    if (sizeof(W) == 4) key = (double)__fdiv_rn((float)wj, (float)q64);
-    else key = (double)wj / q64;
-    if (!(wj >= (W)0) || isinf(wj)) bad = 1;
-    sum += (double)wj;
-    const int is_nan = key != key;
-    if (best < 0 || (!best_nan && (is_nan || key > best_key))) {
-      best = j;
-      best_key = key;
-      best_nan = is_nan;
-    }
-  }
-  // wave reduction of (nan, key, index) with the same order; lanes without elements hold best = -1
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const int64_t ob = __shfl_xor(best, d, 64);
-    const int on = __shfl_xor(best_nan, d, 64);
-    const double ok = __shfl_xor(best_key, d, 64);
-    sum += __shfl_xor(sum, d, 64);
-    bad |= __shfl_xor(bad, d, 64);
-    bool take = false;
-    if (ob >= 0) {
-      if (best < 0) take = true;
-      else if (on != best_nan) take = on > best_nan;
-      else if (!on && ok != best_key) take = ok > best_key;
-      else take = ob < best;
-    }
-    if (take) {
-      best = ob;
-      best_nan = on;
-      best_key = ok;
-    }
-  }
-  if (bad || !(sum > 0.0)) {
-    if (lane == 0) info->overflow = 3;
-    return;
-  }
-  if (lane == 0) emit(a, a.edge_off[i], rs + best, src_pos, batch);
-}
+#include "sampler_biased.h"  // biased (edge_weight) sampling kernels
 
 // ---- host driver -----------------------------------------------------------------------------------
-struct Ctx {
-  const pyg_hip_sampler_host* host;
-  hipStream_t stream;
-  hipStream_t side = nullptr;     // side stream with random-word generation in flight (or nullptr)
-  volatile int* side_stop = nullptr;
-  void quiesce_side() {           // cancel speculation and wait: scratch may be freed afterwards
-    if (!side) return;
-    if (side_stop) *side_stop = 1;
-    (void)hipStreamSynchronize(side);
-    side = nullptr;
-  }
-  std::vector<void*> live;  // every block obtained from host->alloc and not yet handed out/freed
-  void* alloc(size_t bytes) {
-    void* p = host->alloc(host->user, bytes ? bytes : 16);
-    if (p) live.push_back(p);
-    return p;
-  }
-  void release(void* p) {
-    if (!p) return;
-    auto it = std::find(live.begin(), live.end(), p);
-    if (it != live.end()) live.erase(it);
-    host->free(host->user, p);
-  }
-  void keep(void* p) {  // ownership passes to the caller
-    auto it = std::find(live.begin(), live.end(), p);
-    if (it != live.end()) live.erase(it);
-  }
-  void release_all() {
-    for (void* p : live) host->free(host->user, p);
-    live.clear();
-  }
-};
-
-#define PYG_ALLOC(ptr, type, ctx, bytes)                                                   \
-  do {                                                                                     \
-    ptr = static_cast<type>((ctx).alloc(bytes));                                           \
-    if (!ptr) return fail(PYG_HIP_ERR_RUNTIME, "sampler: device allocation of %zu bytes failed", \
-                          (size_t)(bytes));                                                \
-  } while (0)
-
 // growable device array of int64
 struct DevVec {
   int64_t* p = nullptr;
@@ -1894,299 +869,6 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   return PYG_HIP_OK;
 }
 
-struct HostPinned {
-  void* p = nullptr;
-  ~HostPinned() {}
-};
-
-int get_pinned(void** out, size_t bytes) {
-  static thread_local void* buf = nullptr;
-  static thread_local size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) PYG_HIP_CHECK(hipHostFree(buf));
-    buf = nullptr;
-    cap = 0;
-    PYG_HIP_CHECK(hipHostMalloc(&buf, std::max<size_t>(bytes, 4096), hipHostMallocDefault));
-    cap = std::max<size_t>(bytes, 4096);
-  }
-  *out = buf;
-  return PYG_HIP_OK;
-}
-
-// Per-thread, per-device side stream + event pool for the speculative word generation.
-struct SideStream {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> events;
-  size_t used = 0;
-  int next_event(hipEvent_t* ev) {
-    if (used == events.size()) {
-      hipEvent_t e;
-      PYG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      events.push_back(e);
-    }
-    *ev = events[used++];
-    return PYG_HIP_OK;
-  }
-};
-
-int get_side_stream(SideStream** out) {
-  static thread_local std::vector<SideStream*> cache;
-  int dev = 0;
-  PYG_HIP_CHECK(hipGetDevice(&dev));
-  for (SideStream* ss : cache)
-    if (ss->device == dev) {
-      ss->used = 0;
-      *out = ss;
-      return PYG_HIP_OK;
-    }
-  SideStream* ss = new SideStream();
-  ss->device = dev;
-  PYG_HIP_CHECK(hipStreamCreateWithFlags(&ss->stream, hipStreamNonBlocking));
-  cache.push_back(ss);
-  *out = ss;
-  return PYG_HIP_OK;
-}
-
-struct RngHost {
-  int64_t blocks = 0;         // 128-word blocks consumed (prefetched, in the reference's terms) so far
-  u64* dev = nullptr;         // device copy of all blocks
-  int64_t dev_cap_blocks = 0;
-  int64_t word = 0;           // engine state: linear word index
-  int units = 4;              //               16-bit units left in that word
-  int64_t raw_used = 0;       // generator outputs consumed directly so far (biased sampling's uniform_)
-  int64_t cur_shift = 0;      // raw_used at the time the engine's CURRENT block was fetched (WordSrc)
-  // device continuation of the caller's mt19937 (fast path)
-  bool engine = false;
-  MtDev init;                 // the caller's engine at call start
-  int64_t a0 = 0;             // outputs left in its current array
-  int64_t o_r0 = 0;           // engine output index of raw position 0 of the current base window
-  bool started = false;       // a round has been launched: the base window lives in `window`
-  uint32_t* window = nullptr; // device: the last 624 raw values generated (base window of the next round)
-  uint32_t* base_raw = nullptr;   // device: raw copy of a round's base window (jump kernel input)
-  uint32_t* windows = nullptr;    // device: start windows of segments 1 .. kMtMaxSeg-1
-  volatile int* stop = nullptr;
-  SideStream* side = nullptr;
-  struct Mark {
-    int64_t upto32;           // outputs complete once `ev` has fired
-    hipEvent_t ev;
-  };
-  std::vector<Mark> marks;
-  size_t waited = 0;          // marks[0 .. waited) are already ordered before the main stream
-  // outputs [0, generated32) exist once the last launched round has finished
-  int64_t generated32() const { return started ? o_r0 + 624 : 0; }
-};
-
-constexpr int64_t kSpecCapWords = (int64_t)kMtMaxSeg * kMtSeg / 2;  // one round: 655 k words (5 MB)
-
-// Launches rounds on the side stream until at least `target32` outputs exist.
-int rng_generate(Ctx& c, RngHost& r, int64_t target32) {
-  while (!r.started || r.generated32() < target32) {
-    // this round: segments 0 .. K-1 of kMtSeg values (segment 0 one more), raw positions [624, 625 + K seg)
-    // K workgroups: segment 0 (kMtSeg + 1 values, the prefix kernel) and K - 1 jump segments of stride * kMtSeg
-    // values each; requests beyond one unit round (64 x 20480) use the long grid: 4x fewer jump windows per output
-    const int64_t units = (target32 - (r.o_r0 + 625) + kMtSeg - 1) / kMtSeg;  // kMtSeg-sized pieces wanted
-    const int64_t stride = units > kMtMaxSeg ? kMtStride : 1;
-    int64_t K = 1 + (std::max<int64_t>(units, 1) - 1 + stride - 1) / stride;
-    K = std::max<int64_t>(1, std::min<int64_t>(K, kMtMaxSeg));
-    const int64_t t_end = 625 + (1 + (K - 1) * stride) * kMtSeg;
-    const int64_t new_gen = r.o_r0 + t_end;
-    const int64_t need_cap = (new_gen + 2 + 255) / 256;
-    if (need_cap > r.dev_cap_blocks) {
-      const int64_t ncap = std::max<int64_t>(need_cap, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
-      u64* nd;
-      PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
-      if (r.started) {  // rare: more words than the first round produced -- move what exists, in main-stream order
-        PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks.back().ev, 0));
-        r.waited = r.marks.size();
-        PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(uint32_t) * (size_t)(r.generated32() + 1),
-                                     hipMemcpyDeviceToDevice, c.stream));
-      }
-      // the block may be recycled from main-stream work that is still in flight
-      hipEvent_t ev;
-      int rc = r.side->next_event(&ev);
-      if (rc != PYG_HIP_OK) return rc;
-      PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
-      PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
-      c.release(r.dev);
-      r.dev = nd;
-      r.dev_cap_blocks = ncap;
-    }
-    uint32_t* out32 = reinterpret_cast<uint32_t*>(r.dev);
-    hipStream_t ss = r.side->stream;
-    hipLaunchKernelGGL(mt_prefix_kernel, dim3(1), dim3(kMtThreads), 0, ss, r.init, r.started ? 0 : 1, r.window,
-                       r.base_raw, out32, r.o_r0, (uint32_t)(kMtSeg + 1), K == 1 ? r.window : (uint32_t*)nullptr,
-                       const_cast<const int*>(r.stop));
-    PYG_HIP_CHECK(hipGetLastError());
-    hipEvent_t ev;
-    int rc = r.side->next_event(&ev);
-    if (rc != PYG_HIP_OK) return rc;
-    PYG_HIP_CHECK(hipEventRecord(ev, ss));
-    r.marks.push_back({r.o_r0 + 625 + kMtSeg, ev});
-    if (K > 1) {
-      MtJumpLists lists;
-      int max_span = 0;
-      for (int k = 1; k < (int)K; ++k) {  // slot k holds the list of segment 1 + (k - 1) * stride
-        int span = 0;
-        rc = mt_jump_list(1 + (k - 1) * (int)stride, kMtJumpParts, &lists.idx[k], &lists.count[k], &span);
-        if (rc != PYG_HIP_OK) return rc;
-        max_span = std::max(max_span, span);
-      }
-      PYG_HIP_CHECK(hipMemsetAsync(r.windows, 0, sizeof(uint32_t) * 624 * (size_t)(K - 1), ss));
-      // raw values of a share + its coefficient offsets (at most 19937 / kMtJumpParts + 1 of them)
-      const int jump_lds = (int)sizeof(uint32_t) * (max_span + 8) + (int)sizeof(uint16_t) * (19937 / kMtJumpParts + 16);
-      static thread_local int attr_lds = 0;
-      if (jump_lds > attr_lds) {
-        PYG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mt_jump_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, jump_lds));
-        attr_lds = jump_lds;
-      }
-      hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(K - 1), kMtJumpParts), dim3(256), jump_lds, ss, r.base_raw,
-                         out32, r.o_r0, lists, r.windows);
-      hipLaunchKernelGGL(mt_segment_kernel, dim3((unsigned)(K - 1)), dim3(kMtThreads), 0, ss, r.windows, out32, r.o_r0,
-                         (uint32_t)kMtSeg, (uint32_t)stride, r.window, const_cast<const int*>(r.stop));
-      PYG_HIP_CHECK(hipGetLastError());
-      rc = r.side->next_event(&ev);
-      if (rc != PYG_HIP_OK) return rc;
-      PYG_HIP_CHECK(hipEventRecord(ev, ss));
-      r.marks.push_back({new_gen, ev});
-    }
-    r.o_r0 += t_end - 624;
-    r.started = true;
-  }
-  return PYG_HIP_OK;
-}
-
-// Adopts the caller's engine and starts generating on the side stream: `spec_words` = the number of words
-// the call may consume at most (16-bit draws); one round of up to kMtMaxSeg concurrent segments.
-int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec_words) {
-  const pyg_hip_mt19937* e = c.host->mt19937;
-  PYG_HIP_REQUIRE(e->left > 0 && e->left <= 624 && e->next <= 624 && (int64_t)e->next + e->left <= 625,
-                  "sampler: invalid mt19937 engine state");
-  static_assert(sizeof(MtDev) == sizeof(pyg_hip_mt19937), "engine layouts must match");
-  ::memcpy(&r.init, e, sizeof(MtDev));
-  r.engine = true;
-  r.a0 = (int64_t)r.init.left - 1;
-  r.o_r0 = r.a0 - 624;  // raw position t of the caller's array is output t - (624 - a0)
-  int rc = get_side_stream(&r.side);
-  if (rc != PYG_HIP_OK) return rc;
-  r.stop = reinterpret_cast<volatile int*>(static_cast<char*>(pinned) + 512);
-  *r.stop = 0;
-  c.side = r.side->stream;
-  c.side_stop = r.stop;
-  PYG_ALLOC(r.window, uint32_t*, c, sizeof(uint32_t) * 624);
-  PYG_ALLOC(r.base_raw, uint32_t*, c, sizeof(uint32_t) * 624);
-  PYG_ALLOC(r.windows, uint32_t*, c, sizeof(uint32_t) * 624 * (size_t)kMtMaxSeg);
-  int64_t top = 128;
-  for (int64_t w : spec_words) top = std::max(top, std::min(w, kSpecCapWords));
-  {
-    // one allocation for everything the first round may write
-    const int64_t segs = std::max<int64_t>(1, std::min<int64_t>((2 * top + kMtSeg - 1) / kMtSeg + 1, kMtMaxSeg));
-    const int64_t cap = (r.o_r0 + 625 + segs * kMtSeg + 2 + 255) / 256 + 1;
-    PYG_ALLOC(r.dev, u64*, c, sizeof(u64) * 128 * (size_t)cap);
-    r.dev_cap_blocks = cap;
-    hipEvent_t ev;  // order the side stream after whatever used these blocks before
-    rc = r.side->next_event(&ev);
-    if (rc != PYG_HIP_OK) return rc;
-    PYG_HIP_CHECK(hipEventRecord(ev, c.stream));
-    PYG_HIP_CHECK(hipStreamWaitEvent(r.side->stream, ev, 0));
-  }
-  // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
-  rc = rng_generate(c, r, std::max<int64_t>(2 * top, 256));
-  if (rc != PYG_HIP_OK) return rc;
-  r.blocks = 1;
-  return PYG_HIP_OK;
-}
-
-// Device engine only: orders the words up to `last_word` (and whatever else the same launch produced)
-// before work submitted to the main stream afterwards; `avail_blocks` = whole 128-word blocks covered.
-// No consumption accounting: also used for words a hop MAY read.
-int rng_wait32(Ctx& c, RngHost& r, int64_t need32, int64_t* avail_blocks);
-int rng_wait(Ctx& c, RngHost& r, int64_t last_word, int64_t* avail_blocks) {
-  return rng_wait32(c, r, (last_word / 128 + 1) * 256, avail_blocks);
-}
-// the same for engine outputs [0, need32)
-int rng_wait32(Ctx& c, RngHost& r, int64_t need32, int64_t* avail_blocks) {
-  if (r.generated32() < need32) {  // beyond the speculation: another round, with some slack
-    int rc = rng_generate(c, r, need32 + need32 / 4);
-    if (rc != PYG_HIP_OK) return rc;
-  }
-  size_t k = 0;
-  while (r.marks[k].upto32 < need32) ++k;
-  if (k >= r.waited) {
-    PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
-    r.waited = k + 1;
-  }
-  if (avail_blocks) *avail_blocks = r.marks[r.waited - 1].upto32 / 256;
-  return PYG_HIP_OK;
-}
-
-// Makes every word up to `last_word` readable by work submitted to the main stream afterwards and
-// counts its blocks as drawn from the caller's generator.
-int rng_ensure(Ctx& c, RngHost& r, int64_t last_word) {
-  const int64_t need_blocks = last_word / 128 + 1;
-  if (r.engine) {
-    int rc = rng_wait(c, r, last_word, nullptr);
-    if (rc != PYG_HIP_OK) return rc;
-    r.blocks = std::max(r.blocks, need_blocks);
-    return PYG_HIP_OK;
-  }
-  if (need_blocks <= r.blocks) return PYG_HIP_OK;
-  if (need_blocks > r.dev_cap_blocks) {
-    const int64_t ncap = std::max<int64_t>(need_blocks, std::max<int64_t>(2 * r.dev_cap_blocks, 16));
-    u64* nd;
-    PYG_ALLOC(nd, u64*, c, sizeof(u64) * 128 * (size_t)ncap);
-    if (r.blocks > 0)
-      PYG_HIP_CHECK(hipMemcpyAsync(nd, r.dev, sizeof(u64) * 128 * (size_t)r.blocks,
-                                   hipMemcpyDeviceToDevice, c.stream));
-    c.release(r.dev);
-    r.dev = nd;
-    r.dev_cap_blocks = ncap;
-  }
-  const int64_t nnew = need_blocks - r.blocks;
-  std::vector<int64_t> tmp((size_t)nnew * 128);
-  c.host->rng_blocks(c.host->user, tmp.data(), nnew, r.blocks == 0 ? 1 : 0);
-  // pageable -> device; the vector dies at scope exit, so make the copy synchronous
-  PYG_HIP_CHECK(hipMemcpyAsync(r.dev + r.blocks * 128, tmp.data(), sizeof(u64) * 128 * (size_t)nnew,
-                               hipMemcpyHostToDevice, c.stream));
-  PYG_HIP_CHECK(hipStreamSynchronize(c.stream));
-  r.blocks = need_blocks;
-  return PYG_HIP_OK;
-}
-
-// Hands the advanced engine back (queued on the main stream; the caller synchronises it).
-int rng_finish(Ctx& c, RngHost& r) {
-  if (!r.engine) return PYG_HIP_OK;
-  const int64_t n32 = r.blocks * 256 + r.raw_used;
-  pyg_hip_mt19937* e = c.host->mt19937;
-  if (n32 <= r.a0) {
-    PYG_HIP_CHECK(hipEventSynchronize(r.marks[0].ev));
-    c.quiesce_side();
-    e->left = (int32_t)(r.init.left - n32);
-    e->next = (uint32_t)(r.init.next + n32);
-    return PYG_HIP_OK;
-  }
-  // the engine is left holding the whole 624-array that contains the last consumed output: make sure
-  // all of it has been generated, and that the launches producing it are not cancelled below
-  const int64_t k_arr = (n32 - r.a0 + 623) / 624;
-  const int64_t end32 = r.a0 + 624 * k_arr;
-  if (r.generated32() < end32) {
-    int rc = rng_generate(c, r, end32);
-    if (rc != PYG_HIP_OK) return rc;
-  }
-  size_t k = 0;
-  while (r.marks[k].upto32 < end32) ++k;
-  PYG_HIP_CHECK(hipEventSynchronize(r.marks[k].ev));
-  if (k >= r.waited) PYG_HIP_CHECK(hipStreamWaitEvent(c.stream, r.marks[k].ev, 0));
-  MtDev* out;
-  PYG_ALLOC(out, MtDev*, c, sizeof(MtDev));
-  hipLaunchKernelGGL(mt_finish_kernel, dim3(1), dim3(256), 0, c.stream,
-                     reinterpret_cast<const uint32_t*>(r.dev), r.a0, n32, out);
-  PYG_HIP_CHECK(hipGetLastError());
-  PYG_HIP_CHECK(hipMemcpyAsync(e, out, sizeof(MtDev), hipMemcpyDeviceToHost, c.stream));
-  c.quiesce_side();
-  return PYG_HIP_OK;
-}
 
 constexpr int kNeedSlow = 1000;  // internal: repeat the call in the synchronising mode
 
@@ -2573,9 +1255,10 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
           PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
           rng.waited = k + 1;
         }
-        hipLaunchKernelGGL(mt_finish_chain_kernel, dim3(1), dim3(256), 0, stream,
-                           reinterpret_cast<const uint32_t*>(rng.dev), rng.a0, chain, rng.marks[k].upto32, hb_dev);
-        PYG_HIP_CHECK(hipGetLastError());
+        {
+          int rc = rng_queue_hand_back(c, rng, chain, rng.marks[k].upto32, hb_dev);
+          if (rc != PYG_HIP_OK) return rc;
+        }
         PYG_HIP_CHECK(hipMemcpyAsync(hand_back, hb_dev, sizeof(MtHandBack), hipMemcpyDeviceToHost, stream));
       }
     }
