@@ -672,8 +672,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
 // The contiguous-range kernel above keeps ~1000 independent read / write streams alive (one per wave); how fast the
 // HBM side serves that depends on where the caching allocator happened to place `input` and `out` (measured on one
 // box, same launch, six candidate output buffers: 5.0 ... 6.1 TB/s, ~3 of 4 allocations at the low end).  Here every
-// workgroup (8 waves, 256-row tile) takes the tiles b, b + G, b + 2G, ... so the chip sweeps ONE narrow window of
-// `input` / `out` front to back (5.4 - 5.9 TB/s on the same buffers).  A workgroup then changes relation every other
+// workgroup (8 waves, 256-row tile) takes every G/8-th tile of its XCD's band, so the chip sweeps eight narrow windows
+// of `input` / `out` front to back (5.4 - 6.3 TB/s on the same buffers).  A workgroup then changes relation every other
 // tile, so the weight switch must be free:
 //   * W[g] is copied [K][M] as it lies in memory by LDS-DMA (global_load_lds_dwordx4, 8 waves x 4 KiB); the 16-byte
 //     chunks of every 1 KiB block (4 k-rows) are permuted on the SOURCE side so that
@@ -703,14 +703,22 @@ __global__ __launch_bounds__(512) void mfma_rows_cyc_kernel(const DevGroup* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 31, h = lane >> 5;
   const int bx = blockIdx.x, G = gridDim.x;
   char* stage = smem + 2 * WB + wave * 8192;
+  // Banded cyclic schedule: the tiles are cut into 8 contiguous bands, the workgroups of XCD k (ids k, k + 8, ...:
+  // consecutive ids go to consecutive XCDs) sweep band k cyclically -- 8 narrow windows instead of one, every page and
+  // L2 line is touched by ONE XCD.  Same rate as the single sweep on unfavourably placed buffers (5.4 TB/s), 6.3
+  // instead of 5.8 TB/s on favourable ones (tools/lab: v3:sched=2).
   const int total = tile_start[B];
-  if (bx >= total) return;
-  const int nloc = (total - 1 - bx) / G + 1;
+  const int nb = (G & 7) == 0 ? 8 : 1;
+  const int band = bx % nb, per = G / nb;
+  const int band0 = (int)((int64_t)band * total / nb), band1 = (int)((int64_t)(band + 1) * total / nb);
+  const int cbase = band0 + bx / nb;  // first tile of this workgroup; then every `per`-th tile of the band
+  if (cbase >= band1) return;
+  const int nloc = (band1 - 1 - cbase) / per + 1;
 
   int lo = 0, hi = B;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (tile_start[mid] <= bx) lo = mid; else hi = mid;
+    if (tile_start[mid] <= cbase) lo = mid; else hi = mid;
   }
   int g = lo;  // group of the tile being prefetched
 
@@ -731,9 +739,9 @@ __global__ __launch_bounds__(512) void mfma_rows_cyc_kernel(const DevGroup* __re
   auto next_group = [&](int gc) -> int {
     const int ts = tile_start[gc + 1];
     if (ts >= total) return -1;
-    const int j = ts > bx ? (ts - bx + G - 1) / G : 0;
-    const int t = bx + j * G;
-    if (t >= total) return -1;
+    const int j = ts > cbase ? (ts - cbase + per - 1) / per : 0;
+    if (j >= nloc) return -1;
+    const int t = cbase + j * per;
     int gg = gc + 1;
     while (tile_start[gg + 1] <= t) ++gg;
     return gg;
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(512) void mfma_rows_cyc_kernel(const DevGroup* __re
   int64_t n_row0 = 0, n_rows = 0;
   bool n_valid = false;
   auto prefetch = [&](int ti) {
-    const int t = bx + ti * G;
+    const int t = cbase + ti * per;
     while (t >= tile_start[g + 1]) {
       ++g;
       dn = descs[g];
@@ -1818,7 +1826,8 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
       const void* kern = reinterpret_cast<const void*>(&mfma_rows_cyc_kernel<T>);
       if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
       const int64_t tiles2_upper = (w.rows_upper + 255) / 256 + B;
-      const int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles2_upper, 1), (int64_t)di.num_cus);
+      int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles2_upper, 1), (int64_t)di.num_cus);
+      if (gx >= 8) gx -= gx % 8;  // whole octets of workgroups: one band of tiles per XCD
       ProfScope prof(stream);
       hipLaunchKernelGGL((mfma_rows_cyc_kernel<T>), dim3((unsigned)gx), dim3(512), lds, stream, w.descs, w.tile_start2, B);
       PYG_HIP_CHECK(hipGetLastError());

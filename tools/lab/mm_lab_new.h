@@ -21,16 +21,27 @@ __global__ __launch_bounds__(NWV * 64) void v3_kernel(const DevGroup* __restrict
   const int bx = blockIdx.x, G = gridDim.x;
   char* stage = smem + (WDB ? 2 : 1) * WB + wave * 8192;
   const int total = tile_start[B];
-  int nloc, cbase = 0;
+  int nloc, cbase = 0, tstep = 1;
   if (SCHED == 0) {
     if (bx >= total) return;
     nloc = (total - 1 - bx) / G + 1;
-  } else {
+    cbase = bx;
+    tstep = G;
+  } else if (SCHED == 1) {
     cbase = (int)((int64_t)bx * total / G);
     nloc = (int)((int64_t)(bx + 1) * total / G) - cbase;
     if (nloc <= 0) return;
+  } else {
+    // banded: workgroups of XCD k (ids k, k + 8, ...) sweep band k of the tiles cyclically
+    const int nb = SCHED == 2 ? 8 : SCHED;            // number of bands
+    const int band = bx % nb, w = bx / nb, per = G / nb;   // G must be a multiple of nb
+    const int b0 = (int)((int64_t)band * total / nb), b1 = (int)((int64_t)(band + 1) * total / nb);
+    cbase = b0 + w;
+    tstep = per;
+    if (cbase >= b1) return;
+    nloc = (b1 - 1 - cbase) / per + 1;
   }
-  auto tile_of = [&](int j) -> int { return SCHED == 0 ? bx + j * G : cbase + j; };
+  auto tile_of = [&](int j) -> int { return cbase + j * tstep; };
 
   // group of the first tile
   int lo = 0, hi = B;
@@ -58,15 +69,9 @@ __global__ __launch_bounds__(NWV * 64) void v3_kernel(const DevGroup* __restrict
   auto next_group = [&](int gc) -> int {
     const int ts = tile_start[gc + 1];
     if (ts >= total) return -1;
-    int t;
-    if (SCHED == 0) {
-      const int j = ts > bx ? (ts - bx + G - 1) / G : 0;
-      t = bx + j * G;
-      if (t >= total) return -1;
-    } else {
-      t = ts > cbase ? ts : cbase;
-      if (t >= cbase + nloc) return -1;
-    }
+    const int j = ts > cbase ? (ts - cbase + tstep - 1) / tstep : 0;
+    if (j >= nloc) return -1;
+    const int t = cbase + j * tstep;
     int gg = gc + 1;
     while (tile_start[gg + 1] <= t) ++gg;
     return gg;
@@ -952,7 +957,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     CK(hipMalloc(&dt, (c.B + 1) * 4));
     CK(hipMemcpy(dt, ht.data(), (c.B + 1) * 4, hipMemcpyHostToDevice));
     const int lds = (wdb ? 2 : 1) * 32768 + nwv * 8192;
-    const int grid = c.cus * wgs;
+    const int grid = opt("g", 0) > 0 ? opt("g", 0) : c.cus * wgs;
     bool done = false;
 #define V3_CASE(F, N, D, W, S)                                                                                       \
   if (flags == F && nwv == N && dbg == D && wdb == W && sched == S) {                                                \
@@ -962,7 +967,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   }
     V3_CASE(3, 8, 0, 1, 0) V3_CASE(0, 8, 0, 1, 0) V3_CASE(3, 4, 0, 1, 0) V3_CASE(3, 8, 1, 1, 0)
     V3_CASE(3, 8, 0, 1, 1) V3_CASE(3, 8, 0, 0, 0) V3_CASE(3, 4, 0, 0, 0) V3_CASE(3, 4, 0, 0, 1) V3_CASE(3, 2, 0, 0, 0)
-    V3_CASE(1, 8, 0, 1, 0) V3_CASE(2, 8, 0, 1, 0)
+    V3_CASE(1, 8, 0, 1, 0) V3_CASE(2, 8, 0, 1, 0) V3_CASE(3, 8, 0, 1, 2) V3_CASE(0, 8, 0, 1, 2) V3_CASE(1, 8, 0, 1, 2) V3_CASE(2, 8, 0, 1, 2) V3_CASE(3, 8, 0, 0, 2) V3_CASE(3, 8, 0, 1, 4) V3_CASE(3, 8, 0, 1, 16) V3_CASE(3, 8, 0, 1, 32) V3_CASE(3, 8, 0, 1, 64)
 #undef V3_CASE
     CK(hipFree(dt));
     if (!done) printf("%s: no such v3 variant\n", spec.c_str());
