@@ -403,14 +403,23 @@ static void host_rng_blocks(void* user, int64_t* words, int64_t num_blocks, int 
 // installs the advanced state afterwards (see pyg_hip_sampler_host::mt19937).
 struct EngineLoan {
   at::CPUGeneratorImpl* gen;
-  std::unique_lock<std::mutex> lock;
   at::mt19937 engine;
   at::mt19937_data_pod pod;
   pyg_hip_mt19937 mt;
   bool ok;
+  // The generator's mutex is held only while the engine state is copied out and while it is installed again --
+  // not across the call: the library may fall back to the host callback (host_rng_blocks -> Tensor.random_(), which
+  // takes the same non-recursive mutex), and other threads' CPU RNG use must not wait for device synchronisations.
+  // Like the reference (random/cpu/rand_engine.h draws without any lock), concurrent sampler calls are the
+  // caller's to serialise.
   EngineLoan()
-      : gen(at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator())),
-        lock(gen->mutex_), engine(gen->engine()), pod(engine.data()), ok(engine.is_valid()) {
+      : gen(at::get_generator_or_default<at::CPUGeneratorImpl>(c10::nullopt, at::detail::getDefaultCPUGenerator())) {
+    {
+      std::lock_guard<std::mutex> lock(gen->mutex_);
+      engine = gen->engine();
+    }
+    pod = engine.data();
+    ok = engine.is_valid();
     static_assert(sizeof(mt.state) == sizeof(uint32_t) * at::MERSENNE_STATE_N, "mt19937 state size");
     std::memcpy(mt.state, pod.state_.data(), sizeof(mt.state));
     mt.left = pod.left_;
@@ -423,6 +432,7 @@ struct EngineLoan {
     pod.left_ = mt.left;
     pod.next_ = mt.next;
     engine.set_data(pod);
+    std::lock_guard<std::mutex> lock(gen->mutex_);
     gen->set_engine(engine);
   }
 };

@@ -745,6 +745,151 @@ __global__ __launch_bounds__(1024) void v5_kernel(const DevGroup* __restrict__ d
   }
 }
 
+
+// persistent copy, U KiB per wave tile: DYN 0 = static cyclic (wave w takes tiles w, w + W, ...), 1 = in-order tickets
+// per wave (8 counters, one per XCD); DEPTH 1 = next tile's loads issued before this tile's stores, 0 = load, store, next.
+template <int U, int DYN, int DEPTH>
+__global__ __launch_bounds__(256) void pcopy_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
+                                                    unsigned int* __restrict__ ctr, int slp, int wait) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const int q8 = blockIdx.x & 7;
+  const long W = (long)gridDim.x * 4;
+  long stat = (long)blockIdx.x * 4 + wave;
+  auto pull = [&]() -> long {
+    if (!DYN) {
+      const long t = stat;
+      stat += W;
+      return t;
+    }
+    unsigned int k = 0;
+    if (lane == 0) k = atomicAdd(&ctr[q8 * 32], 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    return (long)k * 8 + q8;
+  };
+  u32x4 v[U], nx[U];
+  long t = pull();
+  if (DEPTH) {
+    if (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+    }
+    while (t < ntiles) {
+      const long t2 = pull();
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = nx[q];
+      if (t2 < ntiles) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t2 * U + q) * 64 + lane));
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+      for (int k = 0; k < slp; ++k) __builtin_amdgcn_s_sleep(4);
+      t = t2;
+    }
+  } else {
+    while (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+      if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int k = 0; k < slp; ++k) __builtin_amdgcn_s_sleep(4);
+      t = pull();
+    }
+  }
+}
+
+
+// persistent copy with WORKGROUP tickets: a WG of NW waves takes 64 KiB * (NW*U/64) tiles in address order from a per-XCD
+// counter; the first wave to reach step i pulls the ticket and publishes it through LDS (no barrier).
+template <int U, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
+                                                         unsigned int* __restrict__ ctr, int dynamic) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* seq = (int*)smem;  // 2048 entries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2048; i += NW * 64) seq[i] = -1;
+  __syncthreads();
+  const int q8 = blockIdx.x & 7;
+  int step = 0;
+  long stat = blockIdx.x;
+  auto pull = [&]() -> long {
+    if (!dynamic) {
+      const long t = stat;
+      stat += gridDim.x;
+      return t;
+    }
+    int got = 0;
+    if (lane == 0) {
+      int v = atomicCAS(&seq[step], -1, -2);
+      if (v == -1) {
+        v = (int)atomicAdd(&ctr[q8 * 32], 1u);
+        __hip_atomic_store(&seq[step], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        while (v < 0) v = __hip_atomic_load(&seq[step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      got = v;
+    }
+    ++step;
+    got = __builtin_amdgcn_readfirstlane(got);
+    return (long)got * 8 + q8;
+  };
+  u32x4 v[U], nx[U];
+  long t = pull();
+  auto base = [&](long tile) { return (tile * NW + wave) * U * 64 + lane; };
+  if (DEPTH) {
+    if (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+    }
+    while (t < ntiles) {
+      const long t2 = pull();
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = nx[q];
+      if (t2 < ntiles) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t2) + q * 64));
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      t = t2;
+    }
+  } else {
+    while (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      t = pull();
+    }
+  }
+}
+
+
+// bigc morphing towards persistence: every wave copies `rep` tiles one after the other; mode 0 = its tiles are adjacent,
+// 1 = strided by the whole grid; wait = drain the stores before the next loads; slp = s_sleep units between tiles.
+template <int U>
+__global__ __launch_bounds__(256) void bigr_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles, int rep,
+                                                   int mode, int wait, int slp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const long w = (long)blockIdx.x * 4 + wave, W = (long)gridDim.x * 4;
+  for (int r = 0; r < rep; ++r) {
+    const long t = mode == 0 ? w * rep + r : (long)r * W + w;
+    if (t >= ntiles) return;
+    u32x4 v[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+    for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 0; k < slp; ++k) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 static bool run_new(const Ctx& c, const std::string& spec, const std::string& name, std::map<std::string, int>& o) {
   auto opt = [&](const char* k, int dflt) { return o.count(k) ? o[k] : dflt; };
 
@@ -910,6 +1055,100 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     V5_CASE(3, 0) V5_CASE(0, 0) V5_CASE(3, 1)
 #undef V5_CASE
     if (!done && g_round == 0) printf("%s: no such v5 variant\n", spec.c_str());
+    return true;
+  }
+
+  if (name == "pcopy") {
+    const int u = opt("u", 4), dyn = opt("dyn", 1), depth = opt("depth", 1), wgs = opt("wgs", 4), lds = opt("lds", 0), slp = opt("slp", 0), wait = opt("wait", 0);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / (u * 1024);
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
+      CK(hipEventRecord(e0));
+#define PC(UU, DD, PP) if (u == UU && dyn == DD && depth == PP) { if (lds) CK(hipFuncSetAttribute((const void*)&pcopy_kernel<UU, DD, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcopy_kernel<UU, DD, PP>), dim3(c.cus * wgs), dim3(256), lds, 0, in, out, ntiles, ctr, slp, wait); }
+      PC(2, 0, 0) PC(1, 0, 0) PC(8, 0, 0) PC(1, 0, 1) PC(4, 0, 1) PC(4, 1, 1) PC(4, 1, 0) PC(4, 0, 0) PC(8, 1, 1) PC(8, 0, 1) PC(2, 1, 1) PC(2, 1, 0) PC(1, 1, 0) PC(1, 1, 1) PC(2, 0, 1) PC(8, 1, 0)
+#undef PC
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "pcopy2") {
+    const int u = opt("u", 4), nw = opt("nw", 16), depth = opt("depth", 1), wgs = opt("wgs", 1), dyn = opt("dyn", 1), lds = opt("lds", 8192);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / ((long)u * 1024 * nw);
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
+      CK(hipEventRecord(e0));
+#define PC(UU, NN, PP) if (u == UU && nw == NN && depth == PP) { CK(hipFuncSetAttribute((const void*)&pcopy2_kernel<UU, NN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcopy2_kernel<UU, NN, PP>), dim3(c.cus * wgs), dim3(NN * 64), lds, 0, in, out, ntiles, ctr, dyn); }
+      PC(4, 16, 1) PC(4, 16, 0) PC(8, 8, 1) PC(8, 8, 0) PC(4, 8, 1) PC(4, 8, 0) PC(2, 16, 1) PC(2, 16, 0) PC(4, 4, 1) PC(4, 4, 0) PC(8, 4, 1)
+#undef PC
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "bigr") {
+    const int u = opt("u", 4), lds = opt("lds", 40960), rep = opt("rep", 1), mode = opt("mode", 0), wait = opt("wait", 0), slp = opt("slp", 0);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / (u * 1024);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipEventRecord(e0));
+      const unsigned gb = (unsigned)((ntiles + 4L * rep - 1) / (4L * rep));
+#define PC(UU) if (u == UU) { CK(hipFuncSetAttribute((const void*)&bigr_kernel<UU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((bigr_kernel<UU>), dim3(gb), dim3(256), lds, 0, in, out, ntiles, rep, mode, wait, slp); }
+      PC(1) PC(2) PC(4) PC(8)
+#undef PC
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
     return true;
   }
   if (name == "rw") {
