@@ -165,7 +165,7 @@ def main():
     ap.add_argument('--no-legs', action='store_true', help='skip the c4 / c5 / index_sort / scatter / backward legs')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
-    ap.add_argument('--schedule', default='auto', choices=['auto', 'contiguous', 'cyclic'],
+    ap.add_argument('--schedule', default='auto', choices=['auto', 'contiguous', 'cyclic', 'ticket'],
                     help='tile schedule of the bf16 kernel (pyg_hip_matmul_set_schedule)')
     ap.add_argument('--debug-one-device', action='store_true',
                     help='debug only: all ranks share cuda:0 over gloo (exercises the N>1 code path on a 1-GPU box)')

@@ -117,11 +117,13 @@ PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_ho
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
 
 /* Tile schedule of the 16-bit K = M = 128 segment/grouped matmul kernels (process wide):
- *   0  automatic (default): the cyclic schedule once every CU has several 256-row tiles to sweep,
- *      contiguous ranges below that;
- *   1  contiguous tile range per workgroup (mfma_rows_lds_kernel): fastest when the allocator happened to
- *      place input and output favourably (up to 6.1 TB/s on C2), 5.0 TB/s otherwise;
- *   2  cyclic (mfma_rows_cyc_kernel): the chip sweeps one narrow window, 5.4 - 5.9 TB/s on either placement.
+ *   0  automatic (default): the ticket schedule once every CU has several tiles to sweep, contiguous ranges
+ *      below that;
+ *   1  contiguous tile range per workgroup (mfma_rows_lds_kernel): up to 6.1 TB/s on C2 when the allocator happened
+ *      to place input and output favourably, 5.0 TB/s otherwise;
+ *   2  banded cyclic (mfma_rows_cyc_kernel): 6.2 - 6.3 TB/s on favourably placed buffers, 5.4 - 5.6 otherwise;
+ *   3  tickets (mfma_rows_ticket_kernel): tiles drawn in address order from per-XCD counters, W in registers:
+ *      6.1 - 6.2 TB/s on either placement.
  * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
 PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
 

@@ -58,50 +58,60 @@ struct DevGroup {
 };
 
 constexpr int kTileRows = 128;  // rows per workgroup tile in the MFMA kernels (4 waves x 32)
+constexpr int kPairRows = 64;   // rows per tile of the ticket kernel (2 waves x 32)
+constexpr int kTicketWords = 256;  // 8 per-XCD tile counters, 128 bytes apart
 
 // ---- plan kernel: ptr on device -> descriptors + tile/row prefix sums --------------------------
 __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B, const char* a,
                                      const char* w, char* c, const char* bias, int64_t K,
                                      int64_t M, int elt, DevGroup* __restrict__ descs,
                                      int32_t* __restrict__ tile_start,
-                                     int64_t* __restrict__ row_start, int32_t* __restrict__ tile_start2) {
+                                     int64_t* __restrict__ row_start, int32_t* __restrict__ tile_start2,
+                                     int32_t* __restrict__ tile_start3, unsigned int* __restrict__ tickets) {
   // Single block; B is the number of relations (hundreds): a serial-per-chunk scan is plenty.
   __shared__ int64_t s_tiles[256];
   __shared__ int64_t s_tiles2[256];
+  __shared__ int64_t s_tiles3[256];
   __shared__ int64_t s_rows[256];
   const int tid = threadIdx.x;
+  tickets[tid] = 0;  // kTicketWords == blockDim.x: the per-XCD tile counters of the ticket kernel start at 0
   const int nthr = blockDim.x;
   const int64_t per = (B + nthr - 1) / nthr;
   const int64_t beg = min((int64_t)tid * per, B), end = min(beg + per, B);
-  int64_t tiles = 0, tiles2 = 0, rows = 0;
+  int64_t tiles = 0, tiles2 = 0, tiles3 = 0, rows = 0;
   for (int64_t b = beg; b < end; ++b) {
     int64_t r = ptr[b + 1] - ptr[b];
     if (r < 0) r = 0;
     rows += r;
     tiles += (r + kTileRows - 1) / kTileRows;
     tiles2 += (r + 2 * kTileRows - 1) / (2 * kTileRows);
+    tiles3 += (r + kPairRows - 1) / kPairRows;
   }
   s_tiles[tid] = tiles;
   s_tiles2[tid] = tiles2;
+  s_tiles3[tid] = tiles3;
   s_rows[tid] = rows;
   __syncthreads();
   if (tid == 0) {
-    int64_t t = 0, t2 = 0, r = 0;
+    int64_t t = 0, t2 = 0, t3 = 0, r = 0;
     for (int i = 0; i < nthr; ++i) {
-      int64_t tt = s_tiles[i], tt2 = s_tiles2[i], rr = s_rows[i];
+      int64_t tt = s_tiles[i], tt2 = s_tiles2[i], tt3 = s_tiles3[i], rr = s_rows[i];
       s_tiles[i] = t;
       s_tiles2[i] = t2;
+      s_tiles3[i] = t3;
       s_rows[i] = r;
       t += tt;
       t2 += tt2;
+      t3 += tt3;
       r += rr;
     }
     tile_start[B] = (int32_t)t;
     tile_start2[B] = (int32_t)t2;
+    tile_start3[B] = (int32_t)t3;
     row_start[B] = r;
   }
   __syncthreads();
-  int64_t t = s_tiles[tid], t2 = s_tiles2[tid], rs = s_rows[tid];
+  int64_t t = s_tiles[tid], t2 = s_tiles2[tid], t3 = s_tiles3[tid], rs = s_rows[tid];
   for (int64_t b = beg; b < end; ++b) {
     const int64_t p0 = ptr[b];
     int64_t r = ptr[b + 1] - p0;
@@ -119,9 +129,11 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
     descs[b] = d;
     tile_start[b] = (int32_t)t;
     tile_start2[b] = (int32_t)t2;
+    tile_start3[b] = (int32_t)t3;
     row_start[b] = rs;
     t += (r + kTileRows - 1) / kTileRows;
     t2 += (r + 2 * kTileRows - 1) / (2 * kTileRows);
+    t3 += (r + kPairRows - 1) / kPairRows;
     rs += r;
   }
 }
@@ -874,6 +886,329 @@ __global__ __launch_bounds__(512) void mfma_rows_cyc_kernel(const DevGroup* __re
           GU32x4* dst = (GU32x4*)(obase + (int64_t)r * MC * SZ + c * 16);
           if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
         }
+      }
+    }
+  }
+}
+
+// ---- 16-bit, K = 128, 128 output columns: ticket schedule, W in registers ---------------------------------------
+// What bounds the two kernels above is the WRITE side of HBM, and how well it is served depends on the order in which
+// the chip touches `out` (tools/lab: write-only sweeps of the same buffer run at 5.3 - 6.9 TB/s depending on nothing
+// but that order).  Measured on buffers the allocator placed unfavourably, three things matter, and they add up:
+//   1. tiles are handed out IN ADDRESS ORDER, as a non-persistent grid would be dispatched, not pre-assigned: a
+//      workgroup draws its next tile from a counter (one per XCD) when it gets there, so the window of rows in flight
+//      stays narrow however unevenly the waves progress;
+//   2. the XCDs are dealt chunks of 256 KiB (kChunkTiles tiles) of that order -- 32 and 64 KiB chunks are a resonance of
+//      the memory side (5.4 TB/s where 16 KiB or >= 128 KiB chunks give 6.2 - 6.6 for the same copy), and 256 KiB is the
+//      measured optimum for this kernel (192 / 320 / 512 KiB: 5.5 / 5.7 / 6.0 TB/s);
+//   3. few bytes in flight per CU: six waves with one tile ahead each (96 KiB) beat eight or twelve.
+// Six waves per CU cannot share a 32 KiB W through LDS three ways (3 x (32 + 2 x 16) KiB), so each wave keeps the
+// relation's W in REGISTERS: its 32 MFMA A fragments are 128 VGPRs, refilled through a 16 KiB staging area (two
+// halves, by LDS-DMA + ds_read_b64_tr_b16 exactly as in the cyclic kernel) when the relation changes -- at most once
+// per relation and workgroup, because a workgroup's tickets ascend.  A workgroup is a PAIR of waves (64-row tile):
+//   * X: LDS-DMA into two 8 KiB stages per wave, the next tile in flight while this one is multiplied.  The DMA is
+//     issued from inline asm so that the compiler does not know LDS is written behind its back -- it cannot tell the
+//     stage buffers or the ticket ring apart and would otherwise put s_waitcnt vmcnt(0) before every LDS access;
+//   * tickets: wave (s & 1) requests ticket s TWO tiles ahead with an asynchronous global atomic (inline asm, the
+//     return value is collected one iteration later) and hands it to its partner through a 4-slot LDS ring -- the two
+//     waves can never be more than two tickets apart, so no slot is overwritten before it was read;
+//   * every wait names exactly how many YOUNGER vector-memory operations may stay in flight (vmcnt retires in order):
+//     per iteration a wave issues [atomic] [8 DMA of tile i+1] ... [8 stores of tile i], always 8 stores (rows behind
+//     the segment end rewrite its last row with that row's own data), so neither the previous tile's stores nor the
+//     next tile's DMA are ever waited for;
+//   * the loop nest is (runs of one relation) x (tiles): W is loop-invariant in the inner loop, otherwise the register
+//     allocator copies all 128 registers around every iteration.
+// Lane-derived values are re-derived where used (v_mbcnt, two VALU ops) instead of living in VGPRs across the kernel.
+constexpr int kChunkTiles = 16;  // 16 x 64 rows x 256 B = 256 KiB of X (and of out) per XCD turn
+
+__device__ __forceinline__ void wait_vmcnt_16_17(int n) {  // steady state: 16 or 17 younger operations; else drain
+  if (n == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  else if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup* __restrict__ descs,
+                                                                  const int32_t* __restrict__ tile_start, int B,
+                                                                  unsigned int* __restrict__ tickets) {
+  constexpr int NT = 4, NI = 8, NO = 8;
+  typedef __attribute__((address_space(3))) void LDSV;
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  auto lane_now = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  char* wst = smem;                            // 16 KiB: W staging on a relation change, else 2 x 8 KiB epilogue scratch
+  char* xs0 = smem + 16384 + wave * 16384;     // this wave's two X stages
+  int* ring_val = (int*)(smem + 49152);        // [4] ticket values, [4] generations
+  int* ring_gen = ring_val + 4;
+  if (threadIdx.x < 8) ring_val[threadIdx.x] = 0;
+  __syncthreads();
+  const int k8 = blockIdx.x & 7;
+  const int total = tile_start[B];
+  unsigned int* my_ctr = tickets + k8 * 32;
+  auto tile_of = [&](int v) -> int { return ((v / kChunkTiles) * 8 + k8) * kChunkTiles + v % kChunkTiles; };
+
+  unsigned int raw = 0;  // lane 0: return value of the last request, valid once the matching wait has passed
+  auto request = [&]() {
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %[ret], %[off], %[one], %[base] sc0\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ret] "+v"(raw), [sv] "=&s"(sv)
+        : [off] "v"(0), [one] "v"(1u), [base] "s"(my_ctr)
+        : "memory");
+  };
+  auto publish = [&](int s) -> int {  // after the wait for the request
+    asm volatile("" : "+v"(raw));
+    const int v = __builtin_amdgcn_readfirstlane((int)raw);
+    if (lane_now() == 0) {
+      __hip_atomic_store(&ring_val[s & 3], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&ring_gen[s & 3], (s >> 2) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
+  };
+  auto consume = [&](int s) -> int {
+    int v = 0;
+    if (lane_now() == 0) {
+      while (__hip_atomic_load(&ring_gen[s & 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (s >> 2) + 1)
+        __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(&ring_val[s & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+
+  u32x4 wreg[NI][NT];  // A fragment of k-step s, column block tt (layout: see mfma_rows_cyc_kernel)
+  T* bias_lds = reinterpret_cast<T*>(smem + 49152 + 64);  // the relation's 128 bias values (read through LDS: a global
+                                                         // load in the epilogue would drag an s_waitcnt vmcnt(0) along)
+  auto load_w = [&](const char* w, const char* bias) {
+    const int lane = lane_now(), h = lane >> 5;
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const int dma_src_off = dma_r * 256 + dma_c * 16;
+    const int q = lane & 15, grp16 = lane >> 4;
+    const int a_lane_off = 8192 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {  // k-steps 4 r2 ... 4 r2 + 3: 1 KiB blocks {8 r2 ... 8 r2 + 7} of both k halves
+      __syncthreads();
+      if (r2 == 0 && bias) bias_lds[threadIdx.x] = reinterpret_cast<const T*>(bias)[threadIdx.x];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int kb = wave * 16 + r2 * 8 + jj;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                         (LDSV*)(wst + (wave * 8 + jj) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4) * 1024 + tt * 256));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4 + 1) * 1024 + tt * 256));
+          wreg[r2 * 4 + s4][tt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      }
+    }
+  };
+  // 16-byte chunk cs of row r of a stage holds chunk cs ^ (r & 15) of the X row (permuted on the source side)
+  struct Rel {  // the fields of a DevGroup this kernel uses (copying the whole struct sends its tail through scratch)
+    const char* a;
+    const char* w;
+    char* c;
+    const char* bias;
+    int64_t rows;
+  };
+  auto rel_of = [&](int gi) -> Rel {
+    const DevGroup* p = descs + gi;
+    return Rel{p->a, p->w, p->c, p->bias, p->rows};
+  };
+  auto issue_x = [&](const Rel& dg, int64_t row0, int buf) {
+    const uint32_t lds = (uint32_t)(size_t)(xs0 + buf * 8192);
+    const char* base = dg.a + row0 * 256;
+    const int64_t left = dg.rows - row0;
+    const int last = left < 32 ? (int)left - 1 : 31;
+    const int l = lane_now();
+    const int l4 = l >> 4, c0 = (l & 15) ^ l4;
+    uint32_t off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int r = 4 * i + l4;
+      const int c = c0 ^ (4 * (i & 3));
+      r = r > last ? last : r;
+      off[i] = (uint32_t)(r * 256 + c * 16);
+    }
+    uint32_t sv;
+    asm volatile(
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o4], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o5], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o6], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o7], %[base] nt\n\t"
+        "s_mov_b32 m0, %[sv]"
+        : [sv] "=&s"(sv)
+        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]),
+          [o4] "v"(off[4]), [o5] "v"(off[5]), [o6] "v"(off[6]), [o7] "v"(off[7])
+        : "memory", "scc");
+  };
+
+  // ticket 0 synchronously (wave 0); wave 1 requests ticket 1 only after that: a workgroup's tickets must ascend
+  int t_cur;
+  if (wave == 0) {
+    request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t_cur = tile_of(publish(0));
+  } else {
+    t_cur = tile_of(consume(0));
+    request();
+  }
+  if (t_cur >= total) return;
+  int g;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_cur) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  Rel d = rel_of(g);
+  int64_t row0 = (int64_t)(t_cur - tile_start[g]) * kPairRows + wave * 32;
+  bool valid = row0 < d.rows;
+  int d_cur = 0;  // DMA instructions of the current tile (issued one iteration ago)
+  if (valid) {
+    issue_x(d, row0, 0);
+    d_cur = 8;
+  }
+  int s_prev = 0;  // store instructions of the previous tile
+  int buf = 0, i = 0;
+  bool done = false;
+  while (!done) {  // one pass per run of tiles of the same relation
+    load_w(d.w, d.bias);
+    const int wcur = g;
+    for (;; ++i) {
+      // ticket i + 1 (requested one iteration ago by wave (i + 1) & 1; younger: this tile's DMA, the previous stores)
+      int v_next;
+      if (((i + 1) & 1) == wave) {
+        wait_vmcnt_16_17(d_cur + s_prev);
+        v_next = publish(i + 1);
+      } else {
+        v_next = consume(i + 1);
+      }
+      const int t_next = tile_of(v_next);
+      const bool more = t_next < total;
+      int a_now = 0;
+      if (more && ((i + 2) & 1) == wave) {
+        request();
+        a_now = 1;
+      }
+      int gn = g;
+      Rel dn = d;
+      int64_t n_row0 = 0;
+      bool n_valid = false;
+      int d_next = 0;
+      if (more) {
+        if (t_next >= tile_start[gn + 1]) {
+          do ++gn; while (t_next >= tile_start[gn + 1]);
+          dn = rel_of(gn);
+        }
+        n_row0 = (int64_t)(t_next - tile_start[gn]) * kPairRows + wave * 32;
+        n_valid = n_row0 < dn.rows;
+        if (n_valid) {
+          issue_x(dn, n_row0, buf ^ 1);
+          d_next = 8;
+        }
+      }
+      // this tile's X has landed (younger: the previous stores, the request, the next tile's DMA)
+      wait_vmcnt_16_17(s_prev + a_now + d_next);
+      int s_now = 0;
+      if (valid) {
+        const char* stage = xs0 + buf * 8192;
+        char* scratch = wst + wave * 8192;
+        const int lc = lane_now();
+        const int xo = lc & 31, h = lc >> 5;
+        const int cb = (NI * h) ^ (xo & 15);
+        const bool has_bias = d.bias != nullptr;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {  // one 32-column block at a time: 16 accumulators next to the 128 of W
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const char* xrow = stage + xo * 256;
+          u32x4 xa = *reinterpret_cast<const u32x4*>(xrow + cb * 16);
+#pragma unroll
+          for (int s = 0; s < NI; ++s) {
+            u32x4 xn = xa;
+            if (s + 1 < NI) xn = *reinterpret_cast<const u32x4*>(xrow + (cb ^ (s + 1)) * 16);
+            acc = mfma_chunk(T{}, wreg[s][tt], xa, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            xa = xn;
+          }
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[r];
+          if (has_bias) {
+            const T* bp = bias_lds + 64 * h + 16 * tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + r);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<u32x4*>(scratch + xo * 256 + (cb ^ (2 * tt + j)) * 16) = pack8(T{}, v + 8 * j);
+        }
+        // always 8 stores (the waits count them): lanes whose row lies behind the segment end rewrite its last row
+        char* obase = d.c + row0 * 256;
+        const int64_t left = d.rows - row0;
+        const int last = left < 32 ? (int)left - 1 : 31;
+        const int l = lane_now();
+        const int l4 = l >> 4, cs = l & 15;
+#pragma unroll
+        for (int ii = 0; ii < NO; ++ii) {
+          int r = 4 * ii + l4;
+          r = r > last ? last : r;
+          const u32x4 ov = *reinterpret_cast<const u32x4*>(scratch + r * 256 + cs * 16);
+          GU32x4* dst = (GU32x4*)(obase + (uint32_t)(r * 256 + (cs ^ (r & 15)) * 16));
+          __builtin_nontemporal_store(ov, dst);
+          if ((ii & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        s_now = 8;
+      }
+      if (!more) {
+        done = true;
+        break;
+      }
+      t_cur = t_next;
+      g = gn;
+      d = dn;
+      row0 = n_row0;
+      valid = n_valid;
+      d_cur = d_next;
+      s_prev = s_now;
+      buf ^= 1;
+      if (g != wcur) {
+        ++i;
+        break;
       }
     }
   }
@@ -1635,6 +1970,8 @@ struct Workspace {
   int64_t* row_start;   // also reused as out_start by the naive path
   int64_t* ptr_copy;
   int32_t* tile_start2;  // prefix of 256-row workgroup tiles (cyclic-schedule kernel)
+  int32_t* tile_start3;  // prefix of 64-row tiles (ticket kernel)
+  unsigned int* tickets; // kTicketWords counters of the ticket kernel, zero before its launch
   bool any_trans = false;  // host-side note: some group reads a transposed `other`
   int64_t rows_upper = 0;  // host-side note: upper bound of the rows of the call
 };
@@ -1646,6 +1983,8 @@ size_t workspace_bytes(int64_t B) {
   n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
   n += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
   n += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  n += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  n += sizeof(unsigned int) * kTicketWords;
   return n;
 }
 
@@ -1661,6 +2000,10 @@ Workspace carve(void* ws, int64_t B) {
   w.ptr_copy = reinterpret_cast<int64_t*>(p);
   p += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
   w.tile_start2 = reinterpret_cast<int32_t*>(p);
+  p += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  w.tile_start3 = reinterpret_cast<int32_t*>(p);
+  p += align_up(sizeof(int32_t) * (size_t)(B + 1), 256);
+  w.tickets = reinterpret_cast<unsigned int*>(p);
   return w;
 }
 
@@ -1819,7 +2162,22 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
     const DeviceInfo& di = device_info();
     const int sched = g_schedule;
     const bool big = w.rows_upper >= (int64_t)di.num_cus * 256 * 4;
-    if (K == 128 && M == 128 && !w.any_trans && (sched == 2 || (sched == 0 && big))) {
+    if (K == 128 && M == 128 && !w.any_trans && di.num_cus >= 8 && (sched == 3 || (sched == 0 && big))) {
+      snprintf(name, sizeof(name), "mfma_%s_k128_mc128_ticket", tname);
+      g_last_variant = name;
+      constexpr int lds = 16384 + 2 * 16384 + 64 + 256;  // W staging / epilogue scratch, 2 x 2 X stages, ticket ring, bias
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_ticket_kernel<T>);
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+      const int64_t tiles3_upper = (w.rows_upper + kPairRows - 1) / kPairRows + B;
+      int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles3_upper, 8), 3 * (int64_t)di.num_cus);
+      gx -= gx % 8;  // whole octets: every one of the 8 counters is served
+      ProfScope prof(stream);
+      hipLaunchKernelGGL((mfma_rows_ticket_kernel<T>), dim3((unsigned)gx), dim3(128), lds, stream, w.descs, w.tile_start3, B,
+                         w.tickets);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+    if (K == 128 && M == 128 && !w.any_trans && sched == 2) {
       snprintf(name, sizeof(name), "mfma_%s_k128_mc128_cyc", tname);
       g_last_variant = name;
       constexpr int lds = 2 * 128 * 128 * 2 + 8 * 8192;  // two W buffers + 8 stages = 128 KB
@@ -1944,7 +2302,7 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
-void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode == 1 || mode == 2) ? mode : 0; }
+void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 3) ? mode : 0; }
 
 void pyg_hip_profile_enable(int on) {
   g_prof_on = on != 0;
@@ -1985,7 +2343,7 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
   g_last_variant = "none";
   if (B == 0 || N == 0 || M == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(input && other && out, "segment_matmul: NULL tensor");
-  PYG_HIP_REQUIRE((N + kTileRows - 1) / kTileRows + B < (1LL << 31),
+  PYG_HIP_REQUIRE((N + kPairRows - 1) / kPairRows + B < (1LL << 31),
                   "segment_matmul: too many row tiles");
   if (workspace_bytes_ < workspace_bytes(B) || workspace == nullptr)
     return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul: workspace of %zu bytes needed, got %zu",
@@ -2012,7 +2370,7 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
   hipLaunchKernelGGL(plan_segments_kernel, dim3(1), dim3(256), 0, stream, dptr, B,
                      static_cast<const char*>(input), static_cast<const char*>(other),
                      static_cast<char*>(out), static_cast<const char*>(bias), K, M, (int)elt,
-                     w.descs, w.tile_start, w.row_start, w.tile_start2);
+                     w.descs, w.tile_start, w.row_start, w.tile_start2, w.tile_start3, w.tickets);
   PYG_HIP_CHECK(hipGetLastError());
   w.rows_upper = N;
   if (K == 0) {
@@ -2042,12 +2400,13 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   const size_t descs_b = align_up(sizeof(DevGroup) * (size_t)G, 256);
   const size_t tiles_b = align_up(sizeof(int32_t) * (size_t)(G + 1), 256);
   void* staged = nullptr;
-  int rc = pinned_stage().acquire(descs_b + 2 * tiles_b, &staged);
+  int rc = pinned_stage().acquire(descs_b + 3 * tiles_b, &staged);
   if (rc != PYG_HIP_OK) return rc;
   DevGroup* hd = static_cast<DevGroup*>(staged);
   int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b);
   int32_t* ht2 = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b + tiles_b);
-  int64_t tiles2 = 0, rows_total = 0;
+  int32_t* ht3 = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b + 2 * tiles_b);
+  int64_t tiles2 = 0, tiles3 = 0, rows_total = 0;
   bool uniform = true, any_trans = false;
   int64_t tiles = 0, out_elems = 0;
   for (int64_t i = 0; i < G; ++i) {
@@ -2069,7 +2428,10 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
     if (gr.other_trans) any_trans = true;
     ht[i] = (int32_t)tiles;
     ht2[i] = (int32_t)tiles2;
+    ht3[i] = (int32_t)tiles3;
     tiles2 += (hd[i].rows + 2 * kTileRows - 1) / (2 * kTileRows);
+    tiles3 += (hd[i].rows + kPairRows - 1) / kPairRows;
+    PYG_HIP_REQUIRE(tiles3 < (1LL << 31), "grouped_matmul: too many row tiles");
     rows_total += hd[i].rows;
     tiles += (hd[i].rows + kTileRows - 1) / kTileRows;
     out_elems += hd[i].rows * gr.m;
@@ -2079,12 +2441,16 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   w.rows_upper = rows_total;
   ht[G] = (int32_t)tiles;
   ht2[G] = (int32_t)tiles2;
+  ht3[G] = (int32_t)tiles3;
   PYG_HIP_CHECK(hipMemcpyAsync(w.descs, hd, sizeof(DevGroup) * (size_t)G, hipMemcpyHostToDevice,
                                stream));
   PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start, ht, sizeof(int32_t) * (size_t)(G + 1),
                                hipMemcpyHostToDevice, stream));
   PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start2, ht2, sizeof(int32_t) * (size_t)(G + 1),
                                hipMemcpyHostToDevice, stream));
+  PYG_HIP_CHECK(hipMemcpyAsync(w.tile_start3, ht3, sizeof(int32_t) * (size_t)(G + 1),
+                               hipMemcpyHostToDevice, stream));
+  PYG_HIP_CHECK(hipMemsetAsync(w.tickets, 0, sizeof(unsigned int) * kTicketWords, stream));
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;
   if (out_elems == 0) return PYG_HIP_OK;

@@ -145,10 +145,15 @@ def test_many_tiles_per_workgroup_vs_oracle(dtype, K, M, with_bias):
     assert torch.isfinite(out.float()).all()
 
 
-@pytest.fixture
-def cyclic_schedule():
-    ops.set_matmul_schedule('cyclic')
-    yield
+SCHED_SUFFIX = {'cyclic': '_cyc', 'ticket': '_ticket', 'contiguous': ''}
+
+
+@pytest.fixture(params=['cyclic', 'ticket'])
+def cyclic_schedule(request):
+    """The two schedules that replace the contiguous tile ranges on big inputs: banded cyclic (mfma_rows_cyc_kernel)
+    and tickets (mfma_rows_ticket_kernel: wave pairs, W in registers, tiles drawn from per-XCD counters)."""
+    ops.set_matmul_schedule(request.param)
+    yield SCHED_SUFFIX[request.param]
     ops.set_matmul_schedule('auto')
 
 
@@ -178,7 +183,7 @@ def test_cyclic_schedule_kernel_vs_oracle(cyclic_schedule, dtype, with_bias, ptr
     p = ptr.to(DEV) if ptr_on_device else ptr
     out = ops.segment_matmul(x.to(DEV), p, w.to(DEV), None if b is None else b.to(DEV))
     name = 'bf16' if dtype == torch.bfloat16 else 'f16'
-    assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128_cyc'
+    assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128{cyclic_schedule}'
     if dtype == torch.float16:
         ref = oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy(), None if b is None else b.numpy())
         np.testing.assert_allclose(out.cpu().float().numpy(), ref.astype(np.float32), rtol=2 ** -9, atol=2e-3)
@@ -199,7 +204,7 @@ def test_cyclic_schedule_one_relation_and_fewer_tiles_than_workgroups(cyclic_sch
         x = torch.randn(rows, 128, device=DEV).bfloat16()
         w = (torch.randn(1, 128, 128, device=DEV) / 11).bfloat16()
         out = ops.segment_matmul(x, torch.tensor([0, rows]), w)
-        assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128_cyc'
+        assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128' + cyclic_schedule
         ref = (x.float() @ w[0].float()).bfloat16()
         torch.testing.assert_close(out.float(), ref.float(), rtol=2 ** -6, atol=2e-2)
 
@@ -346,7 +351,7 @@ def test_grouped_matmul_pool_writes_into_the_callers_buffer():
         torch.ops.pyg.grouped_matmul_pool(ins, oth, pool)  # wrong number of rows
 
 
-@pytest.mark.parametrize('sched', ['cyclic', 'contiguous'])
+@pytest.mark.parametrize('sched', ['cyclic', 'ticket', 'contiguous'])
 def test_grouped_matmul_k128_both_schedules(sched):
     """grouped_matmul with uniform K = M = 128 reaches the same two kernels through the host-built tile tables."""
     torch.manual_seed(5)
@@ -358,7 +363,7 @@ def test_grouped_matmul_k128_both_schedules(sched):
         outs = ops.grouped_matmul([a.to(DEV) for a in ins], [o.to(DEV) for o in oth])
     finally:
         ops.set_matmul_schedule('auto')
-    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128' + ('_cyc' if sched == 'cyclic' else '')
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128' + SCHED_SUFFIX[sched]
     for a, o, out in zip(ins, oth, outs):
         ref = oracle.matmul(bits(a), bits(o), dtype=oracle.BF16)
         np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -7,
@@ -401,8 +406,9 @@ def test_full_size_c2_properties():
     w[torch.arange(B)[:, None], perm, torch.arange(F)[None, :]] = sign * scale[:, None]
     wd = w.bfloat16().to(DEV)
     seg = torch.repeat_interleave(torch.arange(B, device=DEV), sizes.to(DEV))
-    # both tile schedules (the automatic choice at this size is the cyclic kernel)
-    for mode, variant in (('auto', 'mfma_bf16_k128_mc128_cyc'), ('contiguous', 'mfma_bf16_k128_mc128')):
+    # all three tile schedules (the automatic choice at this size is the ticket kernel)
+    for mode, variant in (('auto', 'mfma_bf16_k128_mc128_ticket'), ('cyclic', 'mfma_bf16_k128_mc128_cyc'),
+                          ('contiguous', 'mfma_bf16_k128_mc128')):
         ops.set_matmul_schedule(mode)
         try:
             out = ops.segment_matmul(x, ptr, wd)

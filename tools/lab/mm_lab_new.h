@@ -442,12 +442,13 @@ __global__ __launch_bounds__(256) void copyv_kernel(const u32x4* __restrict__ in
 // stores it as the "output".  No MFMAs: what would the memory system give such a kernel?
 template <int NW, int RPW, int WLOAD>
 __global__ __launch_bounds__(NW * 64) void proxy_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, const char* __restrict__ w,
-                                                        long ntiles) {
+                                                        long ntiles, int xg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int XI = RPW * 256 / 1024;        // 1 KiB DMA instructions per wave for X
   constexpr int WI = 32768 / (NW * 1024);     // ... for the weight share
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long t = blockIdx.x;
+  const long bk = blockIdx.x & 7, bj = blockIdx.x >> 3;
+  const long t = xg > 1 ? (bj / xg) * (8L * xg) + bk * xg + bj % xg : (long)blockIdx.x;
   if (t >= ntiles) return;
   char* xs = smem + 32768 + wave * (RPW * 256);
   const char* src = (const char*)in + (t * NW + wave) * (RPW * 256);
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256) void pcopy_kernel(const u32x4* __restrict__ in
 // counter; the first wave to reach step i pulls the ticket and publishes it through LDS (no barrier).
 template <int U, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
-                                                         unsigned int* __restrict__ ctr, int dynamic) {
+                                                         unsigned int* __restrict__ ctr, int dynamic, int cg, int wait, int early) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* seq = (int*)smem;  // 2048 entries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -814,12 +815,12 @@ __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict
   __syncthreads();
   const int q8 = blockIdx.x & 7;
   int step = 0;
-  long stat = blockIdx.x;
+  long stat = blockIdx.x >> 3;
   auto pull = [&]() -> long {
     if (!dynamic) {
-      const long t = stat;
-      stat += gridDim.x;
-      return t;
+      const long sq = stat;
+      stat += gridDim.x >> 3;
+      return ((sq / cg) * 8 + q8) * cg + sq % cg;
     }
     int got = 0;
     if (lane == 0) {
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict
     }
     ++step;
     got = __builtin_amdgcn_readfirstlane(got);
-    return (long)got * 8 + q8;
+    return (((long)got / cg) * 8 + q8) * cg + got % cg;
   };
   u32x4 v[U], nx[U];
   long t = pull();
@@ -860,9 +861,12 @@ __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict
     while (t < ntiles) {
 #pragma unroll
       for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+      long t2 = 0;
+      if (early) t2 = pull();
 #pragma unroll
       for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
-      t = pull();
+      if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t = early ? t2 : pull();
     }
   }
 }
@@ -881,12 +885,700 @@ __global__ __launch_bounds__(256) void bigr_kernel(const u32x4* __restrict__ in,
     const long t = mode == 0 ? w * rep + r : (long)r * W + w;
     if (t >= ntiles) return;
     u32x4 v[U];
+    const int op = slp >> 8;
+    if (op == 1) {  // read only
+      u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+      for (int q = 0; q < U; ++q) acc ^= v[q];
+      if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) out[t] = acc;
+    } else if (op == 2) {  // write only
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        u32x4 z = {(unsigned)t, (unsigned)q, (unsigned)lane, 0u};
+        __builtin_nontemporal_store(z, (GU32x4*)(out + (t * U + q) * 64 + lane));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+    }
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int k = 0; k < (slp & 255); ++k) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+
+// XCD-interleave experiments.  bigx: non-persistent, one U KiB tile per wave, but XCD k (= blockIdx % 8) gets xg consecutive
+// workgroup spans (xg * 4 * U KiB contiguous) instead of one.  pcx: persistent static, the U KiB tiles are dealt round-robin
+// over XCDs (tile t -> XCD t % 8) when fine = 1, else in workgroup spans (4 tiles per XCD turn).
+template <int U>
+__global__ __launch_bounds__(256) void bigx_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles, int xg, int op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const long b = blockIdx.x, k = b & 7, j = b >> 3;
+  const long wg = (j / xg) * (8L * xg) + k * xg + (j % xg);
+  const long t = wg * 4 + wave;
+  if (t >= ntiles) return;
+  u32x4 v[U];
+  if (op != 2) {
 #pragma unroll
     for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+  } else {
+#pragma unroll
+    for (int q = 0; q < U; ++q) v[q] = u32x4{(unsigned)t, (unsigned)q, (unsigned)lane, 0u};
+  }
+  if (op == 1) {
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < U; ++q) acc ^= v[q];
+    if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) out[t] = acc;
+  } else {
 #pragma unroll
     for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
-    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int k = 0; k < slp; ++k) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void pcx_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles, int fine, int op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const long k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const long wpx = (long)(gridDim.x >> 3) * 4;  // waves per XCD
+  const long W = (long)gridDim.x * 4;
+  for (long r = 0;; ++r) {
+    const long t = fine ? (r * wpx + j * 4 + wave) * 8 + k : r * W + (long)blockIdx.x * 4 + wave;
+    if (t >= ntiles) break;
+    u32x4 v[U];
+    if (op != 2) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+    } else {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = u32x4{(unsigned)t, (unsigned)q, (unsigned)lane, 0u};
+    }
+    if (op == 1) {
+      u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < U; ++q) acc ^= v[q];
+      if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) out[t] = acc;
+    } else {
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+    }
+  }
+}
+
+
+// persistent static copy with workgroup tiles (NW waves x U KiB) and a chunked XCD deal: the XCD-local tile sequence s
+// (dealt cyclically to the XCD's workgroups) maps to global tile ((s / cg) * 8 + xcd) * cg + s % cg.
+template <int U, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64) void pcg_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles, int cg, int op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const long k = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+  auto tile_of = [&](long r) { const long sq = r * per + j; return ((sq / cg) * 8 + k) * cg + sq % cg; };
+  auto base = [&](long tile) { return (tile * NW + wave) * U * 64 + lane; };
+  u32x4 v[U], nx[U];
+  long r = 0;
+  long t = tile_of(r);
+  if (DEPTH && op == 0) {
+    if (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+    }
+    while (t < ntiles) {
+      const long t2 = tile_of(++r);
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = nx[q];
+      if (t2 < ntiles) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t2) + q * 64));
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      t = t2;
+    }
+  } else {
+    while (t < ntiles) {
+      if (op != 2) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+      } else {
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = u32x4{(unsigned)t, (unsigned)q, (unsigned)lane, 0u};
+      }
+      if (op == 1) {
+        u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < U; ++q) acc ^= v[q];
+        if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u) out[t] = acc;
+      } else {
+#pragma unroll
+        for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      }
+      t = tile_of(++r);
+    }
+  }
+}
+
+
+// wave-independent persistent copy: every wave (its own 64-thread workgroup) pulls tickets from its XCD's counter; a ticket
+// is REP consecutive 8 KiB tiles, copied one after the other with the next tile's loads in flight (DEPTH 1) or not (0);
+// ticket s of XCD k covers tiles (((s / cg) * 8 + k) * cg + s % cg) * REP ...; the next ticket is pulled one ticket early.
+template <int DEPTH>
+__global__ __launch_bounds__(64) void pcw_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
+                                                  unsigned int* __restrict__ ctr, int rep, int cg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int U = 8;
+  const int lane = threadIdx.x;
+  if (threadIdx.x == 100000) smem[0] = 1;
+  const int k = blockIdx.x & 7;
+  auto pull = [&]() -> long {
+    unsigned int s = 0;
+    if (lane == 0) s = atomicAdd(&ctr[k * 32], 1u);
+    s = __builtin_amdgcn_readfirstlane(s);
+    return (((long)(s / cg) * 8 + k) * cg + s % cg) * rep;
+  };
+  long cur = pull(), pend = pull();
+  int r = 0;
+  auto advance = [&]() -> long {  // next tile index (may be >= ntiles: the caller stops there)
+    if (++r < rep) return cur + r;
+    cur = pend;
+    r = 0;
+    if (cur < ntiles) pend = pull();
+    return cur;
+  };
+  u32x4 v[U], nx[U];
+  long t = cur;
+  if (DEPTH) {
+    if (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+    }
+    while (t < ntiles) {
+      const long t2 = advance();
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = nx[q];
+      if (t2 < ntiles) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t2 * U + q) * 64 + lane));
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+      t = t2;
+    }
+  } else {
+    while (t < ntiles) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + (t * U + q) * 64 + lane));
+#pragma unroll
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + (t * U + q) * 64 + lane));
+      t = advance();
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v6: wave-pair workgroups (2 waves x 32 rows = 64-row tiles, three per CU), the relation's W held in REGISTERS (the 32
+//     MFMA A fragments of a wave = 128 VGPRs, refilled through a 16 KiB LDS staging area on a relation change), X by
+//     LDS-DMA into two 8 KiB stages per wave (next tile in flight while this one is multiplied), tiles handed out IN
+//     ADDRESS ORDER by per-XCD ticket counters with the XCD deal in chunks of cg tiles
+//     (tile = ((s / cg) * 8 + xcd) * cg + s % cg).  The first wave of the pair to need ticket i pulls it and publishes
+//     it through a small LDS ring.
+// ------------------------------------------------------------------------------------------------
+template <int FLAGS, int DBG>
+__global__ __launch_bounds__(128, 2) void v6_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start,
+                                                    int B, unsigned int* __restrict__ ctr, int cg) {
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int XAUX = (FLAGS & 1) ? 2 : 0;
+  constexpr int NT = 4, NI = 8, NO = 8, R = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // lane-derived values are re-derived where they are used (two VALU ops) instead of living in VGPRs across the whole
+  // kernel: with 128 registers of W the allocator otherwise spills them and reloads them behind an s_waitcnt vmcnt(0)
+  auto lane_now = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  char* wst = smem;
+  char* xs0 = smem + 16384 + wave * 16384;
+  int* claim = (int*)(smem + 49152);
+  int* ready = claim + R;
+  int* val = ready + R;
+  int* prog = val + R;
+  for (int i = tid; i < 3 * R + 2; i += 128) claim[i] = 0;
+  __syncthreads();
+  const int k8 = blockIdx.x & 7;
+  const int total = tile_start[B];
+  int step = 0;
+  auto pull = [&]() -> int {
+    int v = 0;
+    if (lane_now() == 0) {
+      const int slot = step & (R - 1), lap = step / R;
+      while (min(__hip_atomic_load(&prog[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                 __hip_atomic_load(&prog[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + R <= step)
+        __builtin_amdgcn_s_sleep(1);
+      const int old = atomicCAS(&claim[slot], lap, lap + 1);
+      if (old == lap) {
+        v = (int)atomicAdd(&ctr[k8 * 32], 1u);
+        __hip_atomic_store(&val[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ready[slot], lap + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        while (__hip_atomic_load(&ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != lap + 1) __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(&val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __hip_atomic_store(&prog[wave], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    ++step;
+    v = __builtin_amdgcn_readfirstlane(v);
+    return ((v / cg) * 8 + k8) * cg + v % cg;
+  };
+
+  // W fragments: wreg[s][tt] = A operand of k-step s, column tile tt (see v3 for the LDS layout they are read from)
+  bf16x8 wreg[NI][NT];
+  auto load_w = [&](const char* w) {
+    const int lane = lane_now(), h = lane >> 5;
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const int dma_src_off = dma_r * 256 + dma_c * 16;
+    const int q = lane & 15, grp16 = lane >> 4;
+    const int a_lane_off = 8192 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int kb = wave * 16 + r2 * 8 + jj;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                         (LDSV*)(wst + (wave * 8 + jj) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4) * 1024 + tt * 256));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4 + 1) * 1024 + tt * 256));
+          wreg[r2 * 4 + s4][tt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      }
+    }
+  };
+  // per-lane pieces of the X / out addressing (16-byte chunk cs of row r sits at chunk cs ^ (r & 15) of the LDS row)
+  auto issue_x = [&](const DevGroup& dg, int64_t row0, int buf) {
+    char* xs = xs0 + buf * 8192;
+    const char* base = dg.a + row0 * 256;                       // wave-uniform
+    const int64_t left = dg.rows - row0;
+    const int last = left < 32 ? (int)left - 1 : 31;            // wave-uniform
+    const int l = lane_now();
+    const int l4 = l >> 4, c0 = (l & 15) ^ l4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int r = 4 * i + l4;
+      const int c = c0 ^ (4 * (i & 3));
+      r = r > last ? last : r;
+      const uint32_t off = (uint32_t)(r * 256 + c * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off), (LDSV*)(xs + i * 1024), 16, 0, XAUX);
+    }
+  };
+
+  int t_cur = pull();
+  if (t_cur >= total) return;
+  int g;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_cur) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  DevGroup d = descs[g];
+  int64_t row0 = (int64_t)(t_cur - tile_start[g]) * 64 + wave * 32;
+  bool valid = row0 < d.rows;
+  if (valid) issue_x(d, row0, 0);
+  int wcur = -1, buf = 0;
+  while (true) {
+    const int t_next = pull();
+    const bool more = t_next < total;
+    int gn = g;
+    DevGroup dn = d;
+    int64_t n_row0 = 0;
+    bool n_valid = false;
+    if (more) {
+      if (t_next >= tile_start[gn + 1]) {
+        do ++gn; while (t_next >= tile_start[gn + 1]);
+        dn = descs[gn];
+      }
+      n_row0 = (int64_t)(t_next - tile_start[gn]) * 64 + wave * 32;
+      n_valid = n_row0 < dn.rows;
+      if (n_valid) issue_x(dn, n_row0, buf ^ 1);
+    }
+    if (g != wcur) {
+      load_w(d.w);
+      wcur = g;
+    } else if (n_valid) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (valid) {
+      const char* stage = xs0 + buf * 8192;
+      char* scratch = wst + wave * 8192;
+      const int lc = lane_now();
+      const int xo = lc & 31, h = lc >> 5;
+      const int cb = (NI * h) ^ (xo & 15);  // LDS addresses below: one or two VALU ops each, recomputed per tile
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        if (!(DBG & 1)) {
+          const char* xrow = stage + xo * 256;
+          u32x4 xa = *reinterpret_cast<const u32x4*>(xrow + cb * 16);
+#pragma unroll
+          for (int s = 0; s < NI; ++s) {
+            u32x4 xn = xa;
+            if (s + 1 < NI) xn = *reinterpret_cast<const u32x4*>(xrow + (cb ^ (s + 1)) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][2 * half + j], __builtin_bit_cast(bf16x8, xa), acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            xa = xn;
+          }
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const int tt = 2 * half + j2;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[j2][r];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<u32x4*>(scratch + xo * 256 + (cb ^ (2 * tt + j)) * 16) = pack8(v + 8 * j);
+          }
+        }
+      }
+      char* obase = d.c + row0 * 256;                            // wave-uniform
+      const int64_t left = d.rows - row0;
+      const int nrow = left < 32 ? (int)left : 32;
+      const int l = lane_now();
+      const int l4 = l >> 4, c0 = (l & 15) ^ l4;
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(scratch + i * 1024 + l * 16);
+        const int r = 4 * i + l4;
+        const int c = c0 ^ (4 * (i & 3));
+        if (r < nrow) {
+          GU32x4* dst = (GU32x4*)(obase + (uint32_t)(r * 256 + c * 16));
+          if (NT_STORE) __builtin_nontemporal_store(ov, dst); else *dst = ov;
+        }
+      }
+    }
+    if (!more) break;
+    t_cur = t_next;
+    g = gn;
+    d = dn;
+    row0 = n_row0;
+    valid = n_valid;
+    buf ^= 1;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v7: v6 with the ticket two tiles ahead and exact vmcnt bookkeeping.  Ticket s is requested by wave (s & 1) of the
+//     pair with an asynchronous global atomic (inline asm: the compiler must not wait for it), collected one iteration
+//     later and handed to the partner through a 4-slot LDS ring (the two waves can never be more than two tickets
+//     apart).  Per iteration a wave issues, in this order: [atomic(i+2)] [8 DMA of tile i+1] ... [8 stores of tile i];
+//     every wait names exactly the number of YOUNGER operations it may leave in flight (vmcnt retires in order on
+//     gfx9), so neither the stores of the previous tile nor the next tile's DMA are ever waited for.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vm(int n) {  // steady state: 16 or 17 younger operations; anything else drains
+  if (n == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  else if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int FLAGS, int DBG>
+__global__ __launch_bounds__(128, 2) void v7_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start,
+                                                    int B, unsigned int* __restrict__ ctr, int cg) {
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int XAUX = (FLAGS & 1) ? 2 : 0;
+  constexpr int NT = 4, NI = 8, NO = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  auto lane_now = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  char* wst = smem;
+  char* xs0 = smem + 16384 + wave * 16384;
+  int* ring_val = (int*)(smem + 49152);  // [4]
+  int* ring_gen = ring_val + 4;          // [4]
+  if (threadIdx.x < 8) ring_val[threadIdx.x] = 0;
+  __syncthreads();
+  const int k8 = blockIdx.x & 7;
+  const int total = tile_start[B];
+  unsigned int* my_ctr = ctr + k8 * 32;
+  const int cgq = cg;
+  auto tile_of = [&](int v) -> int { return ((v / cgq) * 8 + k8) * cgq + v % cgq; };
+
+  unsigned int raw = 0;  // lane 0: the atomic's return value, valid once the matching wait has passed
+  auto request = [&]() {
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %[ret], %[off], %[one], %[base] sc0\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ret] "+v"(raw), [sv] "=&s"(sv)
+        : [off] "v"(0), [one] "v"(1u), [base] "s"(my_ctr)
+        : "memory");
+  };
+  auto publish = [&](int s) {  // after the wait for the atomic
+    asm volatile("" : "+v"(raw));
+    const int v = __builtin_amdgcn_readfirstlane((int)raw);
+    if (lane_now() == 0) {
+      __hip_atomic_store(&ring_val[s & 3], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&ring_gen[s & 3], (s >> 2) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
+  };
+  auto consume = [&](int s) -> int {
+    int v = 0;
+    if (lane_now() == 0) {
+      while (__hip_atomic_load(&ring_gen[s & 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (s >> 2) + 1) __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(&ring_val[s & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+
+  bf16x8 wreg[NI][NT];
+  auto load_w = [&](const char* w) {
+    const int lane = lane_now(), h = lane >> 5;
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const int dma_src_off = dma_r * 256 + dma_c * 16;
+    const int q = lane & 15, grp16 = lane >> 4;
+    const int a_lane_off = 8192 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int kb = wave * 16 + r2 * 8 + jj;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                         (LDSV*)(wst + (wave * 8 + jj) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4) * 1024 + tt * 256));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4 + 1) * 1024 + tt * 256));
+          wreg[r2 * 4 + s4][tt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      }
+    }
+  };
+  // The X DMA is issued from inline asm: the compiler then does not know that LDS is written behind its back and does not
+  // put an s_waitcnt vmcnt(0) in front of every LDS access that might alias the stage (it cannot tell the two stage
+  // buffers, or the ticket ring, apart) -- the waits are the explicit ones below.
+  auto issue_x = [&](const DevGroup& dg, int64_t row0, int buf) {
+    const uint32_t lds = (uint32_t)(size_t)(xs0 + buf * 8192);
+    const char* base = dg.a + row0 * 256;
+    const int64_t left = dg.rows - row0;
+    const int last = left < 32 ? (int)left - 1 : 31;
+    const int l = lane_now();
+    const int l4 = l >> 4, c0 = (l & 15) ^ l4;
+    uint32_t off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int r = 4 * i + l4;
+      const int c = c0 ^ (4 * (i & 3));
+      r = r > last ? last : r;
+      off[i] = (uint32_t)(r * 256 + c * 16);
+    }
+    uint32_t sv;
+    asm volatile(
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o4], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o5], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o6], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o7], %[base] nt\n\t"
+        "s_mov_b32 m0, %[sv]"
+        : [sv] "=&s"(sv)
+        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]),
+          [o4] "v"(off[4]), [o5] "v"(off[5]), [o6] "v"(off[6]), [o7] "v"(off[7])
+        : "memory", "scc");
+  };
+
+  // prologue: ticket 0 synchronously (wave 0), ticket 1 requested (wave 1)
+  int t_cur;
+  if (wave == 0) {
+    request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t_cur = tile_of(publish(0));
+  } else {
+    t_cur = tile_of(consume(0));
+    request();  // after ticket 0 has been drawn: a workgroup's tickets must ascend (the relation cursor only moves forward)
+  }
+  if (t_cur >= total) return;
+  int g;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_cur) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  DevGroup d = descs[g];
+  int64_t row0 = (int64_t)(t_cur - tile_start[g]) * 64 + wave * 32;
+  bool valid = row0 < d.rows;
+  int d_cur = 0;  // DMA instructions of the current tile (issued last iteration)
+  if (valid) {
+    issue_x(d, row0, 0);
+    d_cur = 8;
+  }
+  int s_prev = 0;  // store instructions of the previous tile that may still be in flight (0 when not known exactly)
+  int buf = 0, i = 0;
+  bool done = false;
+  // outer loop: one pass per run of tiles of the same relation (W is loop-invariant inside, so the 128 registers stay put)
+  while (!done) {
+  load_w(d.w);
+  const int wcur = g;
+  for (;; ++i) {
+    // S0: ticket i + 1 (requested one iteration ago by wave (i + 1) & 1; younger operations: this tile's DMA, the previous stores)
+    int v_next;
+    if (((i + 1) & 1) == wave) {
+      wait_vm(d_cur + s_prev);
+      v_next = publish(i + 1);
+    } else {
+      v_next = consume(i + 1);
+    }
+    const int t_next = tile_of(v_next);
+    const bool more = t_next < total;
+    // S1: request ticket i + 2
+    int a_now = 0;
+    if (more && ((i + 2) & 1) == wave) {
+      request();
+      a_now = 1;
+    }
+    // S2: next tile's DMA
+    int gn = g;
+    DevGroup dn = d;
+    int64_t n_row0 = 0;
+    bool n_valid = false;
+    int d_next = 0;
+    if (more) {
+      if (t_next >= tile_start[gn + 1]) {
+        do ++gn; while (t_next >= tile_start[gn + 1]);
+        dn = descs[gn];
+      }
+      n_row0 = (int64_t)(t_next - tile_start[gn]) * 64 + wave * 32;
+      n_valid = n_row0 < dn.rows;
+      if (n_valid) {
+        issue_x(dn, n_row0, buf ^ 1);
+        d_next = 8;
+      }
+    }
+    // S3: this tile's X has landed (younger: previous stores, the request, the next DMA)
+    wait_vm(s_prev + a_now + d_next);
+    int s_now = 0;
+    if (valid) {
+      const char* stage = xs0 + buf * 8192;
+      char* scratch = wst + wave * 8192;
+      const int lc = lane_now();
+      const int xo = lc & 31, h = lc >> 5;
+      const int cb = (NI * h) ^ (xo & 15);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {  // one 32-column block at a time: 16 accumulator registers next to the 128 of W
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!(DBG & 1)) {
+          const char* xrow = stage + xo * 256;
+          u32x4 xa = *reinterpret_cast<const u32x4*>(xrow + cb * 16);
+#pragma unroll
+          for (int s = 0; s < NI; ++s) {
+            u32x4 xn = xa;
+            if (s + 1 < NI) xn = *reinterpret_cast<const u32x4*>(xrow + (cb ^ (s + 1)) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][tt], __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            xa = xn;
+          }
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          *reinterpret_cast<u32x4*>(scratch + xo * 256 + (cb ^ (2 * tt + j)) * 16) = pack8(v + 8 * j);
+      }
+      // 8 unconditional stores (the wait bookkeeping counts them): lanes whose row lies behind the segment end rewrite the
+      // segment's last row with that row's own data
+      char* obase = d.c + row0 * 256;
+      const int64_t left = d.rows - row0;
+      const int last = left < 32 ? (int)left - 1 : 31;
+      const int l = lane_now();
+      const int l4 = l >> 4, cs = l & 15;
+#pragma unroll
+      for (int ii = 0; ii < NO; ++ii) {
+        int r = 4 * ii + l4;
+        r = r > last ? last : r;
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(scratch + r * 256 + cs * 16);
+        GU32x4* dst = (GU32x4*)(obase + (uint32_t)(r * 256 + (cs ^ (r & 15)) * 16));
+        if (NT_STORE) __builtin_nontemporal_store(ov, dst); else *dst = ov;
+        if ((ii & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      s_now = 8;
+    }
+    if (!more) {
+      done = true;
+      break;
+    }
+    t_cur = t_next;
+    g = gn;
+    d = dn;
+    row0 = n_row0;
+    valid = n_valid;
+    d_cur = d_next;
+    s_prev = s_now;
+    buf ^= 1;
+    if (g != wcur) {
+      ++i;
+      break;
+    }
+  }
   }
 }
 
@@ -965,7 +1657,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   }
 
   if (name == "proxy") {
-    const int nw = opt("nw", 8), rpw = opt("rpw", 16), wl = opt("w", 1), pad = opt("pad", 0);
+    const int nw = opt("nw", 8), rpw = opt("rpw", 16), wl = opt("w", 1), pad = opt("pad", 0), xg = opt("xg", 1);
     const long nbytes = c.rows * 256;
     const long ntiles = nbytes / ((long)nw * rpw * 256);
     const int lds = 32768 + nw * rpw * 256 + pad;
@@ -977,7 +1669,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     float best = 1e30f, sum = 0;
     for (int i = 0; i < 7; ++i) {
       CK(hipEventRecord(e0));
-#define PX(N, R, W) if (nw == N && rpw == R && wl == W) { CK(hipFuncSetAttribute((const void*)&proxy_kernel<N, R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((proxy_kernel<N, R, W>), dim3((unsigned)ntiles), dim3(N * 64), lds, 0, in, out, (const char*)c.w, ntiles); }
+#define PX(N, R, W) if (nw == N && rpw == R && wl == W) { CK(hipFuncSetAttribute((const void*)&proxy_kernel<N, R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((proxy_kernel<N, R, W>), dim3((unsigned)((ntiles + 8 * xg - 1) / (8 * xg) * (8 * xg))), dim3(N * 64), lds, 0, in, out, (const char*)c.w, ntiles, xg); }
       PX(8, 16, 1) PX(8, 16, 0) PX(4, 32, 1) PX(4, 32, 0) PX(4, 16, 1) PX(8, 32, 1) PX(8, 8, 1) PX(16, 8, 1) PX(16, 16, 1) PX(2, 32, 1) PX(8, 4, 1) PX(16, 4, 1)
 #undef PX
       CK(hipEventRecord(e1));
@@ -996,8 +1688,10 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   if (name == "v4") {
     const int flags = opt("flags", 3), dbg = opt("dbg", 0), pad = opt("pad", 0);
     static TileRec* drec = nullptr;
-    static int ntiles = 0;
-    if (!drec) {
+    static int ntiles = 0, last_xg = -1;
+    if (!drec || last_xg != opt("xg", 1)) {
+      last_xg = opt("xg", 1);
+      if (drec) CK(hipFree(drec));
       std::vector<TileRec> hr;
       for (int b = 0; b < c.B; ++b) {
         const int64_t n = c.ptr[b + 1] - c.ptr[b];
@@ -1012,6 +1706,19 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
         }
       }
       ntiles = (int)hr.size();
+      const int xg = opt("xg", 1);
+      if (xg > 1) {  // block b (XCD b % 8) takes tile (j / xg) * 8 * xg + (b % 8) * xg + j % xg, j = b / 8
+        std::vector<TileRec> pr;
+        TileRec none = hr[0];
+        none.rows = 0;
+        const long span = 8L * xg, nb = (ntiles + span - 1) / span * span;
+        for (long b = 0; b < nb; ++b) {
+          const long k = b & 7, j = b >> 3, t = (j / xg) * span + k * xg + j % xg;
+          pr.push_back(t < ntiles ? hr[t] : none);
+        }
+        hr.swap(pr);
+        ntiles = (int)hr.size();
+      }
       CK(hipMalloc(&drec, hr.size() * sizeof(TileRec)));
       CK(hipMemcpy(drec, hr.data(), hr.size() * sizeof(TileRec), hipMemcpyHostToDevice));
     }
@@ -1091,7 +1798,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   }
 
   if (name == "pcopy2") {
-    const int u = opt("u", 4), nw = opt("nw", 16), depth = opt("depth", 1), wgs = opt("wgs", 1), dyn = opt("dyn", 1), lds = opt("lds", 8192);
+    const int u = opt("u", 4), nw = opt("nw", 16), depth = opt("depth", 1), wgs = opt("wgs", 1), dyn = opt("dyn", 1), lds = opt("lds", 8192), cg = opt("cg", 1), wait = opt("wait", 0), early = opt("early", 0);
     const long nbytes = c.rows * 256;
     const long ntiles = nbytes / ((long)u * 1024 * nw);
     static unsigned int* ctr = nullptr;
@@ -1105,8 +1812,8 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     for (int i = 0; i < 7; ++i) {
       CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
       CK(hipEventRecord(e0));
-#define PC(UU, NN, PP) if (u == UU && nw == NN && depth == PP) { CK(hipFuncSetAttribute((const void*)&pcopy2_kernel<UU, NN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcopy2_kernel<UU, NN, PP>), dim3(c.cus * wgs), dim3(NN * 64), lds, 0, in, out, ntiles, ctr, dyn); }
-      PC(4, 16, 1) PC(4, 16, 0) PC(8, 8, 1) PC(8, 8, 0) PC(4, 8, 1) PC(4, 8, 0) PC(2, 16, 1) PC(2, 16, 0) PC(4, 4, 1) PC(4, 4, 0) PC(8, 4, 1)
+#define PC(UU, NN, PP) if (u == UU && nw == NN && depth == PP) { CK(hipFuncSetAttribute((const void*)&pcopy2_kernel<UU, NN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcopy2_kernel<UU, NN, PP>), dim3(c.cus * wgs), dim3(NN * 64), lds, 0, in, out, ntiles, ctr, dyn, cg, wait, early); }
+      PC(4, 16, 1) PC(4, 16, 0) PC(8, 8, 1) PC(8, 8, 0) PC(4, 8, 1) PC(4, 8, 0) PC(2, 16, 1) PC(2, 16, 0) PC(4, 4, 1) PC(4, 4, 0) PC(8, 4, 1) PC(8, 4, 0) PC(2, 8, 0) PC(2, 4, 0) PC(1, 4, 0) PC(1, 8, 0) PC(8, 2, 0) PC(8, 2, 1) PC(8, 12, 0) PC(8, 12, 1) PC(8, 6, 0) PC(8, 6, 1)
 #undef PC
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
@@ -1123,7 +1830,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   }
 
   if (name == "bigr") {
-    const int u = opt("u", 4), lds = opt("lds", 40960), rep = opt("rep", 1), mode = opt("mode", 0), wait = opt("wait", 0), slp = opt("slp", 0);
+    const int u = opt("u", 4), lds = opt("lds", 40960), rep = opt("rep", 1), mode = opt("mode", 0), wait = opt("wait", 0), slp = opt("slp", 0) + 256 * opt("op", 0);
     const long nbytes = c.rows * 256;
     const long ntiles = nbytes / (u * 1024);
     hipEvent_t e0, e1;
@@ -1145,10 +1852,142 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
     }
+    const double bytes = (opt("op", 0) ? 1.0 : 2.0) * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "bigx" || name == "pcx") {
+    const int u = opt("u", 4), lds = opt("lds", name == "bigx" ? 40960 : 0), xg = opt("xg", 1), op = opt("op", 0), fine = opt("fine", 1), wgs = opt("wgs", 4);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / (u * 1024);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipEventRecord(e0));
+      unsigned gb = (unsigned)((ntiles + 3) / 4);
+      gb = (gb + 8 * xg - 1) / (8 * xg) * (8 * xg);
+#define PC(UU) if (u == UU) { if (name == "bigx") { CK(hipFuncSetAttribute((const void*)&bigx_kernel<UU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((bigx_kernel<UU>), dim3(gb), dim3(256), lds, 0, in, out, ntiles, xg, op); } else { if (lds) CK(hipFuncSetAttribute((const void*)&pcx_kernel<UU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcx_kernel<UU>), dim3(c.cus * wgs), dim3(256), lds, 0, in, out, ntiles, fine, op); } }
+      PC(1) PC(2) PC(4) PC(8)
+#undef PC
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = (op ? 1.0 : 2.0) * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "pcg") {
+    const int u = opt("u", 8), nw = opt("nw", 8), depth = opt("depth", 1), wgs = opt("wgs", 1), cg = opt("cg", 1), op = opt("op", 0), lds = opt("lds", 0);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / ((long)u * 1024 * nw);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipEventRecord(e0));
+#define PC(UU, NN, PP) if (u == UU && nw == NN && depth == PP) { if (lds) CK(hipFuncSetAttribute((const void*)&pcg_kernel<UU, NN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcg_kernel<UU, NN, PP>), dim3(c.cus * wgs), dim3(NN * 64), lds, 0, in, out, ntiles, cg, op); }
+      PC(8, 8, 1) PC(8, 8, 0) PC(4, 16, 1) PC(4, 16, 0) PC(4, 8, 1) PC(4, 8, 0) PC(4, 4, 1) PC(4, 4, 0) PC(8, 4, 1) PC(8, 4, 0)
+#undef PC
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = (op ? 1.0 : 2.0) * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
+    return true;
+  }
+
+  if (name == "pcw") {
+    const int depth = opt("depth", 1), wpc = opt("wpc", 6), rep = opt("rep", 4), cgb = opt("cgk", 512);
+    const int lds = opt("lds", 160 * 1024 / wpc - 1024);
+    const int cg = cgb / (8 * rep) > 0 ? cgb / (8 * rep) : 1;  // chunk of cgk KiB
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / 8192;
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    for (int i = 0; i < 7; ++i) {
+      CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
+      CK(hipEventRecord(e0));
+      if (depth) { CK(hipFuncSetAttribute((const void*)&pcw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcw_kernel<1>), dim3(c.cus * wpc), dim3(64), lds, 0, in, out, ntiles, ctr, rep, cg); }
+      else { CK(hipFuncSetAttribute((const void*)&pcw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); hipLaunchKernelGGL((pcw_kernel<0>), dim3(c.cus * wpc), dim3(64), lds, 0, in, out, ntiles, ctr, rep, cg); }
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
     const double bytes = 2.0 * nbytes;
     if (g_round == 0)
       printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
     fflush(stdout);
+    return true;
+  }
+
+  if (name == "v6" || name == "v7") {
+    const int flags = opt("flags", 3), dbg = opt("dbg", 0), wgs = opt("wgs", 3), cgk = opt("cgk", 512);
+    const int cg = cgk / 16 > 0 ? cgk / 16 : 1;
+    std::vector<int32_t> ht(c.B + 1);
+    long tiles = 0;
+    for (int b = 0; b < c.B; ++b) {
+      ht[b] = (int32_t)tiles;
+      tiles += (c.ptr[b + 1] - c.ptr[b] + 63) / 64;
+    }
+    ht[c.B] = (int32_t)tiles;
+    int32_t* dt;
+    CK(hipMalloc(&dt, (c.B + 1) * 4));
+    CK(hipMemcpy(dt, ht.data(), (c.B + 1) * 4, hipMemcpyHostToDevice));
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    const int lds = opt("lds", 49152 + 1024);
+    const int grid = c.cus * wgs;
+    bool done = false;
+#define V6_CASE(F, D)                                                                                          \
+  if (flags == F && dbg == D) {                                                                                \
+    CK(hipFuncSetAttribute((const void*)&v6_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));   \
+    bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v6_kernel<F, D>), dim3(grid), dim3(128), lds, 0, c.descs, dt, c.B, ctr, cg); }); \
+    done = true;                                                                                               \
+  }
+    if (name == "v6") { V6_CASE(3, 0) V6_CASE(0, 0) V6_CASE(3, 1) V6_CASE(2, 0) V6_CASE(1, 0) }
+#undef V6_CASE
+#define V7_CASE(F, D)                                                                                          \
+  if (name == "v7" && flags == F && dbg == D) {                                                                \
+    CK(hipFuncSetAttribute((const void*)&v7_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));   \
+    bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v7_kernel<F, D>), dim3(grid), dim3(128), lds, 0, c.descs, dt, c.B, ctr, cg); }); \
+    done = true;                                                                                               \
+  }
+    V7_CASE(3, 0) V7_CASE(0, 0) V7_CASE(3, 1) V7_CASE(2, 0) V7_CASE(1, 0)
+#undef V7_CASE
+    CK(hipFree(dt));
+    if (!done && g_round == 0) printf("%s: no such v6 variant\n", spec.c_str());
     return true;
   }
   if (name == "rw") {
