@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-end evidence on the GPU box: bench lines, rocprofv3 kernel stats of the same command, PMC passes (own runs).
+#   tools/profile_round.sh <out dir under gpurun_out/>
+R=/root/repo/gpurun_out/$1
+mkdir -p $R
+cd /tmp && export TMPDIR=/tmp
+python /root/repo/bench.py > $R/bench_full_1.json 2> $R/bench_full_1.err
+python /root/repo/bench.py > $R/bench_full_2.json 2> $R/bench_full_2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_bench -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 > $R/bench_under_rocprof.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_mm_$c -o p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sampler --no-legs > $R/pmc_mm_$c.log 2>&1
+done
+python /root/repo/bench.py --dtype f32 --no-sampler > $R/bench_f32.json 2> $R/bench_f32.err
