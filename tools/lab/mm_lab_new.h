@@ -808,6 +808,8 @@ __global__ __launch_bounds__(256) void pcopy_kernel(const u32x4* __restrict__ in
 template <int U, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
                                                          unsigned int* __restrict__ ctr, int dynamic, int cg, int wait, int early) {
+  const int perm = wait >> 4;
+  wait &= 15;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* seq = (int*)smem;  // 2048 entries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -839,11 +841,13 @@ __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict
   };
   u32x4 v[U], nx[U];
   long t = pull();
-  auto base = [&](long tile) { return (tile * NW + wave) * U * 64 + lane; };
+  // perm: 16-byte chunk cs of row r goes to / comes from chunk cs ^ (r & 15) (the MFMA kernels' stage swizzle); row = 4 q + lane / 16
+  auto base = [&](long tile) { return (tile * NW + wave) * U * 64 + (perm ? 0 : lane); };
+  auto pl = [&](int q) { return perm ? ((lane & ~15) | ((lane & 15) ^ ((4 * q + (lane >> 4)) & 15))) : 0; };
   if (DEPTH) {
     if (t < ntiles) {
 #pragma unroll
-      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+      for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64 + pl(q)));
     }
     while (t < ntiles) {
       const long t2 = pull();
@@ -851,20 +855,20 @@ __global__ __launch_bounds__(NW * 64) void pcopy2_kernel(const u32x4* __restrict
       for (int q = 0; q < U; ++q) v[q] = nx[q];
       if (t2 < ntiles) {
 #pragma unroll
-        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t2) + q * 64));
+        for (int q = 0; q < U; ++q) nx[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t2) + q * 64 + pl(q)));
       }
 #pragma unroll
-      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64 + pl(q)));
       t = t2;
     }
   } else {
     while (t < ntiles) {
 #pragma unroll
-      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64));
+      for (int q = 0; q < U; ++q) v[q] = __builtin_nontemporal_load((const GU32x4*)(in + base(t) + q * 64 + pl(q)));
       long t2 = 0;
       if (early) t2 = pull();
 #pragma unroll
-      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64));
+      for (int q = 0; q < U; ++q) __builtin_nontemporal_store(v[q], (GU32x4*)(out + base(t) + q * 64 + pl(q)));
       if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       t = early ? t2 : pull();
     }
@@ -1493,6 +1497,12 @@ __global__ __launch_bounds__(128, 2) void v7_kernel(const DevGroup* __restrict__
       request();
       a_now = 1;
     }
+    if (DBG & 2) {  // proxy order: this tile's X first, then the next tile's DMA (one tile of loads in flight)
+      const int n = s_prev + a_now;
+      if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // S2: next tile's DMA
     int gn = g;
     DevGroup dn = d;
@@ -1512,7 +1522,7 @@ __global__ __launch_bounds__(128, 2) void v7_kernel(const DevGroup* __restrict__
       }
     }
     // S3: this tile's X has landed (younger: previous stores, the request, the next DMA)
-    wait_vm(s_prev + a_now + d_next);
+    if (!(DBG & 2)) wait_vm(s_prev + a_now + d_next);
     int s_now = 0;
     if (valid) {
       const char* stage = xs0 + buf * 8192;
@@ -1581,6 +1591,337 @@ __global__ __launch_bounds__(128, 2) void v7_kernel(const DevGroup* __restrict__
   }
   }
 }
+
+
+// pcopy2 (nw = 2, u = 8, depth 1, WG tickets) with the loads done by LDS-DMA from inline asm into two 8 KiB stages per wave
+// and the stores fed from LDS: does the DMA path itself cost bandwidth against VGPR loads?
+__global__ __launch_bounds__(128) void pcopyd_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long ntiles,
+                                                     unsigned int* __restrict__ ctr, int cg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* seq = (int*)(smem + 32768);  // 2048 entries
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 2048; i += 128) seq[i] = -1;
+  __syncthreads();
+  const int q8 = blockIdx.x & 7;
+  int step = 0;
+  auto pull = [&]() -> long {
+    int got = 0;
+    if (lane == 0) {
+      int v = atomicCAS(&seq[step], -1, -2);
+      if (v == -1) {
+        v = (int)atomicAdd(&ctr[q8 * 32], 1u);
+        __hip_atomic_store(&seq[step], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        while (v < 0) v = __hip_atomic_load(&seq[step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      got = v;
+    }
+    ++step;
+    got = __builtin_amdgcn_readfirstlane(got);
+    return (((long)got / cg) * 8 + q8) * cg + got % cg;
+  };
+  char* xs0 = smem + wave * 16384;
+  auto issue = [&](long tile, int buf) {
+    const uint32_t lds = (uint32_t)(size_t)(xs0 + buf * 8192);
+    const char* base = (const char*)in + (tile * 2 + wave) * 8192;
+    uint32_t off[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) off[q] = lane * 16 + q * 1024;
+    uint32_t sv;
+    asm volatile(
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o4], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o5], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o6], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o7], %[base] nt\n\t"
+        "s_mov_b32 m0, %[sv]"
+        : [sv] "=&s"(sv)
+        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]),
+          [o4] "v"(off[4]), [o5] "v"(off[5]), [o6] "v"(off[6]), [o7] "v"(off[7])
+        : "memory", "scc");
+  };
+  long t = pull();
+  int buf = 0;
+  if (t < ntiles) issue(t, 0);
+  while (t < ntiles) {
+    const long t2 = pull();
+    if (t2 < ntiles) {
+      issue(t2, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* st = xs0 + buf * 8192;
+    u32x4* dst = out + (t * 2 + wave) * 512 + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(st + q * 1024 + lane * 16);
+      __builtin_nontemporal_store(v, (GU32x4*)(dst + q * 64));
+    }
+    t = t2;
+    buf ^= 1;
+  }
+}
+
+template <int FLAGS, int DBG>
+__global__ __launch_bounds__(128, 2) void v8_kernel(const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start,
+                                                    int B, unsigned int* __restrict__ ctr, int cg) {
+  constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  constexpr int XAUX = (FLAGS & 1) ? 2 : 0;
+  constexpr int NT = 4, NI = 8, NO = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  auto lane_now = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  char* wst = smem;
+  char* xs0 = smem + 16384 + wave * 8192;
+  int* ring_val = (int*)(smem + 32768);  // [4]
+  int* ring_gen = ring_val + 4;          // [4]
+  if (threadIdx.x < 8) ring_val[threadIdx.x] = 0;
+  __syncthreads();
+  const int k8 = blockIdx.x & 7;
+  const int total = tile_start[B];
+  unsigned int* my_ctr = ctr + k8 * 32;
+  const int cgq = cg;
+  auto tile_of = [&](int v) -> int { return ((v / cgq) * 8 + k8) * cgq + v % cgq; };
+
+  unsigned int raw = 0;  // lane 0: the atomic's return value, valid once the matching wait has passed
+  auto request = [&]() {
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %[ret], %[off], %[one], %[base] sc0\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ret] "+v"(raw), [sv] "=&s"(sv)
+        : [off] "v"(0), [one] "v"(1u), [base] "s"(my_ctr)
+        : "memory");
+  };
+  auto publish = [&](int s) {  // after the wait for the atomic
+    asm volatile("" : "+v"(raw));
+    const int v = __builtin_amdgcn_readfirstlane((int)raw);
+    if (lane_now() == 0) {
+      __hip_atomic_store(&ring_val[s & 3], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&ring_gen[s & 3], (s >> 2) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
+  };
+  auto consume = [&](int s) -> int {
+    int v = 0;
+    if (lane_now() == 0) {
+      while (__hip_atomic_load(&ring_gen[s & 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (s >> 2) + 1) __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(&ring_val[s & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+
+  bf16x8 wreg[NI][NT];
+  auto load_w = [&](const char* w) {
+    const int lane = lane_now(), h = lane >> 5;
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const int dma_src_off = dma_r * 256 + dma_c * 16;
+    const int q = lane & 15, grp16 = lane >> 4;
+    const int a_lane_off = 8192 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int kb = wave * 16 + r2 * 8 + jj;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + kb * 1024 + dma_src_off),
+                                         (LDSV*)(wst + (wave * 8 + jj) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4) * 1024 + tt * 256));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wst + a_lane_off + (2 * s4 + 1) * 1024 + tt * 256));
+          wreg[r2 * 4 + s4][tt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      }
+    }
+  };
+  // X goes HBM -> registers (8 x 16 bytes per lane, whole rows per instruction) -> the wave's stage; the compiler places
+  // the wait for the registers itself (it knows these loads and the stores; the asm atomic is older than the loads)
+  u32x4 xr[NI];
+  auto issue_x = [&](const DevGroup& dg, int64_t row0) {
+    const char* base = dg.a + row0 * 256;
+    const int64_t left = dg.rows - row0;
+    const int last = left < 32 ? (int)left - 1 : 31;
+    const int l = lane_now();
+    const int l4 = l >> 4, c0 = (l & 15) ^ l4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int r = 4 * i + l4;
+      const int c = c0 ^ (4 * (i & 3));
+      r = r > last ? last : r;
+      xr[i] = __builtin_nontemporal_load((const GU32x4*)(base + (uint32_t)(r * 256 + c * 16)));
+    }
+  };
+  auto stage_x = [&]() {
+    const int l = lane_now();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(xs0 + i * 1024 + l * 16) = xr[i];
+  };
+
+  // prologue: ticket 0 synchronously (wave 0), ticket 1 requested (wave 1)
+  int t_cur;
+  if (wave == 0) {
+    request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t_cur = tile_of(publish(0));
+  } else {
+    t_cur = tile_of(consume(0));
+    request();  // after ticket 0 has been drawn: a workgroup's tickets must ascend (the relation cursor only moves forward)
+  }
+  if (t_cur >= total) return;
+  int g;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_cur) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  DevGroup d = descs[g];
+  int64_t row0 = (int64_t)(t_cur - tile_start[g]) * 64 + wave * 32;
+  bool valid = row0 < d.rows;
+  int d_cur = 0;  // DMA instructions of the current tile (issued last iteration)
+  if (valid) {
+    issue_x(d, row0);
+    stage_x();
+    d_cur = 0;
+  }
+  int s_prev = 0;  // store instructions of the previous tile that may still be in flight (0 when not known exactly)
+  int buf = 0, i = 0;
+  bool done = false;
+  // outer loop: one pass per run of tiles of the same relation (W is loop-invariant inside, so the 128 registers stay put)
+  while (!done) {
+  load_w(d.w);
+  const int wcur = g;
+  for (;; ++i) {
+    // S0: ticket i + 1 (requested one iteration ago by wave (i + 1) & 1; younger operations: this tile's DMA, the previous stores)
+    int v_next;
+    if (DBG & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (((i + 1) & 1) == wave) {
+      if (s_prev == 8 && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      v_next = publish(i + 1);
+    } else {
+      v_next = consume(i + 1);
+    }
+    const int t_next = tile_of(v_next);
+    const bool more = t_next < total;
+    // S1: request ticket i + 2
+    int a_now = 0;
+    if (more && ((i + 2) & 1) == wave) {
+      request();
+      a_now = 1;
+    }
+    // S2: next tile's DMA
+    int gn = g;
+    DevGroup dn = d;
+    int64_t n_row0 = 0;
+    bool n_valid = false;
+    int d_next = 0;
+    if (more) {
+      if (t_next >= tile_start[gn + 1]) {
+        do ++gn; while (t_next >= tile_start[gn + 1]);
+        dn = descs[gn];
+      }
+      n_row0 = (int64_t)(t_next - tile_start[gn]) * 64 + wave * 32;
+      n_valid = n_row0 < dn.rows;
+      if (n_valid) issue_x(dn, n_row0);
+    }
+    // S3: this tile's X has landed (younger: previous stores, the request, the next DMA)
+    int s_now = 0;
+    if (valid) {
+      const char* stage = xs0;
+      char* scratch = wst + wave * 8192;
+      const int lc = lane_now();
+      const int xo = lc & 31, h = lc >> 5;
+      const int cb = (NI * h) ^ (xo & 15);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {  // one 32-column block at a time: 16 accumulator registers next to the 128 of W
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!(DBG & 1)) {
+          const char* xrow = stage + xo * 256;
+          u32x4 xa = *reinterpret_cast<const u32x4*>(xrow + cb * 16);
+#pragma unroll
+          for (int s = 0; s < NI; ++s) {
+            u32x4 xn = xa;
+            if (s + 1 < NI) xn = *reinterpret_cast<const u32x4*>(xrow + (cb ^ (s + 1)) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s][tt], __builtin_bit_cast(bf16x8, xa), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            xa = xn;
+          }
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          *reinterpret_cast<u32x4*>(scratch + xo * 256 + (cb ^ (2 * tt + j)) * 16) = pack8(v + 8 * j);
+      }
+      // 8 unconditional stores (the wait bookkeeping counts them): lanes whose row lies behind the segment end rewrite the
+      // segment's last row with that row's own data
+      char* obase = d.c + row0 * 256;
+      const int64_t left = d.rows - row0;
+      const int last = left < 32 ? (int)left - 1 : 31;
+      const int l = lane_now();
+      const int l4 = l >> 4, cs = l & 15;
+#pragma unroll
+      for (int ii = 0; ii < NO; ++ii) {
+        int r = 4 * ii + l4;
+        r = r > last ? last : r;
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(scratch + r * 256 + cs * 16);
+        GU32x4* dst = (GU32x4*)(obase + (uint32_t)(r * 256 + (cs ^ (r & 15)) * 16));
+        if (NT_STORE) __builtin_nontemporal_store(ov, dst); else *dst = ov;
+        if ((ii & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      s_now = 8;
+    }
+    if (!more) {
+      done = true;
+      break;
+    }
+    t_cur = t_next;
+    g = gn;
+    d = dn;
+    row0 = n_row0;
+    valid = n_valid;
+    s_prev = s_now;
+    if (valid) stage_x();  // waits for the registers (the stores just issued stay in flight)
+    if (g != wcur) {
+      ++i;
+      break;
+    }
+  }
+  }
+}
+
 
 static bool run_new(const Ctx& c, const std::string& spec, const std::string& name, std::map<std::string, int>& o) {
   auto opt = [&](const char* k, int dflt) { return o.count(k) ? o[k] : dflt; };
@@ -1798,7 +2139,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
   }
 
   if (name == "pcopy2") {
-    const int u = opt("u", 4), nw = opt("nw", 16), depth = opt("depth", 1), wgs = opt("wgs", 1), dyn = opt("dyn", 1), lds = opt("lds", 8192), cg = opt("cg", 1), wait = opt("wait", 0), early = opt("early", 0);
+    const int u = opt("u", 4), nw = opt("nw", 16), depth = opt("depth", 1), wgs = opt("wgs", 1), dyn = opt("dyn", 1), lds = opt("lds", 8192), cg = opt("cg", 1), wait = opt("wait", 0) + 16 * opt("perm", 0), early = opt("early", 0);
     const long nbytes = c.rows * 256;
     const long ntiles = nbytes / ((long)u * 1024 * nw);
     static unsigned int* ctr = nullptr;
@@ -1952,7 +2293,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     return true;
   }
 
-  if (name == "v6" || name == "v7") {
+  if (name == "v6" || name == "v7" || name == "v8") {
     const int flags = opt("flags", 3), dbg = opt("dbg", 0), wgs = opt("wgs", 3), cgk = opt("cgk", 512);
     const int cg = cgk / 16 > 0 ? cgk / 16 : 1;
     std::vector<int32_t> ht(c.B + 1);
@@ -1984,10 +2325,53 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v7_kernel<F, D>), dim3(grid), dim3(128), lds, 0, c.descs, dt, c.B, ctr, cg); }); \
     done = true;                                                                                               \
   }
-    V7_CASE(3, 0) V7_CASE(0, 0) V7_CASE(3, 1) V7_CASE(2, 0) V7_CASE(1, 0)
+    V7_CASE(3, 0) V7_CASE(0, 0) V7_CASE(3, 1) V7_CASE(2, 0) V7_CASE(1, 0) V7_CASE(3, 2) V7_CASE(3, 3)
 #undef V7_CASE
+    if (name == "v8") {
+      const int lds8 = opt("lds", 32768 + 64);
+      CK(hipFuncSetAttribute((const void*)&v8_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+      CK(hipFuncSetAttribute((const void*)&v8_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+      CK(hipFuncSetAttribute((const void*)&v8_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+      CK(hipFuncSetAttribute((const void*)&v8_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+      if (dbg == 4) bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v8_kernel<3, 4>), dim3(grid), dim3(128), lds8, 0, c.descs, dt, c.B, ctr, cg); });
+      else if (dbg == 8) bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v8_kernel<3, 8>), dim3(grid), dim3(128), lds8, 0, c.descs, dt, c.B, ctr, cg); });
+      else if (dbg == 0) bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v8_kernel<3, 0>), dim3(grid), dim3(128), lds8, 0, c.descs, dt, c.B, ctr, cg); });
+      else bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v8_kernel<3, 1>), dim3(grid), dim3(128), lds8, 0, c.descs, dt, c.B, ctr, cg); });
+      done = true;
+    }
     CK(hipFree(dt));
     if (!done && g_round == 0) printf("%s: no such v6 variant\n", spec.c_str());
+    return true;
+  }
+
+  if (name == "pcopyd") {
+    const int wgs = opt("wgs", 3), cg = opt("cg", 16), lds = opt("lds", 32768 + 8192);
+    const long nbytes = c.rows * 256;
+    const long ntiles = nbytes / 16384;
+    static unsigned int* ctr = nullptr;
+    if (!ctr) CK(hipMalloc(&ctr, 8 * 32 * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const u32x4* in = (const u32x4*)c.x;
+    u32x4* out = (u32x4*)c.out;
+    CK(hipFuncSetAttribute((const void*)&pcopyd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int i = 0; i < 7; ++i) {
+      CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0));
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(pcopyd_kernel, dim3(c.cus * wgs), dim3(128), lds, 0, in, out, ntiles, ctr, cg);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (i >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * nbytes;
+    if (g_round == 0)
+      printf("%-36s best %.3f ms %.2f TB/s | mean %.3f ms %.2f TB/s\n", spec.c_str(), best, bytes / best * 1e-9, sum / 5, bytes / (sum / 5) * 1e-9);
+    fflush(stdout);
     return true;
   }
   if (name == "rw") {
