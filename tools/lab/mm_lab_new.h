@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(128, 2) void v7_kernel(const DevGroup* __restrict__
   bool done = false;
   // outer loop: one pass per run of tiles of the same relation (W is loop-invariant inside, so the 128 registers stay put)
   while (!done) {
-  load_w(d.w);
+  if (!(DBG & 4) || i == 0) load_w(d.w);  // DBG & 4: W loaded once (wrong results): what do the refills cost?
   const int wcur = g;
   for (;; ++i) {
     // S0: ticket i + 1 (requested one iteration ago by wave (i + 1) & 1; younger operations: this tile's DMA, the previous stores)
@@ -2325,7 +2325,7 @@ static bool run_new(const Ctx& c, const std::string& spec, const std::string& na
     bench(c, spec, [&] { CK(hipMemsetAsync(ctr, 0, 8 * 32 * 4, 0)); hipLaunchKernelGGL((v7_kernel<F, D>), dim3(grid), dim3(128), lds, 0, c.descs, dt, c.B, ctr, cg); }); \
     done = true;                                                                                               \
   }
-    V7_CASE(3, 0) V7_CASE(0, 0) V7_CASE(3, 1) V7_CASE(2, 0) V7_CASE(1, 0) V7_CASE(3, 2) V7_CASE(3, 3)
+    V7_CASE(3, 0) V7_CASE(0, 0) V7_CASE(3, 1) V7_CASE(2, 0) V7_CASE(1, 0) V7_CASE(3, 2) V7_CASE(3, 3) V7_CASE(3, 4)
 #undef V7_CASE
     if (name == "v8") {
       const int lds8 = opt("lds", 32768 + 64);
