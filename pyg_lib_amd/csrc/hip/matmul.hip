@@ -957,8 +957,10 @@ __global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup
   auto request = [&]() {
     unsigned long long sv;
     asm volatile(
+        "s_nop 4\n\t"  // (as in issue_x)
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, 1\n\t"
+        "s_nop 0\n\t"
         "global_atomic_add %[ret], %[off], %[one], %[base] sc0\n\t"
         "s_mov_b64 exec, %[sv]"
         : [ret] "+v"(raw), [sv] "=&s"(sv)
@@ -1048,6 +1050,7 @@ __global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup
     }
     uint32_t sv;
     asm volatile(
+        "s_nop 4\n\t"  // base / lds may have been written by v_readfirstlane: VALU-written SGPR -> VMEM address / M0
         "s_mov_b32 %[sv], m0\n\t"
         "s_mov_b32 m0, %[lds]\n\t"
         "s_nop 0\n\t"
@@ -1484,6 +1487,247 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_wide256_kernel(
     }
   }
 }
+
+// ---- 16-bit, K = 256, 256 output columns, 64 rows per wave ----------------------------------------------------------
+// PMC on the kernel above (C4, profiles/r2_pmc_c4_wide256.json): MFMA pipes busy 24 %, half of the wave cycles issuing
+// and 30 % waiting -- its inner loop is bound by LDS reads, not by MFMA: every step a wave reads 8 KiB of W fragments
+// + 1 KiB of X for 8 MFMAs (256 cycles), and the four waves of the CU share one 128 B/clk LDS (>= 288 cycles).  Here a
+// wave owns TWO 32-row blocks (256-row workgroup tiles) and every W fragment feeds two MFMAs: 10 KiB of LDS reads per
+// 16 MFMAs.  The 16 accumulator blocks (256 registers) live in AGPRs (one wave per SIMD: 512 registers), X arrives a
+// K-QUARTER at a time -- 64 rows x 64 k = the wave's 8 KiB stage -- through two register buffers that are refilled
+// two quarters ahead, and lane half h multiplies the 16-byte k-chunk 2 u + h in step u (a quarter is then one
+// contiguous 128-byte line per row).  W image, column mapping and epilogue follow the kernel above.
+//   There is no "this wave has no rows in this tile" path: such a wave (and every row behind a segment's end) works on
+// the segment's LAST row instead -- loads clamp to it, its result is stored to it again (same bytes as its owner
+// writes).  Every tile is then the same straight line of 32 loads and 32 stores, the loads are ordinary (compiler
+// visible) loads, and with the first tile peeled the compiler's own s_waitcnt vmcnt counts are exact: the previous
+// tile's stores stay in flight while this tile multiplies.  (A version with the loads in inline asm and hand-kept
+// counts, as in the kernel above, broke on the invalid -> valid transition: the compiler may copy an asm output
+// register at a control-flow merge before the data has arrived.)
+template <typename T>
+__global__ __launch_bounds__(256) void mfma_rows_wide256r2_kernel(const DevGroup* __restrict__ descs,
+                                                                  const int32_t* __restrict__ tile_start, int B) {
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  constexpr int SZ = 2, NW = 4;
+  constexpr int K = 256, KH = 128, MC = 256;
+  constexpr int NT = MC / 32;      // 8 column blocks
+  constexpr int BM = NW * 64;      // 256-row tiles
+  static_assert(BM == 2 * kTileRows, "tile_start2 is built for 256-row tiles");
+  constexpr int WROW = KH * SZ;    // 256 bytes per image row
+  constexpr int WIMG = MC * WROW;  // 64 KB per K-half
+  constexpr int STAGE = 8192;      // per wave: 64 rows x 128 B (a K quarter) / 32 rows x 256 B (an output round)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 31;
+  const int h = lane >> 5;
+  const int bx = blockIdx.x, G = gridDim.x;
+  char* stage = smem + 2 * WIMG + wave * STAGE;
+
+  const int total = tile_start[B];
+  const int cbase = (int)((int64_t)bx * total / G);
+  const int t1 = (int)((int64_t)(bx + 1) * total / G) - cbase;
+  if (t1 <= 0) return;
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= cbase) lo = mid; else hi = mid;
+  }
+  int g = lo;
+  int staged = -1;
+
+  // image row (= output column) of lane x for column block tt: crow0 + 16 tt; its swizzle is crow0 & 15
+  const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
+  const int wsw = crow0 & 15;
+  const char* wrow = smem + crow0 * WROW;
+
+  struct Rel {  // what a tile needs of its relation; `first` = the wave's first row, clamped into the segment
+    const char* a;
+    const char* w;
+    char* c;
+    const char* bias;
+    int64_t first;
+    int last;  // rows first .. first + last exist (0 <= last <= 63); later rows of the wave stand for first + last
+    int trans;
+    int group;
+  };
+  Rel nx;
+  auto plan = [&](int ti) {
+    const int t = cbase + ti;
+    while (t >= tile_start[g + 1]) ++g;
+    const DevGroup* p = descs + g;
+    const int64_t rows = p->rows;
+    int64_t r0 = (int64_t)(t - tile_start[g]) * BM + wave * 64;
+    if (r0 > rows - 1) r0 = rows - 1;
+    const int64_t left = rows - r0;
+    nx = Rel{p->a, p->w, p->c, p->bias, r0, left < 64 ? (int)left - 1 : 63, p->trans, g};
+  };
+  // quarter q of the wave's 64 rows: instruction i covers rows 8 i .. 8 i + 7, lane l reads chunk (l & 7) ^ (row & 7) of
+  // its row's 128-byte quarter, so that the linear stage write leaves chunk c at slot c ^ (row & 7)
+  u32x4 xr[2][8];
+  const int l3 = lane >> 3;
+  const int coff = ((lane & 7) ^ l3) * 16;  // (row & 7) == lane >> 3 for every instruction
+  auto load_q = [&](int b, const Rel& rl, int q) {
+    const char* base = rl.a + rl.first * (K * SZ) + q * 128;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int r = 8 * i + l3;
+      r = r > rl.last ? rl.last : r;
+      xr[b][i] = __builtin_nontemporal_load((const GU32x4*)(base + (uint32_t)(r * (K * SZ) + coff)));
+    }
+  };
+
+  Rel cur;
+  auto tile_body = [&](int t) {
+    if (cur.group != staged) {
+      __syncthreads();
+      const char* w = cur.w;
+      if (!cur.trans) {
+        // W[k][m] row-major: 8 columns per 16-byte load, scattered as 2-byte stores into the swizzled image
+        constexpr int CW = MC / 8;
+        for (int idx = tid; idx < K * CW; idx += NW * 64) {
+          const int k = idx / CW;
+          const int cc = (idx - k * CW) * 8;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)k * MC + cc) * SZ);
+          char* img = smem + (k >= KH ? WIMG : 0);
+          const int kk = k & (KH - 1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int m = cc + e;
+            const uint16_t sv = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+            *reinterpret_cast<uint16_t*>(img + m * WROW + (((kk >> 3) ^ (m & 15)) * 16) + (kk & 7) * 2) = sv;
+          }
+        }
+      } else {
+        // W^T[m][k] row-major: whole chunks
+        constexpr int CW = K / 8;
+        for (int idx = tid; idx < MC * CW; idx += NW * 64) {
+          const int m = idx / CW;
+          const int kc = idx - m * CW;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(w + ((int64_t)m * K + kc * 8) * SZ);
+          char* img = smem + (kc >= 16 ? WIMG : 0);
+          *reinterpret_cast<u32x4*>(img + m * WROW + (((kc & 15) ^ (m & 15)) * 16)) = v;
+        }
+      }
+      __syncthreads();
+      staged = cur.group;
+    }
+    const bool have_next = t + 1 < t1;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][i][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = q & 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[b][i];
+      // refill this buffer two quarters ahead (the last tile of the workgroup reloads its own quarters: same count
+      // of loads on every path, and nothing reads them)
+      if (q < 2) {
+        load_q(b, cur, q + 2);
+      } else {
+        if (q == 2) {
+          if (have_next) plan(t + 1); else nx = cur;
+        }
+        load_q(b, nx, q - 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const char* img = wrow + (q >> 1) * WIMG;
+      const char* xrow0 = stage + x * 128;
+      const char* xrow1 = stage + (32 + x) * 128;
+      const int xs = x & 7;
+      const int c0 = ((8 * q) & 15) + h;  // chunk within the K half of step j: c0 + 2 j
+      u32x4 xa0 = *reinterpret_cast<const u32x4*>(xrow0 + ((h ^ xs) * 16));
+      u32x4 xa1 = *reinterpret_cast<const u32x4*>(xrow1 + ((h ^ xs) * 16));
+      u32x4 wa[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+        wa[tt] = *reinterpret_cast<const u32x4*>(img + tt * 16 * WROW + ((c0 ^ wsw) * 16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" : "+v"(wa[NT - 1]));  // wait for this step's fragments before the next reads go out
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 xb0 = xa0, xb1 = xa1;
+        u32x4 wb[NT];
+        if (j + 1 < 4) {
+          const int cx = 2 * (j + 1) + h;
+          xb0 = *reinterpret_cast<const u32x4*>(xrow0 + ((cx ^ xs) * 16));
+          xb1 = *reinterpret_cast<const u32x4*>(xrow1 + ((cx ^ xs) * 16));
+          const int c = c0 + 2 * (j + 1);
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            wb[tt] = *reinterpret_cast<const u32x4*>(img + tt * 16 * WROW + ((c ^ wsw) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          acc[0][tt] = mfma_chunk(T{}, wa[tt], xa0, acc[0][tt]);
+          acc[1][tt] = mfma_chunk(T{}, wa[tt], xa1, acc[1][tt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < 4) {
+          xa0 = xb0;
+          xa1 = xb1;
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) wa[tt] = wb[tt];
+        }
+      }
+    }
+    // 32 stores, always: row r of the wave goes to row min(r, last) (rows behind the end hold the last row's result)
+    const T* bp = cur.bias ? reinterpret_cast<const T*>(cur.bias) + (MC / 2) * h : nullptr;
+    char* obase = cur.c + cur.first * MC * SZ;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {  // column blocks 4 rd .. 4 rd + 3 of both lane halves
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int tt = 4 * rd + q4;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[rb][tt][r];
+          if (bp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = round_to(T{}, v[r]) + load_bias(bp + 16 * tt + r);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c = 8 * h + 2 * q4 + j;  // 16 chunks per stage row: [half 0: 8 chunks | half 1: 8 chunks]
+            *reinterpret_cast<u32x4*>(stage + (x * 16 + (c ^ (x & 15))) * 16) = pack_chunk(T{}, v + 8 * j);
+          }
+        }
+        u32x4 ov[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int p = i * 64 + lane;
+          const int r = p >> 4;
+          const int c = (p & 15) ^ (r & 15);
+          int ro = 32 * rb + r;
+          ro = ro > cur.last ? cur.last : ro;
+          GU32x4* dst = (GU32x4*)(obase + (uint32_t)(ro * MC * SZ + ((MC / 2) * (c >> 3) + 64 * rd + 8 * (c & 7)) * SZ));
+          __builtin_nontemporal_store(ov[i], dst);
+        }
+      }
+    }
+    cur = nx;
+  };
+
+  plan(0);
+  cur = nx;
+  load_q(0, cur, 0);
+  load_q(1, cur, 1);
+  tile_body(0);  // peeled: inside the loop the memory operations in flight are the same on entry and on the back edge
+  for (int t = 1; t < t1; ++t) tile_body(t);
+}
+
 
 // ---- fp32 variant with a pipelined epilogue ---------------------------------------------------------
 // fp32 at K = 128 is bound by the MFMA rate (AI = 32 flop/B), and the weight image + X stages leave room for
@@ -2147,6 +2391,19 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
       if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
       const DeviceInfo& di = device_info();
       const int ncol = M / 256;
+      if (ncol == 1 && g_schedule != 1) {
+        // 64 rows per wave (256-row tiles): every W fragment read from LDS feeds two MFMAs
+        snprintf(name, sizeof(name), "mfma_%s_k256_wide256r2", tname);
+        g_last_variant = name;
+        const void* kern2 = reinterpret_cast<const void*>(&mfma_rows_wide256r2_kernel<T>);
+        if (int rc_ = ensure_dynamic_lds(kern2, lds)) return rc_;
+        const int64_t tiles2_upper = (w.rows_upper + 255) / 256 + B;
+        const int64_t gx2 = std::min<int64_t>(std::max<int64_t>(tiles2_upper, 1), (int64_t)di.num_cus);
+        ProfScope prof(stream);
+        hipLaunchKernelGGL((mfma_rows_wide256r2_kernel<T>), dim3((unsigned)gx2), dim3(256), lds, stream, w.descs, w.tile_start2, B);
+        PYG_HIP_CHECK(hipGetLastError());
+        return PYG_HIP_OK;
+      }
       int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus);
       if (ncol > 1) gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus / ncol) + 7) / 8 * 8);
       ProfScope prof(stream);

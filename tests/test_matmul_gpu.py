@@ -505,3 +505,41 @@ def test_grouped_matmul_backward_uses_weight_gradient_kernel(dtype):
         for i in range(len(sizes)):
             assert direct[i].shape == (F, F)
             torch.testing.assert_close(direct[i].float(), grads[len(sizes) + i].float(), rtol=2e-2, atol=eps * 64)
+
+
+def test_full_size_c4_properties():
+    """BASELINE config C4 on one device: grouped_matmul over 512 separate (input, weight) pairs, rows log-uniform in
+    [256, 65536] (the job bench_legs.leg_c4 times), F_in = F_out = 256, bf16.  W_g = 2^(g % 5 - 2) * (signed
+    permutation): every output element is an exactly representable bf16, so each group's result must equal the
+    permuted, scaled input bit for bit; plus the row-count bookkeeping of the output list."""
+    import bench_legs
+    rows = bench_legs.c4_group_rows()
+    assert len(rows) == 512 and min(rows) >= 256 and max(rows) <= 65536
+    F = 256
+    g = torch.Generator(device='cpu').manual_seed(4)
+    gd = torch.Generator(device=DEV).manual_seed(5)
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in rows]).to(DEV)
+    sign = (torch.randint(0, 2, (len(rows), F), generator=g) * 2 - 1).float().to(DEV)
+    scale = (2.0 ** (torch.arange(len(rows)) % 5 - 2).float()).to(DEV)
+    xs = [torch.randn(r, F, device=DEV, generator=gd).bfloat16() for r in rows]
+    ws = []
+    for i in range(len(rows)):
+        w = torch.zeros(F, F, device=DEV)
+        w[perm[i], torch.arange(F, device=DEV)] = sign[i] * scale[i]
+        ws.append(w.bfloat16())
+    # both K = 256 kernels: 64 rows per wave (default) and 32 rows per wave ('contiguous' selects the older kernel)
+    for mode, variant in (('auto', 'mfma_bf16_k256_wide256r2'), ('contiguous', 'mfma_bf16_k256_wide256')):
+        ops.set_matmul_schedule(mode)
+        try:
+            outs = ops.grouped_matmul(xs, ws)
+        finally:
+            ops.set_matmul_schedule('auto')
+        assert ops.matmul_last_variant() == variant
+        assert len(outs) == len(rows)
+        bad = 0
+        for i, (x, o) in enumerate(zip(xs, outs)):
+            assert o.shape == (rows[i], F) and o.dtype == torch.bfloat16
+            exp = (x.float()[:, perm[i]] * (sign[i] * scale[i])).bfloat16()
+            bad += int((exp != o).sum())
+        assert bad == 0
+        del outs
