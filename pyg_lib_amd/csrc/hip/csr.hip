@@ -94,18 +94,34 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
     }
   }
   if (live) {
-    for (int64_t e = a + lane; e < b; e += L) {
-      const int64_t p = PERM ? perm[e] : e;
-      const P x = *reinterpret_cast<const P*>(sp + p * s.K);
+    // four positions per trip: their loads are in flight together (a row is ~10 positions long in the sampler's
+    // graphs and the loop is a chain of dependent memory round trips otherwise); accumulated in position order
+    constexpr int U = 4;
+    for (int64_t e0 = a + lane; e0 < b; e0 += (int64_t)U * L) {
+      int64_t pp[U];
+      P xx[U];
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        const acc_t v = Math<T>::up(x.v[i]);
-        if constexpr (OP == CSR_SUM || OP == CSR_MEAN) {
-          acc[i] += v;
-        } else if constexpr (OP == CSR_MIN) {
-          if (v < acc[i]) { acc[i] = v; best[i] = p; }
-        } else {
-          if (v > acc[i]) { acc[i] = v; best[i] = p; }
+      for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + (int64_t)u * L;
+        const int64_t ec = e < b ? e : e0;  // clamped: the load is issued unconditionally, the value is ignored below
+        pp[u] = PERM ? perm[ec] : ec;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) xx[u] = *reinterpret_cast<const P*>(sp + pp[u] * s.K);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e0 + (int64_t)u * L >= b) break;
+        const int64_t p = pp[u];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const acc_t v = Math<T>::up(xx[u].v[i]);
+          if constexpr (OP == CSR_SUM || OP == CSR_MEAN) {
+            acc[i] += v;
+          } else if constexpr (OP == CSR_MIN) {
+            if (v < acc[i]) { acc[i] = v; best[i] = p; }
+          } else {
+            if (v > acc[i]) { acc[i] = v; best[i] = p; }
+          }
         }
       }
     }
