@@ -11,3 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_mm_$c -o p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sampler --no-legs > $R/pmc_mm_$c.log 2>&1
 done
 python /root/repo/bench.py --dtype f32 --no-sampler > $R/bench_f32.json 2> $R/bench_f32.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_ops_$c -o p -- python /root/repo/tools/pmc_targets.py > $R/pmc_ops_$c.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_samp -o samp -- python /root/repo/tools/profile_sampler.py 20 > $R/prof_samp.log 2>&1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 /root/repo/bench.py --gpus 2 --debug-one-device --no-cpu-baseline > $R/bench_2rank_debug.json 2> $R/bench_2rank_debug.err
