@@ -543,3 +543,58 @@ def test_full_size_c4_properties():
             bad += int((exp != o).sum())
         assert bad == 0
         del outs
+
+
+def test_ticket_kernel_random_partitions_match_contiguous_bitwise():
+    """Property test of the dynamic schedule: for random ragged partitions (empty relations, single rows, runs of tiny
+    relations, tails of every length) the ticket kernel -- tiles drawn from counters in whatever order the waves get
+    there -- must produce the very bits of the contiguous-range kernel (same MFMA order per output element)."""
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(3)
+    for trial in range(24):
+        B = int(rng.integers(1, 200))
+        kind = trial % 4
+        if kind == 0:
+            sizes = rng.integers(0, 3000, B)
+        elif kind == 1:
+            sizes = rng.integers(0, 70, B)          # many tiny relations: a refill of W for almost every tile
+        elif kind == 2:
+            sizes = (rng.random(B) < 0.5) * rng.integers(1, 20000, B)  # half of the relations empty
+        else:
+            sizes = np.array([int(rng.integers(1, 400_000))] + [int(v) for v in rng.integers(0, 65, B - 1)])
+        ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+        n = int(ptr[-1])
+        if n == 0:
+            continue
+        x = torch.randn(n, 128, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(B, 128, 128, generator=g) / 11).bfloat16().to(DEV)
+        bias = torch.randn(B, 128, generator=g).bfloat16().to(DEV) if trial % 3 == 0 else None
+        outs = {}
+        for mode in ('ticket', 'contiguous'):
+            ops.set_matmul_schedule(mode)
+            try:
+                outs[mode] = ops.segment_matmul(x, ptr, w, bias)
+                assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128' + SCHED_SUFFIX[mode]
+            finally:
+                ops.set_matmul_schedule('auto')
+        assert torch.equal(outs['ticket'].view(torch.int16), outs['contiguous'].view(torch.int16)), (trial, B, n)
+
+
+def test_ticket_kernel_on_two_streams_at_once():
+    """Every call owns its counters (they live in the call's workspace): two calls in flight on different streams."""
+    g = torch.Generator().manual_seed(8)
+    ptr = torch.tensor([0, 150_000, 150_001, 420_000])
+    xs = [torch.randn(420_000, 128, generator=g).bfloat16().to(DEV) for _ in range(2)]
+    ws = [(torch.randn(3, 128, 128, generator=g) / 11).bfloat16().to(DEV) for _ in range(2)]
+    ref = [ops.segment_matmul(x, ptr, w) for x, w in zip(xs, ws)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(5):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                outs[i] = ops.segment_matmul(xs[i], ptr, ws[i])
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(outs[i].view(torch.int16), ref[i].view(torch.int16))
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128_ticket'
