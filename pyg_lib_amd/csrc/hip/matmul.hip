@@ -989,8 +989,23 @@ __global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup
   u32x4 wreg[NI][NT];  // A fragment of k-step s, column block tt (layout: see mfma_rows_cyc_kernel)
   T* bias_lds = reinterpret_cast<T*>(smem + 49152 + 64);  // the relation's 128 bias values (read through LDS: a global
                                                          // load in the epilogue would drag an s_waitcnt vmcnt(0) along)
-  auto load_w = [&](const char* w, const char* bias) {
+  auto load_w = [&](const char* w, const char* bias, int trans) {
     const int lane = lane_now(), h = lane >> 5;
+    if (trans) {
+      // `other` stored [M][K] (the dX pass hands W itself and asks for X W^T): a fragment -- 8 consecutive k of one
+      // output column -- is then 16 contiguous bytes; lane x is A-row x, i.e. output column
+      // 64 ((x >> 2) & 1) + 16 tt + 4 (x >> 3) + (x & 3) (the column mapping of the cyclic kernel's LDS image)
+      __syncthreads();  // the partner is done with the previous relation's bias
+      if (bias) bias_lds[threadIdx.x] = reinterpret_cast<const T*>(bias)[threadIdx.x];
+      const int xx = lane & 31;
+      const char* wl = w + (64 * ((xx >> 2) & 1) + 4 * (xx >> 3) + (xx & 3)) * 256 + 128 * h;
+#pragma unroll
+      for (int s = 0; s < NI; ++s)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) wreg[s][tt] = *reinterpret_cast<const u32x4*>(wl + tt * 16 * 256 + s * 16);
+      __syncthreads();  // the bias is in place
+      return;
+    }
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
     const int dma_src_off = dma_r * 256 + dma_c * 16;
@@ -1028,10 +1043,11 @@ __global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup
     char* c;
     const char* bias;
     int64_t rows;
+    int trans;
   };
   auto rel_of = [&](int gi) -> Rel {
     const DevGroup* p = descs + gi;
-    return Rel{p->a, p->w, p->c, p->bias, p->rows};
+    return Rel{p->a, p->w, p->c, p->bias, p->rows, p->trans};
   };
   auto issue_x = [&](const Rel& dg, int64_t row0, int buf) {
     const uint32_t lds = (uint32_t)(size_t)(xs0 + buf * 8192);
@@ -1108,7 +1124,7 @@ __global__ __launch_bounds__(128, 2) void mfma_rows_ticket_kernel(const DevGroup
   int buf = 0, i = 0;
   bool done = false;
   while (!done) {  // one pass per run of tiles of the same relation
-    load_w(d.w, d.bias);
+    load_w(d.w, d.bias, d.trans);
     const int wcur = g;
     for (;; ++i) {
       // ticket i + 1 (requested one iteration ago by wave (i + 1) & 1; younger: this tile's DMA, the previous stores)
@@ -2419,7 +2435,7 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
     const DeviceInfo& di = device_info();
     const int sched = g_schedule;
     const bool big = w.rows_upper >= (int64_t)di.num_cus * 256 * 4;
-    if (K == 128 && M == 128 && !w.any_trans && di.num_cus >= 8 && (sched == 3 || (sched == 0 && big))) {
+    if (K == 128 && M == 128 && di.num_cus >= 8 && (sched == 3 || (sched == 0 && big))) {
       snprintf(name, sizeof(name), "mfma_%s_k128_mc128_ticket", tname);
       g_last_variant = name;
       constexpr int lds = 16384 + 2 * 16384 + 64 + 256;  // W staging / epilogue scratch, 2 x 2 X stages, ticket ring, bias

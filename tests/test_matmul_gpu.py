@@ -598,3 +598,34 @@ def test_ticket_kernel_on_two_streams_at_once():
         for i in range(2):
             assert torch.equal(outs[i].view(torch.int16), ref[i].view(torch.int16))
     assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128_ticket'
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_ticket_kernel_transposed_weights(dtype):
+    """`other` given as a transposed view (what the dX pass of the backward issues: grad @ W^T): the ticket kernel
+    reads its register fragments straight from the [M][K] storage.  Same bits as the contiguous-range kernel, and
+    the oracle's product of the logical operands."""
+    torch.manual_seed(12)
+    rows = [700, 1, 0, 256, 513, 90, 1024, 33, 5000]
+    ins = [torch.randn(r, 128).to(dtype) for r in rows]
+    oth = [(torch.randn(128, 128) / 11).to(dtype) for _ in rows]
+    d_in = [a.to(DEV) for a in ins]
+    d_oth = [o.to(DEV).t().contiguous().t() for o in oth]  # logical [K, M], stored [M][K]
+    assert not d_oth[0].is_contiguous()
+    outs = {}
+    name = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    for mode in ('ticket', 'contiguous'):
+        ops.set_matmul_schedule(mode)
+        try:
+            outs[mode] = ops.grouped_matmul(d_in, d_oth)
+        finally:
+            ops.set_matmul_schedule('auto')
+        assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128' + SCHED_SUFFIX[mode]
+    for a, o, t, c in zip(ins, oth, outs['ticket'], outs['contiguous']):
+        assert torch.equal(t.view(torch.int16), c.view(torch.int16))
+        if dtype == torch.bfloat16:
+            ref = oracle.matmul(bits(a), bits(o), dtype=oracle.BF16)
+            np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(t)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -7, atol=1e-4)
+        else:
+            ref = oracle.matmul(a.numpy(), o.numpy())
+            np.testing.assert_allclose(t.cpu().float().numpy(), ref.astype(np.float32), rtol=2 ** -9, atol=2e-3)
