@@ -709,13 +709,22 @@ struct AssignStore {
   }
 };
 
+// the work of hop_boundary_kernel (below), carried by the finalize launch of a hop's last relation
+struct HopBoundary {
+  TypeState* types;
+  int num_types;
+  int64_t* rel_sizes;
+  int num_rel;
+  int next_hop;  // < 0: none
+};
+
 // Local ids of every emitted edge.  Thread 0 also closes the relation: publishes its totals to pinned host
 // memory and advances the device-resident engine position and node-list sizes for the next relation.
 __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __restrict__ vals,
                                 int64_t n, int64_t* __restrict__ out_col, const HopInfo* __restrict__ info,
                                 HopInfo* __restrict__ publish, ChainState* __restrict__ chain,
                                 TypeState* __restrict__ ts, const int64_t* __restrict__ rel_size,
-                                int64_t* __restrict__ rel_size_next) {
+                                int64_t* __restrict__ rel_size_next, HopBoundary hb = HopBoundary{nullptr, 0, nullptr, 0, -1}) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t col_off = rel_size ? *rel_size : 0;  // fully queued mode: edges this relation emitted before
   if (p == 0 && rel_size_next) *rel_size_next = col_off + (info->overflow ? 0 : info->tot.edges);
@@ -730,6 +739,16 @@ __global__ void finalize_kernel(const u64* __restrict__ slots, const u64* __rest
       ts->size += info->uniq;
       ts->distinct += info->uniq;
     }
+  }
+  if (p == 0 && hb.next_hop >= 0) {
+    // last relation of a hop (fully queued mode): what hop_boundary_kernel does, without its launch -- nobody else in
+    // this kernel reads the slices or the next hops' rows of rel_sizes, and this thread has just made its own updates
+    for (int i = 0; i < hb.num_types; ++i) {
+      hb.types[i].slice_b = hb.types[i].slice_e;
+      hb.types[i].slice_e = hb.types[i].size;
+    }
+    for (int i = 0; i < hb.num_rel; ++i)
+      hb.rel_sizes[(int64_t)(hb.next_hop + 1) * hb.num_rel + i] = hb.rel_sizes[(int64_t)hb.next_hop * hb.num_rel + i];
   }
   if (info && (p >= info->tot.edges || info->overflow)) return;
   if (p < n) out_col[col_off + p] = (int64_t)vals[slots[p]];
@@ -1129,7 +1148,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       return p;
     };
     int64_t* rel_sizes = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (size_t)(L + 1) * (size_t)num_relations));
-    PYG_HIP_CHECK(hipMemsetAsync(rel_sizes, 0, sizeof(int64_t) * (size_t)num_relations, stream));
+    // rows 0 and 1: hop 0 starts from empty relations (what hop_boundary_kernel(next_hop = 0) would copy over)
+    PYG_HIP_CHECK(hipMemsetAsync(rel_sizes, 0, sizeof(int64_t) * 2 * (size_t)num_relations, stream));
     for (int t = 0; t < num_node_types; ++t) {
       NodeSet& n = ns[(size_t)t];
       if (node_bound[(size_t)t] == 0) continue;
@@ -1154,10 +1174,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     }
     int64_t avail_blocks = 0;
     int64_t spec_word = rng.word;
+    bool boundary_done = true;  // hop 0 needs none (rows 0 and 1 of rel_sizes are zero, the slices are the seeds)
     for (int ell = 0; ell < L; ++ell) {
-      hipLaunchKernelGGL(hop_boundary_kernel, dim3((unsigned)((std::max(num_node_types, num_relations) + 63) / 64)),
-                         dim3(64), 0, stream, tstate, num_node_types, ell > 0 ? 1 : 0, rel_sizes, num_relations, ell);
-      PYG_HIP_CHECK(hipGetLastError());
+      if (!boundary_done) {  // the previous hop queued no relation that could carry it
+        hipLaunchKernelGGL(hop_boundary_kernel, dim3((unsigned)((std::max(num_node_types, num_relations) + 63) / 64)),
+                           dim3(64), 0, stream, tstate, num_node_types, 1, rel_sizes, num_relations, ell);
+        PYG_HIP_CHECK(hipGetLastError());
+      }
+      boundary_done = ell + 1 >= L;  // nothing follows the last hop
+      int last_rel = -1;
+      for (int e = 0; e < num_relations; ++e)
+        if (eb[(size_t)ell][(size_t)e] != 0) last_rel = e;
       for (int e = 0; e < num_relations; ++e) {
         const int64_t Eb = eb[(size_t)ell][(size_t)e];
         if (Eb == 0) continue;
@@ -1233,8 +1260,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         if (rc != PYG_HIP_OK) return rc;
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Eb + 255) / 256)), dim3(256), 0, stream, e_slot,
                            dn.table.vals, Eb, st.col.p, info_dev + slot, const_cast<HopInfo*>(info_host) + slot, chain,
-                           tstate + dst, (const int64_t*)a.rel_size, rel_sizes + (int64_t)(ell + 1) * num_relations + e);
+                           tstate + dst, (const int64_t*)a.rel_size, rel_sizes + (int64_t)(ell + 1) * num_relations + e,
+                           (e == last_rel && ell + 1 < L)
+                               ? HopBoundary{tstate, num_node_types, rel_sizes, num_relations, ell + 1}
+                               : HopBoundary{nullptr, 0, nullptr, 0, -1});
         PYG_HIP_CHECK(hipGetLastError());
+        if (e == last_rel) boundary_done = true;
         queued.push_back({ell, e});
       }
     }
