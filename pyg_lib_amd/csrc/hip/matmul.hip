@@ -1580,17 +1580,20 @@ __global__ __launch_bounds__(256) void mfma_rows_wide256r2_kernel(const DevGroup
     const int64_t left = rows - r0;
     nx = Rel{p->a, p->w, p->c, p->bias, r0, left < 64 ? (int)left - 1 : 63, p->trans, g};
   };
-  // quarter q of the wave's 64 rows: instruction i covers rows 8 i .. 8 i + 7, lane l reads chunk (l & 7) ^ (row & 7) of
-  // its row's 128-byte quarter, so that the linear stage write leaves chunk c at slot c ^ (row & 7)
+  // quarter q of the wave's 64 rows: instruction i covers rows 8 i .. 8 i + 7, lane l reads chunk
+  // (l & 7) ^ ((row >> 1) & 7) of its row's 128-byte quarter, so that the linear stage write leaves chunk c at slot
+  // c ^ ((row >> 1) & 7): ds_read_b128 serves the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32) in one
+  // cycle each over 64 banks, and with 128-byte rows the bank is (row & 1, slot) -- (row >> 1) & 7 is a permutation of
+  // 0..7 over the even rows of either group and over the odd ones (row & 7 gave 2-way conflicts).
   u32x4 xr[2][8];
   const int l3 = lane >> 3;
-  const int coff = ((lane & 7) ^ l3) * 16;  // (row & 7) == lane >> 3 for every instruction
   auto load_q = [&](int b, const Rel& rl, int q) {
     const char* base = rl.a + rl.first * (K * SZ) + q * 128;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int r = 8 * i + l3;
-      r = r > rl.last ? rl.last : r;
+      const int row = 8 * i + l3;
+      const int coff = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+      const int r = row > rl.last ? rl.last : row;
       xr[b][i] = __builtin_nontemporal_load((const GU32x4*)(base + (uint32_t)(r * (K * SZ) + coff)));
     }
   };
@@ -1657,7 +1660,7 @@ __global__ __launch_bounds__(256) void mfma_rows_wide256r2_kernel(const DevGroup
       const char* img = wrow + (q >> 1) * WIMG;
       const char* xrow0 = stage + x * 128;
       const char* xrow1 = stage + (32 + x) * 128;
-      const int xs = x & 7;
+      const int xs = (x >> 1) & 7;  // rows x and 32 + x share it
       const int c0 = ((8 * q) & 15) + h;  // chunk within the K half of step j: c0 + 2 j
       u32x4 xa0 = *reinterpret_cast<const u32x4*>(xrow0 + ((h ^ xs) * 16));
       u32x4 xa1 = *reinterpret_cast<const u32x4*>(xrow1 + ((h ^ xs) * 16));
