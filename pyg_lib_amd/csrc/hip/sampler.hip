@@ -843,6 +843,12 @@ struct NodeSet {
   int64_t dense_n = 0;        // > 0: every id of this type is < dense_n and keys are plain node ids (not disjoint)
 };
 
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void table_clear_kernel(u64x2* __restrict__ p, int64_t n16) {
+  const u64x2 e = {kEmpty, kEmpty};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = e;
+}
+
 // keys and vals share one block (one allocation, one memset); `hint` = entries expected by the end of
 // the call, so that the table is usually built once instead of being rehashed every hop.
 int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
@@ -862,11 +868,17 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   if (!ns.table.keys && ns.dense_n > 0 && (u64)ns.dense_n <= 4 * ncap && ns.dense_n <= (1ll << 27)) {
     // direct-address table: at most twice the bytes of the hash table it replaces
     HashTable dt;
-    PYG_ALLOC(dt.keys, u64*, c, sizeof(u64) * (size_t)ns.dense_n);
+    PYG_ALLOC(dt.keys, u64*, c, sizeof(u64) * (size_t)(ns.dense_n + (ns.dense_n & 1)));  // whole 16-byte stores
     dt.vals = dt.keys;
     dt.mask = 0;
     dt.dense = 1;
-    PYG_HIP_CHECK(hipMemsetAsync(dt.keys, 0xFF, sizeof(u64) * (size_t)ns.dense_n, c.stream));
+    // cleared by an own kernel: the runtime's fill kernel takes 12 us for the 19.6 MB of a products-sized table (1.6 TB/s)
+    {
+      const int64_t n16 = (ns.dense_n + 1) / 2;
+      hipLaunchKernelGGL(table_clear_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, 1 << 20)), dim3(256), 0,
+                         c.stream, reinterpret_cast<u64x2*>(dt.keys), n16);
+      PYG_HIP_CHECK(hipGetLastError());
+    }
     ns.table = dt;
     ns.entries_bound = need;
     return PYG_HIP_OK;
