@@ -25,7 +25,7 @@ def make_graph(device, seed=0):
     return rowptr, col
 
 
-def run(device, batches=20, warmup=3, cpu_batches=2):
+def run(device, batches=50, warmup=5, cpu_batches=2):
     from pyg_lib_amd import sampler
     rowptr, col = make_graph(device)
     g = torch.Generator(device='cpu').manual_seed(1)
