@@ -90,8 +90,8 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const K* __restrict__ 
 }
 
 // ---- pass kernels ---------------------------------------------------------------------------------------
-// hist[d * G + g]: number of keys with digit d in the slice of workgroup g.  Equal digits inside a wave
-// are counted by ONE LDS atomic (match-any leader), so skewed digits (high bytes) do not serialise.
+// hist[d * G + g]: number of keys with digit d in the slice of workgroup g.  A wave whose keys all share the digit
+// (a constant high byte) adds once; otherwise one LDS atomic per key.
 // RAW (packed mode, non-negative keys): digits of the value itself, no sign-bit flip.
 template <typename K, bool RAW = false>
 __global__ __launch_bounds__(kThreads) void hist_kernel(const K* __restrict__ keys, int64_t n, int64_t slice,
@@ -100,20 +100,59 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const K* __restrict__ ke
   bins[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int64_t beg = blockIdx.x * slice;
   const int64_t end = min(beg + slice, n);
-  for (int64_t i0 = beg; i0 < end; i0 += kThreads) {
-    const int64_t i = i0 + threadIdx.x;
-    const bool valid = i < end;
-    const unsigned d = !valid ? 0u : RAW ? (unsigned)(((uint64_t)keys[i] >> shift) & 0xff) : digit_of(keys[i], shift);
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
+  // all lanes on one digit (a constant high byte): one add for the wave; otherwise one LDS atomic per key -- a handful
+  // of bank cycles per wave for spread digits, where a 9-ballot match-any cost ~100 cycles per trip
+  auto count = [&](K key, bool valid) {
+    const unsigned d = !valid ? 0u : RAW ? (unsigned)(((uint64_t)key >> shift) & 0xff) : digit_of(key, shift);
+    const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+    const unsigned long long same = __ballot(valid && d == d0);
+    const unsigned long long live = __ballot(valid);
+    if (same == live) {
+      if (lane == 0 && live) atomicAdd(&bins[d0], (unsigned)__popcll(live));
+    } else if (valid) {
+      atomicAdd(&bins[d], 1u);
     }
-    if (valid && (peers & lt_mask) == 0) atomicAdd(&bins[d], (unsigned)__popcll(peers));
+  };
+  constexpr int U = 4;
+  bool wide = false;
+  if constexpr (sizeof(K) == 8) wide = (reinterpret_cast<uintptr_t>(keys + beg) & 15) == 0;  // a sliced tensor may not be
+  if (wide) {
+    // 16-byte loads (two keys), four per thread and trip in flight: one 8-byte load per trip left this kernel at
+    // 2.2 TB/s.  Slices start on even positions (multiples of the scatter tile).
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int64_t npair = (end - beg) / 2;
+    const u64x2* kp = reinterpret_cast<const u64x2*>(keys + beg);
+    for (int64_t j0 = 0; j0 < npair; j0 += (int64_t)U * kThreads) {
+      u64x2 kv[U];
+      bool valid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t j = j0 + u * kThreads + threadIdx.x;
+        valid[u] = j < npair;
+        kv[u] = kp[valid[u] ? j : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        count((K)kv[u][0], valid[u]);
+        count((K)kv[u][1], valid[u]);
+      }
+    }
+    if ((end - beg) & 1) count(keys[end - 1], threadIdx.x == 0);
+  } else {
+    for (int64_t i0 = beg; i0 < end; i0 += (int64_t)U * kThreads) {
+      K kv[U];
+      bool valid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * kThreads + threadIdx.x;
+        valid[u] = i < end;
+        kv[u] = keys[valid[u] ? i : beg];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) count(kv[u], valid[u]);
+    }
   }
   __syncthreads();
   hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = bins[threadIdx.x];
