@@ -26,6 +26,8 @@
 // element per pass in both directions (12 -> 8 GB for 1e8 int64 keys in 3 passes), 64 KB instead of 128 KB of LDS per
 // 8192-key tile (two workgroups per CU).  Same stable order, bit-identical result.
 #include "common.h"
+
+#include <mutex>
 #include "scan.h"
 
 #include <algorithm>
@@ -168,7 +170,7 @@ struct HistStore {
 };
 
 // Stable scatter of one pass.  FIRST: the index payload is the identity (arange), not read.
-template <typename K, bool FIRST>
+template <typename K, bool FIRST, bool ATOMIC_RANK = false>
 __global__ __launch_bounds__(kSThreads) void scatter_kernel(const K* __restrict__ keys_in,
                                                             const int64_t* __restrict__ idx_in, K* __restrict__ keys_out,
                                                             int64_t* __restrict__ idx_out, int64_t n, int64_t slice,
@@ -209,6 +211,12 @@ __global__ __launch_bounds__(kSThreads) void scatter_kernel(const K* __restrict_
       const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
       const bool valid = i < end;
       const unsigned d = valid ? digit_of(key[r], shift) : 0u;
+      if (ATOMIC_RANK) {
+        // the LDS hands a wave's returning atomics on one address their values in ascending lane order (checked on
+        // the device before this variant is used: lds_rank_order_ok): the stable rank without the 9 ballots
+        rank[r] = valid ? (unsigned short)atomicAdd(&my_cnt[d], 1u) : (unsigned short)0;
+        continue;
+      }
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kSThreads) void scatter_kernel(const K* __restrict_
 // Packed mode: stable scatter of one pass over 64-bit words (key << ib | position).  IN_KEYS: the input is the key
 // vector (first pass: words are formed on the fly), else words.  OUT_SPLIT: the output is (keys, indices) (last pass),
 // else words.  `shift` addresses the digit inside the WORD (ib + 8 * pass).
-template <typename K, bool IN_KEYS, bool OUT_SPLIT>
+template <typename K, bool IN_KEYS, bool OUT_SPLIT, bool ATOMIC_RANK = false>
 __global__ __launch_bounds__(kSThreads) void scatter_packed_kernel(const K* __restrict__ keys_in, const uint64_t* __restrict__ words_in,
                                                                    uint64_t* __restrict__ words_out, K* __restrict__ keys_out,
                                                                    int64_t* __restrict__ idx_out, int64_t n, int64_t slice, int shift,
@@ -319,6 +327,10 @@ __global__ __launch_bounds__(kSThreads) void scatter_packed_kernel(const K* __re
       const int64_t i = tile + wave * kWaveKeys + r * 64 + lane;
       const bool valid = i < end;
       const unsigned d = valid ? (unsigned)((word[r] >> shift) & 0xff) : 0u;
+      if (ATOMIC_RANK) {
+        rank[r] = valid ? (unsigned short)atomicAdd(&my_cnt[d], 1u) : (unsigned short)0;  // see scatter_kernel
+        continue;
+      }
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
@@ -402,6 +414,66 @@ __global__ void copy_identity_kernel(const K* __restrict__ in, K* __restrict__ o
   }
 }
 
+// ---- does the LDS rank a wave's conflicting returning atomics in lane order? -------------------------------------
+// The scatter kernels' stable rank of a key among the equal digits of its wave costs 9 ballots per round of 64 keys and
+// makes those kernels VALU-bound (2.6 - 3.3 TB/s of their traffic).  ds_add_rtn_u32 gives the same number in one
+// instruction IF lanes that hit one address receive their return values in ascending lane order.  That is how the LDS
+// of this chip resolves the conflict (tools/probe/lds_atomic_order.hip: 2.7e8 ranks, spread / few / constant /
+// same-bank digits, no deviation), but it is not an architectural promise, so it is checked on the device the first
+// time a sort runs there; a device that fails keeps the ballot variant.
+__global__ __launch_bounds__(512) void lds_rank_probe_kernel(unsigned* __restrict__ bad, int rounds, unsigned seed) {
+  __shared__ unsigned cnt[8][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = lane; j < 256; j += 64) cnt[wave][j] = 0;
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  unsigned x = seed ^ (blockIdx.x * 9781u + threadIdx.x * 6271u + 1u);
+  unsigned errors = 0;
+  for (int r = 0; r < rounds; ++r) {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const int mode = (blockIdx.x + r) & 3;  // spread, four values, constant, same bank
+    const unsigned d = mode == 0 ? (x & 255u) : mode == 1 ? (x & 3u) : mode == 2 ? 7u : ((x & 15u) * 16u);
+    unsigned long long peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const unsigned want = cnt[wave][d] + (unsigned)__popcll(peers & lt);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned got = atomicAdd(&cnt[wave][d], 1u);
+    __builtin_amdgcn_wave_barrier();
+    errors += got != want;
+  }
+  if (errors) atomicAdd(bad, errors);
+}
+
+// per device, once per process; synchronises a private stream (never the caller's) on that first call
+bool lds_rank_order_ok() {
+  static std::mutex mu;
+  static int state[64] = {0};  // 0 unknown, 1 yes, 2 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    state[dev] = 2;
+    unsigned* bad = nullptr;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&bad), 4) == hipSuccess) {
+      unsigned host = 1;
+      if (hipMemsetAsync(bad, 0, 4, st) == hipSuccess) {
+        hipLaunchKernelGGL(lds_rank_probe_kernel, dim3(device_info().num_cus * 2), dim3(512), 0, st, bad, 64, 0x9e3779b9u);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&host, bad, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess && host == 0)
+          state[dev] = 1;
+      }
+    }
+    if (bad) (void)hipFree(bad);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  return state[dev] == 1;
+}
+
 struct Plan {
   int64_t groups;  // workgroups per pass
   int64_t slice;   // keys per workgroup (multiple of kTile)
@@ -441,6 +513,7 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
     return fail(PYG_HIP_ERR_WORKSPACE, "index_sort: workspace of %zu bytes needed, got %zu", ws_bytes(n, sizeof(K)),
                 ws_size);
   const Plan p = make_plan(n);
+  const bool atomic_rank = lds_rank_order_ok();
   char* w = static_cast<char*>(ws);
   K* kbuf = reinterpret_cast<K*>(w);
   w += align_up((size_t)n * sizeof(int64_t), 256);
@@ -511,17 +584,23 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
         if (rc != PYG_HIP_OK) return rc;
         uint64_t* wout = wbuf[ps & 1];
         const int shift = ib + 8 * ps;
-#define PYG_PACKED(INK, OUTS)                                                                                              \
-  {                                                                                                                        \
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_packed_kernel<K, INK, OUTS>), plds)) return rc_; \
-    hipLaunchKernelGGL((scatter_packed_kernel<K, INK, OUTS>), dim3((unsigned)p.groups), dim3(kSThreads), plds, stream, keys, win, \
-                       wout, keys_out, idx_out, n, p.slice, shift, ib, offs);                                              \
+#define PYG_PACKED2(INK, OUTS, AR)                                                                                              \
+  {                                                                                                                            \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_packed_kernel<K, INK, OUTS, AR>), plds)) return rc_; \
+    hipLaunchKernelGGL((scatter_packed_kernel<K, INK, OUTS, AR>), dim3((unsigned)p.groups), dim3(kSThreads), plds, stream, keys, \
+                       win, wout, keys_out, idx_out, n, p.slice, shift, ib, offs);                                             \
+  }
+#define PYG_PACKED(INK, OUTS)                     \
+  {                                               \
+    if (atomic_rank) PYG_PACKED2(INK, OUTS, true) \
+    else PYG_PACKED2(INK, OUTS, false)            \
   }
         if (first && last) PYG_PACKED(true, true)
         else if (first) PYG_PACKED(true, false)
         else if (last) PYG_PACKED(false, true)
         else PYG_PACKED(false, false)
 #undef PYG_PACKED
+#undef PYG_PACKED2
         PYG_HIP_CHECK(hipGetLastError());
         win = wout;
       }
@@ -546,14 +625,20 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
                                          scan_tmp + ntiles, stream);
     if (rc != PYG_HIP_OK) return rc;
     constexpr int lds = (int)scatter_lds_bytes(sizeof(K));
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_kernel<K, true>), lds)) return rc_;
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_kernel<K, false>), lds)) return rc_;
-    if (ps == 0)
-      hipLaunchKernelGGL((scatter_kernel<K, true>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k,
-                         (const int64_t*)nullptr, kdst[cur], idst[cur], n, p.slice, shift, offs);
-    else
-      hipLaunchKernelGGL((scatter_kernel<K, false>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k,
-                         (const int64_t*)iin, kdst[cur], idst[cur], n, p.slice, shift, offs);
+#define PYG_SCATTER(FIRSTP, AR, IDX)                                                                                        \
+  {                                                                                                                     \
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&scatter_kernel<K, FIRSTP, AR>), lds)) return rc_;    \
+    hipLaunchKernelGGL((scatter_kernel<K, FIRSTP, AR>), dim3((unsigned)p.groups), dim3(kSThreads), lds, stream, src_k, \
+                       (const int64_t*)(IDX), kdst[cur], idst[cur], n, p.slice, shift, offs);                            \
+  }
+    if (ps == 0) {
+      if (atomic_rank) PYG_SCATTER(true, true, nullptr)
+      else PYG_SCATTER(true, false, nullptr)
+    } else {
+      if (atomic_rank) PYG_SCATTER(false, true, iin)
+      else PYG_SCATTER(false, false, iin)
+    }
+#undef PYG_SCATTER
     PYG_HIP_CHECK(hipGetLastError());
     kin = kdst[cur];
     iin = idst[cur];
