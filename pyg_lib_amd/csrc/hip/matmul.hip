@@ -1885,9 +1885,14 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
       }
     }
   };
-  // `younger16`: exactly the 16 unpredicated stores of an overlapped epilogue were issued after the loads
-  auto stage_x = [&](bool younger16) {
-    if (younger16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  // `younger`: exactly the 4 * NT unpredicated stores of an overlapped epilogue (four per 32-column block) were issued
+  // after the loads.  (The count was a fixed 16 until round 2: right for MC = 128 only -- with MC = 64 / 32 the wait
+  // let 8 / 12 LOADS stay in flight, which surfaced as one garbage tile in one of ~15 runs of the parity suite.)
+  auto stage_x = [&](bool younger) {
+    if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
@@ -2085,7 +2090,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_f32_pipe_kernel(
         dbg_t[1] += c1 - c0;
         c0 = c1;
       }
-      // younger than the staged tile's loads: exactly the 16 stores of the overlapped epilogue -- unless those
+      // younger than the staged tile's loads: exactly the 4 * NT stores of the overlapped epilogue -- unless those
       // loads were issued before this iteration's flush / restage traffic (then every older access has to land)
       if (valid) stage_x(overlapped && !flushed && loads_in_loop);
       if constexpr ((DBG & 8) != 0) {
