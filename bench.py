@@ -20,8 +20,9 @@ The JSON line also carries
   roofline      dominant kernel vs the HBM roofline: algorithmic bytes / HIP-event kernel time on the launch stream
                 (pyg_hip_profile_*), plus `achievable`: what hand-written device copies of the same 1 read : 1 write
                 byte mix reach on this box on the same two buffers (pyg_hip_stream_copy: fine-grained sweep = the best
-                copy known on this hardware; contiguous / cyclic = the kernel's two tile schedules without the
-                arithmetic)
+                copy known on this hardware; contiguous / cyclic = the static tile schedules of the two older kernels
+                without the arithmetic -- the default ticket-schedule kernel draws its tiles in address order and is
+                not tied to either)
   cpu_baseline  the reference's CPU arithmetic -- one at::matmul per relation (ops/cpu/matmul_kernel.cpp:195-201)
                 -- as per-segment torch.matmul on CPU tensors of the same dtype, all host threads; `cpu_port` is the
                 oracle's own C restatement (test infrastructure) on a smaller sample
