@@ -7,15 +7,18 @@ OUT=../libpyg_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden -I../../include -Ihip"
 mkdir -p build
 objs=""
+pids=""
 for f in hip/*.hip; do
   o=build/$(basename "$f" .hip).o
   stale=0
   for h in hip/*.h ../../include/pyg_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     echo "hipcc $f"
-    $HIPCC $FLAGS -c "$f" -o "$o"
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids="$pids $!"
   fi
   objs="$objs $o"
 done
+for p in $pids; do wait $p || { echo "hipcc failed"; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
 echo "built $OUT"

@@ -19,7 +19,7 @@
 //     16-bit types; v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) for fp32 -- gfx950 has no TF32.
 // Shapes outside the specialised (K, M) set, and the remaining dtypes of
 // AT_DISPATCH_ALL_TYPES_AND2, run a plain one-thread-per-output kernel ("naive").
-#include "common.h"
+#include "matmul_common.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -30,32 +30,6 @@
 
 namespace pyg_hip {
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-struct bf16_t {
-  uint16_t v;
-};
-struct f16_t {
-  uint16_t v;
-};
-
-// Device-side group descriptor (48 bytes).
-struct DevGroup {
-  const char* a;
-  const char* w;
-  char* c;
-  const char* bias;
-  int64_t rows;
-  int32_t k;
-  int32_t m;
-  int32_t trans;
-  int32_t pad;
-};
 
 constexpr int kTileRows = 128;  // rows per workgroup tile in the MFMA kernels (4 waves x 32)
 constexpr int kPairRows = 64;   // rows per tile of the ticket kernel (2 waves x 32)
@@ -125,7 +99,7 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
     d.k = (int32_t)K;
     d.m = (int32_t)M;
     d.trans = 0;
-    d.pad = 0;
+    d.pad = gen_class(d.a, d.w, d.c, K, M, elt, 0);
     descs[b] = d;
     tile_start[b] = (int32_t)t;
     tile_start2[b] = (int32_t)t2;
@@ -139,55 +113,6 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
 }
 
 // ---- MFMA kernels ------------------------------------------------------------------------------
-template <typename T>
-struct Elem;
-template <>
-struct Elem<bf16_t> {
-  static constexpr int kSize = 2;
-  static constexpr int kPerChunk = 8;   // elements per 16-byte chunk
-  static constexpr int kStepsPerChunk = 1;  // MFMA k-steps fed by one chunk
-};
-template <>
-struct Elem<f16_t> {
-  static constexpr int kSize = 2;
-  static constexpr int kPerChunk = 8;
-  static constexpr int kStepsPerChunk = 1;
-};
-template <>
-struct Elem<float> {
-  static constexpr int kSize = 4;
-  static constexpr int kPerChunk = 4;
-  static constexpr int kStepsPerChunk = 4;
-};
-
-__device__ __forceinline__ f32x16 mfma_chunk(bf16_t, u32x4 a, u32x4 b, f32x16 acc) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                 __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_chunk(f16_t, u32x4 a, u32x4 b, f32x16 acc) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
-                                                __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_chunk(float, u32x4 a, u32x4 b, f32x16 acc) {
-  f32x4 af = __builtin_bit_cast(f32x4, a);
-  f32x4 bf = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
-  return acc;
-}
-
-__device__ __forceinline__ float load_bias(const bf16_t* p) {
-  return __builtin_bit_cast(float, (uint32_t)p->v << 16);
-}
-__device__ __forceinline__ float load_bias(const f16_t* p) {
-  return (float)__builtin_bit_cast(_Float16, p->v);
-}
-__device__ __forceinline__ float load_bias(const float* p) { return *p; }
-__device__ __forceinline__ float round_to(bf16_t, float v) { return (float)(__bf16)v; }
-__device__ __forceinline__ float round_to(f16_t, float v) { return (float)(_Float16)v; }
-__device__ __forceinline__ float round_to(float, float v) { return v; }
-
 // Store 16 consecutive output elements (fp32 accumulators -> T) at `dst` (16-byte aligned).
 __device__ __forceinline__ void store16(bf16_t*, char* dst, const float (&v)[16]) {
   u32x4 lo, hi;
@@ -2242,6 +2167,8 @@ struct Workspace {
   unsigned int* tickets; // kTicketWords counters of the ticket kernel, zero before its launch
   bool any_trans = false;  // host-side note: some group reads a transposed `other`
   int64_t rows_upper = 0;  // host-side note: upper bound of the rows of the call
+  bool gen_ok = false;     // host-side note: every group can run the general-shape MFMA kernel (element-aligned pointers)
+  int64_t mean_k = 0;      // host-side note: row-weighted mean contraction length (tile run length of that kernel)
 };
 
 size_t workspace_bytes(int64_t B) {
@@ -2567,6 +2494,12 @@ int run_planned(int dtype, const Workspace& w, int B, int64_t K, int64_t M, bool
     if (rc != PYG_HIP_OK) return rc;
     if (handled) return PYG_HIP_OK;
   }
+  if (w.gen_ok && (dtype == PYG_BF16 || dtype == PYG_F16 || dtype == PYG_F32)) {
+    // general shapes (per-group K / M / alignment): matmul_gen.hip
+    g_last_variant = dtype == PYG_BF16 ? "mfma_bf16_gen" : dtype == PYG_F16 ? "mfma_f16_gen" : "mfma_f32_gen";
+    ProfScope prof(stream);
+    return launch_matmul_gen(dtype, w.descs, w.tile_start, B, tiles_upper, w.mean_k, stream);
+  }
   return dispatch_naive(dtype, w, B, out_elems_upper, stream);
 }
 
@@ -2623,7 +2556,7 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
   PYG_HIP_REQUIRE(B < (1LL << 31), "segment_matmul: too many segments");
   g_last_variant = "none";
   if (B == 0 || N == 0 || M == 0) return PYG_HIP_OK;
-  PYG_HIP_REQUIRE(input && other && out, "segment_matmul: NULL tensor");
+  PYG_HIP_REQUIRE(out && (K == 0 || (input && other)), "segment_matmul: NULL tensor");
   PYG_HIP_REQUIRE((N + kPairRows - 1) / kPairRows + B < (1LL << 31),
                   "segment_matmul: too many row tiles");
   if (workspace_bytes_ < workspace_bytes(B) || workspace == nullptr)
@@ -2660,6 +2593,10 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
   }
   const int64_t tiles_upper = (N + kTileRows - 1) / kTileRows + B;
   const bool fast = aligned16(input) && aligned16(other) && aligned16(out);
+  const uintptr_t all_ptrs = (uintptr_t)input | (uintptr_t)other | (uintptr_t)out | (uintptr_t)bias;
+  w.gen_ok = (dtype == PYG_F32 || dtype == PYG_BF16 || dtype == PYG_F16) && all_ptrs % elt == 0 && K < (1LL << 21) &&
+             M < (1LL << 21);
+  w.mean_k = K;
   return run_planned(dtype, w, (int)B, K, M, fast, tiles_upper, N * M, stream);
 }
 
@@ -2689,7 +2626,8 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   int32_t* ht3 = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + descs_b + 2 * tiles_b);
   int64_t tiles2 = 0, tiles3 = 0, rows_total = 0;
   bool uniform = true, any_trans = false;
-  int64_t tiles = 0, out_elems = 0;
+  bool gen_ok = dtype == PYG_F32 || dtype == PYG_BF16 || dtype == PYG_F16;
+  int64_t tiles = 0, out_elems = 0, k_rows = 0;
   for (int64_t i = 0; i < G; ++i) {
     const pyg_hip_group& gr = groups[i];
     PYG_HIP_REQUIRE(gr.rows >= 0 && gr.k >= 0 && gr.m >= 0, "grouped_matmul: negative size");
@@ -2703,7 +2641,11 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
     hd[i].k = gr.k;
     hd[i].m = gr.m;
     hd[i].trans = gr.other_trans ? 1 : 0;
-    hd[i].pad = 0;
+    hd[i].pad = gen_class(gr.input, gr.other, gr.out, gr.k, gr.m, (int)elt, hd[i].trans);
+    if ((((uintptr_t)gr.input | (uintptr_t)gr.other | (uintptr_t)gr.out) % elt) != 0 || gr.k >= (1 << 21) ||
+        gr.m >= (1 << 21))
+      gen_ok = false;
+    k_rows += (int64_t)gr.k * hd[i].rows;
     if (gr.k != groups[0].k || gr.m != groups[0].m) uniform = false;
     if (!aligned16(gr.input) || !aligned16(gr.other) || !aligned16(gr.out)) uniform = false;
     if (gr.other_trans) any_trans = true;
@@ -2720,6 +2662,8 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   }
   w.any_trans = any_trans;
   w.rows_upper = rows_total;
+  w.gen_ok = gen_ok;
+  w.mean_k = rows_total > 0 ? k_rows / rows_total : 0;
   ht[G] = (int32_t)tiles;
   ht2[G] = (int32_t)tiles2;
   ht3[G] = (int32_t)tiles3;
@@ -2736,6 +2680,7 @@ int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, vo
   if (rc != PYG_HIP_OK) return rc;
   if (out_elems == 0) return PYG_HIP_OK;
   if (groups[0].k == 0) uniform = false;
+  if (uniform && !mfma_shape_ok(dtype, groups[0].k, groups[0].m)) uniform = false;
   return run_planned(dtype, w, (int)G, groups[0].k, groups[0].m, uniform, tiles, out_elems,
                      stream);
 }

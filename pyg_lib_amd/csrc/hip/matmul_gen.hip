@@ -1,0 +1,446 @@
+// General-shape MFMA kernel of segment_matmul / grouped_matmul (own translation unit; dispatch in matmul.hip).
+//
+// The reference's CUDA path hands CUTLASS one GemmCoord per group (pyg_lib/csrc/ops/cuda/matmul_kernel.cu:33-67), i.e.
+// every group has its own (rows, K, M); its tests use K = 16 / 9 / 32 with M = 48 / 42 / 64
+// (test/ops/test_matmul.py:56-72).  The specialised kernels of matmul.hip cover ONE (K, M) per launch with
+// K in {32 ... 512}, M % 32 == 0 and 16-byte aligned rows; everything else -- K = 100 (ogbn-products), the K-per-type
+// lists of a HeteroDictLinear, odd M, element-aligned views -- runs here:
+//   * one workgroup (4 waves) per 128-row tile of ONE group, dispatched in address order (run-to-completion grid, the
+//     blockIdx -> tile map deals every XCD runs of `run` consecutive tiles, ~256 KiB);
+//   * the tile is multiplied 128 output columns at a time, the contraction in chunks of 128 bytes per row (64 16-bit
+//     / 32 fp32 values): per chunk a [128 rows][chunk] image of X and a [chunk][128 columns] image of W[g] are staged
+//     in LDS (double-buffered; the global loads of chunk s+1 are in registers while chunk s multiplies);
+//   * alignment classes instead of shape specialisation: a group's X / W / out accesses use the widest vector (16, 8,
+//     4 or 2 bytes) that divides both its base address and its row pitch, chosen per group on the host / by the plan
+//     kernel (DevGroup::pad).  A row-major block is then read with whole vectors that never straddle a row end, the K
+//     and M tails and the rows behind the group's end are ZERO-FILLED in the LDS image, and the MFMA loop is the same
+//     for every shape; stores are masked by (row, column byte);
+//   * W is read as it lies in memory: [K][M] images feed the MFMA "A" operand (8 consecutive k of one output column)
+//     through the transposing LDS read ds_read_b64_tr_b16 (16-bit) / four ds_read_b32 (fp32, whose MFMA takes one
+//     value per lane); a transposed `other` ([M][K] storage: the dX pass) is staged like X and read with ds_read_b128;
+//   * the accumulators leave through a wave-private LDS stage (aliased on the stage buffer that is idle during the
+//     tile's last chunk) so that global stores are whole row pieces, bias as in the other kernels.
+// D = W^T X^T per 32x32 block as in the specialised kernels: lane (j, h) owns row j of the wave's 32 rows.
+
+#include "matmul_common.h"
+
+#include <algorithm>
+
+namespace pyg_hip {
+namespace {
+
+constexpr int kGenPX = 144;                   // pitch of a [row][128-byte slice] image: 16-byte pad => conflict-free b128
+constexpr int kGenXBytes = 128 * kGenPX;      // 18432
+constexpr int kGenWBytes = 64 * (256 + 64);   // [64 k][128 col] 16-bit image (fp32: [32][128] x 576 = 18432)
+constexpr int kGenBuf = kGenXBytes + kGenWBytes;
+constexpr int kGenLds = 2 * kGenBuf;          // 77824 bytes: two workgroups per CU
+constexpr int kGenPS = 272;                   // epilogue stage pitch (256 bytes of one output row + pad)
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int V> struct GenVec;
+template <> struct GenVec<16> { typedef u32x4 type; };
+template <> struct GenVec<8> { typedef u32x2 type; };
+template <> struct GenVec<4> { typedef uint32_t type; };
+template <> struct GenVec<2> { typedef uint16_t type; };
+
+// A block of 16384 / ROWBYTES rows x ROWBYTES bytes, 64 bytes per thread (256 threads), as V-byte vectors: vector idx
+// = i * 256 + tid -> (row, v).  Vectors outside (rows_valid, bytes_valid) read as zero.
+template <int V, int ROWBYTES>
+__device__ __forceinline__ void gen_load(uint32_t (&r)[16], const char* base, uint32_t pitch, int rows_valid,
+                                         int bytes_valid, int tid, bool stream) {
+  constexpr int NV = ROWBYTES / V;
+  constexpr int PER = 64 / V;
+  typedef typename GenVec<V>::type VT;
+  typedef __attribute__((address_space(1))) VT GVT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx / NV;
+    const int v = idx % NV;
+    const bool ok = row < rows_valid && v * V < bytes_valid;
+    const GVT* src = (const GVT*)(base + ((uint32_t)row * pitch + (uint32_t)(v * V)));  // < 2^31: K, M bounded by the host
+    if constexpr (V == 16) {
+      u32x4 q = {0u, 0u, 0u, 0u};
+      if (ok) q = stream ? __builtin_nontemporal_load(src) : *src;
+      r[4 * i] = q[0];
+      r[4 * i + 1] = q[1];
+      r[4 * i + 2] = q[2];
+      r[4 * i + 3] = q[3];
+    } else {
+      static_assert(V == 8, "register path: 16- and 8-byte vectors");
+      u32x2 q = {0u, 0u};
+      if (ok) q = stream ? __builtin_nontemporal_load(src) : *src;
+      r[2 * i] = q[0];
+      r[2 * i + 1] = q[1];
+    }
+  }
+}
+
+template <int V, int ROWBYTES, int PITCH>
+__device__ __forceinline__ void gen_stage(const uint32_t (&r)[16], char* img, int tid) {
+  constexpr int NV = ROWBYTES / V;
+  constexpr int PER = 64 / V;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx / NV;
+    const int v = idx % NV;
+    char* dst = img + row * PITCH + v * V;
+    if constexpr (V == 16) {
+      const u32x4 q = {r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
+      *reinterpret_cast<u32x4*>(dst) = q;
+    } else {
+      const u32x2 q = {r[2 * i], r[2 * i + 1]};
+      *reinterpret_cast<u32x2*>(dst) = q;
+    }
+  }
+}
+
+// Narrow classes (4- and 2-byte vectors: rows that are not even 8-byte multiples) are copied global -> LDS in place at
+// staging time, a few vectors at a time: keeping 16 / 32 loads per thread in flight across the multiply costs more
+// registers than such shapes are worth (with all four widths on the register path the kernel spilled 300 VGPRs).
+template <int V, int ROWBYTES, int PITCH>
+__device__ __forceinline__ void gen_copy(char* img, const char* base, uint32_t pitch, int rows_valid, int bytes_valid,
+                                         int tid) {
+  constexpr int NV = ROWBYTES / V;
+  constexpr int PER = 64 / V;
+  typedef typename GenVec<V>::type VT;
+  typedef __attribute__((address_space(1))) VT GVT;
+#pragma unroll 4
+  for (int i = 0; i < PER; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx / NV;
+    const int v = idx % NV;
+    VT q = 0;
+    if (row < rows_valid && v * V < bytes_valid) q = *(const GVT*)(base + ((uint32_t)row * pitch + (uint32_t)(v * V)));
+    *reinterpret_cast<VT*>(img + row * PITCH + v * V) = q;
+  }
+}
+
+// One operand block of a step: where it lies in memory and how much of it exists.
+struct GenBlock {
+  const char* base;
+  uint32_t pitch;
+  int rows_valid;
+  int bytes_valid;
+};
+
+template <int ROWBYTES>
+__device__ __forceinline__ void gen_load_cls(int lg, uint32_t (&r)[16], const GenBlock& b, int tid, bool stream) {
+  if (lg >= 4) gen_load<16, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
+  else if (lg == 3) gen_load<8, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
+}
+
+template <int ROWBYTES, int PITCH>
+__device__ __forceinline__ void gen_stage_cls(int lg, const uint32_t (&r)[16], char* img, const GenBlock& b, int tid) {
+  if (lg >= 4) gen_stage<16, ROWBYTES, PITCH>(r, img, tid);
+  else if (lg == 3) gen_stage<8, ROWBYTES, PITCH>(r, img, tid);
+  else if (lg == 2) gen_copy<4, ROWBYTES, PITCH>(img, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid);
+  else gen_copy<2, ROWBYTES, PITCH>(img, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid);
+}
+
+// Wave-private stage (32 rows x 256 bytes of output, pitch kGenPS) -> global rows, V-byte pieces masked by
+// (row < rows_valid, column byte < bytes_valid).
+template <int V>
+__device__ __forceinline__ void gen_store(const char* st, char* dst, uint32_t pitch, int rows_valid, int bytes_valid,
+                                          int lane) {
+  constexpr int NV = 256 / V;
+  constexpr int PER = NV / 2;
+  typedef typename GenVec<V>::type VT;
+  typedef __attribute__((address_space(1))) VT GVT;
+#pragma unroll 8
+  for (int i = 0; i < PER; ++i) {
+    const int idx = i * 64 + lane;
+    const int r = idx / NV;
+    const int v = idx % NV;
+    const VT val = *reinterpret_cast<const VT*>(st + r * kGenPS + v * V);
+    if (r < rows_valid && v * V < bytes_valid) {
+      GVT* p = (GVT*)(dst + ((uint32_t)r * pitch + (uint32_t)(v * V)));
+      if constexpr (V >= 8) __builtin_nontemporal_store(val, p);
+      else *p = val;
+    }
+  }
+}
+
+__device__ __forceinline__ u32x2 gen_pack4(bf16_t, const float* v) {
+  u32x2 q;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint16_t a = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i]);
+    const uint16_t b = __builtin_bit_cast(uint16_t, (__bf16)v[2 * i + 1]);
+    q[i] = (uint32_t)a | ((uint32_t)b << 16);
+  }
+  return q;
+}
+__device__ __forceinline__ u32x2 gen_pack4(f16_t, const float* v) {
+  u32x2 q;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint16_t a = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i]);
+    const uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)v[2 * i + 1]);
+    q[i] = (uint32_t)a | ((uint32_t)b << 16);
+  }
+  return q;
+}
+
+// One chunk of the contraction for one wave: acc[b] += W^T[32 b ... 32 b + 31][chunk] * X^T[chunk][32 rows], b < NBLK.
+// `xp` = the lane's row of the X image (+ 16 h), `W` = the W image ([k][128 columns], or [128 columns][k] if TRANS).
+template <typename T, int NBLK, bool TRANS>
+__device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const char* W, int kvalid, int lane) {
+  constexpr int SZ = Elem<T>::kSize;
+  constexpr int PW = 128 * SZ + 64;
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4i16* lds_v4;
+  const int j = lane & 31, h = lane >> 5;
+  if constexpr (SZ == 2) {
+    const int nks = (kvalid + 15) >> 4;
+    if constexpr (!TRANS) {
+      const int q = lane & 15, g1 = (lane >> 4) & 1;
+      const char* wp = W + (h * 8 + (q >> 2)) * PW + (g1 * 16 + (q & 3) * 4) * 2;
+      for (int ks = 0; ks < nks; ++ks) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xp + ks * 32);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wp + ks * 16 * PW + b * 64));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wp + (ks * 16 + 4) * PW + b * 64));
+          const u32x4 wa = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[b] = mfma_chunk(T{}, wa, xa, acc[b]);
+        }
+      }
+    } else {
+      const char* wp = W + j * kGenPX + h * 16;
+      for (int ks = 0; ks < nks; ++ks) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xp + ks * 32);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          const u32x4 wa = *reinterpret_cast<const u32x4*>(wp + b * 32 * kGenPX + ks * 32);
+          acc[b] = mfma_chunk(T{}, wa, xa, acc[b]);
+        }
+      }
+    }
+  } else {
+    // fp32: v_mfma_f32_32x32x2_f32 takes one value per lane and step; lane half h of 16-byte piece kq holds
+    // k = 8 kq + 4 h + e, e = 0 ... 3 (the contraction order inside a chunk is permuted, A and B alike)
+    const int nkq = (kvalid + 7) >> 3;
+    if constexpr (!TRANS) {
+      const char* wp = W + (h * 4) * PW + j * 4;
+      for (int kq = 0; kq < nkq; ++kq) {
+        const f32x4 xf = *reinterpret_cast<const f32x4*>(xp + kq * 32);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          float a[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = *reinterpret_cast<const float*>(wp + (kq * 8 + e) * PW + b * 128);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xf[e], acc[b], 0, 0, 0);
+        }
+      }
+    } else {
+      const char* wp = W + j * kGenPX + h * 16;
+      for (int kq = 0; kq < nkq; ++kq) {
+        const f32x4 xf = *reinterpret_cast<const f32x4*>(xp + kq * 32);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(wp + b * 32 * kGenPX + kq * 32);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], xf[e], acc[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* __restrict__ descs,
+                                                               const int32_t* __restrict__ tile_start, int B,
+                                                               int run_log2) {
+  constexpr int SZ = Elem<T>::kSize;
+  constexpr int KC = 128 / SZ;          // contraction values per chunk
+  constexpr int PW = 128 * SZ + 64;     // pitch of the [k][128 columns] image of W
+  constexpr int WROWB = 128 * SZ;       // bytes of one k-row of that image
+  constexpr int PB = 64 / (16 * SZ) * 2;  // 32-column blocks per 256-byte epilogue pass: 4 (16-bit) / 2 (fp32)
+  static_assert(KC * PW <= kGenWBytes, "W image");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+
+  // blockIdx -> tile: consecutive workgroup ids go to consecutive XCDs; XCD k is dealt runs of 2^run_log2
+  // consecutive tiles (tiles ((s >> r) * 8 + k) << r ... ), so every XCD streams ~256 KiB contiguous pieces
+  const int bs = (int)blockIdx.x >> 3, bk = (int)blockIdx.x & 7;
+  const int t = ((((bs >> run_log2) << 3) + bk) << run_log2) + (bs & ((1 << run_log2) - 1));
+  const int total = tile_start[B];
+  if (t >= total) return;
+
+  // group of the tile: the last g with tile_start[g] <= t, by a 64-ary search (two dependent loads for B <= 4096)
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool pred = idx < hi && tile_start[idx < hi ? idx : lo] <= t;
+    const int n = __builtin_popcountll(__ballot(pred));  // lane 0 always holds (tile_start[lo] <= t)
+    lo += (n - 1) * step;
+    hi = lo + step < hi ? lo + step : hi;
+  }
+  const DevGroup d = descs[lo];
+  const int K = d.k, M = d.m;
+  const bool trans = d.trans != 0;
+  const int lgx = d.pad & 7, lgw = (d.pad >> 3) & 7, lgc = (d.pad >> 6) & 7;
+  const int64_t row0 = (int64_t)(t - tile_start[lo]) * 128;
+  const int rows_here = (int)(d.rows - row0 < 128 ? d.rows - row0 : 128);
+  const int nchunks = K > 0 ? (K + KC - 1) / KC : 1;
+  const int ncb = (M + 127) >> 7;
+  const int nsteps = ncb * nchunks;
+  const uint32_t xpitch = (uint32_t)K * SZ, opitch = (uint32_t)M * SZ;  // K, M < 2^21 (host check): 128 rows < 2^31 bytes
+  const char* xbase = d.a + row0 * xpitch;
+  const bool xstream = ncb == 1;  // X is read once: streaming hint
+
+  uint32_t xr[16], wr[16];
+  auto x_block = [&](int s) {
+    const int c = s % nchunks;
+    return GenBlock{xbase + c * 128, xpitch, rows_here, K * SZ - c * 128};
+  };
+  auto w_block = [&](int s) {
+    const int nb = s / nchunks;
+    const int c = s - nb * nchunks;
+    if (!trans) return GenBlock{d.w + ((int64_t)c * KC * M + nb * 128) * SZ, opitch, K - c * KC, (M - nb * 128) * SZ};
+    return GenBlock{d.w + (int64_t)nb * 128 * xpitch + c * 128, xpitch, M - nb * 128, K * SZ - c * 128};
+  };
+  // The per-vector offsets of every (operand, class) pair are loop-invariant; hoisted out of the step loop they cost
+  // ~150 registers (seen as 300 spilled VGPRs).  The thread id goes through an opaque asm per step instead: a handful
+  // of integer instructions per chunk.
+  auto issue = [&](int s) {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    gen_load_cls<128>(lgx, xr, x_block(s), t2, xstream);
+    if (!trans) gen_load_cls<WROWB>(lgw, wr, w_block(s), t2, false);
+    else gen_load_cls<128>(lgw, wr, w_block(s), t2, false);
+  };
+  auto stage = [&](int s) {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    char* X = smem + (s & 1) * kGenBuf;
+    gen_stage_cls<128, kGenPX>(lgx, xr, X, x_block(s), t2);
+    if (!trans) gen_stage_cls<WROWB, PW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    else gen_stage_cls<128, kGenPX>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+  };
+
+  issue(0);
+  stage(0);
+  __syncthreads();
+
+  const bool active = wave * 32 < rows_here;  // waves without rows still load, stage and meet the barriers
+  f32x16 acc[4];
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int nb = s / nchunks;
+    const int c = s - nb * nchunks;
+    if (s + 1 < nsteps) issue(s + 1);
+    const char* X = smem + (s & 1) * kGenBuf;
+    const char* W = X + kGenXBytes;
+    const int mvalid = M - nb * 128 < 128 ? M - nb * 128 : 128;
+    const int nblk = (mvalid + 31) >> 5;
+    if (active) {
+      if (c == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      }
+      const int kvalid = K - c * KC < KC ? K - c * KC : KC;
+      const char* xp = X + (wave * 32 + j) * kGenPX + h * 16;
+      // column blocks behind M multiply the zero-filled part of the W image: only whole halves are skipped
+      if (nblk > 2) {
+        if (!trans) gen_mma<T, 4, false>(acc, xp, W, kvalid, lane);
+        else gen_mma<T, 4, true>(acc, xp, W, kvalid, lane);
+      } else {
+        if (!trans) gen_mma<T, 2, false>(acc, xp, W, kvalid, lane);
+        else gen_mma<T, 2, true>(acc, xp, W, kvalid, lane);
+      }
+    }
+    if (c == nchunks - 1) {
+      if (active) {
+        // epilogue: the other stage buffer is idle (its next contents are still in xr / wr)
+        char* st = smem + ((s + 1) & 1) * kGenBuf + wave * (32 * kGenPS);
+        const int wrows = rows_here - wave * 32 < 32 ? rows_here - wave * 32 : 32;
+        char* obase = d.c + (row0 + wave * 32) * (int64_t)opitch + (int64_t)nb * 128 * SZ;
+        const T* bias = d.bias ? reinterpret_cast<const T*>(d.bias) + nb * 128 : nullptr;
+#pragma unroll
+        for (int p = 0; p < 4 / PB; ++p) {
+          if (p * PB < nblk) {
+#pragma unroll
+            for (int bb = 0; bb < PB; ++bb) {
+              const int b = p * PB + bb;
+              if (b < nblk) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                  float v[4];
+                  const int col = 32 * b + 8 * g4 + 4 * h;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[b][4 * g4 + e];
+                    if (bias && col + e < mvalid) v[e] = round_to(T{}, v[e]) + load_bias(bias + col + e);
+                  }
+                  char* dst = st + j * kGenPS + (32 * bb + 8 * g4 + 4 * h) * SZ;
+                  if constexpr (SZ == 2) {
+                    *reinterpret_cast<u32x2*>(dst) = gen_pack4(T{}, v);
+                  } else {
+                    const f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                  }
+                }
+              }
+            }
+            const int bvalid = mvalid * SZ - p * 256;
+            char* od = obase + p * 256;
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            if (lgc >= 4) gen_store<16>(st, od, opitch, wrows, bvalid, l2);
+            else if (lgc == 3) gen_store<8>(st, od, opitch, wrows, bvalid, l2);
+            else if (lgc == 2) gen_store<4>(st, od, opitch, wrows, bvalid, l2);
+            else gen_store<2>(st, od, opitch, wrows, bvalid, l2);
+          }
+        }
+      }
+      if (s + 1 < nsteps) __syncthreads();  // everybody is done with its stage before the next chunk lands there
+    }
+    if (s + 1 < nsteps) {
+      stage(s + 1);
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T>
+int launch_gen(const DevGroup* descs, const int32_t* tile_start, int B, int64_t tiles_upper, int64_t mean_k,
+               hipStream_t stream) {
+  const void* kern = reinterpret_cast<const void*>(&mfma_rows_gen_kernel<T>);
+  if (int rc_ = ensure_dynamic_lds(kern, kGenLds)) return rc_;
+  // every XCD is dealt runs of ~256 KiB of consecutive X tiles (32 / 64 KiB pieces per XCD are the slow ones)
+  const int64_t tile_bytes = std::max<int64_t>(128 * mean_k * Elem<T>::kSize, 1);
+  int run_log2 = 0;
+  while (run_log2 < 4 && (tile_bytes << (run_log2 + 1)) <= 262144) ++run_log2;
+  const int64_t per = 8LL << run_log2;
+  const int64_t grid = (std::max<int64_t>(tiles_upper, 1) + per - 1) / per * per;
+  hipLaunchKernelGGL((mfma_rows_gen_kernel<T>), dim3((unsigned)grid), dim3(256), kGenLds, stream, descs, tile_start, B,
+                     run_log2);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+}  // namespace
+
+int launch_matmul_gen(int dtype, const void* descs, const int32_t* tile_start, int B, int64_t tiles_upper, int64_t mean_k,
+                      hipStream_t stream) {
+  const DevGroup* d = static_cast<const DevGroup*>(descs);
+  if (dtype == PYG_BF16) return launch_gen<bf16_t>(d, tile_start, B, tiles_upper, mean_k, stream);
+  if (dtype == PYG_F16) return launch_gen<f16_t>(d, tile_start, B, tiles_upper, mean_k, stream);
+  if (dtype == PYG_F32) return launch_gen<float>(d, tile_start, B, tiles_upper, mean_k, stream);
+  return fail(PYG_HIP_ERR_INVALID, "matmul (general shapes): unsupported dtype %d", dtype);
+}
+
+}  // namespace pyg_hip

@@ -49,7 +49,7 @@ def test_docstring_example_generic_path(ptr_on_device):
     x, ptr, w, b = (torch.from_numpy(GOLD[k]) for k in ('doc_x', 'doc_ptr', 'doc_w', 'doc_bias'))
     p = ptr.to(DEV) if ptr_on_device else ptr
     out = ops.segment_matmul(x.to(DEV), p, w.to(DEV))
-    assert ops.matmul_last_variant() == 'naive'
+    assert ops.matmul_last_variant() == 'mfma_f32_gen'  # K = 16 -> 32... any shape: the general-shape MFMA kernel
     np.testing.assert_allclose(out.cpu().numpy(), GOLD['doc_out'], atol=1e-5)
     outb = ops.segment_matmul(x.to(DEV), p, w.to(DEV), bias=b.to(DEV))
     np.testing.assert_allclose(outb.cpu().numpy(), GOLD['doc_out_bias'], atol=1e-5)
