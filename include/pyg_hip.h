@@ -123,7 +123,10 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  *      to place input and output favourably, 5.0 TB/s otherwise;
  *   2  banded cyclic (mfma_rows_cyc_kernel): 6.2 - 6.3 TB/s on favourably placed buffers, 5.4 - 5.6 otherwise;
  *   3  tickets (mfma_rows_ticket_kernel): tiles drawn in address order from per-XCD counters, W in registers:
- *      6.1 - 6.2 TB/s on either placement.
+ *      6.1 - 6.2 TB/s on either placement;
+ *   4  (measurement only) every bf16 / f16 / f32 call through the general-shape MFMA kernel (matmul_gen.hip), also the
+ *      shapes that have a specialised kernel;
+ *   5  (measurement only) every call through the one-thread-per-output kernel.
  * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
 PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
 

@@ -2482,7 +2482,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int run_planned(int dtype, const Workspace& w, int B, int64_t K, int64_t M, bool uniform,
                 int64_t tiles_upper, int64_t out_elems_upper, hipStream_t stream) {
-  if (uniform && mfma_shape_ok(dtype, K, M)) {
+  // schedules 4 / 5 (measurement only): every float shape through the general-shape kernel / the one-thread-per-output one
+  if (g_schedule == 5) return dispatch_naive(dtype, w, B, out_elems_upper, stream);
+  if (uniform && mfma_shape_ok(dtype, K, M) && g_schedule != 4) {
     bool handled = false;
     int rc = PYG_HIP_OK;
     if (dtype == PYG_BF16)
@@ -2516,7 +2518,7 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
-void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 3) ? mode : 0; }
+void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 5) ? mode : 0; }
 
 void pyg_hip_profile_enable(int on) {
   g_prof_on = on != 0;

@@ -33,7 +33,7 @@ constexpr int kGenPX = 144;                   // pitch of a [row][128-byte slice
 constexpr int kGenXBytes = 128 * kGenPX;      // 18432
 constexpr int kGenWBytes = 64 * (256 + 64);   // [64 k][128 col] 16-bit image (fp32: [32][128] x 576 = 18432)
 constexpr int kGenBuf = kGenXBytes + kGenWBytes;
-constexpr int kGenLds = 2 * kGenBuf;          // 77824 bytes: two workgroups per CU
+constexpr int kGenLds = kGenBuf;              // 38912 bytes: ONE stage buffer (the second one is the registers), 3 workgroups per CU
 constexpr int kGenPS = 272;                   // epilogue stage pitch (256 bytes of one output row + pad)
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -251,46 +251,21 @@ __device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* __restrict__ descs,
-                                                               const int32_t* __restrict__ tile_start, int B,
-                                                               int run_log2) {
+// One 128-row tile of group `d` (rows row0 ...): all column passes and contraction chunks.  NBLK = 32-column blocks
+// multiplied per pass (2 when the group has at most 64 columns), TRANS = `other` is stored [M][K].  One function
+// per (NBLK, TRANS) so that every variant owns its accumulators: with the variants as branches inside one step loop
+// the accumulators were copied between the branches' register assignments on every step (128 v_mov per chunk).
+template <typename T, int NBLK, bool TRANS>
+__device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, char* smem, const int tid,
+                                         const int lane, const int wave) {
   constexpr int SZ = Elem<T>::kSize;
   constexpr int KC = 128 / SZ;          // contraction values per chunk
   constexpr int PW = 128 * SZ + 64;     // pitch of the [k][128 columns] image of W
   constexpr int WROWB = 128 * SZ;       // bytes of one k-row of that image
   constexpr int PB = 64 / (16 * SZ) * 2;  // 32-column blocks per 256-byte epilogue pass: 4 (16-bit) / 2 (fp32)
-  static_assert(KC * PW <= kGenWBytes, "W image");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31;
-  const int h = lane >> 5;
-
-  // blockIdx -> tile: consecutive workgroup ids go to consecutive XCDs; XCD k is dealt runs of 2^run_log2
-  // consecutive tiles (tiles ((s >> r) * 8 + k) << r ... ), so every XCD streams ~256 KiB contiguous pieces
-  const int bs = (int)blockIdx.x >> 3, bk = (int)blockIdx.x & 7;
-  const int t = ((((bs >> run_log2) << 3) + bk) << run_log2) + (bs & ((1 << run_log2) - 1));
-  const int total = tile_start[B];
-  if (t >= total) return;
-
-  // group of the tile: the last g with tile_start[g] <= t, by a 64-ary search (two dependent loads for B <= 4096)
-  int lo = 0, hi = B;
-  while (hi - lo > 1) {
-    const int step = (hi - lo + 63) >> 6;
-    const int idx = lo + lane * step;
-    const bool pred = idx < hi && tile_start[idx < hi ? idx : lo] <= t;
-    const int n = __builtin_popcountll(__ballot(pred));  // lane 0 always holds (tile_start[lo] <= t)
-    lo += (n - 1) * step;
-    hi = lo + step < hi ? lo + step : hi;
-  }
-  const DevGroup d = descs[lo];
+  constexpr bool trans = TRANS;
   const int K = d.k, M = d.m;
-  const bool trans = d.trans != 0;
   const int lgx = d.pad & 7, lgw = (d.pad >> 3) & 7, lgc = (d.pad >> 6) & 7;
-  const int64_t row0 = (int64_t)(t - tile_start[lo]) * 128;
   const int rows_here = (int)(d.rows - row0 < 128 ? d.rows - row0 : 128);
   const int nchunks = K > 0 ? (K + KC - 1) / KC : 1;
   const int ncb = (M + 127) >> 7;
@@ -323,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* _
   auto stage = [&](int s) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    char* X = smem + (s & 1) * kGenBuf;
+    char* X = smem;
     gen_stage_cls<128, kGenPX>(lgx, xr, X, x_block(s), t2);
     if (!trans) gen_stage_cls<WROWB, PW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
     else gen_stage_cls<128, kGenPX>(lgw, wr, X + kGenXBytes, w_block(s), t2);
@@ -340,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* _
     const int nb = s / nchunks;
     const int c = s - nb * nchunks;
     if (s + 1 < nsteps) issue(s + 1);
-    const char* X = smem + (s & 1) * kGenBuf;
+    const char* X = smem;
     const char* W = X + kGenXBytes;
     const int mvalid = M - nb * 128 < 128 ? M - nb * 128 : 128;
     const int nblk = (mvalid + 31) >> 5;
@@ -352,20 +327,20 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* _
           for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
       }
       const int kvalid = K - c * KC < KC ? K - c * KC : KC;
-      const char* xp = X + (wave * 32 + j) * kGenPX + h * 16;
-      // column blocks behind M multiply the zero-filled part of the W image: only whole halves are skipped
-      if (nblk > 2) {
-        if (!trans) gen_mma<T, 4, false>(acc, xp, W, kvalid, lane);
-        else gen_mma<T, 4, true>(acc, xp, W, kvalid, lane);
-      } else {
-        if (!trans) gen_mma<T, 2, false>(acc, xp, W, kvalid, lane);
-        else gen_mma<T, 2, true>(acc, xp, W, kvalid, lane);
-      }
+      int l1 = lane;
+      asm volatile("" : "+v"(l1));  // as in issue(): keep the lane-derived LDS offsets of all variants out of registers
+      const char* xp = X + (wave * 32 + (l1 & 31)) * kGenPX + (l1 >> 5) * 16;
+      // column blocks behind M multiply the zero-filled part of the W image
+      gen_mma<T, NBLK, TRANS>(acc, xp, W, kvalid, l1);
     }
+    if (s + 1 < nsteps || c == nchunks - 1) __syncthreads();  // everybody has multiplied: the buffer is free
     if (c == nchunks - 1) {
       if (active) {
-        // epilogue: the other stage buffer is idle (its next contents are still in xr / wr)
-        char* st = smem + ((s + 1) & 1) * kGenBuf + wave * (32 * kGenPS);
+        // epilogue through the (now idle) stage buffer; the next chunk is still in xr / wr
+        char* st = smem + wave * (32 * kGenPS);
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int j = l2 & 31, h = l2 >> 5;
         const int wrows = rows_here - wave * 32 < 32 ? rows_here - wave * 32 : 32;
         char* obase = d.c + (row0 + wave * 32) * (int64_t)opitch + (int64_t)nb * 128 * SZ;
         const T* bias = d.bias ? reinterpret_cast<const T*>(d.bias) + nb * 128 : nullptr;
@@ -397,8 +372,6 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* _
             }
             const int bvalid = mvalid * SZ - p * 256;
             char* od = obase + p * 256;
-            int l2 = lane;
-            asm volatile("" : "+v"(l2));
             if (lgc >= 4) gen_store<16>(st, od, opitch, wrows, bvalid, l2);
             else if (lgc == 3) gen_store<8>(st, od, opitch, wrows, bvalid, l2);
             else if (lgc == 2) gen_store<4>(st, od, opitch, wrows, bvalid, l2);
@@ -412,6 +385,45 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_gen_kernel(const DevGroup* _
       stage(s + 1);
       __syncthreads();
     }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void mfma_rows_gen_kernel(const DevGroup* __restrict__ descs,
+                                                               const int32_t* __restrict__ tile_start, int B,
+                                                               int run_log2) {
+  static_assert((128 / Elem<T>::kSize) * (128 * Elem<T>::kSize + 64) <= kGenWBytes, "W image");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // blockIdx -> tile: consecutive workgroup ids go to consecutive XCDs; XCD k is dealt runs of 2^run_log2
+  // consecutive tiles (tiles ((s >> r) * 8 + k) << r ... ), so every XCD streams ~256 KiB contiguous pieces
+  const int bs = (int)blockIdx.x >> 3, bk = (int)blockIdx.x & 7;
+  const int t = ((((bs >> run_log2) << 3) + bk) << run_log2) + (bs & ((1 << run_log2) - 1));
+  const int total = tile_start[B];
+  if (t >= total) return;
+
+  // group of the tile: the last g with tile_start[g] <= t, by a 64-ary search (two dependent loads for B <= 4096)
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool pred = idx < hi && tile_start[idx < hi ? idx : lo] <= t;
+    const int n = __builtin_popcountll(__ballot(pred));  // lane 0 always holds (tile_start[lo] <= t)
+    lo += (n - 1) * step;
+    hi = lo + step < hi ? lo + step : hi;
+  }
+  const DevGroup d = descs[lo];
+  const int64_t row0 = (int64_t)(t - tile_start[lo]) * 128;
+  if (d.m > 64) {
+    if (!d.trans) gen_tile<T, 4, false>(d, row0, smem, tid, lane, wave);
+    else gen_tile<T, 4, true>(d, row0, smem, tid, lane, wave);
+  } else {
+    if (!d.trans) gen_tile<T, 2, false>(d, row0, smem, tid, lane, wave);
+    else gen_tile<T, 2, true>(d, row0, smem, tid, lane, wave);
   }
 }
 

@@ -354,8 +354,10 @@ def set_matmul_schedule(mode: str = 'auto') -> None:
     """Tile schedule of the 16-bit ``K = M = 128`` matmul kernels: ``'auto'`` (default), ``'contiguous'`` (one
     tile range per workgroup), ``'cyclic'`` (every XCD sweeps its band of tiles) or ``'ticket'`` (tiles drawn in
     address order from per-XCD counters, W in registers) -- see ``pyg_hip_matmul_set_schedule`` in
-    include/pyg_hip.h.  Process wide."""
-    _capi.lib().pyg_hip_matmul_set_schedule({'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3}[mode])
+    include/pyg_hip.h.  ``'general'`` / ``'naive'`` (measurement only) send every floating-point shape through the
+    general-shape MFMA kernel / every call through the one-thread-per-output kernel.  Process wide."""
+    _capi.lib().pyg_hip_matmul_set_schedule({'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3, 'general': 4,
+                                             'naive': 5}[mode])
 
 
 __all__ = [
