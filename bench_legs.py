@@ -98,6 +98,88 @@ def leg_c4(device, rank, world, iters=10, F=256, dtype=torch.bfloat16):
 
 
 # ---------------------------------------------------------------------------------------------------
+# grouped_matmul with per-group shapes (HeteroDictLinear: one K per node type) and segment_matmul K = 100
+# ---------------------------------------------------------------------------------------------------
+
+def _kernel_ms(fn, iters=10, warmup=3):
+    """Mean duration of the matmul kernel itself: HIP events recorded around it on its launch stream
+    (pyg_hip_profile_*, include/pyg_hip.h)."""
+    import ctypes
+    from pyg_lib_amd import _capi
+    L = _capi.lib()
+    L.pyg_hip_profile_enable.argtypes = [ctypes.c_int]
+    L.pyg_hip_profile_collect.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.pyg_hip_profile_collect.restype = ctypes.c_int
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    L.pyg_hip_profile_enable(1)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_float * iters)()
+    n = L.pyg_hip_profile_collect(buf, iters)
+    L.pyg_hip_profile_enable(0)
+    return sum(buf[i] for i in range(min(n, iters))) / max(min(n, iters), 1)
+
+
+def leg_grouped_mixed(device, rows_total=6_000_000, G=64, ks=(100, 128, 256, 768), M=128, dtype=torch.bfloat16):
+    """64 groups, rows log-uniform [1 Ki, 256 Ki] scaled to 6 M rows, K cycling through 100 / 128 / 256 / 768, M = 128:
+    a mixed-shape list as the reference's grouped GEMM takes (one GemmCoord per group,
+    ops/cuda/matmul_kernel.cu:33-67).  Runs the general-shape MFMA kernel (csrc/hip/matmul_gen.hip); the
+    one-thread-per-output kernel such lists ran before round 3 is timed beside it."""
+    from pyg_lib_amd import ops
+    g = torch.Generator().manual_seed(0)
+    rows = torch.exp(torch.rand(G, generator=g) * (math.log(262144.0) - math.log(1024.0)) + math.log(1024.0))
+    rows = (rows / rows.sum() * rows_total).long().tolist()
+    gd = torch.Generator(device=device).manual_seed(1)
+    kk = [ks[i % len(ks)] for i in range(G)]
+    xs = [torch.randn(r, k, device=device, generator=gd).to(dtype) for r, k in zip(rows, kk)]
+    ws = [(torch.randn(k, M, device=device, generator=gd) / k ** 0.5).to(dtype) for k in kk]
+    s = xs[0].element_size()
+    alg = sum(s * (r * k + r * M + k * M) for r, k in zip(rows, kk))
+    flops = sum(2.0 * r * k * M for r, k in zip(rows, kk))
+    ms = _kernel_ms(lambda: ops.grouped_matmul(xs, ws))
+    variant = ops.matmul_last_variant()
+    res = _rate(alg, ms)
+    res.update(workload=f'grouped_matmul: {G} groups, {sum(rows)} rows, K in {list(ks)} -> M={M}, bf16 (per-group shapes)',
+               kernel=variant, TFLOPs=round(flops / (ms * 1e-3) / 1e12, 1), bound='hbm')
+    ops.set_matmul_schedule('naive')
+    try:
+        ms_naive = _kernel_ms(lambda: ops.grouped_matmul(xs, ws), iters=2, warmup=1)
+        res['naive_kernel'] = dict(ms=round(ms_naive, 3), GBps=round(alg / (ms_naive * 1e-3) / 1e9, 1),
+                                   slowdown=round(ms_naive / ms, 1))
+    finally:
+        ops.set_matmul_schedule('auto')
+    del xs, ws
+    # segment_matmul with ogbn-products' feature width
+    N, K, B = 8_000_000, 100, 47
+    x = torch.randn(N, K, device=device, generator=gd).to(dtype)
+    w = (torch.randn(B, K, M, device=device, generator=gd) / 10).to(dtype)
+    fr = torch.rand(B, generator=g)
+    sizes = torch.floor(fr / fr.sum() * N).long()
+    sizes[-1] += N - sizes.sum()
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w))
+    res['segment_k100'] = dict(workload=f'segment_matmul: {N} rows, K=100 -> M={M}, {B} segments, bf16',
+                               kernel=ops.matmul_last_variant(), **_rate(s * (N * K + N * M + B * K * M), ms))
+    return res
+
+
+def leg_segment_matmul_f32(device, make_c2, iters=5):
+    """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  AI = 32 flop/B is above the fp32 ridge
+    (157 TF / 8 TB/s = 20), so the bound is the dense fp32 MFMA rate (v_mfma_f32_32x32x2_f32)."""
+    from pyg_lib_amd import ops
+    x, ptr, w, (N, B, F) = make_c2(device, 0, 1, torch.float32, 1.0)
+    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
+    tf = 2.0 * N * F * F / (ms * 1e-3) / 1e12
+    alg = 4 * (2 * N * F + B * F * F) + 8 * (B + 1)
+    return dict(workload='segment_matmul C2 in fp32 (154 relations, 21,111,007 rows, F=128)', kernel=ops.matmul_last_variant(),
+                bound='mfma', achieved=round(tf, 1), peak=157.0, unit='TFLOP/s', frac=round(tf / 157.0, 4),
+                kernel_ms=round(ms, 4), alg_bytes=int(alg), hbm_GBps=round(alg / (ms * 1e-3) / 1e9, 1))
+
+
+# ---------------------------------------------------------------------------------------------------
 # C5: hetero_neighbor_sample + R-GCN layer on a MAG-shaped graph (BASELINE.json configs[4])
 # ---------------------------------------------------------------------------------------------------
 

@@ -75,9 +75,18 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
     index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128``; anything else
-    takes the three-op chain."""
+    takes the three-op chain.
+
+    The fused operator is inference-only (``pyg::rgcn_fused`` has no autograd formula): when gradients are being
+    recorded for ``x`` or ``weight`` the differentiable three-op chain runs instead, so a training loop that switches
+    to this function keeps learning.  Accumulation: messages are rounded to the storage type (what the chain
+    materialises), summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with
+    one packed 16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile
+    boundaries) is rounded once per run, where ``scatter_sum`` rounds once per destination."""
     total = offsets['__total__']
-    if not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and weight.size(-1) == 128 and x.is_cuda):
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+    if needs_grad or not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and
+                          weight.size(-1) == 128 and x.is_cuda):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:

@@ -135,7 +135,8 @@ def _grouped_into(inputs: List[Tensor], others: List[Tensor], pool: Tensor) -> L
 
 
 def grouped_matmul_sharded(inputs_local: List[Tensor], others_local: List[Tensor], plan: GroupPlan, rank: int,
-                           gather: bool = False, group=None, matmul_into=None):
+                           gather: bool = False, group=None, matmul_into=None, out_features: Optional[int] = None,
+                           dtype: Optional[torch.dtype] = None, device=None):
     """grouped_matmul over this rank's groups (``plan.local_groups(rank)``, in that order).
 
     The outputs are written into this rank's slot of a ``[world, max_rows, M]`` pool.  With
@@ -143,17 +144,28 @@ def grouped_matmul_sharded(inputs_local: List[Tensor], others_local: List[Tensor
     rest of the pool is untouched; with ``gather=True`` one in-place ``all_gather_into_tensor`` fills the
     other slots and the function returns ``(all_outs, pool)`` with every group's result (global order)
     as a row slice of the pool.  ``matmul_into(inputs, others, slot)`` must write ``inputs[i] @ others[i]``
-    to consecutive row ranges of ``slot`` and return them (default: ``pyg::grouped_matmul_pool``)."""
+    to consecutive row ranges of ``slot`` and return them (default: ``pyg::grouped_matmul_pool``).
+
+    A rank that owns no group (more ranks than non-empty groups) cannot read the pool's shape from its tensors:
+    pass ``out_features`` / ``dtype`` / ``device`` then; such a rank skips the matmul and still takes part in the
+    collective with its (empty) slot."""
     if matmul_into is None:
         matmul_into = _grouped_into
     mine = plan.local_groups(rank)
     assert len(inputs_local) == len(mine) == len(others_local), 'inputs_local must hold exactly this rank\'s groups'
     ref = others_local[0] if others_local else None
-    assert ref is not None or not gather, 'a rank without groups cannot size the gather pool'
-    m = ref.size(-1)
-    pool = ref.new_empty((plan.world_size, max(plan.max_rows, 1), m))
+    if ref is not None:
+        m = ref.size(-1) if out_features is None else int(out_features)
+        dtype = ref.dtype if dtype is None else dtype
+        device = ref.device if device is None else device
+    else:
+        if out_features is None or dtype is None or device is None:
+            raise ValueError('grouped_matmul_sharded: a rank without groups needs out_features, dtype and device '
+                             'to size its slot of the pool')
+        m = int(out_features)
+    pool = torch.empty((plan.world_size, max(plan.max_rows, 1), m), dtype=dtype, device=device)
     slot = pool[rank]
-    local_outs = matmul_into(inputs_local, others_local, slot[:plan.load[rank]])
+    local_outs = matmul_into(inputs_local, others_local, slot[:plan.load[rank]]) if mine else []
     if not gather or plan.world_size == 1:
         if not gather:
             return local_outs, pool

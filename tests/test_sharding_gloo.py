@@ -165,3 +165,43 @@ def test_shard_rows_partition():
             assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
             cnt = sharding.shard_counts(n, w)
             assert sum(cnt) == n and max(cnt) - min(cnt) <= 1
+
+
+def _empty_rank_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pyg_lib_amd import sharding
+        g = torch.Generator().manual_seed(0)
+        rows = [40]   # one group, two ranks: LPT leaves rank 1 without work
+        ins = [torch.randn(r, 16, generator=g) for r in rows]
+        oth = [torch.randn(16, 8, generator=g) for _ in rows]
+        plan = sharding.GroupPlan(rows, world)
+        mine = plan.local_groups(rank)
+        assert (mine == []) == (rank == 1)
+        kw = dict(out_features=8, dtype=torch.float32, device='cpu')
+        outs, pool = sharding.grouped_matmul_sharded([ins[i] for i in mine], [oth[i] for i in mine], plan, rank,
+                                                     gather=True, matmul_into=_oracle_grouped_into, **kw)
+        ok = len(outs) == 1 and torch.allclose(outs[0], ins[0] @ oth[0], atol=1e-5)
+        louts, _ = sharding.grouped_matmul_sharded([ins[i] for i in mine], [oth[i] for i in mine], plan, rank,
+                                                   gather=False, matmul_into=_oracle_grouped_into, **kw)
+        ok = ok and len(louts) == len(mine)
+        if rank == 1:  # without the shape arguments the empty rank says what it needs instead of hanging its peers
+            try:
+                sharding.grouped_matmul_sharded([], [], plan, rank, gather=False, matmul_into=_oracle_grouped_into)
+                ok = False
+            except ValueError:
+                pass
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_groups_still_joins_the_all_gather():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_empty_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
