@@ -7,7 +7,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <ATen/record_function.h>
-#include <rocprofiler-sdk-roctx/roctx.h>
+#include <dlfcn.h>
 
 #include "pyg_hip.h"
 
@@ -32,9 +32,34 @@ inline int dtype_code(at::ScalarType t) {
 
 // Op-level tracing: every operator entry shows up as a RECORD_FUNCTION range in the PyTorch
 // profiler and as a roctx range in rocprofv3 --marker-trace, named like the schema ("pyg::segment_matmul").
+// roctx is OPTIONAL: the two entry points are looked up in librocprofiler-sdk-roctx.so at first use (dlopen), so
+// libpyg.so carries no link-time dependency on the profiler SDK -- a host without it just gets no roctx ranges.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (h) {
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+  }
+};
+inline const RoctxApi& roctx_api() {
+  static const RoctxApi api;
+  return api;
+}
 struct RoctxRange {
-  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
-  ~RoctxRange() { roctxRangePop(); }
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) {
+    if (on) roctx_api().push(name);
+  }
+  ~RoctxRange() {
+    if (on) roctx_api().pop();
+  }
   RoctxRange(const RoctxRange&) = delete;
   RoctxRange& operator=(const RoctxRange&) = delete;
 };

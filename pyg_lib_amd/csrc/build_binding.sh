@@ -26,5 +26,5 @@ done
 for p in $pids; do wait $p; done
 $CXX -shared -fPIC $objs -o $OUT \
   -L"$TORCH/lib" -ltorch -ltorch_cpu -ltorch_hip -lc10 -lc10_hip \
-  -L/opt/rocm/lib -lrocprofiler-sdk-roctx -L.. -lpyg_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$TORCH/lib"
+  -ldl -L.. -lpyg_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$TORCH/lib"
 echo "built $OUT"

@@ -27,6 +27,8 @@
 // 8192-key tile (two workgroups per CU).  Same stable order, bit-identical result.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include "scan.h"
 
@@ -448,6 +450,19 @@ __global__ __launch_bounds__(512) void lds_rank_probe_kernel(unsigned* __restric
   if (errors) atomicAdd(bad, errors);
 }
 
+// The atomic in-wave rank is OPT-IN (environment PYG_HIP_SORT_ATOMIC_RANK=1): it is ~5 % faster, but it rests on an
+// LDS property the ISA does not promise (conflicting ds_add_rtn_u32 of one wave return in lane order), and a stable
+// LSD radix sort that loses stability in one pass is silently wrong.  The default is the ballot rank, which depends on
+// nothing but the ISA.  With the variable set, the probe below still has to pass once per device and process (it
+// allocates and synchronises a private stream: do not opt in under stream capture).
+bool atomic_rank_requested() {
+  static const bool on = [] {
+    const char* e = getenv("PYG_HIP_SORT_ATOMIC_RANK");
+    return e != nullptr && e[0] != '\0' && e[0] != '0';
+  }();
+  return on;
+}
+
 // per device, once per process; synchronises a private stream (never the caller's) on that first call
 bool lds_rank_order_ok() {
   static std::mutex mu;
@@ -483,7 +498,7 @@ Plan make_plan(int64_t n) {
   const int64_t tiles = (n + kTile - 1) / kTile;
   int64_t groups = std::min<int64_t>(tiles, (int64_t)device_info().num_cus * 4);
   if (groups < 1) groups = 1;
-  const int64_t tiles_per = (tiles + groups - 1) / groups;
+  const int64_t tiles_per = std::max<int64_t>((tiles + groups - 1) / groups, 1);  // n == 0: one empty slice, no division by zero
   Plan p;
   p.slice = tiles_per * kTile;
   p.groups = (n + p.slice - 1) / p.slice;
@@ -513,7 +528,7 @@ int run_sort(const void* keys_, int64_t n, int64_t max_value, int has_max, void*
     return fail(PYG_HIP_ERR_WORKSPACE, "index_sort: workspace of %zu bytes needed, got %zu", ws_bytes(n, sizeof(K)),
                 ws_size);
   const Plan p = make_plan(n);
-  const bool atomic_rank = lds_rank_order_ok();
+  const bool atomic_rank = atomic_rank_requested() && lds_rank_order_ok();
   char* w = static_cast<char*>(ws);
   K* kbuf = reinterpret_cast<K*>(w);
   w += align_up((size_t)n * sizeof(int64_t), 256);

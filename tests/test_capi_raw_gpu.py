@@ -1,0 +1,92 @@
+"""The C-ABI driven with raw device pointers through ctypes, no torch operator in between.
+
+PyTorch only allocates the device buffers and names the stream here; every call goes
+`ctypes -> libpyg_hip.so` exactly as a cgo / JNI / N-API host would bind it.  Results against the oracle.
+"""
+import ctypes
+import os.path as osp
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+DEV = 'cuda:0'
+PYG_F32, PYG_BF16, PYG_I64 = 0, 3, 8
+
+
+@pytest.fixture(scope='module')
+def lib():
+    L = ctypes.CDLL(osp.join(ROOT, 'pyg_lib_amd', 'libpyg_hip.so'))
+    c = ctypes
+    L.pyg_hip_last_error.restype = c.c_char_p
+    L.pyg_hip_matmul_workspace_size.restype = c.c_size_t
+    L.pyg_hip_matmul_workspace_size.argtypes = [c.c_int64]
+    L.pyg_hip_matmul_last_variant.restype = c.c_char_p
+    L.pyg_hip_segment_matmul.restype = c.c_int
+    L.pyg_hip_segment_matmul.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p,
+                                         c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p]
+    L.pyg_hip_index_sort_workspace_size.restype = c.c_size_t
+    L.pyg_hip_index_sort_workspace_size.argtypes = [c.c_int, c.c_int64]
+    L.pyg_hip_index_sort.restype = c.c_int
+    L.pyg_hip_index_sort.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_int64, c.c_int, c.c_void_p, c.c_void_p,
+                                     c.c_void_p, c.c_size_t, c.c_void_p]
+    return L
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize('ptr_on_device', [0, 1])
+@pytest.mark.parametrize('K,M,dtype', [(128, 128, torch.bfloat16), (100, 72, torch.bfloat16), (64, 64, torch.float32),
+                                       (100, 47, torch.float32)])
+def test_segment_matmul_raw_pointers(lib, ptr_on_device, K, M, dtype):
+    torch.manual_seed(K + M)
+    sizes = [300, 0, 129, 1000, 37]
+    ptr_host = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N, B = int(ptr_host[-1]), len(sizes)
+    x = torch.randn(N, K).to(dtype)
+    w = (torch.randn(B, K, M) / K ** 0.5).to(dtype)
+    xd, wd = x.to(DEV), w.to(DEV)
+    out = torch.empty(N, M, dtype=dtype, device=DEV)
+    ws_bytes = lib.pyg_hip_matmul_workspace_size(B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    ptr_dev = torch.from_numpy(ptr_host).to(DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    p = ptr_dev.data_ptr() if ptr_on_device else ptr_host.ctypes.data
+    rc = lib.pyg_hip_segment_matmul(PYG_BF16 if dtype == torch.bfloat16 else PYG_F32, xd.data_ptr(), p, ptr_on_device,
+                                    wd.data_ptr(), None, out.data_ptr(), N, K, M, B, ws.data_ptr(), ws_bytes, stream)
+    assert rc == 0, lib.pyg_hip_last_error()
+    torch.cuda.synchronize()
+    assert lib.pyg_hip_matmul_last_variant().startswith(b'mfma_')
+    if dtype == torch.bfloat16:
+        ref = oracle.segment_matmul(bits(x), ptr_host, bits(w), dtype=oracle.BF16)
+        np.testing.assert_allclose(oracle.bf16_bits_to_f32(bits(out)), oracle.bf16_bits_to_f32(ref), rtol=2 ** -7, atol=1e-3)
+    else:
+        ref = oracle.segment_matmul(x.numpy(), ptr_host, w.numpy())
+        assert np.linalg.norm(out.cpu().numpy() - ref) <= 1e-5 * np.linalg.norm(ref)
+    # error convention: int status + thread-local message, nothing thrown across the boundary
+    rc = lib.pyg_hip_segment_matmul(PYG_F32, xd.data_ptr(), p, ptr_on_device, wd.data_ptr(), None, out.data_ptr(), N, K, M,
+                                    B, ws.data_ptr(), 16, stream)
+    assert rc != 0 and b'workspace' in lib.pyg_hip_last_error()
+
+
+@pytest.mark.parametrize('n,max_value', [(0, 10), (1, 10), (32769, 5), (1_000_003, 2_449_029), (300_000, 2 ** 40)])
+def test_index_sort_raw_pointers(lib, n, max_value):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, max_value, n, dtype=np.int64)
+    kd = torch.from_numpy(keys).to(DEV)
+    keys_out = torch.empty(n, dtype=torch.int64, device=DEV)
+    idx_out = torch.empty(n, dtype=torch.int64, device=DEV)
+    ws_bytes = lib.pyg_hip_index_sort_workspace_size(PYG_I64, n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+    rc = lib.pyg_hip_index_sort(PYG_I64, kd.data_ptr(), n, max_value, 1, keys_out.data_ptr(), idx_out.data_ptr(),
+                                ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.pyg_hip_last_error()
+    torch.cuda.synchronize()
+    ref_v, ref_i = oracle.index_sort(keys)
+    assert np.array_equal(keys_out.cpu().numpy(), ref_v) and np.array_equal(idx_out.cpu().numpy(), ref_i)

@@ -182,3 +182,55 @@ def test_fused_rgcn_falls_back_for_other_shapes():
     off = rgcn.type_offsets({'a': 50}, ['a'])
     torch.testing.assert_close(rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w),
                                rgcn.rgcn_layer(x, off, {ets[0]: r}, {ets[0]: c}, ets, w))
+
+
+def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
+    """BASELINE config C5 at FULL size (the graph bench.py's `c5` leg samples: 1.94 M nodes of 4 types, the 7 relations,
+    42.2 M entries; batch 1024 papers, fan-out [15, 10]): every output of the device sampler -- rows, cols, node ids,
+    edge ids, per-hop counts of all relations / node types -- against the oracle on one batch, then the fused layer on
+    that sample against a float64 restatement."""
+    import oracle
+    import bench_legs
+    from pyg_lib_amd import sampler, rgcn
+    types = list(bench_legs.MAG_SIZES)
+    ets = [(s, r, d) for s, r, d, _ in bench_legs.MAG_RELS]
+    rp, cl = bench_legs.make_mag_graph(torch.device('cuda:0'))
+    fan = {e: [15, 10] for e in ets}
+    seeds = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=torch.Generator().manual_seed(1))[:1024]
+    torch.manual_seed(2024)
+    out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds.cuda()}, fan)
+    after = torch.get_rng_state()
+    ref = oracle.hetero_neighbor_sample(types, ets, {e: v.cpu().numpy() for e, v in rp.items()},
+                                        {e: v.cpu().numpy() for e, v in cl.items()}, {'paper': seeds.numpy()}, fan,
+                                        rng_seed=2024)
+    row_d, col_d, node_d, edge_d = out[0], out[1], out[2], out[3]
+    total = 0
+    for e in ets:
+        assert torch.equal(row_d[e].cpu(), torch.from_numpy(ref[0][e])), e
+        assert torch.equal(col_d[e].cpu(), torch.from_numpy(ref[1][e])), e
+        assert torch.equal(edge_d[e].cpu(), torch.from_numpy(ref[3][e])), e
+        assert list(out[5][e]) == list(ref[5][e]), e
+        total += row_d[e].numel()
+    for t in types:
+        assert torch.equal(node_d[t].cpu(), torch.from_numpy(ref[2][t])), t
+        assert list(out[4][t]) == list(ref[4][t]), t
+    assert total > 400_000
+    # the generator was advanced exactly as the reference's engine would have advanced it
+    torch.manual_seed(2024)
+    sampler.hetero_neighbor_sample({e: v.cpu() for e, v in rp.items()}, {e: v.cpu() for e, v in cl.items()},
+                                   {'paper': seeds}, fan)  # the CPU key of this build: same draws from the generator
+    assert torch.equal(after, torch.get_rng_state())
+
+    F = 128
+    g = torch.Generator(device='cuda').manual_seed(3)
+    feat = {t: torch.randn(bench_legs.MAG_SIZES[t], F, device='cuda', generator=g).bfloat16() for t in types}
+    W = (torch.randn(len(ets), F, F, device='cuda', generator=g) / F ** 0.5).bfloat16()
+    off = rgcn.type_offsets({t: node_d[t].numel() for t in types}, types)
+    x = torch.cat([feat[t][node_d[t]] for t in types])
+    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, ets, W)
+    want = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
+    for i, (s, r, d) in enumerate(ets):
+        msg = (x[col_d[(s, r, d)] + off[d]].double() @ W[i].double()).bfloat16().double()
+        want.index_add_(0, row_d[(s, r, d)] + off[s], msg)
+    scale = want.abs().max().item()
+    assert scale > 1.0 and (y.double() - want).abs().max().item() <= 2e-2 * scale

@@ -1,0 +1,188 @@
+"""Repetition under memory noise of the kernels whose waits are placed by hand.
+
+The ticket kernel, the pipelined fp32 kernel, the 64-rows-per-wave K = 256 kernel and the fused R-GCN kernel issue
+their loads from inline asm and wait with exact `vmcnt` counts; a miscounted wait reads a register before its load has
+landed -- a bug that shows as ONE garbage tile in one of many runs, and only when the load happens to be late (commit
+f4884f2 fixed such a count in the fp32 kernel for M = 64 / 32: the parity suite passed 14 times out of 15 with it).
+Here every kernel runs 32 times on fresh ragged partitions while a second stream keeps the memory system busy with
+large copies (late loads, uneven arrival), and every run must reproduce, bit for bit, a result that was itself checked:
+the 16-bit K = M = 128 kernels against the contiguous-range kernel, the others against their own first run after that
+run was compared with a float64 product.
+"""
+import numpy as np
+import pytest
+import torch
+
+from pyg_lib_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REPS = 32
+
+
+class Noise:
+    """Large device copies on a side stream: ~100 us each, queued ahead so that they overlap whatever the main
+    stream launches next."""
+
+    def __init__(self, mbytes=192):
+        self.stream = torch.cuda.Stream()
+        self.a = torch.empty(mbytes << 20, dtype=torch.uint8, device=DEV).random_()
+        self.b = torch.empty_like(self.a)
+
+    def burst(self, n=24):
+        with torch.cuda.stream(self.stream):
+            for i in range(n):
+                if i & 1:
+                    self.a.copy_(self.b)
+                else:
+                    self.b.copy_(self.a)
+
+
+def ragged_ptr(rng, B, kind, scale):
+    if kind == 0:
+        sizes = rng.integers(0, 3 * scale, B)
+    elif kind == 1:
+        sizes = rng.integers(0, 70, B)
+    elif kind == 2:
+        sizes = (rng.random(B) < 0.5) * rng.integers(1, 8 * scale, B)
+    else:
+        sizes = np.array([int(rng.integers(1, 120 * scale))] + [int(v) for v in rng.integers(0, 65, B - 1)])
+    return torch.tensor([0] + np.cumsum(sizes).tolist())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_ticket_kernel_under_noise_matches_contiguous_bitwise(dtype):
+    rng = np.random.default_rng(1)
+    noise = Noise()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    name = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    for rep in range(REPS):
+        B = int(rng.integers(1, 200))
+        ptr = ragged_ptr(rng, B, rep % 4, 1000)
+        n = int(ptr[-1])
+        if n == 0:
+            continue
+        x = torch.randn(n, 128, device=DEV, generator=g).to(dtype)
+        w = (torch.randn(B, 128, 128, device=DEV, generator=g) / 11).to(dtype)
+        bias = torch.randn(B, 128, device=DEV, generator=g).to(dtype) if rep % 3 == 0 else None
+        try:
+            ops.set_matmul_schedule('contiguous')
+            ref = ops.segment_matmul(x, ptr, w, bias)
+            ops.set_matmul_schedule('ticket')
+            noise.burst()
+            out = ops.segment_matmul(x, ptr, w, bias)
+            assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128_ticket'
+        finally:
+            ops.set_matmul_schedule('auto')
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (rep, B, n)
+
+
+def _repeat_against_first(make_call, check_first, reps=REPS):
+    noise = Noise()
+    first = None
+    for rep in range(reps):
+        noise.burst()
+        out = make_call()
+        torch.cuda.synchronize()
+        if first is None:
+            check_first(out)
+            first = [o.clone() for o in out] if isinstance(out, (list, tuple)) else out.clone()
+        elif isinstance(out, (list, tuple)):
+            for a, b in zip(out, first):
+                assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
+                                   b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16)), rep
+        else:
+            assert torch.equal(out.view(torch.int32) if out.dtype == torch.float32 else out.view(torch.int16),
+                               first.view(torch.int32) if first.dtype == torch.float32 else first.view(torch.int16)), rep
+
+
+@pytest.mark.parametrize('M', [128, 64, 32])
+def test_fp32_pipelined_kernel_under_noise_is_reproducible(M):
+    """M = 64 / 32 are the widths whose hand-kept store count was wrong before f4884f2."""
+    rng = np.random.default_rng(M)
+    g = torch.Generator(device=DEV).manual_seed(M)
+    B = 61
+    ptr = ragged_ptr(rng, B, 0, 1500)
+    n = int(ptr[-1])
+    x = torch.randn(n, 128, device=DEV, generator=g)
+    w = torch.randn(B, 128, M, device=DEV, generator=g) / 11
+
+    def check(out):
+        assert ops.matmul_last_variant() == f'mfma_f32_k128_mc{M}'
+        for b in (0, 7, 30, 60):
+            s, e = int(ptr[b]), int(ptr[b + 1])
+            ref = x[s:e].double() @ w[b].double()
+            assert (out[s:e].double() - ref).norm() <= 1e-5 * max(ref.norm().item(), 1e-30)
+        assert torch.isfinite(out).all()
+
+    _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w), check)
+
+
+def test_k256_two_blocks_per_wave_kernel_under_noise_is_reproducible():
+    rng = np.random.default_rng(256)
+    g = torch.Generator(device=DEV).manual_seed(256)
+    rows = [int(v) for v in rng.integers(0, 9000, 96)]
+    rows[3] = 0
+    rows[10] = 1
+    xs = [torch.randn(r, 256, device=DEV, generator=g).bfloat16() for r in rows]
+    ws = [(torch.randn(256, 256, device=DEV, generator=g) / 16).bfloat16() for _ in rows]
+
+    def check(outs):
+        assert ops.matmul_last_variant() == 'mfma_bf16_k256_wide256r2'
+        for i in (0, 5, 50, 95):
+            ref = (xs[i].double() @ ws[i].double())
+            torch.testing.assert_close(outs[i].double(), ref, rtol=2 ** -7, atol=2e-2)
+
+    _repeat_against_first(lambda: ops.grouped_matmul(xs, ws), check)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_general_shape_kernel_under_noise_is_reproducible(dtype):
+    rng = np.random.default_rng(100)
+    g = torch.Generator(device=DEV).manual_seed(100)
+    shapes = [(int(rng.integers(0, 20000)), int(k), 128) for k in (100, 128, 256, 768, 100, 40, 768, 129)]
+    xs = [torch.randn(r, k, device=DEV, generator=g).to(dtype) for r, k, m in shapes]
+    ws = [(torch.randn(k, m, device=DEV, generator=g) / k ** 0.5).to(dtype) for r, k, m in shapes]
+
+    def check(outs):
+        assert ops.matmul_last_variant().endswith('_gen')
+        for a, o, out in zip(xs, ws, outs):
+            ref = a.double() @ o.double()
+            if dtype == torch.float32:
+                assert (out.double() - ref).norm() <= 1e-5 * max(ref.norm().item(), 1e-30)
+            else:
+                torch.testing.assert_close(out.double(), ref, rtol=2 ** -7, atol=2e-2)
+
+    _repeat_against_first(lambda: ops.grouped_matmul(xs, ws), check)
+
+
+def test_fused_rgcn_kernel_under_noise_stays_exact():
+    """Integer-valued features and signed-permutation weights (every partial sum exact): the fused gather -> MFMA ->
+    packed-atomic scatter kernel must give the float64 result in every repetition, whatever order its atomics land."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(4)
+    n, F = 5000, 128
+    x = torch.randint(-3, 4, (n, F), generator=g).float()
+    counts = [30_000, 0, 17, 8192 + 33, 129, 50_000, 1]
+    ets = [('a', f'r{i}', 'a') for i in range(len(counts))]
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in counts])
+    W = torch.zeros(len(counts), F, F)
+    W[torch.arange(len(counts))[:, None], perm, torch.arange(F)[None, :]] = \
+        (torch.randint(0, 2, (len(counts), F), generator=g) * 2 - 1).float()
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        rows[et] = torch.sort(torch.randint(0, 2000, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    want = torch.zeros(n, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), x[cols[et].cpu()].double() @ W[i].double())
+    assert want.abs().max() <= 256
+    xd, Wd = x.bfloat16().cuda(), W.bfloat16().cuda()
+    noise = Noise()
+    for rep in range(REPS):
+        noise.burst()
+        y = rgcn.rgcn_layer_fused(xd, off, rows, cols, ets, Wd)
+        torch.cuda.synchronize()
+        assert torch.equal(y.double().cpu(), want), rep
