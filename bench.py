@@ -248,8 +248,9 @@ def main():
     # HBM bytes from PMC (FETCH_SIZE / WRITE_SIZE, separate --pmc passes of this command, corrected as
     # MI355X_MICROARCH.md prescribes): recorded in profiles/ per kernel variant, valid for the full single-GPU launch
     traffic = None
+    traffic_source = None
     if world == 1 and args.scale == 1.0 and args.dtype == 'bf16':
-        for name in ('r2_segment_matmul_c2_pmc.json', 'r1_segment_matmul_c2_pmc.json'):
+        for name in ('r3_segment_matmul_c2_pmc.json', 'r2_segment_matmul_c2_pmc.json', 'r1_segment_matmul_c2_pmc.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if not os.path.exists(pmc):
                 continue
@@ -257,6 +258,7 @@ def main():
                 rec = json.load(open(pmc))
                 if rec.get('kernel_variant', 'mfma_bf16_k128_mc128') == variant:
                     traffic = int(rec['hbm_traffic_bytes'])
+                    traffic_source = 'profiles/' + name + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
                     break
             except Exception:  # noqa: BLE001
                 pass
@@ -265,13 +267,13 @@ def main():
         # fp32, F = 128: AI = 32 flop/B is above the fp32 ridge (157 TF / 8 TB/s = 20): bound by the fp32 MFMA rate
         roofline = dict(bound='mfma', achieved=None if tflops is None else round(tflops, 1), peak=F32_MFMA_PEAK_TFLOPS,
                         unit='TFLOP/s', frac=None if tflops is None else round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
-                        hbm_GBps=None if achieved is None else round(achieved, 1))
+                        traffic=traffic, traffic_source=traffic_source, kernel=variant, kernel_ms=round(kernel_ms, 4),
+                        alg_bytes=int(alg_bytes), hbm_GBps=None if achieved is None else round(achieved, 1))
     else:
         roofline = dict(bound='hbm', achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit='GB/s', frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, kernel=variant, kernel_ms=round(kernel_ms, 4), alg_bytes=int(alg_bytes),
-                        mfma_tflops=None if tflops is None else round(tflops, 1))
+                        traffic=traffic, traffic_source=traffic_source, kernel=variant, kernel_ms=round(kernel_ms, 4),
+                        alg_bytes=int(alg_bytes), mfma_tflops=None if tflops is None else round(tflops, 1))
 
     # context for `frac`: hand-written copies of the same byte mix on this box, right after the timed region
     if rank == 0 and world == 1 and args.dtype == 'bf16':

@@ -8,6 +8,9 @@ Here every kernel runs 32 times on fresh ragged partitions while a second stream
 large copies (late loads, uneven arrival), and every run must reproduce, bit for bit, a result that was itself checked:
 the 16-bit K = M = 128 kernels against the contiguous-range kernel, the others against their own first run after that
 run was compared with a float64 product.
+
+Checked in round 3 by reverting f4884f2's wait counts in a scratch build: `test_fp32_pipelined_kernel_...[32]` failed
+in 3 of 3 runs of this file, `[64]` in 2 of 3 (the unreverted build passes).
 """
 import numpy as np
 import pytest
@@ -186,3 +189,31 @@ def test_fused_rgcn_kernel_under_noise_stays_exact():
         y = rgcn.rgcn_layer_fused(xd, off, rows, cols, ets, Wd)
         torch.cuda.synchronize()
         assert torch.equal(y.double().cpu(), want), rep
+
+
+def test_bench_two_ranks_on_one_device_exercises_the_sharded_branch():
+    """`bench.py --gpus 2` with both ranks on cuda:0 over gloo (RCCL refuses two ranks per device): the N > 1 branch
+    -- row shards, barrier + max-over-ranks timing, the all-gather leg, C4's LPT shards with the in-place gather --
+    runs on every driver pass, and its JSON line has the shape the driver reads."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+           '--warmup', '1', '--scale', '0.05', '--debug-one-device', '--no-sampler', '--no-cpu-baseline']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    r = json.loads(line)
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['value'] > 0 and r['steps'] == 3
+    assert r['config']['rows_per_gpu'] * 2 <= r['config']['rows'] + 1
+    assert 'ms' in r['allgather'] and r['allgather']['backend'] == 'gloo', r['allgather']
+    assert r['c4']['n_gpus'] == 2 and 'incl_allgather' in r['c4'] and r['c4']['compute_only']['ms'] > 0, r['c4']
+    assert r['roofline']['kernel'].startswith('mfma_')
