@@ -3,11 +3,12 @@
 // and ops/softmax.cpp:46-53; argument checks follow the operator fronts (segment_csr.cpp:9-151,
 // softmax.cpp:9-44) and the CPU kernels (ops/cpu/segment_csr_kernel.cpp); autograd formulas follow
 // ops/autograd/segment_csr_kernel.cpp and ops/autograd/softmax_kernel.cpp.  Kernels: csrc/hip/csr.hip
-// through the C-ABI of include/pyg_hip.h.  HIP tensors only -- no CPU key is registered.
+// through the C-ABI of include/pyg_hip.h for HIP tensors, cpu_reduce.h for CPU tensors (key CPU, same fronts).
 #include <torch/autograd.h>
 #include <torch/library.h>
 
 #include "binding_common.h"
+#include "cpu_reduce.h"
 
 namespace pyg_amd {
 namespace {
@@ -27,7 +28,7 @@ struct CsrView {
 CsrView csr_view(const char* name, const Tensor& src, const Tensor& indptr) {
   TORCH_CHECK(src.device() == indptr.device(), name, ": src and indptr must be on the same device (got src=",
               src.device(), ", indptr=", indptr.device(), ")");
-  TORCH_CHECK(src.is_cuda(), name, ": tensors must live on a HIP device");
+  TORCH_CHECK(src.is_cuda() || src.is_cpu(), name, ": tensors must live on the CPU or on a HIP device");
   TORCH_CHECK(src.dim() >= indptr.dim(), name, ": src.dim() must be >= indptr.dim() (got src.dim()=", src.dim(),
               ", indptr.dim()=", indptr.dim(), ")");
   CsrView v;
@@ -64,7 +65,9 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
   if (op == CSR_MEAN)
     TORCH_CHECK(at::isFloatingType(src.scalar_type()), "\"", name, "_cpu\" not implemented for '", src.scalar_type(), "'");
   const auto v = csr_view(name, src, indptr);
-  DeviceGuard guard(src.device());
+  const bool on_cpu = src.is_cpu();
+  std::optional<DeviceGuard> guard;
+  if (!on_cpu) guard.emplace(src.device());
   auto src_c = src.contiguous();
   const int64_t dim = v.dim;
   const bool fresh = !optional_out.has_value();
@@ -89,13 +92,21 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
     if (fresh && (op == CSR_MIN || op == CSR_MAX)) out.fill_(0);
     return std::make_tuple(out, arg);
   }
+  const int64_t N = out.size(dim) * v.leading;
+  const int64_t K = N > 0 ? out.numel() / N : 0;
+  if (on_cpu) {
+    if (fresh && (op == CSR_MIN || op == CSR_MAX)) cpu::fill_identity(op == CSR_MIN ? PYG_REDUCE_MIN : PYG_REDUCE_MAX, out);
+    cpu::segment_csr(op, src_c, v.indptr.data_ptr<int64_t>(), v.stride, out, arg.defined() ? arg.data_ptr<int64_t>() : nullptr,
+                     v.leading, out.size(dim), E, K);
+    // rows without entries keep the sentinel; a fresh output reads 0 there (segment_csr_kernel.cpp:400-404)
+    if (fresh && (op == CSR_MIN || op == CSR_MAX)) out.masked_fill_(arg == E, 0);
+    return std::make_tuple(out, arg);
+  }
   const int code = dtype_code(src_c.scalar_type());
   void* stream = current_stream(src_c);
   if (fresh && (op == CSR_MIN || op == CSR_MAX))
     check_status(pyg_hip_fill_reduce_identity(op == CSR_MIN ? PYG_REDUCE_MIN : PYG_REDUCE_MAX, code, out.data_ptr(),
                                               out.numel(), stream));
-  const int64_t N = out.size(dim) * v.leading;
-  const int64_t K = N > 0 ? out.numel() / N : 0;
   check_status(pyg_hip_segment_csr(op, code, src_c.data_ptr(), v.indptr.data_ptr<int64_t>(), v.stride, out.data_ptr(),
                                    arg.defined() ? arg.data_ptr<int64_t>() : nullptr, fresh ? 1 : 0, v.leading,
                                    out.size(dim), E, K, stream));
@@ -126,7 +137,9 @@ Tensor gather_csr_kernel(const Tensor& src, const Tensor& indptr, const std::opt
   const auto v = csr_view(name, src, indptr);
   const int64_t dim = v.dim;
   TORCH_CHECK(src.size(dim) == 0 || src.size(dim) == v.rows, name, ": src.size(dim) must equal indptr.size(-1) - 1");
-  DeviceGuard guard(src.device());
+  const bool on_cpu = src.is_cpu();
+  std::optional<DeviceGuard> guard;
+  if (!on_cpu) guard.emplace(src.device());
   auto src_c = src.contiguous();
   Tensor out;
   if (optional_out.has_value()) {
@@ -147,6 +160,10 @@ Tensor gather_csr_kernel(const Tensor& src, const Tensor& indptr, const std::opt
   }
   const int64_t N = v.rows * v.leading;
   const int64_t K = src_c.numel() / N;
+  if (on_cpu) {
+    cpu::gather_csr(src_c, v.indptr.data_ptr<int64_t>(), v.stride, out, v.leading, v.rows, out.size(dim), K);
+    return out;
+  }
   check_status(pyg_hip_gather_csr(dtype_code(src_c.scalar_type()), src_c.data_ptr(), v.indptr.data_ptr<int64_t>(),
                                   v.stride, out.data_ptr(), v.leading, v.rows, out.size(dim), K, current_stream(src_c)));
   return out;
@@ -160,7 +177,8 @@ struct SoftmaxShape {
 SoftmaxShape softmax_shape(const char* name, const Tensor& src, const Tensor& ptr, int64_t dim) {
   TORCH_CHECK(src.is_contiguous(), name, ": Expected contiguous tensor, but got non-contiguous tensor for argument #0 'src'");
   TORCH_CHECK(ptr.is_contiguous(), name, ": Expected contiguous tensor, but got non-contiguous tensor for argument 'ptr'");
-  TORCH_CHECK(src.is_cuda() && ptr.is_cuda(), name, ": tensors must live on a HIP device");
+  TORCH_CHECK(src.device() == ptr.device() && (src.is_cuda() || src.is_cpu()), name,
+              ": src and ptr must live on the same device (CPU or HIP)");
   TORCH_CHECK(ptr.scalar_type() == at::kLong && ptr.dim() == 1, name, ": ptr must be a 1-dimensional int64 tensor");
   TORCH_CHECK(src.scalar_type() == at::kFloat || src.scalar_type() == at::kDouble, "\"", name,
               "_kernel_impl\" not implemented for '", src.scalar_type(), "'");
@@ -178,8 +196,12 @@ SoftmaxShape softmax_shape(const char* name, const Tensor& src, const Tensor& pt
 Tensor softmax_csr_kernel(const Tensor& src, const Tensor& ptr, int64_t dim) {
   PYG_TRACE("pyg::softmax_csr");
   const auto s = softmax_shape("softmax_csr_forward", src, ptr, dim);
-  DeviceGuard guard(src.device());
   auto out = at::zeros_like(src);
+  if (src.is_cpu()) {
+    cpu::softmax_csr(src, ptr.data_ptr<int64_t>(), out, s.outer, s.D, s.inner, ptr.numel() - 1);
+    return out;
+  }
+  DeviceGuard guard(src.device());
   check_status(pyg_hip_softmax_csr(dtype_code(src.scalar_type()), src.data_ptr(), ptr.data_ptr<int64_t>(), out.data_ptr(),
                                    s.outer, s.D, s.inner, ptr.numel() - 1, current_stream(src)));
   return out;
@@ -191,8 +213,12 @@ Tensor softmax_csr_backward_kernel(const Tensor& out, const Tensor& out_grad, co
   TORCH_CHECK(out_grad.is_contiguous() && out_grad.sizes() == out.sizes() && out_grad.scalar_type() == out.scalar_type() &&
                   out_grad.device() == out.device(),
               "softmax_csr_backward: out_grad must be a contiguous tensor shaped and typed like out");
-  DeviceGuard guard(out.device());
   auto in_grad = at::zeros_like(out);
+  if (out.is_cpu()) {
+    cpu::softmax_csr_backward(out, out_grad, ptr.data_ptr<int64_t>(), in_grad, s.outer, s.D, s.inner, ptr.numel() - 1);
+    return in_grad;
+  }
+  DeviceGuard guard(out.device());
   check_status(pyg_hip_softmax_csr_backward(dtype_code(out.scalar_type()), out.data_ptr(), out_grad.data_ptr(),
                                             ptr.data_ptr<int64_t>(), in_grad.data_ptr(), s.outer, s.D, s.inner,
                                             ptr.numel() - 1, current_stream(out)));
@@ -406,6 +432,17 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
 }
 
 TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_sum_csr"), TORCH_FN(segment_sum_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_mean_csr"), TORCH_FN(segment_mean_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_min_csr"), TORCH_FN(segment_min_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_max_csr"), TORCH_FN(segment_max_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::gather_csr"), TORCH_FN(gather_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::softmax_csr"), TORCH_FN(softmax_csr_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::softmax_csr_backward"), TORCH_FN(softmax_csr_backward_kernel));
+}
+
+// key CPU (pyg_lib/csrc/ops/cpu/segment_csr_kernel.cpp:652-661, softmax_kernel.cpp:250-255)
+TORCH_LIBRARY_IMPL(pyg, CPU, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_sum_csr"), TORCH_FN(segment_sum_csr_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_mean_csr"), TORCH_FN(segment_mean_csr_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_min_csr"), TORCH_FN(segment_min_csr_kernel));

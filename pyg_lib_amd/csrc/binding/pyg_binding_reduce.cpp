@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "binding_common.h"
+#include "cpu_reduce.h"
 
 namespace pyg_amd {
 
@@ -116,15 +117,20 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
                                               std::optional<int64_t> dim_size, int64_t inferred_size) {
   PYG_TRACE("pyg::scatter_or_segment_coo");
   const char* name = op_name(op, coo);
-  TORCH_CHECK(src.is_cuda() && index_b.is_cuda(), name, ": tensors must live on a HIP device");
+  TORCH_CHECK(src.device() == index_b.device(), name, ": src and index must be on the same device (got src=", src.device(),
+              ", index=", index_b.device(), ")");
   TORCH_CHECK(index_b.scalar_type() == at::kLong, name, ": index must be int64");
-  DeviceGuard guard(src.device());
+  const bool on_cpu = src.is_cpu();  // dispatch key CPU: same front, kernels of cpu_reduce.h instead of the C-ABI
+  TORCH_CHECK(on_cpu || src.is_cuda(), name, ": tensors must live on the CPU or on a HIP device");
+  std::optional<DeviceGuard> guard;
+  if (!on_cpu) guard.emplace(src.device());
   auto src_c = src.contiguous();
   Tensor out;
   const bool fresh = !optional_out.has_value();
   if (!fresh) {
     out = optional_out.value();
-    TORCH_CHECK(out.is_contiguous(), name, ": 'out' must be contiguous on the device path");
+    TORCH_CHECK(out.is_contiguous(), name, ": 'out' must be contiguous");
+    TORCH_CHECK(out.device() == src.device(), name, ": src and out must be on the same device");
     TORCH_CHECK(out.scalar_type() == src.scalar_type(), name, ": 'out' must have the dtype of 'src'");
     TORCH_CHECK(out.dim() == src.dim(), name, ": out.dim() must match src.dim()");
     for (int64_t i = 0; i < out.dim(); ++i)
@@ -137,10 +143,13 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
     else out = at::empty(sizes, src_c.options());
   }
   const int dt = dtype_code(src_c.scalar_type());
-  void* stream = current_stream(src_c);
+  void* stream = on_cpu ? nullptr : current_stream(src_c);
   Tensor arg, init;
   const bool minmax = op == OP_MIN || op == OP_MAX;
-  if (minmax) {
+  if (minmax && on_cpu) {
+    arg = at::full(out.sizes(), src_c.size(dim), index_b.options().dtype(at::kLong));  // sentinel: no source position
+    if (fresh) cpu::fill_identity(op, out);
+  } else if (minmax) {
     arg = at::empty(out.sizes(), index_b.options().dtype(at::kLong));
     if (fresh) check_status(pyg_hip_fill_reduce_identity(op, dt, out.data_ptr(), out.numel(), stream));
     else init = out.clone();
@@ -152,6 +161,13 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
       arg.fill_(src_c.size(dim));
       if (fresh) out.fill_(0);
     }
+    return std::make_tuple(out, arg);
+  }
+  if (on_cpu) {
+    cpu::scatter(op, src_c, l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk, out, minmax ? arg.data_ptr<int64_t>() : nullptr,
+                 l.B, l.E, l.K, l.N, coo);
+    // buckets nobody wrote keep the sentinel; a fresh output reads 0 there (scatter_kernel.cpp:358-366)
+    if (minmax && fresh) out.masked_fill_(arg == src_c.size(dim), 0);
     return std::make_tuple(out, arg);
   }
   // scratch for the sort-based sum (large unsorted float scatters only; see pyg_hip_scatter)
@@ -304,15 +320,20 @@ Tensor gather_coo_kernel(const Tensor& src, const Tensor& index, const std::opti
   TORCH_CHECK(dim >= 0, name, ": index must have at least 1 dimension");
   for (int64_t i = 0; i < dim; ++i)
     TORCH_CHECK(src.size(i) == index.size(i), name, ": src.size(", i, ") must match index.size(", i, ")");
-  TORCH_CHECK(src.is_cuda() && index.is_cuda(), name, ": tensors must live on a HIP device");
+  TORCH_CHECK(src.device() == index.device(), name, ": src and index must be on the same device");
   TORCH_CHECK(index.scalar_type() == at::kLong, name, ": index must be int64");
-  DeviceGuard guard(src.device());
+  const bool on_cpu = src.is_cpu();
+  TORCH_CHECK(on_cpu || src.is_cuda(), name, ": tensors must live on the CPU or on a HIP device");
+  std::optional<DeviceGuard> guard;
+  if (!on_cpu) guard.emplace(src.device());
   auto src_c = src.contiguous();
   auto index_c = index.contiguous();
   Tensor out;
   if (optional_out.has_value()) {
     out = optional_out.value();
-    TORCH_CHECK(out.is_contiguous(), name, ": 'out' must be contiguous on the device path");
+    TORCH_CHECK(out.is_contiguous(), name, ": 'out' must be contiguous");
+    TORCH_CHECK(out.device() == src.device() && out.scalar_type() == src.scalar_type(), name,
+                ": 'out' must live on the device of 'src' and have its dtype");
     for (int64_t i = 0; i < src_c.dim(); ++i)
       if (i != dim) TORCH_CHECK(src_c.size(i) == out.size(i), name, ": out.size(", i, ") must match src.size(", i, ")");
   } else {
@@ -329,6 +350,10 @@ Tensor gather_coo_kernel(const Tensor& src, const Tensor& index, const std::opti
   for (int64_t i = 0; i < dim; ++i) B *= index_c.size(i);
   const int64_t K = out.numel() / index_c.numel();
   const int64_t N = src_c.size(dim);
+  if (on_cpu) {
+    cpu::gather_coo(src_c, index_c.data_ptr<int64_t>(), out, B, E, K, N);
+    return out;
+  }
   check_status(pyg_hip_gather_coo(dtype_code(src_c.scalar_type()), src_c.data_ptr(), index_c.data_ptr<int64_t>(),
                                   out.data_ptr(), B, E, K, N, current_stream(src_c)));
   return out;
@@ -645,6 +670,20 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
 
 TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::index_sort"), TORCH_FN(index_sort_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_sum"), TORCH_FN(scatter_sum_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_mul"), TORCH_FN(scatter_mul_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_min"), TORCH_FN(scatter_min_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_max"), TORCH_FN(scatter_max_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_sum_coo"), TORCH_FN(segment_sum_coo_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_mean_coo"), TORCH_FN(segment_mean_coo_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_min_coo"), TORCH_FN(segment_min_coo_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_max_coo"), TORCH_FN(segment_max_coo_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::gather_coo"), TORCH_FN(gather_coo_kernel));
+}
+
+// key CPU (pyg_lib/csrc/ops/cpu/scatter_kernel.cpp:513-518, segment_coo_kernel.cpp:748-757): the same fronts; they branch
+// to the kernels of cpu_reduce.h on CPU tensors
+TORCH_LIBRARY_IMPL(pyg, CPU, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_sum"), TORCH_FN(scatter_sum_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_mul"), TORCH_FN(scatter_mul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::scatter_min"), TORCH_FN(scatter_min_kernel));

@@ -184,3 +184,114 @@ def test_index_sort_on_cpu(dtype):
         ops.index_sort(torch.zeros(4, 4, dtype=torch.long))
     with pytest.raises(RuntimeError):
         ops.index_sort(torch.zeros(4))
+
+
+# ---- scatter / segment_coo / gather_coo / segment_csr / gather_csr / softmax_csr on CPU tensors ----------------------
+# (key CPU; csrc/binding/cpu_reduce.h).  The expectations are the outputs recorded from the REAL reference build
+# (tests/golden/reduce_golden.npz, csr_golden.npz; oracle/build_ref.sh): the CPU kernels keep the reference's order of
+# operations, so everything -- floating sums and bf16 per-element rounding included -- must match bit for bit.
+
+from tests.golden import reduce_cases as RC  # noqa: E402
+from tests.golden import csr_cases as CC  # noqa: E402
+
+
+def _t(a, bf16=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a).copy())
+    return t.view(torch.int16).view(torch.bfloat16) if bf16 else t
+
+
+def _same_bits(got, ref):
+    assert got.shape == ref.shape and got.dtype == ref.dtype and got.device.type == 'cpu'
+    if got.dtype in (torch.bfloat16, torch.float16):
+        return torch.equal(got.contiguous().view(torch.int16), ref.contiguous().view(torch.int16))
+    if got.is_floating_point():
+        it = torch.int32 if got.dtype == torch.float32 else torch.int64
+        return torch.equal(got.contiguous().view(it), ref.contiguous().view(it))
+    return torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('name', RC.names('scatter'))
+def test_scatter_on_cpu_matches_reference_bitwise(name):
+    c = RC.case(name)
+    out = _t(c['out0'], c['bf16'])
+    res = getattr(ops, 'scatter_' + c['op'])(_t(c['src'], c['bf16']), _t(c['index']), c['dim'], out, c['dim_size'])
+    val = res[0] if c['op'] in ('min', 'max') else res
+    assert _same_bits(val, _t(c['res'], c['bf16'])), name
+    if c['op'] in ('min', 'max'):
+        assert torch.equal(res[1], _t(c['arg']))
+    if out is not None:
+        assert val.data_ptr() == out.data_ptr()
+
+
+@pytest.mark.parametrize('name', RC.names('coo'))
+def test_segment_coo_on_cpu_matches_reference_bitwise(name):
+    c = RC.case(name)
+    res = getattr(ops, f"segment_{c['op']}_coo")(_t(c['src'], c['bf16']), _t(c['index']), _t(c['out0'], c['bf16']),
+                                                 c['dim_size'])
+    val = res[0] if c['op'] in ('min', 'max') else res
+    assert _same_bits(val, _t(c['res'], c['bf16'])), name
+    if c['op'] in ('min', 'max'):
+        assert torch.equal(res[1], _t(c['arg']))
+
+
+@pytest.mark.parametrize('name', RC.names('gather'))
+def test_gather_coo_on_cpu_matches_reference(name):
+    c = RC.case(name)
+    assert _same_bits(ops.gather_coo(_t(c['src'], c['bf16']), _t(c['index'])), _t(c['res'], c['bf16']))
+
+
+@pytest.mark.parametrize('name', CC.names('reduce'))
+def test_segment_csr_on_cpu_matches_reference_bitwise(name):
+    c = CC.case(name)
+    out = _t(c['out0'], c['bf16'])
+    res = getattr(ops, f"segment_{c['op']}_csr")(_t(c['src'], c['bf16']), _t(c['indptr']), out)
+    val = res[0] if c['op'] in ('min', 'max') else res
+    assert _same_bits(val, _t(c['res'], c['bf16'])), name
+    if c['op'] in ('min', 'max'):
+        assert torch.equal(res[1], _t(c['arg']))
+    if out is not None:
+        assert val.data_ptr() == out.data_ptr()
+
+
+@pytest.mark.parametrize('name', CC.names('gather'))
+def test_gather_csr_on_cpu_matches_reference(name):
+    c = CC.case(name)
+    res = ops.gather_csr(_t(c['src'], c['bf16']), _t(c['indptr']), _t(c['out0'], c['bf16']))
+    assert _same_bits(res, _t(c['res'], c['bf16']))
+
+
+@pytest.mark.parametrize('name', CC.names('softmax'))
+def test_softmax_csr_on_cpu_matches_reference_bitwise(name):
+    c = CC.case(name)
+    out = ops.softmax_csr(_t(c['src']), _t(c['ptr']), c['dim'])
+    assert _same_bits(out, _t(c['res'])), name   # same libm expf, same order
+    gin = torch.ops.pyg.softmax_csr_backward(_t(c['res']), _t(c['out_grad']), _t(c['ptr']), c['dim'])
+    assert _same_bits(gin, _t(c['in_grad'])), name
+
+
+def test_reduce_ops_on_cpu_autograd_and_composites():
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(50, 8, generator=g, requires_grad=True)
+    index = torch.randint(0, 7, (50,), generator=g)
+    ops.scatter_sum(src, index, dim=0, dim_size=7).sum().backward()
+    assert torch.equal(src.grad, torch.ones_like(src))
+    out, arg = ops.scatter_max(src.detach(), index, 0, None, 7)
+    ref = torch.full((7, 8), float('-inf')).scatter_reduce(0, index[:, None].expand(50, 8), src.detach(), 'amax')
+    assert torch.equal(out, torch.where(ref == float('-inf'), torch.zeros(()), ref))
+    mean = ops.scatter_mean(src.detach(), index, 0, None, 7)
+    cnt = torch.bincount(index, minlength=7).clamp(min=1)[:, None]
+    torch.testing.assert_close(mean, torch.zeros(7, 8).index_add_(0, index, src.detach()) / cnt)
+    indptr = torch.tensor([0, 10, 10, 35, 50])
+    s = src.detach().clone().requires_grad_()
+    ops.segment_mean_csr(s, indptr).sum().backward()
+    lens = (indptr[1:] - indptr[:-1]).clamp(min=1).float()
+    torch.testing.assert_close(s.grad, (1 / lens).repeat_interleave(indptr[1:] - indptr[:-1])[:, None].expand(50, 8))
+    x = torch.randn(50, 3, generator=g, requires_grad=True)
+    y = ops.softmax_csr(x, indptr, 0)
+    torch.testing.assert_close(y[10:35].sum(0), torch.ones(3))
+    y[10:35, 0].sum().backward()
+    assert torch.isfinite(x.grad).all()
+    with pytest.raises(RuntimeError):
+        ops.scatter_sum(src.detach(), torch.tensor([9] * 50), 0, None, 7)   # out-of-range index: checked on CPU
