@@ -293,6 +293,12 @@ typedef struct {
  * missing host->mt19937 fail with PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
+/* Driver the calling thread's last neighbor / hetero sampler call ran: "fused" (bounded fan-outs: 3 launches per hop,
+ * csrc/hip/sampler_fused.h), "queued" (round 2's chain: PYG_HIP_SAMPLER_FUSED=0 or more than 4 relations expanding one
+ * node type), "synchronising" (unbounded / > 64 fan-outs, weighted relations, a hub that needed a word top-up, or
+ * PYG_HIP_SAMPLER_SYNC_MODE=1).  Diagnostics only; every driver returns the same bits. */
+PYG_HIP_API const char* pyg_hip_sampler_last_mode(void);
+
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                                const pyg_hip_relation* relations_host,
                                                int num_seed_sets,

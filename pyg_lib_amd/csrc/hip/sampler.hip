@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <vector>
 
 namespace pyg_hip {
@@ -151,9 +152,18 @@ __host__ __device__ inline void rng_push_draw(RngTab& t, int n) {
   t = tab_pack(dw, nb);
 }
 
+// g after f, at least one of them in the packed 5-state form (a draw wider than 16 bits somewhere: rare).  Kept out of
+// line: the scans apply their operator ~20 times per thread, and the packed path inlined into each of them is what
+// made the fused apply kernels need 244 registers.
+__host__ __device__ __attribute__((noinline)) RngTab rng_compose_general(RngTab f, RngTab g);
+
 // g after f
 __host__ __device__ inline RngTab rng_compose(RngTab f, RngTab g) {
   if (tab_is_pure(f) && tab_is_pure(g)) return f + (g & ~kPureTab);
+  return rng_compose_general(f, g);
+}
+
+__host__ __device__ __attribute__((noinline)) RngTab rng_compose_general(RngTab f, RngTab g) {
   f = tab_general(f);
   g = tab_general(g);
   u64 e[5];
@@ -314,9 +324,13 @@ struct RangeCtx {
   const int64_t* batch;       // batch id of every node of the src list
   int* error;                 // set to 1 on a non time-sorted neighbourhood
   __device__ void operator()(int64_t v, int64_t src_pos, int64_t count, int64_t* rs_out, int64_t* re_out) const {
+    eval(v, time ? batch[src_pos] : 0, count, rs_out, re_out);
+  }
+  // the same for a node whose batch id is known directly (a node that is being appended: sampler_fused.h)
+  __device__ void eval(int64_t v, int64_t batch_id, int64_t count, int64_t* rs_out, int64_t* re_out) const {
     int64_t rs = rowptr[v], re = rowptr[v + 1];
     if (time && re > rs && count != 0) {
-      const int64_t st = seed_times[batch[src_pos]];
+      const int64_t st = seed_times[batch_id];
       int64_t lo = rs, hi = re;  // first p in [rs, re) with st < time(p)
       while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
@@ -466,6 +480,12 @@ struct HopArgs {
   int64_t* e_eid;             // or nullptr
   u64* e_slot;
   HashTable table;
+  // fused chain (sampler_fused.h): emission positions of relations that share a table are ordered by pos_base;
+  // a node's engine position = (w0, u0) of the relation advanced by its prefix table
+  int64_t pos_base = 0;
+  const RngTab* tab_prefix = nullptr;
+  int64_t w0 = 0;
+  int u0 = 4;
 };
 
 struct RngCursor {
@@ -501,7 +521,7 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
   if (!a.table.keys) return;  // dist_neighbor_sample: no relabelling (neighbor_kernel.cpp:296-303)
   const u64 s = table_slot(a.table, make_key(w, src_batch, a.num_batches));
   a.e_slot[pos] = s;
-  __hip_atomic_fetch_min(&a.table.vals[s], kProvisional + (u64)pos, __ATOMIC_RELAXED,
+  __hip_atomic_fetch_min(&a.table.vals[s], kProvisional + (u64)(a.pos_base + pos), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -602,13 +622,11 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
 // Position of draw g in the word stream when every draw of the node takes the same n units
 // (rand_engine.h:41-76): the current word still serves u / n draws, every later word 4 / n.
 template <int G>
-__global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
-  if (hop_overflow(a)) return;
-  resolve_device_state(a);
+__device__ __forceinline__ void sample_group_body(const HopArgs& a, int64_t blk) {
   const int lane = threadIdx.x & 63;
   const int g = lane & (G - 1);
   const int gbase = lane & ~(G - 1);
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t i = (blk * (int64_t)blockDim.x + threadIdx.x) / G;
   const bool live = i < a.frontier;
   const int64_t count = a.count;  // 0 < count <= G
   int64_t src_pos = 0, src_batch = 0, rs = 0, deg = 0, off = 0;
@@ -630,8 +648,16 @@ __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
     const u64 range = (u64)idx + 1;
     const int n = need_units(range);
     const int n0 = need_units(a.replace ? (u64)deg : (u64)(deg - count + 1));
-    const int64_t w0 = a.rng_word[i];
-    const int u0 = a.rng_units[i];
+    int64_t w0;
+    int u0;
+    if (a.tab_prefix) {
+      const RngTab tp = a.tab_prefix[i];
+      w0 = a.w0 + tab_dw(tp, a.u0);
+      u0 = tab_nb(tp, a.u0);
+    } else {
+      w0 = a.rng_word[i];
+      u0 = a.rng_units[i];
+    }
     u64 val;
     if (n0 == need_units((u64)deg)) {
       // uniform draw width: closed-form position
@@ -673,6 +699,13 @@ __global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
   }
   if (samp) emit(a, off + g, rs + pick, src_pos, src_batch);
   else if (all && g < deg) emit(a, off + g, rs + g, src_pos, src_batch);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void sample_group_kernel(HopArgs a) {
+  if (hop_overflow(a)) return;
+  resolve_device_state(a);
+  sample_group_body<G>(a, blockIdx.x);
 }
 
 // owner flag of emission p: it holds the table minimum  <=>  first occurrence of a NEW node
@@ -810,6 +843,8 @@ void launch_sample(const HopArgs& a, int64_t F, hipStream_t stream) {
 
 #include "sampler_biased.h"  // biased (edge_weight) sampling kernels
 
+#include "sampler_fused.h"
+
 // ---- host driver -----------------------------------------------------------------------------------
 // growable device array of int64
 struct DevVec {
@@ -903,10 +938,15 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
 
 constexpr int kNeedSlow = 1000;  // internal: repeat the call in the synchronising mode
 
+// which driver the calling thread's last sampler call ran (pyg_hip_sampler_last_mode): tests and benchmarks assert it
+thread_local const char* g_sampler_mode = "none";
+
 struct RelState {
   DevVec row, col, eid;
   std::vector<int64_t> edges_per_hop;
 };
+
+#include "sampler_fused_host.h"
 
 int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* rels,
                 int num_seed_sets, const pyg_hip_seed_set* seeds, const int64_t* const* node_time,
@@ -939,10 +979,14 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
   const size_t hand_back_offset =
       align_up(1024 + sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 96), 64);
+  // fused chain (sampler_fused.h): host copy of its tables
+  const size_t fused_tables_offset = align_up(hand_back_offset + sizeof(MtHandBack), 256);
+  const size_t fused_tables_bytes =
+      align_up(8 * (size_t)(L + 1) * num_node_types + 8 * (size_t)num_node_types + 20 * (size_t)std::max(L, 1) * num_relations + 64, 256);
   void* pinned = nullptr;
   {
-    // scratch + one HopInfo per (hop, relation) + the engine hand-back of the fully queued mode
-    int rc = get_pinned(&pinned, hand_back_offset + sizeof(MtHandBack));
+    // scratch + one HopInfo per (hop, relation) + the engine hand-back of the fully queued mode + the fused chain's blocks
+    int rc = get_pinned(&pinned, fused_tables_offset + fused_tables_bytes);
     if (rc != PYG_HIP_OK) return rc;
   }
 
@@ -1015,62 +1059,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     }
   }
 
-  // ---- seeds ----
-  int64_t batch0 = 0;
-  for (int s = 0; s < num_seed_sets; ++s) {
-    const pyg_hip_seed_set& ss = seeds[s];
-    PYG_HIP_REQUIRE(ss.node_type >= 0 && ss.node_type < num_node_types, "sampler: bad seed type");
-    NodeSet& n = ns[(size_t)ss.node_type];
-    PYG_HIP_REQUIRE(n.nodes.size == 0, "sampler: node type seeded twice");
-    const int64_t S = ss.num_seed;
-    n.slice_b = 0;
-    n.slice_e = S;
-    if (S == 0) continue;
-    // fully queued mode: the list and the table are created at their final (bound) size right away
-    const int64_t nb = fast ? node_bound[(size_t)ss.node_type] : 0;
-    int rc = n.nodes.reserve(c, S, S + nb);
-    if (rc != PYG_HIP_OK) return rc;
-    if (disjoint) {
-      rc = n.batch.reserve(c, S, S + nb);
-      if (rc != PYG_HIP_OK) return rc;
-    }
-    rc = table_reserve(c, n, S, S + nb);
-    if (rc != PYG_HIP_OK) return rc;
-    u64* slots;
-    PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
-    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
-                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
-                       disjoint ? n.batch.p : (int64_t*)nullptr, slots, tstate + ss.node_type);
-    PYG_HIP_CHECK(hipGetLastError());
-    if (temporal) {
-      const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
-      if (ss.seed_time || nt) {
-        hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
-                           ss.seed, ss.seed_time, nt, S, batch0, seed_times);
-        PYG_HIP_CHECK(hipGetLastError());
-      } else {
-        // the reference would index an empty seed_times vector here (undefined behaviour)
-        return fail(PYG_HIP_ERR_INVALID, "Seed time needs to be specified");
-      }
-    }
-    // ranks of first occurrences = local ids (duplicates keep their first id)
-    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
-    int64_t* tile_buf;
-    PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
-    FlagLoad fl{slots, n.table.vals};
-    AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    // the number of distinct seeds (Mapper::curr) goes straight into the device-resident type state: the
-    // host never needs it, so the seeds cost no synchronisation
-    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &tstate[ss.node_type].distinct, stream);
-    if (rc != PYG_HIP_OK) return rc;
-    n.nodes.size = S;
-    if (disjoint) n.batch.size = S;
-    c.release(slots);
-    c.release(tile_buf);
-    batch0 += S;
-  }
-  // The word generation is queued behind the seed kernels (which do not need it; its launches would
-  // otherwise sit in front of them on the host).
+  const bool fused = fast && fused_eligible(rels, num_relations, num_node_types, num_seed_sets, csc, L, eb);
+  std::vector<FusedSeed> fseeds;
+
+  // The word generation (side stream).  Round 2's chain queues it behind the seed kernels (which do not need it; its
+  // launches would otherwise sit in front of them on the host); the fused chain, whose hops follow each other within
+  // ~40 us, needs the round's later segments as early as possible and starts it first.
   auto start_rng = [&]() -> int {
   if (c.host->mt19937) {
     // upper bounds of the words each hop can consume: every frontier node draws `count` 16-bit numbers
@@ -1110,7 +1104,74 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
     return PYG_HIP_OK;
   };
-  {
+  if (fused) {
+    int rc = start_rng();
+    if (rc != PYG_HIP_OK) return rc;
+  }
+
+  // ---- seeds ----
+  int64_t batch0 = 0;
+  for (int s = 0; s < num_seed_sets; ++s) {
+    const pyg_hip_seed_set& ss = seeds[s];
+    PYG_HIP_REQUIRE(ss.node_type >= 0 && ss.node_type < num_node_types, "sampler: bad seed type");
+    NodeSet& n = ns[(size_t)ss.node_type];
+    PYG_HIP_REQUIRE(n.nodes.size == 0, "sampler: node type seeded twice");
+    const int64_t S = ss.num_seed;
+    n.slice_b = 0;
+    n.slice_e = S;
+    if (S == 0) continue;
+    // fully queued mode: the list and the table are created at their final (bound) size right away
+    const int64_t nb = fast ? node_bound[(size_t)ss.node_type] : 0;
+    int rc = n.nodes.reserve(c, S, S + nb);
+    if (rc != PYG_HIP_OK) return rc;
+    if (disjoint) {
+      rc = n.batch.reserve(c, S, S + nb);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    rc = table_reserve(c, n, fused ? S + nb : S, S + nb);  // fused chain: sized once (the seeds' slot handles stay valid)
+    if (rc != PYG_HIP_OK) return rc;
+    u64* slots;
+    PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
+    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
+                       disjoint ? n.batch.p : (int64_t*)nullptr, slots, tstate + ss.node_type);
+    PYG_HIP_CHECK(hipGetLastError());
+    if (temporal) {
+      const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
+      if (ss.seed_time || nt) {
+        hipLaunchKernelGGL(seed_time_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                           ss.seed, ss.seed_time, nt, S, batch0, seed_times);
+        PYG_HIP_CHECK(hipGetLastError());
+      } else {
+        // the reference would index an empty seed_times vector here (undefined behaviour)
+        return fail(PYG_HIP_ERR_INVALID, "Seed time needs to be specified");
+      }
+    }
+    if (fused) {
+      // the seeds' first-occurrence scan also carries hop 0's counts: queued with the chain (run_fused_chain)
+      fseeds.push_back(FusedSeed{ss.node_type, S, slots});
+      n.nodes.size = S;
+      if (disjoint) n.batch.size = S;
+      batch0 += S;
+      continue;
+    }
+    // ranks of first occurrences = local ids (duplicates keep their first id)
+    const int64_t ntiles = (S + kScanTile - 1) / kScanTile;
+    int64_t* tile_buf;
+    PYG_ALLOC(tile_buf, int64_t*, c, sizeof(int64_t) * (size_t)(ntiles + 1));
+    FlagLoad fl{slots, n.table.vals};
+    AssignStore as{slots, n.table.vals, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    // the number of distinct seeds (Mapper::curr) goes straight into the device-resident type state: the
+    // host never needs it, so the seeds cost no synchronisation
+    rc = device_scan<int64_t, SumOp>(fl, as, S, tile_buf, &tstate[ss.node_type].distinct, stream);
+    if (rc != PYG_HIP_OK) return rc;
+    n.nodes.size = S;
+    if (disjoint) n.batch.size = S;
+    c.release(slots);
+    c.release(tile_buf);
+    batch0 += S;
+  }
+  if (!fused) {  // the fused chain started it before the seeds (its rounds are the critical path of hops 1 ...)
     int rc = start_rng();
     if (rc != PYG_HIP_OK) return rc;
   }
@@ -1134,7 +1195,17 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   // A relation that lacks random words (draws wider than 16 bits) aborts the rest of the queue untouched
   // and the call is repeated in the synchronising mode below (kNeedSlow).
   bool done_fast = false;
-  if (fast) {
+  if (fused) {
+    int rc = run_fused_chain(c, num_node_types, num_relations, rels, L, csc, replace, disjoint, num_batches, node_time,
+                             temporal_last, seed_times, err_flag, ns, rs, eb, fbh, node_bound, rel_bound, fseeds, rng,
+                             chain,
+                             static_cast<char*>(pinned) + fused_tables_offset,
+                             reinterpret_cast<MtHandBack*>(static_cast<char*>(pinned) + hand_back_offset), &hand_back,
+                             nodes_per_hop, pt);
+    if (rc != PYG_HIP_OK) return rc;  // kNeedSlow included
+    g_sampler_mode = "fused";
+    done_fast = true;
+  } else if (fast) {
     struct Queued {
       int ell, e;
     };
@@ -1342,9 +1413,11 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       for (int t = 0; t < num_node_types; ++t)
         nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size - before[(size_t)t]);
     }
+    g_sampler_mode = "queued";
     done_fast = true;
   }
   if (!done_fast) {
+  g_sampler_mode = "synchronising";
 
   struct Pending {
     int e = 0;
@@ -2188,6 +2261,8 @@ inline size_t relabel_ws_bytes(int64_t S, int64_t E) {
 }  // namespace pyg_hip
 
 using namespace pyg_hip;
+
+extern "C" const char* pyg_hip_sampler_last_mode(void) { return g_sampler_mode; }
 
 extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                               const pyg_hip_relation* relations, int num_seed_sets,

@@ -1,0 +1,596 @@
+// Fused chain of the fully queued sampler mode (included by sampler.hip inside its anonymous namespace).
+//
+// Round 2's fully queued mode ran, per (hop, relation): count scan (2 launches) -> sample -> first-occurrence scan
+// (2 launches) -> finalize, each a 5 - 10 us kernel behind a dependent launch boundary; 22 launches per C3 batch, ~90
+// for a 7-relation hetero batch.  What the reference's sequential loop (neighbor_kernel.cpp:332-514, 518-841) really
+// orders is less than that:
+//   * the degree of a node is known WHERE IT IS APPENDED.  The first-occurrence scan of hop l therefore carries, next
+//     to the rank (= local id), the (edges, RNG transition table) pair of the new node for every relation that will
+//     expand its type in hop l + 1: its prefix IS hop l + 1's count scan (edge offset + engine position of every
+//     frontier node), and its total the relation's emitted-edge count -- no separate count scan, no second gather of
+//     rowptr[node];
+//   * the engine position at which a relation starts is a fold of the totals of everything before it: all of them
+//     are known when its hop starts, so every relation of a hop samples in ONE launch;
+//   * relations that append to the same node type share its table: emission positions are ordered across them by a
+//     per-relation base, so atomicMin(position) still finds the reference's first occurrence, and one scan per node
+//     type (its relations' tiles concatenated in relation order) hands out the ids;
+//   * finalize (local ids of every emitted edge) only reads table entries that already hold final ids, which a later
+//     atomicMin(provisional position) never changes: it rides in the NEXT hop's sampling launch.
+// Per hop: [finalize(l - 1) | sample(l)] -> reduce(l) -> apply(l): three launches whatever the number of relations;
+// C3: 13 launches instead of 22.  State is write-once tables (sizes per hop and type, totals per hop and relation):
+// nothing a running launch reads is written by it, so there is no versioning and no chain kernel.  Every launch is a
+// list of work items whose records travel IN THE KERNEL ARGUMENT (<= 3 KB: no staging copy, and a block needs one
+// dependent load -- its counts from the tables -- before its data, like round 2's kernels).
+// Same outputs, same generator advance: every test of the fully queued mode runs through this path
+// (PYG_HIP_SAMPLER_FUSED=0 selects round 2's chain for A/B timing).
+
+constexpr int kMaxCons = 4;         // relations of the next hop that expand one node type; more: round 2's chain
+constexpr int kMaxParts = 8;        // relations queued per hop; more: round 2's chain
+constexpr int kMaxLaunchCons = 12;  // consumers over all node types of one scan launch
+
+template <int NC>
+struct FusedAgg {
+  int64_t rank;
+  CountAgg next[NC];
+};
+template <>
+struct FusedAgg<0> {
+  int64_t rank;
+};
+
+template <int NC>
+struct FusedOp {
+  __device__ FusedAgg<NC> operator()(const FusedAgg<NC>& a, const FusedAgg<NC>& b) const {
+    FusedAgg<NC> r;
+    r.rank = a.rank + b.rank;
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) r.next[c] = CountOp()(a.next[c], b.next[c]);
+    }
+    return r;
+  }
+  __device__ static FusedAgg<NC> identity() {
+    FusedAgg<NC> r;
+    r.rank = 0;
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) r.next[c] = CountOp::identity();
+    }
+    return r;
+  }
+};
+
+// write-once tables of one call (device; copied to the host once, behind the last launch)
+struct FTables {
+  int64_t* size_at;   // [(L + 1) * T]: length of type t's node list at the start of hop h (h = 0: the seeds)
+  int64_t* dup;       // [T]: seed positions that repeat an earlier seed (list positions - distinct nodes)
+  CountAgg* tot;      // [L * R]: emitted edges + RNG transition table of (hop, relation)
+  int32_t* overflow;  // [L * R]: 0 ok, 1 this relation lacked random words, 2 something before it did
+  int64_t word0;      // engine position at the start of the call
+  int units0;
+  int L, R, T;
+};
+
+struct FConsumer {  // a relation of the NEXT hop that expands the segment's node type
+  RangeCtx range;
+  int64_t count;
+  int replace;
+  int tot_index;      // (l + 1) * R + e'
+  int64_t* edge_off;  // [frontier bound of (l + 1, e')]: exclusive prefix of the emitted edges
+  RngTab* tabp;       //                                  exclusive prefix of the RNG tables
+};
+
+struct FSegHdr {  // one node type in one phase: the emissions of every relation that appends to it, in relation order
+  u64* vals;
+  int64_t* nodes;
+  int64_t* batch;          // disjoint: batch ids of the list, else nullptr
+  const int64_t* size_in;  // hop: &size_at[l * T + t]; seeds: nullptr
+  int64_t* size_out;       // hop: &size_at[(l + 1) * T + t]; seeds: &size_at[t]
+  int64_t* dup;            // &dup[t]
+  void* tile_agg;          // FusedAgg<NC>[tiles of all parts]
+  int seeds;
+  int ncons;
+};
+
+struct FPart {  // one relation's emissions of the hop (or one seed set); carries its segment's header
+  FSegHdr h;
+  const u64* slots;
+  const int64_t* e_node;
+  const int64_t* e_batch;
+  u64* cache;        // per emission: first-occurrence flag + the consumers' counts, kept from reduce for apply
+  int64_t n_fixed;   // seeds: number of seeds; relations: -1 (n = tot[tot_index].edges)
+  int64_t pos_base;  // emission position of this part's p = 0 within the segment
+  int tot_index;
+  int tile0;         // first tile of this part within the segment
+  int last;          // last part of the segment: its last block publishes the segment's totals
+  int cons0;         // first consumer of the segment in the launch's consumer array
+};
+
+struct FScanLaunch {  // kernel argument of the two scan passes of a phase
+  FTables tb;
+  int n;                   // items: the parts, then (apply pass of a hop) the carry block
+  int ell;                 // hop (carry)
+  unsigned type_mask_lo, type_mask_hi;  // carry: bit t set = type t has a segment (its last block writes the size)
+  int cum[kMaxParts + 1];  // inclusive prefix of the items' block counts
+  int nc[kMaxParts + 1];   // consumers of the part's segment; -1: the carry block
+  FPart part[kMaxParts];
+  FConsumer cons[kMaxLaunchCons];
+};
+
+struct FSampleRec {  // sampling of relation e in hop l: what does not depend on the tables
+  const int64_t* nodes;  // src node list
+  const int64_t* batch;  // src batch ids (disjoint) or nullptr
+  RangeCtx range;
+  int64_t count;
+  int64_t num_batches;
+  const int64_t* edge_off;
+  const RngTab* tabp;
+  int64_t* e_row;
+  int64_t* e_node;
+  int64_t* e_batch;
+  int64_t* e_eid;
+  u64* e_slot;
+  HashTable table;
+  int64_t pos_base;
+  int replace;
+  int ell, e, t_src;
+};
+
+struct FFinalRec {  // local ids of relation e's emissions of hop l
+  const u64* slots;
+  const u64* vals;
+  int64_t* out_col;  // base of the relation's col output
+  int ell, e;
+};
+
+enum FRole { kRoleSample8 = 0, kRoleSample16, kRoleSample32, kRoleSample64, kRoleFinalize, kRoleFold };
+
+struct FSampleLaunch {  // kernel argument of [finalize(l - 1) | sample(l)] (+ the engine fold behind the last hop)
+  FTables tb;
+  ChainState* chain;  // fold
+  int n;
+  int pad;
+  int cum[2 * kMaxParts + 2];
+  unsigned char role[2 * kMaxParts + 2];
+  unsigned char idx[2 * kMaxParts + 2];  // index into s[] / f[]
+  FSampleRec s[kMaxParts];
+  FFinalRec f[kMaxParts];
+};
+
+// An argument record lies in device memory, where the old kernels had it as a kernel argument (= in SGPRs).  Read
+// dword-wise through v_readfirstlane the compiler knows every field is wave-uniform: addresses and branch conditions
+// built from it stay scalar (without this the sampling role needed 80 VGPRs instead of 35: 5 waves per SIMD instead of
+// 8 on a kernel that is nothing but dependent gathers).
+template <typename T>
+__device__ __forceinline__ T uniform_record(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  T out;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(p);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s[i]);
+  return out;
+}
+
+// RNG table of a row of degree >= 2^16 (draws of 32 / 64 bits): rare, kept out of line -- inlined it cost the scan
+// kernels ~150 registers
+__device__ __noinline__ RngTab wide_draw_table(int64_t deg, int64_t count, int replace) {
+  RngTab t = rng_identity();
+  if (replace) {
+    const int n = need_units((u64)deg);
+    for (int64_t j = 0; j < count; ++j) rng_push_draw(t, n);
+  } else {
+    for (int64_t j = deg - count; j < deg; ++j) rng_push_draw(t, need_units((u64)(j + 1)));
+  }
+  return t;
+}
+
+// (edges, RNG table) of node v for one consumer: CountLoad::operator() for a node that is being appended
+__device__ __forceinline__ CountAgg consumer_count(const FConsumer& cs, int64_t v, int64_t batch_id) {
+  CountAgg r;
+  r.tab = rng_identity();
+  r.edges = 0;
+  int64_t rs, re;
+  cs.range.eval(v, batch_id, cs.count, &rs, &re);
+  const int64_t deg = re - rs;
+  const int64_t count = cs.count;
+  if (deg <= 0 || count == 0) return r;
+  if (count < 0 || (!cs.replace && count >= deg)) {
+    r.edges = deg;
+    return r;
+  }
+  r.edges = count;
+  if ((u64)deg < (1ull << 16)) r.tab = tab_pure(count);
+  else r.tab = wide_draw_table(deg, count, cs.replace);
+  return r;
+}
+
+// the same, never inlined: apply only needs it for the rare "general" cache entries
+__device__ __noinline__ CountAgg consumer_count_slow(const FConsumer& cs, int64_t v, int64_t batch_id) {
+  return consumer_count(cs, v, batch_id);
+}
+
+// cache word of an emission: bit 0 = first occurrence; consumer c at bits [1 + 15 c, 16 + 15 c): edges (7 bits, <= 64),
+// bit 7 = sampled (count 16-bit draws), bit 8 = "general" (a draw wider than 16 bits: the table is recomputed)
+__device__ __forceinline__ u64 cons_encode(const CountAgg& a) {
+  u64 code = (u64)a.edges & 0x7f;
+  if (!tab_is_pure(a.tab)) code |= 1u << 8;
+  else if (a.tab != rng_identity()) code |= 1u << 7;
+  return code;
+}
+
+__device__ __forceinline__ int64_t part_count(const FScanLaunch& L, const FPart& pt) {
+  if (pt.n_fixed >= 0) return pt.n_fixed;
+  const int over = L.tb.overflow[pt.tot_index];
+  const int64_t edges = L.tb.tot[pt.tot_index].edges;
+  return __builtin_amdgcn_readfirstlane(over) ? 0 : edges;
+}
+
+template <int NC>
+struct FCons {
+  FConsumer c[NC > 0 ? NC : 1];
+  __device__ __forceinline__ void load(const FScanLaunch& L, int first) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) c[i] = L.cons[first + i];
+  }
+};
+
+// ---- reduce: tile aggregates of (first-occurrence flag, next-hop counts) -----------------------------------------
+template <int NC>
+__device__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
+  typedef FusedAgg<NC> T;
+  typedef FusedOp<NC> Op;
+  __shared__ T lds[8];
+  FCons<NC> cons;
+  cons.load(L, pt.cons0);
+  const int64_t n = part_count(L, pt);
+  const int64_t base = (int64_t)lt * kScanTile + threadIdx.x * kScanItems;
+  Op op;
+  T agg = Op::identity();
+  if (base < n) {
+    // two rounds of dependent loads: [slot, node, batch] of every item, then [table value, the consumers' row bounds]
+    // (the bounds are fetched whether or not the emission turns out to be a first occurrence: off the critical path)
+    u64 sl[kScanItems], vv[kScanItems];
+    int64_t nd[kScanItems], bt[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const int64_t pc = base + k < n ? base + k : n - 1;
+      sl[k] = pt.slots[pc];
+      if constexpr (NC > 0) {
+        nd[k] = pt.e_node[pc];
+        bt[k] = pt.e_batch ? pt.e_batch[pc] : 0;
+      }
+    }
+    T v[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      vv[k] = pt.h.vals[sl[k]];
+      v[k] = Op::identity();
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[k].next[c] = consumer_count(cons.c[c], nd[k], bt[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const int64_t p = base + k;
+      if (p >= n) break;
+      const bool flag = vv[k] == kProvisional + (u64)(pt.pos_base + p);
+      v[k].rank = flag ? 1 : 0;
+      u64 word = flag ? 1ull : 0ull;
+      if constexpr (NC > 0) {
+        if (flag || pt.h.seeds) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) word |= cons_encode(v[k].next[c]) << (1 + 15 * c);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) v[k].next[c] = CountOp::identity();
+        }
+      }
+      pt.cache[p] = word;
+      agg = op(agg, v[k]);
+    }
+  }
+  T total;
+  (void)block_exclusive<T, Op>(agg, lds, op, &total);
+  if (threadIdx.x == 0) static_cast<T*>(pt.h.tile_agg)[pt.tile0 + lt] = total;
+}
+
+// ---- apply: ids, node-list append, the next hop's per-node prefixes; the segment's last block publishes its totals
+template <int NC>
+__device__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
+  typedef FusedAgg<NC> T;
+  typedef FusedOp<NC> Op;
+  __shared__ T lds[8];
+  FCons<NC> cons;
+  cons.load(L, pt.cons0);
+  const int64_t n = part_count(L, pt);
+  const int64_t size0 = pt.h.seeds ? 0 : *pt.h.size_in;
+  const int64_t id0 = pt.h.seeds ? 0 : size0 - *pt.h.dup;
+  const int64_t base = (int64_t)lt * kScanTile + threadIdx.x * kScanItems;
+  Op op;
+  T v[kScanItems];
+  u64 word[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t p = base + k;
+    v[k] = Op::identity();
+    word[k] = 0;
+    if (p < n) {
+      word[k] = pt.cache[p];
+      v[k].rank = (int64_t)(word[k] & 1);
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const u64 code = (word[k] >> (1 + 15 * c)) & 0x7fff;
+          if (code & (1u << 8)) {  // a row of degree >= 2^16 with a wide draw: rebuild its table
+            v[k].next[c] = consumer_count_slow(cons.c[c], pt.e_node[p], pt.e_batch ? pt.e_batch[p] : 0);
+          } else {
+            v[k].next[c].edges = (int64_t)(code & 0x7f);
+            v[k].next[c].tab = (code & (1u << 7)) ? tab_pure(cons.c[c].count) : rng_identity();
+          }
+        }
+      }
+    }
+  }
+  T agg = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) agg = op(agg, v[k]);
+  T total;
+  T run = block_exclusive<T, Op>(agg, lds, op, &total);
+  // every block reduces the aggregates of the tiles in front of it (of the whole segment) for itself
+  T before = Op::identity();
+  const int ntb = pt.tile0 + lt;
+  const T* tiles = static_cast<const T*>(pt.h.tile_agg);
+  for (int c0 = 0; c0 < ntb; c0 += kScanThreads) {
+    const int i = c0 + (int)threadIdx.x;
+    const T t = i < ntb ? tiles[i] : Op::identity();
+    T chunk;
+    (void)block_exclusive<T, Op>(t, lds, op, &chunk);
+    before = op(before, chunk);
+  }
+  run = op(before, run);
+  if (pt.last && lt == nblocks - 1 && threadIdx.x == 0) {
+    const T grand = op(before, total);
+    if (pt.h.seeds) {
+      *pt.h.size_out = pt.n_fixed;
+      *pt.h.dup = pt.n_fixed - grand.rank;
+    } else {
+      *pt.h.size_out = size0 + grand.rank;
+    }
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) L.tb.tot[cons.c[c].tot_index] = grand.next[c];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t p = base + k;
+    if (p < n) {
+      const bool flag = (word[k] & 1) != 0;
+      if (flag) {
+        pt.h.vals[pt.slots[p]] = (u64)(id0 + run.rank);
+        if (!pt.h.seeds) {
+          pt.h.nodes[size0 + run.rank] = pt.e_node[p];
+          if (pt.h.batch) pt.h.batch[size0 + run.rank] = pt.e_batch[p];
+        }
+      }
+      if constexpr (NC > 0) {
+        if (flag || pt.h.seeds) {
+          const int64_t i = pt.h.seeds ? p : run.rank;  // index in the next hop's frontier
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            cons.c[c].edge_off[i] = run.next[c].edges;
+            cons.c[c].tabp[i] = run.next[c].tab;
+          }
+        }
+      }
+    }
+    run = op(run, v[k]);
+  }
+}
+
+// ---- sample: relation e of hop l; everything position-dependent is resolved from the tables ------------------------
+// Per block: ONE round of loads (lane k of the first wave reads total k and overflow flag k; L * R <= 64), then the fold
+// over the relations in front -- finalize_kernel's chain advance and hop_overflow()'s sticky abort -- runs on shuffles.
+struct FResolved {
+  int64_t frontier;  // -1: this relation (or one before it) lacks random words
+  int64_t begin;
+  int64_t word;
+  int units;
+  int pad;
+  int64_t rel_off;
+};
+
+__device__ __forceinline__ FResolved fused_resolve(const FTables& tb, int ell, int e, int t_src, int64_t avail_blocks,
+                                                  bool publish) {
+  const int lane = threadIdx.x & 63;
+  const int n = tb.L * tb.R;
+  CountAgg mine = CountOp::identity();
+  int over_in = 0;
+  if (lane < n) {
+    mine = tb.tot[lane];
+    over_in = lane < ell * tb.R ? tb.overflow[lane] : 0;
+  }
+  const int64_t begin = ell > 0 ? tb.size_at[(ell - 1) * tb.T + t_src] : 0;
+  const int64_t end = tb.size_at[ell * tb.T + t_src];
+  bool aborted = __ballot(over_in != 0) != 0;
+  bool own = false;
+  int64_t w = tb.word0;
+  int u = tb.units0;
+  int64_t rel_off = 0;
+  const int last = ell * tb.R + e;
+  for (int k = 0; k <= last; ++k) {
+    CountAgg t;
+    t.edges = __shfl(mine.edges, k);
+    t.tab = (RngTab)__shfl((unsigned long long)mine.tab, k);
+    if (k < ell * tb.R && (k % tb.R) == e) rel_off += t.edges;
+    if (t.edges > 0) {
+      if (k >= ell * tb.R) {  // hop_overflow(): a relation of this hop that lacks words stops everything behind it
+        const int64_t end_word = w + tab_dw(t.tab, u);
+        if (end_word / 128 + 1 > avail_blocks) {
+          if (k < last) aborted = true;
+          else own = true;
+        }
+      }
+      if (k < last) {
+        const int u0 = u;
+        w += tab_dw(t.tab, u0);
+        u = tab_nb(t.tab, u0);
+      }
+    }
+  }
+  const bool over = aborted || own;
+  if (publish && threadIdx.x == 0) tb.overflow[last] = over ? (aborted ? 2 : 1) : 0;
+  FResolved r;  // every lane computed the same values: say so
+  r.frontier = over ? -1 : end - begin;
+  r.begin = begin;
+  r.word = w;
+  r.units = u;
+  r.pad = 0;
+  r.rel_off = rel_off;
+  return uniform_record(&r);
+}
+
+template <int G>
+__device__ __forceinline__ void fused_sample(const FSampleLaunch& L, const FSampleRec& rec, int blk, int64_t avail_blocks,
+                                             const u64* words) {
+  const FResolved r = fused_resolve(L.tb, rec.ell, rec.e, rec.t_src, avail_blocks, blk == 0);
+  if (r.frontier <= 0) return;
+  HopArgs a;
+  a.avail_blocks = avail_blocks;
+  a.nodes = rec.nodes;
+  a.batch = rec.batch;
+  a.begin = r.begin;
+  a.frontier = r.frontier;
+  a.range = rec.range;
+  a.col = rec.range.col;
+  a.count = rec.count;
+  a.replace = rec.replace;
+  a.num_batches = rec.num_batches;
+  a.edge_off = rec.edge_off;
+  a.rng_word = nullptr;
+  a.rng_units = nullptr;
+  a.words = words;
+  a.e_row = rec.e_row + r.rel_off;
+  a.e_node = rec.e_node;
+  a.e_batch = rec.e_batch;
+  a.e_eid = rec.e_eid ? rec.e_eid + r.rel_off : nullptr;
+  a.e_slot = rec.e_slot;
+  a.table = rec.table;
+  a.pos_base = rec.pos_base;
+  a.tab_prefix = rec.tabp;
+  a.w0 = r.word;
+  a.u0 = r.units;
+  sample_group_body<G>(a, blk);
+}
+
+__device__ __forceinline__ void fused_finalize(const FSampleLaunch& L, const FFinalRec& ff, int blk) {
+  const FTables& tb = L.tb;
+  const int k = ff.ell * tb.R + ff.e;
+  const int lane = threadIdx.x & 63;
+  int64_t mine = 0;
+  if (lane <= ff.ell) mine = tb.tot[lane * tb.R + ff.e].edges;  // hops 0 ... l of this relation
+  const int over = tb.overflow[k];
+  int64_t off = 0;
+  for (int h = 0; h < ff.ell; ++h) off += __shfl(mine, h);
+  const int64_t n = __shfl(mine, ff.ell);
+  if (__builtin_amdgcn_readfirstlane(over)) return;
+  const int64_t p = (int64_t)blk * blockDim.x + threadIdx.x;
+  if (p < n) ff.out_col[off + p] = (int64_t)ff.vals[ff.slots[p]];
+}
+
+// tables at the start of a call: sizes 0, totals identity, no overflow
+__global__ void fused_init_kernel(FTables tb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (tb.L + 1) * tb.T) tb.size_at[i] = 0;
+  if (i < tb.T) tb.dup[i] = 0;
+  if (i < tb.L * tb.R) {
+    tb.tot[i] = CountOp::identity();
+    tb.overflow[i] = 0;
+  }
+}
+
+// launch kind 1: [finalize of the previous hop | sampling of this hop] (+ the engine fold behind the last hop)
+// GMAX = the widest lane group of any sampling item of the launch (registers of the 64-lane variant only where needed)
+template <int GMAX>
+__global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L, int64_t avail_blocks,
+                                                           const u64* __restrict__ words) {
+  const int bx = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * kMaxParts + 2; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
+  const int b = bx - (k > 0 ? L.cum[k - 1] : 0);
+  const int role = L.role[k];
+  const int idx = L.idx[k];
+  switch (role) {
+    case kRoleSample8: fused_sample<8>(L, L.s[idx], b, avail_blocks, words); break;
+    case kRoleSample16:
+      if constexpr (GMAX >= 16) fused_sample<16>(L, L.s[idx], b, avail_blocks, words);
+      break;
+    case kRoleSample32:
+      if constexpr (GMAX >= 32) fused_sample<32>(L, L.s[idx], b, avail_blocks, words);
+      break;
+    case kRoleSample64:
+      if constexpr (GMAX >= 64) fused_sample<64>(L, L.s[idx], b, avail_blocks, words);
+      break;
+    case kRoleFinalize: fused_finalize(L, L.f[idx], b); break;
+    default: {  // kRoleFold
+      if (threadIdx.x == 0) {
+        int64_t w = L.tb.word0;
+        int u = L.tb.units0;
+        bool ab = false;
+        for (int q = 0; q < L.tb.L * L.tb.R; ++q) {
+          const CountAgg t = L.tb.tot[q];
+          if (t.edges > 0) {
+            const int u0 = u;
+            w += tab_dw(t.tab, u0);
+            u = tab_nb(t.tab, u0);
+          }
+          ab = ab || L.tb.overflow[q] != 0;
+        }
+        L.chain->word = w;
+        L.chain->units = u;
+        L.chain->abort = ab ? 1 : 0;
+      }
+      break;
+    }
+  }
+}
+
+// launch kinds 2 / 3: the scans' two passes.  MAXNC = the most consumers of any segment of the launch (the registers of
+// the widest aggregate are only paid where one occurs: the last hop carries none).
+template <int MAXNC, bool APPLY>
+__global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
+  const int bx = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxParts + 1; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
+  const int first = k > 0 ? L.cum[k - 1] : 0;
+  const int b = bx - first;
+  const int nblocks = L.cum[k] - first;
+  const int nc = L.nc[k];
+  if (nc < 0) {  // carry: node types nobody appended to in this hop keep their size
+    const int t = (int)threadIdx.x;
+    if (t < L.tb.T) {
+      const bool has = t < 32 ? ((L.type_mask_lo >> t) & 1u) != 0 : ((L.type_mask_hi >> (t - 32)) & 1u) != 0;
+      if (!has) L.tb.size_at[(L.ell + 1) * L.tb.T + t] = L.tb.size_at[L.ell * L.tb.T + t];
+    }
+    return;
+  }
+  const FPart& pt = L.part[k];
+#define PYG_FUSED_CASE(N)                               \
+  if (MAXNC >= N && nc == N) {                          \
+    if constexpr (MAXNC >= N) {                         \
+      if (APPLY) fused_apply<N>(L, pt, b, nblocks);     \
+      else fused_reduce<N>(L, pt, b);                   \
+    }                                                   \
+    return;                                             \
+  }
+  PYG_FUSED_CASE(0)
+  PYG_FUSED_CASE(1)
+  PYG_FUSED_CASE(2)
+  PYG_FUSED_CASE(3)
+  PYG_FUSED_CASE(4)
+#undef PYG_FUSED_CASE
+}

@@ -1,0 +1,473 @@
+// Host side of the fused chain (sampler_fused.h): 3 launches per hop, every record in the launch's kernel argument (no
+// staging copy), the write-once tables read back once behind the last launch.  Included by sampler.hip.
+
+struct FusedSeed {  // one seed set, recorded by the seeds loop of run_sampler (insert kernel already queued)
+  int type;
+  int64_t S;
+  u64* slots;
+};
+
+// consumers of node type t for hop `next` (relations of that hop that expand t), in relation order
+inline std::vector<int> fused_consumers(const pyg_hip_relation* rels, int num_relations, int csc,
+                                        const std::vector<std::vector<int64_t>>& eb, int next, int L, int t) {
+  std::vector<int> out;
+  if (next >= L) return out;
+  for (int e = 0; e < num_relations; ++e) {
+    const int src = !csc ? rels[e].src_type : rels[e].dst_type;
+    if (src == t && eb[(size_t)next][(size_t)e] != 0) out.push_back(e);
+  }
+  return out;
+}
+
+// can the call run the fused chain?  (every type has at most kMaxCons consumers per hop, tile counts stay small)
+inline bool fused_eligible(const pyg_hip_relation* rels, int num_relations, int num_node_types, int num_seed_sets,
+                           int csc, int L, const std::vector<std::vector<int64_t>>& eb) {
+  if (num_node_types > 64 || L * num_relations > 64 || num_seed_sets > kMaxParts) return false;
+  static const bool off = [] {
+    const char* e = getenv("PYG_HIP_SAMPLER_FUSED");
+    return e != nullptr && e[0] == '0';
+  }();
+  if (off) return false;
+  for (int next = 0; next <= L; ++next) {  // next = the hop whose relations consume what phase next - 1 appends
+    int launch_cons = 0;
+    for (int t = 0; t < num_node_types; ++t) {
+      const int nc = (int)fused_consumers(rels, num_relations, csc, eb, next, L, t).size();
+      if (nc > kMaxCons) return false;
+      launch_cons += nc;  // (upper bound: types without a segment in that phase carry none)
+    }
+    if (launch_cons > kMaxLaunchCons) return false;
+  }
+  for (int ell = 0; ell < L; ++ell) {
+    std::vector<int64_t> tiles((size_t)num_node_types, 0);
+    int queued = 0;
+    for (int e = 0; e < num_relations; ++e) {
+      const int dst = !csc ? rels[e].dst_type : rels[e].src_type;
+      if (eb[(size_t)ell][(size_t)e] != 0) ++queued;
+      tiles[(size_t)dst] += (eb[(size_t)ell][(size_t)e] + kScanTile - 1) / kScanTile;
+      if (tiles[(size_t)dst] > 8192) return false;  // every apply block reduces the tiles in front of it
+    }
+    if (queued > kMaxParts) return false;
+  }
+  return true;
+}
+
+int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip_relation* rels, int L, int csc,
+                    int replace, int disjoint, int64_t num_batches, const int64_t* const* node_time, int temporal_last,
+                    int64_t* seed_times, int* err_flag, std::vector<NodeSet>& ns, std::vector<RelState>& rs,
+                    const std::vector<std::vector<int64_t>>& eb, const std::vector<std::vector<int64_t>>& fbh,
+                    const std::vector<int64_t>& node_bound, const std::vector<int64_t>& rel_bound,
+                    const std::vector<FusedSeed>& fseeds, RngHost& rng, ChainState* chain, char* tables_host,
+                    MtHandBack* hand_back_host, MtHandBack** hand_back_out,
+                    std::vector<std::vector<int64_t>>& nodes_per_hop, PhaseTimer& pt) {
+  hipStream_t stream = c.stream;
+  const int R = num_relations, T = num_node_types;
+  auto tiles_of = [](int64_t n) { return (int)((n + kScanTile - 1) / kScanTile); };
+  auto src_of = [&](int e) { return !csc ? rels[e].src_type : rels[e].dst_type; };
+  auto dst_of = [&](int e) { return !csc ? rels[e].dst_type : rels[e].src_type; };
+
+  // ---- lists, tables and outputs at their bound size (as in round 2's fully queued mode) ----
+  for (int t = 0; t < T; ++t) {
+    NodeSet& n = ns[(size_t)t];
+    if (node_bound[(size_t)t] == 0) continue;
+    n.nodes.live = n.nodes.size;
+    int rc = n.nodes.reserve(c, n.nodes.size + node_bound[(size_t)t]);
+    if (rc != PYG_HIP_OK) return rc;
+    if (disjoint) {
+      n.batch.live = n.batch.size;
+      rc = n.batch.reserve(c, n.batch.size + node_bound[(size_t)t]);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    // a seeded type reserved its table for the whole call already (its seeds' slot handles must stay valid: no rehash)
+    const int64_t want = n.nodes.size + node_bound[(size_t)t];
+    if (n.entries_bound < want) {
+      PYG_HIP_REQUIRE(n.nodes.size == 0 || n.table.dense, "sampler: internal error (seeded table would be rehashed)");
+      rc = table_reserve(c, n, want - n.entries_bound);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+  }
+  for (int e = 0; e < R; ++e) {
+    RelState& st = rs[(size_t)e];
+    if (rel_bound[(size_t)e] == 0) continue;
+    int rc = st.row.reserve(c, rel_bound[(size_t)e]);
+    if (rc == PYG_HIP_OK) rc = st.col.reserve(c, rel_bound[(size_t)e]);
+    if (rc == PYG_HIP_OK) rc = st.eid.reserve(c, rel_bound[(size_t)e]);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+
+  // ---- arena: staging mirror + per-step scratch ----
+  const size_t tb_bytes = align_up(8 * (size_t)(L + 1) * T + 8 * (size_t)T + sizeof(CountAgg) * (size_t)L * R + 4 * (size_t)L * R, 16);
+  size_t arena_bytes = align_up(tb_bytes, 256);
+  for (const FusedSeed& fsd : fseeds) {
+    const size_t nc = fused_consumers(rels, R, csc, eb, 0, L, fsd.type).size();
+    arena_bytes += align_up(8 * (size_t)fsd.S, 256) + align_up((8 + 16 * nc) * (size_t)(tiles_of(fsd.S) + 1), 256);
+  }
+  for (int ell = 0; ell < L; ++ell) {
+    std::vector<size_t> seg_tiles((size_t)T, 0);
+    for (int e = 0; e < R; ++e) {
+      const int64_t Eb = eb[(size_t)ell][(size_t)e];
+      if (Eb == 0) continue;
+      const int64_t Fb = fbh[(size_t)ell][(size_t)src_of(e)];
+      arena_bytes += 2 * align_up(8 * (size_t)Fb, 256) + (disjoint ? 4 : 3) * align_up(8 * (size_t)Eb, 256);
+      seg_tiles[(size_t)dst_of(e)] += (size_t)tiles_of(Eb);
+    }
+    for (int t = 0; t < T; ++t)
+      if (seg_tiles[(size_t)t]) arena_bytes += align_up((8 + 16 * (size_t)kMaxCons) * (seg_tiles[(size_t)t] + 1), 256);
+  }
+  char* arena;
+  PYG_ALLOC(arena, char*, c, arena_bytes);
+  auto carve = [&](size_t bytes) {
+    char* p = arena;
+    arena += align_up(bytes, 256);
+    return p;
+  };
+  // ---- tables (device; initialised by a kernel) ----
+  char* tb_dev = carve(tb_bytes);
+  FTables tb;
+  tb.size_at = reinterpret_cast<int64_t*>(tb_dev);
+  tb.dup = tb.size_at + (size_t)(L + 1) * T;
+  tb.tot = reinterpret_cast<CountAgg*>(tb.dup + T);
+  tb.overflow = reinterpret_cast<int32_t*>(tb.tot + (size_t)L * R);
+  tb.word0 = rng.word;
+  tb.units0 = rng.units;
+  tb.L = L;
+  tb.R = R;
+  tb.T = T;
+  {
+    const int cells = std::max((L + 1) * T, L * R);
+    hipLaunchKernelGGL(fused_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, tb);
+    PYG_HIP_CHECK(hipGetLastError());
+  }
+
+  auto add_sample = [&](FSampleLaunch& l, int role, int64_t blocks, int idx) {
+    if (blocks <= 0) return;
+    const int k = l.n++;
+    l.cum[k] = (k > 0 ? l.cum[k - 1] : 0) + (int)blocks;
+    l.role[k] = (unsigned char)role;
+    l.idx[k] = (unsigned char)idx;
+  };
+  auto add_part = [&](FScanLaunch& l, int nc, int64_t blocks, const FPart* part) {
+    if (blocks <= 0) return;
+    const int k = l.n++;
+    l.cum[k] = (k > 0 ? l.cum[k - 1] : 0) + (int)blocks;
+    l.nc[k] = nc;
+    if (part) l.part[k] = *part;
+  };
+  int64_t avail_blocks = 0;
+  auto launch_sample = [&](const FSampleLaunch& l) -> int {
+    if (l.n == 0) return PYG_HIP_OK;
+    int gmax = 8;
+    for (int k = 0; k < l.n; ++k)
+      if (l.role[k] <= kRoleSample64) gmax = std::max(gmax, 8 << l.role[k]);
+    const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
+    const u64* words = rng.dev;
+    if (gmax <= 8) hipLaunchKernelGGL(fused_sample_kernel<8>, grid, block, 0, stream, l, avail_blocks, words);
+    else if (gmax <= 16) hipLaunchKernelGGL(fused_sample_kernel<16>, grid, block, 0, stream, l, avail_blocks, words);
+    else if (gmax <= 32) hipLaunchKernelGGL(fused_sample_kernel<32>, grid, block, 0, stream, l, avail_blocks, words);
+    else hipLaunchKernelGGL(fused_sample_kernel<64>, grid, block, 0, stream, l, avail_blocks, words);
+    PYG_HIP_CHECK(hipGetLastError());
+    return PYG_HIP_OK;
+  };
+  auto launch_scan = [&](const FScanLaunch& l, bool apply) -> int {
+    if (l.n == 0) return PYG_HIP_OK;
+    int maxnc = 0;
+    for (int k = 0; k < l.n; ++k) maxnc = std::max(maxnc, l.nc[k]);
+    const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
+#define PYG_FUSED_LAUNCH(N)                                                                    \
+  case N:                                                                                      \
+    if (!apply) hipLaunchKernelGGL((fused_scan_kernel<N, false>), grid, block, 0, stream, l);  \
+    else hipLaunchKernelGGL((fused_scan_kernel<N, true>), grid, block, 0, stream, l);          \
+    break;
+    switch (maxnc) {
+      PYG_FUSED_LAUNCH(0)
+      PYG_FUSED_LAUNCH(1)
+      PYG_FUSED_LAUNCH(2)
+      PYG_FUSED_LAUNCH(3)
+      default:
+        PYG_FUSED_LAUNCH(4)
+    }
+#undef PYG_FUSED_LAUNCH
+    PYG_HIP_CHECK(hipGetLastError());
+    return PYG_HIP_OK;
+  };
+  struct ConsArr {
+    int64_t* edge_off = nullptr;
+    RngTab* tabp = nullptr;
+  };
+  std::vector<ConsArr> cons_arr((size_t)std::max(L * R, 1));
+  auto range_of = [&](int e, const NodeSet& sn) {
+    const pyg_hip_relation& r = rels[e];
+    RangeCtx range;
+    range.rowptr = IdxArr(r.rowptr, r.index_is32);
+    range.col = IdxArr(r.col, r.index_is32);
+    range.time = r.edge_time ? r.edge_time : (node_time ? node_time[dst_of(e)] : nullptr);
+    range.edge_level = r.edge_time ? 1 : 0;
+    range.last = temporal_last;
+    range.seed_times = seed_times;
+    range.batch = disjoint ? sn.batch.p : nullptr;
+    range.error = err_flag;
+    return range;
+  };
+  // appends the consumers of type t for hop `next` to the launch's consumer array (allocating their per-node prefix
+  // arrays) and returns the index of the first one
+  auto fill_consumers = [&](FScanLaunch& l, int* used, FSegHdr& sh, int t, int next) -> int {
+    const std::vector<int> cons = fused_consumers(rels, R, csc, eb, next, L, t);
+    sh.ncons = (int)cons.size();
+    const int first = *used;
+    for (size_t q = 0; q < cons.size(); ++q) {
+      const int e2 = cons[q];
+      const int64_t Fb = fbh[(size_t)next][(size_t)t];
+      ConsArr& ca = cons_arr[(size_t)next * R + e2];
+      ca.edge_off = reinterpret_cast<int64_t*>(carve(8 * (size_t)Fb));
+      ca.tabp = reinterpret_cast<RngTab*>(carve(8 * (size_t)Fb));
+      FConsumer& fc = l.cons[(*used)++];
+      fc.range = range_of(e2, ns[(size_t)t]);
+      fc.count = rels[e2].num_neighbors_host[next];
+      fc.replace = replace;
+      fc.tot_index = next * R + e2;
+      fc.edge_off = ca.edge_off;
+      fc.tabp = ca.tabp;
+    }
+    return first;
+  };
+  auto seg_base = [&](FSegHdr& sh, int t) {
+    NodeSet& n = ns[(size_t)t];
+    ::memset(&sh, 0, sizeof(sh));
+    sh.vals = n.table.vals;
+    sh.nodes = n.nodes.p;
+    sh.batch = disjoint ? n.batch.p : nullptr;
+    sh.dup = tb.dup + t;
+  };
+
+  // ---- seeds: one segment per seeded type; reduce + apply, queued right away ----
+  {
+    FScanLaunch sc;
+    ::memset(&sc, 0, sizeof(sc));
+    sc.tb = tb;
+    int used = 0;
+    for (const FusedSeed& fsd : fseeds) {
+      if (fsd.S == 0) continue;
+      FPart pp;
+      ::memset(&pp, 0, sizeof(pp));
+      seg_base(pp.h, fsd.type);
+      pp.h.size_in = nullptr;
+      pp.h.size_out = tb.size_at + fsd.type;
+      pp.h.seeds = 1;
+      pp.cons0 = fill_consumers(sc, &used, pp.h, fsd.type, 0);
+      const int nt = tiles_of(fsd.S);
+      pp.h.tile_agg = carve((8 + 16 * (size_t)pp.h.ncons) * (size_t)(nt + 1));
+      pp.slots = fsd.slots;
+      pp.e_node = ns[(size_t)fsd.type].nodes.p;
+      pp.e_batch = disjoint ? ns[(size_t)fsd.type].batch.p : nullptr;
+      pp.cache = reinterpret_cast<u64*>(carve(8 * (size_t)fsd.S));
+      pp.n_fixed = fsd.S;
+      pp.pos_base = 0;
+      pp.tot_index = 0;
+      pp.tile0 = 0;
+      pp.last = 1;
+      add_part(sc, pp.h.ncons, nt, &pp);
+    }
+    int rc = launch_scan(sc, false);
+    if (rc != PYG_HIP_OK) return rc;
+    rc = launch_scan(sc, true);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+
+  // ---- hops ----
+  struct Step {
+    int ell, e;
+    FFinalRec fin;
+    int64_t Eb = 0;
+  };
+  std::vector<Step> prev_steps;
+  std::vector<std::vector<Step>> steps_by_hop((size_t)L);
+  int64_t spec_word = rng.word;
+  for (int ell = 0; ell < L; ++ell) {
+    FSampleLaunch p1;
+    FScanLaunch p2;
+    ::memset(&p1, 0, sizeof(p1));
+    ::memset(&p2, 0, sizeof(p2));
+    p1.tb = tb;
+    p1.chain = chain;
+    p2.tb = tb;
+    p2.ell = ell;
+    int nf = 0, nsmp = 0, used = 0;
+    for (const Step& s : prev_steps) {
+      p1.f[nf] = s.fin;
+      add_sample(p1, kRoleFinalize, (s.Eb + 255) / 256, nf++);
+    }
+    // segments of this hop
+    std::vector<FSegHdr> segs((size_t)T);
+    std::vector<int> seg_cons0((size_t)T, 0), seg_tiles((size_t)T, 0), seg_last((size_t)T, -1);
+    std::vector<int64_t> seg_pos((size_t)T, 0);
+    for (int e = 0; e < R; ++e)
+      if (eb[(size_t)ell][(size_t)e] != 0) seg_last[(size_t)dst_of(e)] = e;
+    for (int t = 0; t < T; ++t) {
+      if (seg_last[(size_t)t] < 0) continue;
+      if (t < 32) p2.type_mask_lo |= 1u << t;
+      else p2.type_mask_hi |= 1u << (t - 32);
+      FSegHdr& sh = segs[(size_t)t];
+      seg_base(sh, t);
+      sh.size_in = tb.size_at + (size_t)ell * T + t;
+      sh.size_out = tb.size_at + (size_t)(ell + 1) * T + t;
+      sh.seeds = 0;
+      seg_cons0[(size_t)t] = fill_consumers(p2, &used, sh, t, ell + 1);
+      int nt = 0;
+      for (int e = 0; e < R; ++e)
+        if (dst_of(e) == t) nt += tiles_of(eb[(size_t)ell][(size_t)e]);
+      sh.tile_agg = carve((8 + 16 * (size_t)sh.ncons) * (size_t)(nt + 1));
+    }
+    std::vector<Step> cur;
+    for (int e = 0; e < R; ++e) {
+      const int64_t Eb = eb[(size_t)ell][(size_t)e];
+      if (Eb == 0) continue;
+      const pyg_hip_relation& r = rels[e];
+      const int src = src_of(e), dst = dst_of(e);
+      NodeSet& sn = ns[(size_t)src];
+      NodeSet& dn = ns[(size_t)dst];
+      RelState& st = rs[(size_t)e];
+      const int64_t count = r.num_neighbors_host[ell];
+      const int64_t Fb = fbh[(size_t)ell][(size_t)src];
+      int64_t* e_node = reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb));
+      int64_t* e_batch = disjoint ? reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb)) : nullptr;
+      u64* e_slot = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
+      u64* cache = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
+      const ConsArr& ca = cons_arr[(size_t)ell * R + e];
+      PYG_HIP_REQUIRE(ca.edge_off != nullptr, "sampler: internal error (no producer for a queued relation)");
+      FSampleRec& sr = p1.s[nsmp];
+      sr.nodes = sn.nodes.p;
+      sr.batch = disjoint ? sn.batch.p : nullptr;
+      sr.range = range_of(e, sn);
+      sr.count = count;
+      sr.num_batches = num_batches;
+      sr.edge_off = ca.edge_off;
+      sr.tabp = ca.tabp;
+      sr.e_row = st.row.p;
+      sr.e_node = e_node;
+      sr.e_batch = e_batch;
+      sr.e_eid = st.eid.p;
+      sr.e_slot = e_slot;
+      sr.table = dn.table;
+      sr.pos_base = seg_pos[(size_t)dst];
+      sr.replace = replace;
+      sr.ell = ell;
+      sr.e = e;
+      sr.t_src = src;
+      const int role = count <= 8 ? kRoleSample8 : count <= 16 ? kRoleSample16 : count <= 32 ? kRoleSample32 : kRoleSample64;
+      const int64_t per = count <= 8 ? 32 : count <= 16 ? 16 : count <= 32 ? 8 : 4;  // frontier nodes per block
+      add_sample(p1, role, (Fb + per - 1) / per, nsmp++);
+      FPart pp;
+      ::memset(&pp, 0, sizeof(pp));
+      pp.h = segs[(size_t)dst];
+      pp.cons0 = seg_cons0[(size_t)dst];
+      pp.slots = e_slot;
+      pp.e_node = e_node;
+      pp.e_batch = e_batch;
+      pp.cache = cache;
+      pp.n_fixed = -1;
+      pp.pos_base = seg_pos[(size_t)dst];
+      pp.tot_index = ell * R + e;
+      pp.tile0 = seg_tiles[(size_t)dst];
+      pp.last = seg_last[(size_t)dst] == e ? 1 : 0;
+      add_part(p2, pp.h.ncons, tiles_of(Eb), &pp);
+      seg_pos[(size_t)dst] += Eb;
+      seg_tiles[(size_t)dst] += tiles_of(Eb);
+      Step s;
+      s.ell = ell;
+      s.e = e;
+      s.Eb = Eb;
+      s.fin.slots = e_slot;
+      s.fin.vals = dn.table.vals;
+      s.fin.out_col = st.col.p;
+      s.fin.ell = ell;
+      s.fin.e = e;
+      cur.push_back(s);
+    }
+    // ---- queue the hop: [finalize(l - 1) | sample(l)] -> reduce -> apply (+ carry) ----
+    for (const Step& s : cur) spec_word += (s.Eb + 3) / 4 + 1;
+    int rc = PYG_HIP_OK;
+    if (!cur.empty()) {  // order the words this hop may read (16-bit draws, cumulative bound) before its sampling launch
+      rc = rng_wait(c, rng, spec_word, &avail_blocks);
+      if (rc != PYG_HIP_OK) return rc;
+    }
+    rc = launch_sample(p1);
+    if (rc != PYG_HIP_OK) return rc;
+    rc = launch_scan(p2, false);
+    if (rc != PYG_HIP_OK) return rc;
+    add_part(p2, -1, 1, nullptr);  // carry block: apply pass only
+    rc = launch_scan(p2, true);
+    if (rc != PYG_HIP_OK) return rc;
+    steps_by_hop[(size_t)ell] = cur;
+    prev_steps = cur;
+  }
+  {
+    FSampleLaunch fin;
+    ::memset(&fin, 0, sizeof(fin));
+    fin.tb = tb;
+    fin.chain = chain;
+    int nf = 0;
+    for (const Step& s : prev_steps) {
+      fin.f[nf] = s.fin;
+      add_sample(fin, kRoleFinalize, (s.Eb + 255) / 256, nf++);
+    }
+    add_sample(fin, kRoleFold, 1, 0);
+    int rc = launch_sample(fin);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  // the engine hand-back rides behind the last launch (its position was folded into `chain`)
+  *hand_back_out = nullptr;
+  if (rng.engine) {
+    const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
+    size_t k = 0;
+    while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
+    if (k < rng.marks.size()) {
+      MtHandBack* hb_dev;
+      PYG_ALLOC(hb_dev, MtHandBack*, c, sizeof(MtHandBack));
+      hand_back_host->status = -1;
+      if (k >= rng.waited) {
+        PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
+        rng.waited = k + 1;
+      }
+      int rc = rng_queue_hand_back(c, rng, chain, rng.marks[k].upto32, hb_dev);
+      if (rc != PYG_HIP_OK) return rc;
+      PYG_HIP_CHECK(hipMemcpyAsync(hand_back_host, hb_dev, sizeof(MtHandBack), hipMemcpyDeviceToHost, stream));
+      *hand_back_out = hand_back_host;
+    }
+  }
+  PYG_HIP_CHECK(hipMemcpyAsync(tables_host, tb_dev, tb_bytes, hipMemcpyDeviceToHost, stream));
+  pt.lap(4);
+  PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  pt.lap(5);
+  if (err_flag)
+    PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0, "Found invalid non-sorted temporal neighborhood");
+
+  // ---- fold the tables into the host's bookkeeping ----
+  const int64_t* h_size = reinterpret_cast<const int64_t*>(tables_host);
+  const CountAgg* h_tot = reinterpret_cast<const CountAgg*>(tables_host + 8 * (size_t)(L + 1) * T + 8 * (size_t)T);
+  const int32_t* h_over = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(h_tot) + sizeof(CountAgg) * (size_t)L * R);
+  for (int k = 0; k < L * R; ++k)
+    if (h_over[k]) return kNeedSlow;
+  for (int ell = 0; ell < L; ++ell) {
+    for (int e = 0; e < R; ++e) rs[(size_t)e].edges_per_hop.push_back(0);
+    for (const Step& s : steps_by_hop[(size_t)ell]) {
+      const CountAgg t = h_tot[(size_t)ell * R + s.e];
+      RelState& st = rs[(size_t)s.e];
+      if (t.edges > 0) {
+        const int64_t end_word = rng.word + tab_dw(t.tab, rng.units);
+        rng.blocks = std::max(rng.blocks, end_word / 128 + 1);
+        rng.word = end_word;
+        rng.units = tab_nb(t.tab, rng.units);
+      }
+      st.row.size += t.edges;
+      st.col.size += t.edges;
+      st.eid.size += t.edges;
+      st.edges_per_hop.back() = t.edges;
+    }
+    for (int t = 0; t < T; ++t) {
+      const int64_t now = h_size[(size_t)(ell + 1) * T + t], before = h_size[(size_t)ell * T + t];
+      nodes_per_hop[(size_t)t].push_back(now - before);
+      ns[(size_t)t].nodes.size = now;
+      if (disjoint) ns[(size_t)t].batch.size = now;
+    }
+  }
+  return PYG_HIP_OK;
+}

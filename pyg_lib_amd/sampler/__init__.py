@@ -91,4 +91,14 @@ def hetero_neighbor_sample(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[E
             to_edge_keys(edges_per_hop))
 
 
-__all__ = ['neighbor_sample', 'hetero_neighbor_sample']
+def last_mode() -> str:
+    """Driver of the calling thread's last sampler call: 'fused', 'queued' or 'synchronising' (diagnostics; see
+    ``pyg_hip_sampler_last_mode`` in include/pyg_hip.h)."""
+    import ctypes
+    from .. import _capi
+    L = _capi.lib()
+    L.pyg_hip_sampler_last_mode.restype = ctypes.c_char_p
+    return L.pyg_hip_sampler_last_mode().decode()
+
+
+__all__ = ['neighbor_sample', 'hetero_neighbor_sample', 'last_mode']

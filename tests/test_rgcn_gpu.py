@@ -199,6 +199,7 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
     seeds = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=torch.Generator().manual_seed(1))[:1024]
     torch.manual_seed(2024)
     out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds.cuda()}, fan)
+    assert sampler.last_mode() == 'fused'   # every relation of a hop in one launch per phase (sampler_fused.h)
     after = torch.get_rng_state()
     ref = oracle.hetero_neighbor_sample(types, ets, {e: v.cpu().numpy() for e, v in rp.items()},
                                         {e: v.cpu().numpy() for e, v in cl.items()}, {'paper': seeds.numpy()}, fan,

@@ -257,6 +257,7 @@ def test_products_scale_batch_is_bit_exact():
     col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
     seeds = rng.permutation(n)[:1024].astype(np.int64)
     out, after, ref = run_both(rowptr, col, seeds, [15, 10, 5], 12345)
+    assert sampler.last_mode() == 'fused'   # 3 launches per hop (csrc/hip/sampler_fused.h)
     assert_same(out, after, ref, 12345)
     assert sum(ref[5]) > 500_000
 
