@@ -211,19 +211,19 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
     fan = {e: [15, 10] for e in ets}
     gs = torch.Generator().manual_seed(1)
     seeds = [torch.randperm(MAG_SIZES['paper'], generator=gs)[:batch].to(device) for _ in range(iters + 3)]
-    layer = getattr(rgcn, 'rgcn_layer_fused', None) or rgcn.rgcn_layer
     state = {}
 
     def sample(i):
         return sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds[i]}, fan)
 
+    def layer(out):
+        # features are gathered from the global tables inside the kernel: no per-batch feature matrix
+        return rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W)
+
     def one(i):
         out = sample(i)
-        row_d, col_d, node_d = out[0], out[1], out[2]
-        off = rgcn.type_offsets({t: node_d[t].numel() for t in types}, types)
-        x = torch.cat([feat[t][node_d[t]] for t in types])
-        y = layer(x, off, row_d, col_d, ets, W)
-        state['last'] = (out, x, off)
+        y = layer(out)
+        state['last'] = out
         return out, y
 
     torch.manual_seed(100)
@@ -242,16 +242,16 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
         sample(i)
     torch.cuda.synchronize()
     samp_ms = (time.perf_counter() - t0) / iters * 1e3
-    out, x, off = state['last']
-    layer_ms = _event_ms(lambda: layer(x, off, out[0], out[1], ets, W), iters)
+    out = state['last']
+    layer_ms = _event_ms(lambda: layer(out), iters)
     e = sum(v.numel() for v in out[0].values())
-    n = x.size(0)
-    esz = x.element_size()
+    n = sum(v.numel() for v in out[2].values())
+    esz = W.element_size()
     # layer: per edge one gathered source row in (+ 16 B of indices), per node one output row written
     alg = e * (F * esz + 16) + n * F * esz + len(ets) * F * F * esz
     return dict(workload='hetero_neighbor_sample + R-GCN layer, MAG-shaped graph (4 node types, 7 relations, ~42 M '
                          'entries), batch 1024 papers, fanout [15, 10], F=128 bf16 (BASELINE.json configs[4])',
-                layer_impl=layer.__name__, edges_per_batch=edges // iters, nodes_last_batch=n,
+                layer_impl='rgcn_layer_fused_tables', sampler_mode=sampler.last_mode(), edges_per_batch=edges // iters, nodes_last_batch=n,
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
                 layer=_rate(alg, layer_ms))
 

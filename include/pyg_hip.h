@@ -163,6 +163,14 @@ typedef struct {
   int64_t gather_offset;
   int64_t scatter_offset;
   const void* weight;           /* device, [K, M] row-major, 16-byte aligned */
+  /* Optional second indirection ("true fusion": the per-batch feature matrix x is never materialised).  With `x`
+   * non-NULL this relation gathers from its OWN table x [x_rows, K] (e.g. the global feature table of its source
+   * node type) at row gather_map[gather_index[e]] (gather_map = that type's sampled node ids, gather_map_len
+   * entries), or gather_index[e] + gather_offset if gather_map is NULL.  All zero: the call's x, as before. */
+  const void* x;
+  const int64_t* gather_map;
+  int64_t x_rows;
+  int64_t gather_map_len;
 } pyg_hip_rgcn_relation;
 
 PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges);
@@ -175,11 +183,14 @@ PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int6
  *   x [num_x_rows, K], out [num_out_rows, M] (ACCUMULATED into: zero it for a plain aggregation), both `dtype`
  *   (PYG_BF16 / PYG_F16) row-major; K = M = 128 (other shapes: PYG_HIP_ERR_UNSUPPORTED, the caller keeps the
  *   three-op chain).  Messages are rounded to `dtype` once (as the chain does), runs of equal destination are
- *   summed in fp32 and added with packed 16-bit atomics.  `relations` is a host array.  Never synchronises.
+ *   summed in fp32 and added with packed 16-bit atomics.  `relations` is a host array.  Never synchronises --
+ *   unless `checked` != 0: then every gather / scatter index is validated against num_x_rows (x_rows, gather_map_len)
+ *   / num_out_rows on the device, offenders are redirected to row 0, and the call waits for the stream and returns
+ *   PYG_HIP_ERR_INVALID if there was one (unchecked, a bad index is an out-of-bounds read / an atomic into foreign memory).
  */
 PYG_HIP_API int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* relations,
                                    int64_t num_relations, void* out, int64_t num_out_rows, int64_t K, int64_t M,
-                                   void* workspace, size_t workspace_bytes, void* stream);
+                                   int checked, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- neighbor_sample / hetero_neighbor_sample ---------------------------------------------- */
 

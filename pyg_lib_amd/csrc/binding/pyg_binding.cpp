@@ -19,6 +19,8 @@
 #include <torch/autograd.h>
 #include <torch/library.h>
 
+#include <cstdlib>
+
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -246,7 +248,25 @@ std::vector<Tensor> grouped_matmul_pool_kernel(const at::TensorList input, const
 }
 
 // This build only: gather -> per-relation matmul -> scatter-add in one launch (csrc/hip/rgcn.hip).  `out` is
-// accumulated into and returned.
+// accumulated into and returned.  PYG_HIP_RGCN_CHECK=1 validates every index on the device (and synchronises).
+static bool rgcn_checked() {
+  static const bool on = [] {
+    const char* e = getenv("PYG_HIP_RGCN_CHECK");
+    return e != nullptr && e[0] != '\0' && e[0] != '0';
+  }();
+  return on;
+}
+
+static void rgcn_index_checks(const at::TensorList gather_index, const at::TensorList scatter_index, const Tensor& like,
+                              size_t r) {
+  TORCH_CHECK(gather_index[r].scalar_type() == at::kLong && scatter_index[r].scalar_type() == at::kLong &&
+                  gather_index[r].dim() == 1 && gather_index[r].sizes() == scatter_index[r].sizes(),
+              "rgcn_fused: index vectors must be 1-D int64 tensors of equal length");
+  TORCH_CHECK(gather_index[r].device() == like.device() && scatter_index[r].device() == like.device(),
+              "rgcn_fused: index vectors must live on the device of the features (got ", gather_index[r].device(), " / ",
+              scatter_index[r].device(), " vs ", like.device(), ")");
+}
+
 Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, const at::TensorList scatter_index,
                          at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
   PYG_TRACE("pyg::rgcn_fused");
@@ -267,12 +287,10 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
   std::vector<Tensor> keep;
   int64_t E = 0;
   for (size_t r = 0; r < R; ++r) {
-    TORCH_CHECK(gather_index[r].scalar_type() == at::kLong && scatter_index[r].scalar_type() == at::kLong &&
-                    gather_index[r].dim() == 1 && gather_index[r].sizes() == scatter_index[r].sizes() &&
-                    gather_index[r].is_cuda() && scatter_index[r].is_cuda(),
-                "rgcn_fused: index vectors must be 1-D int64 device tensors of equal length");
+    rgcn_index_checks(gather_index, scatter_index, x, r);
     auto g = gather_index[r].contiguous();
     auto s = scatter_index[r].contiguous();
+    rels[r] = pyg_hip_rgcn_relation{};
     rels[r].gather_index = g.data_ptr<int64_t>();
     rels[r].scatter_index = s.data_ptr<int64_t>();
     rels[r].num_edges = g.numel();
@@ -285,8 +303,68 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
   }
   auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, x.options().dtype(at::kByte));
   check_status(pyg_hip_rgcn_fused(dtype_code(x.scalar_type()), xc.data_ptr(), xc.size(0), rels.data(), (int64_t)R,
-                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), ws.data_ptr(), (size_t)ws.numel(),
-                                  current_stream(x)));
+                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), rgcn_checked() ? 1 : 0,
+                                  ws.data_ptr(), (size_t)ws.numel(), current_stream(x)));
+  return out;
+}
+
+// The same without the per-batch feature matrix: relation r gathers row node_id[gather_type[r]][gather_index[r][e]] of
+// the GLOBAL feature table feat[gather_type[r]] -- what `x = cat([feat[t][node_id[t]] ...])` followed by rgcn_fused
+// computes, minus the ATen gathers, the cat and the [sum n_t, K] intermediate.
+Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList node_id, at::IntArrayRef gather_type,
+                                const at::TensorList gather_index, const at::TensorList scatter_index,
+                                at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
+  PYG_TRACE("pyg::rgcn_fused_tables");
+  const size_t R = gather_index.size(), T = feat.size();
+  TORCH_CHECK(T > 0 && node_id.size() == T, "rgcn_fused_tables: one node-id vector per feature table expected");
+  TORCH_CHECK(scatter_index.size() == R && gather_type.size() == R && scatter_offset.size() == R,
+              "rgcn_fused_tables: one gather type, gather / scatter index vector and offset per relation expected");
+  const Tensor& f0 = feat[0];
+  TORCH_CHECK(f0.is_cuda() && weight.is_cuda() && out.is_cuda() && f0.device() == weight.device() && f0.device() == out.device(),
+              "rgcn_fused_tables: tensors must live on the same HIP device");
+  TORCH_CHECK(out.dim() == 2 && weight.dim() == 3 && (size_t)weight.size(0) == R && weight.size(2) == out.size(1),
+              "rgcn_fused_tables: expected weight [R, K, M], out [N_out, M]");
+  TORCH_CHECK(out.is_contiguous() && out.scalar_type() == weight.scalar_type(), "rgcn_fused_tables: 'out' must be contiguous and typed like 'weight'");
+  DeviceGuard guard(f0.device());
+  std::vector<Tensor> keep;
+  std::vector<Tensor> fc(T), nc(T);
+  for (size_t t = 0; t < T; ++t) {
+    TORCH_CHECK(feat[t].dim() == 2 && feat[t].size(1) == weight.size(1) && feat[t].scalar_type() == weight.scalar_type() &&
+                    feat[t].device() == f0.device(),
+                "rgcn_fused_tables: feat[", t, "] must be [N_t, K] on the common device and typed like 'weight'");
+    TORCH_CHECK(node_id[t].dim() == 1 && node_id[t].scalar_type() == at::kLong && node_id[t].device() == f0.device(),
+                "rgcn_fused_tables: node_id[", t, "] must be a 1-D int64 tensor on the common device");
+    fc[t] = feat[t].contiguous();
+    nc[t] = node_id[t].contiguous();
+  }
+  const auto wc = weight.contiguous();
+  std::vector<pyg_hip_rgcn_relation> rels(R);
+  int64_t E = 0;
+  for (size_t r = 0; r < R; ++r) {
+    rgcn_index_checks(gather_index, scatter_index, f0, r);
+    TORCH_CHECK(gather_type[r] >= 0 && (size_t)gather_type[r] < T, "rgcn_fused_tables: gather_type out of range");
+    auto g = gather_index[r].contiguous();
+    auto s = scatter_index[r].contiguous();
+    const size_t t = (size_t)gather_type[r];
+    rels[r] = pyg_hip_rgcn_relation{};
+    rels[r].gather_index = g.data_ptr<int64_t>();
+    rels[r].scatter_index = s.data_ptr<int64_t>();
+    rels[r].num_edges = g.numel();
+    rels[r].gather_offset = 0;
+    rels[r].scatter_offset = scatter_offset[r];
+    rels[r].weight = static_cast<const char*>(wc.data_ptr()) + (int64_t)r * wc.size(1) * wc.size(2) * wc.element_size();
+    rels[r].x = fc[t].data_ptr();
+    rels[r].gather_map = nc[t].data_ptr<int64_t>();
+    rels[r].x_rows = fc[t].size(0);
+    rels[r].gather_map_len = nc[t].numel();
+    E += g.numel();
+    keep.push_back(g);
+    keep.push_back(s);
+  }
+  auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, f0.options().dtype(at::kByte));
+  check_status(pyg_hip_rgcn_fused(dtype_code(weight.scalar_type()), nullptr, 0, rels.data(), (int64_t)R, out.data_ptr(),
+                                  out.size(0), wc.size(1), out.size(1), rgcn_checked() ? 1 : 0, ws.data_ptr(),
+                                  (size_t)ws.numel(), current_stream(f0)));
   return out;
 }
 
@@ -789,6 +867,9 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused(Tensor x, Tensor[] gather_index, Tensor[] scatter_index, int[] gather_offset, "
       "int[] scatter_offset, Tensor weight, Tensor(a!) out) -> Tensor(a!)"));
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::rgcn_fused_tables(Tensor[] feat, Tensor[] node_id, int[] gather_type, Tensor[] gather_index, "
+      "Tensor[] scatter_index, int[] scatter_offset, Tensor weight, Tensor(a!) out) -> Tensor(a!)"));
   // this build only: grouped_matmul writing into a caller-provided [sum rows, M] pool (sharded driver)
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::grouped_matmul_pool(Tensor[] input, Tensor[] other, Tensor(a!) pool) -> Tensor[]"));
@@ -825,6 +906,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul_pool"), TORCH_FN(grouped_matmul_pool_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused_tables"), TORCH_FN(rgcn_fused_tables_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused"), TORCH_FN(rgcn_fused_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::dist_neighbor_sample"), TORCH_FN(dist_neighbor_sample_kernel));

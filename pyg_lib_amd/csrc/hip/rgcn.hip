@@ -43,6 +43,10 @@ struct RelDev {
   int64_t num_edges;
   int64_t gather_offset;
   int64_t scatter_offset;
+  const char* x;              // feature rows this relation gathers from (the call's x, or the source type's own table)
+  const int64_t* gather_map;  // nullptr, or: row = gather_map[gather_index[e]] (sampled local id -> global node id)
+  int64_t x_rows;             // rows of `x` (checked mode)
+  int64_t map_len;            // entries of gather_map (checked mode)
 };
 
 struct TileDev {
@@ -89,9 +93,11 @@ __device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
 }
 
 // K = M = 128, 16-bit T
-template <bool BF16>
+// CHECK: every gather / scatter index is validated; an offender sets *error and is redirected to row 0 (the host
+// reports it): without the check a bad index is an out-of-bounds DMA read or an atomic into foreign memory.
+template <bool BF16, bool CHECK>
 __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const TileDev* __restrict__ tiles,
-                                                        const char* __restrict__ x, char* __restrict__ out) {
+                                                        char* __restrict__ out, int64_t out_rows, int* __restrict__ error) {
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
@@ -117,15 +123,34 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   int64_t gi = 0, si = 0;
   if (nrows > 0) {
     const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
-    gi = rel.gather_index[e] + rel.gather_offset;
+    gi = rel.gather_index[e];
+    if (rel.gather_map) {  // double indirection done here: the gathered feature matrix never exists
+      if (CHECK && (gi < 0 || gi >= rel.map_len)) {
+        *error = 1;
+        gi = 0;
+      }
+      gi = rel.gather_map[gi];
+    } else {
+      gi += rel.gather_offset;
+    }
     si = rel.scatter_index[e] + rel.scatter_offset;
+    if (CHECK) {
+      if (gi < 0 || gi >= rel.x_rows) {
+        *error = 1;
+        gi = 0;
+      }
+      if (si < 0 || si >= out_rows) {
+        *error = 2;
+        si = 0;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int p = i * 64 + lane;
       const int r = p >> 4, cs = p & 15;
       const int c = cs ^ (r & 15);
       const int64_t row = __shfl(gi, r);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + row * 256 + c * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rel.x + row * 256 + c * 16),
                                        (LDSV*)(xs + i * 1024), 16, 0, 0);
     }
   }
@@ -199,12 +224,12 @@ size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edge
   if (num_relations < 0) num_relations = 0;
   if (num_edges < 0) num_edges = 0;
   const size_t tiles = (size_t)(num_edges / 128 + num_relations + 1);
-  return align_up(sizeof(RelDev) * (size_t)std::max<int64_t>(num_relations, 1), 256) + align_up(sizeof(TileDev) * tiles, 256);
+  return align_up(sizeof(RelDev) * (size_t)std::max<int64_t>(num_relations, 1), 256) + align_up(sizeof(TileDev) * tiles, 256) + 256;
 }
 
 int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R,
-                       void* out, int64_t num_out_rows, int64_t K, int64_t M, void* workspace, size_t workspace_bytes,
-                       void* stream_) {
+                       void* out, int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace,
+                       size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16, "rgcn_fused: bfloat16 / float16 only");
   if (K != 128 || M != 128) return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (got %lld x %lld)", (long long)K, (long long)M);
@@ -222,9 +247,13 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     tiles += (rels[r].num_edges + 127) / 128;
   }
   if (E == 0) return PYG_HIP_OK;
-  PYG_HIP_REQUIRE(x && out, "rgcn_fused: NULL tensor");
-  PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0,
-                  "rgcn_fused: misaligned tensor");
+  PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
+  for (int64_t r = 0; r < R; ++r) {
+    const void* xr = rels[r].x ? rels[r].x : x;
+    PYG_HIP_REQUIRE(rels[r].num_edges == 0 || xr != nullptr, "rgcn_fused: relation %lld has no feature table", (long long)r);
+    PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(xr) & 15) == 0, "rgcn_fused: misaligned feature table");
+  }
+  PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "rgcn_fused: misaligned tensor");
   PYG_HIP_REQUIRE(tiles < (1LL << 31), "rgcn_fused: too many tiles");
   if (workspace == nullptr || workspace_bytes < pyg_hip_rgcn_fused_workspace_size(R, E))
     return fail(PYG_HIP_ERR_WORKSPACE, "rgcn_fused: workspace of %zu bytes needed, got %zu",
@@ -244,6 +273,10 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     hr[r].num_edges = rels[r].num_edges;
     hr[r].gather_offset = rels[r].gather_offset;
     hr[r].scatter_offset = rels[r].scatter_offset;
+    hr[r].x = static_cast<const char*>(rels[r].x ? rels[r].x : x);
+    hr[r].gather_map = rels[r].gather_map;
+    hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
+    hr[r].map_len = rels[r].gather_map_len;
     for (int64_t k = 0; k < (rels[r].num_edges + 127) / 128; ++k) ht[t++] = TileDev{(int32_t)r, (int32_t)k};
   }
   char* w = static_cast<char*>(workspace);
@@ -253,14 +286,20 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   const RelDev* drel = reinterpret_cast<const RelDev*>(w);
   const TileDev* dtile = reinterpret_cast<const TileDev*>(w + rel_b);
   constexpr int lds = 32768 + 4 * 8192;
-  if (dtype == PYG_BF16) {
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&rgcn_fused_kernel<true>), lds)) return rc_;
-    hipLaunchKernelGGL((rgcn_fused_kernel<true>), dim3((unsigned)tiles), dim3(256), lds, stream, drel, dtile,
-                       static_cast<const char*>(x), static_cast<char*>(out));
-  } else {
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&rgcn_fused_kernel<false>), lds)) return rc_;
-    hipLaunchKernelGGL((rgcn_fused_kernel<false>), dim3((unsigned)tiles), dim3(256), lds, stream, drel, dtile,
-                       static_cast<const char*>(x), static_cast<char*>(out));
+  int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
+  if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
+  const void* kern = dtype == PYG_BF16 ? (checked ? (const void*)&rgcn_fused_kernel<true, true> : (const void*)&rgcn_fused_kernel<true, false>)
+                                       : (checked ? (const void*)&rgcn_fused_kernel<false, true> : (const void*)&rgcn_fused_kernel<false, false>);
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+  char* outc = static_cast<char*>(out);
+  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev};
+  PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)tiles), dim3(256), args, lds, stream));
+  if (checked) {  // checked mode synchronises: the caller asked for a verdict
+    int host_err = 0;
+    PYG_HIP_CHECK(hipMemcpyAsync(&host_err, err_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (host_err == 1) return fail(PYG_HIP_ERR_INVALID, "rgcn_fused: gather index out of range");
+    if (host_err == 2) return fail(PYG_HIP_ERR_INVALID, "rgcn_fused: scatter index out of range");
   }
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;

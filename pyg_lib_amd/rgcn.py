@@ -98,3 +98,36 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
         soff.append(offsets[row_t])
     out = x.new_zeros(total, weight.size(-1))
     return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)
+
+
+def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str, Tensor], node_types: List[str],
+                            row_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
+                            edge_types: List[EdgeType], weight: Tensor, csc: bool = False) -> Tensor:
+    r"""The fused layer straight from the GLOBAL feature tables: what
+
+        x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
+        rgcn_layer_fused(x, type_offsets(...), row_dict, col_dict, edge_types, weight)
+
+    computes, without ``x``: every relation's rows are gathered through the sampler's ``node_id`` of its source type
+    inside the kernel (``pyg::rgcn_fused_tables``), so the per-batch feature matrix, the ATen gathers and the ``cat``
+    disappear.  Returns ``[sum_t len(node_id_dict[t]), F_out]`` in ``node_types`` order.  Same conditions (16-bit,
+    ``F = 128``, no gradients) as :func:`rgcn_layer_fused`; otherwise the chain above runs."""
+    off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
+    f0 = feat_dict[node_types[0]]
+    needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feat_dict.values()))
+    ok = f0.is_cuda and f0.dtype in (torch.bfloat16, torch.float16) and f0.size(1) == 128 and weight.size(-1) == 128
+    if needs_grad or not ok:
+        x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
+        return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc)
+    tidx = {t: i for i, t in enumerate(node_types)}
+    gather, scatter, gtype, soff = [], [], [], []
+    for et in edge_types:
+        src, _, dst = et
+        row_t, col_t = (src, dst) if not csc else (dst, src)
+        gather.append(col_dict[et])
+        scatter.append(row_dict[et])
+        gtype.append(tidx[col_t])
+        soff.append(off[row_t])
+    out = f0.new_zeros(off['__total__'], weight.size(-1))
+    return torch.ops.pyg.rgcn_fused_tables([feat_dict[t] for t in node_types], [node_id_dict[t] for t in node_types],
+                                           gtype, gather, scatter, soff, weight, out)

@@ -235,3 +235,111 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
         want.index_add_(0, row_d[(s, r, d)] + off[s], msg)
     scale = want.abs().max().item()
     assert scale > 1.0 and (y.double() - want).abs().max().item() <= 2e-2 * scale
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_fused_tables_equals_fused_on_the_materialised_features(dtype):
+    """pyg::rgcn_fused_tables gathers feat[type][node_id[type][col]] inside the kernel: it must produce the very bits
+    of pyg::rgcn_fused on x = cat(feat[t][node_id[t]]) when the features are integer valued (exact sums), and agree
+    within one rounding per run otherwise."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(5)
+    types = ['a', 'b', 'c']
+    n_global = {'a': 5000, 'b': 300, 'c': 20000}
+    n_local = {'a': 700, 'b': 64, 'c': 1500}
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'b'), ('b', 'r2', 'a'), ('c', 'r3', 'a'), ('a', 'r4', 'c'), ('c', 'r5', 'c')]
+    counts = [4000, 33, 1000, 0, 129, 9000]
+    F = 128
+    for integer in (True, False):
+        feat = {t: (torch.randint(-3, 4, (n_global[t], F), generator=g).float() if integer
+                    else torch.randn(n_global[t], F, generator=g)).to(dtype).cuda() for t in types}
+        node_id = {t: torch.randperm(n_global[t], generator=g)[:n_local[t]].cuda() for t in types}
+        if integer:
+            perm = torch.stack([torch.randperm(F, generator=g) for _ in ets])
+            W = torch.zeros(len(ets), F, F)
+            W[torch.arange(len(ets))[:, None], perm, torch.arange(F)[None, :]] = \
+                (torch.randint(0, 2, (len(ets), F), generator=g) * 2 - 1).float()
+        else:
+            W = torch.randn(len(ets), F, F, generator=g) / F ** 0.5
+        W = W.to(dtype).cuda()
+        rows, cols = {}, {}
+        for (s, r, d), c in zip(ets, counts):
+            rows[(s, r, d)] = torch.sort(torch.randint(0, min(n_local[s], 200), (c,), generator=g)).values.cuda()
+            cols[(s, r, d)] = torch.randint(0, n_local[d], (c,), generator=g).cuda()
+        y = rgcn.rgcn_layer_fused_tables(feat, node_id, types, rows, cols, ets, W)
+        x = torch.cat([feat[t][node_id[t]] for t in types])
+        off = rgcn.type_offsets(n_local, types)
+        y_ref = rgcn.rgcn_layer_fused(x, off, rows, cols, ets, W)
+        assert y.shape == y_ref.shape == (sum(n_local.values()), F)
+        if integer:
+            assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+            want = torch.zeros(y.shape, dtype=torch.float64)
+            for i, (s, r, d) in enumerate(ets):
+                want.index_add_(0, rows[(s, r, d)].cpu() + off[s], x[cols[(s, r, d)] + off[d]].double().cpu() @ W[i].double().cpu())
+            assert torch.equal(y.double().cpu(), want)
+        else:
+            scale = y_ref.float().abs().max().item()
+            assert (y.float() - y_ref.float()).abs().max().item() <= 2e-2 * scale
+
+
+def test_checked_mode_reports_bad_indices(monkeypatch):
+    """PYG_HIP_RGCN_CHECK=1: every gather / scatter index is validated on the device (unchecked, a bad index
+    is an out-of-bounds DMA read or a packed atomic into foreign memory); index tensors on another device are refused."""
+    import ctypes
+    import os.path as osp
+    from pyg_lib_amd import _capi
+    L = _capi.lib()
+    x = torch.randn(100, 128, device='cuda').bfloat16()
+    w = torch.randn(1, 128, 128, device='cuda').bfloat16()
+    out = torch.zeros(50, 128, device='cuda').bfloat16()
+    g = torch.randint(0, 100, (300,), device='cuda')
+    s = torch.sort(torch.randint(0, 50, (300,), device='cuda')).values
+
+    class Rel(ctypes.Structure):
+        _fields_ = [('gather_index', ctypes.c_void_p), ('scatter_index', ctypes.c_void_p), ('num_edges', ctypes.c_int64),
+                    ('gather_offset', ctypes.c_int64), ('scatter_offset', ctypes.c_int64), ('weight', ctypes.c_void_p),
+                    ('x', ctypes.c_void_p), ('gather_map', ctypes.c_void_p), ('x_rows', ctypes.c_int64),
+                    ('gather_map_len', ctypes.c_int64)]
+
+    L.pyg_hip_rgcn_fused_workspace_size.restype = ctypes.c_size_t
+    L.pyg_hip_rgcn_fused_workspace_size.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.pyg_hip_rgcn_fused.restype = ctypes.c_int
+    L.pyg_hip_rgcn_fused.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    ws_bytes = L.pyg_hip_rgcn_fused_workspace_size(1, 300)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(gi, si, checked):
+        rel = Rel(gi.data_ptr(), si.data_ptr(), gi.numel(), 0, 0, w.data_ptr(), None, None, 0, 0)
+        return L.pyg_hip_rgcn_fused(3, x.data_ptr(), 100, ctypes.byref(rel), 1, out.data_ptr(), 50, 128, 128, checked,
+                                    ws.data_ptr(), ws_bytes, stream)
+
+    assert call(g, s, 1) == 0
+    bad_g = g.clone()
+    bad_g[17] = 100
+    assert call(bad_g, s, 1) != 0 and b'gather index out of range' in L.pyg_hip_last_error()
+    bad_s = s.clone()
+    bad_s[-1] = 50
+    assert call(g, bad_s, 1) != 0 and b'scatter index out of range' in L.pyg_hip_last_error()
+    with pytest.raises(RuntimeError, match='must live on the device'):
+        torch.ops.pyg.rgcn_fused(x, [g.cpu()], [s], [0], [0], w, out)
+
+
+def test_fused_layer_falls_back_to_the_differentiable_chain_under_autograd():
+    """ADVICE r2: pyg::rgcn_fused has no autograd formula; with gradients being recorded the wrapper must take the
+    three-op chain, so a training loop that switches to it keeps learning."""
+    from pyg_lib_amd import rgcn
+    ets = [('a', 'x', 'a')]
+    x = torch.randn(50, 128, device='cuda').bfloat16().requires_grad_()
+    w = (torch.randn(1, 128, 128, device='cuda') / 11).bfloat16().requires_grad_()
+    r = torch.sort(torch.randint(0, 50, (300,), device='cuda')).values
+    c = torch.randint(0, 50, (300,), device='cuda')
+    off = rgcn.type_offsets({'a': 50}, ['a'])
+    y = rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w)
+    y.float().sum().backward()
+    assert x.grad is not None and w.grad is not None and x.grad.abs().sum() > 0 and w.grad.abs().sum() > 0
+    with torch.no_grad():
+        y2 = rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w)
+    assert (y.float() - y2.float()).abs().max() <= 3e-2 * y2.float().abs().max()
