@@ -51,7 +51,9 @@ struct RelDev {
 
 struct TileDev {
   int32_t rel;
-  int32_t tile;  // 128-edge tile index inside the relation
+  int32_t tile;   // first 128-edge tile (index inside the relation) of this workgroup's run
+  int32_t count;  // consecutive tiles of the relation it processes with ONE copy of W_r in LDS
+  int32_t pad;
 };
 
 template <bool BF16>
@@ -103,11 +105,9 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
   const TileDev td = tiles[blockIdx.x];
   const RelDev rel = rels[td.rel];
-  const int64_t e0 = (int64_t)td.tile * 128 + wave * 32;   // first edge of this wave inside the relation
-  const int64_t left = rel.num_edges - e0;
-  const int nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
   char* xs = smem + 32768 + wave * 8192;
-  // W: this wave's 8 blocks of 4 k-rows, 16-byte chunks permuted inside a block
+  // W: this wave's 8 blocks of 4 k-rows, 16-byte chunks permuted inside a block (once per workgroup: its `count` tiles
+  // are of one relation -- with one tile per workgroup the weight copy was as many bytes as the gathered rows)
   {
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
@@ -119,98 +119,103 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
                                        (LDSV*)(smem + kb * 1024), 16, 0, 0);
     }
   }
-  // indices of this wave's edges: lane l < 32 holds edge l (rows past the end repeat the last valid edge)
-  int64_t gi = 0, si = 0;
-  if (nrows > 0) {
-    const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
-    gi = rel.gather_index[e];
-    if (rel.gather_map) {  // double indirection done here: the gathered feature matrix never exists
-      if (CHECK && (gi < 0 || gi >= rel.map_len)) {
-        *error = 1;
-        gi = 0;
-      }
-      gi = rel.gather_map[gi];
-    } else {
-      gi += rel.gather_offset;
-    }
-    si = rel.scatter_index[e] + rel.scatter_offset;
-    if (CHECK) {
-      if (gi < 0 || gi >= rel.x_rows) {
-        *error = 1;
-        gi = 0;
-      }
-      if (si < 0 || si >= out_rows) {
-        *error = 2;
-        si = 0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int p = i * 64 + lane;
-      const int r = p >> 4, cs = p & 15;
-      const int c = cs ^ (r & 15);
-      const int64_t row = __shfl(gi, r);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rel.x + row * 256 + c * 16),
-                                       (LDSV*)(xs + i * 1024), 16, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (nrows == 0) return;
   const int q = lane & 15, grp16 = lane >> 4;
   const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
-  f32x16 acc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < NI; ++s) {
-    const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((NI * h + s) ^ (xl & 15))) * 16);
-    u32x4 wa[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + tt * 256));
-      const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + tt * 256));
-      wa[tt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt] = mfma16<BF16>(wa[tt], xa, acc[tt]);
-  }
-  // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
-#pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      u32x4 pk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[tt][8 * j + 2 * i], acc[tt][8 * j + 2 * i + 1]);
-      const int c = 8 * h + 2 * tt + j;
-      *reinterpret_cast<u32x4*>(xs + (xl * 16 + (c ^ (xl & 15))) * 16) = pk;
-    }
-  }
-  // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row
   const int cch = lane >> 2, cdw = lane & 3;
-  float s0 = 0.f, s1 = 0.f;
-  int64_t cur = __shfl(si, 0);
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    if (r < nrows) {
-      const int64_t d = __shfl(si, r);
-      if (d != cur) {  // wave-uniform
-        atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
-        s0 = 0.f;
-        s1 = 0.f;
-        cur = d;
+  for (int tt = 0; tt < td.count; ++tt) {
+    const int64_t e0 = (int64_t)(td.tile + tt) * 128 + wave * 32;   // first edge of this wave inside the relation
+    const int64_t left = rel.num_edges - e0;
+    const int nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+    // indices of this wave's edges: lane l < 32 holds edge l (rows past the end repeat the last valid edge)
+    int64_t gi = 0, si = 0;
+    if (nrows > 0) {
+      const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
+      gi = rel.gather_index[e];
+      if (rel.gather_map) {  // double indirection done here: the gathered feature matrix never exists
+        if (CHECK && (gi < 0 || gi >= rel.map_len)) {
+          *error = 1;
+          gi = 0;
+        }
+        gi = rel.gather_map[gi];
+      } else {
+        gi += rel.gather_offset;
       }
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
-      float a, b;
-      unpack2<BF16>(v, &a, &b);
-      s0 += a;
-      s1 += b;
+      si = rel.scatter_index[e] + rel.scatter_offset;
+      if (CHECK) {
+        if (gi < 0 || gi >= rel.x_rows) {
+          *error = 1;
+          gi = 0;
+        }
+        if (si < 0 || si >= out_rows) {
+          *error = 2;
+          si = 0;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p >> 4, cs = p & 15;
+        const int c = cs ^ (r & 15);
+        const int64_t row = __shfl(gi, r);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rel.x + row * 256 + c * 16),
+                                         (LDSV*)(xs + i * 1024), 16, 0, 0);
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tt == 0) __syncthreads();  // everybody's part of W has landed; the X stage is private to the wave
+    if (nrows == 0) continue;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((NI * h + s) ^ (xl & 15))) * 16);
+      u32x4 wa[NT];
+#pragma unroll
+      for (int t4 = 0; t4 < NT; ++t4) {
+        const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + t4 * 256));
+        const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + t4 * 256));
+        wa[t4] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < NT; ++t4) acc[t4] = mfma16<BF16>(wa[t4], xa, acc[t4]);
+    }
+    // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
+#pragma unroll
+    for (int t4 = 0; t4 < NT; ++t4) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[t4][8 * j + 2 * i], acc[t4][8 * j + 2 * i + 1]);
+        const int c = 8 * h + 2 * t4 + j;
+        *reinterpret_cast<u32x4*>(xs + (xl * 16 + (c ^ (xl & 15))) * 16) = pk;
+      }
+    }
+    // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row
+    float s0 = 0.f, s1 = 0.f;
+    int64_t cur = __shfl(si, 0);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if (r < nrows) {
+        const int64_t d = __shfl(si, r);
+        if (d != cur) {  // wave-uniform
+          atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+          s0 = 0.f;
+          s1 = 0.f;
+          cur = d;
+        }
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
+        float a, b;
+        unpack2<BF16>(v, &a, &b);
+        s0 += a;
+        s1 += b;
+      }
+    }
+    atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
   }
-  atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
 }
 
 }  // namespace
@@ -238,13 +243,19 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   if (R == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
   int64_t E = 0, tiles = 0;
+  for (int64_t r = 0; r < R; ++r) E += std::max<int64_t>(rels[r].num_edges, 0);
+  // tiles per workgroup: W_r (32 KB) is copied once per workgroup, so runs of a few tiles amortise it -- as long as
+  // the grid still has several workgroups for each of the chip's 2 x CUs slots
+  const int64_t slots = 2 * (int64_t)device_info().num_cus;
+  const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (4 * slots)));
+  E = 0;
   for (int64_t r = 0; r < R; ++r) {
     PYG_HIP_REQUIRE(rels[r].num_edges >= 0, "rgcn_fused: negative edge count");
     PYG_HIP_REQUIRE(rels[r].num_edges == 0 || (rels[r].gather_index && rels[r].scatter_index && rels[r].weight),
                     "rgcn_fused: NULL tensor in relation %lld", (long long)r);
     PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(rels[r].weight) & 15) == 0, "rgcn_fused: weights must be 16-byte aligned");
     E += rels[r].num_edges;
-    tiles += (rels[r].num_edges + 127) / 128;
+    tiles += ((rels[r].num_edges + 127) / 128 + run - 1) / run;
   }
   if (E == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
@@ -277,7 +288,8 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     hr[r].gather_map = rels[r].gather_map;
     hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
     hr[r].map_len = rels[r].gather_map_len;
-    for (int64_t k = 0; k < (rels[r].num_edges + 127) / 128; ++k) ht[t++] = TileDev{(int32_t)r, (int32_t)k};
+    const int64_t nt = (rels[r].num_edges + 127) / 128;
+    for (int64_t k = 0; k < nt; k += run) ht[t++] = TileDev{(int32_t)r, (int32_t)k, (int32_t)std::min<int64_t>(run, nt - k), 0};
   }
   char* w = static_cast<char*>(workspace);
   PYG_HIP_CHECK(hipMemcpyAsync(w, staged, rel_b + tile_b, hipMemcpyHostToDevice, stream));

@@ -328,7 +328,11 @@ struct RangeCtx {
   }
   // the same for a node whose batch id is known directly (a node that is being appended: sampler_fused.h)
   __device__ void eval(int64_t v, int64_t batch_id, int64_t count, int64_t* rs_out, int64_t* re_out) const {
-    int64_t rs = rowptr[v], re = rowptr[v + 1];
+    narrow(rowptr[v], rowptr[v + 1], batch_id, count, rs_out, re_out);
+  }
+  // the temporal narrowing of a row whose bounds [rs, re) the caller has already fetched (sampler_fused.h issues the
+  // row-bound loads of all items and consumers back to back before it looks at any of them)
+  __device__ void narrow(int64_t rs, int64_t re, int64_t batch_id, int64_t count, int64_t* rs_out, int64_t* re_out) const {
     if (time && re > rs && count != 0) {
       const int64_t st = seed_times[batch_id];
       int64_t lo = rs, hi = re;  // first p in [rs, re) with st < time(p)
@@ -936,7 +940,8 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
 }
 
 
-constexpr int kNeedSlow = 1000;  // internal: repeat the call in the synchronising mode
+constexpr int kNeedSlow = 1000;    // internal: repeat the call in the synchronising mode
+constexpr int kNeedQueued = 1001;  // internal: repeat the call through round 2's fully queued chain (no fused chain)
 
 // which driver the calling thread's last sampler call ran (pyg_hip_sampler_last_mode): tests and benchmarks assert it
 thread_local const char* g_sampler_mode = "none";
@@ -951,7 +956,7 @@ struct RelState {
 int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* rels,
                 int num_seed_sets, const pyg_hip_seed_set* seeds, const int64_t* const* node_time,
                 int temporal_last, int L, int csc, int replace, int disjoint, int return_edge_id,
-                Ctx& c, pyg_hip_sample_result* res, bool allow_fast) {
+                Ctx& c, pyg_hip_sample_result* res, bool allow_fast, bool allow_fused = true) {
   hipStream_t stream = c.stream;
   std::vector<NodeSet> ns((size_t)num_node_types);
   std::vector<RelState> rs((size_t)num_relations);
@@ -1059,7 +1064,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     }
   }
 
-  const bool fused = fast && fused_eligible(rels, num_relations, num_node_types, num_seed_sets, csc, L, eb);
+  const bool fused = fast && allow_fused && fused_eligible(rels, num_relations, num_node_types, num_seed_sets, csc, L, eb);
   std::vector<FusedSeed> fseeds;
 
   // The word generation (side stream).  Round 2's chain queues it behind the seed kernels (which do not need it; its
@@ -2294,6 +2299,15 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   const bool allow_fast = getenv("PYG_HIP_SAMPLER_SYNC_MODE") == nullptr;  // experiment / test knob
   int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time,
                        temporal_last, L, csc, replace, disjoint, return_edge_id, c, result, allow_fast);
+  if (rc == kNeedQueued) {
+    // the fused chain met a sampled row of degree >= 2^16 (draws wider than 16 bits): nothing was handed out and the
+    // caller's engine is untouched -- start over through round 2's chain, which carries the general RNG tables
+    c.quiesce_side();
+    (void)hipStreamSynchronize(c.stream);
+    c.release_all();
+    rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time, temporal_last, L,
+                     csc, replace, disjoint, return_edge_id, c, result, allow_fast, false);
+  }
   if (rc == kNeedSlow) {
     // a hub row made its draws wider than the speculation assumed: nothing was handed out and the
     // caller's engine is untouched -- start over in the synchronising mode

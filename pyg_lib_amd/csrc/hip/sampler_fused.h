@@ -24,7 +24,8 @@
 // Same outputs, same generator advance: every test of the fully queued mode runs through this path
 // (PYG_HIP_SAMPLER_FUSED=0 selects round 2's chain for A/B timing).
 
-constexpr int kMaxCons = 4;         // relations of the next hop that expand one node type; more: round 2's chain
+constexpr int kMaxCons = 3;         // relations of the next hop that expand one node type; more: round 2's chain
+                                    // (with 4 the reduce pass holds 64 row bounds per thread and spills)
 constexpr int kMaxParts = 8;        // relations queued per hop; more: round 2's chain
 constexpr int kMaxLaunchCons = 12;  // consumers over all node types of one scan launch
 
@@ -45,7 +46,10 @@ struct FusedOp {
     r.rank = a.rank + b.rank;
     if constexpr (NC > 0) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) r.next[c] = CountOp()(a.next[c], b.next[c]);
+      for (int c = 0; c < NC; ++c) {  // 16-bit draws only (see consumer_count_bounds): tables compose by addition
+        r.next[c].edges = a.next[c].edges + b.next[c].edges;
+        r.next[c].tab = a.next[c].tab + (b.next[c].tab & ~kPureTab);
+      }
     }
     return r;
   }
@@ -66,6 +70,8 @@ struct FTables {
   int64_t* dup;       // [T]: seed positions that repeat an earlier seed (list positions - distinct nodes)
   CountAgg* tot;      // [L * R]: emitted edges + RNG transition table of (hop, relation)
   int32_t* overflow;  // [L * R]: 0 ok, 1 this relation lacked random words, 2 something before it did
+  int32_t* wide;      // [1]: a sampled row of degree >= 2^16 was met (draws wider than 16 bits): the chain stops, the
+                      // call is repeated through round 2's chain, which carries the general transition tables
   int64_t word0;      // engine position at the start of the call
   int units0;
   int L, R, T;
@@ -172,26 +178,14 @@ __device__ __forceinline__ T uniform_record(const T* p) {
   return out;
 }
 
-// RNG table of a row of degree >= 2^16 (draws of 32 / 64 bits): rare, kept out of line -- inlined it cost the scan
-// kernels ~150 registers
-__device__ __noinline__ RngTab wide_draw_table(int64_t deg, int64_t count, int replace) {
-  RngTab t = rng_identity();
-  if (replace) {
-    const int n = need_units((u64)deg);
-    for (int64_t j = 0; j < count; ++j) rng_push_draw(t, n);
-  } else {
-    for (int64_t j = deg - count; j < deg; ++j) rng_push_draw(t, need_units((u64)(j + 1)));
-  }
-  return t;
-}
-
 // (edges, RNG table) of node v for one consumer: CountLoad::operator() for a node that is being appended
-__device__ __forceinline__ CountAgg consumer_count(const FConsumer& cs, int64_t v, int64_t batch_id) {
+__device__ __forceinline__ CountAgg consumer_count_bounds(const FConsumer& cs, int64_t rs0, int64_t re0, int64_t batch_id,
+                                                          int32_t* wide) {
   CountAgg r;
   r.tab = rng_identity();
   r.edges = 0;
   int64_t rs, re;
-  cs.range.eval(v, batch_id, cs.count, &rs, &re);
+  cs.range.narrow(rs0, re0, batch_id, cs.count, &rs, &re);
   const int64_t deg = re - rs;
   const int64_t count = cs.count;
   if (deg <= 0 || count == 0) return r;
@@ -200,22 +194,18 @@ __device__ __forceinline__ CountAgg consumer_count(const FConsumer& cs, int64_t 
     return r;
   }
   r.edges = count;
-  if ((u64)deg < (1ull << 16)) r.tab = tab_pure(count);
-  else r.tab = wide_draw_table(deg, count, cs.replace);
+  r.tab = tab_pure(count);
+  // a draw wider than 16 bits needs the packed 5-state tables (and more words than the speculation generated): not
+  // carried here -- with them inlined the scan kernels needed 250 registers + 2.4 KB of scratch per lane
+  if ((u64)deg >= (1ull << 16)) *wide = 1;
   return r;
 }
 
-// the same, never inlined: apply only needs it for the rare "general" cache entries
-__device__ __noinline__ CountAgg consumer_count_slow(const FConsumer& cs, int64_t v, int64_t batch_id) {
-  return consumer_count(cs, v, batch_id);
-}
-
 // cache word of an emission: bit 0 = first occurrence; consumer c at bits [1 + 15 c, 16 + 15 c): edges (7 bits, <= 64),
-// bit 7 = sampled (count 16-bit draws), bit 8 = "general" (a draw wider than 16 bits: the table is recomputed)
+// bit 7 = sampled (count 16-bit draws)
 __device__ __forceinline__ u64 cons_encode(const CountAgg& a) {
   u64 code = (u64)a.edges & 0x7f;
-  if (!tab_is_pure(a.tab)) code |= 1u << 8;
-  else if (a.tab != rng_identity()) code |= 1u << 7;
+  if (a.tab != rng_identity()) code |= 1u << 7;
   return code;
 }
 
@@ -262,13 +252,24 @@ __device__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
       }
     }
     T v[kScanItems];
+    int64_t r0[kScanItems][NC > 0 ? NC : 1], r1[kScanItems][NC > 0 ? NC : 1];
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
       vv[k] = pt.h.vals[sl[k]];
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          r0[k][c] = cons.c[c].range.rowptr[nd[k]];
+          r1[k][c] = cons.c[c].range.rowptr[nd[k] + 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
       v[k] = Op::identity();
       if constexpr (NC > 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[k].next[c] = consumer_count(cons.c[c], nd[k], bt[k]);
+        for (int c = 0; c < NC; ++c) v[k].next[c] = consumer_count_bounds(cons.c[c], r0[k][c], r1[k][c], bt[k], L.tb.wide);
       }
     }
 #pragma unroll
@@ -323,12 +324,8 @@ __device__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int n
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const u64 code = (word[k] >> (1 + 15 * c)) & 0x7fff;
-          if (code & (1u << 8)) {  // a row of degree >= 2^16 with a wide draw: rebuild its table
-            v[k].next[c] = consumer_count_slow(cons.c[c], pt.e_node[p], pt.e_batch ? pt.e_batch[p] : 0);
-          } else {
-            v[k].next[c].edges = (int64_t)(code & 0x7f);
-            v[k].next[c].tab = (code & (1u << 7)) ? tab_pure(cons.c[c].count) : rng_identity();
-          }
+          v[k].next[c].edges = (int64_t)(code & 0x7f);
+          v[k].next[c].tab = (code & (1u << 7)) ? tab_pure(cons.c[c].count) : rng_identity();
         }
       }
     }
@@ -414,7 +411,7 @@ __device__ __forceinline__ FResolved fused_resolve(const FTables& tb, int ell, i
   }
   const int64_t begin = ell > 0 ? tb.size_at[(ell - 1) * tb.T + t_src] : 0;
   const int64_t end = tb.size_at[ell * tb.T + t_src];
-  bool aborted = __ballot(over_in != 0) != 0;
+  bool aborted = __ballot(over_in != 0) != 0 || *tb.wide != 0;
   bool own = false;
   int64_t w = tb.word0;
   int u = tb.units0;
@@ -509,6 +506,7 @@ __global__ void fused_init_kernel(FTables tb) {
     tb.tot[i] = CountOp::identity();
     tb.overflow[i] = 0;
   }
+  if (i == 0) *tb.wide = 0;
 }
 
 // launch kind 1: [finalize of the previous hop | sampling of this hop] (+ the engine fold behind the last hop)
@@ -591,6 +589,5 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
   PYG_FUSED_CASE(1)
   PYG_FUSED_CASE(2)
   PYG_FUSED_CASE(3)
-  PYG_FUSED_CASE(4)
 #undef PYG_FUSED_CASE
 }

@@ -95,7 +95,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   }
 
   // ---- arena: staging mirror + per-step scratch ----
-  const size_t tb_bytes = align_up(8 * (size_t)(L + 1) * T + 8 * (size_t)T + sizeof(CountAgg) * (size_t)L * R + 4 * (size_t)L * R, 16);
+  const size_t tb_bytes =
+      align_up(8 * (size_t)(L + 1) * T + 8 * (size_t)T + sizeof(CountAgg) * (size_t)L * R + 4 * (size_t)L * R + 4, 16);
   size_t arena_bytes = align_up(tb_bytes, 256);
   for (const FusedSeed& fsd : fseeds) {
     const size_t nc = fused_consumers(rels, R, csc, eb, 0, L, fsd.type).size();
@@ -127,6 +128,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   tb.dup = tb.size_at + (size_t)(L + 1) * T;
   tb.tot = reinterpret_cast<CountAgg*>(tb.dup + T);
   tb.overflow = reinterpret_cast<int32_t*>(tb.tot + (size_t)L * R);
+  tb.wide = tb.overflow + (size_t)L * R;
   tb.word0 = rng.word;
   tb.units0 = rng.units;
   tb.L = L;
@@ -181,9 +183,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       PYG_FUSED_LAUNCH(0)
       PYG_FUSED_LAUNCH(1)
       PYG_FUSED_LAUNCH(2)
-      PYG_FUSED_LAUNCH(3)
       default:
-        PYG_FUSED_LAUNCH(4)
+        PYG_FUSED_LAUNCH(3)
     }
 #undef PYG_FUSED_LAUNCH
     PYG_HIP_CHECK(hipGetLastError());
@@ -444,6 +445,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   const int64_t* h_size = reinterpret_cast<const int64_t*>(tables_host);
   const CountAgg* h_tot = reinterpret_cast<const CountAgg*>(tables_host + 8 * (size_t)(L + 1) * T + 8 * (size_t)T);
   const int32_t* h_over = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(h_tot) + sizeof(CountAgg) * (size_t)L * R);
+  if (h_over[(size_t)L * R]) return kNeedQueued;  // a sampled row of degree >= 2^16: round 2's chain carries the wide tables
   for (int k = 0; k < L * R; ++k)
     if (h_over[k]) return kNeedSlow;
   for (int ell = 0; ell < L; ++ell) {
