@@ -30,6 +30,32 @@ indptr[1:] = torch.bincount(sidx, minlength=N).cumsum(0)
 for _ in range(3):
     ops.segment_sum_csr(src, indptr)
     ops.scatter_max(src, index, 0, None, N)
+del src, feat, index, sidx, indptr
+# round 3: general-shape grouped matmul (mixed K), hetero sample (fused chain) + R-GCN layer from the global tables
+import math
+import bench_legs
+from pyg_lib_amd import rgcn
+g2 = torch.Generator().manual_seed(0)
+rows = torch.exp(torch.rand(64, generator=g2) * (math.log(262144.0) - math.log(1024.0)) + math.log(1024.0))
+rows = (rows / rows.sum() * 6_000_000).long().tolist()
+kk = [(100, 128, 256, 768)[i % 4] for i in range(64)]
+xs = [torch.randn(r, k, device=dev, generator=gd).bfloat16() for r, k in zip(rows, kk)]
+ws = [(torch.randn(k, 128, device=dev, generator=gd) / k ** 0.5).bfloat16() for k in kk]
+for _ in range(3):
+    ops.grouped_matmul(xs, ws)
+del xs, ws
+types = list(bench_legs.MAG_SIZES)
+ets = [(s_, r_, d_) for s_, r_, d_, _ in bench_legs.MAG_RELS]
+rp, cl = bench_legs.make_mag_graph(dev)
+featm = {t: torch.randn(bench_legs.MAG_SIZES[t], 128, device=dev, generator=gd).bfloat16() for t in types}
+Wm = (torch.randn(len(ets), 128, 128, device=dev, generator=gd) / 11).bfloat16()
+fan = {e: [15, 10] for e in ets}
+for b in range(4):
+    sd = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=g)[:1024].to(dev)
+    out = sampler.hetero_neighbor_sample(rp, cl, {'paper': sd}, fan)
+    rgcn.rgcn_layer_fused_tables(featm, out[2], types, out[0], out[1], ets, Wm)
+torch.cuda.synchronize()
+del rp, cl, featm
 keys = torch.randint(0, 2_449_029, (100_000_000,), device=dev, generator=gd)
 for _ in range(3):
     ops.index_sort(keys, 2_449_029)

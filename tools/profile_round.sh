@@ -10,7 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_bench -o bench -
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_mm_$c -o p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sampler --no-legs > $R/pmc_mm_$c.log 2>&1
 done
-python /root/repo/bench.py --dtype f32 --no-sampler > $R/bench_f32.json 2> $R/bench_f32.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_ops_$c -o p -- python /root/repo/tools/pmc_targets.py > $R/pmc_ops_$c.log 2>&1
 done
