@@ -167,16 +167,29 @@ def leg_grouped_mixed(device, rows_total=6_000_000, G=64, ks=(100, 128, 256, 768
 
 
 def leg_segment_matmul_f32(device, make_c2, iters=5):
-    """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  AI = 32 flop/B is above the fp32 ridge
-    (157 TF / 8 TB/s = 20), so the bound is the dense fp32 MFMA rate (v_mfma_f32_32x32x2_f32)."""
+    """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  Default arithmetic: split-bf16 (three bf16
+    terms per operand, six bf16 MFMAs per 16 k, fp32 accumulation -- products exact to 2^-26, see
+    `pyg_hip_matmul_set_f32_split`), whose matrix time is 2.7x below that of v_mfma_f32_32x32x2_f32: the bound is HBM.
+    `exact` = the same call through the fp32 MFMA kernel (AI = 32 flop/B is above the fp32 ridge of 157 TF / 8 TB/s = 20,
+    so that one is bound by the fp32 matrix rate)."""
     from pyg_lib_amd import ops
     x, ptr, w, (N, B, F) = make_c2(device, 0, 1, torch.float32, 1.0)
-    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
-    tf = 2.0 * N * F * F / (ms * 1e-3) / 1e12
     alg = 4 * (2 * N * F + B * F * F) + 8 * (B + 1)
+    flop = 2.0 * N * F * F
+    try:
+        ops.set_matmul_f32_split(False)
+        ms_e = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
+        kern_e = ops.matmul_last_variant()
+    finally:
+        ops.set_matmul_f32_split(True)
+    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
+    tf, tf_e = flop / (ms * 1e-3) / 1e12, flop / (ms_e * 1e-3) / 1e12
+    gbps = alg / (ms * 1e-3) / 1e9
     return dict(workload='segment_matmul C2 in fp32 (154 relations, 21,111,007 rows, F=128)', kernel=ops.matmul_last_variant(),
-                bound='mfma', achieved=round(tf, 1), peak=157.0, unit='TFLOP/s', frac=round(tf / 157.0, 4),
-                kernel_ms=round(ms, 4), alg_bytes=int(alg), hbm_GBps=round(alg / (ms * 1e-3) / 1e9, 1))
+                bound='hbm', achieved=round(gbps, 1), peak=8000.0, unit='GB/s', frac=round(gbps / 8000.0, 4),
+                kernel_ms=round(ms, 4), alg_bytes=int(alg), tflops=round(tf, 1), vs_f32_mfma_peak=round(tf / 157.0, 4),
+                exact=dict(kernel=kern_e, bound='mfma', achieved=round(tf_e, 1), peak=157.0, unit='TFLOP/s',
+                           frac=round(tf_e / 157.0, 4), kernel_ms=round(ms_e, 4)))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -130,6 +130,17 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
 PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
 
+/* Arithmetic of the fp32 K = 128, M % 128 == 0 segment/grouped matmul (process wide):
+ *   1  (default) split-bf16: every fp32 operand is split, round-to-nearest, into three bf16 terms (8 + 8 + 8 significant
+ *      bits; the split is exact to 2^-27 relative) and the six leading cross products run on v_mfma_f32_32x32x16_bf16
+ *      with fp32 accumulation.  Dropped terms: 2^-26 |x||w| per product at most, unbiased -- below the rounding unit
+ *      of an fp32 multiply-add.  2.7x less matrix time than mode 0: the kernel is HBM-bound.
+ *   0  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): bound by the fp32 matrix rate (157 TFLOP/s).
+ * Both meet the fp32 parity bar (relative Frobenius error <= 1e-5 against float64; measured ~1e-7 either way).  The
+ * reference multiplies fp32 on CUTLASS SIMT FMAs, or on TF32 tensor ops (10-bit mantissa products) when torch's
+ * float32 matmul precision allows (ops/cuda/matmul_kernel.cu:157-262); both modes here are at full fp32 accuracy. */
+PYG_HIP_API void pyg_hip_matmul_set_f32_split(int on);
+
 /*
  * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]
  * (input [N, K], grad_out [N, M], grad_other [B, K, M]; fp32 accumulation, one rounding).  Replaces the

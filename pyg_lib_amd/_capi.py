@@ -54,6 +54,8 @@ def lib() -> ctypes.CDLL:
         L.pyg_hip_matmul_last_variant.restype = c.c_char_p
         L.pyg_hip_matmul_set_schedule.restype = None
         L.pyg_hip_matmul_set_schedule.argtypes = [c.c_int]
+        L.pyg_hip_matmul_set_f32_split.restype = None
+        L.pyg_hip_matmul_set_f32_split.argtypes = [c.c_int]
         L.pyg_hip_segment_matmul.restype = c.c_int
         L.pyg_hip_segment_matmul.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p,
                                              c.c_void_p, c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p,

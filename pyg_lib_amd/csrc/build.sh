@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libpyg_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden -I../../include -Ihip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden -I../../include -Ihip $EXTRA_HIPCC_FLAGS"
 mkdir -p build
 objs=""
 pids=""

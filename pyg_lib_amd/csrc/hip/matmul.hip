@@ -326,11 +326,33 @@ __device__ __forceinline__ u32x4 pack_chunk(float, const float* v) {
   return o;
 }
 
+// Split-bf16 helpers (fp32 K = M-chunk = 128 kernel, FLAGS bit 2).  split2(a, b): round-to-nearest-even bf16 pair of
+// (a, b) packed {a low, b high} (v_cvt_pk_bf16_f32), and the exact fp32 residuals a - bf16(a), b - bf16(b).
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t split2(float& a, float& b) {
+  const f32x2_hw v = {a, b};
+  const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+  a -= __builtin_bit_cast(float, p << 16);
+  b -= __builtin_bit_cast(float, p & 0xffff0000u);
+  return p;
+}
+
 template <typename T, int K, int MC, int NW, int FLAGS = 3>
 __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
     const DevGroup* __restrict__ descs, const int32_t* __restrict__ tile_start, int B, int chunk, int ncol) {
   constexpr bool NT_LOAD = (FLAGS & 1) != 0;
   constexpr bool NT_STORE = (FLAGS & 2) != 0;
+  // FLAGS bit 2 (fp32 only): split-bf16 arithmetic -- x = hi + mid + lo with 8 significant bits each (24 in all), W alike;
+  // (round to nearest at every split, so |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x| and the residual left is <= 2^-27 |x|);
+  // the six products of weight 2^0, 2^-9, 2^-9, 2^-18, 2^-18, 2^-18 go through v_mfma_f32_32x32x16_bf16 with fp32
+  // accumulation (the two of weight 2^-27 and the one of 2^-36 are dropped: 1.5e-8 of |x||w| per product, unbiased --
+  // a quarter of the fp32 rounding unit, so the result is as close to the exact product as the fp32 MFMA's).
+  // Six 32-cycle MFMAs per 16 k instead of eight 64-cycle v_mfma_f32_32x32x2_f32: 2.7x less matrix time, which makes
+  // fp32 F = 128 (AI = 32 flop/B) HBM-bound instead of bound by the fp32 matrix rate.  W^T lives in LDS as three
+  // bf16 planes [MC][K] (16-byte chunks XOR-swizzled with the row, no pad: 3 x 32 KB + 4 x 16 KB of stages = 160 KB).
+  constexpr bool X3 = (FLAGS & 4) != 0;
+  static_assert(!X3 || (std::is_same<T, float>::value && K == 128 && MC == 128), "split-bf16: fp32, K = MC = 128");
   constexpr int SZ = Elem<T>::kSize;
   constexpr int EPC = Elem<T>::kPerChunk;  // elements per 16-byte chunk
   constexpr int NT = MC / 32;
@@ -344,7 +366,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   constexpr int NO = CPO / 2;
   constexpr int OM = (CPO < 16 ? CPO : 16) - 1;
   constexpr int STAGE = 32 * 16 * (CPR > CPO ? CPR : CPO);  // bytes per wave
-  constexpr int WBYTES = MC * LDW;
+  constexpr int PLANE = MC * K * 2;  // X3: one bf16 plane of W^T
+  constexpr int WBYTES = X3 ? 3 * PLANE : MC * LDW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -399,12 +422,21 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   int staged = -1;  // group whose weight is in LDS
 
   const int crow0 = (MC / 2) * ((x >> 2) & 1) + 4 * (x >> 3) + (x & 3);
-  const char* wfrag = smem + crow0 * LDW + (K / 2) * h * SZ;
+  const char* wfrag = X3 ? smem + crow0 * (K * 2) : smem + crow0 * LDW + (K / 2) * h * SZ;
 
   // per-lane constants of the coalesced <-> fragment re-shaping
   // load/store side: position p = i*64 + lane -> row r = p / CPR, slot c' = p % CPR
   // fragment side:   lane (x, h) reads row x, chunk c at slot c ^ (x & XM)
   u32x4 xr[NI];
+  uint32_t xoff[8];  // X3: byte offset of this lane's 16 bytes of load i (< 8) inside a whole 32-row tile
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = i * 64 + lane;
+      const int r = p / CPR;
+      xoff[i] = (uint32_t)(r * (K * SZ) + (((p % CPR) ^ (r & XM)) * 16));
+    }
+  }
   DevGroup dn = descs[g];
   int64_t n_row0 = 0, n_rows = 0;
   bool n_valid = false;
@@ -418,7 +450,17 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
     n_rows = dn.rows;
     n_row0 = (int64_t)(t - tile_start[g]) * BM + wave * 32;
     n_valid = n_row0 < n_rows;
-    if (n_valid) {
+    if (X3 && n_valid && n_row0 + 32 <= n_rows) {
+      // whole tile: tile base + per-lane offsets computed once (loads i and i + 8 lie 16 rows = 8 KiB apart)
+      const char* base = dn.a + n_row0 * (K * SZ);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        typedef __attribute__((address_space(1))) u32x4 GU32x4;
+        const GU32x4* src = (const GU32x4*)(base + xoff[i & 7] + (i >> 3) * 8192);
+        if (ncol == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=a"(xr[i]) : "v"(src) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xr[i]) : "v"(src) : "memory");
+      }
+    } else if (n_valid) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int p = i * 64 + lane;
@@ -432,7 +474,16 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         const GU32x4* src = (const GU32x4*)(dn.a + row * (K * SZ) + c * 16);
         // with several column-chunk readers the tile must STAY in L2 for the others: no streaming hint (with it
         // C4's X came from HBM 1.86 times, PMC FETCH_SIZE; without it 1.01 times)
-        xr[i] = (NT_LOAD && ncol == 1) ? __builtin_nontemporal_load(src) : *src;
+        if constexpr (X3) {
+          // through inline asm: the wait is placed by hand (x3_wait) -- the compiler cannot count the stores that were
+          // issued after these loads across the loop's branches and would wait for them too (vmcnt retires in order)
+          // (into AGPRs: the one wave per SIMD has 192 of them idle, and a value the compiler believes defined must
+          // not be moved before its load has landed -- under VGPR pressure it would be)
+          if (ncol == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=a"(xr[i]) : "v"(src) : "memory");
+          else asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(xr[i]) : "v"(src) : "memory");
+        } else {
+          xr[i] = (NT_LOAD && ncol == 1) ? __builtin_nontemporal_load(src) : *src;
+        }
       }
     }
   };
@@ -450,18 +501,65 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
   int cg = g;
   int64_t row0 = n_row0, rows = n_rows;
   bool valid = n_valid;
+  // X3: `stores_younger` = exactly the NO unpredicated stores of a whole tile were issued after the loads now awaited
+  bool stores_younger = false;
+  auto x3_wait = [&]() {
+    if constexpr (X3) {
+      static_assert(!X3 || NO == 16, "the hand-placed wait counts the 16 stores of a 32 x 128 fp32 tile");
+      if (stores_younger && !(FLAGS & 16)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  x3_wait();
   if (valid) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
   }
   if (t0 + 1 < t1) prefetch(t0 + 1);
 
+  constexpr bool TIMED = (FLAGS & 32) != 0;  // experiment builds: per-phase cycle sums of workgroup 0 / wave 0
+  uint64_t ph[6] = {0, 0, 0, 0, 0, 0}, stamp = 0;
+  auto tick = [&](int i) {
+    if constexpr (TIMED) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      ph[i] += now - stamp;
+      stamp = now;
+    }
+  };
+  if constexpr (TIMED) stamp = __builtin_amdgcn_s_memtime();
   for (int t = t0; t < t1; ++t) {
     if (cg != staged) {
       __syncthreads();
       const char* w = d.w;
       const int M = d.m;
-      if (!d.trans) {
+      if constexpr (X3) {
+        // fp32 W[k][m] (or W^T[m][k]) -> three bf16 planes [m][k]: element (m, k) at plane + m * 256 + (((k >> 3) ^ (m & 15)) * 16)
+        // + (k & 7) * 2
+        constexpr int CW = 32;  // 16-byte chunks per source row (K = MC = 128 floats)
+        for (int idx = tid; idx < 128 * CW; idx += NW * 64) {
+          const int r = idx / CW;
+          const int c4 = (idx - r * CW) * 4;
+          const int64_t src = !d.trans ? ((int64_t)r * M + col0 + c4) : ((int64_t)(col0 + r) * K + c4);
+          // (whole-vector bit_cast: __builtin_bit_cast(float, v[e]) on a vector element reads element 0, clang 19)
+          const f32x4 v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(w + src * 4));
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            float f0 = v[e], f1 = v[e + 1];
+            const uint32_t ph = split2(f0, f1);
+            const uint32_t pm = split2(f0, f1);
+            const uint32_t pl = split2(f0, f1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int k = !d.trans ? r : c4 + e + u;
+              const int mm = !d.trans ? c4 + e + u : r;
+              char* dst = smem + mm * (K * 2) + (((k >> 3) ^ (mm & 15)) * 16) + (k & 7) * 2;
+              *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(ph >> (16 * u));
+              *reinterpret_cast<uint16_t*>(dst + PLANE) = (uint16_t)(pm >> (16 * u));
+              *reinterpret_cast<uint16_t*>(dst + 2 * PLANE) = (uint16_t)(pl >> (16 * u));
+            }
+          }
+        }
+      } else if (!d.trans) {
         constexpr int CW = MC / EPC;
         for (int idx = tid; idx < K * CW; idx += NW * 64) {
           const int k = idx / CW;
@@ -495,6 +593,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       staged = cg;
     }
 
+    tick(0);  // bookkeeping + W staging
     u32x4 ov[NO];
     if (valid) {
       f32x16 acc[NT];
@@ -503,6 +602,68 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+      if constexpr (X3) {
+        // 16 units of 12 MFMAs: unit u = (K-step s = u >> 1, column blocks 2 (u & 1), +1).  The W fragments of unit u + 1
+        // and (even units) the X chunks of step s + 1 are read from LDS while unit u's MFMAs run; odd units also split
+        // those X chunks.  One wave per SIMD: nothing else hides an LDS round trip.
+        const int wsw = crow0 & 15;  // rows crow0 + 16 tt share it
+        const char* xrow = stage + x * (CPR * 16);
+        const int xs = x & XM;
+        u32x4 wq[2][6], qx[2], xf[2][3];
+        auto read_w = [&](int u, u32x4 (&wv)[6]) {
+          const int s8 = u >> 1;
+          const char* wr = wfrag + (2 * (u & 1)) * 16 * (K * 2) + (((8 * h + s8) ^ wsw) * 16);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wv[3 * j + pl] = *reinterpret_cast<const u32x4*>(wr + j * 16 * (K * 2) + pl * PLANE);
+        };
+        auto read_x = [&](int s8) {
+          // lane (x, h): k = 64 h + 8 s8 + e, e = 0 ... 7: two 16-byte fp32 chunks of its half row
+          const int c = NI * h + 2 * s8;
+          qx[0] = *reinterpret_cast<const u32x4*>(xrow + ((c ^ xs) * 16));
+          qx[1] = *reinterpret_cast<const u32x4*>(xrow + (((c + 1) ^ xs) * 16));
+        };
+        auto split_x = [&](u32x4 (&o)[3]) {
+          const f32x4 f0 = __builtin_bit_cast(f32x4, qx[0]), f1 = __builtin_bit_cast(f32x4, qx[1]);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            float a = p < 2 ? f0[2 * p] : f1[2 * p - 4];
+            float b2 = p < 2 ? f0[2 * p + 1] : f1[2 * p - 3];
+            o[0][p] = split2(a, b2);
+            o[1][p] = split2(a, b2);
+            o[2][p] = split2(a, b2);
+          }
+        };
+        read_x(0);
+        read_w(0, wq[0]);
+        split_x(xf[0]);
+#pragma unroll
+        for (int u = 0; u < ((FLAGS & 8) ? 1 : 16); ++u) {
+          const int s8 = u >> 1;
+          // this unit's fragments were issued a unit ago: wait for them here, not (with the reads below) at the MFMAs
+          asm volatile("" : "+v"(wq[u & 1][5]));
+          __builtin_amdgcn_sched_barrier(0);
+          if (u + 1 < 16) read_w(u + 1, wq[(u + 1) & 1]);
+          if ((u & 1) == 0 && s8 + 1 < 8) read_x(s8 + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const u32x4(&xv)[3] = xf[s8 & 1];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int tt = 2 * (u & 1) + j;
+            const u32x4 wh = wq[u & 1][3 * j], wm = wq[u & 1][3 * j + 1], wl = wq[u & 1][3 * j + 2];
+            // smallest terms first
+            acc[tt] = mfma_chunk(bf16_t{}, wl, xv[0], acc[tt]);
+            acc[tt] = mfma_chunk(bf16_t{}, wh, xv[2], acc[tt]);
+            acc[tt] = mfma_chunk(bf16_t{}, wm, xv[1], acc[tt]);
+            acc[tt] = mfma_chunk(bf16_t{}, wm, xv[0], acc[tt]);
+            acc[tt] = mfma_chunk(bf16_t{}, wh, xv[1], acc[tt]);
+            acc[tt] = mfma_chunk(bf16_t{}, wh, xv[0], acc[tt]);
+          }
+          if ((u & 1) == 1 && s8 + 1 < 8) split_x(xf[(s8 + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       // fragments of step s+1 are read from LDS while the MFMAs of step s run
       u32x4 xa = *reinterpret_cast<const u32x4*>(stage + (x * CPR + ((NI * h) ^ (x & XM))) * 16);
       u32x4 wa[NT];
@@ -547,6 +708,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         }
       }
 
+      }  // !X3
+      tick(1);  // K loop
       // epilogue: fragment order -> swizzled stage -> row order (ov)
       const T* bp = d.bias ? reinterpret_cast<const T*>(d.bias) + col0 + (MC / 2) * h : nullptr;
 #pragma unroll
@@ -568,6 +731,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
     }
 
+    tick(2);  // epilogue through LDS
     // stage the next tile (its loads were issued one tile ago) and issue the loads after it
     const DevGroup d_out = d;
     const int64_t row0_out = row0, rows_out = rows;
@@ -578,14 +742,33 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
       row0 = n_row0;
       rows = n_rows;
       valid = n_valid;
+      x3_wait();
+      tick(3);  // waiting for the X loads
       if (valid) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(stage + (i * 64 + lane) * 16) = xr[i];
       }
       if (t + 2 < t1) prefetch(t + 2);
     }
+    tick(4);  // staging X + issuing the next loads
+    stores_younger = false;
 
-    if (valid_out) {
+    if (X3 && valid_out && row0_out + 32 <= rows_out) {
+      // whole tile: NO unpredicated stores, which the next x3_wait leaves in flight
+      const int M = d_out.m;
+      char* obase = d_out.c + (row0_out * M + col0) * SZ;
+#pragma unroll
+      for (int i = 0; i < NO; ++i) {
+        const int p = i * 64 + lane;
+        const int r = p / CPO;
+        const int c = (p % CPO) ^ (r & OM);
+        typedef __attribute__((address_space(1))) u32x4 GU32x4;
+        GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + c * 16);
+        if ((FLAGS & 16) && ov[i][0] != 0x12345u) continue;
+        if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
+      }
+      stores_younger = true;
+    } else if (valid_out) {
       const int M = d_out.m;
       char* obase = d_out.c + (row0_out * M + col0) * SZ;
 #pragma unroll
@@ -594,13 +777,20 @@ __global__ __launch_bounds__(NW * 64) void mfma_rows_lds_kernel(
         const int r = p / CPO;
         const int cs = p % CPO;
         const int c = cs ^ (r & OM);
-        if (row0_out + r < rows_out) {
+        if (row0_out + r < rows_out && (!(FLAGS & 16) || ov[i][0] == 0x12345u)) {
           typedef __attribute__((address_space(1))) u32x4 GU32x4;
           GU32x4* dst = (GU32x4*)(obase + (int64_t)r * M * SZ + c * 16);
           if (NT_STORE) __builtin_nontemporal_store(ov[i], dst); else *dst = ov[i];
         }
       }
     }
+    tick(5);  // stores
+  }
+  if constexpr (TIMED) {
+    if (blockIdx.x == 0 && tid == 0)
+      printf("x3 phases (cycles, %d tiles): book %llu kloop %llu epilogue %llu loadwait %llu stage+issue %llu stores %llu\n", nloc,
+             (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3],
+             (unsigned long long)ph[4], (unsigned long long)ph[5]);
   }
 }
 
@@ -2136,6 +2326,8 @@ thread_local const char* g_last_variant = "";
 struct ProfPair { hipEvent_t a, b; };
 // tile schedule of the 16-bit K = M = 128 kernels: 0 = automatic, 1 = contiguous ranges, 2 = cyclic
 int g_schedule = 0;
+// fp32 K = 128, M % 128 == 0: 1 = split-bf16 arithmetic (default), 0 = v_mfma_f32_32x32x2_f32
+int g_f32_split = 1;
 thread_local bool g_prof_on = false;
 thread_local std::vector<ProfPair> g_prof;
 
@@ -2400,6 +2592,40 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
       return PYG_HIP_OK;
     }
   }
+  if constexpr (Elem<T>::kSize == 4) {
+    if (K == 128 && M % 128 == 0 && g_f32_split) {
+      // fp32 through three bf16 planes per operand (mfma_rows_lds_kernel FLAGS bit 2): HBM-bound instead of bound by
+      // the fp32 matrix rate
+      g_last_variant = "mfma_f32_k128_mc128_x3";
+      constexpr int NW = 4;
+      constexpr int lds = 3 * 128 * 128 * 2 + NW * 32 * 128 * 4;  // 96 KB of W planes + 4 x 16 KB stages = 160 KB
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_lds_kernel<T, 128, 128, NW, 7>);
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+      const DeviceInfo& di = device_info();
+      const int ncol = M / 128;
+      int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles_upper, 1), (int64_t)di.num_cus);
+      if (ncol > 1) gx = std::max<int64_t>(8, (std::min<int64_t>(gx, (int64_t)di.num_cus / ncol) + 7) / 8 * 8);
+      ProfScope prof(stream);
+#ifdef PYG_HIP_MM_EXPERIMENTS
+      if (const char* e = getenv("PYG_HIP_MM_X3DBG")) {
+        const int dbg = atoi(e);
+        const void* dk = dbg == 8 ? (const void*)&mfma_rows_lds_kernel<T, 128, 128, NW, 15>
+                       : dbg == 16 ? (const void*)&mfma_rows_lds_kernel<T, 128, 128, NW, 23>
+                       : dbg == 32 ? (const void*)&mfma_rows_lds_kernel<T, 128, 128, NW, 39>
+                                   : (const void*)&mfma_rows_lds_kernel<T, 128, 128, NW, 31>;
+        PYG_HIP_CHECK(hipFuncSetAttribute(dk, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int chunk0 = 0, nc = ncol;
+        void* args[] = {(void*)&w.descs, (void*)&w.tile_start, (void*)&B, (void*)&chunk0, (void*)&nc};
+        PYG_HIP_CHECK(hipLaunchKernel(dk, dim3((unsigned)(gx * ncol)), dim3(NW * 64), args, lds, stream));
+        return PYG_HIP_OK;
+      }
+#endif
+      hipLaunchKernelGGL((mfma_rows_lds_kernel<T, 128, 128, NW, 7>), dim3((unsigned)(gx * ncol)), dim3(NW * 64), lds, stream,
+                         w.descs, w.tile_start, B, 0, ncol);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
+  }
   int MC = (M % 128 == 0 && K <= 256) ? 128 : (M % 64 == 0 ? 64 : 32);
   if constexpr (Elem<T>::kSize == 2) {
     // 16-bit, K <= 128: one workgroup can own 256 columns (weights + stages fit), X is read by one CU only
@@ -2519,6 +2745,8 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
 void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 5) ? mode : 0; }
+
+void pyg_hip_matmul_set_f32_split(int on) { g_f32_split = on != 0; }
 
 void pyg_hip_profile_enable(int on) {
   g_prof_on = on != 0;

@@ -360,6 +360,14 @@ def set_matmul_schedule(mode: str = 'auto') -> None:
                                              'naive': 5}[mode])
 
 
+def set_matmul_f32_split(on: bool = True) -> None:
+    """fp32 ``K = 128, M % 128 == 0`` matmul arithmetic: ``True`` (default) multiplies through three bf16 planes per
+    operand (6 bf16 MFMAs per 16 k, fp32 accumulation; products exact to 2^-26 relative, i.e. below the fp32 rounding
+    unit -- HBM-bound), ``False`` through ``v_mfma_f32_32x32x2_f32`` (bound by the fp32 matrix rate).  Process wide; see
+    ``pyg_hip_matmul_set_f32_split`` in include/pyg_hip.h."""
+    _capi.lib().pyg_hip_matmul_set_f32_split(1 if on else 0)
+
+
 __all__ = [
     'grouped_matmul',
     'segment_matmul',

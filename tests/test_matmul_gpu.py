@@ -73,14 +73,48 @@ def test_ragged_bf16_with_empty_segments(ptr_on_device):
                                rtol=2 ** -6, atol=1e-6)
 
 
-def test_ragged_fp32_mfma_1e5():
+@pytest.mark.parametrize('split', [True, False])
+def test_ragged_fp32_mfma_1e5(split):
+    """Both fp32 arithmetic modes (split-bf16, the default, and v_mfma_f32_32x32x2_f32) against the reference's recorded
+    fp32 output and the oracle: north_star's 1e-5 bar, met with two orders of magnitude to spare."""
     x = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_x']))
     w = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_w']))
     ptr = torch.from_numpy(GOLD['bf_ptr'])
-    out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
-    assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128'
-    assert rel_fro(out.cpu().numpy(), GOLD['f32r_out']) <= 1e-5
-    assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(x.numpy(), GOLD['bf_ptr'], w.numpy())) <= 1e-5
+    try:
+        ops.set_matmul_f32_split(split)
+        out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
+    finally:
+        ops.set_matmul_f32_split(True)
+    assert ops.matmul_last_variant() == ('mfma_f32_k128_mc128_x3' if split else 'mfma_f32_k128_mc128')
+    assert rel_fro(out.cpu().numpy(), GOLD['f32r_out']) <= 1e-6
+    assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(x.numpy(), GOLD['bf_ptr'], w.numpy())) <= 1e-6
+
+
+def test_fp32_split_bf16_is_as_accurate_as_the_fp32_mfma():
+    """Full-mantissa inputs (the golden X / W above are bf16-valued, which the split represents in its first term alone),
+    wide dynamic range, transposed weight views, bias, ragged segments with empty and one-row groups: the split-bf16
+    result must be as close to the float64 product as the fp32 MFMA kernel's (measured 1.2e-7 vs 1.5e-7)."""
+    g = torch.Generator().manual_seed(11)
+    sizes = [700, 0, 1, 33, 4097, 128, 31]
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    for M, scale, trans in ((128, 1.0, False), (256, 1e4, False), (128, 1e-6, True), (384, 1.0, True)):
+        x = (torch.randn(n, 128, generator=g) * scale * torch.exp(3 * torch.randn(n, 1, generator=g))).to(DEV)
+        w = torch.randn(len(sizes), M, 128, generator=g).to(DEV).transpose(1, 2) if trans else \
+            torch.randn(len(sizes), 128, M, generator=g).to(DEV)
+        bias = torch.randn(len(sizes), M, generator=g).to(DEV) * scale
+        ref = torch.cat([x[int(ptr[b]):int(ptr[b + 1])].double() @ w[b].double() + bias[b].double() for b in range(len(sizes))])
+        errs = {}
+        for split in (True, False):
+            try:
+                ops.set_matmul_f32_split(split)
+                out = ops.segment_matmul(x, ptr, w, bias)
+            finally:
+                ops.set_matmul_f32_split(True)
+            assert ops.matmul_last_variant().endswith('_x3') == split
+            # row-wise: every row has its own scale
+            errs[split] = ((out.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
+        assert errs[True] <= 1e-6 and errs[True] <= 1.5 * errs[False] + 1e-9, errs
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])

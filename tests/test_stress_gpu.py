@@ -119,7 +119,35 @@ def test_fp32_pipelined_kernel_under_noise_is_reproducible(M):
             assert (out[s:e].double() - ref).norm() <= 1e-5 * max(ref.norm().item(), 1e-30)
         assert torch.isfinite(out).all()
 
-    _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w), check)
+    try:
+        ops.set_matmul_f32_split(False)  # M = 128 would otherwise take the split-bf16 kernel (next test)
+        _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w), check)
+    finally:
+        ops.set_matmul_f32_split(True)
+
+
+@pytest.mark.parametrize('M', [128, 256])
+def test_fp32_split_bf16_kernel_under_noise_is_reproducible(M):
+    """The split-bf16 kernel loads X through inline asm into AGPRs and waits with `vmcnt(16)` when exactly the 16
+    unpredicated stores of a whole tile are younger; ragged segments mix whole and partial tiles."""
+    rng = np.random.default_rng(M + 1)
+    g = torch.Generator(device=DEV).manual_seed(M + 1)
+    B = 61
+    ptr = ragged_ptr(rng, B, 0, 1500)
+    n = int(ptr[-1])
+    x = torch.randn(n, 128, device=DEV, generator=g)
+    w = torch.randn(B, 128, M, device=DEV, generator=g) / 11
+    bias = torch.randn(B, M, device=DEV, generator=g)
+
+    def check(out):
+        assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128_x3'
+        for b in (0, 7, 30, 60):
+            s, e = int(ptr[b]), int(ptr[b + 1])
+            ref = x[s:e].double() @ w[b].double() + bias[b].double()
+            assert (out[s:e].double() - ref).norm() <= 1e-6 * max(ref.norm().item(), 1e-30)
+        assert torch.isfinite(out).all()
+
+    _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
 
 
 def test_k256_two_blocks_per_wave_kernel_under_noise_is_reproducible():
