@@ -561,8 +561,10 @@ def test_full_size_c4_properties():
         w = torch.zeros(F, F, device=DEV)
         w[perm[i], torch.arange(F, device=DEV)] = sign[i] * scale[i]
         ws.append(w.bfloat16())
-    # both K = 256 kernels: 64 rows per wave (default) and 32 rows per wave ('contiguous' selects the older kernel)
-    for mode, variant in (('auto', 'mfma_bf16_k256_wide256r2'), ('contiguous', 'mfma_bf16_k256_wide256')):
+    # the three K = 256 kernels: W in registers (default), W in LDS with 64 rows per wave ('cyclic' selects it) and with
+    # 32 rows per wave ('contiguous')
+    for mode, variant in (('auto', 'mfma_bf16_k256_regw'), ('cyclic', 'mfma_bf16_k256_wide256r2'),
+                          ('contiguous', 'mfma_bf16_k256_wide256')):
         ops.set_matmul_schedule(mode)
         try:
             outs = ops.grouped_matmul(xs, ws)

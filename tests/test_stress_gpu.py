@@ -150,22 +150,62 @@ def test_fp32_split_bf16_kernel_under_noise_is_reproducible(M):
     _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
 
 
-def test_k256_two_blocks_per_wave_kernel_under_noise_is_reproducible():
+@pytest.mark.parametrize('mode,variant', [('auto', 'mfma_bf16_k256_regw'), ('cyclic', 'mfma_bf16_k256_wide256r2')])
+def test_k256_kernels_under_noise_are_reproducible(mode, variant):
+    """K = M = 256: the register-W kernel (X tiles and W chunks by LDS-DMA from inline asm, waits that name 8 - 20 younger
+    operations) and the 64-rows-per-wave kernel.  Many short relations: every workgroup changes relation often, with
+    and without bias, plain and transposed weights."""
     rng = np.random.default_rng(256)
     g = torch.Generator(device=DEV).manual_seed(256)
     rows = [int(v) for v in rng.integers(0, 9000, 96)]
     rows[3] = 0
     rows[10] = 1
+    rows[11] = 33
+    rows[12] = 32
+    rows[13] = 64
     xs = [torch.randn(r, 256, device=DEV, generator=g).bfloat16() for r in rows]
     ws = [(torch.randn(256, 256, device=DEV, generator=g) / 16).bfloat16() for _ in rows]
+    ws = [w.t().contiguous().t() if i % 3 == 1 else w for i, w in enumerate(ws)]  # every third one stored [M][K]
 
     def check(outs):
-        assert ops.matmul_last_variant() == 'mfma_bf16_k256_wide256r2'
-        for i in (0, 5, 50, 95):
+        assert ops.matmul_last_variant() == variant
+        for i in (0, 1, 5, 10, 11, 12, 13, 50, 95):
             ref = (xs[i].double() @ ws[i].double())
             torch.testing.assert_close(outs[i].double(), ref, rtol=2 ** -7, atol=2e-2)
 
-    _repeat_against_first(lambda: ops.grouped_matmul(xs, ws), check)
+    try:
+        ops.set_matmul_schedule(mode)
+        _repeat_against_first(lambda: ops.grouped_matmul(xs, ws), check)
+    finally:
+        ops.set_matmul_schedule('auto')
+
+
+def test_k256_register_w_kernel_matches_the_lds_w_kernel_bitwise():
+    """Random ragged partitions with bias (segment_matmul): the two kernels accumulate every output element in the
+    same k order, so their results must be the same bits -- empty relations, single rows, 32 / 33 / 64 / 65-row
+    relations (the empty and the partial second half of a 64-row tile), runs of tiny relations."""
+    rng = np.random.default_rng(77)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    for trial in range(12):
+        B = int(rng.integers(1, 120))
+        ptr = ragged_ptr(rng, B, trial % 4, 700)
+        n = int(ptr[-1])
+        if n == 0:
+            continue
+        dtype = torch.bfloat16 if trial % 3 else torch.float16
+        x = torch.randn(n, 256, device=DEV, generator=g).to(dtype)
+        w = (torch.randn(B, 256, 256, device=DEV, generator=g) / 16).to(dtype)
+        bias = torch.randn(B, 256, device=DEV, generator=g).to(dtype) if trial % 2 else None
+        try:
+            ops.set_matmul_schedule('cyclic')
+            ref = ops.segment_matmul(x, ptr, w, bias)
+            assert ops.matmul_last_variant().endswith('_k256_wide256r2')
+            ops.set_matmul_schedule('auto')
+            out = ops.segment_matmul(x, ptr, w, bias)
+            assert ops.matmul_last_variant().endswith('_k256_regw')
+        finally:
+            ops.set_matmul_schedule('auto')
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (trial, B, n)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
