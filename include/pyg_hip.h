@@ -127,6 +127,9 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  *   4  (measurement only) every bf16 / f16 / f32 call through the general-shape MFMA kernel (matmul_gen.hip), also the
  *      shapes that have a specialised kernel;
  *   5  (measurement only) every call through the one-thread-per-output kernel.
+ * 16-bit K = M = 256 (three kernels): 0 = W in registers + LDS-DMA item ring (mfma_rows_k256_regw_kernel, default),
+ * 1 = W in LDS, 32 rows per wave (mfma_rows_wide256_kernel), 2 / 3 = W in LDS, 64 rows per wave
+ * (mfma_rows_wide256r2_kernel).
  * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
 PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
 

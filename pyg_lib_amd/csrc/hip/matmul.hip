@@ -1869,8 +1869,9 @@ __global__ __launch_bounds__(256) void mfma_rows_wide256r2_kernel(const DevGroup
 // overlaps a wave's phases, and every MFMA needs an LDS read for W next to the one for X.  Here the roles are swapped:
 //   * wave w of a four-wave workgroup owns output columns 64 w ... 64 w + 63 and keeps its slice of W (256 k x 64
 //     columns = 32 KiB) as 32 MFMA A fragments in 128 registers.
-//   * LDS holds a ring of three 16 KiB buffers filled by LDS-DMA (two to three items in flight while one is consumed)
-//     plus one 16 KiB output tile: 64 KiB, so TWO workgroups share a CU (two waves per SIMD, from different
+//   * LDS holds a ring of two 16 KiB buffers filled by LDS-DMA (one to two items in flight while one is consumed; a
+//     third slot is slower, 1.29 instead of 1.23 ms on C4: the memory side prefers few bytes in flight per CU) plus one
+//     16 KiB output tile: 48.5 KiB; the 128 W registers allow TWO workgroups per CU (two waves per SIMD, from different
 //     workgroups: while one multiplies, the other stores / issues / waits at its barrier.  An eight-wave workgroup
 //     with 32 columns per wave ran all its waves in lock-step through its barriers: 6.7k cycles per 64 rows with the
 //     matrix pipes busy 2k of them).
@@ -1884,10 +1885,10 @@ __global__ __launch_bounds__(256) void mfma_rows_wide256r2_kernel(const DevGroup
 //   * an X item: every wave multiplies the whole tile against its columns (16 ds_read_b128 feed 32 MFMAs), writes its
 //     32 x 64 results into the output tile, and after a barrier stores 8 whole 512-byte rows of it.
 //   * two barriers per item: "item i has landed" (each wave has waited for its own four DMA instructions) and "the
-//     output tile is complete / ring buffer i % 3 is free".  The DMA goes through inline asm with hand-placed waits:
+//     output tile is complete / ring slot i % 2 is free".  The DMA goes through inline asm with hand-placed waits:
 //     every wave issues exactly 4 DMA per item and 4 stores per X item (rows behind a segment's end are clamped to its
 //     last row on both sides, items behind the workgroup's range re-read its last tile into a buffer nobody consumes),
-//     so the wait for item i names 8 + 4 x (X items among i - 3, i - 2, i - 1) younger operations that stay in flight.
+//     so the wait for item i names 4 + 4 x (X items among i - 2, i - 1) younger operations that stay in flight.
 //   * 16-byte chunk c of row r lies at slot (c & 16) | ((c ^ r) & 15) of its 512-byte LDS row (permuted on the source
 //     side of the DMA): conflict-free B-fragment reads; the output tile uses the same permutation.
 // A workgroup owns a contiguous range of 64-row tiles (tile_start3) and walks it in 32-row halves.
@@ -1897,7 +1898,12 @@ __device__ uint64_t g_regw_dbg[4 * 1024];  // per workgroup: start, end (10 ns t
 template <typename T>
 __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGroup* __restrict__ descs,
                                                                      const int32_t* __restrict__ tile_start, int B) {
-  constexpr int NB = 3;           // ring buffers
+#ifdef PYG_HIP_REGW_NB
+  constexpr int NB = PYG_HIP_REGW_NB;
+#else
+  constexpr int NB = 2;           // ring slots (C4: 1.23 ms with two, 1.29 ms with three -- few bytes in flight per CU)
+#endif
+  static_assert(NB == 2 || NB == 3, "wait_item names the younger operations of a 2- or 3-slot ring");
   constexpr int XB = 32 * 512;    // bytes per item / output tile
   typedef short v4i16 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(1))) u32x4 GU32x4;
@@ -2006,12 +2012,13 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
   int s1 = 0, s2 = 0, s3 = 0;  // stores issued with the last three items (0 or 4 each)
   int consumed = 0;            // items consumed so far (the first NB were issued back to back: wait for everything)
   auto wait_item = [&]() {
-    // item i has landed; younger: [stores of i - 3] [DMA i + 1] [stores of i - 2] [DMA i + 2] [stores of i - 1]
-    const int younger = consumed < NB ? 0 : 8 + s1 + s2 + s3;
+    // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
+    const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
     if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ++consumed;
   };
@@ -2026,6 +2033,12 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
   for (int b = 0; b < NB; ++b) issue_item();
   int gc = g_first;
   int u = 0;
+#ifdef PYG_HIP_MM_EXPERIMENTS
+  uint64_t ph[7] = {0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_amdgcn_s_memtime();
+#define REGW_TICK(i) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - stamp; stamp = now_; }
+#else
+#define REGW_TICK(i)
+#endif
   while (u < nloc) {
     const DevGroup* p = descs + gc;
     // ---- this relation's W ----
@@ -2098,7 +2111,9 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
       const int64_t row0 = (int64_t)(t - c_ts0) * 64 + 32 * (u & 1);
       const int64_t left = c_rows - row0;
       wait_item();
+      REGW_TICK(0)
       __syncthreads();
+      REGW_TICK(1)
       const char* xb = smem + cbuf * XB;
       f32x16 acc[2];
 #pragma unroll
@@ -2125,6 +2140,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      REGW_TICK(2)
       // results -> output tile: lane (n, h) holds columns 64 wave + 32 cb + 8 g + 4 h + (0 ... 3), g = 0 ... 3, of row n
       {
         char* orow = obuf + n * 512 + 8 * h;
@@ -2161,8 +2177,11 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
             *reinterpret_cast<u32x2*>(orow + (((8 * wave + 4 * cb + gq) ^ (n & 15)) * 16)) = o;
           }
       }
+      REGW_TICK(3)
       __syncthreads();
+      REGW_TICK(4)
       issue_item();
+      REGW_TICK(5)
       // always 4 stores (the waits count them): rows behind the segment end rewrite its last row with its own data.
       // An empty second half (`left` <= 0) has multiplied the segment's last row 32 times (issue_item clamps to it)
       // and stores it again: LDS row 0, global row `last` < 0 relative to the half.
@@ -2180,12 +2199,18 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
         }
       }
       retire(4);
+      REGW_TICK(6)
     }
     if (u < nloc) {
       do ++gc; while (t_begin + (u >> 1) >= tile_start[gc + 1]);
     }
   }
 #ifdef PYG_HIP_MM_EXPERIMENTS
+  if (threadIdx.x == 0 && blockIdx.x == 0 && ph[2] != 1)
+    printf("regw phases (cycles, %d halves): wait %llu bar1 %llu mfma %llu epi %llu bar2 %llu issue %llu stores %llu\n", nloc,
+           (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3],
+           (unsigned long long)ph[4], (unsigned long long)ph[5], (unsigned long long)ph[6]);
+#undef REGW_TICK
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     g_regw_dbg[4 * blockIdx.x] = real0;
     g_regw_dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -2870,7 +2895,12 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
         // W in registers, X tiles by LDS-DMA, two four-wave workgroups per CU
         snprintf(name, sizeof(name), "mfma_%s_k256_regw", tname);
         g_last_variant = name;
-        constexpr int lds3 = 4 * 32 * 512 + 512;  // a ring of three 16 KiB items + the output tile + the bias row = 64.5 KiB
+#ifdef PYG_HIP_REGW_NB
+        constexpr int lds3 = (PYG_HIP_REGW_NB + 1) * 32 * 512 + 512;
+#else
+        constexpr int lds3 = 3 * 32 * 512 + 512;  // a ring of two 16 KiB items + the output tile + the bias row = 48.5 KiB
+#endif
+  // a ring of three 16 KiB items + the output tile + the bias row = 64.5 KiB
         const void* kern3 = reinterpret_cast<const void*>(&mfma_rows_k256_regw_kernel<T>);
         if (int rc_ = ensure_dynamic_lds(kern3, lds3)) return rc_;
         const int64_t tiles3_upper = (w.rows_upper + kPairRows - 1) / kPairRows + B;
