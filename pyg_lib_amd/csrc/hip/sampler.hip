@@ -50,7 +50,19 @@ struct PhaseTimer {
     acc[k] += std::chrono::duration<double, std::micro>(now - last).count();
     last = now;
   }
+  // finer trace: (label, microseconds since the call started)
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double>> marks;
+  void mark(const char* what) {
+    if (!on) return;
+    marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
   ~PhaseTimer() {
+    if (on && !marks.empty()) {
+      fprintf(stderr, "[pyg_hip sampler] trace us:");
+      for (auto& m : marks) fprintf(stderr, " %s=%.0f", m.first, m.second);
+      fprintf(stderr, "\n");
+    }
     if (on)
       fprintf(stderr,
               "[pyg_hip sampler] us: seeds=%.0f count+scan+sync=%.0f rng=%.0f reserve=%.0f "
@@ -1009,6 +1021,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     *err_flag = 0;
   }
 
+  pt.mark("pinned");
   // device-resident engine position and node-list sizes (see the hop loop)
   ChainState* chain;
   TypeState* tstate;
@@ -1109,10 +1122,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
     return PYG_HIP_OK;
   };
+  pt.mark("bounds");
   if (fused) {
     int rc = start_rng();
     if (rc != PYG_HIP_OK) return rc;
   }
+  pt.mark("rng_started");
 
   // ---- seeds ----
   int64_t batch0 = 0;
@@ -1182,6 +1197,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   }
   for (int t = 0; t < num_node_types; ++t) nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size);
   pt.lap(0);
+  pt.mark("seeds_queued");
 
   // ---- hops ----
   // Engine position and node-list sizes live on the device (ChainState / TypeState): the relations of a

@@ -151,9 +151,19 @@ struct FFinalRec {  // local ids of relation e's emissions of hop l
 
 enum FRole { kRoleSample8 = 0, kRoleSample16, kRoleSample32, kRoleSample64, kRoleFinalize, kRoleFold };
 
+struct FFoldRec {  // what the fold role hands to the host, straight into pinned memory (no copies behind the last launch)
+  MtHandBack* hb;            // engine hand-back (nullptr: the caller's engine is not device-resident)
+  int64_t a0, generated32;   // mt_finish_chain_kernel's arguments
+  char* tables_host;         // copy of the write-once tables
+  const char* tables_dev;
+  int tables_bytes;
+  int pad;
+};
+
 struct FSampleLaunch {  // kernel argument of [finalize(l - 1) | sample(l)] (+ the engine fold behind the last hop)
   FTables tb;
   ChainState* chain;  // fold
+  FFoldRec fold;
   int n;
   int pad;
   int cum[2 * kMaxParts + 2];
@@ -162,6 +172,8 @@ struct FSampleLaunch {  // kernel argument of [finalize(l - 1) | sample(l)] (+ t
   FSampleRec s[kMaxParts];
   FFinalRec f[kMaxParts];
 };
+
+static_assert(sizeof(FSampleLaunch) <= 4096, "launch records travel in the kernel argument");
 
 // An argument record lies in device memory, where the old kernels had it as a kernel argument (= in SGPRs).  Read
 // dword-wise through v_readfirstlane the compiler knows every field is wave-uniform: addresses and branch conditions
@@ -533,7 +545,8 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
       if constexpr (GMAX >= 64) fused_sample<64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleFinalize: fused_finalize(L, L.f[idx], b); break;
-    default: {  // kRoleFold
+    default: {  // kRoleFold: the engine position, the tables and the engine hand-back, written where the host reads them
+      __shared__ int64_t fold_word;
       if (threadIdx.x == 0) {
         int64_t w = L.tb.word0;
         int u = L.tb.units0;
@@ -550,6 +563,37 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
         L.chain->word = w;
         L.chain->units = u;
         L.chain->abort = ab ? 1 : 0;
+        fold_word = w;
+      }
+      __syncthreads();
+      if (L.fold.tables_host) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.fold.tables_dev);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(L.fold.tables_host);
+        for (int i = threadIdx.x; i < L.fold.tables_bytes / 4; i += 256) dst[i] = src[i];
+      }
+      if (L.fold.hb) {  // mt_finish_chain_kernel (sampler_rng.hip), with the position just folded
+        MtHandBack* hb = L.fold.hb;
+        const uint32_t* out32 = reinterpret_cast<const uint32_t*>(words);
+        const int64_t a0 = L.fold.a0;
+        const int64_t n32 = (fold_word / 128 + 1) * 256;
+        int status = 0;
+        const int64_t mp = n32 - a0;
+        const int64_t k = (mp + 623) / 624;
+        if (n32 <= a0) status = 2;
+        else if (a0 + 624 * k > L.fold.generated32) status = 1;
+        if (status == 0) {
+          const int64_t o0 = a0 + 624 * (k - 1);
+          for (int i = threadIdx.x; i < 624; i += 256) hb->st.state[i] = mt_untemper(mt_output_at(out32, o0 + i));
+          if (threadIdx.x == 0) {
+            const int64_t nx = mp - 624 * (k - 1);
+            hb->st.next = (uint32_t)nx;
+            hb->st.left = (int32_t)(625 - nx);
+          }
+        }
+        if (threadIdx.x == 0) {
+          hb->n32 = n32;
+          hb->status = status;
+        }
       }
       break;
     }

@@ -114,8 +114,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     for (int t = 0; t < T; ++t)
       if (seg_tiles[(size_t)t]) arena_bytes += align_up((8 + 16 * (size_t)kMaxCons) * (seg_tiles[(size_t)t] + 1), 256);
   }
+  pt.mark("chain_entry");
   char* arena;
   PYG_ALLOC(arena, char*, c, arena_bytes);
+  pt.mark("arena");
   auto carve = [&](size_t bytes) {
     char* p = arena;
     arena += align_up(bytes, 256);
@@ -267,6 +269,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       pp.last = 1;
       add_part(sc, pp.h.ncons, nt, &pp);
     }
+    pt.mark("seedscan_built");
     int rc = launch_scan(sc, false);
     if (rc != PYG_HIP_OK) return rc;
     rc = launch_scan(sc, true);
@@ -387,7 +390,9 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     for (const Step& s : cur) spec_word += (s.Eb + 3) / 4 + 1;
     int rc = PYG_HIP_OK;
     if (!cur.empty()) {  // order the words this hop may read (16-bit draws, cumulative bound) before its sampling launch
+      pt.mark("hop_built");
       rc = rng_wait(c, rng, spec_word, &avail_blocks);
+      pt.mark("rng_waited");
       if (rc != PYG_HIP_OK) return rc;
     }
     rc = launch_sample(p1);
@@ -396,6 +401,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     if (rc != PYG_HIP_OK) return rc;
     add_part(p2, -1, 1, nullptr);  // carry block: apply pass only
     rc = launch_scan(p2, true);
+    pt.mark("hop_queued");
     if (rc != PYG_HIP_OK) return rc;
     steps_by_hop[(size_t)ell] = cur;
     prev_steps = cur;
@@ -411,33 +417,36 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       add_sample(fin, kRoleFinalize, (s.Eb + 255) / 256, nf++);
     }
     add_sample(fin, kRoleFold, 1, 0);
+    // The fold block also leaves the tables and the engine hand-back in pinned host memory (kernels write there
+    // directly, as they do for the temporal error flag): no launch and no copy behind the last hop.
+    fin.fold.tables_host = tables_host;
+    fin.fold.tables_dev = tb_dev;
+    fin.fold.tables_bytes = (int)tb_bytes;
+    *hand_back_out = nullptr;
+    if (rng.engine) {
+      const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
+      size_t k = 0;
+      while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
+      if (k < rng.marks.size()) {
+        hand_back_host->status = -1;
+        if (k >= rng.waited) {
+          PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
+          rng.waited = k + 1;
+        }
+        fin.fold.hb = hand_back_host;
+        fin.fold.a0 = rng.a0;
+        fin.fold.generated32 = rng.marks[k].upto32;
+        *hand_back_out = hand_back_host;
+      }
+    }
     int rc = launch_sample(fin);
     if (rc != PYG_HIP_OK) return rc;
   }
-  // the engine hand-back rides behind the last launch (its position was folded into `chain`)
-  *hand_back_out = nullptr;
-  if (rng.engine) {
-    const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
-    size_t k = 0;
-    while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
-    if (k < rng.marks.size()) {
-      MtHandBack* hb_dev;
-      PYG_ALLOC(hb_dev, MtHandBack*, c, sizeof(MtHandBack));
-      hand_back_host->status = -1;
-      if (k >= rng.waited) {
-        PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
-        rng.waited = k + 1;
-      }
-      int rc = rng_queue_hand_back(c, rng, chain, rng.marks[k].upto32, hb_dev);
-      if (rc != PYG_HIP_OK) return rc;
-      PYG_HIP_CHECK(hipMemcpyAsync(hand_back_host, hb_dev, sizeof(MtHandBack), hipMemcpyDeviceToHost, stream));
-      *hand_back_out = hand_back_host;
-    }
-  }
-  PYG_HIP_CHECK(hipMemcpyAsync(tables_host, tb_dev, tb_bytes, hipMemcpyDeviceToHost, stream));
   pt.lap(4);
+  pt.mark("all_queued");
   PYG_HIP_CHECK(hipStreamSynchronize(stream));
   pt.lap(5);
+  pt.mark("synced");
   if (err_flag)
     PYG_HIP_REQUIRE(*static_cast<volatile int*>(err_flag) == 0, "Found invalid non-sorted temporal neighborhood");
 

@@ -52,6 +52,18 @@ struct MtHandBack {
   int32_t pad;
 };
 
+// inverse of the engine's output tempering (raw state value from a tempered output)
+__device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
+  y ^= y >> 18;
+  y ^= (y << 15) & 0xefc60000u;
+  uint32_t t = y;  // invert y ^= (y << 7) & B: 7 known low bits grow by 7 per round
+  for (int i = 0; i < 4; ++i) t = y ^ ((t << 7) & 0x9d2c5680u);
+  y = t;
+  t = y;           // invert y ^= y >> 11
+  for (int i = 0; i < 2; ++i) t = y ^ (t >> 11);
+  return t;
+}
+
 // tempered engine output o of the device-generated stream (mt_emit's layout: little-endian u64 words, even
 // output = high half with bit 63 flipped)
 __device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ out32, int64_t o) {
