@@ -1916,8 +1916,15 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
 
   const int total = tile_start[B];
   const int G = (int)gridDim.x;
-  const int t_begin = (int)((int64_t)blockIdx.x * total / G);
-  const int nloc = 2 * ((int)((int64_t)(blockIdx.x + 1) * total / G) - t_begin);  // 32-row halves
+  // consecutive workgroup ids go to consecutive XCDs: XCD k takes the k-th eighth of the ranges, so the workgroups
+  // that share a relation's W (neighbours in tile order) share an L2
+#ifdef PYG_HIP_REGW_PLAIN_ORDER
+  const int bid = (int)blockIdx.x;
+#else
+  const int bid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+#endif
+  const int t_begin = (int)((int64_t)bid * total / G);
+  const int nloc = 2 * ((int)((int64_t)(bid + 1) * total / G) - t_begin);  // 32-row halves
   if (nloc <= 0) return;
 #ifdef PYG_HIP_MM_EXPERIMENTS
   const uint64_t real0 = __builtin_amdgcn_s_memrealtime();
@@ -2135,8 +2142,13 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
           __builtin_amdgcn_sched_barrier(0);
           if (s + 4 < 16) xf[s & 3] = *reinterpret_cast<const u32x4*>(xrow + (((2 * (s + 4) + h) ^ xsw) * 16));
           __builtin_amdgcn_sched_barrier(0);
+#ifdef PYG_HIP_REGW_NOMFMA  // timing experiment (wrong results): data movement only
+          acc[0][s] += __builtin_bit_cast(float, xa[0] ^ wreg[s][0][0]);
+          acc[1][s] += __builtin_bit_cast(float, xa[1] ^ wreg[s][1][1]);
+#else
           acc[0] = mfma_chunk(T{}, wreg[s][0], xa, acc[0]);
           acc[1] = mfma_chunk(T{}, wreg[s][1], xa, acc[1]);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -2219,6 +2231,362 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
   }
 #endif
 }
+
+// ---- fp32, K = M = 128 by split-bf16: W planes in registers, X tiles through the LDS-DMA ring ---------------------------
+// The split-bf16 arithmetic of mfma_rows_lds_kernel<float, ..., FLAGS bit 2> in the structure of the kernel above (that
+// kernel's 96 KiB of W planes fill the LDS: one wave per SIMD, nothing overlaps its phases).  Wave w of a four-wave
+// workgroup owns output columns 32 w ... 32 w + 31 and keeps the three bf16 terms of its slice of W (128 k x 32 columns)
+// as 8 x 3 MFMA A fragments in 96 registers.  The ring carries 16 KiB fp32 items: a 32-row X tile, or one of the FOUR
+// 32-k-row chunks of a new relation's W (every lane reads its column's 16 values per chunk and splits them).  An X
+// item: barrier, every wave splits 8 rows of the tile ONCE into three bf16 planes in LDS (round-to-nearest, 72 VALU
+// instructions per wave -- splitting inside the K loop would cost every wave the whole tile: 288 next to 48 MFMAs),
+// barrier, 8 K steps of 3 ds_read_b128 + 6 MFMAs, results into the fp32 output tile, barrier, 4 stores of whole rows.
+// LDS: ring 2 x 16 + output 16 + planes 24 KiB + bias = 72.5 KiB: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevGroup* __restrict__ descs,
+                                                                      const int32_t* __restrict__ tile_start, int B) {
+#ifdef PYG_HIP_F32RW_NB
+  constexpr int NB = PYG_HIP_F32RW_NB;
+#else
+  constexpr int NB = 2;           // ring slots
+#endif
+  static_assert(NB == 2 || NB == 3, "wait_item names the younger operations of a 2- or 3-slot ring");
+  constexpr int XB = 32 * 512;    // bytes per item / output tile
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int n = lane & 31, h = lane >> 5;
+  char* planes = smem + NB * XB;                   // 3 x [32 rows][128 k] bf16: the current X tile, split
+  float* bias_lds = reinterpret_cast<float*>(smem + NB * XB + 3 * 8192);  // the relation's 128 bias values
+
+  const int total = tile_start[B];
+  const int G = (int)gridDim.x;
+  // consecutive workgroup ids go to consecutive XCDs: XCD k takes the k-th eighth of the ranges, so the workgroups
+  // that share a relation's W (neighbours in tile order) share an L2
+  const int bid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_begin = (int)((int64_t)bid * total / G);
+  const int nloc = 2 * ((int)((int64_t)(bid + 1) * total / G) - t_begin);  // 32-row halves
+  if (nloc <= 0) return;
+  int g_first;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_begin) lo = mid; else hi = mid;
+    }
+    g_first = lo;
+  }
+
+  // ---- issue side: the item sequence is, per relation met in the range: [4 chunks of W unless transposed] [its halves]
+  int ig = g_first;                              // relation of the issue front
+  int iu = 0;                                    // next half-tile to issue
+  int ibuf = 0;                                  // ring slot of the next item
+  // fields of relation `ig` (kept in registers: every asm block clobbers "memory", so the compiler would re-read them)
+  const char* i_a;
+  const char* i_w;
+  int64_t i_rows;
+  int i_ts0, i_ts1, iw;                          // its first tile, the next relation's first tile, W chunks to issue
+  auto issue_enter = [&](int g) {
+    const DevGroup* p = descs + g;
+    i_a = p->a;
+    i_w = p->w;
+    i_rows = p->rows;
+    iw = p->trans ? 0 : 4;
+    i_ts0 = tile_start[g];
+    i_ts1 = tile_start[g + 1];
+  };
+  issue_enter(ig);
+  auto issue_item = [&]() {
+    const char* base;
+    int last = 31;
+    if (iw > 0) {
+      base = i_w + (4 - iw) * XB;
+      --iw;
+    } else {
+      const int uu = iu < nloc ? iu : nloc - 1;  // behind the range: the last half again (nobody consumes it)
+      const int t = t_begin + (uu >> 1);
+      int64_t row0 = (int64_t)(t - i_ts0) * 64 + 32 * (uu & 1);
+      int64_t left = i_rows - row0;
+      if (left <= 0) {  // the second half of a segment's last tile is empty: 32 times the segment's last row
+        row0 = i_rows - 1;
+        left = 1;
+      }
+      if (left < 32) last = (int)left - 1;
+      base = i_a + row0 * 512;
+      if (iu < nloc) {
+        ++iu;
+        if (iu < nloc && t_begin + (iu >> 1) >= i_ts1) {
+          do ++ig; while (t_begin + (iu >> 1) >= tile_start[ig + 1]);
+          issue_enter(ig);
+        }
+      }
+    }
+    const uint32_t lds = (uint32_t)(size_t)(smem + ibuf * XB + wave * 4096);
+    ibuf = ibuf + 1 == NB ? 0 : ibuf + 1;
+    uint32_t off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * wave + 2 * i + h;
+      const int c = (n & 16) | ((n ^ r) & 15);
+      const int rc = r > last ? last : r;
+      off[i] = (uint32_t)(rc * 512 + c * 16);
+    }
+    uint32_t sv;
+    asm volatile(
+        "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+        "s_mov_b32 m0, %[sv]"
+        : [sv] "=&s"(sv)
+        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
+        : "memory", "scc");
+  };
+
+  // ---- consume side ----
+  u32x4 wreg[8][3];  // A fragments of K step s: the hi / mid / lo bf16 terms of W[16 s + 8 h ... + 7][32 wave + n]
+  int cbuf = 0;                // ring slot of the item consumed next
+  int s1 = 0, s2 = 0, s3 = 0;  // stores issued with the last three items (0 or 4 each)
+  int consumed = 0;            // items consumed so far (the first NB were issued back to back: wait for everything)
+  auto wait_item = [&]() {
+    // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
+    const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
+    if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ++consumed;
+  };
+  auto retire = [&](int stores) {
+    s3 = s2;
+    s2 = s1;
+    s1 = stores;
+    cbuf = cbuf + 1 == NB ? 0 : cbuf + 1;
+  };
+
+#pragma unroll
+  for (int b = 0; b < NB; ++b) issue_item();
+  int gc = g_first;
+  int u = 0;
+#ifdef PYG_HIP_MM_EXPERIMENTS
+  uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_amdgcn_s_memtime();
+#define F32RW_TICK(i) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - stamp; stamp = now_; }
+#else
+#define F32RW_TICK(i)
+#endif
+  while (u < nloc) {
+    const DevGroup* p = descs + gc;
+    // ---- this relation's W ----
+    auto split8 = [&](const float (&f)[8], u32x4 (&o)[3]) {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        float a0 = f[2 * pr], a1 = f[2 * pr + 1];
+        o[0][pr] = split2(a0, a1);
+        o[1][pr] = split2(a0, a1);
+        o[2][pr] = split2(a0, a1);
+      }
+    };
+    if (p->trans) {
+      // `other` stored [M][K]: 8 consecutive k of output column 32 wave + n are 32 contiguous bytes
+      const char* wl = p->w + (32 * wave + n) * 512 + 32 * h;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + 64 * s), v1 = *reinterpret_cast<const f32x4*>(wl + 64 * s + 16);
+        const float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(f, wreg[s]);
+      }
+    } else {
+      // a chunk = k-rows 32 c ... 32 c + 31 of W as they lie in memory (512-byte rows, chunk-swizzled like an X tile);
+      // lane (n, h) picks column 32 wave + n of rows 16 s2 + 8 h + e
+      const int cc = 8 * wave + (n >> 2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        wait_item();
+        __syncthreads();
+        const char* wb = smem + cbuf * XB;
+#pragma unroll
+        for (int s2k = 0; s2k < 2; ++s2k) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int kk = 16 * s2k + 8 * h + e;
+            f[e] = *reinterpret_cast<const float*>(wb + kk * 512 + (((cc & 16) | ((cc ^ kk) & 15)) * 16) + 4 * (n & 3));
+          }
+          split8(f, wreg[2 * c + s2k]);
+        }
+        // the reads must have returned before the slot is refilled
+#pragma unroll
+        for (int s2k = 0; s2k < 2; ++s2k)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wreg[2 * c + s2k][pl]));
+        __syncthreads();
+        issue_item();
+        retire(0);
+      }
+    }
+    const bool has_bias = p->bias != nullptr;
+    if (has_bias) {
+      __syncthreads();  // everybody is done with the previous relation's bias
+      if (threadIdx.x < 128) bias_lds[threadIdx.x] = reinterpret_cast<const float*>(p->bias)[threadIdx.x];
+      __syncthreads();
+    }
+    // "use" what was loaded HERE with ordinary loads: the compiler's wait for them then sits in this (rare) path --
+    // left to the first MFMA of the tile loop it becomes an s_waitcnt vmcnt(0) in every iteration, which also drains
+    // the DMA and the stores the hand-placed waits leave in flight
+    if (p->trans) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wreg[s][pl]));
+    }
+    const int64_t c_rows = p->rows;
+    char* const c_out = p->c;
+    const int c_ts0 = tile_start[gc];
+
+    // ---- this relation's halves inside the range ----
+    const int t_rel_end = tile_start[gc + 1];
+    for (; u < nloc && t_begin + (u >> 1) < t_rel_end; ++u) {
+      const int t = t_begin + (u >> 1);
+      const int64_t row0 = (int64_t)(t - c_ts0) * 64 + 32 * (u & 1);
+      const int64_t left = c_rows - row0;
+      wait_item();
+      F32RW_TICK(0)
+      // no barrier here: a wave splits the 8 rows it has loaded itself, and nobody reads the planes any more (the
+      // previous item's last barrier lies behind everybody's K loop)
+      F32RW_TICK(1)
+      char* const xb = smem + cbuf * XB;
+      char* const obuf = xb;  // the fp32 tile is dead once it is split (barrier below): its slot takes the results
+      // split this wave's 8 rows of the tile into the three bf16 planes: lane l takes 16 consecutive floats of row
+      // 8 wave + (l >> 3) (two 16-byte bf16 chunks per plane; chunk c of row r lies at slot c ^ (r & 15) of its 256 bytes)
+      {
+        const int r = 8 * wave + (lane >> 3);
+        const int c0 = 4 * (lane & 7);
+        float f[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = c0 + j;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * 512 + (((cc & 16) | ((cc ^ r) & 15)) * 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[4 * j + e] = v[e];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          u32x4 o[3];
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            float a0 = f[8 * half + 2 * pr], a1 = f[8 * half + 2 * pr + 1];
+            o[0][pr] = split2(a0, a1);
+            o[1][pr] = split2(a0, a1);
+            o[2][pr] = split2(a0, a1);
+          }
+          const int bc = 2 * (lane & 7) + half;  // bf16 chunk of the row
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<u32x4*>(planes + pl * 8192 + r * 256 + ((bc ^ (r & 15)) * 16)) = o[pl];
+        }
+      }
+      F32RW_TICK(2)
+      __syncthreads();
+      F32RW_TICK(3)
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      {
+        // B fragments two K steps ahead of their MFMAs
+        const char* prow = planes + n * 256;
+        const int psw = n & 15;
+        u32x4 xf[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) xf[s][pl] = *reinterpret_cast<const u32x4*>(prow + pl * 8192 + (((2 * s + h) ^ psw) * 16));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const u32x4 xh = xf[s & 1][0], xm = xf[s & 1][1], xl = xf[s & 1][2];
+          asm volatile("" : "+v"(xf[s & 1][2]));  // the wait for these fragments goes here, in front of the next reads
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < 8) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              xf[s & 1][pl] = *reinterpret_cast<const u32x4*>(prow + pl * 8192 + (((2 * (s + 2) + h) ^ psw) * 16));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // smallest terms first
+          acc = mfma_chunk(bf16_t{}, wreg[s][2], xh, acc);
+          acc = mfma_chunk(bf16_t{}, wreg[s][0], xl, acc);
+          acc = mfma_chunk(bf16_t{}, wreg[s][1], xm, acc);
+          acc = mfma_chunk(bf16_t{}, wreg[s][1], xh, acc);
+          acc = mfma_chunk(bf16_t{}, wreg[s][0], xm, acc);
+          acc = mfma_chunk(bf16_t{}, wreg[s][0], xh, acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      F32RW_TICK(4)
+      // results -> output tile: lane (n, h) holds columns 32 wave + 8 g + 4 h + (0 ... 3), g = 0 ... 3, of row n
+      {
+        char* orow = obuf + n * 512;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
+          if (has_bias) v += *reinterpret_cast<const f32x4*>(bias_lds + 32 * wave + 8 * gq + 4 * h);
+          const int oc = 8 * wave + 2 * gq + h;  // 16-byte chunk of the output row
+          *reinterpret_cast<f32x4*>(orow + (((oc & 16) | ((oc ^ n) & 15)) * 16)) = v;
+        }
+      }
+      F32RW_TICK(5)
+      __syncthreads();
+      F32RW_TICK(6)
+      // always 4 stores (the waits count them): rows behind the segment end rewrite its last row with its own data.  An
+      // empty second half (`left` <= 0) has multiplied the segment's last row 32 times (issue_item clamps to it) and
+      // stores it again: LDS row 0, global row `last` < 0 relative to the half.  The results are read out of the ring
+      // slot BEFORE its refill is issued: a wave's DMA writes exactly the 8 rows it reads here.
+      {
+        const int last = left < 32 ? (int)left - 1 : 31;
+        char* cbase = c_out + row0 * 512;
+        u32x4 ov[4];
+        int64_t goff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 8 * wave + 2 * i + h;
+          const int rg = r > last ? last : r;
+          const int rl = rg < 0 ? 0 : rg;
+          ov[i] = *reinterpret_cast<const u32x4*>(obuf + rl * 512 + n * 16);
+          const int c = (n & 16) | ((n ^ rl) & 15);
+          goff[i] = (int64_t)rg * 512 + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ov[i]));  // the reads have returned
+        issue_item();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(ov[i], (GU32x4*)(cbase + goff[i]));
+      }
+      retire(4);
+      F32RW_TICK(7)
+    }
+    if (u < nloc) {
+      do ++gc; while (t_begin + (u >> 1) >= tile_start[gc + 1]);
+    }
+  }
+#ifdef PYG_HIP_MM_EXPERIMENTS
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("f32regw phases (cycles, %d halves): wait %llu bar1 %llu split %llu bar1b %llu mfma %llu epi %llu bar2 %llu issue+stores %llu\n", nloc,
+           (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3],
+           (unsigned long long)ph[4], (unsigned long long)ph[5], (unsigned long long)ph[6], (unsigned long long)ph[7]);
+#endif
+#undef F32RW_TICK
+}
+
+
 
 // ---- fp32 variant with a pipelined epilogue ---------------------------------------------------------
 // fp32 at K = 128 is bound by the MFMA rate (AI = 32 flop/B), and the weight image + X stages leave room for
@@ -3012,6 +3380,27 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
     }
   }
   if constexpr (Elem<T>::kSize == 4) {
+    if (K == 128 && M == 128 && g_f32_split && (g_schedule == 3 || (g_schedule == 0 && w.rows_upper < 512 * (int64_t)B))) {
+      // split-bf16 with the W planes in registers and an LDS-DMA item ring, two four-wave workgroups per CU: a
+      // relation change costs four ring items instead of a 96 KiB image built with 2-byte LDS writes -- the choice for
+      // many short relations (4 Mi rows: 128 rows per relation 1.25 vs 2.52 ms, 1024 rows 1.15 vs 1.13, 16 Ki rows
+      // 0.98 vs 0.94); `'ticket'` forces it
+      g_last_variant = "mfma_f32_k128_regw_x3";
+#ifdef PYG_HIP_F32RW_NB
+      constexpr int lds = PYG_HIP_F32RW_NB * 32 * 512 + 3 * 8192 + 512;
+#else
+      constexpr int lds = 2 * 32 * 512 + 3 * 8192 + 512;  // ring of two fp32 items + three bf16 planes + the bias row
+#endif
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_f32x3_regw_kernel);
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+      const DeviceInfo& di = device_info();
+      const int64_t tiles3_upper = (w.rows_upper + kPairRows - 1) / kPairRows + B;
+      const int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles3_upper, 1), 2 * (int64_t)di.num_cus);
+      ProfScope prof(stream);
+      hipLaunchKernelGGL(mfma_rows_f32x3_regw_kernel, dim3((unsigned)gx), dim3(256), lds, stream, w.descs, w.tile_start3, B);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
     if (K == 128 && M % 128 == 0 && g_f32_split) {
       // fp32 through three bf16 planes per operand (mfma_rows_lds_kernel FLAGS bit 2): HBM-bound instead of bound by
       // the fp32 matrix rate

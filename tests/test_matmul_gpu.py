@@ -85,9 +85,40 @@ def test_ragged_fp32_mfma_1e5(split):
         out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
     finally:
         ops.set_matmul_f32_split(True)
-    assert ops.matmul_last_variant() == ('mfma_f32_k128_mc128_x3' if split else 'mfma_f32_k128_mc128')
+    assert ops.matmul_last_variant() in (('mfma_f32_k128_mc128_x3', 'mfma_f32_k128_regw_x3') if split else ('mfma_f32_k128_mc128',))
     assert rel_fro(out.cpu().numpy(), GOLD['f32r_out']) <= 1e-6
     assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(x.numpy(), GOLD['bf_ptr'], w.numpy())) <= 1e-6
+
+
+def test_fp32_split_bf16_register_w_kernel_many_short_segments():
+    """Many short segments route fp32 K = M = 128 to the register-W variant of the split-bf16 kernel (W chunks and X
+    tiles through one LDS-DMA ring): empty segments, 1 / 31 / 32 / 33 / 64 / 65-row segments (empty and partial second
+    halves of a 64-row tile), bias, transposed weights; against float64 and against the LDS-W variant."""
+    g = torch.Generator().manual_seed(12)
+    rng = np.random.default_rng(12)
+    sizes = [int(v) for v in rng.integers(0, 200, 400)]
+    sizes[:8] = [0, 1, 31, 32, 33, 64, 65, 0]
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    for trans, with_bias in ((False, False), (False, True), (True, True)):
+        x = torch.randn(n, 128, generator=g).to(DEV)
+        w = torch.randn(len(sizes), 128, 128, generator=g).to(DEV)
+        if trans:
+            w = w.transpose(1, 2).contiguous().transpose(1, 2)
+        bias = torch.randn(len(sizes), 128, generator=g).to(DEV) if with_bias else None
+        out = ops.segment_matmul(x, ptr, w, bias)
+        assert ops.matmul_last_variant() == 'mfma_f32_k128_regw_x3'
+        try:
+            ops.set_matmul_schedule('contiguous')
+            ref = ops.segment_matmul(x, ptr, w, bias)
+            assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128_x3'
+        finally:
+            ops.set_matmul_schedule('auto')
+        want = torch.cat([x[int(ptr[b]):int(ptr[b + 1])].double() @ w[b].double() + (bias[b].double() if with_bias else 0)
+                          for b in range(len(sizes))])
+        assert (out.double() - want).norm() <= 1e-6 * want.norm()
+        assert (ref.double() - want).norm() <= 1e-6 * want.norm()
+        assert (out.double() - ref.double()).abs().max() <= 1e-4 * want.abs().max()  # (different k grouping per MFMA)
 
 
 def test_fp32_split_bf16_is_as_accurate_as_the_fp32_mfma():

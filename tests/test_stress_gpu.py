@@ -150,6 +150,34 @@ def test_fp32_split_bf16_kernel_under_noise_is_reproducible(M):
     _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
 
 
+def test_fp32_split_bf16_register_w_kernel_under_noise_is_reproducible():
+    """The ring kernel's fp32 variant (`'ticket'` forces it for any segment length): DMA from inline asm, waits naming
+    4 - 12 younger operations, results staged in the ring slot that is refilled right behind the stores' LDS reads."""
+    rng = np.random.default_rng(5)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B = 200
+    ptr = ragged_ptr(rng, B, 1, 1)
+    ptr = torch.cat([ptr, ptr[-1:] + torch.tensor([5000, 5001, 12000])])
+    n = int(ptr[-1])
+    x = torch.randn(n, 128, device=DEV, generator=g)
+    w = torch.randn(B + 3, 128, 128, device=DEV, generator=g) / 11
+    bias = torch.randn(B + 3, 128, device=DEV, generator=g)
+
+    def check(out):
+        assert ops.matmul_last_variant() == 'mfma_f32_k128_regw_x3'
+        for b in (0, 7, 30, 199, 200, 202):
+            s, e = int(ptr[b]), int(ptr[b + 1])
+            ref = x[s:e].double() @ w[b].double() + bias[b].double()
+            assert (out[s:e].double() - ref).norm() <= 1e-6 * max(ref.norm().item(), 1e-30)
+        assert torch.isfinite(out).all()
+
+    try:
+        ops.set_matmul_schedule('ticket')
+        _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
+    finally:
+        ops.set_matmul_schedule('auto')
+
+
 @pytest.mark.parametrize('mode,variant', [('auto', 'mfma_bf16_k256_regw'), ('cyclic', 'mfma_bf16_k256_wide256r2')])
 def test_k256_kernels_under_noise_are_reproducible(mode, variant):
     """K = M = 256: the register-W kernel (X tiles and W chunks by LDS-DMA from inline asm, waits that name 8 - 20 younger

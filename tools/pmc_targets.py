@@ -44,6 +44,19 @@ ws = [(torch.randn(k, 128, device=dev, generator=gd) / k ** 0.5).bfloat16() for 
 for _ in range(3):
     ops.grouped_matmul(xs, ws)
 del xs, ws
+# round 3: C4 (K = M = 256, register-W kernel) and fp32 K = 128 (split-bf16 kernel, 4 Mi rows in 64 segments)
+c4rows = bench_legs.c4_group_rows()
+xs = [torch.randn(r, 256, device=dev, generator=gd).bfloat16() for r in c4rows]
+ws = [(torch.randn(256, 256, device=dev, generator=gd) / 16).bfloat16() for _ in c4rows]
+for _ in range(3):
+    ops.grouped_matmul(xs, ws)
+del xs, ws
+xf = torch.randn(1 << 22, 128, device=dev, generator=gd)
+wf = torch.randn(64, 128, 128, device=dev, generator=gd) / 11
+pf = torch.arange(0, (1 << 22) + 1, (1 << 22) // 64)
+for _ in range(3):
+    ops.segment_matmul(xf, pf, wf)
+del xf, wf
 types = list(bench_legs.MAG_SIZES)
 ets = [(s_, r_, d_) for s_, r_, d_, _ in bench_legs.MAG_RELS]
 rp, cl = bench_legs.make_mag_graph(dev)
