@@ -602,7 +602,9 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
 
 // launch kinds 2 / 3: the scans' two passes.  MAXNC = the most consumers of any segment of the launch (the registers of
 // the widest aggregate are only paid where one occurs: the last hop carries none).
-template <int MAXNC, bool APPLY>
+// MODE 0 = reduce, 1 = apply, 2 = both passes in ONE single-block launch (the seeds of a C3-sized batch are one tile:
+// the block has every aggregate of the launch itself, a launch and its boundary less on the call's host-bound start)
+template <int MAXNC, int MODE>
 __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
   const int bx = (int)blockIdx.x;
   int k = 0;
@@ -624,8 +626,13 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
 #define PYG_FUSED_CASE(N)                               \
   if (MAXNC >= N && nc == N) {                          \
     if constexpr (MAXNC >= N) {                         \
-      if (APPLY) fused_apply<N>(L, pt, b, nblocks);     \
+      if (MODE == 1) fused_apply<N>(L, pt, b, nblocks); \
       else fused_reduce<N>(L, pt, b);                   \
+      if (MODE == 2) {                                  \
+        __threadfence_block();                          \
+        __syncthreads();                                \
+        fused_apply<N>(L, pt, b, nblocks);              \
+      }                                                 \
     }                                                   \
     return;                                             \
   }

@@ -171,15 +171,16 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     PYG_HIP_CHECK(hipGetLastError());
     return PYG_HIP_OK;
   };
-  auto launch_scan = [&](const FScanLaunch& l, bool apply) -> int {
+  auto launch_scan = [&](const FScanLaunch& l, int mode) -> int {  // 0 reduce, 1 apply, 2 both (single-block launches)
     if (l.n == 0) return PYG_HIP_OK;
     int maxnc = 0;
     for (int k = 0; k < l.n; ++k) maxnc = std::max(maxnc, l.nc[k]);
     const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
 #define PYG_FUSED_LAUNCH(N)                                                                    \
   case N:                                                                                      \
-    if (!apply) hipLaunchKernelGGL((fused_scan_kernel<N, false>), grid, block, 0, stream, l);  \
-    else hipLaunchKernelGGL((fused_scan_kernel<N, true>), grid, block, 0, stream, l);          \
+    if (mode == 0) hipLaunchKernelGGL((fused_scan_kernel<N, 0>), grid, block, 0, stream, l);   \
+    else if (mode == 1) hipLaunchKernelGGL((fused_scan_kernel<N, 1>), grid, block, 0, stream, l); \
+    else hipLaunchKernelGGL((fused_scan_kernel<N, 2>), grid, block, 0, stream, l);             \
     break;
     switch (maxnc) {
       PYG_FUSED_LAUNCH(0)
@@ -270,9 +271,13 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       add_part(sc, pp.h.ncons, nt, &pp);
     }
     pt.mark("seedscan_built");
-    int rc = launch_scan(sc, false);
-    if (rc != PYG_HIP_OK) return rc;
-    rc = launch_scan(sc, true);
+    int rc;
+    if (sc.n > 0 && sc.cum[sc.n - 1] == 1) {
+      rc = launch_scan(sc, 2);  // one tile in all: both passes in one launch
+    } else {
+      rc = launch_scan(sc, 0);
+      if (rc == PYG_HIP_OK) rc = launch_scan(sc, 1);
+    }
     if (rc != PYG_HIP_OK) return rc;
   }
 
@@ -397,10 +402,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     }
     rc = launch_sample(p1);
     if (rc != PYG_HIP_OK) return rc;
-    rc = launch_scan(p2, false);
+    rc = launch_scan(p2, 0);
     if (rc != PYG_HIP_OK) return rc;
     add_part(p2, -1, 1, nullptr);  // carry block: apply pass only
-    rc = launch_scan(p2, true);
+    rc = launch_scan(p2, 1);
     pt.mark("hop_queued");
     if (rc != PYG_HIP_OK) return rc;
     steps_by_hop[(size_t)ell] = cur;
