@@ -27,7 +27,9 @@ The JSON line also carries
                 -- as per-segment torch.matmul on CPU tensors of the same dtype, all host threads; `cpu_port` is the
                 oracle's own C restatement (test infrastructure) on a smaller sample
   sampler       neighbor_sample sampled-edges/s on the C3-shaped synthetic graph (single GPU by design)
-  segment_matmul_f32   C2 in fp32 (north_star's 1e-5 parity configuration; bound = fp32 MFMA rate)
+  segment_matmul_f32   C2 in fp32 (north_star's 1e-5 parity configuration): split-bf16 MFMAs, bound = HBM; `exact` =
+                       the fp32 MFMA kernel (bound = fp32 MFMA rate)
+  segment_short        4 Mi rows in 16 384 relations of 256 rows (the item-ring kernel; the ticket kernel beside it)
   grouped_mixed        per-group shapes (K in {100, 128, 256, 768}) through the general-shape MFMA kernel + the
                        one-thread-per-output kernel's time beside it; segment_matmul with K = 100
   c4, c5, index_sort, scatter_sum, segment_matmul_backward   the other configs / ops (bench_legs.py)
@@ -352,6 +354,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs and args.dtype == 'bf16':
         for key, fn in (('segment_matmul_f32', lambda: bench_legs.leg_segment_matmul_f32(device, make_c2)),
                         ('grouped_mixed', lambda: bench_legs.leg_grouped_mixed(device)),
+                        ('segment_short', lambda: bench_legs.leg_segment_short(device)),
                         ('c5', lambda: bench_legs.leg_c5(device)),
                         ('index_sort', lambda: bench_legs.leg_index_sort(device)),
                         ('scatter_sum', lambda: bench_legs.leg_scatter_sum(device))):

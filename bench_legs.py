@@ -166,6 +166,31 @@ def leg_grouped_mixed(device, rows_total=6_000_000, G=64, ks=(100, 128, 256, 768
     return res
 
 
+def leg_segment_short(device, rows=1 << 22, seg_rows=256, F=128, dtype=torch.bfloat16):
+    """Many short relations: 4 Mi rows cut into 256-row segments (16 384 relations, each with its own 32 KiB W -- a
+    third of the bytes are weights).  The automatic choice is the item-ring kernel (a relation change = two ring items);
+    the ticket kernel (W replicated in every wave's registers, refilled through a staging area) beside it."""
+    from pyg_lib_amd import ops
+    B = rows // seg_rows
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(rows, F, device=device, generator=g).to(dtype)
+    w = (torch.randn(B, F, F, device=device, generator=g) / F ** 0.5).to(dtype)
+    ptr = torch.arange(0, rows + 1, seg_rows)
+    esz = x.element_size()
+    alg = 2 * rows * F * esz + B * F * F * esz + 8 * (B + 1)
+    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=6, warmup=2)
+    kern = ops.matmul_last_variant()
+    try:
+        ops.set_matmul_schedule('ticket')
+        ms_t = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=4, warmup=1)
+        kern_t = ops.matmul_last_variant()
+    finally:
+        ops.set_matmul_schedule('auto')
+    return dict(workload=f'segment_matmul, {rows} rows in {B} segments of {seg_rows}, F={F} bf16', kernel=kern,
+                alg_bytes=int(alg), kernel_ms=round(ms, 4), GBps=round(alg / (ms * 1e-3) / 1e9, 1),
+                frac=round(alg / (ms * 1e-3) / 8e12, 4), ticket=dict(kernel=kern_t, kernel_ms=round(ms_t, 4)))
+
+
 def leg_segment_matmul_f32(device, make_c2, iters=5):
     """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  Default arithmetic: split-bf16 (three bf16
     terms per operand, six bf16 MFMAs per 16 k, fp32 accumulation -- products exact to 2^-26, see

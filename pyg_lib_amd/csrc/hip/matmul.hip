@@ -2232,6 +2232,300 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
 #endif
 }
 
+// ---- 16-bit, K = M = 128: the item ring of the kernel above for many short relations ---------------------------------
+// The ticket kernel keeps the whole W in every wave's registers and refills it through a staging area with two
+// workgroup barriers per relation change: 6.1 TB/s on long relations, 4.3 at 4096 rows per relation, 3.8 at 512, 1.5 at 64
+// (4 Mi rows).  Here a relation change is two ring items: wave w of a four-wave workgroup keeps its 32 columns of W as 8
+// fragments (32 registers), the ring carries 16 KiB items -- a 64-row X tile or one of the two 64-k-row chunks of a new
+// W -- and an X item is 16 ds_read_b128 + 16 MFMAs per wave, 8 ds_write_b64 into the output tile, barrier, 4 stores of
+// four whole rows each.  48.3 KiB of LDS and ~100 registers: three workgroups per CU.  Same waits as above (4 DMA per
+// item, 4 stores per X item).
+template <typename T>
+__global__ __launch_bounds__(256, 3) void mfma_rows_k128_ring_kernel(const DevGroup* __restrict__ descs,
+                                                                     const int32_t* __restrict__ tile_start, int B) {
+  constexpr int NB = 2;           // ring slots
+  static_assert(NB == 2 || NB == 3, "wait_item names the younger operations of a 2- or 3-slot ring");
+  constexpr int XB = 64 * 256;    // bytes per item / output tile
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u32x4 GU32x4;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int n = lane & 31, h = lane >> 5;
+  char* obuf = smem + NB * XB;
+
+  const int total = tile_start[B];
+  const int G = (int)gridDim.x;
+  // consecutive workgroup ids go to consecutive XCDs: XCD k takes the k-th eighth of the ranges, so the workgroups
+  // that share a relation's W (neighbours in tile order) share an L2
+  const int bid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_begin = (int)((int64_t)bid * total / G);
+  const int nloc = (int)((int64_t)(bid + 1) * total / G) - t_begin;  // 64-row tiles
+  if (nloc <= 0) return;
+  int g_first;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_begin) lo = mid; else hi = mid;
+    }
+    g_first = lo;
+  }
+
+  // ---- issue side: the item sequence is, per relation met in the range: [2 chunks of W unless transposed] [its tiles]
+  int ig = g_first;                              // relation of the issue front
+  int iu = 0;                                    // next tile to issue
+  int ibuf = 0;                                  // ring slot of the next item
+  // fields of relation `ig` (kept in registers: every asm block clobbers "memory", so the compiler would re-read them)
+  const char* i_a;
+  const char* i_w;
+  int64_t i_rows;
+  int i_ts0, i_ts1, iw;                          // its first tile, the next relation's first tile, W chunks to issue
+  auto issue_enter = [&](int g) {
+    const DevGroup* p = descs + g;
+    i_a = p->a;
+    i_w = p->w;
+    i_rows = p->rows;
+    iw = p->trans ? 0 : 2;
+    i_ts0 = tile_start[g];
+    i_ts1 = tile_start[g + 1];
+  };
+  issue_enter(ig);
+  auto issue_item = [&]() {
+    const char* base;
+    int last = 63;
+    if (iw > 0) {
+      base = i_w + (2 - iw) * XB;
+      --iw;
+    } else {
+      const int uu = iu < nloc ? iu : nloc - 1;  // behind the range: the last tile again (nobody consumes it)
+      const int t = t_begin + uu;
+      const int64_t row0 = (int64_t)(t - i_ts0) * 64;
+      const int64_t left = i_rows - row0;
+      if (left < 64) last = (int)left - 1;
+      base = i_a + row0 * 256;
+      if (iu < nloc) {
+        ++iu;
+        if (iu < nloc && t_begin + iu >= i_ts1) {
+          do ++ig; while (t_begin + iu >= tile_start[ig + 1]);
+          issue_enter(ig);
+        }
+      }
+    }
+    const uint32_t lds = (uint32_t)(size_t)(smem + ibuf * XB + wave * 4096);
+    ibuf = ibuf + 1 == NB ? 0 : ibuf + 1;
+    uint32_t off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * wave + 4 * i + (lane >> 4);
+      const int c = (lane ^ r) & 15;
+      const int rc = r > last ? last : r;
+      off[i] = (uint32_t)(rc * 256 + c * 16);
+    }
+    uint32_t sv;
+    asm volatile(
+        "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
+        "s_mov_b32 %[sv], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+        "s_mov_b32 m0, %[sv]"
+        : [sv] "=&s"(sv)
+        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
+        : "memory", "scc");
+  };
+
+  // ---- consume side ----
+  u32x4 wreg[8];  // A fragments: W[64 h + 8 s ... + 7][32 wave + n] -- the k order of the other K = 128 kernels: same bits
+  T* bias_lds = reinterpret_cast<T*>(smem + (NB + 1) * XB);  // the relation's 128 bias values
+  int cbuf = 0;                // ring slot of the item consumed next
+  int s1 = 0, s2 = 0, s3 = 0;  // stores issued with the last three items (0 or 4 each)
+  int consumed = 0;            // items consumed so far (the first NB were issued back to back: wait for everything)
+  auto wait_item = [&]() {
+    // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
+    const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
+    if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ++consumed;
+  };
+  auto retire = [&](int stores) {
+    s3 = s2;
+    s2 = s1;
+    s1 = stores;
+    cbuf = cbuf + 1 == NB ? 0 : cbuf + 1;
+  };
+
+#pragma unroll
+  for (int b = 0; b < NB; ++b) issue_item();
+  int gc = g_first;
+  int u = 0;
+  while (u < nloc) {
+    const DevGroup* p = descs + gc;
+    // ---- this relation's W ----
+    if (p->trans) {
+      // `other` stored [M][K]: 8 consecutive k of output column 32 wave + n are 16 contiguous bytes
+      const char* wl = p->w + (32 * wave + n) * 256 + 128 * h;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wreg[s] = *reinterpret_cast<const u32x4*>(wl + 16 * s);
+    } else {
+      // a chunk = 64 k-rows of W as they lie in memory (256-byte rows, chunk-swizzled like an X tile): chunk c holds the
+      // k of lane half h = c.  Lane (q, half16) of a transposing read supplies row 8 s + 4 half + (q >> 2), columns
+      // 16 half16 + 4 (q & 3) ... + 3 of the 8 k-rows x 32 columns of one fragment, and receives column 16 half16 + q
+      const int q = lane & 15, half16 = (lane >> 4) & 1;
+      const int cc = 4 * wave + 2 * half16 + ((q & 3) >> 1);  // 16-byte chunk of the row
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        wait_item();
+        __syncthreads();
+        const char* wb = smem + cbuf * XB;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          v4i16 a[2];
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int kk = 8 * s + 4 * half + (q >> 2);
+            a[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(
+                wb + kk * 256 + (((cc ^ kk) & 15) * 16) + 8 * (q & 1)));
+          }
+          const u32x4 frag = __builtin_bit_cast(u32x4, __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7));
+          if (h == c) wreg[s] = frag;
+        }
+        // the reads must have returned before the slot is refilled
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(wreg[s]));
+        __syncthreads();
+        issue_item();
+        retire(0);
+      }
+    }
+    const bool has_bias = p->bias != nullptr;
+    if (has_bias) {
+      __syncthreads();  // everybody is done with the previous relation's bias
+      if (threadIdx.x < 128) bias_lds[threadIdx.x] = reinterpret_cast<const T*>(p->bias)[threadIdx.x];
+      __syncthreads();
+    }
+    // "use" what was loaded HERE with ordinary loads: the compiler's wait for them then sits in this (rare) path --
+    // left to the first MFMA of the tile loop it becomes an s_waitcnt vmcnt(0) in every iteration, which also drains
+    // the DMA and the stores the hand-placed waits leave in flight
+    if (p->trans) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(wreg[s]));
+    }
+    const int64_t c_rows = p->rows;
+    char* const c_out = p->c;
+    const int c_ts0 = tile_start[gc];
+
+    // ---- this relation's tiles inside the range ----
+    const int t_rel_end = tile_start[gc + 1];
+    for (; u < nloc && t_begin + u < t_rel_end; ++u) {
+      const int t = t_begin + u;
+      const int64_t row0 = (int64_t)(t - c_ts0) * 64;
+      const int64_t left = c_rows - row0;
+      wait_item();
+      __syncthreads();
+      const char* xb = smem + cbuf * XB;
+      f32x16 acc[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+      {
+        // B fragments two k-steps (four reads) ahead of their MFMAs
+        const char* xrow0 = xb + n * 256;
+        const char* xrow1 = xb + (32 + n) * 256;
+        const int xsw = n & 15;  // (32 + n) & 15 == n & 15
+        u32x4 xf[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          xf[s][0] = *reinterpret_cast<const u32x4*>(xrow0 + (((8 * h + s) ^ xsw) * 16));
+          xf[s][1] = *reinterpret_cast<const u32x4*>(xrow1 + (((8 * h + s) ^ xsw) * 16));
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const u32x4 xa0 = xf[s & 1][0], xa1 = xf[s & 1][1];
+          asm volatile("" : "+v"(xf[s & 1][1]));  // the wait for these fragments goes here, in front of the next reads
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < 8) {
+            xf[s & 1][0] = *reinterpret_cast<const u32x4*>(xrow0 + (((8 * h + s + 2) ^ xsw) * 16));
+            xf[s & 1][1] = *reinterpret_cast<const u32x4*>(xrow1 + (((8 * h + s + 2) ^ xsw) * 16));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0] = mfma_chunk(T{}, wreg[s], xa0, acc[0]);
+          acc[1] = mfma_chunk(T{}, wreg[s], xa1, acc[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // results -> output tile: lane (n, h) holds columns 32 wave + 8 g + 4 h + (0 ... 3), g = 0 ... 3, of rows n and 32 + n
+      {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          char* orow = obuf + (32 * rb + n) * 256 + 8 * h;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            f32x2_hw v01 = {acc[rb][4 * gq], acc[rb][4 * gq + 1]}, v23 = {acc[rb][4 * gq + 2], acc[rb][4 * gq + 3]};
+            u32x2 o;
+            if constexpr (std::is_same<T, bf16_t>::value) {
+              if (has_bias) {
+                const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_lds + 32 * wave + 8 * gq + 4 * h);
+                const f32x2_hw r01 = __builtin_convertvector(__builtin_convertvector(v01, bf16x2_hw), f32x2_hw);
+                const f32x2_hw r23 = __builtin_convertvector(__builtin_convertvector(v23, bf16x2_hw), f32x2_hw);
+                v01[0] = r01[0] + __builtin_bit_cast(float, bb[0] << 16);
+                v01[1] = r01[1] + __builtin_bit_cast(float, bb[0] & 0xffff0000u);
+                v23[0] = r23[0] + __builtin_bit_cast(float, bb[1] << 16);
+                v23[1] = r23[1] + __builtin_bit_cast(float, bb[1] & 0xffff0000u);
+              }
+              o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v01, bf16x2_hw));
+              o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v23, bf16x2_hw));
+            } else {
+              typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+              if (has_bias) {
+                const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_lds + 32 * wave + 8 * gq + 4 * h);
+                const uint32_t bw0 = bb[0], bw1 = bb[1];  // (scalars: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                const f16x2_hw b01 = __builtin_bit_cast(f16x2_hw, bw0), b23 = __builtin_bit_cast(f16x2_hw, bw1);
+                v01 = __builtin_convertvector(__builtin_convertvector(v01, f16x2_hw), f32x2_hw) + __builtin_convertvector(b01, f32x2_hw);
+                v23 = __builtin_convertvector(__builtin_convertvector(v23, f16x2_hw), f32x2_hw) + __builtin_convertvector(b23, f32x2_hw);
+              }
+              o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v01, f16x2_hw));
+              o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v23, f16x2_hw));
+            }
+            *reinterpret_cast<u32x2*>(orow + ((((4 * wave + gq) ^ n) & 15) * 16)) = o;
+          }
+        }
+      }
+      __syncthreads();
+      issue_item();
+      // always 4 stores (the waits count them): rows behind the segment end rewrite its last row with its own data
+      {
+        const int last = left < 64 ? (int)left - 1 : 63;
+        char* cbase = c_out + row0 * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int r = 16 * wave + 4 * i + (lane >> 4);
+          r = r > last ? last : r;
+          const u32x4 ov = *reinterpret_cast<const u32x4*>(obuf + r * 256 + (lane & 15) * 16);
+          const int c = (lane ^ r) & 15;
+          __builtin_nontemporal_store(ov, (GU32x4*)(cbase + r * 256 + c * 16));
+        }
+      }
+      retire(4);
+    }
+    if (u < nloc) {
+      do ++gc; while (t_begin + u >= tile_start[gc + 1]);
+    }
+  }
+}
+
 // ---- fp32, K = M = 128 by split-bf16: W planes in registers, X tiles through the LDS-DMA ring ---------------------------
 // The split-bf16 arithmetic of mfma_rows_lds_kernel<float, ..., FLAGS bit 2> in the structure of the kernel above (that
 // kernel's 96 KiB of W planes fill the LDS: one wave per SIMD, nothing overlaps its phases).  Wave w of a four-wave
@@ -3053,6 +3347,8 @@ struct ProfPair { hipEvent_t a, b; };
 int g_schedule = 0;
 // fp32 K = 128, M % 128 == 0: 1 = split-bf16 arithmetic (default), 0 = v_mfma_f32_32x32x2_f32
 int g_f32_split = 1;
+// 16-bit K = M = 128: relations shorter than this on average take the item-ring kernel (automatic schedule)
+constexpr int64_t kRingMeanRows = 4096;
 thread_local bool g_prof_on = false;
 thread_local std::vector<ProfPair> g_prof;
 
@@ -3349,6 +3645,20 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
     const DeviceInfo& di = device_info();
     const int sched = g_schedule;
     const bool big = w.rows_upper >= (int64_t)di.num_cus * 256 * 4;
+    if (K == 128 && M == 128 && (sched == 6 || (sched == 0 && w.rows_upper < kRingMeanRows * (int64_t)B))) {
+      // many short relations: the item ring (a relation change = two ring items)
+      snprintf(name, sizeof(name), "mfma_%s_k128_mc128_ring", tname);
+      g_last_variant = name;
+      constexpr int lds = 3 * 64 * 256 + 256;
+      const void* kern = reinterpret_cast<const void*>(&mfma_rows_k128_ring_kernel<T>);
+      if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+      const int64_t tiles3_upper = (w.rows_upper + kPairRows - 1) / kPairRows + B;
+      const int64_t gx = std::min<int64_t>(std::max<int64_t>(tiles3_upper, 1), 3 * (int64_t)di.num_cus);
+      ProfScope prof(stream);
+      hipLaunchKernelGGL((mfma_rows_k128_ring_kernel<T>), dim3((unsigned)gx), dim3(256), lds, stream, w.descs, w.tile_start3, B);
+      PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    }
     if (K == 128 && M == 128 && di.num_cus >= 8 && (sched == 3 || (sched == 0 && big))) {
       snprintf(name, sizeof(name), "mfma_%s_k128_mc128_ticket", tname);
       g_last_variant = name;
@@ -3380,11 +3690,11 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
     }
   }
   if constexpr (Elem<T>::kSize == 4) {
-    if (K == 128 && M == 128 && g_f32_split && (g_schedule == 3 || (g_schedule == 0 && w.rows_upper < 512 * (int64_t)B))) {
+    if (K == 128 && M == 128 && g_f32_split && (g_schedule == 6 || (g_schedule == 0 && w.rows_upper < 512 * (int64_t)B))) {
       // split-bf16 with the W planes in registers and an LDS-DMA item ring, two four-wave workgroups per CU: a
       // relation change costs four ring items instead of a 96 KiB image built with 2-byte LDS writes -- the choice for
       // many short relations (4 Mi rows: 128 rows per relation 1.25 vs 2.52 ms, 1024 rows 1.15 vs 1.13, 16 Ki rows
-      // 0.98 vs 0.94); `'ticket'` forces it
+      // 0.98 vs 0.94); `'ring'` forces it
       g_last_variant = "mfma_f32_k128_regw_x3";
 #ifdef PYG_HIP_F32RW_NB
       constexpr int lds = PYG_HIP_F32RW_NB * 32 * 512 + 3 * 8192 + 512;
@@ -3552,7 +3862,7 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
-void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 5) ? mode : 0; }
+void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 6) ? mode : 0; }
 
 void pyg_hip_matmul_set_f32_split(int on) { g_f32_split = on != 0; }
 

@@ -356,10 +356,12 @@ def set_matmul_schedule(mode: str = 'auto') -> None:
     address order from per-XCD counters, W in registers) -- see ``pyg_hip_matmul_set_schedule`` in
     include/pyg_hip.h.  ``'general'`` / ``'naive'`` (measurement only) send every floating-point shape through the
     general-shape MFMA kernel / every call through the one-thread-per-output kernel.  For 16-bit ``K = M = 256`` the
+    ``'ring'`` forces the item-ring kernels (the automatic choice for many short relations: 16-bit ``K = M = 128`` below
+    4096 rows per relation on average, fp32 below 512).  For 16-bit ``K = M = 256`` the
     same switch selects among that shape's three kernels (``'auto'``: W in registers, ``'contiguous'`` / ``'cyclic'``:
     W in LDS with 32 / 64 rows per wave).  Process wide."""
     _capi.lib().pyg_hip_matmul_set_schedule({'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3, 'general': 4,
-                                             'naive': 5}[mode])
+                                             'naive': 5, 'ring': 6}[mode])
 
 
 def set_matmul_f32_split(on: bool = True) -> None:

@@ -61,7 +61,7 @@ def test_ragged_bf16_with_empty_segments(ptr_on_device):
     ptr = torch.from_numpy(GOLD['bf_ptr'])
     p = ptr.to(DEV) if ptr_on_device else ptr
     out = ops.segment_matmul(x.to(DEV), p, w.to(DEV))
-    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128'
+    assert ops.matmul_last_variant() == 'mfma_bf16_k128_mc128_ring'  # short relations: the item-ring kernel
     got = bits(out)
     ref = oracle.segment_matmul(GOLD['bf_x'], GOLD['bf_ptr'], GOLD['bf_w'], dtype=oracle.BF16)
     for expect in (ref, GOLD['bf_out']):
@@ -210,13 +210,14 @@ def test_many_tiles_per_workgroup_vs_oracle(dtype, K, M, with_bias):
     assert torch.isfinite(out.float()).all()
 
 
-SCHED_SUFFIX = {'cyclic': '_cyc', 'ticket': '_ticket', 'contiguous': ''}
+SCHED_SUFFIX = {'cyclic': '_cyc', 'ticket': '_ticket', 'contiguous': '', 'ring': '_ring'}
 
 
-@pytest.fixture(params=['cyclic', 'ticket'])
+@pytest.fixture(params=['cyclic', 'ticket', 'ring'])
 def cyclic_schedule(request):
-    """The two schedules that replace the contiguous tile ranges on big inputs: banded cyclic (mfma_rows_cyc_kernel)
-    and tickets (mfma_rows_ticket_kernel: wave pairs, W in registers, tiles drawn from per-XCD counters)."""
+    """The schedules next to the contiguous tile ranges: banded cyclic (mfma_rows_cyc_kernel), tickets
+    (mfma_rows_ticket_kernel: wave pairs, W in registers, tiles drawn from per-XCD counters) and the item ring
+    (mfma_rows_k128_ring_kernel: W slices in registers, X tiles and W chunks through one LDS-DMA ring)."""
     ops.set_matmul_schedule(request.param)
     yield SCHED_SUFFIX[request.param]
     ops.set_matmul_schedule('auto')
@@ -416,7 +417,7 @@ def test_grouped_matmul_pool_writes_into_the_callers_buffer():
         torch.ops.pyg.grouped_matmul_pool(ins, oth, pool)  # wrong number of rows
 
 
-@pytest.mark.parametrize('sched', ['cyclic', 'ticket', 'contiguous'])
+@pytest.mark.parametrize('sched', ['cyclic', 'ticket', 'contiguous', 'ring'])
 def test_grouped_matmul_k128_both_schedules(sched):
     """grouped_matmul with uniform K = M = 128 reaches the same two kernels through the host-built tile tables."""
     torch.manual_seed(5)
@@ -473,7 +474,7 @@ def test_full_size_c2_properties():
     seg = torch.repeat_interleave(torch.arange(B, device=DEV), sizes.to(DEV))
     # all three tile schedules (the automatic choice at this size is the ticket kernel)
     for mode, variant in (('auto', 'mfma_bf16_k128_mc128_ticket'), ('cyclic', 'mfma_bf16_k128_mc128_cyc'),
-                          ('contiguous', 'mfma_bf16_k128_mc128')):
+                          ('contiguous', 'mfma_bf16_k128_mc128'), ('ring', 'mfma_bf16_k128_mc128_ring')):
         ops.set_matmul_schedule(mode)
         try:
             out = ops.segment_matmul(x, ptr, wd)
@@ -637,7 +638,7 @@ def test_ticket_kernel_random_partitions_match_contiguous_bitwise():
         w = (torch.randn(B, 128, 128, generator=g) / 11).bfloat16().to(DEV)
         bias = torch.randn(B, 128, generator=g).bfloat16().to(DEV) if trial % 3 == 0 else None
         outs = {}
-        for mode in ('ticket', 'contiguous'):
+        for mode in ('ticket', 'contiguous', 'ring'):
             ops.set_matmul_schedule(mode)
             try:
                 outs[mode] = ops.segment_matmul(x, ptr, w, bias)
@@ -645,6 +646,7 @@ def test_ticket_kernel_random_partitions_match_contiguous_bitwise():
             finally:
                 ops.set_matmul_schedule('auto')
         assert torch.equal(outs['ticket'].view(torch.int16), outs['contiguous'].view(torch.int16)), (trial, B, n)
+        assert torch.equal(outs['ring'].view(torch.int16), outs['contiguous'].view(torch.int16)), (trial, B, n)
 
 
 def test_ticket_kernel_on_two_streams_at_once():
@@ -681,13 +683,15 @@ def test_ticket_kernel_transposed_weights(dtype):
     assert not d_oth[0].is_contiguous()
     outs = {}
     name = 'bf16' if dtype == torch.bfloat16 else 'f16'
-    for mode in ('ticket', 'contiguous'):
+    for mode in ('ticket', 'contiguous', 'ring'):
         ops.set_matmul_schedule(mode)
         try:
             outs[mode] = ops.grouped_matmul(d_in, d_oth)
         finally:
             ops.set_matmul_schedule('auto')
         assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128' + SCHED_SUFFIX[mode]
+    for r_, c_ in zip(outs['ring'], outs['contiguous']):
+        assert torch.equal(r_.view(torch.int16), c_.view(torch.int16))
     for a, o, t, c in zip(ins, oth, outs['ticket'], outs['contiguous']):
         assert torch.equal(t.view(torch.int16), c.view(torch.int16))
         if dtype == torch.bfloat16:

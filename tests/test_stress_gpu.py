@@ -53,8 +53,9 @@ def ragged_ptr(rng, B, kind, scale):
     return torch.tensor([0] + np.cumsum(sizes).tolist())
 
 
+@pytest.mark.parametrize('mode', ['ticket', 'ring'])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_ticket_kernel_under_noise_matches_contiguous_bitwise(dtype):
+def test_ticket_kernel_under_noise_matches_contiguous_bitwise(dtype, mode):
     rng = np.random.default_rng(1)
     noise = Noise()
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -71,10 +72,10 @@ def test_ticket_kernel_under_noise_matches_contiguous_bitwise(dtype):
         try:
             ops.set_matmul_schedule('contiguous')
             ref = ops.segment_matmul(x, ptr, w, bias)
-            ops.set_matmul_schedule('ticket')
+            ops.set_matmul_schedule(mode)
             noise.burst()
             out = ops.segment_matmul(x, ptr, w, bias)
-            assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128_ticket'
+            assert ops.matmul_last_variant() == f'mfma_{name}_k128_mc128_{mode}'
         finally:
             ops.set_matmul_schedule('auto')
         torch.cuda.synchronize()
@@ -151,7 +152,7 @@ def test_fp32_split_bf16_kernel_under_noise_is_reproducible(M):
 
 
 def test_fp32_split_bf16_register_w_kernel_under_noise_is_reproducible():
-    """The ring kernel's fp32 variant (`'ticket'` forces it for any segment length): DMA from inline asm, waits naming
+    """The ring kernel's fp32 variant (`'ring'` forces it for any segment length): DMA from inline asm, waits naming
     4 - 12 younger operations, results staged in the ring slot that is refilled right behind the stores' LDS reads."""
     rng = np.random.default_rng(5)
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -172,7 +173,7 @@ def test_fp32_split_bf16_register_w_kernel_under_noise_is_reproducible():
         assert torch.isfinite(out).all()
 
     try:
-        ops.set_matmul_schedule('ticket')
+        ops.set_matmul_schedule('ring')
         _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
     finally:
         ops.set_matmul_schedule('auto')
