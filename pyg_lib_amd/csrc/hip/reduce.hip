@@ -307,19 +307,34 @@ __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restric
     for (int i = 0; i < VN; ++i) acc[i] = 0.f;
     int64_t cur = index[b * s.isb + e0 * s.ise];
     bool first = true;
-    for (int64_t e = e0; e < e1; ++e) {
-      const int64_t idx = index[b * s.isb + e * s.ise];
-      if (idx != cur) {
-        T* dst = out + (b * s.N + cur) * s.K + c * VN;
-        if (SORTED && !first) Vec<T>::add_plain(dst, acc);
-        else Vec<T>::flush(dst, acc);
-        first = false;
+    // batches of 8 positions: their indices and 16-byte source slices are all requested before the first is consumed
+    // (one dependent load per trip left the sorted sums at 4.3 TB/s: a wave had 1 KiB in flight)
+    constexpr int U = 8;
+    for (int64_t eb = e0; eb < e1; eb += U) {
+      int64_t idxv[U];
+      u32x4 val[U];
 #pragma unroll
-        for (int i = 0; i < VN; ++i) acc[i] = 0.f;
-        cur = idx;
+      for (int u = 0; u < U; ++u) {
+        const int64_t e = eb + u < e1 ? eb + u : e1 - 1;
+        idxv[u] = index[b * s.isb + e * s.ise];
+        const int64_t srow = perm ? perm[e] : (b * s.E + e);
+        val[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + srow * s.K + c * VN));
       }
-      const int64_t srow = perm ? perm[e] : (b * s.E + e);
-      Vec<T>::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + srow * s.K + c * VN)), acc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (eb + u >= e1) break;
+        const int64_t idx = idxv[u];
+        if (idx != cur) {
+          T* dst = out + (b * s.N + cur) * s.K + c * VN;
+          if (SORTED && !first) Vec<T>::add_plain(dst, acc);
+          else Vec<T>::flush(dst, acc);
+          first = false;
+#pragma unroll
+          for (int i = 0; i < VN; ++i) acc[i] = 0.f;
+          cur = idx;
+        }
+        Vec<T>::unpack(val[u], acc);
+      }
     }
     Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
   }
