@@ -139,6 +139,10 @@ PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
  *      with fp32 accumulation.  Dropped terms: 2^-26 |x||w| per product at most, unbiased -- below the rounding unit
  *      of an fp32 multiply-add.  2.7x less matrix time than mode 0: the kernel is HBM-bound.
  *   0  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): bound by the fp32 matrix rate (157 TFLOP/s).
+ *      Range: an operand whose magnitude exceeds the largest bf16 (3.39e38) rounds to infinity in its first term (NaN
+ *      where the fp32 MFMA gives a finite product), and the third terms of operands below ~2^-100 fall into the bf16
+ *      denormals the matrix unit flushes (their products keep 16 instead of 24 bits): data outside 2^-100 ... 2^127
+ *      wants mode 0.
  * Both meet the fp32 parity bar (relative Frobenius error <= 1e-5 against float64; measured ~1e-7 either way).  The
  * reference multiplies fp32 on CUTLASS SIMT FMAs, or on TF32 tensor ops (10-bit mantissa products) when torch's
  * float32 matmul precision allows (ops/cuda/matmul_kernel.cu:157-262); both modes here are at full fp32 accuracy. */
