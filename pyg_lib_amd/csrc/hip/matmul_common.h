@@ -82,6 +82,18 @@ __device__ __forceinline__ float round_to(bf16_t, float v) { return (float)(__bf
 __device__ __forceinline__ float round_to(f16_t, float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ float round_to(float, float v) { return v; }
 
+// Split-bf16 helpers (fp32 K = M-chunk = 128 kernel, FLAGS bit 2).  split2(a, b): round-to-nearest-even bf16 pair of
+// (a, b) packed {a low, b high} (v_cvt_pk_bf16_f32), and the exact fp32 residuals a - bf16(a), b - bf16(b).
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t split2(float& a, float& b) {
+  const f32x2_hw v = {a, b};
+  const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+  a -= __builtin_bit_cast(float, p << 16);
+  b -= __builtin_bit_cast(float, p & 0xffff0000u);
+  return p;
+}
+
 // ---- alignment classes of the general-shape kernel (matmul_gen.h) ---------------------------------
 __host__ __device__ inline int gen_log2_align(uint64_t v) {
   // log2 of the largest power of two <= 16 dividing v (v == 0: 16)
@@ -108,5 +120,10 @@ __host__ __device__ inline int gen_class(const void* a, const void* w, const voi
 // PYG_F16; `tile_start` the prefix of 128-row tiles per group, `mean_k` the row-weighted mean contraction length.
 int launch_matmul_gen(int dtype, const void* descs, const int32_t* tile_start, int B, int64_t tiles_upper, int64_t mean_k,
                       hipStream_t stream);
+// matmul_ring.hip: the item-ring kernels.  `tile_start3` is the prefix of 64-row tiles per group, `tiles3_upper` an upper
+// bound of their number; `dtype` PYG_BF16 / PYG_F16.
+int launch_ring_k256(int dtype, const void* descs, const int32_t* tile_start3, int B, int64_t tiles3_upper, hipStream_t stream);
+int launch_ring_k128(int dtype, const void* descs, const int32_t* tile_start3, int B, int64_t tiles3_upper, hipStream_t stream);
+int launch_ring_f32x3(const void* descs, const int32_t* tile_start3, int B, int64_t tiles3_upper, hipStream_t stream);
 
 }  // namespace pyg_hip
