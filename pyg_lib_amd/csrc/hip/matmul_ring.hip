@@ -11,6 +11,41 @@
 namespace pyg_hip {
 namespace {
 
+// Four LDS-DMA instructions of 1 KiB each (one wave's share of a 16 KiB ring item): lane l of instruction i fetches the
+// 16 bytes at base + off[i] into LDS byte lds + 1024 i + 16 l.  Issued from inline asm: the compiler must not know that
+// LDS is written behind its back (it cannot tell the ring slots apart and would drain vmcnt before every LDS access),
+// and the waits are placed by hand (ring_wait_younger).
+__device__ __forceinline__ void ring_dma4(uint32_t lds, const char* base, const uint32_t (&off)[4]) {
+  uint32_t sv;
+  asm volatile(
+      "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
+      "s_mov_b32 %[sv], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
+      "s_mov_b32 m0, %[sv]"
+      : [sv] "=&s"(sv)
+      : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
+      : "memory", "scc");
+}
+
+// vmcnt retires in order: waiting until at most `younger` vector-memory operations are outstanding leaves exactly the
+// ones issued after the awaited DMA in flight (4 DMA per item, 4 stores per X item: multiples of four up to 20).
+__device__ __forceinline__ void ring_wait_younger(int younger) {
+  if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- 16-bit, K = M = 256: W in registers, X tiles by LDS-DMA (the C4 shape) -------------------------------------------
 // The two kernels above keep the 128 KiB weight matrix in LDS: one workgroup of four waves per CU, one wave per SIMD,
 // X through registers (64 KiB in flight per CU) -- their waves wait for memory more than half of the time, nothing
@@ -127,23 +162,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
       const int rc = r > last ? last : r;
       off[i] = (uint32_t)(rc * 512 + c * 16);
     }
-    uint32_t sv;
-    asm volatile(
-        "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
-        "s_mov_b32 %[sv], m0\n\t"
-        "s_mov_b32 m0, %[lds]\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
-        "s_mov_b32 m0, %[sv]"
-        : [sv] "=&s"(sv)
-        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
-        : "memory", "scc");
+    ring_dma4(lds, base, off);
   };
 
   // ---- consume side ----
@@ -155,12 +174,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_k256_regw_kernel(const DevGr
   auto wait_item = [&]() {
     // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
     const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
-    if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_wait_younger(younger);
     ++consumed;
   };
   auto retire = [&](int stores) {
@@ -426,23 +440,7 @@ __global__ __launch_bounds__(256, 3) void mfma_rows_k128_ring_kernel(const DevGr
       const int rc = r > last ? last : r;
       off[i] = (uint32_t)(rc * 256 + c * 16);
     }
-    uint32_t sv;
-    asm volatile(
-        "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
-        "s_mov_b32 %[sv], m0\n\t"
-        "s_mov_b32 m0, %[lds]\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
-        "s_mov_b32 m0, %[sv]"
-        : [sv] "=&s"(sv)
-        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
-        : "memory", "scc");
+    ring_dma4(lds, base, off);
   };
 
   // ---- consume side ----
@@ -454,12 +452,7 @@ __global__ __launch_bounds__(256, 3) void mfma_rows_k128_ring_kernel(const DevGr
   auto wait_item = [&]() {
     // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
     const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
-    if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_wait_younger(younger);
     ++consumed;
   };
   auto retire = [&](int stores) {
@@ -725,23 +718,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevG
       const int rc = r > last ? last : r;
       off[i] = (uint32_t)(rc * 512 + c * 16);
     }
-    uint32_t sv;
-    asm volatile(
-        "s_nop 4\n\t"  // base / lds may come out of v_readfirstlane: VALU-written SGPR -> VMEM address / M0
-        "s_mov_b32 %[sv], m0\n\t"
-        "s_mov_b32 m0, %[lds]\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o0], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o1], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o2], %[base] nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %[o3], %[base] nt\n\t"
-        "s_mov_b32 m0, %[sv]"
-        : [sv] "=&s"(sv)
-        : [lds] "s"(lds), [base] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
-        : "memory", "scc");
+    ring_dma4(lds, base, off);
   };
 
   // ---- consume side ----
@@ -752,12 +729,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevG
   auto wait_item = [&]() {
     // item i has landed; younger (NB = 2): [stores of i - 2] [DMA i + 1] [stores of i - 1]; (NB = 3): one more pair
     const int younger = consumed < NB ? 0 : 4 * (NB - 1) + s1 + s2 + (NB == 3 ? s3 : 0);
-    if (younger == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_wait_younger(younger);
     ++consumed;
   };
   auto retire = [&](int stores) {
