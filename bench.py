@@ -108,7 +108,7 @@ def cpu_baseline_aten(dtype='bf16', rows=None, budget_s=25.0):
         best = dt if best is None else min(best, dt)
         reps += 1
     return dict(value=round(2.0 * rows * F * F / best / 1e9, 2), unit='GFLOP/s', cores=torch.get_num_threads(),
-                kind='aten-per-segment',
+                kind='reference', via='aten-per-segment',
                 sample=f'per-relation torch.matmul on CPU {dtype} tensors (= at::matmul_out per segment, '
                        f'ops/cpu/matmul_kernel.cpp:195-201): the full C2 relation list ({B} relations, {rows} rows, F=128; a 1 Mi-row '
                        f'random block repeated), best of {reps} passes, {torch.get_num_threads()} threads')
