@@ -25,10 +25,12 @@ def test_segment_matmul_replays_from_a_captured_graph(dtype, F, rows, variant):
     w = (torch.randn(B, F, F, device=DEV, generator=g) / F ** 0.5).to(dtype)
     bias = torch.randn(B, F, device=DEV, generator=g).to(dtype)
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):  # warm-up on the capture stream: kernel attributes, allocator pools
+    side.wait_stream(torch.cuda.current_stream())  # the inputs are produced on the current stream
+    with torch.cuda.stream(side):  # warm-up off the default stream: kernel attributes, allocator pools
         for _ in range(2):
             ops.segment_matmul(x, ptr, w, bias)
     torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
     if variant is not None:
         assert ops.matmul_last_variant() == variant
     graph = torch.cuda.CUDAGraph()
