@@ -111,24 +111,32 @@ static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const
   const size_t G = input.size();
   std::vector<Tensor> outs;
   if (G == 0) return outs;
-  at::CheckedFrom c{"grouped_matmul"};
-  std::vector<std::string> names;  // keep the TensorArg names alive
-  names.reserve(2 * G);
-  for (size_t i = 0; i < G; ++i) {
-    names.push_back("input[" + std::to_string(i) + "]");
-    names.push_back("other[" + std::to_string(i) + "]");
+  // The reference's argument checks (TensorArg messages naming the offending list entry).  With 512 groups, building
+  // 1024 names and TensorArgs up front cost more host time than anything else in the call: look first, and go through
+  // the naming checks only when something is wrong (they then raise the reference's message).
+  bool plain = input[0].defined();
+  for (size_t i = 0; plain && i < G; ++i) {
+    const Tensor& a = input[i];
+    const Tensor& o = other[i];
+    plain = a.defined() && o.defined() && a.scalar_type() == input[0].scalar_type() &&
+            o.scalar_type() == input[0].scalar_type() && a.dim() == 2 && o.dim() == 2 && o.size(0) == a.size(1) &&
+            a.is_cuda() && o.is_cuda();
   }
-  for (size_t i = 0; i < G; ++i) {
-    at::TensorArg a{input[i], names[2 * i].c_str(), 0};
-    at::TensorArg o{other[i], names[2 * i + 1].c_str(), 1};
-    at::checkDefined(c, a);
-    at::checkDefined(c, o);
-    at::checkScalarType(c, a, input[0].scalar_type());
-    at::checkScalarType(c, o, input[0].scalar_type());
-    at::checkDim(c, a, 2);
-    at::checkDim(c, o, 2);
-    at::checkSize(c, o, 0, a->size(-1));
-    TORCH_CHECK(input[i].is_cuda() && other[i].is_cuda(), "grouped_matmul: tensors must live on a HIP device");
+  if (!plain) {
+    at::CheckedFrom c{"grouped_matmul"};
+    for (size_t i = 0; i < G; ++i) {
+      const std::string na = "input[" + std::to_string(i) + "]", no = "other[" + std::to_string(i) + "]";
+      at::TensorArg a{input[i], na.c_str(), 0};
+      at::TensorArg o{other[i], no.c_str(), 1};
+      at::checkDefined(c, a);
+      at::checkDefined(c, o);
+      at::checkScalarType(c, a, input[0].scalar_type());
+      at::checkScalarType(c, o, input[0].scalar_type());
+      at::checkDim(c, a, 2);
+      at::checkDim(c, o, 2);
+      at::checkSize(c, o, 0, a->size(-1));
+      TORCH_CHECK(input[i].is_cuda() && other[i].is_cuda(), "grouped_matmul: tensors must live on a HIP device");
+    }
   }
   DeviceGuard guard(input[0].device());
   std::vector<pyg_hip_group> groups(G);
@@ -207,35 +215,42 @@ static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const
   } else {
     pool = at::empty({std::max<int64_t>(total, 1)}, input[0].options());
   }
-  // aliases of the pool that are NOT tracked as views (see above)
-  at::AutoDispatchBelowADInplaceOrView untracked;
+  char* const pool_base = static_cast<char*>(pool.data_ptr());
   for (size_t i = 0; i < G; ++i) {
-    auto a = input[i].contiguous();
+    Tensor a = input[i];
+    if (!a.is_contiguous()) {
+      a = a.contiguous();
+      keep.push_back(a);
+    }
     Tensor o = other[i];
     int trans = 0;
     if (!o.is_contiguous()) {
       // a transposed view (backward pass, pyg_lib/ops/__init__.py:84,91) is read in place
-      if (o.t().is_contiguous()) trans = 1;
-      else o = o.contiguous();
+      if (o.t().is_contiguous()) {
+        trans = 1;
+      } else {
+        o = o.contiguous();
+        keep.push_back(o);
+      }
     }
-    // one dispatcher call per output (512 groups: the operator front is the bottleneck, not the kernel)
-    auto out = pool.as_strided({a.size(0), other[i].size(-1)}, {other[i].size(-1), 1}, offs[i]);
     groups[i].input = a.data_ptr();
     groups[i].other = o.data_ptr();
-    groups[i].out = out.data_ptr();
+    groups[i].out = pool_base + offs[i] * elt;
     groups[i].rows = a.size(0);
     groups[i].k = (int32_t)a.size(1);
     groups[i].m = (int32_t)other[i].size(-1);
     groups[i].other_trans = trans;
     groups[i].reserved = 0;
-    keep.push_back(a);
-    keep.push_back(o);
-    outs.push_back(out);
   }
   auto ws = at::empty({(int64_t)pyg_hip_matmul_workspace_size((int64_t)G)},
                       input[0].options().dtype(at::kByte));
   check_status(pyg_hip_grouped_matmul(dtype_code(input[0].scalar_type()), groups.data(), (int64_t)G,
                                       ws.data_ptr(), (size_t)ws.numel(), current_stream(input[0])));
+  // the outputs: one dispatcher call each, made while the kernel runs (aliases of the pool that are NOT tracked as
+  // views, see above)
+  at::AutoDispatchBelowADInplaceOrView untracked;
+  for (size_t i = 0; i < G; ++i)
+    outs.push_back(pool.as_strided({input[i].size(0), other[i].size(-1)}, {other[i].size(-1), 1}, offs[i]));
   return outs;
 }
 
