@@ -126,7 +126,12 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  *      6.1 - 6.2 TB/s on either placement;
  *   4  (measurement only) every bf16 / f16 / f32 call through the general-shape MFMA kernel (matmul_gen.hip), also the
  *      shapes that have a specialised kernel;
- *   5  (measurement only) every call through the one-thread-per-output kernel.
+ *   5  (measurement only) every call through the one-thread-per-output kernel;
+ *   6  the item-ring kernels (matmul_ring.hip): W slices in registers, X tiles and W chunks through one LDS-DMA ring --
+ *      what mode 0 picks for many short relations (16-bit: fewer than 4096 rows per relation on average: 5.0 - 5.4
+ *      TB/s at any segment length, where the ticket kernel falls to 3.0 at 256 rows; fp32 split-bf16: fewer than 512).
+ *      Bit-identical to modes 1 - 3 (same k order per output element).
+ * In mode 0 the ticket schedule is also what long relations get (>= 4096 rows on average).
  * 16-bit K = M = 256 (three kernels): 0 = W in registers + LDS-DMA item ring (mfma_rows_k256_regw_kernel, default),
  * 1 = W in LDS, 32 rows per wave (mfma_rows_wide256_kernel), 2 / 3 = W in LDS, 64 rows per wave
  * (mfma_rows_wide256r2_kernel).
@@ -138,11 +143,11 @@ PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
  *      bits; the split is exact to 2^-27 relative) and the six leading cross products run on v_mfma_f32_32x32x16_bf16
  *      with fp32 accumulation.  Dropped terms: 2^-26 |x||w| per product at most, unbiased -- below the rounding unit
  *      of an fp32 multiply-add.  2.7x less matrix time than mode 0: the kernel is HBM-bound.
- *   0  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): bound by the fp32 matrix rate (157 TFLOP/s).
  *      Range: an operand whose magnitude exceeds the largest bf16 (3.39e38) rounds to infinity in its first term (NaN
  *      where the fp32 MFMA gives a finite product), and the third terms of operands below ~2^-100 fall into the bf16
  *      denormals the matrix unit flushes (their products keep 16 instead of 24 bits): data outside 2^-100 ... 2^127
  *      wants mode 0.
+ *   0  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): bound by the fp32 matrix rate (157 TFLOP/s).
  * Both meet the fp32 parity bar (relative Frobenius error <= 1e-5 against float64; measured ~1e-7 either way).  The
  * reference multiplies fp32 on CUTLASS SIMT FMAs, or on TF32 tensor ops (10-bit mantissa products) when torch's
  * float32 matmul precision allows (ops/cuda/matmul_kernel.cu:157-262); both modes here are at full fp32 accuracy. */
