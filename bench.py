@@ -176,15 +176,31 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
     ap.add_argument('--schedule', default='auto', choices=['auto', 'contiguous', 'cyclic', 'ticket'],
-                    help='tile schedule of the bf16 kernel (pyg_hip_matmul_set_schedule)')
+                    help='tile schedule of the bf16 kernel (PYG_HIP_MM_SCHED_* of pyg_hip.h)')
     ap.add_argument('--debug-one-device', action='store_true',
                     help='debug only: all ranks share cuda:0 over gloo (exercises the N>1 code path on a 1-GPU box)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks, one per GPU (what the driver's own
+        # `python -m torch.distributed.run ... bench.py --gpus N` command does)
+        have = torch.cuda.device_count()
+        if not args.debug_one_device and have < args.gpus:
+            sys.exit(f'bench.py: --gpus {args.gpus} asked for, but only {have} HIP device(s) are visible')
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(sys.executable, cmd, env)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     import torch.distributed as dist
     distributed = world > 1
     if args.debug_one_device:

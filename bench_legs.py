@@ -192,25 +192,25 @@ def leg_segment_short(device, rows=1 << 22, seg_rows=256, F=128, dtype=torch.bfl
 
 
 def leg_segment_matmul_f32(device, make_c2, iters=5):
-    """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  Default arithmetic: split-bf16 (three bf16
-    terms per operand, six bf16 MFMAs per 16 k, fp32 accumulation -- products exact to 2^-26, see
-    `pyg_hip_matmul_set_f32_split`), whose matrix time is 2.7x below that of v_mfma_f32_32x32x2_f32: the bound is HBM.
-    `exact` = the same call through the fp32 MFMA kernel (AI = 32 flop/B is above the fp32 ridge of 157 TF / 8 TB/s = 20,
-    so that one is bound by the fp32 matrix rate)."""
+    """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  `exact` = torch's default precision
+    ('highest'): IEEE fp32 MFMAs (AI = 32 flop/B is above the fp32 ridge of 157 TF / 8 TB/s = 20, so that kernel is bound by
+    the fp32 matrix rate).  The top-level figures = torch.set_float32_matmul_precision('high'), the setting under which the
+    reference switches to TF32: here split-bf16 (three bf16 terms per operand, six bf16 MFMAs per 16 k, fp32 accumulation --
+    products exact to 2^-26, PYG_HIP_MM_F32_SPLIT in pyg_hip.h), whose matrix time is 2.7x lower: the bound is HBM."""
     from pyg_lib_amd import ops
     x, ptr, w, (N, B, F) = make_c2(device, 0, 1, torch.float32, 1.0)
     alg = 4 * (2 * N * F + B * F * F) + 8 * (B + 1)
     flop = 2.0 * N * F * F
-    try:
-        ops.set_matmul_f32_split(False)
+    with ops.matmul_f32_split(False):  # torch's default precision ('highest')
         ms_e = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
         kern_e = ops.matmul_last_variant()
-    finally:
-        ops.set_matmul_f32_split(True)
-    ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
+    with ops.matmul_f32_split(True):   # torch.set_float32_matmul_precision('high')
+        ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
+        kern_s = ops.matmul_last_variant()
     tf, tf_e = flop / (ms * 1e-3) / 1e12, flop / (ms_e * 1e-3) / 1e12
     gbps = alg / (ms * 1e-3) / 1e9
-    return dict(workload='segment_matmul C2 in fp32 (154 relations, 21,111,007 rows, F=128)', kernel=ops.matmul_last_variant(),
+    return dict(workload='segment_matmul C2 in fp32 (154 relations, 21,111,007 rows, F=128)', kernel=kern_s,
+                precision="torch float32_matmul_precision 'high' (split-bf16); `exact` = 'highest', torch's default",
                 bound='hbm', achieved=round(gbps, 1), peak=8000.0, unit='GB/s', frac=round(gbps / 8000.0, 4),
                 kernel_ms=round(ms, 4), alg_bytes=int(alg), tflops=round(tf, 1), vs_f32_mfma_peak=round(tf / 157.0, 4),
                 exact=dict(kernel=kern_e, bound='mfma', achieved=round(tf_e, 1), peak=157.0, unit='TFLOP/s',

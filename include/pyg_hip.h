@@ -65,6 +65,59 @@ PYG_HIP_API const char* pyg_hip_arch(void);
 
 /* ---- segment_matmul / grouped_matmul ------------------------------------------------------ */
 
+/*
+ * Per-call mode of pyg_hip_segment_matmul / pyg_hip_grouped_matmul (`flags` argument; 0 = defaults).  The mode is an
+ * argument, not process state: calls in flight on different threads (autograd workers next to the main thread) never
+ * see each other's choice -- the reference keeps its launch state in unlocked process globals
+ * (ops/cuda/matmul_kernel.cu:19,118-119); this build does not.
+ *
+ * Bits 0-3: tile schedule / kernel family (PYG_HIP_MM_SCHED_*); every choice gives the same bits per output element
+ * for the 16-bit types (same k order), they differ in speed only.
+ *   AUTO        (default) the ticket schedule once every CU has several tiles to sweep, the item ring for many short
+ *               relations (16-bit: fewer than 4096 rows per relation on average; fp32 split-bf16: fewer than 512),
+ *               contiguous ranges below that;
+ *   CONTIGUOUS  one contiguous tile range per workgroup (mfma_rows_lds_kernel): up to 6.1 TB/s on C2 when the
+ *               allocator happened to place input and output favourably, 5.0 TB/s otherwise;
+ *   CYCLIC      banded cyclic (mfma_rows_cyc_kernel): 6.2 - 6.3 TB/s on favourably placed buffers, 5.4 - 5.6 otherwise;
+ *   TICKET      tiles drawn in address order from per-XCD counters, W in registers (mfma_rows_ticket_kernel):
+ *               6.1 - 6.2 TB/s on either placement;
+ *   GENERAL     (measurement only) every bf16 / f16 / f32 call through the general-shape MFMA kernel (matmul_gen.hip),
+ *               also the shapes that have a specialised kernel;
+ *   NAIVE       (measurement only) every call through the one-thread-per-output kernel;
+ *   RING        the item-ring kernels (matmul_ring.hip): W slices in registers, X tiles and W chunks through one
+ *               LDS-DMA ring: 5.0 - 5.4 TB/s at any segment length, where the ticket kernel falls to 3.0 at 256 rows.
+ * 16-bit K = M = 256 has three kernels: AUTO / RING = W in registers + LDS-DMA item ring (mfma_rows_k256_regw_kernel),
+ * CONTIGUOUS = W in LDS, 32 rows per wave (mfma_rows_wide256_kernel), CYCLIC / TICKET = W in LDS, 64 rows per wave
+ * (mfma_rows_wide256r2_kernel).  The reference has no counterpart (its CUTLASS problem visitor is fixed,
+ * ops/cuda/matmul_kernel.cu:121-287).
+ *
+ * Bit 8, PYG_HIP_MM_F32_SPLIT: arithmetic of the fp32 K = 128, M % 128 == 0 kernels.
+ *   clear (default)  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): IEEE fp32 products and sums, Inf / NaN / the
+ *      whole fp32 range behave as in the reference's CPU kernel; bound by the fp32 matrix rate (157 TFLOP/s).
+ *   set   split-bf16: every fp32 operand is split, round-to-nearest, into three bf16 terms (8 + 8 + 8 significant
+ *      bits; the split is exact to 2^-27 relative) and the six leading cross products run on v_mfma_f32_32x32x16_bf16
+ *      with fp32 accumulation.  Dropped terms: 2^-26 |x||w| per product at most, unbiased -- below the rounding unit
+ *      of an fp32 multiply-add; 2.7x less matrix time: the kernel is HBM-bound.  Special values: a NaN operand gives
+ *      NaN as it must; a +-Inf operand, or a finite one beyond the largest bf16 (|v| > 3.3895e38), gives NaN in every
+ *      output it feeds (first term Inf, residual Inf - Inf) where the exact kernel gives +-Inf / a finite product;
+ *      third terms of operands below ~2^-100 fall into the bf16 denormals the matrix unit flushes (those products keep
+ *      16 instead of 24 bits).  This is the reduced-guarantee mode in the sense of the reference's TF32 switch: the
+ *      torch binding sets the bit only when at::globalContext().float32MatmulPrecision() != HIGHEST, the rule of
+ *      ops/cuda/matmul_kernel.cu:158-165 (torch's default is HIGHEST, i.e. the bit is clear unless the user called
+ *      torch.set_float32_matmul_precision('high' | 'medium')).  Unlike TF32 the mode keeps full fp32 accuracy on
+ *      finite data inside 2^-100 ... 2^127 (relative Frobenius error ~1e-7 against float64, as the exact kernel).
+ * Any other bit set: PYG_HIP_ERR_INVALID.
+ */
+#define PYG_HIP_MM_SCHED_AUTO 0
+#define PYG_HIP_MM_SCHED_CONTIGUOUS 1
+#define PYG_HIP_MM_SCHED_CYCLIC 2
+#define PYG_HIP_MM_SCHED_TICKET 3
+#define PYG_HIP_MM_SCHED_GENERAL 4
+#define PYG_HIP_MM_SCHED_NAIVE 5
+#define PYG_HIP_MM_SCHED_RING 6
+#define PYG_HIP_MM_SCHED_MASK 0xf
+#define PYG_HIP_MM_F32_SPLIT 0x100
+
 /* Workspace (device bytes) needed by pyg_hip_segment_matmul / pyg_hip_grouped_matmul for
  * `num_groups` segments/groups. */
 PYG_HIP_API size_t pyg_hip_matmul_workspace_size(int64_t num_groups);
@@ -80,13 +133,14 @@ PYG_HIP_API size_t pyg_hip_matmul_workspace_size(int64_t num_groups);
  *          reference no host synchronisation happens in either case.
  *   bias   optional [B, M] (may be NULL): fused epilogue for the Python-side loop
  *          pyg_lib/ops/__init__.py:169-171.
+ *   flags  PYG_HIP_MM_* above (0 = automatic schedule, exact fp32).
  *   Rows outside [ptr[0], ptr[B]) are left untouched (the reference leaves them
  *   uninitialised, matmul_kernel.cpp:416).
  */
 PYG_HIP_API int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr,
                                        int ptr_on_device, const void* other, const void* bias,
                                        void* out, int64_t N, int64_t K, int64_t M, int64_t B,
-                                       void* workspace, size_t workspace_bytes, void* stream);
+                                       void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /* One group of a grouped matmul: out[rows, m] = input[rows, k] @ other[k, m].
  * `other_trans` != 0 means `other` is stored [m, k] row-major (a transposed view, as produced
@@ -110,48 +164,11 @@ typedef struct {
  * descriptors (copied asynchronously into the workspace).
  */
 PYG_HIP_API int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups_host, int64_t G,
-                                       void* workspace, size_t workspace_bytes, void* stream);
+                                       void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /* Name of the kernel variant the last matmul call on this thread dispatched to
  * ("mfma_bf16_k128_m128", "naive", ...): lets tests assert that the MFMA path ran. */
 PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
-
-/* Tile schedule of the 16-bit K = M = 128 segment/grouped matmul kernels (process wide):
- *   0  automatic (default): the ticket schedule once every CU has several tiles to sweep, contiguous ranges
- *      below that;
- *   1  contiguous tile range per workgroup (mfma_rows_lds_kernel): up to 6.1 TB/s on C2 when the allocator happened
- *      to place input and output favourably, 5.0 TB/s otherwise;
- *   2  banded cyclic (mfma_rows_cyc_kernel): 6.2 - 6.3 TB/s on favourably placed buffers, 5.4 - 5.6 otherwise;
- *   3  tickets (mfma_rows_ticket_kernel): tiles drawn in address order from per-XCD counters, W in registers:
- *      6.1 - 6.2 TB/s on either placement;
- *   4  (measurement only) every bf16 / f16 / f32 call through the general-shape MFMA kernel (matmul_gen.hip), also the
- *      shapes that have a specialised kernel;
- *   5  (measurement only) every call through the one-thread-per-output kernel;
- *   6  the item-ring kernels (matmul_ring.hip): W slices in registers, X tiles and W chunks through one LDS-DMA ring --
- *      what mode 0 picks for many short relations (16-bit: fewer than 4096 rows per relation on average: 5.0 - 5.4
- *      TB/s at any segment length, where the ticket kernel falls to 3.0 at 256 rows; fp32 split-bf16: fewer than 512).
- *      Bit-identical to modes 1 - 3 (same k order per output element).
- * In mode 0 the ticket schedule is also what long relations get (>= 4096 rows on average).
- * 16-bit K = M = 256 (three kernels): 0 = W in registers + LDS-DMA item ring (mfma_rows_k256_regw_kernel, default),
- * 1 = W in LDS, 32 rows per wave (mfma_rows_wide256_kernel), 2 / 3 = W in LDS, 64 rows per wave
- * (mfma_rows_wide256r2_kernel).
- * The reference has no counterpart (its CUTLASS problem visitor is fixed, ops/cuda/matmul_kernel.cu:121-287). */
-PYG_HIP_API void pyg_hip_matmul_set_schedule(int mode);
-
-/* Arithmetic of the fp32 K = 128, M % 128 == 0 segment/grouped matmul (process wide):
- *   1  (default) split-bf16: every fp32 operand is split, round-to-nearest, into three bf16 terms (8 + 8 + 8 significant
- *      bits; the split is exact to 2^-27 relative) and the six leading cross products run on v_mfma_f32_32x32x16_bf16
- *      with fp32 accumulation.  Dropped terms: 2^-26 |x||w| per product at most, unbiased -- below the rounding unit
- *      of an fp32 multiply-add.  2.7x less matrix time than mode 0: the kernel is HBM-bound.
- *      Range: an operand whose magnitude exceeds the largest bf16 (3.39e38) rounds to infinity in its first term (NaN
- *      where the fp32 MFMA gives a finite product), and the third terms of operands below ~2^-100 fall into the bf16
- *      denormals the matrix unit flushes (their products keep 16 instead of 24 bits): data outside 2^-100 ... 2^127
- *      wants mode 0.
- *   0  v_mfma_f32_32x32x2_f32 (mfma_rows_f32_pipe_kernel): bound by the fp32 matrix rate (157 TFLOP/s).
- * Both meet the fp32 parity bar (relative Frobenius error <= 1e-5 against float64; measured ~1e-7 either way).  The
- * reference multiplies fp32 on CUTLASS SIMT FMAs, or on TF32 tensor ops (10-bit mantissa products) when torch's
- * float32 matmul precision allows (ops/cuda/matmul_kernel.cu:157-262); both modes here are at full fp32 accuracy. */
-PYG_HIP_API void pyg_hip_matmul_set_f32_split(int on);
 
 /*
  * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]

@@ -52,18 +52,29 @@ def lib() -> ctypes.CDLL:
         L.pyg_hip_matmul_workspace_size.restype = c.c_size_t
         L.pyg_hip_matmul_workspace_size.argtypes = [c.c_int64]
         L.pyg_hip_matmul_last_variant.restype = c.c_char_p
-        L.pyg_hip_matmul_set_schedule.restype = None
-        L.pyg_hip_matmul_set_schedule.argtypes = [c.c_int]
-        L.pyg_hip_matmul_set_f32_split.restype = None
-        L.pyg_hip_matmul_set_f32_split.argtypes = [c.c_int]
         L.pyg_hip_segment_matmul.restype = c.c_int
         L.pyg_hip_segment_matmul.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p,
                                              c.c_void_p, c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p,
-                                             c.c_size_t, c.c_void_p]
+                                             c.c_size_t, c.c_int, c.c_void_p]
         L.pyg_hip_grouped_matmul.restype = c.c_int
-        L.pyg_hip_grouped_matmul.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p]
+        L.pyg_hip_grouped_matmul.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_size_t, c.c_int, c.c_void_p]
         _LIB = L
     return _LIB
+
+
+_BINDING = None
+
+
+def binding() -> ctypes.CDLL:
+    """libpyg.so (the torch operator library) through ctypes, for its two non-operator hooks."""
+    global _BINDING
+    if _BINDING is None:
+        L = ctypes.CDLL(osp.join(_HERE, 'libpyg.so'))
+        L.pyg_binding_set_matmul_schedule.restype = None
+        L.pyg_binding_set_matmul_schedule.argtypes = [ctypes.c_int]
+        L.pyg_binding_get_matmul_schedule.restype = ctypes.c_int
+        _BINDING = L
+    return _BINDING
 
 
 def check(rc: int) -> None:

@@ -84,5 +84,12 @@ inline void* current_stream(const Tensor& t) {
   return static_cast<void*>(current_hip_stream((c10::DeviceIndex)t.get_device()));
 }
 
+// `flags` of pyg_hip_segment_matmul / pyg_hip_grouped_matmul (include/pyg_hip.h) for a call made on this thread:
+//  * the tile schedule is a thread-local of the binding (set through pyg_binding_set_matmul_schedule, a test /
+//    measurement hook; SegmentMatmul carries the forward's value into its backward, which runs on an autograd thread);
+//  * fp32 arithmetic follows torch's switch exactly as the reference does (ops/cuda/matmul_kernel.cu:158-165):
+//    float32MatmulPrecision() == HIGHEST (torch's default) -> IEEE fp32 MFMAs, anything else -> the split-bf16 kernels.
+int& matmul_schedule_tls();
+int matmul_flags(at::ScalarType t);
 
 }  // namespace pyg_amd

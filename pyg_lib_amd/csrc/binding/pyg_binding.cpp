@@ -47,6 +47,24 @@ inline rel_type to_rel_type(const edge_type& key) {
 // ---------------------------------------------------------------------------------------------
 int64_t cuda_version() { return pyg_hip_version(); }
 
+int& matmul_schedule_tls() {
+  static thread_local int sched = PYG_HIP_MM_SCHED_AUTO;
+  return sched;
+}
+
+int matmul_flags(at::ScalarType t) {
+  int flags = matmul_schedule_tls() & PYG_HIP_MM_SCHED_MASK;
+  if (t == at::kFloat && at::globalContext().float32MatmulPrecision() != at::Float32MatmulPrecision::HIGHEST)
+    flags |= PYG_HIP_MM_F32_SPLIT;
+  return flags;
+}
+
+struct ScheduleGuard {
+  int prev;
+  explicit ScheduleGuard(int s) : prev(matmul_schedule_tls()) { matmul_schedule_tls() = s; }
+  ~ScheduleGuard() { matmul_schedule_tls() = prev; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // matmul  (front: pyg_lib/csrc/ops/matmul.cpp:12-61, kernels: ops/cuda/matmul_kernel.cu:289-319)
 // ---------------------------------------------------------------------------------------------
@@ -85,7 +103,8 @@ static Tensor segment_matmul_impl(const Tensor& input, const Tensor& ptr, const 
   check_status(pyg_hip_segment_matmul(dtype_code(x.scalar_type()), x.data_ptr(), p.data_ptr<int64_t>(),
                                       p.is_cuda() ? 1 : 0, w.data_ptr(),
                                       b.defined() ? b.data_ptr() : nullptr, out.data_ptr(), N, K, M, B,
-                                      ws.data_ptr(), (size_t)ws.numel(), current_stream(x)));
+                                      ws.data_ptr(), (size_t)ws.numel(), matmul_flags(x.scalar_type()),
+                                      current_stream(x)));
   return out;
 }
 
@@ -245,7 +264,8 @@ static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const
   auto ws = at::empty({(int64_t)pyg_hip_matmul_workspace_size((int64_t)G)},
                       input[0].options().dtype(at::kByte));
   check_status(pyg_hip_grouped_matmul(dtype_code(input[0].scalar_type()), groups.data(), (int64_t)G,
-                                      ws.data_ptr(), (size_t)ws.numel(), current_stream(input[0])));
+                                      ws.data_ptr(), (size_t)ws.numel(), matmul_flags(input[0].scalar_type()),
+                                      current_stream(input[0])));
   // the outputs: one dispatcher call each, made while the kernel runs (aliases of the pool that are NOT tracked as
   // views, see above)
   at::AutoDispatchBelowADInplaceOrView untracked;
@@ -421,6 +441,7 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
     at::AutoDispatchBelowADInplaceOrView g;
     Tensor out = segment_matmul_below_autograd(input, ptr, other);
     ctx->save_for_backward({input, ptr, other});
+    ctx->saved_data["sched"] = (int64_t)matmul_schedule_tls();
     return {out};
   }
 
@@ -429,6 +450,7 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
     const auto grad_out = grad_outs[0];
     const auto saved = ctx->get_saved_variables();
     const auto input = saved[0], ptr = saved[1], other = saved[2];
+    ScheduleGuard sched((int)ctx->saved_data["sched"].toInt());
     Tensor input_grad, other_grad;
     if (torch::autograd::any_variable_requires_grad({input})) {
       // dX = segment_matmul(dY, ptr, W^T)
@@ -939,3 +961,12 @@ TORCH_LIBRARY_IMPL(pyg, BackendSelect, m) {
 }
 
 }  // namespace pyg_amd
+
+// Test / measurement hook of libpyg.so (not an operator): tile schedule of the matmul calls made from the calling
+// thread (PYG_HIP_MM_SCHED_* of include/pyg_hip.h), returned to automatic by 0.  Thread-local by design.
+extern "C" __attribute__((visibility("default"))) void pyg_binding_set_matmul_schedule(int mode) {
+  pyg_amd::matmul_schedule_tls() = (mode >= 0 && mode <= PYG_HIP_MM_SCHED_RING) ? mode : PYG_HIP_MM_SCHED_AUTO;
+}
+extern "C" __attribute__((visibility("default"))) int pyg_binding_get_matmul_schedule(void) {
+  return pyg_amd::matmul_schedule_tls();
+}

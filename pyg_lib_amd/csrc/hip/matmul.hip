@@ -2312,10 +2312,20 @@ thread_local const char* g_last_variant = "";
 // Optional per-launch timing of the dominant kernel (bench.py roofline leg): when enabled, a pair of
 // HIP events brackets the main kernel on the stream it is launched on.
 struct ProfPair { hipEvent_t a, b; };
-// tile schedule of the 16-bit K = M = 128 kernels: 0 = automatic, 1 = contiguous ranges, 2 = cyclic
-int g_schedule = 0;
-// fp32 K = 128, M % 128 == 0: 1 = split-bf16 arithmetic (default), 0 = v_mfma_f32_32x32x2_f32
-int g_f32_split = 1;
+// The mode of the call in flight on this thread, decoded from the entry point's `flags` argument (pyg_hip.h): nothing
+// here outlives a call, so two threads with different modes never see each other's choice.
+// tile schedule (PYG_HIP_MM_SCHED_*): 0 = automatic, 1 = contiguous ranges, 2 = cyclic, ...
+thread_local int g_schedule = 0;
+// fp32 K = 128, M % 128 == 0: 1 = split-bf16 arithmetic (PYG_HIP_MM_F32_SPLIT), 0 = v_mfma_f32_32x32x2_f32
+thread_local int g_f32_split = 0;
+
+inline int decode_mode(int flags) {
+  const int sched = flags & PYG_HIP_MM_SCHED_MASK;
+  if (sched > PYG_HIP_MM_SCHED_RING || (flags & ~(PYG_HIP_MM_SCHED_MASK | PYG_HIP_MM_F32_SPLIT)) != 0) return -1;
+  g_schedule = sched;
+  g_f32_split = (flags & PYG_HIP_MM_F32_SPLIT) ? 1 : 0;
+  return 0;
+}
 // 16-bit K = M = 128: relations shorter than this on average take the item-ring kernel (automatic schedule)
 constexpr int64_t kRingMeanRows = 4096;
 thread_local bool g_prof_on = false;
@@ -2524,7 +2534,7 @@ int dispatch_mfma(const char* tname, const Workspace& w, int B, int K, int M, in
       if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
       const DeviceInfo& di = device_info();
       const int ncol = M / 256;
-      if (ncol == 1 && g_schedule == 0) {
+      if (ncol == 1 && (g_schedule == 0 || g_schedule == 6)) {
         // W in registers, X tiles by LDS-DMA, two four-wave workgroups per CU
         snprintf(name, sizeof(name), "mfma_%s_k256_regw", tname);
         g_last_variant = name;
@@ -2760,10 +2770,6 @@ size_t pyg_hip_matmul_workspace_size(int64_t num_groups) {
 
 const char* pyg_hip_matmul_last_variant(void) { return g_last_variant; }
 
-void pyg_hip_matmul_set_schedule(int mode) { g_schedule = (mode >= 1 && mode <= 6) ? mode : 0; }
-
-void pyg_hip_matmul_set_f32_split(int on) { g_f32_split = on != 0; }
-
 void pyg_hip_profile_enable(int on) {
   g_prof_on = on != 0;
   if (!g_prof_on) {
@@ -2793,10 +2799,11 @@ int pyg_hip_profile_collect(float* ms_out, int capacity) {
 int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,
                            const void* other, const void* bias, void* out, int64_t N, int64_t K,
                            int64_t M, int64_t B, void* workspace, size_t workspace_bytes_,
-                           void* stream_) {
+                           int flags, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const size_t elt = dtype_size(dtype);
   PYG_HIP_REQUIRE(elt != 0, "segment_matmul: unknown dtype %d", dtype);
+  PYG_HIP_REQUIRE(decode_mode(flags) == 0, "segment_matmul: unknown bits in 'flags' (0x%x)", flags);
   PYG_HIP_REQUIRE(N >= 0 && K >= 0 && M >= 0 && B >= 0, "segment_matmul: negative size");
   PYG_HIP_REQUIRE(ptr != nullptr, "segment_matmul: 'ptr' is NULL");
   PYG_HIP_REQUIRE(B < (1LL << 31), "segment_matmul: too many segments");
@@ -2847,10 +2854,11 @@ int pyg_hip_segment_matmul(int dtype, const void* input, const int64_t* ptr, int
 }
 
 int pyg_hip_grouped_matmul(int dtype, const pyg_hip_group* groups, int64_t G, void* workspace,
-                           size_t workspace_bytes_, void* stream_) {
+                           size_t workspace_bytes_, int flags, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const size_t elt = dtype_size(dtype);
   PYG_HIP_REQUIRE(elt != 0, "grouped_matmul: unknown dtype %d", dtype);
+  PYG_HIP_REQUIRE(decode_mode(flags) == 0, "grouped_matmul: unknown bits in 'flags' (0x%x)", flags);
   PYG_HIP_REQUIRE(G >= 0 && G < (1LL << 31), "grouped_matmul: bad group count");
   g_last_variant = "none";
   if (G == 0) return PYG_HIP_OK;

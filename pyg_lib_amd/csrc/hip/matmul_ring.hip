@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevG
       // always 4 stores (the waits count them): rows behind the segment end rewrite its last row with its own data.  An
       // empty second half (`left` <= 0) has multiplied the segment's last row 32 times (issue_item clamps to it) and
       // stores it again: LDS row 0, global row `last` < 0 relative to the half.  The results are read out of the ring
-      // slot BEFORE its refill is issued: a wave's DMA writes exactly the 8 rows it reads here.
+      // slot BEFORE its refill is issued.
       {
         const int last = left < 32 ? (int)left - 1 : 31;
         char* cbase = c_out + row0 * 512;
@@ -918,6 +918,10 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevG
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ov[i]));  // the reads have returned
+        // a whole tile: a wave's DMA writes exactly the 8 rows it has just read.  A partial tile clamps rows beyond the
+        // segment end to row `last` (or 0), which lies in ANOTHER wave's DMA region: every wave's reads must have
+        // returned before anybody refills (`left` is uniform over the workgroup)
+        if (left < 32) __syncthreads();
         issue_item();
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(ov[i], (GU32x4*)(cbase + goff[i]));
@@ -929,8 +933,6 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_f32x3_regw_kernel(const DevG
     }
   }
 }
-
-
 
 
 template <typename T>

@@ -6,6 +6,8 @@ device -- there is no CPU kernel and no Triton path in this package.
 """
 from typing import List, Optional, Tuple
 
+import contextlib
+
 import torch
 from torch import Tensor
 
@@ -350,26 +352,43 @@ def matmul_last_variant() -> str:
     return _capi.lib().pyg_hip_matmul_last_variant().decode()
 
 
+_SCHEDULES = {'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3, 'general': 4, 'naive': 5, 'ring': 6}
+
+
 def set_matmul_schedule(mode: str = 'auto') -> None:
-    """Tile schedule of the 16-bit ``K = M = 128`` matmul kernels: ``'auto'`` (default), ``'contiguous'`` (one
-    tile range per workgroup), ``'cyclic'`` (every XCD sweeps its band of tiles) or ``'ticket'`` (tiles drawn in
-    address order from per-XCD counters, W in registers) -- see ``pyg_hip_matmul_set_schedule`` in
-    include/pyg_hip.h.  ``'general'`` / ``'naive'`` (measurement only) send every floating-point shape through the
-    general-shape MFMA kernel / every call through the one-thread-per-output kernel.  For 16-bit ``K = M = 256`` the
-    ``'ring'`` forces the item-ring kernels (the automatic choice for many short relations: 16-bit ``K = M = 128`` below
-    4096 rows per relation on average, fp32 below 512).  For 16-bit ``K = M = 256`` the
-    same switch selects among that shape's three kernels (``'auto'``: W in registers, ``'contiguous'`` / ``'cyclic'``:
-    W in LDS with 32 / 64 rows per wave).  Process wide."""
-    _capi.lib().pyg_hip_matmul_set_schedule({'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3, 'general': 4,
-                                             'naive': 5, 'ring': 6}[mode])
+    """Tile schedule / kernel family of the matmul calls made FROM THE CALLING THREAD (a test and measurement hook; the
+    backward of a ``segment_matmul`` inherits the schedule its forward ran with).  It becomes the ``PYG_HIP_MM_SCHED_*``
+    bits of the ``flags`` argument of ``pyg_hip_segment_matmul`` / ``pyg_hip_grouped_matmul`` (include/pyg_hip.h):
+
+    * ``'auto'`` (default): ticket schedule for long relations, item ring for many short ones, contiguous ranges for
+      small calls;
+    * 16-bit ``K = M = 128``: ``'contiguous'`` (one tile range per workgroup), ``'cyclic'`` (every XCD sweeps its band of
+      tiles), ``'ticket'`` (tiles drawn in address order from per-XCD counters, W in registers), ``'ring'`` (W slices in
+      registers, X tiles through an LDS-DMA item ring) -- the same bits from each, they differ in speed only;
+    * 16-bit ``K = M = 256``: ``'auto'`` / ``'ring'`` = W in registers + item ring, ``'contiguous'`` = W in LDS with 32
+      rows per wave, ``'cyclic'`` / ``'ticket'`` = W in LDS with 64 rows per wave;
+    * fp32 ``K = M = 128`` in split-bf16 arithmetic: ``'ring'`` forces the register-W ring kernel;
+    * ``'general'`` / ``'naive'`` (measurement only): every floating-point shape through the general-shape MFMA kernel /
+      every call through the one-thread-per-output kernel.
+
+    fp32 arithmetic is not selected here: it follows ``torch.get_float32_matmul_precision()`` as in the reference
+    (``'highest'``, torch's default: IEEE fp32 MFMAs; ``'high'`` / ``'medium'``: the split-bf16 kernels for
+    ``K = 128, M % 128 == 0``)."""
+    _capi.binding().pyg_binding_set_matmul_schedule(_SCHEDULES[mode])
 
 
-def set_matmul_f32_split(on: bool = True) -> None:
-    """fp32 ``K = 128, M % 128 == 0`` matmul arithmetic: ``True`` (default) multiplies through three bf16 planes per
-    operand (6 bf16 MFMAs per 16 k, fp32 accumulation; products exact to 2^-26 relative, i.e. below the fp32 rounding
-    unit -- HBM-bound), ``False`` through ``v_mfma_f32_32x32x2_f32`` (bound by the fp32 matrix rate).  Process wide; see
-    ``pyg_hip_matmul_set_f32_split`` in include/pyg_hip.h."""
-    _capi.lib().pyg_hip_matmul_set_f32_split(1 if on else 0)
+@contextlib.contextmanager
+def matmul_f32_split(on: bool = True):
+    """Context manager over ``torch.set_float32_matmul_precision``: ``True`` -> ``'high'`` (fp32 ``K = 128, M % 128 == 0``
+    matmuls run the split-bf16 kernels: three bf16 planes per operand, fp32 accumulation, HBM-bound), ``False`` ->
+    ``'highest'`` (IEEE fp32 MFMAs; torch's default).  Restores the previous setting on exit.  Note that the switch is
+    torch's own process-wide one -- the same the reference consults (ops/cuda/matmul_kernel.cu:158-165)."""
+    prev = torch.get_float32_matmul_precision()
+    torch.set_float32_matmul_precision('high' if on else 'highest')
+    try:
+        yield
+    finally:
+        torch.set_float32_matmul_precision(prev)
 
 
 __all__ = [

@@ -85,8 +85,9 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     boundaries) is rounded once per run, where ``scatter_sum`` rounds once per destination."""
     total = offsets['__total__']
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
-    if needs_grad or not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and
-                          weight.size(-1) == 128 and x.is_cuda):
+    if needs_grad or not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and weight.dim() == 3 and
+                          weight.size(-1) == 128 and x.is_cuda and weight.dtype == x.dtype and
+                          weight.device == x.device):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:
@@ -115,7 +116,13 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
     f0 = feat_dict[node_types[0]]
     needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feat_dict.values()))
-    ok = f0.is_cuda and f0.dtype in (torch.bfloat16, torch.float16) and f0.size(1) == 128 and weight.size(-1) == 128
+    # every table and the weight: one device, one 16-bit type, F = 128 (anything else: the chain, which checks nothing
+    # more than its own ops do)
+    ok = f0.is_cuda and f0.dtype in (torch.bfloat16, torch.float16) and weight.dim() == 3 and weight.size(-1) == 128 and \
+        weight.dtype == f0.dtype and weight.device == f0.device and \
+        all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
+            for f in (feat_dict[t] for t in node_types)) and \
+        all(node_id_dict[t].device == f0.device and node_id_dict[t].dtype == torch.long for t in node_types)
     if needs_grad or not ok:
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
         return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc)

@@ -28,7 +28,7 @@ def lib():
     L.pyg_hip_matmul_last_variant.restype = c.c_char_p
     L.pyg_hip_segment_matmul.restype = c.c_int
     L.pyg_hip_segment_matmul.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p,
-                                         c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p]
+                                         c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p, c.c_size_t, c.c_int, c.c_void_p]
     L.pyg_hip_index_sort_workspace_size.restype = c.c_size_t
     L.pyg_hip_index_sort_workspace_size.argtypes = [c.c_int, c.c_int64]
     L.pyg_hip_index_sort.restype = c.c_int
@@ -59,7 +59,7 @@ def test_segment_matmul_raw_pointers(lib, ptr_on_device, K, M, dtype):
     stream = torch.cuda.current_stream().cuda_stream
     p = ptr_dev.data_ptr() if ptr_on_device else ptr_host.ctypes.data
     rc = lib.pyg_hip_segment_matmul(PYG_BF16 if dtype == torch.bfloat16 else PYG_F32, xd.data_ptr(), p, ptr_on_device,
-                                    wd.data_ptr(), None, out.data_ptr(), N, K, M, B, ws.data_ptr(), ws_bytes, stream)
+                                    wd.data_ptr(), None, out.data_ptr(), N, K, M, B, ws.data_ptr(), ws_bytes, 0, stream)
     assert rc == 0, lib.pyg_hip_last_error()
     torch.cuda.synchronize()
     assert lib.pyg_hip_matmul_last_variant().startswith(b'mfma_')
@@ -71,8 +71,12 @@ def test_segment_matmul_raw_pointers(lib, ptr_on_device, K, M, dtype):
         assert np.linalg.norm(out.cpu().numpy() - ref) <= 1e-5 * np.linalg.norm(ref)
     # error convention: int status + thread-local message, nothing thrown across the boundary
     rc = lib.pyg_hip_segment_matmul(PYG_F32, xd.data_ptr(), p, ptr_on_device, wd.data_ptr(), None, out.data_ptr(), N, K, M,
-                                    B, ws.data_ptr(), 16, stream)
+                                    B, ws.data_ptr(), 16, 0, stream)
     assert rc != 0 and b'workspace' in lib.pyg_hip_last_error()
+    # unknown mode bits are refused, not ignored
+    rc = lib.pyg_hip_segment_matmul(PYG_F32, xd.data_ptr(), p, ptr_on_device, wd.data_ptr(), None, out.data_ptr(), N, K, M,
+                                    B, ws.data_ptr(), ws_bytes, 0x40, stream)
+    assert rc != 0 and b'flags' in lib.pyg_hip_last_error()
 
 
 @pytest.mark.parametrize('n,max_value', [(0, 10), (1, 10), (32769, 5), (1_000_003, 2_449_029), (300_000, 2 ** 40)])

@@ -75,16 +75,13 @@ def test_ragged_bf16_with_empty_segments(ptr_on_device):
 
 @pytest.mark.parametrize('split', [True, False])
 def test_ragged_fp32_mfma_1e5(split):
-    """Both fp32 arithmetic modes (split-bf16, the default, and v_mfma_f32_32x32x2_f32) against the reference's recorded
+    """Both fp32 arithmetic modes (v_mfma_f32_32x32x2_f32, the default, and split-bf16 under torch's 'high' precision) against the reference's recorded
     fp32 output and the oracle: north_star's 1e-5 bar, met with two orders of magnitude to spare."""
     x = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_x']))
     w = torch.from_numpy(oracle.bf16_bits_to_f32(GOLD['bf_w']))
     ptr = torch.from_numpy(GOLD['bf_ptr'])
-    try:
-        ops.set_matmul_f32_split(split)
+    with ops.matmul_f32_split(split):
         out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV))
-    finally:
-        ops.set_matmul_f32_split(True)
     assert ops.matmul_last_variant() in (('mfma_f32_k128_mc128_x3', 'mfma_f32_k128_regw_x3') if split else ('mfma_f32_k128_mc128',))
     assert rel_fro(out.cpu().numpy(), GOLD['f32r_out']) <= 1e-6
     assert rel_fro(out.cpu().numpy(), oracle.segment_matmul(x.numpy(), GOLD['bf_ptr'], w.numpy())) <= 1e-6
@@ -106,14 +103,15 @@ def test_fp32_split_bf16_register_w_kernel_many_short_segments():
         if trans:
             w = w.transpose(1, 2).contiguous().transpose(1, 2)
         bias = torch.randn(len(sizes), 128, generator=g).to(DEV) if with_bias else None
-        out = ops.segment_matmul(x, ptr, w, bias)
-        assert ops.matmul_last_variant() == 'mfma_f32_k128_regw_x3'
-        try:
-            ops.set_matmul_schedule('contiguous')
-            ref = ops.segment_matmul(x, ptr, w, bias)
-            assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128_x3'
-        finally:
-            ops.set_matmul_schedule('auto')
+        with ops.matmul_f32_split(True):
+            out = ops.segment_matmul(x, ptr, w, bias)
+            assert ops.matmul_last_variant() == 'mfma_f32_k128_regw_x3'
+            try:
+                ops.set_matmul_schedule('contiguous')
+                ref = ops.segment_matmul(x, ptr, w, bias)
+                assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128_x3'
+            finally:
+                ops.set_matmul_schedule('auto')
         want = torch.cat([x[int(ptr[b]):int(ptr[b + 1])].double() @ w[b].double() + (bias[b].double() if with_bias else 0)
                           for b in range(len(sizes))])
         assert (out.double() - want).norm() <= 1e-6 * want.norm()
@@ -137,15 +135,160 @@ def test_fp32_split_bf16_is_as_accurate_as_the_fp32_mfma():
         ref = torch.cat([x[int(ptr[b]):int(ptr[b + 1])].double() @ w[b].double() + bias[b].double() for b in range(len(sizes))])
         errs = {}
         for split in (True, False):
-            try:
-                ops.set_matmul_f32_split(split)
+            with ops.matmul_f32_split(split):
                 out = ops.segment_matmul(x, ptr, w, bias)
-            finally:
-                ops.set_matmul_f32_split(True)
             assert ops.matmul_last_variant().endswith('_x3') == split
             # row-wise: every row has its own scale
             errs[split] = ((out.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
         assert errs[True] <= 1e-6 and errs[True] <= 1.5 * errs[False] + 1e-9, errs
+
+
+def _special_value_case(M, seed):
+    """fp32 K = 128 inputs with IEEE special values at known places; returns (x, ptr, w, rows) where `rows` names the
+    affected rows.  Relation 2's weight holds an Inf, relation 3's a NaN."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = [300, 0, 70, 33, 129, 1]
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n = int(ptr[-1])
+    x = torch.randn(n, 128, generator=g)
+    w = torch.randn(len(sizes), 128, M, generator=g) / 128 ** 0.5
+    rows = dict(pinf=3, ninf=5, both=6, nan=7, huge=9, tiny=11, denorm=12, zero=13, infzero=14)
+    x[rows['pinf'], 17] = float('inf')
+    x[rows['ninf'], 100] = float('-inf')
+    x[rows['both'], 2] = float('inf')
+    x[rows['both'], 90] = float('-inf')
+    x[rows['nan'], 64] = float('nan')
+    x[rows['huge']] = 0
+    x[rows['huge'], 5] = 3.3e38          # beyond the largest bf16 (3.3895e38 rounds up at 3.39e38; 3.3e38 has a bf16 hi term
+    x[rows['huge'], 6] = -3.4e38         # below the limit, -3.4e38 rounds to -Inf in bf16)
+    x[rows['tiny']] *= 1e-38             # around the smallest normal
+    x[rows['denorm']] *= 1e-42           # fp32 denormals
+    x[rows['zero']] = 0
+    x[rows['infzero']] = 0
+    x[rows['infzero'], 40] = float('inf')
+    w[0, 40, 3] = 0.0                    # Inf * 0 = NaN in column 3 of row `infzero`
+    w[0, 5] *= 1e-3                      # keep the huge products finite
+    w[0, 6] *= 1e-3
+    w[2, 8, 1] = float('inf')            # relation 2 (rows 300 .. 369): column 1 is +-Inf / NaN everywhere
+    w[3, 0, 0] = float('nan')            # relation 3 (rows 370 .. 402): column 0 is NaN everywhere
+    return x, ptr, w, rows
+
+
+def _torch_cpu_reference(x, ptr, w):
+    # the call the reference's CPU kernel makes per segment (ops/cpu/matmul_kernel.cpp:195-201)
+    return torch.cat([x[int(ptr[b]):int(ptr[b + 1])] @ w[b] for b in range(w.size(0))])
+
+
+@pytest.mark.parametrize('M', [128, 256, 64])
+@pytest.mark.parametrize('sched', ['auto', 'contiguous'])
+def test_fp32_special_values_exact_mode_matches_the_cpu_reference(M, sched):
+    """torch's default precision ('highest') -> IEEE fp32 MFMAs: the Inf / NaN pattern (with signs) of the output equals
+    the oracle's and the per-segment torch CPU matmul's, huge and tiny operands give the same finite values."""
+    x, ptr, w, rows = _special_value_case(M, 77)
+    assert torch.get_float32_matmul_precision() == 'highest'
+    try:
+        ops.set_matmul_schedule(sched)
+        out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV)).cpu()
+    finally:
+        ops.set_matmul_schedule('auto')
+    assert not ops.matmul_last_variant().endswith('_x3'), ops.matmul_last_variant()
+    ref = torch.from_numpy(oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy()))
+    ref_t = _torch_cpu_reference(x, ptr, w)
+    for r in (ref, ref_t):
+        assert torch.equal(torch.isnan(out), torch.isnan(r))
+        assert torch.equal(torch.isposinf(out), torch.isposinf(r))
+        assert torch.equal(torch.isneginf(out), torch.isneginf(r))
+    # what the pattern must contain
+    assert torch.isinf(out[rows['pinf']]).all() and torch.isinf(out[rows['ninf']]).all()
+    assert torch.isnan(out[rows['both']]).all() and torch.isnan(out[rows['nan']]).all()
+    assert torch.isnan(out[rows['infzero'], 3]) and torch.isinf(out[rows['infzero'], 4])
+    assert torch.isfinite(out[rows['huge']]).all() and out[rows['huge']].abs().max() > 1e34
+    assert (out[rows['zero']] == 0).all()
+    assert not torch.isfinite(out[300:370, 1]).any() and torch.isnan(out[370:403, 0]).all()
+    fin = torch.isfinite(ref)
+    err = (out.double() - ref.double())[fin].abs()
+    scale = (x.double().abs() @ torch.ones(128, 1, dtype=torch.double)).expand_as(ref)[fin].clamp_min(1e-45)
+    assert (err / scale).max() <= 1e-5                       # every finite element, relative to its row's magnitude
+    # denormal and near-denormal rows: the products are exact in fp32 unless the matrix unit flushes denormal inputs;
+    # either way the absolute error stays below ten smallest-normals
+    assert (out[rows['tiny']].double() - ref[rows['tiny']].double()).abs().max() <= 1e-37
+    assert (out[rows['denorm']].double() - ref[rows['denorm']].double()).abs().max() <= 1e-37
+
+
+@pytest.mark.parametrize('sched', ['contiguous', 'ring'])
+def test_fp32_special_values_split_mode_is_the_documented_one(sched):
+    """torch.set_float32_matmul_precision('high') -> split-bf16 (PYG_HIP_MM_F32_SPLIT, the counterpart of the reference's
+    TF32 switch, ops/cuda/matmul_kernel.cu:158-165).  What include/pyg_hip.h promises: NaN stays NaN; an Inf operand or
+    one beyond the largest bf16 makes the outputs it feeds non-finite (NaN where the exact kernel has +-Inf or a finite
+    value) and touches nothing else; every other element keeps fp32 accuracy."""
+    x, ptr, w, rows = _special_value_case(128, 78)
+    with ops.matmul_f32_split(True):
+        try:
+            ops.set_matmul_schedule(sched)
+            out = ops.segment_matmul(x.to(DEV), ptr, w.to(DEV)).cpu()
+        finally:
+            ops.set_matmul_schedule('auto')
+    assert ops.matmul_last_variant() == ('mfma_f32_k128_regw_x3' if sched == 'ring' else 'mfma_f32_k128_mc128_x3')
+    ref = torch.from_numpy(oracle.segment_matmul(x.numpy(), ptr.numpy(), w.numpy()))
+    nonfinite_ref = ~torch.isfinite(ref)
+    # non-finite in the reference -> non-finite here (never a finite number in place of Inf / NaN)
+    assert (~torch.isfinite(out))[nonfinite_ref].all()
+    assert torch.equal(torch.isnan(out) & torch.isnan(ref), torch.isnan(ref))
+    # the only finite reference values that may turn non-finite: row `huge` (operands beyond the bf16 range)
+    lost = torch.isfinite(ref) & ~torch.isfinite(out)
+    lost[rows['huge']] = False
+    assert not lost.any()
+    fin = torch.isfinite(ref) & torch.isfinite(out)
+    fin[rows['tiny']] = False      # third terms below 2^-100 are flushed: 16 instead of 24 bits, checked below
+    fin[rows['denorm']] = False
+    err = (out.double() - ref.double())[fin].abs()
+    scale = (x.double().abs() @ torch.ones(128, 1, dtype=torch.double)).expand_as(ref)[fin].clamp_min(1e-45)
+    assert (err / scale).max() <= 1e-5
+    for r in ('tiny', 'denorm'):
+        assert torch.isfinite(out[rows[r]]).all()
+        assert (out[rows[r]].double() - ref[rows[r]].double()).abs().max() <= 1e-3 * ref[rows[r]].abs().max() + 1e-37
+
+
+def test_fp32_mode_follows_torch_precision_per_call_and_per_thread():
+    """The arithmetic is chosen per call from torch's switch, the schedule is a thread-local of the binding: a thread that
+    asks for 'naive' does not change what another thread's calls run."""
+    import threading
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5000, 128, generator=g).to(DEV)
+    w = torch.randn(2, 128, 128, generator=g).to(DEV)
+    ptr = torch.tensor([0, 2500, 5000])
+    seen = {}
+
+    def other_thread():
+        ops.set_matmul_schedule('naive')
+        ops.segment_matmul(x, ptr, w)
+        seen['other'] = ops.matmul_last_variant()
+
+    ops.segment_matmul(x, ptr, w)
+    assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128'
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join()
+    assert seen['other'] == 'naive'
+    ops.segment_matmul(x, ptr, w)
+    assert ops.matmul_last_variant() == 'mfma_f32_k128_mc128'      # this thread's schedule is still automatic
+    for prec, want in (('high', 'mfma_f32_k128_mc128_x3'), ('medium', 'mfma_f32_k128_mc128_x3'), ('highest', 'mfma_f32_k128_mc128')):
+        torch.set_float32_matmul_precision(prec)
+        try:
+            ops.segment_matmul(x, ptr, w)
+            assert ops.matmul_last_variant() == want, (prec, ops.matmul_last_variant())
+        finally:
+            torch.set_float32_matmul_precision('highest')
+    # the backward of a forward that ran under a schedule runs under the same one (autograd thread)
+    xg = x.clone().requires_grad_()
+    try:
+        ops.set_matmul_schedule('naive')
+        out = ops.segment_matmul(xg, ptr, w)
+    finally:
+        ops.set_matmul_schedule('auto')
+    out.sum().backward()
+    ref = torch.cat([torch.ones(2500, 128, device=DEV) @ w[b].t() for b in range(2)])
+    assert (xg.grad - ref).norm() <= 1e-5 * ref.norm()
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])

@@ -120,11 +120,8 @@ def test_fp32_pipelined_kernel_under_noise_is_reproducible(M):
             assert (out[s:e].double() - ref).norm() <= 1e-5 * max(ref.norm().item(), 1e-30)
         assert torch.isfinite(out).all()
 
-    try:
-        ops.set_matmul_f32_split(False)  # M = 128 would otherwise take the split-bf16 kernel (next test)
+    with ops.matmul_f32_split(False):  # (torch's default: the exact fp32 MFMA kernel)
         _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w), check)
-    finally:
-        ops.set_matmul_f32_split(True)
 
 
 @pytest.mark.parametrize('M', [128, 256])
@@ -148,7 +145,8 @@ def test_fp32_split_bf16_kernel_under_noise_is_reproducible(M):
             assert (out[s:e].double() - ref).norm() <= 1e-6 * max(ref.norm().item(), 1e-30)
         assert torch.isfinite(out).all()
 
-    _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
+    with ops.matmul_f32_split(True):
+        _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
 
 
 def test_fp32_split_bf16_register_w_kernel_under_noise_is_reproducible():
@@ -174,7 +172,8 @@ def test_fp32_split_bf16_register_w_kernel_under_noise_is_reproducible():
 
     try:
         ops.set_matmul_schedule('ring')
-        _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
+        with ops.matmul_f32_split(True):
+            _repeat_against_first(lambda: ops.segment_matmul(x, ptr, w, bias), check)
     finally:
         ops.set_matmul_schedule('auto')
 
@@ -294,17 +293,15 @@ def test_bench_two_ranks_on_one_device_exercises_the_sharded_branch():
     runs on every driver pass, and its JSON line has the shape the driver reads."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+    # no launcher: bench.py re-executes itself under torch.distributed.run with two ranks (what `python bench.py --gpus N`
+    # does on a multi-GPU node with the nccl backend)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
            '--warmup', '1', '--scale', '0.05', '--debug-one-device', '--no-sampler', '--no-cpu-baseline']
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]

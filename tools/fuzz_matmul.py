@@ -48,7 +48,7 @@ while time.time() < t_end:
     grouped = bool(rng.integers(0, 3) == 0) and B <= 150
     try:
         ops.set_matmul_schedule(sched)
-        ops.set_matmul_f32_split(split)
+        torch.set_float32_matmul_precision('high' if split else 'highest')
         if grouped:
             xs = [x[int(ptr[b]):int(ptr[b + 1])] for b in range(B)]
             ws = [w[b] for b in range(B)]
@@ -60,7 +60,7 @@ while time.time() < t_end:
         var = ops.matmul_last_variant()
     finally:
         ops.set_matmul_schedule('auto')
-        ops.set_matmul_f32_split(True)
+        torch.set_float32_matmul_precision('highest')
     seen[var] = seen.get(var, 0) + 1
     assert out.shape == (n, M) and out.dtype == dtype
     if n == 0:

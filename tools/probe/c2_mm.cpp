@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
       p0 = p1 + 1;
     }
     for (int i = 0; i < 3; ++i) {
-      int rc = pyg_hip_segment_matmul(PYG_BF16, x, ptr.data(), 0, w, nullptr, out, rows, K, M, B, ws, wsb, nullptr);
+      int rc = pyg_hip_segment_matmul(PYG_BF16, x, ptr.data(), 0, w, nullptr, out, rows, K, M, B, ws, wsb, 0, nullptr);
       if (rc != 0) {
         printf("[%s] error %d: %s\n", e.c_str(), rc, pyg_hip_last_error());
         break;
@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
     pyg_hip_profile_enable(1);
     const int reps = 10;
     for (int i = 0; i < reps; ++i)
-      pyg_hip_segment_matmul(PYG_BF16, x, ptr.data(), 0, w, nullptr, out, rows, K, M, B, ws, wsb, nullptr);
+      pyg_hip_segment_matmul(PYG_BF16, x, ptr.data(), 0, w, nullptr, out, rows, K, M, B, ws, wsb, 0, nullptr);
     float ms[reps];
     int n = pyg_hip_profile_collect(ms, reps);
     pyg_hip_profile_enable(0);

@@ -23,7 +23,7 @@ for M in (128, 256):
     if trial==2: w = w.abs()
     bias=torch.randn(B,M,device=dev) if trial==0 else None
     for mode in (True, False):
-        ops.set_matmul_f32_split(mode)
+        torch.set_float32_matmul_precision('high' if mode else 'highest')
         out=ops.segment_matmul(x,ptr,w,bias)
         torch.cuda.synchronize()
         print(M, trial, mode, ops.matmul_last_variant(), 'relerr %.3e' % err(out,x,ptr,w,bias), 'maxabs %.3e' % (out.double() - torch.cat([x[int(ptr[b]):int(ptr[b+1])].double()@w[b].double() + (bias[b].double() if bias is not None else 0) for b in range(B)])).abs().max().item())
@@ -31,7 +31,7 @@ for M in (128, 256):
 xs=[torch.randn(r,128,device=dev) for r in (500, 0, 3333)]
 ws=[torch.randn(128,128,device=dev).t() for _ in xs]
 for mode in (True, False):
-    ops.set_matmul_f32_split(mode)
+    torch.set_float32_matmul_precision('high' if mode else 'highest')
     outs=ops.grouped_matmul(xs,ws)
     print('grouped trans', mode, ops.matmul_last_variant(), [((o.double()-a.double()@b.double()).norm()/max((a.double()@b.double()).norm().item(),1e-30)).item() for o,a,b in zip(outs,xs,ws)])
 # timing on C2 fp32
@@ -39,7 +39,7 @@ n=1<<22; B=64
 x=torch.randn(n,128,device=dev); w=torch.randn(B,128,128,device=dev)/11
 ptr=torch.arange(0,n+1,n//B)
 for mode in (True, False):
-    ops.set_matmul_f32_split(mode)
+    torch.set_float32_matmul_precision('high' if mode else 'highest')
     for _ in range(3): out=ops.segment_matmul(x,ptr,w)
     torch.cuda.synchronize()
     a=torch.cuda.Event(enable_timing=True); b=torch.cuda.Event(enable_timing=True)
