@@ -163,6 +163,26 @@ def leg_grouped_mixed(device, rows_total=6_000_000, G=64, ks=(100, 128, 256, 768
     ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w))
     res['segment_k100'] = dict(workload=f'segment_matmul: {N} rows, K=100 -> M={M}, {B} segments, bf16',
                                kernel=ops.matmul_last_variant(), **_rate(s * (N * K + N * M + B * K * M), ms))
+    # its weight gradient alone (dW[b] = X_b^T dY_b through the general-shape dW kernel, matmul_dw_gen.hip): reads X and dY
+    # once, writes B x K x M
+    xg, wg = x.detach(), w.detach().requires_grad_()
+    gy = torch.randn(N, M, device=device, generator=gd).to(dtype)
+    before = ops.matmul_dw_counters()
+
+    def dw_only():
+        out = ops.segment_matmul(xg, ptr, wg)
+        (gw,) = torch.autograd.grad(out, [wg], gy)
+        return gw
+
+    ms_fdw = _event_ms(dw_only, 5)
+    after = ops.matmul_dw_counters()
+    ms_f = _event_ms(lambda: ops.segment_matmul(x, ptr, w), 5)
+    alg_dw = s * (N * K + N * M) + s * B * K * M
+    r = _rate(alg_dw, max(ms_fdw - ms_f, 1e-6))
+    r.update(workload=f'weight gradient of the K=100 segment_matmul above (one launch; forward time subtracted)',
+             kernel='dw_gen_kernel' if after[1] > before[1] else ('seg_dw_kernel' if after[0] > before[0] else 'reference loop'),
+             ms_forward_plus_dw=round(ms_fdw, 4))
+    res['segment_k100_backward'] = r
     return res
 
 

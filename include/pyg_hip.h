@@ -174,16 +174,24 @@ PYG_HIP_API const char* pyg_hip_matmul_last_variant(void);
  * Weight gradient of segment_matmul:  grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]
  * (input [N, K], grad_out [N, M], grad_other [B, K, M]; fp32 accumulation, one rounding).  Replaces the
  * per-relation loop of SegmentMatmul::backward (ops/autograd/matmul_kernel.cpp:92-107: B x
- * at::matmul(input_i^T, grad_out_i) + at::stack) with one persistent launch.  fp32 / bf16 / fp16 with
- * K in {64, 128, 256} and M % 64 == 0; other cases return PYG_HIP_ERR_UNSUPPORTED (the caller keeps the
- * reference formula).  `workspace`: pyg_hip_segment_matmul_dw_workspace_size(B, K, M) bytes of device
- * scratch (tile plan + fp32 accumulators).  Never synchronises.
+ * at::matmul(input_i^T, grad_out_i) + at::stack) with one persistent launch.  fp32 / bf16 / fp16, ANY K and M and any
+ * element-aligned operands: K in {64, 128, 256} with M % 64 == 0 and 16-byte aligned operands run the shape-specialised
+ * kernels of matmul_dw.hip, everything else the general-shape kernel (matmul_dw_gen.hip: 128 x 128 output blocks, tails
+ * zero-filled in LDS, widest vector loads the alignment allows).  fp32 multiplies on v_mfma_f32_32x32x2_f32 (IEEE fp32).
+ * Other dtypes return PYG_HIP_ERR_UNSUPPORTED (the caller keeps the reference formula).  `workspace`:
+ * pyg_hip_segment_matmul_dw_workspace_size(B, K, M) bytes of device scratch (tile plan + fp32 accumulators).  Never
+ * synchronises.
  */
 PYG_HIP_API size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M);
 /* Grouped form (the others_grad of GroupedMatmul.backward, pyg_lib/ops/__init__.py:88-94): for every
- * group i, out_pool[i] = input_i^T @ other_i with input_i [rows_i, k] and other_i [rows_i, m] row-major
- * (uniform k, m; `out`/`other_trans` of pyg_hip_group are ignored); out_pool is one [G, k, m] block.
- * Same kernel, same workspace formula (B = G). */
+ * group i, out_i = input_i^T @ other_i with input_i [rows_i, k_i] and other_i [rows_i, m_i] row-major, PER-GROUP k_i,
+ * m_i (`out` / `other_trans` of pyg_hip_group are ignored); out_pool receives the [k_i, m_i] results back to back in
+ * group order (out_i starts at element sum_{j < i} k_j m_j; uniform shapes: one [G, k, m] block).  Workspace:
+ * pyg_hip_grouped_matmul_dw_workspace_size(groups, G). */
+PYG_HIP_API size_t pyg_hip_grouped_matmul_dw_workspace_size(const pyg_hip_group* groups, int64_t G);
+/* Diagnostic: calls served by the shape-specialised / the general-shape weight-gradient kernels since the library was
+ * loaded (process wide).  Either pointer may be NULL. */
+PYG_HIP_API void pyg_hip_matmul_dw_counters(int64_t* specialised, int64_t* general);
 PYG_HIP_API int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* groups, int64_t G, void* out_pool,
                                           void* workspace, size_t workspace_bytes, void* stream);
 PYG_HIP_API int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, int ptr_on_device,

@@ -168,26 +168,32 @@ static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const
   // every X_i and G skinny GEMMs.
   {
     const auto st = input[0].scalar_type();
-    bool dw = (st == at::kBFloat16 || st == at::kHalf || st == at::kFloat);
-    const int64_t K = input[0].size(0), M = other[0].size(1);
-    dw = dw && !caller_pool.has_value() && (K == 64 || K == 128 || K == 256) && M % 64 == 0;
-    for (size_t i = 0; dw && i < G; ++i)
-      dw = input[i].size(0) == K && other[i].size(1) == M && !input[i].is_contiguous() &&
-           input[i].t().is_contiguous() && other[i].is_contiguous() && (uintptr_t)input[i].data_ptr() % 16 == 0 &&
-           (uintptr_t)other[i].data_ptr() % 16 == 0;
-    if (dw) {
+    bool dw = (st == at::kBFloat16 || st == at::kHalf || st == at::kFloat) && !caller_pool.has_value();
+    const int64_t esz = (int64_t)input[0].element_size();
+    // every input is a transposed view (tensors that are both -- one row, one column, no elements -- count), at
+    // least one of them a real one: a plain forward call never comes here
+    bool any_view = false;
+    for (size_t i = 0; dw && i < G; ++i) {
+      dw = input[i].t().is_contiguous() && other[i].is_contiguous() && input[i].size(0) > 0 && other[i].size(1) > 0 &&
+           (uintptr_t)input[i].data_ptr() % esz == 0 && (uintptr_t)other[i].data_ptr() % esz == 0;
+      any_view = any_view || !input[i].is_contiguous();
+    }
+    if (dw && any_view) {
+      // per-group shapes: K_i = input[i].size(0), M_i = other[i].size(1); the results lie back to back in one pool
+      std::vector<int64_t> poff(G + 1, 0);
       for (size_t i = 0; i < G; ++i) {
-        groups[i].input = input[i].data_ptr();  // X_i, row-major [rows_i, K]
-        groups[i].other = other[i].data_ptr();  // dY_i [rows_i, M]
+        groups[i].input = input[i].data_ptr();  // X_i, row-major [rows_i, K_i]
+        groups[i].other = other[i].data_ptr();  // dY_i [rows_i, M_i]
         groups[i].out = nullptr;
         groups[i].rows = input[i].size(1);
-        groups[i].k = (int32_t)K;
-        groups[i].m = (int32_t)M;
+        groups[i].k = (int32_t)input[i].size(0);
+        groups[i].m = (int32_t)other[i].size(1);
         groups[i].other_trans = 0;
         groups[i].reserved = 0;
+        poff[i + 1] = poff[i] + input[i].size(0) * other[i].size(1);
       }
-      auto pool = at::empty({(int64_t)G, K, M}, input[0].options());
-      auto ws = at::empty({(int64_t)pyg_hip_segment_matmul_dw_workspace_size((int64_t)G, K, M)},
+      auto pool = at::empty({poff[G]}, input[0].options());
+      auto ws = at::empty({(int64_t)pyg_hip_grouped_matmul_dw_workspace_size(groups.data(), (int64_t)G)},
                           input[0].options().dtype(at::kByte));
       const int rc = pyg_hip_grouped_matmul_dw(dtype_code(st), groups.data(), (int64_t)G, pool.data_ptr(), ws.data_ptr(),
                                                (size_t)ws.numel(), current_stream(input[0]));
@@ -195,7 +201,8 @@ static std::vector<Tensor> grouped_matmul_impl(const at::TensorList input, const
         // plain aliases of the pool, not tracked views: the reference returns G independent tensors, and
         // outputs that are "views of a multi-output function" could not be modified in place by the caller
         at::AutoDispatchBelowADInplaceOrView untracked;
-        for (size_t i = 0; i < G; ++i) outs.push_back(pool.select(0, (int64_t)i));
+        for (size_t i = 0; i < G; ++i)
+          outs.push_back(pool.as_strided({input[i].size(0), other[i].size(1)}, {other[i].size(1), 1}, poff[i]));
         return outs;
       }
       TORCH_CHECK(rc == PYG_HIP_ERR_UNSUPPORTED, pyg_hip_last_error());
@@ -418,7 +425,7 @@ static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Te
   if (!input.is_cuda()) return Tensor();  // CPU tensors: the reference formula below
   if (st != at::kBFloat16 && st != at::kHalf && st != at::kFloat) return Tensor();
   const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
-  if (!(K == 64 || K == 128 || K == 256) || M % 64 != 0 || B == 0) return Tensor();
+  if (B == 0 || K == 0 || M == 0) return at::empty({B, K, M}, other.options());
   DeviceGuard guard(input.device());
   auto x = input.contiguous();
   auto gy = grad_out.contiguous();
@@ -457,11 +464,12 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
       input_grad = segment_matmul_below_autograd(grad_out, ptr, other.transpose(-2, -1));
     }
     if (torch::autograd::any_variable_requires_grad({other})) {
-      // dW[b] = X_b^T @ dY_b: one persistent MFMA launch for the 16-bit types (csrc/hip/matmul_dw.hip) ...
+      // dW[b] = X_b^T @ dY_b: one persistent MFMA launch for bf16 / f16 / fp32 and any (K, M) (csrc/hip/matmul_dw.hip,
+      // matmul_dw_gen.hip) ...
       other_grad = segment_matmul_dw(input, ptr, grad_out, other);
     }
     if (torch::autograd::any_variable_requires_grad({other}) && !other_grad.defined()) {
-      // ... the reference's per-relation formula elsewhere (fp32 / fp64 / unsupported shapes)
+      // ... the reference's per-relation formula elsewhere (fp64, integer types, CPU tensors)
       const auto size = (ptr.narrow(0, 1, ptr.numel() - 1) - ptr.narrow(0, 0, ptr.numel() - 1)).cpu();
       const auto sizes = at::IntArrayRef(size.data_ptr<int64_t>(), (size_t)size.numel());
       const auto xs = input.split_with_sizes(sizes, 0);

@@ -19,13 +19,14 @@
 //     of a block on disjoint banks.
 //   * Accumulators are flushed with native global_atomic_add_f32 into an fp32 [B, K, M] scratch
 //     (43 M atomics for C2, L2-resident) and rounded once to the storage type by a tiny epilogue.
-#include "common.h"
+#include "matmul_common.h"
 
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 namespace pyg_hip {
 namespace {
@@ -622,6 +623,10 @@ int run_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int6
               (long long)K, (long long)M);
 }
 
+// shapes of the specialised kernels above; everything else (and operands that are not 16-byte aligned) runs
+// matmul_dw_gen.hip
+inline bool dw_fast_shape(int64_t K, int64_t M) { return (K == 64 || K == 128 || K == 256) && M > 0 && M % 64 == 0; }
+
 int round_out(int dtype, const float* acc, void* out, int64_t n, hipStream_t stream) {
   if (dtype == PYG_F32) {  // the accumulators ARE the result
     PYG_HIP_CHECK(hipMemcpyAsync(out, acc, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream));
@@ -642,10 +647,35 @@ int round_out(int dtype, const float* acc, void* out, int64_t n, hipStream_t str
 
 using namespace pyg_hip;
 
+namespace {
+// launches of the shape-specialised / the general-shape weight-gradient kernels since the library was loaded (tests
+// assert that a backward pass ran a device kernel and not the caller's fallback formula; the backward runs on an
+// autograd thread, so a thread-local "last variant" would not be visible to the test)
+std::atomic<int64_t> g_dw_fast{0}, g_dw_gen{0};
+}  // namespace
+
 extern "C" {
 
+void pyg_hip_matmul_dw_counters(int64_t* specialised, int64_t* general) {
+  if (specialised) *specialised = g_dw_fast.load();
+  if (general) *general = g_dw_gen.load();
+}
+
 size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M) {
-  return dw_ws_bytes(B < 0 ? 0 : B, K < 0 ? 0 : K, M < 0 ? 0 : M);
+  B = B < 0 ? 0 : B, K = K < 0 ? 0 : K, M = M < 0 ? 0 : M;
+  return std::max(dw_ws_bytes(B, K, M), dw_gen_workspace_bytes(B, B * K * M));
+}
+
+size_t pyg_hip_grouped_matmul_dw_workspace_size(const pyg_hip_group* groups, int64_t G) {
+  if (G <= 0 || groups == nullptr) return dw_gen_workspace_bytes(0, 0);
+  int64_t elems = 0;
+  bool uniform = true;
+  for (int64_t i = 0; i < G; ++i) {
+    elems += (int64_t)std::max(groups[i].k, 0) * std::max(groups[i].m, 0);
+    uniform = uniform && groups[i].k == groups[0].k && groups[i].m == groups[0].m;
+  }
+  const size_t gen = dw_gen_workspace_bytes(G, elems);
+  return uniform ? std::max(gen, dw_ws_bytes(G, std::max(groups[0].k, 0), std::max(groups[0].m, 0))) : gen;
 }
 
 int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, int ptr_on_device, const void* grad_out,
@@ -657,10 +687,15 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
   PYG_HIP_REQUIRE(ptr && grad_other && (N == 0 || (input && grad_out)), "segment_matmul_dw: NULL tensor");
   if (dtype != PYG_BF16 && dtype != PYG_F16 && dtype != PYG_F32)
     return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: float32 / bfloat16 / float16 only (dtype %d)", dtype);
-  PYG_HIP_REQUIRE(((uintptr_t)input % 16 == 0) && ((uintptr_t)grad_out % 16 == 0), "segment_matmul_dw: tensors must be 16-byte aligned");
-  if (workspace == nullptr || workspace_bytes < dw_ws_bytes(B, K, M))
-    return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul_dw: workspace of %zu bytes needed, got %zu", dw_ws_bytes(B, K, M),
-                workspace_bytes);
+  const size_t need = pyg_hip_segment_matmul_dw_workspace_size(B, K, M);
+  if (workspace == nullptr || workspace_bytes < need)
+    return fail(PYG_HIP_ERR_WORKSPACE, "segment_matmul_dw: workspace of %zu bytes needed, got %zu", need, workspace_bytes);
+  if (!dw_fast_shape(K, M) || ((uintptr_t)input | (uintptr_t)grad_out) % 16 != 0) {
+    const int rc = dw_gen_segment(dtype, input, ptr, ptr_on_device, grad_out, grad_other, N, K, M, B, workspace, stream);
+    if (rc == PYG_HIP_OK) ++g_dw_gen;
+    return rc;
+  }
+  ++g_dw_fast;
   char* w = static_cast<char*>(workspace);
   int64_t* ptr_dev = reinterpret_cast<int64_t*>(w);
   w += align_up(sizeof(int64_t) * (size_t)(B + 1), 256);
@@ -704,19 +739,25 @@ int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64
     return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: float32 / bfloat16 / float16 only (dtype %d)", dtype);
   const int64_t K = host_groups[0].k, M = host_groups[0].m;
   int64_t tiles = 0;
+  bool fast = dw_fast_shape(K, M);
   for (int64_t i = 0; i < G; ++i) {
     const pyg_hip_group& g = host_groups[i];
-    if (g.k != K || g.m != M) return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: groups must share (K, M)");
-    PYG_HIP_REQUIRE(g.rows >= 0 && (g.rows == 0 || (g.input && g.other)), "grouped_matmul_dw: NULL tensor in group %lld",
+    PYG_HIP_REQUIRE(g.rows >= 0 && g.k >= 0 && g.m >= 0, "grouped_matmul_dw: negative size in group %lld", (long long)i);
+    PYG_HIP_REQUIRE(g.rows == 0 || g.k == 0 || g.m == 0 || (g.input && g.other), "grouped_matmul_dw: NULL tensor in group %lld",
                     (long long)i);
-    if (((uintptr_t)g.input | (uintptr_t)g.other) % 16 != 0)
-      return fail(PYG_HIP_ERR_UNSUPPORTED, "grouped_matmul_dw: operands must be 16-byte aligned");
+    if (g.k != K || g.m != M || ((uintptr_t)g.input | (uintptr_t)g.other) % 16 != 0) fast = false;
     tiles += (g.rows + kTile - 1) / kTile;
   }
-  if (K * M == 0) return PYG_HIP_OK;
-  if (workspace == nullptr || workspace_bytes < dw_ws_bytes(G, K, M))
-    return fail(PYG_HIP_ERR_WORKSPACE, "grouped_matmul_dw: workspace of %zu bytes needed, got %zu", dw_ws_bytes(G, K, M),
-                workspace_bytes);
+  const size_t need = pyg_hip_grouped_matmul_dw_workspace_size(host_groups, G);
+  if (workspace == nullptr || workspace_bytes < need)
+    return fail(PYG_HIP_ERR_WORKSPACE, "grouped_matmul_dw: workspace of %zu bytes needed, got %zu", need, workspace_bytes);
+  // per-group shapes, shapes without a specialised kernel, element-aligned views: the general-shape kernel
+  if (!fast) {
+    const int rc = dw_gen_grouped(dtype, host_groups, G, out_pool, workspace, stream);
+    if (rc == PYG_HIP_OK) ++g_dw_gen;
+    return rc;
+  }
+  ++g_dw_fast;
   char* w = static_cast<char*>(workspace) + align_up(sizeof(int64_t) * (size_t)(G + 1), 256);
   DwGroup* groups = reinterpret_cast<DwGroup*>(w);
   w += dw_groups_bytes(G);

@@ -352,6 +352,15 @@ def matmul_last_variant() -> str:
     return _capi.lib().pyg_hip_matmul_last_variant().decode()
 
 
+def matmul_dw_counters() -> Tuple[int, int]:
+    """(specialised, general): calls served by the shape-specialised / the general-shape weight-gradient kernels since the
+    library was loaded (process wide -- the backward pass runs on an autograd thread)."""
+    import ctypes
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _capi.lib().pyg_hip_matmul_dw_counters(ctypes.byref(a), ctypes.byref(b))
+    return int(a.value), int(b.value)
+
+
 _SCHEDULES = {'auto': 0, 'contiguous': 1, 'cyclic': 2, 'ticket': 3, 'general': 4, 'naive': 5, 'ring': 6}
 
 

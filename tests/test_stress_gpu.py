@@ -287,6 +287,116 @@ def test_fused_rgcn_kernel_under_noise_stays_exact():
         assert torch.equal(y.double().cpu(), want), rep
 
 
+# ---- kernels that accumulate through hardware float atomics ----------------------------------
+# Their results depend on the order the atomics land (fp32 / fp64 / packed 16-bit adds do not commute exactly), so a
+# repetition is compared with a float64 reference under the operator's tolerance instead of bit for bit -- except where
+# the inputs make every partial sum exact (small integers), where any lost or doubled update, any stale accumulator and
+# any write from a neighbour shows as a wrong integer.
+
+def _repeat_exact(make_call, want, reps=REPS, burst=24):
+    noise = Noise()
+    for rep in range(reps):
+        noise.burst(burst)
+        out = make_call()
+        torch.cuda.synchronize()
+        got = out.double().cpu()
+        if not torch.equal(got, want):
+            bad = (got != want).nonzero()
+            raise AssertionError(f'rep {rep}: {bad.size(0)} wrong elements, first at {bad[0].tolist()}: '
+                                 f'{got[tuple(bad[0])].item()} != {want[tuple(bad[0])].item()}')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('K,M', [(64, 64), (128, 128), (256, 256)])
+def test_weight_gradient_kernel_under_noise_stays_exact(dtype, K, M):
+    """seg_dw_kernel / seg_dw_wide256_kernel / seg_dw_f32_kernel: workgroups add their partial X^T dY slabs into a zeroed
+    fp32 accumulator with global_atomic_add_f32, a second kernel rounds.  X in {-1, 0, 1}, dY small integers: every
+    partial sum is an exact fp32 integer, so dW must equal the float64 product in every repetition."""
+    g = torch.Generator().manual_seed(K + M)
+    sizes = [0, 37, 128, 129, 1000, 0, 5000, 31, 257, 9000]
+    ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
+    n, B = int(ptr[-1]), len(sizes)
+    x = torch.randint(-1, 2, (n, K), generator=g).float()
+    gy = torch.randint(-2, 3, (n, M), generator=g).float()
+    want = torch.stack([x[ptr[b]:ptr[b + 1]].double().t() @ gy[ptr[b]:ptr[b + 1]].double() for b in range(B)])
+    assert want.abs().max() < 256   # exact in bf16 as well
+    xd = x.to(dtype).to(DEV)
+    gyd = gy.to(dtype).to(DEV)
+    wd = torch.zeros(B, K, M, dtype=dtype, device=DEV, requires_grad=True)
+
+    def call():
+        y = ops.segment_matmul(xd, ptr if call.host else ptr.to(DEV), wd)
+        call.host = not call.host
+        return torch.autograd.grad(y, [wd], gyd)[0]
+    call.host = True
+    _repeat_exact(call, want)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16, torch.float64])
+@pytest.mark.parametrize('K', [128, 5, 96])
+@pytest.mark.parametrize('sorted_index', [False, True])
+def test_scatter_sum_under_noise_stays_exact(dtype, K, sorted_index):
+    """scatter_sum_vec_kernel (16-byte rows, native fp32 / fp64 / packed bf16 / f16 atomics), scatter_elem_kernel (K = 5)
+    and the sorted-run path of segment_sum_coo: integer-valued sources whose bucket sums stay below 256."""
+    g = torch.Generator().manual_seed(K)
+    E, N = 20000, 700
+    src = torch.randint(-2, 3, (E, K), generator=g).float()
+    index = torch.randint(0, N, (E,), generator=g)
+    if sorted_index:
+        index = index.sort().values
+    want = torch.zeros(N, K, dtype=torch.float64).index_add_(0, index, src.double())
+    assert want.abs().max() < 256
+    sd, idx = src.to(dtype).to(DEV), index.to(DEV)
+    if sorted_index:
+        _repeat_exact(lambda: ops.segment_sum_coo(sd, idx, dim_size=N), want)
+    else:
+        _repeat_exact(lambda: ops.scatter_sum(sd, idx, 0, None, N), want)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_scatter_sum_into_a_caller_buffer_under_noise_stays_exact(dtype):
+    """`out=` accumulation (no zero fill by the operator) and a fresh output allocated right after a large block was
+    returned to the caching allocator: the accumulator's initial contents are exactly what the caller / the operator
+    wrote, never what the block held before."""
+    g = torch.Generator().manual_seed(9)
+    E, N, K = 30000, 1500, 128
+    src = torch.randint(-2, 3, (E, K), generator=g).float()
+    index = torch.randint(0, N, (E,), generator=g)
+    base = torch.randint(-4, 5, (N, K), generator=g).float()
+    want_out = base.double().index_add(0, index, src.double())
+    want_new = torch.zeros(N, K, dtype=torch.float64).index_add_(0, index, src.double())
+    sd, idx = src.to(dtype).to(DEV), index.to(DEV)
+
+    def into_out():
+        out = base.to(dtype).to(DEV)
+        return ops.scatter_sum(sd, idx, 0, out, N)
+
+    def after_free():
+        junk = torch.full((N, K), 77.0, dtype=dtype, device=DEV)   # a block of the output's size, dirty, freed ...
+        del junk
+        return ops.scatter_sum(sd, idx, 0, None, N)               # ... and most likely handed out again here
+
+    _repeat_exact(into_out, want_out, reps=16)
+    _repeat_exact(after_free, want_new, reps=16)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_segment_sum_csr_under_noise_stays_exact(dtype):
+    from pyg_lib_amd import ops as o
+    g = torch.Generator().manual_seed(10)
+    N, K = 4000, 128
+    deg = torch.randint(0, 12, (N,), generator=g)
+    deg[5] = 3000
+    indptr = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)])
+    E = int(indptr[-1])
+    src = torch.randint(-2, 3, (E, K), generator=g).float()
+    seg = torch.repeat_interleave(torch.arange(N), deg)
+    want = torch.zeros(N, K, dtype=torch.float64).index_add_(0, seg, src.double())
+    assert want.abs().max() < 256   # one 3000-element row included: fp32 partial sums, one rounding
+    sd, ip = src.to(dtype).to(DEV), indptr.to(DEV)
+    _repeat_exact(lambda: o.segment_sum_csr(sd, ip), want, reps=16)
+
+
 def test_bench_two_ranks_on_one_device_exercises_the_sharded_branch():
     """`bench.py --gpus 2` with both ranks on cuda:0 over gloo (RCCL refuses two ranks per device): the N > 1 branch
     -- row shards, barrier + max-over-ranks timing, the all-gather leg, C4's LPT shards with the in-place gather --
