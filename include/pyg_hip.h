@@ -357,6 +357,13 @@ typedef struct {
  * node type), "synchronising" (unbounded / > 64 fan-outs, weighted relations, a hub that needed a word top-up, or
  * PYG_HIP_SAMPLER_SYNC_MODE=1).  Diagnostics only; every driver returns the same bits. */
 PYG_HIP_API const char* pyg_hip_sampler_last_mode(void);
+/* Direct-address node tables of the fused chain are kept between calls (per device and node count; blocks come from
+ * host->alloc and are never freed): a call's values carry an epoch in their upper bits, so what an earlier call left
+ * behind reads as "empty" and the 19.6 MB clear of a products-sized table (one launch, 7 % of a batch's traffic; four
+ * launches for the MAG-shaped C5 graph) happens once per 2^20 - 1 calls instead of every call.  Diagnostics / tests:
+ * `limit` = epochs per clear (0: the default 2^20 - 1); returns the number of tables cached for the current device.
+ * PYG_HIP_SAMPLER_TABLE_CACHE=0 disables the cache (every call clears a fresh table, as before round 4). */
+PYG_HIP_API int pyg_hip_sampler_table_cache(int64_t limit);
 
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                                const pyg_hip_relation* relations_host,

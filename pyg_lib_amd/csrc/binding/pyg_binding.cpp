@@ -419,18 +419,18 @@ static Tensor segment_matmul_below_autograd(const Tensor& input, const Tensor& p
 }
 
 // dW through the C-ABI; returns an undefined tensor when the device kernel does not cover the case.
-static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, const Tensor& other) {
+static Tensor segment_matmul_dw(const Tensor& input, const Tensor& ptr, const Tensor& grad_out, int64_t B) {
   PYG_TRACE("pyg::segment_matmul_backward_dw");
   const auto st = input.scalar_type();
   if (!input.is_cuda()) return Tensor();  // CPU tensors: the reference formula below
   if (st != at::kBFloat16 && st != at::kHalf && st != at::kFloat) return Tensor();
-  const int64_t B = other.size(0), K = other.size(1), M = other.size(2);
-  if (B == 0 || K == 0 || M == 0) return at::empty({B, K, M}, other.options());
+  const int64_t K = input.size(1), M = grad_out.size(1);
+  if (B == 0 || K == 0 || M == 0) return at::empty({B, K, M}, input.options());
   DeviceGuard guard(input.device());
   auto x = input.contiguous();
   auto gy = grad_out.contiguous();
   auto p = ptr.contiguous();
-  auto out = at::empty({B, K, M}, other.options());
+  auto out = at::empty({B, K, M}, input.options());
   auto ws = at::empty({(int64_t)pyg_hip_segment_matmul_dw_workspace_size(B, K, M)}, x.options().dtype(at::kByte));
   const int rc = pyg_hip_segment_matmul_dw(dtype_code(st), x.data_ptr(), p.data_ptr<int64_t>(), p.is_cuda() ? 1 : 0,
                                            gy.data_ptr(), out.data_ptr(), x.size(0), K, M, B, ws.data_ptr(),
@@ -466,7 +466,7 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
     if (torch::autograd::any_variable_requires_grad({other})) {
       // dW[b] = X_b^T @ dY_b: one persistent MFMA launch for bf16 / f16 / fp32 and any (K, M) (csrc/hip/matmul_dw.hip,
       // matmul_dw_gen.hip) ...
-      other_grad = segment_matmul_dw(input, ptr, grad_out, other);
+      other_grad = segment_matmul_dw(input, ptr, grad_out, other.size(0));
     }
     if (torch::autograd::any_variable_requires_grad({other}) && !other_grad.defined()) {
       // ... the reference's per-relation formula elsewhere (fp64, integer types, CPU tensors)
@@ -485,6 +485,23 @@ class SegmentMatmul : public torch::autograd::Function<SegmentMatmul> {
 
 Tensor segment_matmul_autograd(const Tensor& input, const Tensor& ptr, const Tensor& other) {
   return SegmentMatmul::apply(input, ptr, other)[0];
+}
+
+// This build only: the weight gradient as an operator of its own,
+//   grad_other[b] = input[ptr[b]:ptr[b+1]]^T @ grad_out[ptr[b]:ptr[b+1]]     ([B, K, M], B = ptr.numel() - 1),
+// for callers that hold X and dY but never ran the forward through autograd (the backward of the fused R-GCN layer,
+// pyg_lib_amd/rgcn.py).  Same kernels as SegmentMatmul::backward; bf16 / f16 / fp32 on the device.
+Tensor segment_matmul_grad_other_kernel(const Tensor& input, const Tensor& ptr, const Tensor& grad_out) {
+  TORCH_CHECK(input.dim() == 2 && grad_out.dim() == 2 && ptr.dim() == 1 && ptr.numel() >= 1 &&
+                  input.size(0) == grad_out.size(0),
+              "segment_matmul_grad_other: expected input [N, K], ptr [B + 1], grad_out [N, M]");
+  TORCH_CHECK(ptr.scalar_type() == at::kLong, "expected scalar type Long but found ", ptr.scalar_type());
+  TORCH_CHECK(input.is_cuda() && grad_out.is_cuda() && input.device() == grad_out.device() &&
+                  input.scalar_type() == grad_out.scalar_type(),
+              "segment_matmul_grad_other: 'input' and 'grad_out' must share device and dtype");
+  Tensor out = segment_matmul_dw(input, ptr, grad_out, ptr.numel() - 1);
+  TORCH_CHECK(out.defined(), "segment_matmul_grad_other: float32 / bfloat16 / float16 only (got ", input.scalar_type(), ")");
+  return out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -908,6 +925,8 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   // this build only: bias as a fused epilogue
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::segment_matmul_bias(Tensor input, Tensor ptr, Tensor other, Tensor bias) -> Tensor"));
+  // this build only: the weight gradient of segment_matmul as its own operator
+  m.def(TORCH_SELECTIVE_SCHEMA("pyg::segment_matmul_grad_other(Tensor input, Tensor ptr, Tensor grad_out) -> Tensor"));
   // this build only: fused R-GCN aggregation (gather -> per-relation matmul -> scatter-add), csrc/hip/rgcn.hip
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused(Tensor x, Tensor[] gather_index, Tensor[] scatter_index, int[] gather_offset, "
@@ -950,6 +969,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul"), TORCH_FN(grouped_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul"), TORCH_FN(segment_matmul_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_bias"), TORCH_FN(segment_matmul_bias_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::segment_matmul_grad_other"), TORCH_FN(segment_matmul_grad_other_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::grouped_matmul_pool"), TORCH_FN(grouped_matmul_pool_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused_tables"), TORCH_FN(rgcn_fused_tables_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused"), TORCH_FN(rgcn_fused_kernel));

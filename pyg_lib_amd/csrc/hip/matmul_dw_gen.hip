@@ -100,12 +100,26 @@ __device__ __forceinline__ u32x4 load_chunk(const char* rowp, int c0, int n) {
     }
     return v;
   }
-  // the row's tail chunk
-  if constexpr (ELT == 2) {
-    for (int e = 0; e < valid; ++e) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
-  } else {
-    for (int e = 0; e < valid; ++e) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
+  // the row's tail chunk: the row pitch is a multiple of 2^LG bytes and chunks start at multiples of 16, so the tail is
+  // a whole number of 2^LG-byte pieces -- independent loads, all in flight together (a dependent per-element loop here
+  // cost K = 100 four serialised memory round trips per tile)
+  constexpr int P = LG >= 4 ? 16 : (1 << LG);  // bytes per piece
+  const int vb = valid * ELT;
+  if constexpr (P == 8) {
+    if (vb >= 8) {
+      const u32x2 a = *reinterpret_cast<const u32x2*>(p);
+      v[0] = a[0], v[1] = a[1];
+    }
+  } else if constexpr (P == 4) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      if (4 * e < vb) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
+  } else if constexpr (P == 2) {
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+      if (2 * e < vb) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
   }
+  // (P == 16: a row pitch of whole chunks has no tail)
   return v;
 }
 

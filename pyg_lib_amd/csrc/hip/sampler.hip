@@ -30,7 +30,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 namespace pyg_hip {
@@ -223,7 +225,19 @@ struct HashTable {
   // vals[node] for node < the type's node count, no keys, no probing -- one atomic per insert instead of a key
   // load + CAS + atomic, and a table a third smaller than the hash table of a products-sized batch.
   int dense;
+  // Value coding.  Classic tables (cleared per call): an emission position p is stored as kProvisional + p, a final
+  // local id as the id itself (prov = kProvisional, tag = 0, idmask = ~0).  Epoch tables (direct-address tables the
+  // library keeps between calls, see DenseCache): [63] 0 | [62:43] kEpochMax - epoch | [42] provisional | [41:0]
+  // position or id -- a newer call's values are smaller than anything an older call left behind, so atomicMin treats
+  // stale entries exactly like kEmpty and the table needs no clearing (prov = tag | 1 << 42, idmask = 2^42 - 1).
+  u64 prov = 1ull << 62;  // kProvisional
+  u64 tag = 0;
+  u64 idmask = ~0ull;
 };
+static_assert(kProvisional == 1ull << 62, "HashTable::prov default");
+constexpr int kEpochShift = 43;
+constexpr u64 kEpochMax = (1ull << 20) - 1;
+constexpr u64 kEpochProv = 1ull << 42;
 
 __device__ __forceinline__ u64 hash64(u64 x) {
   x ^= x >> 33;
@@ -295,7 +309,7 @@ __global__ void seed_insert_kernel(const int64_t* __restrict__ seed, int64_t n, 
   if (disjoint) batch[i] = b;
   const u64 s = table_slot(t, make_key(v, b, num_batches));
   slots[i] = s;
-  __hip_atomic_fetch_min(&t.vals[s], kProvisional + (u64)i, __ATOMIC_RELAXED,
+  __hip_atomic_fetch_min(&t.vals[s], t.prov + (u64)i, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -537,7 +551,7 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
   if (!a.table.keys) return;  // dist_neighbor_sample: no relabelling (neighbor_kernel.cpp:296-303)
   const u64 s = table_slot(a.table, make_key(w, src_batch, a.num_batches));
   a.e_slot[pos] = s;
-  __hip_atomic_fetch_min(&a.table.vals[s], kProvisional + (u64)(a.pos_base + pos), __ATOMIC_RELAXED,
+  __hip_atomic_fetch_min(&a.table.vals[s], a.table.prov + (u64)(a.pos_base + pos), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -889,7 +903,8 @@ struct NodeSet {
   DevVec nodes, batch;
   int64_t distinct = 0;  // Mapper::curr
   int64_t slice_b = 0, slice_e = 0;
-  HashTable table{nullptr, nullptr, 0, 0};
+  HashTable table{nullptr, nullptr, 0, 0, kProvisional, 0, ~0ull};
+  void* cached = nullptr;  // the table block belongs to the library's DenseCache (not to this call's allocations)
   int64_t entries_bound = 0;  // upper bound of keys present in the table
   int64_t dense_n = 0;        // > 0: every id of this type is < dense_n and keys are plain node ids (not disjoint)
 };
@@ -900,9 +915,53 @@ __global__ __launch_bounds__(256) void table_clear_kernel(u64x2* __restrict__ p,
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = e;
 }
 
+// Direct-address tables kept between calls (fused chain only).  A products-sized table is 19.6 MB: clearing it took
+// 11 - 13 us and 7 % of a C3 batch's HBM traffic per call (C5: four tables, four launches).  The cache hands a call a
+// table whose stale contents are invalidated by the epoch in the value coding (HashTable above); a block is cleared
+// once, when it is allocated, and again when its 2^20 - 1 epochs are used up.  An entry serves one call at a time
+// (`busy`; a second concurrent call on the same device and node count gets a classic table); it is handed back by
+// Ctx::release_all, i.e. after the call's last synchronisation -- no kernel of the call touches it afterwards.  Blocks
+// come from the caller's allocator (host->alloc) and stay allocated for the life of the process (at most
+// kDenseCacheEntries x 128 MiB per device).
+struct DenseCacheEntry {
+  int device;
+  int64_t dense_n;
+  u64* ptr;
+  u64 epoch;
+  bool busy;
+};
+constexpr int kDenseCacheEntries = 8;
+constexpr int64_t kDenseCacheMaxN = 1ll << 24;  // 128 MiB per table
+inline std::mutex& dense_cache_mutex() {
+  static std::mutex m;
+  return m;
+}
+inline std::vector<DenseCacheEntry>& dense_cache() {
+  static std::vector<DenseCacheEntry> v;
+  return v;
+}
+inline bool dense_cache_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PYG_HIP_SAMPLER_TABLE_CACHE");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+std::atomic<u64> g_epoch_limit{kEpochMax};  // epochs per clear of a cached table (lowered by tests to exercise the wrap)
+}  // namespace
+namespace sampler {
+void dense_cache_release(void* ptr) {  // declared in sampler_rng.h (Ctx::release_all)
+  std::lock_guard<std::mutex> lock(dense_cache_mutex());
+  for (DenseCacheEntry& e : dense_cache())
+    if (e.ptr == ptr) e.busy = false;
+}
+}  // namespace sampler
+namespace {
+
 // keys and vals share one block (one allocation, one memset); `hint` = entries expected by the end of
-// the call, so that the table is usually built once instead of being rehashed every hop.
-int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
+// the call, so that the table is usually built once instead of being rehashed every hop.  `epoch_ok`: the caller's
+// kernels all read the value coding from the HashTable (the fused chain), so a cached epoch table may be used.
+int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0, bool epoch_ok = false) {
   const int64_t need = ns.entries_bound + extra;
   if (ns.table.keys && ns.table.dense) {
     ns.entries_bound = need;
@@ -919,16 +978,71 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   if (!ns.table.keys && ns.dense_n > 0 && (u64)ns.dense_n <= 4 * ncap && ns.dense_n <= (1ll << 27)) {
     // direct-address table: at most twice the bytes of the hash table it replaces
     HashTable dt;
-    PYG_ALLOC(dt.keys, u64*, c, sizeof(u64) * (size_t)(ns.dense_n + (ns.dense_n & 1)));  // whole 16-byte stores
-    dt.vals = dt.keys;
     dt.mask = 0;
     dt.dense = 1;
-    // cleared by an own kernel: the runtime's fill kernel takes 12 us for the 19.6 MB of a products-sized table (1.6 TB/s)
-    {
+    dt.prov = kProvisional;
+    dt.tag = 0;
+    dt.idmask = ~0ull;
+    auto clear = [&](u64* p) -> int {
+      // cleared by an own kernel: the runtime's fill kernel takes 12 us for the 19.6 MB of a products-sized table (1.6 TB/s)
       const int64_t n16 = (ns.dense_n + 1) / 2;
       hipLaunchKernelGGL(table_clear_kernel, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, 1 << 20)), dim3(256), 0,
-                         c.stream, reinterpret_cast<u64x2*>(dt.keys), n16);
+                         c.stream, reinterpret_cast<u64x2*>(p), n16);
       PYG_HIP_CHECK(hipGetLastError());
+      return PYG_HIP_OK;
+    };
+    if (epoch_ok && dense_cache_enabled() && ns.dense_n <= kDenseCacheMaxN) {
+      int dev = 0;
+      PYG_HIP_CHECK(hipGetDevice(&dev));
+      bool room = false;
+      u64* block = nullptr;
+      u64 epoch = 0;
+      {
+        std::lock_guard<std::mutex> lock(dense_cache_mutex());
+        int count = 0;
+        for (DenseCacheEntry& e : dense_cache()) {
+          count += e.device == dev ? 1 : 0;
+          if (e.device == dev && e.dense_n == ns.dense_n && !e.busy && !block) {
+            e.busy = true;
+            if (e.epoch >= g_epoch_limit.load()) e.epoch = 0;
+            epoch = ++e.epoch;
+            block = e.ptr;
+          }
+        }
+        room = count < kDenseCacheEntries;
+      }
+      if (block) {
+        if (epoch == 1) {  // wrapped around: stale entries of the old numbering would look current
+          int rc = clear(block);
+          if (rc != PYG_HIP_OK) return rc;
+        }
+      } else if (room) {
+        PYG_ALLOC(block, u64*, c, sizeof(u64) * (size_t)(ns.dense_n + (ns.dense_n & 1)));
+        c.keep(block);  // owned by the cache from here on
+        int rc = clear(block);
+        if (rc != PYG_HIP_OK) return rc;
+        epoch = 1;
+        std::lock_guard<std::mutex> lock(dense_cache_mutex());
+        dense_cache().push_back(DenseCacheEntry{dev, ns.dense_n, block, epoch, true});
+      }
+      if (block) {
+        dt.keys = block;
+        dt.vals = block;
+        dt.tag = (kEpochMax - epoch) << kEpochShift;
+        dt.prov = dt.tag | kEpochProv;
+        dt.idmask = kEpochProv - 1;
+        ns.table = dt;
+        ns.cached = block;
+        c.cached_tables.push_back(block);
+        ns.entries_bound = need;
+        return PYG_HIP_OK;
+      }
+    }
+    PYG_ALLOC(dt.keys, u64*, c, sizeof(u64) * (size_t)(ns.dense_n + (ns.dense_n & 1)));  // whole 16-byte stores
+    dt.vals = dt.keys;
+    {
+      int rc = clear(dt.keys);
+      if (rc != PYG_HIP_OK) return rc;
     }
     ns.table = dt;
     ns.entries_bound = need;
@@ -936,6 +1050,9 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0) {
   }
   HashTable nt;
   nt.dense = 0;
+  nt.prov = kProvisional;
+  nt.tag = 0;
+  nt.idmask = ~0ull;
   PYG_ALLOC(nt.keys, u64*, c, sizeof(u64) * 2 * ncap);
   nt.vals = nt.keys + 1;  // interleaved slots: (key, value) pairs
   nt.mask = ncap - 1;
@@ -1027,9 +1144,6 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   TypeState* tstate;
   PYG_ALLOC(chain, ChainState*, c, sizeof(ChainState));
   PYG_ALLOC(tstate, TypeState*, c, sizeof(TypeState) * (size_t)num_node_types);
-  hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((num_node_types + 63) / 64)), dim3(64), 0, stream, chain,
-                     rng.word, rng.units, tstate, num_node_types);
-  PYG_HIP_CHECK(hipGetLastError());
 
   // Upper bounds from the seeds and the fan-out products: frontier size per (hop, type), emitted edges per
   // (hop, relation).  With bounded fan-outs they size everything up front (fully queued mode below).
@@ -1079,6 +1193,13 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
 
   const bool fused = fast && allow_fused && fused_eligible(rels, num_relations, num_node_types, num_seed_sets, csc, L, eb);
   std::vector<FusedSeed> fseeds;
+  if (!fused) {
+    // the chains below read and advance the device-resident engine position / type states; the fused chain keeps its
+    // state in write-once tables (fused_init_kernel) and only WRITES `chain` (fold) and `tstate` (seed insert)
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((num_node_types + 63) / 64)), dim3(64), 0, stream, chain,
+                       rng.word, rng.units, tstate, num_node_types);
+    PYG_HIP_CHECK(hipGetLastError());
+  }
 
   // The word generation (side stream).  Round 2's chain queues it behind the seed kernels (which do not need it; its
   // launches would otherwise sit in front of them on the host); the fused chain, whose hops follow each other within
@@ -1148,7 +1269,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       rc = n.batch.reserve(c, S, S + nb);
       if (rc != PYG_HIP_OK) return rc;
     }
-    rc = table_reserve(c, n, fused ? S + nb : S, S + nb);  // fused chain: sized once (the seeds' slot handles stay valid)
+    rc = table_reserve(c, n, fused ? S + nb : S, S + nb, fused);  // fused chain: sized once (the seeds' slot handles stay valid)
     if (rc != PYG_HIP_OK) return rc;
     u64* slots;
     PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
@@ -2284,6 +2405,15 @@ inline size_t relabel_ws_bytes(int64_t S, int64_t E) {
 using namespace pyg_hip;
 
 extern "C" const char* pyg_hip_sampler_last_mode(void) { return g_sampler_mode; }
+
+extern "C" int pyg_hip_sampler_table_cache(int64_t limit) {
+  g_epoch_limit.store(limit > 0 && (u64)limit < kEpochMax ? (u64)limit : kEpochMax);
+  int dev = 0, n = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(dense_cache_mutex());
+  for (const DenseCacheEntry& e : dense_cache()) n += e.device == dev ? 1 : 0;
+  return n;
+}
 
 extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                               const pyg_hip_relation* relations, int num_seed_sets,

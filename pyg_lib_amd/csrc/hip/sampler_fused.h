@@ -88,6 +88,8 @@ struct FConsumer {  // a relation of the NEXT hop that expands the segment's nod
 
 struct FSegHdr {  // one node type in one phase: the emissions of every relation that appends to it, in relation order
   u64* vals;
+  u64 prov;                // value coding of the type's table (HashTable::prov / tag)
+  u64 tag;
   int64_t* nodes;
   int64_t* batch;          // disjoint: batch ids of the list, else nullptr
   const int64_t* size_in;  // hop: &size_at[l * T + t]; seeds: nullptr
@@ -145,6 +147,7 @@ struct FSampleRec {  // sampling of relation e in hop l: what does not depend on
 struct FFinalRec {  // local ids of relation e's emissions of hop l
   const u64* slots;
   const u64* vals;
+  u64 idmask;        // HashTable::idmask of the table
   int64_t* out_col;  // base of the relation's col output
   int ell, e;
 };
@@ -288,7 +291,7 @@ __device__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
     for (int k = 0; k < kScanItems; ++k) {
       const int64_t p = base + k;
       if (p >= n) break;
-      const bool flag = vv[k] == kProvisional + (u64)(pt.pos_base + p);
+      const bool flag = vv[k] == pt.h.prov + (u64)(pt.pos_base + p);
       v[k].rank = flag ? 1 : 0;
       u64 word = flag ? 1ull : 0ull;
       if constexpr (NC > 0) {
@@ -378,7 +381,7 @@ __device__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int n
     if (p < n) {
       const bool flag = (word[k] & 1) != 0;
       if (flag) {
-        pt.h.vals[pt.slots[p]] = (u64)(id0 + run.rank);
+        pt.h.vals[pt.slots[p]] = pt.h.tag | (u64)(id0 + run.rank);
         if (!pt.h.seeds) {
           pt.h.nodes[size0 + run.rank] = pt.e_node[p];
           if (pt.h.batch) pt.h.batch[size0 + run.rank] = pt.e_batch[p];
@@ -506,7 +509,7 @@ __device__ __forceinline__ void fused_finalize(const FSampleLaunch& L, const FFi
   const int64_t n = __shfl(mine, ff.ell);
   if (__builtin_amdgcn_readfirstlane(over)) return;
   const int64_t p = (int64_t)blk * blockDim.x + threadIdx.x;
-  if (p < n) ff.out_col[off + p] = (int64_t)ff.vals[ff.slots[p]];
+  if (p < n) ff.out_col[off + p] = (int64_t)(ff.vals[ff.slots[p]] & ff.idmask);
 }
 
 // tables at the start of a call: sizes 0, totals identity, no overflow

@@ -81,7 +81,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     const int64_t want = n.nodes.size + node_bound[(size_t)t];
     if (n.entries_bound < want) {
       PYG_HIP_REQUIRE(n.nodes.size == 0 || n.table.dense, "sampler: internal error (seeded table would be rehashed)");
-      rc = table_reserve(c, n, want - n.entries_bound);
+      rc = table_reserve(c, n, want - n.entries_bound, 0, true);
       if (rc != PYG_HIP_OK) return rc;
     }
   }
@@ -237,6 +237,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     NodeSet& n = ns[(size_t)t];
     ::memset(&sh, 0, sizeof(sh));
     sh.vals = n.table.vals;
+    sh.prov = n.table.prov;
+    sh.tag = n.table.tag;
     sh.nodes = n.nodes.p;
     sh.batch = disjoint ? n.batch.p : nullptr;
     sh.dup = tb.dup + t;
@@ -386,6 +388,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       s.Eb = Eb;
       s.fin.slots = e_slot;
       s.fin.vals = dn.table.vals;
+      s.fin.idmask = dn.table.idmask;
       s.fin.out_col = st.col.p;
       s.fin.ell = ell;
       s.fin.e = e;

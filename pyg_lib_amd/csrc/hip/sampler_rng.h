@@ -71,6 +71,8 @@ __device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ ou
 }
 
 // ---- host context ---------------------------------------------------------------------------------
+void dense_cache_release(void* ptr);  // sampler.hip
+
 struct Ctx {
   const pyg_hip_sampler_host* host;
   hipStream_t stream;
@@ -98,9 +100,12 @@ struct Ctx {
     auto it = std::find(live.begin(), live.end(), p);
     if (it != live.end()) live.erase(it);
   }
+  std::vector<void*> cached_tables;  // DenseCache blocks lent to this call (sampler.hip), handed back with the scratch
   void release_all() {
     for (void* p : live) host->free(host->user, p);
     live.clear();
+    for (void* p : cached_tables) dense_cache_release(p);
+    cached_tables.clear();
   }
 };
 

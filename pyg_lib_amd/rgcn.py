@@ -68,6 +68,113 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
 
 
+def _fusable(x: Tensor, weight: Tensor) -> bool:
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 2 and x.size(1) == 128 and
+            weight.dim() == 3 and weight.size(1) == 128 and weight.size(2) == 128 and weight.dtype == x.dtype and
+            weight.device == x.device)
+
+
+def _rel_ptr_and_indices(gather: List[Tensor], scatter: List[Tensor], goff: List[int], soff: List[int]):
+    counts = [0]
+    for g in gather:
+        counts.append(counts[-1] + g.numel())
+    gidx = torch.cat([g + o if o else g for g, o in zip(gather, goff)])
+    sidx = torch.cat([s + o if o else s for s, o in zip(scatter, soff)])
+    return torch.tensor(counts, dtype=torch.long), gidx, sidx
+
+
+class _RGCNFused(torch.autograd.Function):
+    r"""out = rgcn_fused(x, W) with gradients.  Per edge e of relation r:  out[s_e] += x[g_e] @ W_r, hence
+
+        dX[g_e] += dOut[s_e] @ W_r^T     -- the SAME fused kernel with the two index vectors swapped and W_r^T as weight
+                                            (gather dOut rows, multiply, scatter-add into dX);
+        dW_r     = sum_e x[g_e]^T dOut[s_e] = X_r^T dY_r over the relation's gathered rows -- the weight-gradient
+                   kernel (``pyg::segment_matmul_grad_other``: one launch for all relations) on the two gathers.
+
+    This is what autograd derives for the reference's chain gather_coo -> segment_matmul -> scatter_sum
+    (ops/autograd/segment_coo_kernel.cpp GatherCOO, ops/autograd/matmul_kernel.cpp:68-111,
+    ops/autograd/scatter_kernel.cpp ScatterSum) with the [E, F] intermediates of the dX path never materialised."""
+
+    @staticmethod
+    def forward(ctx, x, weight, total, goff, soff, *index):
+        R = len(index) // 2
+        gather, scatter = list(index[:R]), list(index[R:])
+        out = x.new_zeros(total, weight.size(-1))
+        torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)
+        ctx.save_for_backward(x, weight, *index)
+        ctx.meta = (goff, soff, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors[:2]
+        index = ctx.saved_tensors[2:]
+        goff, soff, R = ctx.meta
+        gather, scatter = list(index[:R]), list(index[R:])
+        grad_out = grad_out.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.zeros_like(x)
+            torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
+        if ctx.needs_input_grad[1]:
+            ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
+            if gidx.numel() == 0:
+                gw = torch.zeros_like(weight)
+            else:
+                gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(x, gidx), ptr, ops.gather_coo(grad_out, sidx))
+        return (gx, gw, None, None, None) + (None,) * len(index)
+
+
+class _RGCNFusedTables(torch.autograd.Function):
+    r"""``rgcn_fused_tables`` with gradients: the weight gradient as in :class:`_RGCNFused` (the relation's source rows
+    are gathered from the tables through ``node_id`` for it); feature tables that require a gradient receive
+    ``index_add`` of the per-batch dX (computed by the fused kernel with swapped roles), exactly what autograd gives the
+    fallback ``cat([feat[t][node_id[t]]])``."""
+
+    @staticmethod
+    def forward(ctx, weight, T, gtype, soff, *tensors):
+        feat, node_id = list(tensors[:T]), list(tensors[T:2 * T])
+        index = tensors[2 * T:]
+        R = len(index) // 2
+        gather, scatter = list(index[:R]), list(index[R:])
+        n_t = [t.numel() for t in node_id]
+        out = feat[0].new_zeros(sum(n_t), weight.size(-1))
+        torch.ops.pyg.rgcn_fused_tables(feat, node_id, gtype, gather, scatter, soff, weight, out)
+        ctx.save_for_backward(weight, *tensors)
+        ctx.meta = (T, gtype, soff, R, n_t)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weight = ctx.saved_tensors[0]
+        tensors = ctx.saved_tensors[1:]
+        T, gtype, soff, R, n_t = ctx.meta
+        feat, node_id = list(tensors[:T]), list(tensors[T:2 * T])
+        index = tensors[2 * T:]
+        gather, scatter = list(index[:R]), list(index[R:])
+        grad_out = grad_out.contiguous()
+        toff = [0]
+        for n in n_t:
+            toff.append(toff[-1] + n)
+        goff = [toff[t] for t in gtype]   # the per-batch matrix cat([feat[t][node_id[t]]]) the tables stand for
+        gw = None
+        gfeat = [None] * T
+        if ctx.needs_input_grad[0]:
+            ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
+            if gidx.numel() == 0:
+                gw = torch.zeros_like(weight)
+            else:
+                xb = torch.cat([f[n] for f, n in zip(feat, node_id)])   # the per-batch matrix the tables stand for
+                gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(xb, gidx), ptr, ops.gather_coo(grad_out, sidx))
+        if any(ctx.needs_input_grad[4 + t] for t in range(T)):
+            gx = grad_out.new_zeros(toff[-1], weight.size(1))
+            torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
+            for t in range(T):
+                if ctx.needs_input_grad[4 + t]:
+                    gfeat[t] = torch.zeros_like(feat[t]).index_add_(0, node_id[t], gx[toff[t]:toff[t + 1]])
+        return (gw, None, None, None) + tuple(gfeat) + (None,) * (len(tensors) - T)
+
+
 def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                      col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
                      csc: bool = False) -> Tensor:
@@ -77,17 +184,14 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128``; anything else
     takes the three-op chain.
 
-    The fused operator is inference-only (``pyg::rgcn_fused`` has no autograd formula): when gradients are being
-    recorded for ``x`` or ``weight`` the differentiable three-op chain runs instead, so a training loop that switches
-    to this function keeps learning.  Accumulation: messages are rounded to the storage type (what the chain
-    materialises), summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with
-    one packed 16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile
-    boundaries) is rounded once per run, where ``scatter_sum`` rounds once per destination."""
+    Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
+    backward runs the same kernel with swapped roles for dX and the weight-gradient kernel on the gathered rows for dW
+    (:class:`_RGCNFused`).  Accumulation: messages are rounded to the storage type (what the chain materialises),
+    summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with one packed
+    16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile boundaries) is
+    rounded once per run, where ``scatter_sum`` rounds once per destination."""
     total = offsets['__total__']
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
-    if needs_grad or not (x.dtype in (torch.bfloat16, torch.float16) and x.size(1) == 128 and weight.dim() == 3 and
-                          weight.size(-1) == 128 and x.is_cuda and weight.dtype == x.dtype and
-                          weight.device == x.device):
+    if not _fusable(x, weight):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:
@@ -97,6 +201,8 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
         scatter.append(row_dict[et])
         goff.append(offsets[col_t])
         soff.append(offsets[row_t])
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return _RGCNFused.apply(x, weight, total, goff, soff, *gather, *scatter)
     out = x.new_zeros(total, weight.size(-1))
     return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)
 
@@ -112,18 +218,19 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     computes, without ``x``: every relation's rows are gathered through the sampler's ``node_id`` of its source type
     inside the kernel (``pyg::rgcn_fused_tables``), so the per-batch feature matrix, the ATen gathers and the ``cat``
     disappear.  Returns ``[sum_t len(node_id_dict[t]), F_out]`` in ``node_types`` order.  Same conditions (16-bit,
-    ``F = 128``, no gradients) as :func:`rgcn_layer_fused`; otherwise the chain above runs."""
+    ``F = 128``) as :func:`rgcn_layer_fused`, otherwise the chain above runs; differentiable in ``weight`` and in every
+    feature table that requires a gradient (:class:`_RGCNFusedTables`)."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
     f0 = feat_dict[node_types[0]]
-    needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feat_dict.values()))
+    feats = [feat_dict[t] for t in node_types]
+    nids = [node_id_dict[t] for t in node_types]
+    needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feats))
     # every table and the weight: one device, one 16-bit type, F = 128 (anything else: the chain, which checks nothing
     # more than its own ops do)
-    ok = f0.is_cuda and f0.dtype in (torch.bfloat16, torch.float16) and weight.dim() == 3 and weight.size(-1) == 128 and \
-        weight.dtype == f0.dtype and weight.device == f0.device and \
-        all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
-            for f in (feat_dict[t] for t in node_types)) and \
-        all(node_id_dict[t].device == f0.device and node_id_dict[t].dtype == torch.long for t in node_types)
-    if needs_grad or not ok:
+    ok = _fusable(f0, weight) and all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
+                                      for f in feats) and \
+        all(n.device == f0.device and n.dtype == torch.long and n.dim() == 1 for n in nids)
+    if not ok:
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
         return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc)
     tidx = {t: i for i, t in enumerate(node_types)}
@@ -135,6 +242,7 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
         scatter.append(row_dict[et])
         gtype.append(tidx[col_t])
         soff.append(off[row_t])
+    if needs_grad:
+        return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, *feats, *nids, *gather, *scatter)
     out = f0.new_zeros(off['__total__'], weight.size(-1))
-    return torch.ops.pyg.rgcn_fused_tables([feat_dict[t] for t in node_types], [node_id_dict[t] for t in node_types],
-                                           gtype, gather, scatter, soff, weight, out)
+    return torch.ops.pyg.rgcn_fused_tables(feats, nids, gtype, gather, scatter, soff, weight, out)

@@ -284,6 +284,9 @@ def test_grouped_matmul_backward_mixed_shapes_is_one_launch(dtype):
         want_w = a.double().t() @ gy.double()
         gx, gw = grads[i], grads[len(xs) + i]
         assert gx.shape == a.shape and gw.shape == o.shape and gw.dtype == dtype
+        if a.size(0) == 0:   # a group without rows: zero weight gradient, empty input gradient
+            assert not gw.any()
+            continue
         assert (gw.double().cpu() - want_w).abs().max().item() <= _dw_tol(dtype, want_w), i
         assert (gx.double().cpu() - want_x).abs().max().item() <= _dw_tol(dtype, want_x) * 8, i
 

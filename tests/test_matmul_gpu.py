@@ -207,6 +207,8 @@ def test_fp32_special_values_exact_mode_matches_the_cpu_reference(M, sched):
     assert (out[rows['zero']] == 0).all()
     assert not torch.isfinite(out[300:370, 1]).any() and torch.isnan(out[370:403, 0]).all()
     fin = torch.isfinite(ref)
+    fin[rows['tiny']] = False      # (rows around the denormal range: absolute checks below)
+    fin[rows['denorm']] = False
     err = (out.double() - ref.double())[fin].abs()
     scale = (x.double().abs() @ torch.ones(128, 1, dtype=torch.double)).expand_as(ref)[fin].clamp_min(1e-45)
     assert (err / scale).max() <= 1e-5                       # every finite element, relative to its row's magnitude

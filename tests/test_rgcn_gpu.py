@@ -327,19 +327,122 @@ def test_checked_mode_reports_bad_indices(monkeypatch):
         torch.ops.pyg.rgcn_fused(x, [g.cpu()], [s], [0], [0], w, out)
 
 
-def test_fused_layer_falls_back_to_the_differentiable_chain_under_autograd():
-    """ADVICE r2: pyg::rgcn_fused has no autograd formula; with gradients being recorded the wrapper must take the
-    three-op chain, so a training loop that switches to it keeps learning."""
-    from pyg_lib_amd import rgcn
-    ets = [('a', 'x', 'a')]
-    x = torch.randn(50, 128, device='cuda').bfloat16().requires_grad_()
-    w = (torch.randn(1, 128, 128, device='cuda') / 11).bfloat16().requires_grad_()
-    r = torch.sort(torch.randint(0, 50, (300,), device='cuda')).values
-    c = torch.randint(0, 50, (300,), device='cuda')
-    off = rgcn.type_offsets({'a': 50}, ['a'])
-    y = rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w)
-    y.float().sum().backward()
-    assert x.grad is not None and w.grad is not None and x.grad.abs().sum() > 0 and w.grad.abs().sum() > 0
+def _hetero_case(g, dtype, integer):
+    types = ['a', 'b', 'c']
+    n_global = {'a': 5000, 'b': 300, 'c': 20000}
+    n_local = {'a': 700, 'b': 64, 'c': 1500}
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'b'), ('b', 'r2', 'a'), ('c', 'r3', 'a'), ('a', 'r4', 'c'), ('c', 'r5', 'c')]
+    counts = [4000, 33, 1000, 0, 129, 9000]
+    F = 128
+    feat = {t: (torch.randint(-2, 3, (n_global[t], F), generator=g).float() if integer
+                else torch.randn(n_global[t], F, generator=g)).to(dtype).cuda() for t in types}
+    node_id = {t: torch.randperm(n_global[t], generator=g)[:n_local[t]].cuda() for t in types}
+    if integer:
+        perm = torch.stack([torch.randperm(F, generator=g) for _ in ets])
+        W = torch.zeros(len(ets), F, F)
+        W[torch.arange(len(ets))[:, None], perm, torch.arange(F)[None, :]] = \
+            (torch.randint(0, 2, (len(ets), F), generator=g) * 2 - 1).float()
+    else:
+        W = torch.randn(len(ets), F, F, generator=g) / F ** 0.5
+    rows, cols = {}, {}
+    for (s, r, d), c in zip(ets, counts):
+        rows[(s, r, d)] = torch.sort(torch.randint(0, min(n_local[s], 200), (c,), generator=g)).values.cuda()
+        cols[(s, r, d)] = torch.randint(0, n_local[d], (c,), generator=g).cuda()
+    return types, n_local, ets, feat, node_id, W.to(dtype).cuda(), rows, cols
+
+
+def _float64_grads(x, W, go, rows, cols, ets, off):
+    """dX, dW of out[row] += x[col] @ W_r in float64 (the formulas autograd derives for the reference's chain)."""
+    xd, Wd, god = x.double().cpu(), W.double().cpu(), go.double().cpu()
+    gx = torch.zeros_like(xd)
+    gw = torch.zeros_like(Wd)
+    for i, (s, r, d) in enumerate(ets):
+        ri, ci = rows[(s, r, d)].cpu() + off[s], cols[(s, r, d)].cpu() + off[d]
+        gx.index_add_(0, ci, god[ri] @ Wd[i].t())
+        gw[i] = xd[ci].t() @ god[ri]
+    return gx, gw
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_fused_layer_is_differentiable_and_matches_the_chain(dtype):
+    """VERDICT r3 Missing 4: `rgcn_layer_fused` under autograd keeps the ONE-launch forward (no fallback) and returns the
+    gradients of the reference's chain gather_coo -> segment_matmul -> scatter_sum: dX through the same fused kernel with
+    swapped index roles and W^T, dW through the weight-gradient kernel on the gathered rows."""
+    from pyg_lib_amd import ops, rgcn
+    g = torch.Generator().manual_seed(31)
+    types, n_local, ets, feat, node_id, W, rows, cols = _hetero_case(g, dtype, integer=False)
+    off = rgcn.type_offsets(n_local, types)
+    x = torch.cat([feat[t][node_id[t]] for t in types])
+    go = torch.randn(x.size(0), 128, generator=g).to(dtype).cuda()
+    xf, wf = x.clone().requires_grad_(), W.clone().requires_grad_()
+    before = ops.matmul_dw_counters()
+    y = rgcn.rgcn_layer_fused(xf, off, rows, cols, ets, wf)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith('_RGCNFused')   # the fused forward, not the chain
+    gx, gw = torch.autograd.grad(y, [xf, wf], go)
+    assert sum(ops.matmul_dw_counters()) == sum(before) + 1                               # dW: one kernel launch
+    # the chain's gradients (same op-level rounding points) and the float64 truth
+    xc, wc = x.clone().requires_grad_(), W.clone().requires_grad_()
+    yc = rgcn.rgcn_layer(xc, off, rows, cols, ets, wc)
+    gxc, gwc = torch.autograd.grad(yc, [xc, wc], go)
+    want_x, want_w = _float64_grads(x, W, go, rows, cols, ets, off)
     with torch.no_grad():
-        y2 = rgcn.rgcn_layer_fused(x, off, {ets[0]: r}, {ets[0]: c}, ets, w)
-    assert (y.float() - y2.float()).abs().max() <= 3e-2 * y2.float().abs().max()
+        y0 = rgcn.rgcn_layer_fused(x, off, rows, cols, ets, W)
+    assert torch.equal(y.detach().view(torch.int16), y0.view(torch.int16)) or \
+        (y.float() - y0.float()).abs().max() <= 2e-2 * y0.float().abs().max()   # (atomic order may differ between runs)
+    eps = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    for got, chain, want in ((gx, gxc, want_x), (gw, gwc, want_w)):
+        scale = want.abs().max().item()
+        assert scale > 0.5
+        err = (got.double().cpu() - want).abs().max().item()
+        err_chain = (chain.double().cpu() - want).abs().max().item()
+        assert err <= 4 * eps * scale, (err, scale)
+        assert err <= 2 * err_chain + eps * scale, (err, err_chain)   # as accurate as the chain's own backward
+
+
+def test_fused_layer_gradients_are_exact_on_integer_data():
+    """Small-integer features, signed-permutation weights, small-integer upstream gradients: every partial sum of dX and
+    dW is an exact bf16 integer, so both must equal the float64 formulas bit for bit."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(32)
+    types, n_local, ets, feat, node_id, W, rows, cols = _hetero_case(g, torch.bfloat16, integer=True)
+    off = rgcn.type_offsets(n_local, types)
+    x = torch.cat([feat[t][node_id[t]] for t in types])
+    go = torch.zeros(x.size(0), 128)
+    hot = torch.randint(0, x.size(0), (60,), generator=g)       # a sparse upstream gradient keeps the sums below 256
+    go[hot] = torch.randint(-1, 2, (60, 128), generator=g).float()
+    go = go.bfloat16().cuda()
+    xf, wf = x.clone().requires_grad_(), W.clone().requires_grad_()
+    y = rgcn.rgcn_layer_fused(xf, off, rows, cols, ets, wf)
+    gx, gw = torch.autograd.grad(y, [xf, wf], go)
+    want_x, want_w = _float64_grads(x, W, go, rows, cols, ets, off)
+    assert want_x.abs().max() < 256 and want_w.abs().max() < 256
+    assert torch.equal(gx.double().cpu(), want_x)
+    assert torch.equal(gw.double().cpu(), want_w)
+
+
+@pytest.mark.parametrize('feat_grad', [False, True])
+def test_fused_tables_layer_is_differentiable(feat_grad):
+    """`rgcn_layer_fused_tables` under autograd: weight gradient always, table gradients (index_add of the per-batch dX)
+    for the tables that ask -- against autograd through the materialised chain."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(33)
+    types, n_local, ets, feat, node_id, W, rows, cols = _hetero_case(g, torch.bfloat16, integer=False)
+    go = torch.randn(sum(n_local.values()), 128, generator=g).bfloat16().cuda()
+    f1 = {t: feat[t].clone().requires_grad_(feat_grad and t != 'b') for t in types}
+    w1 = W.clone().requires_grad_()
+    y = rgcn.rgcn_layer_fused_tables(f1, node_id, types, rows, cols, ets, w1)
+    assert type(y.grad_fn).__name__.startswith('_RGCNFusedTables')
+    wanted = [w1] + [f1[t] for t in types if f1[t].requires_grad]
+    got = torch.autograd.grad(y, wanted, go)
+    f2 = {t: feat[t].clone().requires_grad_(feat_grad and t != 'b') for t in types}
+    w2 = W.clone().requires_grad_()
+    x2 = torch.cat([f2[t][node_id[t]] for t in types])
+    y2 = rgcn.rgcn_layer(x2, rgcn.type_offsets(n_local, types), rows, cols, ets, w2)
+    ref = torch.autograd.grad(y2, [w2] + [f2[t] for t in types if f2[t].requires_grad], go)
+    assert len(got) == len(ref) == (3 if feat_grad else 1)
+    for a, b in zip(got, ref):
+        scale = b.float().abs().max().item()
+        assert a.shape == b.shape and scale > 0.1
+        assert (a.float() - b.float()).abs().max().item() <= 3e-2 * scale
+
+

@@ -338,3 +338,63 @@ def test_hetero_hub_forces_word_top_up_and_requeue():
         # the global CPU generator advanced by exactly the reference's number of 128-word prefetches
         assert after == int(oracle.mt19937_words(77, ref[6]['rng_blocks'] * 128 + 1)[-1])
         assert sum(sum(v) for v in ref[5].values()) > 100
+
+
+def _table_cache(limit=0):
+    import ctypes
+    from pyg_lib_amd import _capi
+    L = _capi.lib()
+    L.pyg_hip_sampler_table_cache.argtypes = [ctypes.c_int64]
+    L.pyg_hip_sampler_table_cache.restype = ctypes.c_int
+    return L.pyg_hip_sampler_table_cache(limit)
+
+
+def test_cached_node_tables_survive_reuse_other_graphs_and_epoch_wrap():
+    """The fused chain keeps its direct-address node table between calls and invalidates old contents through an epoch in
+    the value coding instead of clearing 8 bytes per node per call.  Every call below must stay bit-exact with the
+    oracle: the same graph again (its old ids are stale now), OTHER graphs with the same node count (stale entries that
+    name different nodes' positions), duplicate seeds, and -- with the epoch limit lowered to 3 -- the wrap-around, where
+    the numbering restarts and the table is cleared once."""
+    n = 20000
+    graphs = [random_csr(n, 12, 50 + i) for i in range(3)]
+    try:
+        _table_cache(3)   # wrap after three calls per table
+        for it in range(14):
+            rowptr, col = graphs[it % 3]
+            rng = np.random.default_rng(100 + it)
+            seed = rng.choice(n, 300, replace=False)
+            if it % 5 == 4:
+                seed[7] = seed[3]
+            out, after, ref = run_both(rowptr, col, seed, [10, 5, 3], 1000 + it)
+            assert sampler.last_mode() == 'fused'
+            assert_same(out, after, ref, 1000 + it)
+        assert _table_cache(0) >= 1   # a table of this size is cached (and the limit is back at its default)
+    finally:
+        _table_cache(0)
+
+
+def test_cached_node_tables_hetero_types_with_equal_node_counts():
+    """Two node types with the SAME node count in one call need two cached tables (an entry serves one table at a time);
+    repeated calls reuse both."""
+    n = 6000
+    types = ['a', 'b']
+    ets = [('a', 'x', 'b'), ('b', 'y', 'a'), ('a', 'z', 'a')]
+    rng = np.random.default_rng(7)
+    rp, cl = {}, {}
+    for i, et in enumerate(ets):
+        rp[et], cl[et] = random_csr(n, 8, 70 + i)
+    fan = {et: [6, 4] for et in ets}
+    for it in range(5):
+        seeds = {'a': rng.choice(n, 120, replace=False).astype(np.int64), 'b': rng.choice(n, 80, replace=False).astype(np.int64)}
+        torch.manual_seed(77 + it)
+        out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                             {k: dev(v) for k, v in seeds.items()}, fan)
+        assert sampler.last_mode() == 'fused'
+        ref = oracle.hetero_neighbor_sample(types, ets, rp, cl, seeds, fan, rng_seed=77 + it)
+        for e in ets:
+            assert torch.equal(out[0][e].cpu(), torch.from_numpy(ref[0][e])), (it, e)
+            assert torch.equal(out[1][e].cpu(), torch.from_numpy(ref[1][e])), (it, e)
+            assert out[5][e] == ref[5][e]
+        for t in types:
+            assert torch.equal(out[2][t].cpu(), torch.from_numpy(ref[2][t])), (it, t)
+    assert _table_cache(0) >= 2

@@ -316,7 +316,8 @@ def test_weight_gradient_kernel_under_noise_stays_exact(dtype, K, M):
     sizes = [0, 37, 128, 129, 1000, 0, 5000, 31, 257, 9000]
     ptr = torch.tensor([0] + np.cumsum(sizes).tolist())
     n, B = int(ptr[-1]), len(sizes)
-    x = torch.randint(-1, 2, (n, K), generator=g).float()
+    # sparse X keeps the 9000-row relation's sums small: |dW| < 256 is exact in bf16 too
+    x = torch.randint(-1, 2, (n, K), generator=g).float() * (torch.rand(n, K, generator=g) < 0.06)
     gy = torch.randint(-2, 3, (n, M), generator=g).float()
     want = torch.stack([x[ptr[b]:ptr[b + 1]].double().t() @ gy[ptr[b]:ptr[b + 1]].double() for b in range(B)])
     assert want.abs().max() < 256   # exact in bf16 as well
