@@ -15,8 +15,11 @@
 //     SIMD), parks its rows in a wave-private row-major LDS image -- columns beyond K / M zero-filled, so the
 //     MFMAs never see a tail -- and reads the MFMA operands back transposed (ds_read_b64_tr_b16).  The fp32 kernel
 //     skips 32-column sub-blocks that lie entirely beyond K or M (its MFMAs are 8x slower per element).
-//   * Rows are fetched with the widest vector the group's base address and row pitch allow (16 / 8 / 4 / 2 bytes,
-//     per group: `lx`, `ly`), tails element by element.
+//   * Rows are fetched with the widest vector every operand of the LAUNCH allows (16 / 8 / 4 / 2 bytes: the smallest
+//     alignment class over its groups' base addresses and row pitches selects one of four instantiations -- a class
+//     switch inside the loop made the compiler copy the loaded registers at the merge, i.e. wait for the loads where
+//     they were issued: 2.1 instead of 5.6 TB/s); a chunk is 16 >> LG individually predicated loads, so row tails need
+//     no separate path.
 //   * fp32 runs v_mfma_f32_32x32x2_f32 (IEEE fp32 products and sums, like the exact forward kernel): its operands are
 //     "2 rows x 32 columns", read from the same row-major image with plain 4-byte LDS reads (no transpose).
 #include "matmul_common.h"
@@ -76,50 +79,32 @@ constexpr int gen_pitch(int cols) {
   return (32 + 64 * extra) * 4;
 }
 
-// 16 bytes of row `rowp` starting at element `c0`, zero beyond element `n` of the row; LG = log2 of the widest
-// vector (bytes) every chunk start of this operand is aligned to.
+// 16 bytes of row `rowp` starting at element `c0`, zero beyond element `n` of the row and for rows behind the group
+// (`row_ok`).  LG = log2 of the vector bytes every piece may be fetched with (the launch's alignment class): the chunk is
+// 16 >> LG independent, individually predicated loads -- the row pitch is a multiple of 2^LG bytes, so a row's tail is a
+// whole number of pieces.  No branch arm holds more than a load: the compiler needs no copy (and hence no wait) between
+// the loads and their use a tile later.  (LG = 1 assembles dwords from halves and is only used un-pipelined.)
 template <int ELT, int LG>
-__device__ __forceinline__ u32x4 load_chunk(const char* rowp, int c0, int n) {
-  constexpr int E = 16 / ELT;
+__device__ __forceinline__ u32x4 load_chunk(const char* rowp, int c0, int n, bool row_ok) {
   u32x4 v = {0u, 0u, 0u, 0u};
-  const int valid = n - c0;
-  if (valid <= 0) return v;
+  const int vb = row_ok ? (n - c0) * ELT : 0;  // valid bytes from the chunk start (<= 0: nothing, >= 16: all)
   const char* p = rowp + (int64_t)c0 * ELT;
-  if (valid >= E) {
-    if constexpr (LG >= 4) {
-      v = *reinterpret_cast<const u32x4*>(p);
-    } else if constexpr (LG == 3) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(p), b = *reinterpret_cast<const u32x2*>(p + 8);
-      v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1];
-    } else if constexpr (LG == 2) {
+  if constexpr (LG >= 4) {
+    if (vb >= 16) v = *reinterpret_cast<const u32x4*>(p);
+  } else if constexpr (LG == 3) {
+    u32x2 a = {0u, 0u}, b = {0u, 0u};
+    if (vb >= 8) a = *reinterpret_cast<const u32x2*>(p);
+    if (vb >= 16) b = *reinterpret_cast<const u32x2*>(p + 8);
+    v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1];
+  } else if constexpr (LG == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
-    } else {
+    for (int e = 0; e < 4; ++e)
+      if (vb >= 4 * (e + 1)) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
+  } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
-    }
-    return v;
+    for (int e = 0; e < 8; ++e)
+      if (vb >= 2 * (e + 1)) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
   }
-  // the row's tail chunk: the row pitch is a multiple of 2^LG bytes and chunks start at multiples of 16, so the tail is
-  // a whole number of 2^LG-byte pieces -- independent loads, all in flight together (a dependent per-element loop here
-  // cost K = 100 four serialised memory round trips per tile)
-  constexpr int P = LG >= 4 ? 16 : (1 << LG);  // bytes per piece
-  const int vb = valid * ELT;
-  if constexpr (P == 8) {
-    if (vb >= 8) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(p);
-      v[0] = a[0], v[1] = a[1];
-    }
-  } else if constexpr (P == 4) {
-#pragma unroll
-    for (int e = 0; e < 3; ++e)
-      if (4 * e < vb) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
-  } else if constexpr (P == 2) {
-#pragma unroll
-    for (int e = 0; e < 7; ++e)
-      if (2 * e < vb) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
-  }
-  // (P == 16: a row pitch of whole chunks has no tail)
   return v;
 }
 
@@ -131,21 +116,11 @@ __device__ __forceinline__ void load_rows(u32x4 (&r)[N], const char* base, int64
 #pragma unroll
   for (int it = 0; it < N; ++it) {
     const int p = it * 64 + lane;
-    const int64_t row = row0 + p / C;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows) v = load_chunk<ELT, LG>(base + row * width * ELT, c0 + (p % C) * E, width);
-    r[it] = v;
+    int64_t row = row0 + p / C;
+    const bool ok = row < rows;
+    if (!ok) row = 0;  // (address of a predicated-off load: anything inside the tensor)
+    r[it] = load_chunk<ELT, LG>(base + row * width * ELT, c0 + (p % C) * E, width, ok);
   }
-}
-
-template <int ELT, int C, int N>
-__device__ __forceinline__ void load_rows_any(u32x4 (&r)[N], const char* base, int64_t row0, int64_t rows, int width,
-                                              int c0, int lane, int lg) {
-  // `lg` is uniform over the workgroup: one straight-line copy of the loads per alignment class
-  if (lg >= 4) load_rows<ELT, 4, C, N>(r, base, row0, rows, width, c0, lane);
-  else if (lg == 3) load_rows<ELT, 3, C, N>(r, base, row0, rows, width, c0, lane);
-  else if (lg == 2 || ELT == 4) load_rows<ELT, 2, C, N>(r, base, row0, rows, width, c0, lane);
-  else load_rows<ELT, 1, C, N>(r, base, row0, rows, width, c0, lane);
 }
 
 __device__ __forceinline__ f32x16 gen_mfma16(bf16_t, v8i16 a, v8i16 b, f32x16 c) {
@@ -164,7 +139,7 @@ struct TileKey {
   int64_t acc_off;
 };
 
-template <typename T>
+template <typename T, int LG>
 __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __restrict__ groups,
                                                          const int32_t* __restrict__ tile_start, int B,
                                                          float* __restrict__ acc_out) {
@@ -253,8 +228,8 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
     nk.acc_off = gd.acc_off;
     const int64_t row0 = (int64_t)rt * kTile + wave * 32;
     const int kc0 = nk.kb * KB, mc0 = nk.mb * MB;
-    load_rows_any<ELT, CX, NX>(xr, gd.x, row0, gd.rows, gd.k, kc0, lane, gd.lx);
-    load_rows_any<ELT, CY, NY>(yr, gd.dy, row0, gd.rows, gd.m, mc0, lane, gd.ly);
+    load_rows<ELT, LG, CX, NX>(xr, gd.x, row0, gd.rows, gd.k, kc0, lane);
+    load_rows<ELT, LG, CY, NY>(yr, gd.dy, row0, gd.rows, gd.m, mc0, lane);
   };
 
   // lane constants of the 16-bit transpose reads (see seg_dw_kernel): lane q of a 16-lane group supplies row (q >> 2),
@@ -264,8 +239,12 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
   const int b_off = (khalf * 8 + (q >> 2)) * PY + (half * 16 + (q & 3) * 4) * 2;
   typedef __attribute__((address_space(3))) v4i16* lds_v4;
 
-  prefetch(t_beg);
+  // LG >= 2: the rows of tile t + 1 travel while tile t is multiplied; LG = 1 (operands aligned to the element only)
+  // assembles its dwords from halves, which needs the data at once: fetched at the top of its own iteration
+  constexpr bool PIPE = LG >= 2;
+  if constexpr (PIPE) prefetch(t_beg);
   for (int t = t_beg; t < t_end; ++t) {
+    if constexpr (!PIPE) prefetch(t);
     if (nk.g != ak.g || nk.blk != ak.blk) {
       flush();
       ak = nk;
@@ -285,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (t + 1 < t_end) prefetch(t + 1);
+    if constexpr (PIPE)
+      if (t + 1 < t_end) prefetch(t + 1);
     if constexpr (ELT == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -391,27 +371,39 @@ __global__ void dw_gen_round_kernel(const float* __restrict__ acc, uint16_t* __r
   else out[i] = __builtin_bit_cast(uint16_t, (_Float16)acc[i]);
 }
 
-template <typename T>
-int launch_gen(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* acc, hipStream_t stream) {
+template <typename T, int LG>
+int launch_gen_lg(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* acc, hipStream_t stream) {
   constexpr int ELT = Elem<T>::kSize;
   constexpr int lds = 4 * 32 * (gen_pitch<ELT>(32 * GenCfg<T>::IB) + gen_pitch<ELT>(32 * GenCfg<T>::JB));
   static_assert(lds <= 160 * 1024, "dw_gen_kernel: LDS");
-  const void* kern = reinterpret_cast<const void*>(&dw_gen_kernel<T>);
+  const void* kern = reinterpret_cast<const void*>(&dw_gen_kernel<T, LG>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, device_info().num_cus));
-  hipLaunchKernelGGL((dw_gen_kernel<T>), dim3((unsigned)gx), dim3(256), lds, stream, groups, tile_start, B, acc);
+  hipLaunchKernelGGL((dw_gen_kernel<T, LG>), dim3((unsigned)gx), dim3(256), lds, stream, groups, tile_start, B, acc);
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
+}
+
+// `lg`: alignment class of the launch = the smallest over its groups' operands (log2 of the vector bytes)
+template <typename T>
+int launch_gen(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* acc, int lg,
+               hipStream_t stream) {
+  if (lg >= 4) return launch_gen_lg<T, 4>(groups, tile_start, B, tiles_upper, acc, stream);
+  if (lg == 3) return launch_gen_lg<T, 3>(groups, tile_start, B, tiles_upper, acc, stream);
+  if constexpr (Elem<T>::kSize == 2) {
+    if (lg <= 1) return launch_gen_lg<T, 1>(groups, tile_start, B, tiles_upper, acc, stream);
+  }
+  return launch_gen_lg<T, 2>(groups, tile_start, B, tiles_upper, acc, stream);
 }
 
 inline int gen_kb(int dtype) { return dtype == PYG_F32 ? 32 * GenCfg<float>::IB : 32 * GenCfg<bf16_t>::IB; }
 inline int gen_mb(int dtype) { return dtype == PYG_F32 ? 32 * GenCfg<float>::JB : 32 * GenCfg<bf16_t>::JB; }
 
 int run_gen(int dtype, const DwGenGroup* groups, const int32_t* tile_start, int64_t B, int64_t tiles_upper, float* acc,
-            void* out, int64_t out_elems, hipStream_t stream) {
-  int rc = dtype == PYG_F32    ? launch_gen<float>(groups, tile_start, (int)B, tiles_upper, acc, stream)
-           : dtype == PYG_BF16 ? launch_gen<bf16_t>(groups, tile_start, (int)B, tiles_upper, acc, stream)
-                               : launch_gen<f16_t>(groups, tile_start, (int)B, tiles_upper, acc, stream);
+            void* out, int64_t out_elems, int lg, hipStream_t stream) {
+  int rc = dtype == PYG_F32    ? launch_gen<float>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream)
+           : dtype == PYG_BF16 ? launch_gen<bf16_t>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream)
+                               : launch_gen<f16_t>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream);
   if (rc != PYG_HIP_OK || dtype == PYG_F32) return rc;  // fp32: the atomics went straight into the (zeroed) result
   if (dtype == PYG_BF16)
     hipLaunchKernelGGL(dw_gen_round_kernel<bf16_t>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, stream, acc,
@@ -468,7 +460,10 @@ int dw_gen_segment(int dtype, const void* input, const int64_t* ptr, int ptr_on_
   hipLaunchKernelGGL(dw_gen_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, static_cast<const char*>(input),
                      static_cast<const char*>(grad_out), K, M, elt, kb, mb, groups, tile_start);
   PYG_HIP_CHECK(hipGetLastError());
-  return run_gen(dtype, groups, tile_start, B, tiles_upper, acc, grad_other, B * K * M, stream);
+  // a relation starts ptr[b] rows into the tensors: its alignment is at least that of the base and the row pitch
+  const int lg = std::min(std::min(gen_log2_align((uint64_t)input), gen_log2_align((uint64_t)(K * elt))),
+                          std::min(gen_log2_align((uint64_t)grad_out), gen_log2_align((uint64_t)(M * elt))));
+  return run_gen(dtype, groups, tile_start, B, tiles_upper, acc, grad_other, B * K * M, lg, stream);
 }
 
 int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void* out_pool, void* workspace,
@@ -487,6 +482,7 @@ int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void*
   DwGenGroup* hg = static_cast<DwGenGroup*>(staged);
   int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + gen_groups_bytes(G));
   int64_t t = 0, off = 0;
+  int lg = 4;
   for (int64_t i = 0; i < G; ++i) {
     const pyg_hip_group& g = host_groups[i];
     if (g.k >= (1 << 21) || g.m >= (1 << 21) || (int64_t)g.k * g.m >= (1LL << 28))
@@ -505,6 +501,7 @@ int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void*
     d.nmb = (int16_t)((g.m + mb - 1) / mb);
     PYG_HIP_REQUIRE(d.nkb >= 0 && d.nmb >= 0 && (g.k + kb - 1) / kb < 32768 && (g.m + mb - 1) / mb < 32768,
                     "grouped_matmul_dw: K / M too large");
+    if (g.rows > 0 && g.k > 0 && g.m > 0) lg = std::min(lg, (int)std::min(d.lx, d.ly));
     hg[i] = d;
     ht[i] = (int32_t)t;
     t += (g.rows + kTile - 1) / kTile * (int64_t)d.nkb * d.nmb;
@@ -521,7 +518,7 @@ int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void*
     if (dtype != PYG_F32) PYG_HIP_CHECK(hipMemsetAsync(out_pool, 0, (size_t)elt * (size_t)off, stream));
     return PYG_HIP_OK;
   }
-  return run_gen(dtype, groups, tile_start, G, t, acc, out_pool, off, stream);
+  return run_gen(dtype, groups, tile_start, G, t, acc, out_pool, off, lg, stream);
 }
 
 }  // namespace pyg_hip

@@ -122,25 +122,39 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   const int q = lane & 15, grp16 = lane >> 4;
   const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
   const int cch = lane >> 2, cdw = lane & 3;
-  for (int tt = 0; tt < td.count; ++tt) {
+  // Index pipeline: a tile needs edge -> gather_index -> (gather_map) -> feature row, three dependent memory round
+  // trips before its MFMAs.  The first level of tile t + 1 is requested together with tile t's row DMA, the second
+  // right behind their common wait, so that from its second tile on a workgroup pays ONE round trip per tile.
+  // lane l < 32 holds edge l of the wave's 32 (rows past the end repeat the last valid edge)
+  auto first_level = [&](int tt, int& nrows, int64_t& g1, int64_t& si) {
     const int64_t e0 = (int64_t)(td.tile + tt) * 128 + wave * 32;   // first edge of this wave inside the relation
     const int64_t left = rel.num_edges - e0;
-    const int nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
-    // indices of this wave's edges: lane l < 32 holds edge l (rows past the end repeat the last valid edge)
-    int64_t gi = 0, si = 0;
+    nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+    g1 = 0;
+    si = 0;
     if (nrows > 0) {
       const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
-      gi = rel.gather_index[e];
-      if (rel.gather_map) {  // double indirection done here: the gathered feature matrix never exists
-        if (CHECK && (gi < 0 || gi >= rel.map_len)) {
-          *error = 1;
-          gi = 0;
-        }
-        gi = rel.gather_map[gi];
-      } else {
-        gi += rel.gather_offset;
-      }
+      g1 = rel.gather_index[e];
       si = rel.scatter_index[e] + rel.scatter_offset;
+    }
+  };
+  auto second_level = [&](int nrows, int64_t g1) -> int64_t {
+    if (nrows == 0) return 0;
+    if (!rel.gather_map) return g1 + rel.gather_offset;
+    if (CHECK && (g1 < 0 || g1 >= rel.map_len)) {  // double indirection done here: the gathered feature matrix never exists
+      *error = 1;
+      g1 = 0;
+    }
+    return rel.gather_map[g1];
+  };
+  int nrows_n;
+  int64_t g1_n, si_n, gi_n;
+  first_level(0, nrows_n, g1_n, si_n);
+  gi_n = second_level(nrows_n, g1_n);
+  for (int tt = 0; tt < td.count; ++tt) {
+    const int nrows = nrows_n;
+    int64_t gi = gi_n, si = si_n;
+    if (nrows > 0) {
       if (CHECK) {
         if (gi < 0 || gi >= rel.x_rows) {
           *error = 1;
@@ -161,8 +175,11 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
                                          (LDSV*)(xs + i * 1024), 16, 0, 0);
       }
     }
+    const bool more = tt + 1 < td.count;
+    if (more) first_level(tt + 1, nrows_n, g1_n, si_n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tt == 0) __syncthreads();  // everybody's part of W has landed; the X stage is private to the wave
+    if (more) gi_n = second_level(nrows_n, g1_n);
     if (nrows == 0) continue;
     f32x16 acc[NT];
 #pragma unroll
@@ -244,10 +261,11 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
   int64_t E = 0, tiles = 0;
   for (int64_t r = 0; r < R; ++r) E += std::max<int64_t>(rels[r].num_edges, 0);
-  // tiles per workgroup: W_r (32 KB) is copied once per workgroup, so runs of a few tiles amortise it -- as long as
-  // the grid still has several workgroups for each of the chip's 2 x CUs slots
+  // tiles per workgroup: W_r (32 KB) is copied once per workgroup and every tile behind a workgroup's first has its
+  // indices prefetched, so runs of a few tiles pay -- as long as the grid still has a couple of workgroups for each of
+  // the chip's 2 x CUs slots
   const int64_t slots = 2 * (int64_t)device_info().num_cus;
-  const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (4 * slots)));
+  const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (2 * slots)));
   E = 0;
   for (int64_t r = 0; r < R; ++r) {
     PYG_HIP_REQUIRE(rels[r].num_edges >= 0, "rgcn_fused: negative edge count");

@@ -35,6 +35,24 @@ def type_offsets(num_nodes: Dict[str, int], node_types: List[str]) -> Dict[str, 
     return off
 
 
+class _GatherRows(torch.autograd.Function):
+    r"""``x[index]`` for an UNSORTED index: forward = the ``gather_coo`` kernel, backward = ``scatter_sum`` of the
+    gradient.  ``pyg::gather_coo``'s own autograd formula is ``segment_sum_coo`` -- the reference's
+    (ops/autograd/segment_coo_kernel.cpp) -- which is only valid for the SORTED index its contract asks for; the
+    neighbour columns of a sampled relation are not sorted."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.rows = x.size(0)
+        return ops.gather_coo(x, index)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (index,) = ctx.saved_tensors
+        return ops.scatter_sum(grad_out.contiguous(), index, 0, None, ctx.rows), None
+
+
 def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
                csc: bool = False) -> Tensor:
@@ -63,7 +81,7 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     gidx = torch.cat(gather_idx)
     sidx = torch.cat(scatter_idx)
     ptr = torch.tensor(counts, dtype=torch.long)  # host pointer: staged, never synchronises
-    feats = ops.gather_coo(x, gidx)                           # [E, F_in]
+    feats = _GatherRows.apply(x, gidx)                        # [E, F_in]
     msgs = ops.segment_matmul(feats, ptr, weight)              # [E, F_out]
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
 

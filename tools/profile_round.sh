@@ -7,6 +7,9 @@ cd /tmp && export TMPDIR=/tmp
 python /root/repo/bench.py > $R/bench_full_1.json 2> $R/bench_full_1.err
 python /root/repo/bench.py > $R/bench_full_2.json 2> $R/bench_full_2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_bench -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 > $R/bench_under_rocprof.log 2>&1
+# C2 only (no legs): the headline kernel's average must be reproducible from profiles/ alone -- the full bench's stats mix
+# the segment_short leg into the same kernel name; same box, same options as the PMC passes below
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_c2 -o c2 -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler --no-legs > $R/c2_under_rocprof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_mm_$c -o p -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sampler --no-legs > $R/pmc_mm_$c.log 2>&1
 done
