@@ -24,6 +24,9 @@
 // flush -- at least as accurate as the reference's element-by-element rounding (ops/cpu/scatter_kernel.cpp:82-110).
 #include "common.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <vector>
 
 namespace pyg_hip {
@@ -99,10 +102,25 @@ __device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
 // reports it): without the check a bad index is an out-of-bounds DMA read or an atomic into foreign memory.
 template <bool BF16, bool CHECK>
 __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const TileDev* __restrict__ tiles,
-                                                        char* __restrict__ out, int64_t out_rows, int* __restrict__ error) {
+                                                        char* __restrict__ out, int64_t out_rows, int* __restrict__ error,
+                                                        int dbg) {  // dbg: 0 in the product (timing ablations, experiment builds)
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
+#ifdef PYG_HIP_EXPERIMENTS
+  // phase clocks (dbg & 4): cycles per wave summed into error[2 ...]: 0 W + first indices, 1 wait for the rows, 2 MFMAs,
+  // 3 pack + stage, 4 scatter, 5 tiles
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#define PYG_RGCN_MARK(i)                                     \
+  if (dbg & 4) {                                             \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tph[i] += now_ - tlast;                                  \
+    tlast = now_;                                            \
+  }
+#else
+#define PYG_RGCN_MARK(i)
+#endif
   const TileDev td = tiles[blockIdx.x];
   const RelDev rel = rels[td.rel];
   char* xs = smem + 32768 + wave * 8192;
@@ -151,6 +169,13 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   int64_t g1_n, si_n, gi_n;
   first_level(0, nrows_n, g1_n, si_n);
   gi_n = second_level(nrows_n, g1_n);
+#ifdef PYG_HIP_EXPERIMENTS
+  if (dbg & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(gi_n), "+v"(si_n));
+  }
+#endif
+  PYG_RGCN_MARK(0)
   for (int tt = 0; tt < td.count; ++tt) {
     const int nrows = nrows_n;
     int64_t gi = gi_n, si = si_n;
@@ -170,7 +195,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
         const int p = i * 64 + lane;
         const int r = p >> 4, cs = p & 15;
         const int c = cs ^ (r & 15);
-        const int64_t row = __shfl(gi, r);
+        const int64_t row = (dbg & 2) ? (int64_t)((blockIdx.x * 4 + wave) * 32 + r) : __shfl(gi, r);  // (ablation: sequential rows)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rel.x + row * 256 + c * 16),
                                          (LDSV*)(xs + i * 1024), 16, 0, 0);
       }
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tt == 0) __syncthreads();  // everybody's part of W has landed; the X stage is private to the wave
     if (more) gi_n = second_level(nrows_n, g1_n);
+    PYG_RGCN_MARK(1)
     if (nrows == 0) continue;
     f32x16 acc[NT];
 #pragma unroll
@@ -199,6 +225,10 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
 #pragma unroll
       for (int t4 = 0; t4 < NT; ++t4) acc[t4] = mfma16<BF16>(wa[t4], xa, acc[t4]);
     }
+#ifdef PYG_HIP_EXPERIMENTS
+    if (dbg & 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#endif
+    PYG_RGCN_MARK(2)
     // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
 #pragma unroll
     for (int t4 = 0; t4 < NT; ++t4) {
@@ -211,7 +241,16 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
         *reinterpret_cast<u32x4*>(xs + (xl * 16 + (c ^ (xl & 15))) * 16) = pk;
       }
     }
-    // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row
+    // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row.  All 32 rows of the
+    // lane's column pair are read first (one LDS round trip instead of 32 dependent ones: the atomics below are
+    // `asm volatile` memory clobbers, the compiler would not move a read across them)
+    uint32_t mv[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) mv[r] = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
+#ifdef PYG_HIP_EXPERIMENTS
+    if (dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PYG_RGCN_MARK(3)
     float s0 = 0.f, s1 = 0.f;
     int64_t cur = __shfl(si, 0);
 #pragma unroll
@@ -219,20 +258,27 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
       if (r < nrows) {
         const int64_t d = __shfl(si, r);
         if (d != cur) {  // wave-uniform
-          atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+          if (!(dbg & 1)) atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
           s0 = 0.f;
           s1 = 0.f;
           cur = d;
         }
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
         float a, b;
-        unpack2<BF16>(v, &a, &b);
+        unpack2<BF16>(mv[r], &a, &b);
         s0 += a;
         s1 += b;
       }
     }
-    atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+    if (!(dbg & 1)) atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
+    PYG_RGCN_MARK(4)
+#ifdef PYG_HIP_EXPERIMENTS
+    if (dbg & 4) tph[5] += 1;
+#endif
   }
+#ifdef PYG_HIP_EXPERIMENTS
+  if ((dbg & 4) && lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(error) + 1 + i, tph[i]);
+#endif
 }
 
 }  // namespace
@@ -265,7 +311,12 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   // indices prefetched, so runs of a few tiles pay -- as long as the grid still has a couple of workgroups for each of
   // the chip's 2 x CUs slots
   const int64_t slots = 2 * (int64_t)device_info().num_cus;
-  const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (2 * slots)));
+  int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (4 * slots)));
+  int dbg = 0;
+#ifdef PYG_HIP_EXPERIMENTS  // timing ablations (wrong results by construction): never part of the shipped library
+  if (const char* e = getenv("PYG_HIP_RGCN_RUN")) run = std::max(1, atoi(e));
+  if (const char* e = getenv("PYG_HIP_RGCN_DBG")) dbg = atoi(e);
+#endif
   E = 0;
   for (int64_t r = 0; r < R; ++r) {
     PYG_HIP_REQUIRE(rels[r].num_edges >= 0, "rgcn_fused: negative edge count");
@@ -317,13 +368,22 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   const TileDev* dtile = reinterpret_cast<const TileDev*>(w + rel_b);
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
-  if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
+  if (checked || dbg) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, 64, stream));
   const void* kern = dtype == PYG_BF16 ? (checked ? (const void*)&rgcn_fused_kernel<true, true> : (const void*)&rgcn_fused_kernel<true, false>)
                                        : (checked ? (const void*)&rgcn_fused_kernel<false, true> : (const void*)&rgcn_fused_kernel<false, false>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   char* outc = static_cast<char*>(out);
-  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev};
+  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev, (void*)&dbg};
   PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)tiles), dim3(256), args, lds, stream));
+#ifdef PYG_HIP_EXPERIMENTS
+  if (dbg & 4) {
+    unsigned long long t[7];
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    PYG_HIP_CHECK(hipMemcpy(t, err_dev, sizeof(t), hipMemcpyDeviceToHost));
+    fprintf(stderr, "rgcn phases (cycles per wave-tile; %llu wave-tiles): setup/tile %.0f  row wait %.0f  mfma %.0f  pack %.0f  scatter %.0f\n",
+            t[6], (double)t[1] / t[6], (double)t[2] / t[6], (double)t[3] / t[6], (double)t[4] / t[6], (double)t[5] / t[6]);
+  }
+#endif
   if (checked) {  // checked mode synchronises: the caller asked for a verdict
     int host_err = 0;
     PYG_HIP_CHECK(hipMemcpyAsync(&host_err, err_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
