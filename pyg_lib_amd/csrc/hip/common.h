@@ -65,13 +65,21 @@ const DeviceInfo& device_info();
 // for the whole process (the attribute is per device: a per-thread "done" flag would skip the second GPU).
 int ensure_dynamic_lds(const void* kern, int bytes);
 
-// Pinned host staging buffer (thread local) used for small asynchronous H2D descriptor copies.
-// `acquire` waits for the previous copy that used the buffer before handing it out again.
+// Pinned staging (thread local) for small host -> device descriptor copies: a ring of kSlots buffers, each with its own event.
+// acquire() hands out the next slot (waiting for ITS last copy only -- with one slot every call waited for the
+// previous call's copy, i.e. for the kernel in front of it: back-to-back short operators ran in lock-step with the
+// device); commit() records the slot's event behind the copy the caller has just queued.
 struct PinnedStage {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipEvent_t ev = nullptr;
-  bool pending = false;
+  static constexpr int kSlots = 4;
+  struct Slot {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+  };
+  Slot slots[kSlots];
+  int next = 0;   // slot of the next acquire()
+  int cur = 0;    // slot handed out last (commit() records its event)
   int acquire(size_t bytes, void** out);
   int commit(hipStream_t stream);
 };

@@ -47,26 +47,30 @@ int ensure_dynamic_lds(const void* kern, int bytes) {
 }
 
 int PinnedStage::acquire(size_t bytes, void** out) {
-  if (pending) {
-    PYG_HIP_CHECK(hipEventSynchronize(ev));
-    pending = false;
+  cur = next;
+  next = next + 1 == kSlots ? 0 : next + 1;
+  Slot& s = slots[cur];
+  if (s.pending) {
+    PYG_HIP_CHECK(hipEventSynchronize(s.ev));
+    s.pending = false;
   }
-  if (bytes > cap) {
-    if (ptr) PYG_HIP_CHECK(hipHostFree(ptr));
-    ptr = nullptr;
-    cap = 0;
+  if (bytes > s.cap) {
+    if (s.ptr) PYG_HIP_CHECK(hipHostFree(s.ptr));
+    s.ptr = nullptr;
+    s.cap = 0;
     size_t want = align_up(bytes < 65536 ? 65536 : bytes, 4096);
-    PYG_HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
-    cap = want;
+    PYG_HIP_CHECK(hipHostMalloc(&s.ptr, want, hipHostMallocDefault));
+    s.cap = want;
   }
-  if (!ev) PYG_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  *out = ptr;
+  if (!s.ev) PYG_HIP_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  *out = s.ptr;
   return PYG_HIP_OK;
 }
 
 int PinnedStage::commit(hipStream_t stream) {
-  PYG_HIP_CHECK(hipEventRecord(ev, stream));
-  pending = true;
+  Slot& s = slots[cur];
+  PYG_HIP_CHECK(hipEventRecord(s.ev, stream));
+  s.pending = true;
   return PYG_HIP_OK;
 }
 

@@ -8,10 +8,11 @@
 // gathered features [E, K] nor the messages [E, M] ever exist in HBM, and the per-relation index vectors are read
 // where the sampler left them (no concatenation).
 //
-// One workgroup (4 waves x 32 edges) per 128-edge tile of one relation, dispatched in tile order:
-//   * A-operand rows are GATHERED: the X tile arrives by LDS-DMA (global_load_lds_dwordx4) whose per-lane source
-//     address is x + (gather_index[e] + offset) * row_bytes + chunk * 16 -- a whole 256-byte row per 16 lanes --
-//     into the same XOR-swizzled per-wave stage the segment_matmul kernels use;
+// A persistent grid of four-wave workgroups; a tile is 128 edges of one relation (32 per wave), a workgroup walks a
+// contiguous range of tiles (rgcn_fused_kernel below: the index / row pipeline):
+//   * A-operand rows are GATHERED: lane l of load i fetches 16 bytes of row gather(edge (64 i + l) / 16) -- a whole
+//     256-byte row per 16 lanes -- into registers one tile ahead, and parks them in the same XOR-swizzled per-wave
+//     stage the segment_matmul kernels use;
 //   * W_r is copied in its native [K][M] layout by LDS-DMA and read through ds_read_b64_tr_b16 (see
 //     mfma_rows_cyc_kernel in matmul.hip for the block permutation that keeps those reads conflict free);
 //   * epilogue = SCATTER: the 32 x 128 messages of a wave are rounded to the storage type (exactly what the
@@ -50,13 +51,6 @@ struct RelDev {
   const int64_t* gather_map;  // nullptr, or: row = gather_map[gather_index[e]] (sampled local id -> global node id)
   int64_t x_rows;             // rows of `x` (checked mode)
   int64_t map_len;            // entries of gather_map (checked mode)
-};
-
-struct TileDev {
-  int32_t rel;
-  int32_t tile;   // first 128-edge tile (index inside the relation) of this workgroup's run
-  int32_t count;  // consecutive tiles of the relation it processes with ONE copy of W_r in LDS
-  int32_t pad;
 };
 
 template <bool BF16>
@@ -99,113 +93,156 @@ __device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
 
 // K = M = 128, 16-bit T
 // CHECK: every gather / scatter index is validated; an offender sets *error and is redirected to row 0 (the host
-// reports it): without the check a bad index is an out-of-bounds DMA read or an atomic into foreign memory.
+// reports it): without the check a bad index is an out-of-bounds read or an atomic into foreign memory.
+//
+// Persistent launch: workgroup b owns the contiguous tile range [b T / G, (b + 1) T / G) of the tiles of all relations
+// (tile_start = prefix of ceil(edges_r / 128)); W_r is copied into LDS when the range enters relation r (a handful of
+// workgroups change relation at all).  A tile needs three DEPENDENT memory round trips before its MFMAs -- edge ->
+// gather_index -> (gather_map) -> feature row, ~2.5 - 5 us each on this chip whatever its load -- so every wave runs a
+// three-deep software pipeline over its tiles:
+//     tile t + 2 : first level   (gather_index / scatter_index of the wave's 32 edges, coalesced)
+//     tile t + 1 : second level  (gather_map lookup), then its 32 feature rows travel to REGISTERS (8 x 16 bytes per lane)
+//     tile t     : rows -> LDS stage (the XOR-swizzled layout of the segment_matmul kernels), MFMAs, scatter
+// and pays the round trips once per workgroup instead of three per tile.  (The first version issued one tile at a time by
+// LDS-DMA: 51 % of a wave's time waiting for rows, 30 % for indices; phase clocks of an experiment build.)
 template <bool BF16, bool CHECK>
-__global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const TileDev* __restrict__ tiles,
-                                                        char* __restrict__ out, int64_t out_rows, int* __restrict__ error,
-                                                        int dbg) {  // dbg: 0 in the product (timing ablations, experiment builds)
+__global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const int32_t* __restrict__ tile_start,
+                                                        int R, char* __restrict__ out, int64_t out_rows,
+                                                        int* __restrict__ error, int dbg) {  // dbg: 0 in the product
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
-#ifdef PYG_HIP_EXPERIMENTS
-  // phase clocks (dbg & 4): cycles per wave summed into error[2 ...]: 0 W + first indices, 1 wait for the rows, 2 MFMAs,
-  // 3 pack + stage, 4 scatter, 5 tiles
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-#define PYG_RGCN_MARK(i)                                     \
-  if (dbg & 4) {                                             \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    tph[i] += now_ - tlast;                                  \
-    tlast = now_;                                            \
-  }
-#else
-#define PYG_RGCN_MARK(i)
-#endif
-  const TileDev td = tiles[blockIdx.x];
-  const RelDev rel = rels[td.rel];
+  const int total = tile_start[R];
+  const int G = (int)gridDim.x;
+  const int t_beg = (int)((int64_t)blockIdx.x * total / G);
+  const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
+  if (t_beg >= t_end) return;
   char* xs = smem + 32768 + wave * 8192;
-  // W: this wave's 8 blocks of 4 k-rows, 16-byte chunks permuted inside a block (once per workgroup: its `count` tiles
-  // are of one relation -- with one tile per workgroup the weight copy was as many bytes as the gathered rows)
+
+  // ---- index pipeline -------------------------------------------------------------------------------------------
+  struct Idx {
+    int rel;      // relation of the tile (uniform)
+    int nrows;    // edges of this wave in the tile (uniform; 0: nothing to do)
+    int64_t g;    // lane l < 32: gather index of edge l -- first level: position in the map / table, second level: row
+    int64_t si;   // lane l < 32: output row of edge l
+  };
+  int walker;  // relation of the tile the first level is at (tiles ascend)
   {
+    int lo = 0, hi = R;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= t_beg) lo = mid; else hi = mid;
+    }
+    walker = lo;
+  }
+  auto first_level = [&](int t) -> Idx {
+    Idx o;
+    o.rel = walker;
+    o.nrows = 0;
+    o.g = 0;
+    o.si = 0;
+    if (t >= t_end) return o;
+    while (t >= tile_start[walker + 1]) ++walker;
+    o.rel = walker;
+    const RelDev& rel = rels[walker];
+    const int64_t e0 = (int64_t)(t - tile_start[walker]) * 128 + wave * 32;   // first edge of this wave inside the relation
+    const int64_t left = rel.num_edges - e0;
+    o.nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+    if (o.nrows > 0) {  // rows past the end repeat the last valid edge
+      const int64_t e = e0 + (xl < o.nrows ? xl : o.nrows - 1);
+      o.g = rel.gather_index[e];
+      o.si = rel.scatter_index[e] + rel.scatter_offset;
+    }
+    return o;
+  };
+  auto second_level = [&](Idx& io) {
+    if (io.nrows == 0) return;
+    const RelDev& rel = rels[io.rel];
+    if (!rel.gather_map) {
+      io.g += rel.gather_offset;
+      return;
+    }
+    if (CHECK && (io.g < 0 || io.g >= rel.map_len)) {  // double indirection done here: the gathered feature matrix never exists
+      *error = 1;
+      io.g = 0;
+    }
+    io.g = rel.gather_map[io.g];
+  };
+  // the 32 feature rows of the next tile on their way: lane's chunk i is slot p = 64 i + lane of the stage.  (Two
+  // tiles ahead -- a second register set -- was no faster: 82 vs 79 us on the C5 batch; what is left is not latency.)
+  u32x4 xr[NI];
+  auto issue_rows = [&](Idx& b) {
+    if (b.nrows == 0) return;
+    const RelDev& rel = rels[b.rel];
+    if (CHECK) {
+      if (b.g < 0 || b.g >= rel.x_rows) {
+        *error = 1;
+        b.g = 0;
+      }
+      if (b.si < 0 || b.si >= out_rows) {
+        *error = 2;
+        b.si = 0;
+      }
+    }
+    const char* xb = rel.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = i * 64 + lane;
+      const int r = p >> 4, cs = p & 15;
+      const int c = cs ^ (r & 15);
+      const int64_t row = __shfl(b.g, r);
+      xr[i] = *reinterpret_cast<const u32x4*>(xb + row * 256 + c * 16);
+    }
+  };
+
+  // W of relation `g`: this wave's 8 blocks of 4 k-rows, 16-byte chunks permuted inside a block
+  auto load_w = [&](int g) {
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
-    const char* wsrc = rel.weight + dma_r * 256 + dma_c * 16;
+    const char* wsrc = rels[g].weight + dma_r * 256 + dma_c * 16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kb = wave * 8 + j;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
                                        (LDSV*)(smem + kb * 1024), 16, 0, 0);
     }
-  }
+  };
+
+  // prologue: W of the first relation and the three index chains of tiles t, t + 1, t + 2 are requested together
+  int w_rel = walker;
+  load_w(w_rel);
+  Idx C = first_level(t_beg);
+  Idx Bx = first_level(t_beg + 1);
+  Idx A = first_level(t_beg + 2);
+  second_level(C);
+  second_level(Bx);
+  issue_rows(C);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
+  __syncthreads();
+
   const int q = lane & 15, grp16 = lane >> 4;
   const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
   const int cch = lane >> 2, cdw = lane & 3;
-  // Index pipeline: a tile needs edge -> gather_index -> (gather_map) -> feature row, three dependent memory round
-  // trips before its MFMAs.  The first level of tile t + 1 is requested together with tile t's row DMA, the second
-  // right behind their common wait, so that from its second tile on a workgroup pays ONE round trip per tile.
-  // lane l < 32 holds edge l of the wave's 32 (rows past the end repeat the last valid edge)
-  auto first_level = [&](int tt, int& nrows, int64_t& g1, int64_t& si) {
-    const int64_t e0 = (int64_t)(td.tile + tt) * 128 + wave * 32;   // first edge of this wave inside the relation
-    const int64_t left = rel.num_edges - e0;
-    nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
-    g1 = 0;
-    si = 0;
-    if (nrows > 0) {
-      const int64_t e = e0 + (xl < nrows ? xl : nrows - 1);
-      g1 = rel.gather_index[e];
-      si = rel.scatter_index[e] + rel.scatter_offset;
+  for (int t = t_beg; t < t_end; ++t) {
+    if (C.rel != w_rel) {  // uniform over the workgroup: every wave walks the same tiles
+      __syncthreads();     // everybody is done with the old W
+      w_rel = C.rel;
+      load_w(w_rel);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-  };
-  auto second_level = [&](int nrows, int64_t g1) -> int64_t {
-    if (nrows == 0) return 0;
-    if (!rel.gather_map) return g1 + rel.gather_offset;
-    if (CHECK && (g1 < 0 || g1 >= rel.map_len)) {  // double indirection done here: the gathered feature matrix never exists
-      *error = 1;
-      g1 = 0;
-    }
-    return rel.gather_map[g1];
-  };
-  int nrows_n;
-  int64_t g1_n, si_n, gi_n;
-  first_level(0, nrows_n, g1_n, si_n);
-  gi_n = second_level(nrows_n, g1_n);
-#ifdef PYG_HIP_EXPERIMENTS
-  if (dbg & 4) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(gi_n), "+v"(si_n));
-  }
-#endif
-  PYG_RGCN_MARK(0)
-  for (int tt = 0; tt < td.count; ++tt) {
-    const int nrows = nrows_n;
-    int64_t gi = gi_n, si = si_n;
+    const int nrows = C.nrows;
+    const int64_t si = C.si;
     if (nrows > 0) {
-      if (CHECK) {
-        if (gi < 0 || gi >= rel.x_rows) {
-          *error = 1;
-          gi = 0;
-        }
-        if (si < 0 || si >= out_rows) {
-          *error = 2;
-          si = 0;
-        }
-      }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int p = i * 64 + lane;
-        const int r = p >> 4, cs = p & 15;
-        const int c = cs ^ (r & 15);
-        const int64_t row = (dbg & 2) ? (int64_t)((blockIdx.x * 4 + wave) * 32 + r) : __shfl(gi, r);  // (ablation: sequential rows)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rel.x + row * 256 + c * 16),
-                                         (LDSV*)(xs + i * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(xs + (i * 64 + lane) * 16) = xr[i];
     }
-    const bool more = tt + 1 < td.count;
-    if (more) first_level(tt + 1, nrows_n, g1_n, si_n);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tt == 0) __syncthreads();  // everybody's part of W has landed; the X stage is private to the wave
-    if (more) gi_n = second_level(nrows_n, g1_n);
-    PYG_RGCN_MARK(1)
+    // advance the pipeline: rows of t + 1, second level of t + 2, first level of t + 3
+    issue_rows(Bx);
+    second_level(A);
+    C = Bx;
+    Bx = A;
+    A = first_level(t + 3);
     if (nrows == 0) continue;
     f32x16 acc[NT];
 #pragma unroll
@@ -225,10 +262,6 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
 #pragma unroll
       for (int t4 = 0; t4 < NT; ++t4) acc[t4] = mfma16<BF16>(wa[t4], xa, acc[t4]);
     }
-#ifdef PYG_HIP_EXPERIMENTS
-    if (dbg & 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-#endif
-    PYG_RGCN_MARK(2)
     // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
 #pragma unroll
     for (int t4 = 0; t4 < NT; ++t4) {
@@ -241,16 +274,8 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
         *reinterpret_cast<u32x4*>(xs + (xl * 16 + (c ^ (xl & 15))) * 16) = pk;
       }
     }
-    // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row.  All 32 rows of the
-    // lane's column pair are read first (one LDS round trip instead of 32 dependent ones: the atomics below are
-    // `asm volatile` memory clobbers, the compiler would not move a read across them)
-    uint32_t mv[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) mv[r] = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
-#ifdef PYG_HIP_EXPERIMENTS
-    if (dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    PYG_RGCN_MARK(3)
+    // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row; runs of equal
+    // destination are summed in fp32 and flushed with one packed atomic per lane (a whole 256-byte row per instruction)
     float s0 = 0.f, s1 = 0.f;
     int64_t cur = __shfl(si, 0);
 #pragma unroll
@@ -263,22 +288,15 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
           s1 = 0.f;
           cur = d;
         }
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
         float a, b;
-        unpack2<BF16>(mv[r], &a, &b);
+        unpack2<BF16>(v, &a, &b);
         s0 += a;
         s1 += b;
       }
     }
     if (!(dbg & 1)) atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
-    PYG_RGCN_MARK(4)
-#ifdef PYG_HIP_EXPERIMENTS
-    if (dbg & 4) tph[5] += 1;
-#endif
   }
-#ifdef PYG_HIP_EXPERIMENTS
-  if ((dbg & 4) && lane == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(error) + 1 + i, tph[i]);
-#endif
 }
 
 }  // namespace
@@ -290,9 +308,9 @@ extern "C" {
 
 size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges) {
   if (num_relations < 0) num_relations = 0;
-  if (num_edges < 0) num_edges = 0;
-  const size_t tiles = (size_t)(num_edges / 128 + num_relations + 1);
-  return align_up(sizeof(RelDev) * (size_t)std::max<int64_t>(num_relations, 1), 256) + align_up(sizeof(TileDev) * tiles, 256) + 256;
+  (void)num_edges;
+  return align_up(sizeof(RelDev) * (size_t)std::max<int64_t>(num_relations, 1), 256) +
+         align_up(sizeof(int32_t) * (size_t)(num_relations + 1), 256) + 256;
 }
 
 int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R,
@@ -306,25 +324,13 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   if (R == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
   int64_t E = 0, tiles = 0;
-  for (int64_t r = 0; r < R; ++r) E += std::max<int64_t>(rels[r].num_edges, 0);
-  // tiles per workgroup: W_r (32 KB) is copied once per workgroup and every tile behind a workgroup's first has its
-  // indices prefetched, so runs of a few tiles pay -- as long as the grid still has a couple of workgroups for each of
-  // the chip's 2 x CUs slots
-  const int64_t slots = 2 * (int64_t)device_info().num_cus;
-  int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, (E / 128) / (4 * slots)));
-  int dbg = 0;
-#ifdef PYG_HIP_EXPERIMENTS  // timing ablations (wrong results by construction): never part of the shipped library
-  if (const char* e = getenv("PYG_HIP_RGCN_RUN")) run = std::max(1, atoi(e));
-  if (const char* e = getenv("PYG_HIP_RGCN_DBG")) dbg = atoi(e);
-#endif
-  E = 0;
   for (int64_t r = 0; r < R; ++r) {
     PYG_HIP_REQUIRE(rels[r].num_edges >= 0, "rgcn_fused: negative edge count");
     PYG_HIP_REQUIRE(rels[r].num_edges == 0 || (rels[r].gather_index && rels[r].scatter_index && rels[r].weight),
                     "rgcn_fused: NULL tensor in relation %lld", (long long)r);
     PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(rels[r].weight) & 15) == 0, "rgcn_fused: weights must be 16-byte aligned");
     E += rels[r].num_edges;
-    tiles += ((rels[r].num_edges + 127) / 128 + run - 1) / run;
+    tiles += (rels[r].num_edges + 127) / 128;
   }
   if (E == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
@@ -339,12 +345,12 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     return fail(PYG_HIP_ERR_WORKSPACE, "rgcn_fused: workspace of %zu bytes needed, got %zu",
                 pyg_hip_rgcn_fused_workspace_size(R, E), workspace_bytes);
   const size_t rel_b = align_up(sizeof(RelDev) * (size_t)R, 256);
-  const size_t tile_b = align_up(sizeof(TileDev) * (size_t)tiles, 256);
+  const size_t tile_b = align_up(sizeof(int32_t) * (size_t)(R + 1), 256);
   void* staged = nullptr;
   int rc = pinned_stage().acquire(rel_b + tile_b, &staged);
   if (rc != PYG_HIP_OK) return rc;
   RelDev* hr = static_cast<RelDev*>(staged);
-  TileDev* ht = reinterpret_cast<TileDev*>(static_cast<char*>(staged) + rel_b);
+  int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + rel_b);
   int64_t t = 0;
   for (int64_t r = 0; r < R; ++r) {
     hr[r].gather_index = rels[r].gather_index;
@@ -357,33 +363,36 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     hr[r].gather_map = rels[r].gather_map;
     hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
     hr[r].map_len = rels[r].gather_map_len;
-    const int64_t nt = (rels[r].num_edges + 127) / 128;
-    for (int64_t k = 0; k < nt; k += run) ht[t++] = TileDev{(int32_t)r, (int32_t)k, (int32_t)std::min<int64_t>(run, nt - k), 0};
+    ht[r] = (int32_t)t;
+    t += (rels[r].num_edges + 127) / 128;
   }
+  ht[R] = (int32_t)t;
   char* w = static_cast<char*>(workspace);
   PYG_HIP_CHECK(hipMemcpyAsync(w, staged, rel_b + tile_b, hipMemcpyHostToDevice, stream));
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;
   const RelDev* drel = reinterpret_cast<const RelDev*>(w);
-  const TileDev* dtile = reinterpret_cast<const TileDev*>(w + rel_b);
+  const int32_t* dtile = reinterpret_cast<const int32_t*>(w + rel_b);
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
-  if (checked || dbg) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, 64, stream));
+  if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
   const void* kern = dtype == PYG_BF16 ? (checked ? (const void*)&rgcn_fused_kernel<true, true> : (const void*)&rgcn_fused_kernel<true, false>)
                                        : (checked ? (const void*)&rgcn_fused_kernel<false, true> : (const void*)&rgcn_fused_kernel<false, false>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
-  char* outc = static_cast<char*>(out);
-  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev, (void*)&dbg};
-  PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)tiles), dim3(256), args, lds, stream));
-#ifdef PYG_HIP_EXPERIMENTS
-  if (dbg & 4) {
-    unsigned long long t[7];
-    PYG_HIP_CHECK(hipStreamSynchronize(stream));
-    PYG_HIP_CHECK(hipMemcpy(t, err_dev, sizeof(t), hipMemcpyDeviceToHost));
-    fprintf(stderr, "rgcn phases (cycles per wave-tile; %llu wave-tiles): setup/tile %.0f  row wait %.0f  mfma %.0f  pack %.0f  scatter %.0f\n",
-            t[6], (double)t[1] / t[6], (double)t[2] / t[6], (double)t[3] / t[6], (double)t[4] / t[6], (double)t[5] / t[6]);
-  }
+  // persistent grid: two workgroups per CU (64 KB of LDS each), every one a contiguous range of >= 2 tiles
+  int64_t per_cu = 2;
+  int64_t min_tiles = 2;
+  int dbg = 0;
+#ifdef PYG_HIP_EXPERIMENTS  // timing ablations: never part of the shipped library
+  if (const char* e = getenv("PYG_HIP_RGCN_WGS")) per_cu = std::max(1, atoi(e));
+  if (const char* e = getenv("PYG_HIP_RGCN_MIN_TILES")) min_tiles = std::max(1, atoi(e));
+  if (const char* e = getenv("PYG_HIP_RGCN_DBG")) dbg = atoi(e);
 #endif
+  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((tiles + min_tiles - 1) / min_tiles, per_cu * (int64_t)device_info().num_cus));
+  char* outc = static_cast<char*>(out);
+  int Ri = (int)R;
+  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&Ri, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev, (void*)&dbg};
+  PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, stream));
   if (checked) {  // checked mode synchronises: the caller asked for a verdict
     int host_err = 0;
     PYG_HIP_CHECK(hipMemcpyAsync(&host_err, err_dev, sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -1,6 +1,7 @@
 """Where the fused R-GCN layer's time goes on one C5 batch (experiment build: EXTRA_HIPCC_FLAGS=-DPYG_HIP_EXPERIMENTS):
-the layer alone under PYG_HIP_RGCN_RUN (tiles per workgroup) and PYG_HIP_RGCN_DBG (1 = no atomics, 2 = sequential
-instead of gathered rows, 3 = both), the zero fill of the output on its own, and the kernel without the fill."""
+the layer alone under PYG_HIP_RGCN_WGS (workgroups per CU of the persistent grid), PYG_HIP_RGCN_MIN_TILES (tiles per
+workgroup at least) and PYG_HIP_RGCN_DBG (1 = no atomics), the zero fill of the output on its own, and the kernel
+without the fill."""
 import os
 import sys
 
@@ -42,15 +43,12 @@ tidx = {t: i for i, t in enumerate(types)}
 off = rgcn.type_offsets({t: out[2][t].numel() for t in types}, types)
 args = ([feat[t] for t in types], [out[2][t] for t in types], [tidx[e[2]] for e in ets], [out[1][e] for e in ets],
         [out[0][e] for e in ets], [off[e[0]] for e in ets], W)
-os.environ['PYG_HIP_RGCN_DBG'] = '4'   # phase clocks (one line per call on stderr)
-torch.ops.pyg.rgcn_fused_tables(*args, pre)
-torch.ops.pyg.rgcn_fused_tables(*args, pre)
-torch.cuda.synchronize()
-for run in ('', '1', '2', '4'):
-    for dbg in ('0', '1', '2'):
-        if run:
-            os.environ['PYG_HIP_RGCN_RUN'] = run
-        os.environ['PYG_HIP_RGCN_DBG'] = dbg
-        t_layer = timed(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W))
-        t_kernel = timed(lambda: torch.ops.pyg.rgcn_fused_tables(*args, pre))
-        print(f'run {run or "auto":4s} dbg {dbg}: layer {t_layer:7.1f} us   op without the fill {t_kernel:7.1f} us', flush=True)
+for wgs in ('2',):
+    for mt in ('2', '4', '8'):
+        for dbg in ('0', '1'):
+            os.environ['PYG_HIP_RGCN_WGS'] = wgs
+            os.environ['PYG_HIP_RGCN_MIN_TILES'] = mt
+            os.environ['PYG_HIP_RGCN_DBG'] = dbg
+            t_layer = timed(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W))
+            t_kernel = timed(lambda: torch.ops.pyg.rgcn_fused_tables(*args, pre))
+            print(f'wgs/CU {wgs} min tiles {mt} dbg {dbg}: layer {t_layer:7.1f} us   op without the fill {t_kernel:7.1f} us', flush=True)
