@@ -1,10 +1,81 @@
+import os
 import os.path as osp
+import subprocess
 import sys
 
 ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_HEALTH = {}
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
+
+
+def _gpu_health():
+    """Round 3 / 4 finding: a minority of the pool's GPUs lose hardware floating-point atomic updates at a low
+    rate (whole +x updates missing in scatter_sum, the weight-gradient kernels, the fused R-GCN kernel) while every
+    integer-atomic path stays bit-exact; other GPUs pass the same binaries thousands of times.  tools/probe/atomic_probe
+    (hand-written adds of a known count, seven flavours x three ways of clearing the accumulator) takes a second: its
+    verdict and the GPU's uuid go into the report header / summary, so that a failure of a float-atomic test can be told
+    apart from a defect of the code under test."""
+    if _HEALTH:
+        return _HEALTH
+    _HEALTH['probe'] = 'not run'
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return _HEALTH
+        exe = osp.join(ROOT, 'tools', 'probe', 'atomic_probe')
+        if not osp.exists(exe):
+            _HEALTH['probe'] = 'tools/probe/atomic_probe not built'
+            return _HEALTH
+        try:
+            uuid = subprocess.run(['rocminfo'], capture_output=True, text=True, timeout=60).stdout
+            _HEALTH['uuid'] = ', '.join(sorted({ln.split()[-1] for ln in uuid.splitlines() if 'Uuid' in ln and 'GPU-' in ln}))
+        except Exception:  # noqa: BLE001
+            _HEALTH['uuid'] = '?'
+        out = subprocess.run([exe, '30'], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in out.stdout.splitlines() if 'repetitions wrong' in ln and not ln.split(':')[1].strip().startswith('0 of')]
+        _HEALTH['probe'] = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else f'no output (rc {out.returncode})'
+        _HEALTH['lost'] = lines
+        os.makedirs(osp.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(osp.join(ROOT, 'gpurun_out', 'gpu_health.txt'), 'a') as f:
+            f.write(f"gpu {_HEALTH.get('uuid')}: {_HEALTH['probe']}\n" + ''.join(ln + '\n' for ln in lines))
+    except Exception as e:  # noqa: BLE001 - diagnostics only
+        _HEALTH['probe'] = f'probe failed to run: {e!r}'
+    return _HEALTH
+
+
+def _wants_gpu(config):
+    return 'not gpu' not in (config.getoption('-m') or '')
+
+
+def pytest_sessionstart(session):
+    if _wants_gpu(session.config):
+        _gpu_health()
+
+
+def pytest_report_header(config):
+    if not _wants_gpu(config):
+        return None
+    h = _gpu_health()
+    if h.get('probe') == 'not run':
+        return None
+    return [f"float-atomic probe on GPU {h.get('uuid', '?')}: {h['probe']}"] + [f'    {ln}' for ln in h.get('lost', [])]
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    h = _HEALTH
+    if not h or h.get('probe') == 'not run':
+        return
+    terminalreporter.section('GPU health')
+    terminalreporter.write_line(f"float-atomic probe on GPU {h.get('uuid', '?')}: {h['probe']}")
+    if h.get('lost'):
+        terminalreporter.write_line(f"This GPU LOST hardware float-atomic updates in tools/probe/atomic_probe ({len(h['lost'])} flavour / "
+                                    f"clearing combinations): failures of tests that accumulate with float atomics on it are not "
+                                    f"evidence against the kernels (see DESIGN.md 6).")
+        for ln in h['lost']:
+            terminalreporter.write_line('    ' + ln)
