@@ -126,17 +126,22 @@ struct GenBlock {
   int bytes_valid;
 };
 
-template <int ROWBYTES>
-__device__ __forceinline__ void gen_load_cls(int lg, uint32_t (&r)[16], const GenBlock& b, int tid, bool stream) {
-  if (lg >= 4) gen_load<16, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
-  else if (lg == 3) gen_load<8, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
+// CLS = the alignment class the tile's X and W accesses share (log2 of the vector bytes; a template parameter: with the
+// class as a run-time branch around the loads the arms write the same registers, the compiler copies them at the
+// merge, and a copy needs the data -- the loads of chunk s + 1 were waited for where they were issued instead of
+// behind the multiply of chunk s; the weight-gradient kernel lost 2.7x to the same pattern, profiles/NOTES_r4.md).
+template <int ROWBYTES, int CLS>
+__device__ __forceinline__ void gen_load_cls(uint32_t (&r)[16], const GenBlock& b, int tid, bool stream) {
+  if constexpr (CLS >= 4) gen_load<16, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
+  else if constexpr (CLS == 3) gen_load<8, ROWBYTES>(r, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid, stream);
 }
 
-template <int ROWBYTES, int PITCH>
+// narrow classes (CLS < 3): the operand's own class `lg` picks 4- or 2-byte copies at staging time
+template <int ROWBYTES, int PITCH, int CLS>
 __device__ __forceinline__ void gen_stage_cls(int lg, const uint32_t (&r)[16], char* img, const GenBlock& b, int tid) {
-  if (lg >= 4) gen_stage<16, ROWBYTES, PITCH>(r, img, tid);
-  else if (lg == 3) gen_stage<8, ROWBYTES, PITCH>(r, img, tid);
-  else if (lg == 2) gen_copy<4, ROWBYTES, PITCH>(img, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid);
+  if constexpr (CLS >= 4) gen_stage<16, ROWBYTES, PITCH>(r, img, tid);
+  else if constexpr (CLS == 3) gen_stage<8, ROWBYTES, PITCH>(r, img, tid);
+  else if (lg >= 2) gen_copy<4, ROWBYTES, PITCH>(img, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid);
   else gen_copy<2, ROWBYTES, PITCH>(img, b.base, b.pitch, b.rows_valid, b.bytes_valid, tid);
 }
 
@@ -255,7 +260,7 @@ __device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const 
 // multiplied per pass (2 when the group has at most 64 columns), TRANS = `other` is stored [M][K].  One function
 // per (NBLK, TRANS) so that every variant owns its accumulators: with the variants as branches inside one step loop
 // the accumulators were copied between the branches' register assignments on every step (128 v_mov per chunk).
-template <typename T, int NBLK, bool TRANS>
+template <typename T, int NBLK, bool TRANS, int CLS>
 __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, char* smem, const int tid,
                                          const int lane, const int wave) {
   constexpr int SZ = Elem<T>::kSize;
@@ -291,17 +296,17 @@ __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, 
   auto issue = [&](int s) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    gen_load_cls<128>(lgx, xr, x_block(s), t2, xstream);
-    if (!trans) gen_load_cls<WROWB>(lgw, wr, w_block(s), t2, false);
-    else gen_load_cls<128>(lgw, wr, w_block(s), t2, false);
+    gen_load_cls<128, CLS>(xr, x_block(s), t2, xstream);
+    if (!trans) gen_load_cls<WROWB, CLS>(wr, w_block(s), t2, false);
+    else gen_load_cls<128, CLS>(wr, w_block(s), t2, false);
   };
   auto stage = [&](int s) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
     char* X = smem;
-    gen_stage_cls<128, kGenPX>(lgx, xr, X, x_block(s), t2);
-    if (!trans) gen_stage_cls<WROWB, PW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
-    else gen_stage_cls<128, kGenPX>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    gen_stage_cls<128, kGenPX, CLS>(lgx, xr, X, x_block(s), t2);
+    if (!trans) gen_stage_cls<WROWB, PW, CLS>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    else gen_stage_cls<128, kGenPX, CLS>(lgw, wr, X + kGenXBytes, w_block(s), t2);
   };
 
   issue(0);
@@ -418,13 +423,22 @@ __global__ __launch_bounds__(256, 3) void mfma_rows_gen_kernel(const DevGroup* _
   }
   const DevGroup d = descs[lo];
   const int64_t row0 = (int64_t)(t - tile_start[lo]) * 128;
+  // one straight-line copy of the tile per (column blocks, W storage, alignment class of the X and W accesses)
+  const int cls = min(d.pad & 7, (d.pad >> 3) & 7);
+#define PYG_GEN_TILE(NB, TR)                                                             \
+  do {                                                                                   \
+    if (cls >= 4) gen_tile<T, NB, TR, 4>(d, row0, smem, tid, lane, wave);                \
+    else if (cls == 3) gen_tile<T, NB, TR, 3>(d, row0, smem, tid, lane, wave);           \
+    else gen_tile<T, NB, TR, 2>(d, row0, smem, tid, lane, wave);                         \
+  } while (0)
   if (d.m > 64) {
-    if (!d.trans) gen_tile<T, 4, false>(d, row0, smem, tid, lane, wave);
-    else gen_tile<T, 4, true>(d, row0, smem, tid, lane, wave);
+    if (!d.trans) PYG_GEN_TILE(4, false);
+    else PYG_GEN_TILE(4, true);
   } else {
-    if (!d.trans) gen_tile<T, 2, false>(d, row0, smem, tid, lane, wave);
-    else gen_tile<T, 2, true>(d, row0, smem, tid, lane, wave);
+    if (!d.trans) PYG_GEN_TILE(2, false);
+    else PYG_GEN_TILE(2, true);
   }
+#undef PYG_GEN_TILE
 }
 
 template <typename T>
