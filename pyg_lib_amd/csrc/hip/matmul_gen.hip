@@ -126,7 +126,7 @@ struct GenBlock {
   int bytes_valid;
 };
 
-// CLS = the alignment class the tile's X and W accesses share (log2 of the vector bytes; a template parameter: with the
+// CLS = the alignment class of the operand's accesses (log2 of the vector bytes; a template parameter: with the
 // class as a run-time branch around the loads the arms write the same registers, the compiler copies them at the
 // merge, and a copy needs the data -- the loads of chunk s + 1 were waited for where they were issued instead of
 // behind the multiply of chunk s; the weight-gradient kernel lost 2.7x to the same pattern, profiles/NOTES_r4.md).
@@ -260,7 +260,7 @@ __device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const 
 // multiplied per pass (2 when the group has at most 64 columns), TRANS = `other` is stored [M][K].  One function
 // per (NBLK, TRANS) so that every variant owns its accumulators: with the variants as branches inside one step loop
 // the accumulators were copied between the branches' register assignments on every step (128 v_mov per chunk).
-template <typename T, int NBLK, bool TRANS, int CLS>
+template <typename T, int NBLK, bool TRANS, int CLSX, int CLSW>
 __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, char* smem, const int tid,
                                          const int lane, const int wave) {
   constexpr int SZ = Elem<T>::kSize;
@@ -296,17 +296,17 @@ __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, 
   auto issue = [&](int s) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    gen_load_cls<128, CLS>(xr, x_block(s), t2, xstream);
-    if (!trans) gen_load_cls<WROWB, CLS>(wr, w_block(s), t2, false);
-    else gen_load_cls<128, CLS>(wr, w_block(s), t2, false);
+    gen_load_cls<128, CLSX>(xr, x_block(s), t2, xstream);
+    if (!trans) gen_load_cls<WROWB, CLSW>(wr, w_block(s), t2, false);
+    else gen_load_cls<128, CLSW>(wr, w_block(s), t2, false);
   };
   auto stage = [&](int s) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
     char* X = smem;
-    gen_stage_cls<128, kGenPX, CLS>(lgx, xr, X, x_block(s), t2);
-    if (!trans) gen_stage_cls<WROWB, PW, CLS>(lgw, wr, X + kGenXBytes, w_block(s), t2);
-    else gen_stage_cls<128, kGenPX, CLS>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    gen_stage_cls<128, kGenPX, CLSX>(lgx, xr, X, x_block(s), t2);
+    if (!trans) gen_stage_cls<WROWB, PW, CLSW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    else gen_stage_cls<128, kGenPX, CLSW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
   };
 
   issue(0);
@@ -423,13 +423,20 @@ __global__ __launch_bounds__(256, 3) void mfma_rows_gen_kernel(const DevGroup* _
   }
   const DevGroup d = descs[lo];
   const int64_t row0 = (int64_t)(t - tile_start[lo]) * 128;
-  // one straight-line copy of the tile per (column blocks, W storage, alignment class of the X and W accesses)
-  const int cls = min(d.pad & 7, (d.pad >> 3) & 7);
+  // one straight-line copy of the tile per (column blocks, W storage, alignment classes of the X and of the W accesses:
+  // 16-byte, 8-byte or narrower)
+  const int cx = d.pad & 7, cw = (d.pad >> 3) & 7;
+#define PYG_GEN_TILE_W(NB, TR, CX)                                                       \
+  do {                                                                                   \
+    if (cw >= 4) gen_tile<T, NB, TR, CX, 4>(d, row0, smem, tid, lane, wave);             \
+    else if (cw == 3) gen_tile<T, NB, TR, CX, 3>(d, row0, smem, tid, lane, wave);        \
+    else gen_tile<T, NB, TR, CX, 2>(d, row0, smem, tid, lane, wave);                     \
+  } while (0)
 #define PYG_GEN_TILE(NB, TR)                                                             \
   do {                                                                                   \
-    if (cls >= 4) gen_tile<T, NB, TR, 4>(d, row0, smem, tid, lane, wave);                \
-    else if (cls == 3) gen_tile<T, NB, TR, 3>(d, row0, smem, tid, lane, wave);           \
-    else gen_tile<T, NB, TR, 2>(d, row0, smem, tid, lane, wave);                         \
+    if (cx >= 4) PYG_GEN_TILE_W(NB, TR, 4);                                              \
+    else if (cx == 3) PYG_GEN_TILE_W(NB, TR, 3);                                         \
+    else PYG_GEN_TILE_W(NB, TR, 2);                                                      \
   } while (0)
   if (d.m > 64) {
     if (!d.trans) PYG_GEN_TILE(4, false);
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(256, 3) void mfma_rows_gen_kernel(const DevGroup* _
     if (!d.trans) PYG_GEN_TILE(2, false);
     else PYG_GEN_TILE(2, true);
   }
+#undef PYG_GEN_TILE_W
 #undef PYG_GEN_TILE
 }
 
