@@ -494,15 +494,19 @@ typedef enum {
  *             with the reduce identity: empty buckets are then reset to 0
  *             (scatter_kernel.cpp:351-360).  Otherwise out_init points to a copy of the caller's
  *             initial `out` and untouched buckets keep their value.
- *   index_sorted  != 0 promises an ascending index along e (the COO contract): interior runs are then
- *             reduced without atomics.
- *   workspace optional scratch of pyg_hip_scatter_workspace_size(B, E, N) bytes; with it, large unsorted
- *             float sums sort their indices first (deterministic up to chunk boundaries, ~3x faster
- *             than one atomic per element), and min / max with an index broadcast along k run
- *             atomic-free: buckets become CSR rows (directly for a sorted index, after an index sort
- *             for one large unsorted index vector) reduced in source order -- no CAS loops, no second
- *             arg pass, same exact values and first-match arg.  Without it the atomic kernels run.
+ *   index_sorted  bit 0 (PYG_HIP_SCATTER_SORTED) promises an ascending index along e (the COO contract): runs are
+ *             then reduced without atomics.  Bit 1 (PYG_HIP_SCATTER_FRESH_SUM, SUM only): `out` is a fresh,
+ *             UNINITIALISED output -- the sorted path then writes every slot without reading or clearing it (2 x N x K
+ *             bytes less traffic), every other path clears it first.
+ *   workspace optional scratch of pyg_hip_scatter_workspace_size(B, E, N) bytes; with it, sums and min / max with an
+ *             index broadcast along k run atomic-free: buckets become CSR rows (directly for a sorted index, after
+ *             a stable index sort for one large unsorted index vector with rows of >= 64 bytes) reduced in SOURCE
+ *             order -- deterministic, fp32 accumulation with one rounding per output, every output row written
+ *             once; min / max: no CAS loops, no second arg pass, same exact values and first-match arg.  Without it
+ *             (and for small or element-wise indexed inputs, float64 sums) the atomic kernels run.
  */
+#define PYG_HIP_SCATTER_SORTED 1
+#define PYG_HIP_SCATTER_FRESH_SUM 2
 PYG_HIP_API size_t pyg_hip_scatter_workspace_size(int64_t B, int64_t E, int64_t N);
 PYG_HIP_API int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index,
                                 int64_t index_stride_b, int64_t index_stride_e,

@@ -83,7 +83,9 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
   } else {
     auto sizes = src_c.sizes().vec();
     sizes[dim] = std::max<int64_t>(v.rows, 0);
-    out = (op == CSR_SUM || op == CSR_MEAN) ? at::zeros(sizes, src_c.options()) : at::empty(sizes, src_c.options());
+    // a fresh sum / mean on the device is neither cleared nor read: the kernel writes every slot (fresh = 1 below)
+    const bool needs_zero = (op == CSR_SUM || op == CSR_MEAN) && (on_cpu || src_c.numel() == 0);
+    out = needs_zero ? at::zeros(sizes, src_c.options()) : at::empty(sizes, src_c.options());
   }
   Tensor arg;
   const int64_t E = src_c.size(dim);

@@ -138,7 +138,9 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
   } else {
     auto sizes = src_c.sizes().vec();
     sizes[dim] = dim_size.has_value() ? dim_size.value() : inferred_size;
-    if (op == OP_SUM) out = at::zeros(sizes, src_c.options());
+    // a fresh sum on the device is handed over uninitialised (PYG_HIP_SCATTER_FRESH_SUM): the sorted path writes every
+    // slot without reading it, the other paths clear it themselves
+    if (op == OP_SUM) out = (on_cpu || src_c.numel() == 0) ? at::zeros(sizes, src_c.options()) : at::empty(sizes, src_c.options());
     else if (op == OP_MUL) out = at::ones(sizes, src_c.options());
     else out = at::empty(sizes, src_c.options());
   }
@@ -181,7 +183,8 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
     ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.B, l.E, l.N)}, src_c.options().dtype(at::kByte));
   check_status(pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk,
                                out.data_ptr(), minmax ? arg.data_ptr<int64_t>() : nullptr,
-                               init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N, coo ? 1 : 0,
+                               init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N,
+                               (coo ? PYG_HIP_SCATTER_SORTED : 0) | (fresh && op == OP_SUM ? PYG_HIP_SCATTER_FRESH_SUM : 0),
                                ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0,
                                stream));
   return std::make_tuple(out, arg);

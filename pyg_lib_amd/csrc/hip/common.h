@@ -101,8 +101,11 @@ constexpr int kMtStride = 4;  // long rounds: the jump segments start kMtStride 
 int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* max_span);
 
 // csr.hip: row sums seeded from `out` (the atomic-free, source-order back end of segment_sum_coo).
-int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, void* out, int64_t leading,
-                    int64_t rows, int64_t E, int64_t K, hipStream_t stream);
+// (`fresh` != 0: `out` is uninitialised and every slot is written; else the sums are added to its values.  `perm`,
+// optional: row r sums the source rows perm[indptr[r]] ... perm[indptr[r + 1] - 1] -- a scatter through its stable index sort,
+// i.e. in source order: deterministic, the order of the reference's sequential CPU loop)
+int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, const int64_t* perm, void* out,
+                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream);
 // csr.hip: min / max (+ first-match arg) over CSR rows, optionally reading source position perm[e]
 // instead of e -- the atomic-free back end of sorted and sort-based scatter_min/max (reduce.hip).
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,

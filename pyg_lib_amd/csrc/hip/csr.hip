@@ -78,10 +78,15 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   acc_t acc[V];
   int64_t best[V];
   if constexpr (OP == CSR_SUM) {
-    // the accumulator is seeded from the current `out` slot (zeros or the caller's values)
-    P cur = *reinterpret_cast<const P*>(op);
+    // the accumulator is seeded from the caller's `out` slot; a fresh output starts at +0 without being read (it
+    // need not be cleared either: every slot is written below -- 2 x N x K bytes less traffic)
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = lane == 0 ? Math<T>::up(cur.v[i]) : acc_t(0);
+    for (int i = 0; i < V; ++i) acc[i] = acc_t(0);
+    if (!fresh) {
+      P cur = *reinterpret_cast<const P*>(op);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] = lane == 0 ? Math<T>::up(cur.v[i]) : acc_t(0);
+    }
   } else if constexpr (OP == CSR_MEAN) {
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = acc_t(0);
@@ -96,7 +101,10 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   if (live) {
     // four positions per trip: their loads are in flight together (a row is ~10 positions long in the sampler's
     // graphs and the loop is a chain of dependent memory round trips otherwise); accumulated in position order
-    constexpr int U = 4;
+#ifndef PYG_CSR_U
+#define PYG_CSR_U 4
+#endif
+    constexpr int U = PYG_CSR_U;
     for (int64_t e0 = a + lane; e0 < b; e0 += (int64_t)U * L) {
       int64_t pp[U];
       P xx[U];
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __rest
   const int64_t n = slice * s.rows + row;
   acc_t acc = acc_t(0);
   int64_t best = s.E;
-  if (valid && OP != CSR_MEAN) acc = Math<T>::up(out[n * K + k]);
+  if (valid && OP != CSR_MEAN && !(OP == CSR_SUM && fresh)) acc = Math<T>::up(out[n * K + k]);
   const int64_t CE = kStreamValues / K;
   const T* sp = src + slice * s.E * K;
   for (int64_t base = a0; base < b0; base += CE) {
@@ -504,11 +512,21 @@ int run_minmax_perm(int is_min, const void* src, const int64_t* indptr, const in
 
 }  // namespace
 
-int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, void* out, int64_t leading,
-                    int64_t rows, int64_t E, int64_t K, hipStream_t stream) {
+template <typename T>
+int run_sum_perm(const void* src, const int64_t* indptr, const int64_t* perm, void* out, int fresh, const CsrShape& s,
+                 hipStream_t stream) {
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  return vec ? launch_segment<T, CSR_SUM, VMAX, true>(src, indptr, perm, out, nullptr, fresh, s, stream)
+             : launch_segment<T, CSR_SUM, 1, true>(src, indptr, perm, out, nullptr, fresh, s, stream);
+}
+
+int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, const int64_t* perm, void* out,
+                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream) {
   if (leading * rows * K == 0) return PYG_HIP_OK;
   const CsrShape s{leading, rows, E, K, indptr_stride};
-  PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(CSR_SUM, src, indptr, out, nullptr, 0, s, stream)));
+  if (perm) PYG_DISPATCH_ALL(dtype, (run_sum_perm<scalar_t>(src, indptr, perm, out, fresh, s, stream)));
+  PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(CSR_SUM, src, indptr, out, nullptr, fresh, s, stream)));
 }
 
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,

@@ -422,9 +422,22 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
   const T* init = static_cast<const T*>(init_);
   const int64_t total = s.B * s.E * s.K;
   const int64_t outn = s.B * s.N * s.K;
+  // PYG_HIP_SCATTER_FRESH_SUM: `out` of a sum is uninitialised.  The sorted (CSR-row) path writes every slot and never
+  // reads it; every other path accumulates into zeros, cleared here.
+  const bool fresh_sum = op == OP_SUM && (sorted & PYG_HIP_SCATTER_FRESH_SUM) != 0;
+  sorted &= PYG_HIP_SCATTER_SORTED;
+  const bool csr_rows = op == OP_SUM && sorted && s.isk == 0 && ws && ws_bytes >= scatter_indptr_bytes(s.B, s.N) && total > 0;
+  // one large unsorted index vector, rows of >= 64 bytes: sort the E indices once (3-4 radix passes over 16 E bytes),
+  // buckets become CSR rows summed through the permutation in SOURCE order (the stable sort keeps it): no atomics,
+  // deterministic, every output row written once
+  const bool float_t = std::is_same<T, float>::value || std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
+  const bool sort_rows = op == OP_SUM && !sorted && float_t && s.isk == 0 && s.B == 1 && s.ise == 1 && s.E >= (1 << 15) &&
+                         s.K * (int64_t)sizeof(T) >= 64 && ws &&
+                         ws_bytes >= scatter_sort_ws_bytes(s.E) + scatter_indptr_bytes(1, s.N);
+  if (fresh_sum && !csr_rows && !sort_rows && outn > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(T) * (size_t)outn, stream));
   if (total == 0) return PYG_HIP_OK;
   const unsigned grid = grid_for(total);
-  if (op == OP_SUM && sorted && s.isk == 0 && ws && ws_bytes >= scatter_indptr_bytes(s.B, s.N)) {
+  if (csr_rows) {
     // COO contract (index ascending along e): buckets are CSR rows -- summed in source order in opmath,
     // seeded from `out`, no atomics (the run accumulation of segment_coo_kernel.cpp:104-166, bit for bit)
     int64_t* indptr = reinterpret_cast<int64_t*>(ws);
@@ -432,7 +445,22 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
     hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, index, s.isb, s.ise,
                        s.B, s.E, s.N, indptr);
     PYG_HIP_CHECK(hipGetLastError());
-    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, out, s.B, s.N, s.E, s.K, stream);
+    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, nullptr, out, s.B, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream);
+  }
+  if (sort_rows) {
+    char* w = static_cast<char*>(ws);
+    const size_t sort_bytes = scatter_sort_ws_bytes(s.E);
+    int64_t* keys = reinterpret_cast<int64_t*>(w);
+    int64_t* perm = reinterpret_cast<int64_t*>(w + align_up(sizeof(int64_t) * (size_t)s.E, 256));
+    void* sws = w + 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256);
+    int64_t* indptr = reinterpret_cast<int64_t*>(w + sort_bytes);
+    int rc = index_sort_i64(index, s.E, s.N > 0 ? s.N - 1 : 0, keys, perm, sws,
+                            sort_bytes - 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256), stream);
+    if (rc != PYG_HIP_OK) return rc;
+    hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((s.N + 1 + 255) / 256)), dim3(256), 0, stream,
+                       (const int64_t*)keys, (int64_t)0, (int64_t)1, (int64_t)1, s.E, s.N, indptr);
+    PYG_HIP_CHECK(hipGetLastError());
+    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, perm, out, 1, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream);
   }
   if (op == OP_SUM) {
     if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
@@ -442,27 +470,6 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
           const int64_t threads = s.B * ((s.E + 31) / 32) * (s.K / Vec<T>::N);
           hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
                              src, index, (const int64_t*)nullptr, out, s);
-          PYG_HIP_CHECK(hipGetLastError());
-          return PYG_HIP_OK;
-        }
-        // Unsorted index, rows of >= 64 bytes, one index vector (B == 1): sort the E indices once
-        // (3-4 radix passes over 16 E bytes) and reduce runs through the permutation -- ~E/16 atomics
-        // instead of E, see DESIGN.md 2.4.
-        const size_t need = scatter_sort_ws_bytes(s.E);
-        if (s.B == 1 && s.ise == 1 && s.E >= (1 << 15) && s.K * (int64_t)sizeof(T) >= 64 && ws && ws_bytes >= need) {
-          char* w = static_cast<char*>(ws);
-          int64_t* keys = reinterpret_cast<int64_t*>(w);
-          int64_t* perm = reinterpret_cast<int64_t*>(w + align_up(sizeof(int64_t) * (size_t)s.E, 256));
-          void* sws = w + 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256);
-          int rc = index_sort_i64(index, s.E, s.N > 0 ? s.N - 1 : 0, keys, perm, sws,
-                                  ws_bytes - 2 * align_up(sizeof(int64_t) * (size_t)s.E, 256), stream);
-          if (rc != PYG_HIP_OK) return rc;
-          Shape ss = s;
-          ss.isb = 0;
-          ss.ise = 1;
-          const int64_t threads = ((s.E + 31) / 32) * (s.K / Vec<T>::N);
-          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
-                             src, (const int64_t*)keys, (const int64_t*)perm, out, ss);
           PYG_HIP_CHECK(hipGetLastError());
           return PYG_HIP_OK;
         }
@@ -581,6 +588,8 @@ int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index, in
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(B >= 0 && E >= 0 && K >= 0 && N >= 0, "scatter: negative size");
   if (B * E * K == 0) {
+    if (op == OP_SUM && (index_sorted & PYG_HIP_SCATTER_FRESH_SUM) && out && B * N * K > 0)
+      PYG_HIP_CHECK(hipMemsetAsync(out, 0, dtype_size(dtype) * (size_t)(B * N * K), stream));
     if ((op == OP_MIN || op == OP_MAX) && arg_out && B * N * K > 0) {
       hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((B * N * K + 255) / 256)), dim3(256), 0, stream,
                          arg_out, B * N * K, E);
