@@ -1251,6 +1251,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   pt.mark("rng_started");
 
   // ---- seeds ----
+  // fused chain, one seed set of one tile (the usual mini-batch): its insertion rides in the seeds' scan launch
+  const bool fold_seeds = fused && fused_seed_foldable(seeds, num_seed_sets);
   int64_t batch0 = 0;
   for (int s = 0; s < num_seed_sets; ++s) {
     const pyg_hip_seed_set& ss = seeds[s];
@@ -1273,10 +1275,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (rc != PYG_HIP_OK) return rc;
     u64* slots;
     PYG_ALLOC(slots, u64*, c, sizeof(u64) * (size_t)S);
-    hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
-                       ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
-                       disjoint ? n.batch.p : (int64_t*)nullptr, slots, tstate + ss.node_type);
-    PYG_HIP_CHECK(hipGetLastError());
+    if (!fold_seeds) {
+      hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream,
+                         ss.seed, S, batch0, disjoint, num_batches, n.table, n.nodes.p,
+                         disjoint ? n.batch.p : (int64_t*)nullptr, slots, tstate + ss.node_type);
+      PYG_HIP_CHECK(hipGetLastError());
+    }
     if (temporal) {
       const int64_t* nt = node_time ? node_time[ss.node_type] : nullptr;
       if (ss.seed_time || nt) {
@@ -1290,7 +1294,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     }
     if (fused) {
       // the seeds' first-occurrence scan also carries hop 0's counts: queued with the chain (run_fused_chain)
-      fseeds.push_back(FusedSeed{ss.node_type, S, slots});
+      fseeds.push_back(FusedSeed{ss.node_type, S, slots, ss.seed, batch0, tstate + ss.node_type, fold_seeds});
       n.nodes.size = S;
       if (disjoint) n.batch.size = S;
       batch0 += S;

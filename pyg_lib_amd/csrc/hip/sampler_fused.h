@@ -28,6 +28,10 @@ constexpr int kMaxCons = 3;         // relations of the next hop that expand one
                                     // (with 4 the reduce pass holds 64 row bounds per thread and spills)
 constexpr int kMaxParts = 8;        // relations queued per hop; more: round 2's chain
 constexpr int kMaxLaunchCons = 12;  // consumers over all node types of one scan launch
+constexpr int kOnePassMaxTiles = 256;  // scans of at most this many tiles run as one launch (see fused_onepass)
+constexpr int kAggStride = 8;       // one-pass scan: 64-bit words between two tiles' aggregates (one 64-byte line each: every
+                                    // block reads every aggregate in front of it, and a dense array is a few KB, i.e. a
+                                    // handful of memory channels for a few hundred thousand uncached reads)
 
 template <int NC>
 struct FusedAgg {
@@ -95,7 +99,7 @@ struct FSegHdr {  // one node type in one phase: the emissions of every relation
   const int64_t* size_in;  // hop: &size_at[l * T + t]; seeds: nullptr
   int64_t* size_out;       // hop: &size_at[(l + 1) * T + t]; seeds: &size_at[t]
   int64_t* dup;            // &dup[t]
-  void* tile_agg;          // FusedAgg<NC>[tiles of all parts]
+  void* tile_agg;          // FusedAgg<NC>[tiles of all parts] (one-pass scan: zeroed at the start of the call)
   int seeds;
   int ncons;
 };
@@ -114,8 +118,22 @@ struct FPart {  // one relation's emissions of the hop (or one seed set); carrie
   int cons0;         // first consumer of the segment in the launch's consumer array
 };
 
-struct FScanLaunch {  // kernel argument of the two scan passes of a phase
+struct FSeedFold {  // seeds launch of a call whose seeds are ONE tile: the table initialisation and the seeds' insertion
+                    // (fused_init_kernel, seed_insert_kernel) run in front of the scan, in the same single block
+  const int64_t* seed;  // nullptr: not folded
+  int64_t batch0;
+  int64_t num_batches;
+  HashTable table;
+  TypeState* ts;
+  unsigned* sync;       // the call's tickets + tile aggregates
+  int sync_words;
+  int disjoint;
+};
+
+struct FScanLaunch {  // kernel argument of a phase's scan (one pass; or the reduce / apply pair)
   FTables tb;
+  unsigned* ticket;        // one-pass scan: blocks take their position in the launch from here (zeroed with the aggregates)
+  FSeedFold fold;
   int n;                   // items: the parts, then (apply pass of a hop) the carry block
   int ell;                 // hop (carry)
   unsigned type_mask_lo, type_mask_hi;  // carry: bit t set = type t has a segment (its last block writes the size)
@@ -242,7 +260,7 @@ struct FCons {
 
 // ---- reduce: tile aggregates of (first-occurrence flag, next-hop counts) -----------------------------------------
 template <int NC>
-__device__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
+__device__ __forceinline__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
   typedef FusedAgg<NC> T;
   typedef FusedOp<NC> Op;
   __shared__ T lds[8];
@@ -314,7 +332,7 @@ __device__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
 
 // ---- apply: ids, node-list append, the next hop's per-node prefixes; the segment's last block publishes its totals
 template <int NC>
-__device__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
+__device__ __forceinline__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
   typedef FusedAgg<NC> T;
   typedef FusedOp<NC> Op;
   __shared__ T lds[8];
@@ -385,6 +403,208 @@ __device__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int n
         if (!pt.h.seeds) {
           pt.h.nodes[size0 + run.rank] = pt.e_node[p];
           if (pt.h.batch) pt.h.batch[size0 + run.rank] = pt.e_batch[p];
+        }
+      }
+      if constexpr (NC > 0) {
+        if (flag || pt.h.seeds) {
+          const int64_t i = pt.h.seeds ? p : run.rank;  // index in the next hop's frontier
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            cons.c[c].edge_off[i] = run.next[c].edges;
+            cons.c[c].tabp[i] = run.next[c].tab;
+          }
+        }
+      }
+    }
+    run = op(run, v[k]);
+  }
+}
+
+// ---- one pass: reduce and apply of a tile by the same block -----------------------------------------------------------
+// The reduce / apply pair above costs a launch boundary and a second trip of every emission's (flag, counts) word
+// through memory.  Here a block keeps its items in registers, publishes its tile aggregate and then looks back: it
+// waits for and sums the aggregates of every tile in front of it in its segment.  The blocks take
+// their position from a ticket counter, so a block only ever waits for blocks that started before it (no assumption on
+// the dispatch order, nothing to deadlock on).  The waiting is all-pairs -- every block polls every aggregate in front of
+// it, uncached -- which is the cheaper form up to a few hundred tiles (16 tiles: 11 - 13 us against 17 for the pair of
+// launches, 151 tiles: 16.5 against 19) and the dearer one beyond (750 tiles: 32 - 37 us against 29.5: the polls compete
+// with the gathers of the blocks that still reduce); the host picks per launch (kOnePassMaxTiles).  What apply writes while other blocks still reduce does not disturb them:
+// a table entry turns from its owner's provisional position into a final id, and a non-owner's test
+// `value == provisional + my position` fails on either.
+// FOLD: the seeds of the call are this single block's tile -- it first initialises the call's tables and inserts the seeds
+// (fused_init_kernel + seed_insert_kernel), slot handles, nodes and batch ids staying in registers.
+__device__ __forceinline__ void fused_tables_init(const FTables& tb, int i) {
+  if (i < (tb.L + 1) * tb.T) tb.size_at[i] = 0;
+  if (i < tb.T) tb.dup[i] = 0;
+  if (i < tb.L * tb.R) {
+    tb.tot[i] = CountOp::identity();
+    tb.overflow[i] = 0;
+  }
+  if (i == 0) *tb.wide = 0;
+}
+
+template <int NC, bool FOLD>
+__device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
+  typedef FusedAgg<NC> T;
+  typedef FusedOp<NC> Op;
+  __shared__ T lds[8];
+  FCons<NC> cons;
+  cons.load(L, pt.cons0);
+  const int tid = (int)threadIdx.x;
+  const int64_t n = FOLD ? pt.n_fixed : part_count(L, pt);
+  const int64_t base = (int64_t)lt * kScanTile + tid * kScanItems;
+  Op op;
+  u64 sl[kScanItems];
+  int64_t nd[kScanItems], bt[kScanItems];
+  T v[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    sl[k] = 0;
+    nd[k] = 0;
+    bt[k] = 0;
+    v[k] = Op::identity();
+  }
+  if constexpr (FOLD) {
+    const FSeedFold& f = L.fold;
+    const int cells = max((L.tb.L + 1) * L.tb.T, L.tb.L * L.tb.R);
+    for (int i = tid; i < cells; i += kScanThreads) fused_tables_init(L.tb, i);
+    for (int i = tid; i < f.sync_words / 4; i += kScanThreads) reinterpret_cast<uint4*>(f.sync)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) {
+      f.ts->size = n;
+      f.ts->slice_e = n;
+    }
+    if (base < n) {
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) {
+        const int64_t p = base + k < n ? base + k : n - 1;
+        nd[k] = f.seed[p];
+        bt[k] = f.disjoint ? f.batch0 + p : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) {
+        const int64_t p = base + k;
+        sl[k] = table_slot(f.table, make_key(nd[k], bt[k], f.num_batches));
+        if (p < n) {
+          pt.h.nodes[p] = nd[k];
+          if (f.disjoint) pt.h.batch[p] = bt[k];
+          __hip_atomic_fetch_min(&f.table.vals[sl[k]], f.table.prov + (u64)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    // every initialising store and every insertion has been performed before anybody reads a table value or
+    // overwrites a table cell (the segment's totals go where the initialisation wrote)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+  }
+  T agg = Op::identity();
+  if (base < n) {
+    if constexpr (!FOLD) {
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) {
+        const int64_t pc = base + k < n ? base + k : n - 1;
+        sl[k] = pt.slots[pc];
+        nd[k] = pt.e_node[pc];  // (a hop's last scan carries no consumers but still appends the node)
+        bt[k] = pt.e_batch ? pt.e_batch[pc] : 0;
+      }
+    }
+    u64 vv[kScanItems];
+    int64_t r0[kScanItems][NC > 0 ? NC : 1], r1[kScanItems][NC > 0 ? NC : 1];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      vv[k] = FOLD ? __hip_atomic_load(&pt.h.vals[sl[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pt.h.vals[sl[k]];
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          r0[k][c] = cons.c[c].range.rowptr[nd[k]];
+          r1[k][c] = cons.c[c].range.rowptr[nd[k] + 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const int64_t p = base + k;
+      if (p >= n) break;
+      const bool flag = vv[k] == pt.h.prov + (u64)(pt.pos_base + p);
+      v[k].rank = flag ? 1 : 0;
+      if constexpr (NC > 0) {
+        if (flag || pt.h.seeds) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) v[k].next[c] = consumer_count_bounds(cons.c[c], r0[k][c], r1[k][c], bt[k], L.tb.wide);
+        }
+      }
+      agg = op(agg, v[k]);
+    }
+  }
+  T total;
+  T run = block_exclusive<T, Op>(agg, lds, op, &total);
+  T before = Op::identity();
+  if constexpr (!FOLD) {
+    // Aggregates travel as relaxed agent-scope atomics of self-validating words (rank + 1, edges + 1, a pure table has
+    // bit 63 set: never 0, and the array starts zeroed) -- per-location coherence is all the protocol needs, so there
+    // is no release / acquire pair, which on this chip means an L2 write-back and an L2 invalidate per block.
+    const int ti = pt.tile0 + lt;
+    u64* words = static_cast<u64*>(pt.h.tile_agg);
+    constexpr int W = 1 + 2 * NC;
+    static_assert(W <= kAggStride, "a tile's aggregate has its own 64-byte line");
+    if (tid == 0) {
+      u64* w = words + (size_t)ti * kAggStride;
+      __hip_atomic_store(&w[0], (u64)total.rank + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          __hip_atomic_store(&w[1 + 2 * c], (u64)total.next[c].edges + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&w[2 + 2 * c], (u64)total.next[c].tab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (ti > 0) {
+      T part = Op::identity();
+      for (int i = tid; i < ti; i += kScanThreads) {
+        const u64* w = words + (size_t)i * kAggStride;
+        u64 x[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          while ((x[j] = __hip_atomic_load(&w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(2);
+        T t;
+        t.rank = (int64_t)(x[0] - 1);
+        if constexpr (NC > 0) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            t.next[c].edges = (int64_t)(x[1 + 2 * c] - 1);
+            t.next[c].tab = (RngTab)x[2 + 2 * c];
+          }
+        }
+        part = op(part, t);
+      }
+      (void)block_exclusive<T, Op>(part, lds, op, &before);
+    }
+  }
+  const int64_t size0 = pt.h.seeds ? 0 : *pt.h.size_in;
+  const int64_t id0 = pt.h.seeds ? 0 : size0 - *pt.h.dup;
+  run = op(before, run);
+  if (pt.last && lt == nblocks - 1 && tid == 0) {
+    const T grand = op(before, total);
+    if (pt.h.seeds) {
+      *pt.h.size_out = pt.n_fixed;
+      *pt.h.dup = pt.n_fixed - grand.rank;
+    } else {
+      *pt.h.size_out = size0 + grand.rank;
+    }
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) L.tb.tot[cons.c[c].tot_index] = grand.next[c];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t p = base + k;
+    if (p < n) {
+      const bool flag = v[k].rank != 0;
+      if (flag) {
+        pt.h.vals[sl[k]] = pt.h.tag | (u64)(id0 + run.rank);
+        if (!pt.h.seeds) {
+          pt.h.nodes[size0 + run.rank] = nd[k];
+          if (pt.h.batch) pt.h.batch[size0 + run.rank] = bt[k];
         }
       }
       if constexpr (NC > 0) {
@@ -512,16 +732,11 @@ __device__ __forceinline__ void fused_finalize(const FSampleLaunch& L, const FFi
   if (p < n) ff.out_col[off + p] = (int64_t)(ff.vals[ff.slots[p]] & ff.idmask);
 }
 
-// tables at the start of a call: sizes 0, totals identity, no overflow
-__global__ void fused_init_kernel(FTables tb) {
+// tables at the start of a call: sizes 0, totals identity, no overflow; tickets and tile aggregates of the one-pass scans 0
+__global__ void fused_init_kernel(FTables tb, unsigned* __restrict__ sync, int sync_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (tb.L + 1) * tb.T) tb.size_at[i] = 0;
-  if (i < tb.T) tb.dup[i] = 0;
-  if (i < tb.L * tb.R) {
-    tb.tot[i] = CountOp::identity();
-    tb.overflow[i] = 0;
-  }
-  if (i == 0) *tb.wide = 0;
+  fused_tables_init(tb, i);
+  if (i < sync_words) sync[i] = 0;
 }
 
 // launch kind 1: [finalize of the previous hop | sampling of this hop] (+ the engine fold behind the last hop)
@@ -603,13 +818,20 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
   }
 }
 
-// launch kinds 2 / 3: the scans' two passes.  MAXNC = the most consumers of any segment of the launch (the registers of
-// the widest aggregate are only paid where one occurs: the last hop carries none).
-// MODE 0 = reduce, 1 = apply, 2 = both passes in ONE single-block launch (the seeds of a C3-sized batch are one tile:
-// the block has every aggregate of the launch itself, a launch and its boundary less on the call's host-bound start)
+// launch kinds 2 / 3: the scans.  MAXNC = the most consumers of any segment of the launch (the registers of the widest
+// aggregate are only paid where one occurs: the last hop carries none).
+// MODE 0 = reduce, 1 = apply (the two-pass form: PYG_HIP_SAMPLER_ONEPASS=0), 2 = one pass, 3 = one pass of a single
+// block with the call's initialisation and the seeds' insertion folded in
+constexpr int kScanReduce = 0, kScanApply = 1, kScanOnePass = 2, kScanSeedFold = 3;
 template <int MAXNC, int MODE>
 __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
-  const int bx = (int)blockIdx.x;
+  int bx = (int)blockIdx.x;
+  if constexpr (MODE == kScanOnePass) {
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = (int)__hip_atomic_fetch_add(L.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    bx = __builtin_amdgcn_readfirstlane(s_ticket);
+  }
   int k = 0;
 #pragma unroll
   for (int j = 0; j < kMaxParts + 1; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
@@ -626,18 +848,14 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
     return;
   }
   const FPart& pt = L.part[k];
-#define PYG_FUSED_CASE(N)                               \
-  if (MAXNC >= N && nc == N) {                          \
-    if constexpr (MAXNC >= N) {                         \
-      if (MODE == 1) fused_apply<N>(L, pt, b, nblocks); \
-      else fused_reduce<N>(L, pt, b);                   \
-      if (MODE == 2) {                                  \
-        __threadfence_block();                          \
-        __syncthreads();                                \
-        fused_apply<N>(L, pt, b, nblocks);              \
-      }                                                 \
-    }                                                   \
-    return;                                             \
+#define PYG_FUSED_CASE(N)                                                           \
+  if (MAXNC >= N && nc == N) {                                                      \
+    if constexpr (MAXNC >= N) {                                                     \
+      if constexpr (MODE == kScanReduce) fused_reduce<N>(L, pt, b);                 \
+      else if constexpr (MODE == kScanApply) fused_apply<N>(L, pt, b, nblocks);     \
+      else fused_onepass<N, MODE == kScanSeedFold>(L, pt, b, nblocks);              \
+    }                                                                               \
+    return;                                                                         \
   }
   PYG_FUSED_CASE(0)
   PYG_FUSED_CASE(1)

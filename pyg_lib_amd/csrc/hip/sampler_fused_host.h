@@ -1,11 +1,36 @@
 // Host side of the fused chain (sampler_fused.h): 3 launches per hop, every record in the launch's kernel argument (no
 // staging copy), the write-once tables read back once behind the last launch.  Included by sampler.hip.
 
-struct FusedSeed {  // one seed set, recorded by the seeds loop of run_sampler (insert kernel already queued)
+struct FusedSeed {  // one seed set, recorded by the seeds loop of run_sampler
   int type;
   int64_t S;
   u64* slots;
+  const int64_t* seed;  // folded == true: the insert kernel was NOT queued -- the seeds' scan launch inserts them itself
+  int64_t batch0;
+  TypeState* ts;
+  bool folded;
 };
+
+// PYG_HIP_SAMPLER_ONEPASS=0: the scans as reduce + apply launches, seeds inserted by their own kernel (A/B timing)
+inline bool fused_onepass_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PYG_HIP_SAMPLER_ONEPASS");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+// the seeds of a call can be folded into their scan launch: one seed set of one tile
+inline bool fused_seed_foldable(const pyg_hip_seed_set* seeds, int num_seed_sets) {
+  if (!fused_onepass_enabled()) return false;
+  int sets = 0;
+  int64_t S = 0;
+  for (int s = 0; s < num_seed_sets; ++s)
+    if (seeds[s].num_seed > 0) {
+      ++sets;
+      S = seeds[s].num_seed;
+    }
+  return sets == 1 && S <= kScanTile;
+}
 
 // consumers of node type t for hop `next` (relations of that hop that expand t), in relation order
 inline std::vector<int> fused_consumers(const pyg_hip_relation* rels, int num_relations, int csc,
@@ -114,6 +139,30 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     for (int t = 0; t < T; ++t)
       if (seg_tiles[(size_t)t]) arena_bytes += align_up((8 + 16 * (size_t)kMaxCons) * (seg_tiles[(size_t)t] + 1), 256);
   }
+  // Which scans run as one launch (fused_onepass: up to kOnePassMaxTiles tiles)?  Their tickets (own 64-byte lines) and
+  // tile aggregates are cleared per call.
+  const bool onepass = fused_onepass_enabled();
+  size_t sync_bytes = 64 * (size_t)(L + 1);
+  bool seeds_onepass = onepass;
+  {
+    size_t tiles = 0;
+    for (const FusedSeed& fsd : fseeds) tiles += (size_t)tiles_of(fsd.S);
+    seeds_onepass = onepass && tiles <= (size_t)kOnePassMaxTiles;
+    if (seeds_onepass) sync_bytes += 8 * kAggStride * (tiles + fseeds.size());
+  }
+  std::vector<char> hop_onepass((size_t)L, 0);
+  for (int ell = 0; ell < L; ++ell) {
+    size_t tiles = 0, parts = 0;
+    for (int e = 0; e < R; ++e)
+      if (eb[(size_t)ell][(size_t)e] != 0) {
+        tiles += (size_t)tiles_of(eb[(size_t)ell][(size_t)e]);
+        ++parts;
+      }
+    hop_onepass[(size_t)ell] = onepass && parts > 0 && tiles < (size_t)kOnePassMaxTiles;
+    if (hop_onepass[(size_t)ell]) sync_bytes += 8 * kAggStride * (tiles + parts);
+  }
+  const size_t sync_words = sync_bytes / 4;
+  arena_bytes += align_up(sync_bytes, 256);
   pt.mark("chain_entry");
   char* arena;
   PYG_ALLOC(arena, char*, c, arena_bytes);
@@ -136,9 +185,27 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   tb.L = L;
   tb.R = R;
   tb.T = T;
-  {
-    const int cells = std::max((L + 1) * T, L * R);
-    hipLaunchKernelGGL(fused_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, tb);
+  unsigned* sync = reinterpret_cast<unsigned*>(carve(sync_bytes));
+  char* sync_next = reinterpret_cast<char*>(sync) + 64 * (size_t)(L + 1);
+  auto ticket_of = [&](int launch) { return sync + 16 * (size_t)launch; };  // 0: seeds, 1 + l: hop l
+  auto tile_agg_of = [&](bool one_launch, int ncons, int tiles) {  // aggregates of a segment's tiles
+    if (!one_launch) return carve((8 + 16 * (size_t)ncons) * (size_t)(tiles + 1));
+    char* p = sync_next;
+    sync_next += 8 * kAggStride * (size_t)(tiles + 1);
+    return p;
+  };
+  const bool fold_seeds = fseeds.size() == 1 && fseeds[0].folded && sync_words <= 65536;
+  if (!fold_seeds) {
+    for (const FusedSeed& fsd : fseeds) {
+      if (!fsd.folded) continue;  // left to the chain, but too much for one block to clear: the insert kernel after all
+      NodeSet& n = ns[(size_t)fsd.type];
+      hipLaunchKernelGGL(seed_insert_kernel, dim3((unsigned)((fsd.S + 255) / 256)), dim3(256), 0, stream, fsd.seed, fsd.S,
+                         fsd.batch0, disjoint, num_batches, n.table, n.nodes.p, disjoint ? n.batch.p : (int64_t*)nullptr,
+                         fsd.slots, fsd.ts);
+      PYG_HIP_CHECK(hipGetLastError());
+    }
+    const int cells = std::max((int)sync_words, std::max((L + 1) * T, L * R));
+    hipLaunchKernelGGL(fused_init_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, tb, sync, (int)sync_words);
     PYG_HIP_CHECK(hipGetLastError());
   }
 
@@ -171,16 +238,17 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     PYG_HIP_CHECK(hipGetLastError());
     return PYG_HIP_OK;
   };
-  auto launch_scan = [&](const FScanLaunch& l, int mode) -> int {  // 0 reduce, 1 apply, 2 both (single-block launches)
+  auto launch_scan = [&](const FScanLaunch& l, int mode) -> int {  // kScanReduce / kScanApply / kScanOnePass / kScanSeedFold
     if (l.n == 0) return PYG_HIP_OK;
     int maxnc = 0;
     for (int k = 0; k < l.n; ++k) maxnc = std::max(maxnc, l.nc[k]);
     const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
-#define PYG_FUSED_LAUNCH(N)                                                                    \
-  case N:                                                                                      \
-    if (mode == 0) hipLaunchKernelGGL((fused_scan_kernel<N, 0>), grid, block, 0, stream, l);   \
-    else if (mode == 1) hipLaunchKernelGGL((fused_scan_kernel<N, 1>), grid, block, 0, stream, l); \
-    else hipLaunchKernelGGL((fused_scan_kernel<N, 2>), grid, block, 0, stream, l);             \
+#define PYG_FUSED_LAUNCH(N)                                                                                      \
+  case N:                                                                                                        \
+    if (mode == kScanReduce) hipLaunchKernelGGL((fused_scan_kernel<N, kScanReduce>), grid, block, 0, stream, l); \
+    else if (mode == kScanApply) hipLaunchKernelGGL((fused_scan_kernel<N, kScanApply>), grid, block, 0, stream, l); \
+    else if (mode == kScanOnePass) hipLaunchKernelGGL((fused_scan_kernel<N, kScanOnePass>), grid, block, 0, stream, l); \
+    else hipLaunchKernelGGL((fused_scan_kernel<N, kScanSeedFold>), grid, block, 0, stream, l);                   \
     break;
     switch (maxnc) {
       PYG_FUSED_LAUNCH(0)
@@ -260,7 +328,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       pp.h.seeds = 1;
       pp.cons0 = fill_consumers(sc, &used, pp.h, fsd.type, 0);
       const int nt = tiles_of(fsd.S);
-      pp.h.tile_agg = carve((8 + 16 * (size_t)pp.h.ncons) * (size_t)(nt + 1));
+      pp.h.tile_agg = tile_agg_of(seeds_onepass, pp.h.ncons, nt);
       pp.slots = fsd.slots;
       pp.e_node = ns[(size_t)fsd.type].nodes.p;
       pp.e_batch = disjoint ? ns[(size_t)fsd.type].batch.p : nullptr;
@@ -274,11 +342,24 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     }
     pt.mark("seedscan_built");
     int rc;
-    if (sc.n > 0 && sc.cum[sc.n - 1] == 1) {
-      rc = launch_scan(sc, 2);  // one tile in all: both passes in one launch
+    if (fold_seeds) {
+      const FusedSeed& fsd = fseeds[0];
+      PYG_HIP_REQUIRE(sc.n == 1 && sc.cum[0] == 1, "sampler: internal error (folded seeds are one tile)");
+      sc.fold.seed = fsd.seed;
+      sc.fold.batch0 = fsd.batch0;
+      sc.fold.num_batches = num_batches;
+      sc.fold.table = ns[(size_t)fsd.type].table;
+      sc.fold.ts = fsd.ts;
+      sc.fold.sync = sync;
+      sc.fold.sync_words = (int)sync_words;
+      sc.fold.disjoint = disjoint;
+      rc = launch_scan(sc, kScanSeedFold);
+    } else if (seeds_onepass) {
+      sc.ticket = ticket_of(0);
+      rc = launch_scan(sc, kScanOnePass);
     } else {
-      rc = launch_scan(sc, 0);
-      if (rc == PYG_HIP_OK) rc = launch_scan(sc, 1);
+      rc = launch_scan(sc, kScanReduce);
+      if (rc == PYG_HIP_OK) rc = launch_scan(sc, kScanApply);
     }
     if (rc != PYG_HIP_OK) return rc;
   }
@@ -325,7 +406,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       int nt = 0;
       for (int e = 0; e < R; ++e)
         if (dst_of(e) == t) nt += tiles_of(eb[(size_t)ell][(size_t)e]);
-      sh.tile_agg = carve((8 + 16 * (size_t)sh.ncons) * (size_t)(nt + 1));
+      sh.tile_agg = tile_agg_of(hop_onepass[(size_t)ell] != 0, sh.ncons, nt);
     }
     std::vector<Step> cur;
     for (int e = 0; e < R; ++e) {
@@ -405,10 +486,16 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     }
     rc = launch_sample(p1);
     if (rc != PYG_HIP_OK) return rc;
-    rc = launch_scan(p2, 0);
-    if (rc != PYG_HIP_OK) return rc;
-    add_part(p2, -1, 1, nullptr);  // carry block: apply pass only
-    rc = launch_scan(p2, 1);
+    if (hop_onepass[(size_t)ell]) {
+      add_part(p2, -1, 1, nullptr);  // carry block
+      p2.ticket = ticket_of(1 + ell);
+      rc = launch_scan(p2, kScanOnePass);
+    } else {
+      rc = launch_scan(p2, kScanReduce);
+      if (rc != PYG_HIP_OK) return rc;
+      add_part(p2, -1, 1, nullptr);  // carry block: apply pass only
+      rc = launch_scan(p2, kScanApply);
+    }
     pt.mark("hop_queued");
     if (rc != PYG_HIP_OK) return rc;
     steps_by_hop[(size_t)ell] = cur;

@@ -257,9 +257,28 @@ def test_products_scale_batch_is_bit_exact():
     col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
     seeds = rng.permutation(n)[:1024].astype(np.int64)
     out, after, ref = run_both(rowptr, col, seeds, [15, 10, 5], 12345)
-    assert sampler.last_mode() == 'fused'   # 3 launches per hop (csrc/hip/sampler_fused.h)
+    assert sampler.last_mode() == 'fused'   # 2 - 3 launches per hop (csrc/hip/sampler_fused.h)
     assert_same(out, after, ref, 12345)
     assert sum(ref[5]) > 500_000
+
+
+@pytest.mark.parametrize('num_seeds,disjoint', [(300, False), (1024, True), (3000, False), (3000, True), (70_000, False),
+                                                (300_000, False)])
+def test_every_scan_form_of_the_fused_chain(num_seeds, disjoint):
+    """The seeds' and the hops' first-occurrence scans run in one of three forms (sampler_fused.h): seeds of one tile are
+    inserted and scanned by ONE single-block launch together with the call's initialisation; scans of up to 256 tiles are
+    one launch whose blocks look back at the aggregates in front of them; larger ones are a reduce + apply pair.  Seed
+    counts on either side of both limits, repeated seeds (the duplicate-seed quirk of Mapper) included."""
+    n = 400_000
+    rowptr, col = random_csr(n, 8, seed=21)
+    rng = np.random.default_rng(22)
+    seeds = rng.integers(0, n, num_seeds, dtype=np.int64)
+    seeds[num_seeds // 3] = seeds[0]                     # repeated seeds
+    seeds[num_seeds // 2:num_seeds // 2 + 5] = seeds[1]
+    out, after, ref = run_both(rowptr, col, seeds, [4, 3], 4242, disjoint=disjoint)
+    assert sampler.last_mode() == 'fused'
+    assert_same(out, after, ref, 4242)
+    assert sum(ref[5]) > 3 * num_seeds
 
 
 @pytest.mark.parametrize('case', G.DIST_CASES, ids=[c['name'] for c in G.DIST_CASES])
