@@ -39,6 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void LDSV;
+// global_* instructions: a flat access also counts on lgkmcnt and would make every LDS wait conservative
+typedef const __attribute__((address_space(1))) int64_t GI64;
+typedef const __attribute__((address_space(1))) u32x4 GU32x4;
 
 struct RelDev {
   const int64_t* gather_index;
@@ -61,13 +64,15 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_v __attribute__((ext_vector_type(2)));
+
 template <bool BF16>
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-  if constexpr (BF16) {
-    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
-  } else {
-    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
-  }
+__device__ __forceinline__ uint32_t pack2(float a, float b) {  // one v_cvt_pk_* (element-wise casts cost four instructions)
+  const f32x2_v v = {a, b};
+  if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));
 }
 
 template <bool BF16>
@@ -111,7 +116,10 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
                                                         int* __restrict__ error, int dbg) {  // dbg: 0 in the product
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, xl = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
+  // (through readfirstlane: the compiler then knows that a tile's row count, relation and run structure are wave-uniform
+  // and keeps them -- and the branches on them -- on the scalar unit)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int total = tile_start[R];
   const int G = (int)gridDim.x;
   const int t_beg = (int)((int64_t)blockIdx.x * total / G);
@@ -150,8 +158,8 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     o.nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
     if (o.nrows > 0) {  // rows past the end repeat the last valid edge
       const int64_t e = e0 + (xl < o.nrows ? xl : o.nrows - 1);
-      o.g = rel.gather_index[e];
-      o.si = rel.scatter_index[e] + rel.scatter_offset;
+      o.g = ((GI64*)rel.gather_index)[e];
+      o.si = ((GI64*)rel.scatter_index)[e] + rel.scatter_offset;
     }
     return o;
   };
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
       *error = 1;
       io.g = 0;
     }
-    io.g = rel.gather_map[io.g];
+    io.g = ((GI64*)rel.gather_map)[io.g];
   };
   // the 32 feature rows of the next tile on their way: lane's chunk i is slot p = 64 i + lane of the stage.  (Two
   // tiles ahead -- a second register set -- was no faster: 82 vs 79 us on the C5 batch; what is left is not latency.)
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
       const int r = p >> 4, cs = p & 15;
       const int c = cs ^ (r & 15);
       const int64_t row = __shfl(b.g, r);
-      xr[i] = *reinterpret_cast<const u32x4*>(xb + row * 256 + c * 16);
+      xr[i] = *(GU32x4*)(xb + row * 256 + c * 16);
     }
   };
 
@@ -275,27 +283,38 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
       }
     }
     // scatter: lane owns columns 2*lane, 2*lane + 1 (chunk lane / 4, dword lane % 4) of every row; runs of equal
-    // destination are summed in fp32 and flushed with one packed atomic per lane (a whole 256-byte row per instruction)
+    // destination are summed in fp32 and flushed with one packed atomic per lane (a whole 256-byte row per instruction).
+    // The walk is scalar: the run ends of the wave's 32 rows are ONE ballot, a flush takes its destination from
+    // v_readlane, and the 32 values of a lane are read from the stage up front -- the first version compared per row
+    // through ds_bpermute under exec masks and waited for every row's LDS read before the next (two LDS round trips per
+    // row: ~4 us of a tile's ~9).
+    uint32_t ends;
+    {
+      const int64_t nxt = __shfl_down(si, 1);
+      const uint32_t valid = nrows >= 32 ? 0xffffffffu : ((1u << nrows) - 1u);
+      ends = ((uint32_t)__ballot(si != nxt) & 0x7fffffffu & valid) | (1u << (nrows - 1));
+    }
+    uint32_t mv[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) mv[r] = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
     float s0 = 0.f, s1 = 0.f;
-    int64_t cur = __shfl(si, 0);
+    const int si_lo = (int)(uint32_t)si, si_hi = (int)(uint32_t)((uint64_t)si >> 32);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-      if (r < nrows) {
-        const int64_t d = __shfl(si, r);
-        if (d != cur) {  // wave-uniform
-          if (!(dbg & 1)) atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
-          s0 = 0.f;
-          s1 = 0.f;
-          cur = d;
-        }
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
+      if (r < nrows) {  // (rows behind the end repeat the last edge: not summed)
         float a, b;
-        unpack2<BF16>(v, &a, &b);
+        unpack2<BF16>(mv[r], &a, &b);
         s0 += a;
         s1 += b;
+        if ((ends >> r) & 1u) {  // wave-uniform: row r closes a run
+          const int64_t d = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(si_hi, r) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane(si_lo, r));
+          if (!(dbg & 1)) atomic_add_pk<BF16>(out + d * 256 + lane * 4, s0, s1);
+          s0 = 0.f;
+          s1 = 0.f;
+        }
       }
     }
-    if (!(dbg & 1)) atomic_add_pk<BF16>(out + cur * 256 + lane * 4, s0, s1);
   }
 }
 
