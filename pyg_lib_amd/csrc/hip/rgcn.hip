@@ -86,15 +86,35 @@ __device__ __forceinline__ void unpack2(uint32_t v, float* a, float* b) {
   }
 }
 
+// out[addr] += (a, b) as one packed 16-bit pair, no value returned.  (The builtins, not inline asm: an asm with a memory
+// clobber made the compiler re-read the relation records -- scalar loads with their waits -- behind every flush, and it
+// cannot take the scalar-base addressing form.)
 template <bool BF16>
 __device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
-  const uint32_t v = pack2<BF16>(a, b);
-  typedef __attribute__((address_space(1))) void GV;
-  if constexpr (BF16)
-    asm volatile("global_atomic_pk_add_bf16 %0, %1, off" ::"v"((GV*)addr), "v"(v) : "memory");
-  else
-    asm volatile("global_atomic_pk_add_f16 %0, %1, off" ::"v"((GV*)addr), "v"(v) : "memory");
+  typedef short s16x2_v __attribute__((ext_vector_type(2)));
+  const f32x2_v v = {a, b};
+  if constexpr (BF16) {
+    typedef __attribute__((address_space(1))) bf16x2_v GB;
+    (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((GB*)addr, __builtin_bit_cast(s16x2_v, __builtin_convertvector(v, bf16x2_v)));
+  } else {
+    typedef __attribute__((address_space(1))) f16x2_v GH;
+    (void)__builtin_amdgcn_global_atomic_fadd_v2f16((GH*)addr, __builtin_convertvector(v, f16x2_v));
+  }
 }
+
+template <bool BF16>
+__device__ __forceinline__ void atomic_add_pk_bits(char* addr, uint32_t packed) {  // the same, operand already packed
+  typedef short s16x2_v __attribute__((ext_vector_type(2)));
+  if constexpr (BF16) {
+    typedef __attribute__((address_space(1))) bf16x2_v GB;
+    (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((GB*)addr, __builtin_bit_cast(s16x2_v, packed));
+  } else {
+    typedef __attribute__((address_space(1))) f16x2_v GH;
+    (void)__builtin_amdgcn_global_atomic_fadd_v2f16((GH*)addr, __builtin_bit_cast(f16x2_v, packed));
+  }
+}
+
+typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 
 // K = M = 128, 16-bit T
 // CHECK: every gather / scatter index is validated; an offender sets *error and is redirected to row 0 (the host
@@ -110,10 +130,21 @@ __device__ __forceinline__ void atomic_add_pk(char* addr, float a, float b) {
 //     tile t     : rows -> LDS stage (the XOR-swizzled layout of the segment_matmul kernels), MFMAs, scatter
 // and pays the round trips once per workgroup instead of three per tile.  (The first version issued one tile at a time by
 // LDS-DMA: 51 % of a wave's time waiting for rows, 30 % for indices; phase clocks of an experiment build.)
-template <bool BF16, bool CHECK>
+// Where the time goes now (C5 batch, 565 k edges, ablations of an experiment build through `dbg`; us incl. ~8 us of
+// launch + binding): everything 59; no atomics 53; no row gathers (compute on stale registers) 46 - 49; gathers and
+// indices only 33; indices only 15.  The compute side is the larger one and is made of LDS traffic (64 KB per wave and
+// tile: 32 KB of W fragments, 8 + 8 KB of X, 8 + 8 KB of messages -- 128 bytes per clock and CU = 1.9 us per round of
+// eight wave-tiles), ~330 VALU instructions per wave-tile (4 clocks each: unpack / select / add / round of the scatter
+// walk 230 of them, accumulator reads and packing 100) and 32 MFMAs; one MFMA k-step instead of eight saves 10 us, no
+// scatter walk 18 - 20 us.
+// BIG: some feature table is 4 GB or more (row offsets need 64 bits: two lane exchanges and 64-bit adds per 16-byte load
+// instead of one exchange and a scalar-base load)
+template <bool BF16, bool CHECK, bool BIG>
 __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const int32_t* __restrict__ tile_start,
                                                         int R, char* __restrict__ out, int64_t out_rows,
-                                                        int* __restrict__ error, int dbg) {  // dbg: 0 in the product
+                                                        int* __restrict__ error, int dbg) {
+  // dbg (0 in the product; PYG_HIP_RGCN_DBG of an experiment build): 1 no atomics, 2 no row gathers, 4 no MFMAs / scatter,
+  // 8 no scatter walk, 16 one MFMA k-step instead of eight
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
@@ -128,11 +159,16 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   char* xs = smem + 32768 + wave * 8192;
 
   // ---- index pipeline -------------------------------------------------------------------------------------------
+  // What a stage needs from its relation's record travels with the tile (scalar registers): the record itself is read
+  // when the walk enters a relation, not per tile (scalar loads + their waits, three stages per tile).
   struct Idx {
     int rel;      // relation of the tile (uniform)
     int nrows;    // edges of this wave in the tile (uniform; 0: nothing to do)
     int64_t g;    // lane l < 32: gather index of edge l -- first level: position in the map / table, second level: row
     int64_t si;   // lane l < 32: output row of edge l
+    const char* x;              // the relation's feature table, its row count, map and offset (uniform)
+    const int64_t* gmap;
+    int64_t goff, x_rows, map_len;
   };
   int walker;  // relation of the tile the first level is at (tiles ascend)
   {
@@ -143,47 +179,66 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     }
     walker = lo;
   }
+  RelDev wrel = rels[walker];
+  int w_first = tile_start[walker], w_next = tile_start[walker + 1];
   auto first_level = [&](int t) -> Idx {
     Idx o;
     o.rel = walker;
     o.nrows = 0;
     o.g = 0;
     o.si = 0;
+    o.x = nullptr;
+    o.gmap = nullptr;
+    o.goff = o.x_rows = o.map_len = 0;
     if (t >= t_end) return o;
-    while (t >= tile_start[walker + 1]) ++walker;
+    while (t >= w_next) {
+      ++walker;
+      wrel = rels[walker];
+      w_first = w_next;
+      w_next = tile_start[walker + 1];
+    }
     o.rel = walker;
-    const RelDev& rel = rels[walker];
-    const int64_t e0 = (int64_t)(t - tile_start[walker]) * 128 + wave * 32;   // first edge of this wave inside the relation
-    const int64_t left = rel.num_edges - e0;
+    o.x = wrel.x;
+    o.gmap = wrel.gather_map;
+    o.goff = wrel.gather_offset;
+    o.x_rows = wrel.x_rows;
+    o.map_len = wrel.map_len;
+    const int64_t e0 = (int64_t)(t - w_first) * 128 + wave * 32;   // first edge of this wave inside the relation
+    const int64_t left = wrel.num_edges - e0;
     o.nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
     if (o.nrows > 0) {  // rows past the end repeat the last valid edge
-      const int64_t e = e0 + (xl < o.nrows ? xl : o.nrows - 1);
-      o.g = ((GI64*)rel.gather_index)[e];
-      o.si = ((GI64*)rel.scatter_index)[e] + rel.scatter_offset;
+      const uint32_t el = (uint32_t)(xl < o.nrows ? xl : o.nrows - 1);
+      o.g = ((GI64*)(wrel.gather_index + e0))[el];
+      o.si = ((GI64*)(wrel.scatter_index + e0))[el] + wrel.scatter_offset;
     }
     return o;
   };
   auto second_level = [&](Idx& io) {
     if (io.nrows == 0) return;
-    const RelDev& rel = rels[io.rel];
-    if (!rel.gather_map) {
-      io.g += rel.gather_offset;
+    if (!io.gmap) {
+      io.g += io.goff;
       return;
     }
-    if (CHECK && (io.g < 0 || io.g >= rel.map_len)) {  // double indirection done here: the gathered feature matrix never exists
+    if (CHECK && (io.g < 0 || io.g >= io.map_len)) {  // double indirection done here: the gathered feature matrix never exists
       *error = 1;
       io.g = 0;
     }
-    io.g = ((GI64*)rel.gather_map)[io.g];
+    io.g = ((GI64*)io.gmap)[io.g];
   };
   // the 32 feature rows of the next tile on their way: lane's chunk i is slot p = 64 i + lane of the stage.  (Two
   // tiles ahead -- a second register set -- was no faster: 82 vs 79 us on the C5 batch; what is left is not latency.)
   u32x4 xr[NI];
+  uint32_t coff[NI];  // byte offset of the lane's chunk of load i inside its row
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = i * 64 + lane;
+    const int r = p >> 4, cs = p & 15;
+    coff[i] = (uint32_t)((cs ^ (r & 15)) * 16);
+  }
   auto issue_rows = [&](Idx& b) {
-    if (b.nrows == 0) return;
-    const RelDev& rel = rels[b.rel];
+    if (b.nrows == 0 || (dbg & 2)) return;  // (dbg: timing ablations of an experiment build, 0 in the product)
     if (CHECK) {
-      if (b.g < 0 || b.g >= rel.x_rows) {
+      if (b.g < 0 || b.g >= b.x_rows) {
         *error = 1;
         b.g = 0;
       }
@@ -192,14 +247,19 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
         b.si = 0;
       }
     }
-    const char* xb = rel.x;
+    if constexpr (BIG) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int p = i * 64 + lane;
-      const int r = p >> 4, cs = p & 15;
-      const int c = cs ^ (r & 15);
-      const int64_t row = __shfl(b.g, r);
-      xr[i] = *(GU32x4*)(xb + row * 256 + c * 16);
+      for (int i = 0; i < NI; ++i) {
+        const int64_t row = __shfl(b.g, 4 * i + (lane >> 4));
+        xr[i] = *(GU32x4*)(b.x + row * 256 + coff[i]);
+      }
+    } else {
+      const int rowb = (int)((uint32_t)b.g << 8);  // < 4 GB tables (checked on the host)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t off = (uint32_t)__shfl(rowb, 4 * i + (lane >> 4)) + coff[i];
+        xr[i] = *(GU32x4*)(b.x + off);
+      }
     }
   };
 
@@ -251,14 +311,10 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     C = Bx;
     Bx = A;
     A = first_level(t + 3);
-    if (nrows == 0) continue;
+    if (nrows == 0 || (dbg & 4)) continue;
     f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < NI; ++s) {
+    for (int s = 0; s < ((dbg & 16) ? 1 : NI); ++s) {
       const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((NI * h + s) ^ (xl & 15))) * 16);
       u32x4 wa[NT];
 #pragma unroll
@@ -268,7 +324,13 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
         wa[t4] = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
-      for (int t4 = 0; t4 < NT; ++t4) acc[t4] = mfma16<BF16>(wa[t4], xa, acc[t4]);
+      for (int t4 = 0; t4 < NT; ++t4) {
+        // (the first step takes the constant 0 as its C operand: no 64 moves to clear the accumulators per tile)
+        f32x16 c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+        acc[t4] = mfma16<BF16>(wa[t4], xa, s == 0 ? c0 : acc[t4]);
+      }
     }
     // messages, rounded to T, into the stage (row xl, 16-byte chunks XOR-swizzled with the row)
 #pragma unroll
@@ -288,32 +350,36 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     // v_readlane, and the 32 values of a lane are read from the stage up front -- the first version compared per row
     // through ds_bpermute under exec masks and waited for every row's LDS read before the next (two LDS round trips per
     // row: ~4 us of a tile's ~9).
+    if (dbg & 8) continue;
     uint32_t ends;
     {
       const int64_t nxt = __shfl_down(si, 1);
       const uint32_t valid = nrows >= 32 ? 0xffffffffu : ((1u << nrows) - 1u);
       ends = ((uint32_t)__ballot(si != nxt) & 0x7fffffffu & valid) | (1u << (nrows - 1));
     }
-    uint32_t mv[32];
+    // Straight-line part: every row's running sum of its run, rounded to T, replaces the row's value (= what a flush at
+    // that row writes); a row that opens a run drops the carried sum through a scalar select.  No branch per row, and the
+    // flush code exists once (a loop over the run ends with a register-indexed read) instead of 32 times.
+    u32x32 mv;
 #pragma unroll
     for (int r = 0; r < 32; ++r) mv[r] = *reinterpret_cast<const uint32_t*>(xs + (r * 16 + (cch ^ (r & 15))) * 16 + cdw * 4);
     float s0 = 0.f, s1 = 0.f;
-    const int si_lo = (int)(uint32_t)si, si_hi = (int)(uint32_t)((uint64_t)si >> 32);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-      if (r < nrows) {  // (rows behind the end repeat the last edge: not summed)
-        float a, b;
-        unpack2<BF16>(mv[r], &a, &b);
-        s0 += a;
-        s1 += b;
-        if ((ends >> r) & 1u) {  // wave-uniform: row r closes a run
-          const int64_t d = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(si_hi, r) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readlane(si_lo, r));
-          if (!(dbg & 1)) atomic_add_pk<BF16>(out + d * 256 + lane * 4, s0, s1);
-          s0 = 0.f;
-          s1 = 0.f;
-        }
-      }
+      const uint32_t keep = (r == 0 || ((ends >> (r - 1)) & 1u)) ? 0u : 0xffffffffu;  // wave-uniform
+      float a, b;
+      unpack2<BF16>(mv[r], &a, &b);
+      s0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s0) & keep) + a;
+      s1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s1) & keep) + b;
+      mv[r] = pack2<BF16>(s0, s1);
+    }
+    // flushes: one per run end (bits of `ends`: rows behind the tile's last edge have none)
+    const int si_lo = (int)(uint32_t)si, si_hi = (int)(uint32_t)((uint64_t)si >> 32);
+    for (uint32_t m = ends; m != 0; m &= m - 1) {
+      const int r = __builtin_ctz(m);
+      const int64_t d = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(si_hi, r) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane(si_lo, r));
+      if (!(dbg & 1)) atomic_add_pk_bits<BF16>(out + d * 256 + (uint32_t)(lane * 4), mv[r]);
     }
   }
 }
@@ -395,8 +461,18 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
   if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
-  const void* kern = dtype == PYG_BF16 ? (checked ? (const void*)&rgcn_fused_kernel<true, true> : (const void*)&rgcn_fused_kernel<true, false>)
-                                       : (checked ? (const void*)&rgcn_fused_kernel<false, true> : (const void*)&rgcn_fused_kernel<false, false>);
+  bool big = false;  // a feature table of 4 GB or more: 64-bit row offsets
+  for (int64_t r = 0; r < R; ++r) big = big || hr[r].x_rows >= (1LL << 24);
+  const void* kern;
+  {
+#define PYG_RGCN_PICK(BF, CK, BG) ((const void*)&rgcn_fused_kernel<BF, CK, BG>)
+    const bool bf = dtype == PYG_BF16, ck = checked != 0;
+    kern = bf ? (ck ? (big ? PYG_RGCN_PICK(true, true, true) : PYG_RGCN_PICK(true, true, false))
+                    : (big ? PYG_RGCN_PICK(true, false, true) : PYG_RGCN_PICK(true, false, false)))
+              : (ck ? (big ? PYG_RGCN_PICK(false, true, true) : PYG_RGCN_PICK(false, true, false))
+                    : (big ? PYG_RGCN_PICK(false, false, true) : PYG_RGCN_PICK(false, false, false)));
+#undef PYG_RGCN_PICK
+  }
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   // persistent grid: two workgroups per CU (64 KB of LDS each), every one a contiguous range of >= 2 tiles
   int64_t per_cu = 2;

@@ -172,6 +172,48 @@ def test_fused_rgcn_integer_valued_inputs_are_exact():
     assert torch.equal(y.double().cpu(), want)
 
 
+def test_fused_rgcn_feature_table_of_more_than_4_gib():
+    """Row offsets need 64 bits once a feature table reaches 4 GiB (2^24 rows of 256 bytes): the kernel is instantiated
+    for both widths (rgcn.hip, BIG).  Rows on either side of the 4 GiB line are gathered -- directly and through a node-id
+    map -- from a table that is only initialised where it is read; integer data, exact result."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(9)
+    F = 128
+    n_big = (1 << 24) + 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n_big * F * 2:
+        pytest.skip('not enough device memory for a 4 GiB table')
+    picks = torch.cat([1 + 50_000 * torch.randperm(300, generator=g), (1 << 24) + 1 + torch.randperm(4000, generator=g)[:300],
+                       torch.tensor([0, (1 << 24) - 1, 1 << 24, n_big - 1])])  # distinct rows on both sides of 4 GiB
+    assert picks.unique().numel() == picks.numel()
+    table = torch.empty(n_big, F, dtype=torch.bfloat16, device='cuda')
+    vals = torch.randint(-4, 5, (picks.numel(), F), generator=g).float()
+    table[picks.cuda()] = vals.bfloat16().cuda()
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'a')]
+    counts = [5000, 77]
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in ets])
+    W = torch.zeros(len(ets), F, F)
+    W[torch.arange(len(ets))[:, None], perm, torch.arange(F)[None, :]] = (torch.randint(0, 2, (len(ets), F), generator=g) * 2 - 1).float()
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        rows[et] = torch.sort(torch.randint(0, 40, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, picks.numel(), (c,), generator=g).cuda()
+    # (a) through the node-id map: local node i is global row picks[i]
+    y = rgcn.rgcn_layer_fused_tables({'a': table}, {'a': picks.cuda()}, ['a'], rows, cols, ets, W.bfloat16().cuda())
+    want = torch.zeros(picks.numel(), F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), vals[cols[et].cpu()].double() @ W[i].double())
+    assert want.abs().max() <= 256
+    assert torch.equal(y.double().cpu(), want)
+    # (b) directly: x is the big table itself, the gather index the global row
+    off = rgcn.type_offsets({'a': n_big}, ['a'])
+    cols_g = {et: picks.cuda()[cols[et]] for et in ets}
+    y2 = rgcn.rgcn_layer_fused(table, off, rows, cols_g, ets, W.bfloat16().cuda())
+    assert y2.shape == (n_big, F)
+    assert torch.equal(y2[:picks.numel()].double().cpu(), want)
+    del table, y2
+
+
 def test_fused_rgcn_falls_back_for_other_shapes():
     from pyg_lib_amd import rgcn
     ets = [('a', 'x', 'a')]
