@@ -130,8 +130,8 @@ typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 //     tile t     : rows -> LDS stage (the XOR-swizzled layout of the segment_matmul kernels), MFMAs, scatter
 // and pays the round trips once per workgroup instead of three per tile.  (The first version issued one tile at a time by
 // LDS-DMA: 51 % of a wave's time waiting for rows, 30 % for indices; phase clocks of an experiment build.)
-// Where the time goes now (C5 batch, 565 k edges, ablations of an experiment build through `dbg`; us incl. ~8 us of
-// launch + binding): everything 59; no atomics 53; no row gathers (compute on stale registers) 46 - 49; gathers and
+// Where the time goes now (C5 batch, 565 k edges, ablations of an experiment build through `dbg`; operator us, the
+// kernel alone is 57.6 under rocprofv3): everything 59; no atomics 53; no row gathers (compute on stale registers) 46 - 49; gathers and
 // indices only 33; indices only 15.  The compute side is the larger one and is made of LDS traffic (64 KB per wave and
 // tile: 32 KB of W fragments, 8 + 8 KB of X, 8 + 8 KB of messages -- 128 bytes per clock and CU = 1.9 us per round of
 // eight wave-tiles), ~330 VALU instructions per wave-tile (4 clocks each: unpack / select / add / round of the scatter
