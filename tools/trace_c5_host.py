@@ -1,7 +1,7 @@
-"""Host-side timeline of C5 hetero sampler calls (PYG_HIP_SAMPLER_TRACE=1) next to the wall time per call, and the cost of the
-op's Dict marshalling alone (the same call with every fan-out 0: no sampling work)."""
+"""C5 hetero sampler: wall time per call of (a) the Python front (lists through pyg::hetero_neighbor_sample_flat), (b) the
+reference-schema operator with Dict arguments, (c) the flat operator with prebuilt arguments; PYG_HIP_SAMPLER_TRACE=1
+(set it in the environment) adds the library's own host timeline."""
 import os, sys, time, torch
-os.environ['PYG_HIP_SAMPLER_TRACE'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench_legs
 from pyg_lib_amd import sampler
@@ -10,10 +10,34 @@ rp, cl = bench_legs.make_mag_graph(dev)
 ets = [(s, r, d) for s, r, d, _ in bench_legs.MAG_RELS]
 fan = {e: [15, 10] for e in ets}
 g = torch.Generator().manual_seed(1)
-for b in range(10):
-    seeds = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=g)[:1024].to(dev)
+seeds = [torch.randperm(bench_legs.MAG_SIZES['paper'], generator=g)[:1024].to(dev) for _ in range(40)]
+nt = sorted({t for e in ets for t in (e[0], e[-1])})
+rel = sampler._to_rel_keys
+
+
+def front(s):
+    return sampler.hetero_neighbor_sample(rp, cl, {'paper': s}, fan)
+
+
+def dict_op(s):
+    return torch.ops.pyg.hetero_neighbor_sample(nt, ets, rel(rp), rel(cl), {'paper': s}, rel(fan), None, None, None, None, False,
+                                                False, True, False, 'uniform', True)
+
+
+rps, cls, fl = [rp[e] for e in ets], [cl[e] for e in ets], [c for e in ets for c in fan[e]]
+
+
+def flat_op(s):
+    return torch.ops.pyg.hetero_neighbor_sample_flat(nt, ets, rps, cls, ['paper'], [s], fl, None, None, None, None, False, False,
+                                                     True, False, 'uniform', True)
+
+
+for name, fn in (('front', front), ('dict op', dict_op), ('flat op', flat_op), ('front', front), ('dict op', dict_op)):
+    for s in seeds[:8]:
+        fn(s)
     torch.cuda.synchronize()
     t = time.perf_counter()
-    out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds}, fan)
+    for s in seeds[8:]:
+        fn(s)
     torch.cuda.synchronize()
-    print('call %d wall %.0f us' % (b, (time.perf_counter() - t) * 1e6), file=sys.stderr)
+    print('%-8s %.1f us per call' % (name, (time.perf_counter() - t) / 32 * 1e6), flush=True)
