@@ -1,6 +1,5 @@
-"""C5 hetero sampler: wall time per call of (a) the Python front (lists through pyg::hetero_neighbor_sample_flat), (b) the
-reference-schema operator with Dict arguments, (c) the flat operator with prebuilt arguments; PYG_HIP_SAMPLER_TRACE=1
-(set it in the environment) adds the library's own host timeline."""
+"""C5 hetero sampler: wall time per call of (a) the Python front, (b) the operator with prebuilt Dict arguments;
+PYG_HIP_SAMPLER_TRACE=1 (set it in the environment) adds the library's own host timeline."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench_legs
@@ -24,15 +23,7 @@ def dict_op(s):
                                                 False, True, False, 'uniform', True)
 
 
-rps, cls, fl = [rp[e] for e in ets], [cl[e] for e in ets], [c for e in ets for c in fan[e]]
-
-
-def flat_op(s):
-    return torch.ops.pyg.hetero_neighbor_sample_flat(nt, ets, rps, cls, ['paper'], [s], fl, None, None, None, None, False, False,
-                                                     True, False, 'uniform', True)
-
-
-for name, fn in (('front', front), ('dict op', dict_op), ('flat op', flat_op), ('front', front), ('dict op', dict_op)):
+for name, fn in (('front', front), ('dict op', dict_op), ('front', front), ('dict op', dict_op)):
     for s in seeds[:8]:
         fn(s)
     torch.cuda.synchronize()
