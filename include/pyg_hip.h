@@ -352,7 +352,8 @@ typedef struct {
  * missing host->mt19937 fail with PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
-/* Driver the calling thread's last neighbor / hetero sampler call ran: "fused" (bounded fan-outs: 3 launches per hop,
+/* Driver the calling thread's last neighbor / hetero sampler call ran: "fused" (bounded fan-outs: 2 - 3 launches per hop
+ * -- scans of up to 256 tiles are one launch, PYG_HIP_SAMPLER_ONEPASS=0: always a reduce + apply pair --,
  * csrc/hip/sampler_fused.h), "queued" (round 2's chain: PYG_HIP_SAMPLER_FUSED=0 or more than 4 relations expanding one
  * node type), "synchronising" (unbounded / > 64 fan-outs, weighted relations, a hub that needed a word top-up, or
  * PYG_HIP_SAMPLER_SYNC_MODE=1).  Diagnostics only; every driver returns the same bits. */
