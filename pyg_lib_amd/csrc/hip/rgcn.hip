@@ -164,11 +164,10 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   struct Idx {
     int rel;      // relation of the tile (uniform)
     int nrows;    // edges of this wave in the tile (uniform; 0: nothing to do)
-    int64_t g;    // lane l < 32: gather index of edge l -- first level: position in the map / table, second level: row
-    int64_t si;   // lane l < 32: output row of edge l
+    int64_t si;   // lane l < 32: output row of edge l (set once its load has landed)
     const char* x;              // the relation's feature table, its row count, map and offset (uniform)
     const int64_t* gmap;
-    int64_t goff, x_rows, map_len;
+    int64_t goff, x_rows, map_len, soff;  // (soff: added to the loaded scatter index where it is consumed)
   };
   int walker;  // relation of the tile the first level is at (tiles ascend)
   {
@@ -181,16 +180,21 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   }
   RelDev wrel = rels[walker];
   int w_first = tile_start[walker], w_next = tile_start[walker + 1];
-  auto first_level = [&](int t) -> Idx {
-    Idx o;
+  // first level of tile t: the tile's scalars into `o`, the two index loads into g1 / s1 (lane l < 32: gather index and
+  // output row of edge l).  What a load returns is NOT touched before the top of the next iteration (see the loop): the
+  // compiler orders a use behind everything issued before it (vmcnt counts in order and it cannot see across the loop's
+  // branches how many loads are younger), so a use in mid-iteration waits for the row gathers issued a moment earlier
+  // -- which is what the first version of this pipeline did: 56 % of the wave cycles waiting (SQ_WAIT_ANY).
+  auto first_level = [&](int t, Idx& o, int64_t& g1, int64_t& s1) {
     o.rel = walker;
     o.nrows = 0;
-    o.g = 0;
     o.si = 0;
     o.x = nullptr;
     o.gmap = nullptr;
-    o.goff = o.x_rows = o.map_len = 0;
-    if (t >= t_end) return o;
+    o.goff = o.x_rows = o.map_len = o.soff = 0;
+    g1 = 0;
+    s1 = 0;
+    if (t >= t_end) return;
     while (t >= w_next) {
       ++walker;
       wrel = rels[walker];
@@ -203,27 +207,25 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     o.goff = wrel.gather_offset;
     o.x_rows = wrel.x_rows;
     o.map_len = wrel.map_len;
+    o.soff = wrel.scatter_offset;
     const int64_t e0 = (int64_t)(t - w_first) * 128 + wave * 32;   // first edge of this wave inside the relation
     const int64_t left = wrel.num_edges - e0;
     o.nrows = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
     if (o.nrows > 0) {  // rows past the end repeat the last valid edge
       const uint32_t el = (uint32_t)(xl < o.nrows ? xl : o.nrows - 1);
-      o.g = ((GI64*)(wrel.gather_index + e0))[el];
-      o.si = ((GI64*)(wrel.scatter_index + e0))[el] + wrel.scatter_offset;
+      g1 = ((GI64*)(wrel.gather_index + e0))[el];
+      s1 = ((GI64*)(wrel.scatter_index + e0))[el];
     }
-    return o;
   };
-  auto second_level = [&](Idx& io) {
-    if (io.nrows == 0) return;
-    if (!io.gmap) {
-      io.g += io.goff;
-      return;
-    }
-    if (CHECK && (io.g < 0 || io.g >= io.map_len)) {  // double indirection done here: the gathered feature matrix never exists
+  // second level: the feature row of the lane's edge -- g1 + offset, or (a load) gather_map[g1]
+  auto second_level = [&](const Idx& io, int64_t g1) -> int64_t {
+    if (io.nrows == 0) return 0;
+    if (!io.gmap) return g1 + io.goff;
+    if (CHECK && (g1 < 0 || g1 >= io.map_len)) {  // double indirection done here: the gathered feature matrix never exists
       *error = 1;
-      io.g = 0;
+      g1 = 0;
     }
-    io.g = ((GI64*)io.gmap)[io.g];
+    return ((GI64*)io.gmap)[g1];
   };
   // the 32 feature rows of the next tile on their way: lane's chunk i is slot p = 64 i + lane of the stage.  (Two
   // tiles ahead -- a second register set -- was no faster: 82 vs 79 us on the C5 batch; what is left is not latency.)
@@ -235,12 +237,12 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     const int r = p >> 4, cs = p & 15;
     coff[i] = (uint32_t)((cs ^ (r & 15)) * 16);
   }
-  auto issue_rows = [&](Idx& b) {
+  auto issue_rows = [&](Idx& b, int64_t g2) {
     if (b.nrows == 0 || (dbg & 2)) return;  // (dbg: timing ablations of an experiment build, 0 in the product)
     if (CHECK) {
-      if (b.g < 0 || b.g >= b.x_rows) {
+      if (g2 < 0 || g2 >= b.x_rows) {
         *error = 1;
-        b.g = 0;
+        g2 = 0;
       }
       if (b.si < 0 || b.si >= out_rows) {
         *error = 2;
@@ -250,11 +252,11 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     if constexpr (BIG) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int64_t row = __shfl(b.g, 4 * i + (lane >> 4));
+        const int64_t row = __shfl(g2, 4 * i + (lane >> 4));
         xr[i] = *(GU32x4*)(b.x + row * 256 + coff[i]);
       }
     } else {
-      const int rowb = (int)((uint32_t)b.g << 8);  // < 4 GB tables (checked on the host)
+      const int rowb = (int)((uint32_t)g2 << 8);  // < 4 GB tables (checked on the host)
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const uint32_t off = (uint32_t)__shfl(rowb, 4 * i + (lane >> 4)) + coff[i];
@@ -279,12 +281,19 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   // prologue: W of the first relation and the three index chains of tiles t, t + 1, t + 2 are requested together
   int w_rel = walker;
   load_w(w_rel);
-  Idx C = first_level(t_beg);
-  Idx Bx = first_level(t_beg + 1);
-  Idx A = first_level(t_beg + 2);
-  second_level(C);
-  second_level(Bx);
-  issue_rows(C);
+  Idx C, Bx, A;
+  int64_t pend_g2, pend_g1, pend_si;  // in flight across an iteration: row index of Bx's edges, first level of A
+  {
+    int64_t g1c, g1b, sc, sb;
+    first_level(t_beg, C, g1c, sc);
+    first_level(t_beg + 1, Bx, g1b, sb);
+    first_level(t_beg + 2, A, pend_g1, pend_si);
+    C.si = sc + C.soff;
+    Bx.si = sb + Bx.soff;
+    const int64_t g2c = second_level(C, g1c);
+    pend_g2 = second_level(Bx, g1b);
+    issue_rows(C, g2c);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
   __syncthreads();
 
@@ -305,12 +314,18 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
 #pragma unroll
       for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(xs + (i * 64 + lane) * 16) = xr[i];
     }
-    // advance the pipeline: rows of t + 1, second level of t + 2, first level of t + 3
-    issue_rows(Bx);
-    second_level(A);
+    // advance the pipeline.  Everything outstanding here was issued an iteration ago: FIRST every use of it (the rows
+    // above, the row index of tile t + 1, the first level of t + 2), THEN this iteration's loads -- second level of
+    // t + 2, first level of t + 3, rows of t + 1 -- whose results rest until the next iteration's top.
+    const int64_t g2b = pend_g2;
+    A.si = pend_si + A.soff;
+    pend_g2 = second_level(A, pend_g1);
+    Idx Nx;
+    first_level(t + 3, Nx, pend_g1, pend_si);
+    issue_rows(Bx, g2b);
     C = Bx;
     Bx = A;
-    A = first_level(t + 3);
+    A = Nx;
     if (nrows == 0 || (dbg & 4)) continue;
     f32x16 acc[NT];
 #pragma unroll
