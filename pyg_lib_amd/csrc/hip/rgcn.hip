@@ -27,6 +27,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -139,10 +140,29 @@ typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 // scatter walk 18 - 20 us.
 // BIG: some feature table is 4 GB or more (row offsets need 64 bits: two lane exchanges and 64-bit adds per 16-byte load
 // instead of one exchange and a scalar-base load)
-template <bool BF16, bool CHECK, bool BIG>
-__global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restrict__ rels, const int32_t* __restrict__ tile_start,
-                                                        int R, char* __restrict__ out, int64_t out_rows,
+// The relation records and the tile prefix of a call.  Up to kRgcnInline relations travel IN THE KERNEL ARGUMENT (INL):
+// staging them through pinned memory put a host-to-device copy (a 4 us blit kernel + 6 us of gap on the stream) in front
+// of every launch of a 50 us kernel; longer lists are copied to the workspace as before.
+constexpr int kRgcnInline = 24;
+struct RgcnDesc {
+  const RelDev* rels;
+  const int32_t* tile_start;
+  RelDev irels[kRgcnInline];
+  int32_t itile[kRgcnInline + 1];
+};
+static_assert(sizeof(RgcnDesc) <= 3072, "kernel argument");
+
+template <bool BF16, bool CHECK, bool BIG, bool INL>
+__global__ __launch_bounds__(256) void rgcn_fused_kernel(const RgcnDesc desc, int R, char* __restrict__ out, int64_t out_rows,
                                                         int* __restrict__ error, int dbg) {
+  auto tile_at = [&](int i) -> int {
+    if constexpr (INL) return desc.itile[i];
+    else return desc.tile_start[i];
+  };
+  auto rel_at = [&](int i) -> RelDev {
+    if constexpr (INL) return desc.irels[i];
+    else return desc.rels[i];
+  };
   // dbg (0 in the product; PYG_HIP_RGCN_DBG of an experiment build): 1 no atomics, 2 no row gathers, 4 no MFMAs / scatter,
   // 8 no scatter walk, 16 one MFMA k-step instead of eight
   constexpr int NT = 4, NI = 8;
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   // (through readfirstlane: the compiler then knows that a tile's row count, relation and run structure are wave-uniform
   // and keeps them -- and the branches on them -- on the scalar unit)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int total = tile_start[R];
+  const int total = tile_at(R);
   const int G = (int)gridDim.x;
   const int t_beg = (int)((int64_t)blockIdx.x * total / G);
   const int t_end = (int)((int64_t)(blockIdx.x + 1) * total / G);
@@ -174,12 +194,12 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     int lo = 0, hi = R;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (tile_start[mid] <= t_beg) lo = mid; else hi = mid;
+      if (tile_at(mid) <= t_beg) lo = mid; else hi = mid;
     }
     walker = lo;
   }
-  RelDev wrel = rels[walker];
-  int w_first = tile_start[walker], w_next = tile_start[walker + 1];
+  RelDev wrel = rel_at(walker);
+  int w_first = tile_at(walker), w_next = tile_at(walker + 1);
   // first level of tile t: the tile's scalars into `o`, the two index loads into g1 / s1 (lane l < 32: gather index and
   // output row of edge l).  What a load returns is NOT touched before the top of the next iteration (see the loop): the
   // compiler orders a use behind everything issued before it (vmcnt counts in order and it cannot see across the loop's
@@ -197,9 +217,9 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
     if (t >= t_end) return;
     while (t >= w_next) {
       ++walker;
-      wrel = rels[walker];
+      wrel = rel_at(walker);
       w_first = w_next;
-      w_next = tile_start[walker + 1];
+      w_next = tile_at(walker + 1);
     }
     o.rel = walker;
     o.x = wrel.x;
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RelDev* __restric
   auto load_w = [&](int g) {
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
-    const char* wsrc = rels[g].weight + dma_r * 256 + dma_c * 16;
+    const char* wsrc = rel_at(g).weight + dma_r * 256 + dma_c * 16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kb = wave * 8 + j;
@@ -446,12 +466,20 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
                 pyg_hip_rgcn_fused_workspace_size(R, E), workspace_bytes);
   const size_t rel_b = align_up(sizeof(RelDev) * (size_t)R, 256);
   const size_t tile_b = align_up(sizeof(int32_t) * (size_t)(R + 1), 256);
-  void* staged = nullptr;
-  int rc = pinned_stage().acquire(rel_b + tile_b, &staged);
-  if (rc != PYG_HIP_OK) return rc;
-  RelDev* hr = static_cast<RelDev*>(staged);
-  int32_t* ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + rel_b);
+  const bool inl = R <= kRgcnInline;
+  RgcnDesc desc;
+  ::memset(&desc, 0, sizeof(desc));
+  RelDev* hr = desc.irels;
+  int32_t* ht = desc.itile;
+  if (!inl) {
+    void* staged = nullptr;
+    int rc = pinned_stage().acquire(rel_b + tile_b, &staged);
+    if (rc != PYG_HIP_OK) return rc;
+    hr = static_cast<RelDev*>(staged);
+    ht = reinterpret_cast<int32_t*>(static_cast<char*>(staged) + rel_b);
+  }
   int64_t t = 0;
+  bool big = false;  // a feature table of 4 GB or more: 64-bit row offsets
   for (int64_t r = 0; r < R; ++r) {
     hr[r].gather_index = rels[r].gather_index;
     hr[r].scatter_index = rels[r].scatter_index;
@@ -463,30 +491,33 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     hr[r].gather_map = rels[r].gather_map;
     hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
     hr[r].map_len = rels[r].gather_map_len;
+    big = big || hr[r].x_rows >= (1LL << 24);
     ht[r] = (int32_t)t;
     t += (rels[r].num_edges + 127) / 128;
   }
   ht[R] = (int32_t)t;
   char* w = static_cast<char*>(workspace);
-  PYG_HIP_CHECK(hipMemcpyAsync(w, staged, rel_b + tile_b, hipMemcpyHostToDevice, stream));
-  rc = pinned_stage().commit(stream);
-  if (rc != PYG_HIP_OK) return rc;
-  const RelDev* drel = reinterpret_cast<const RelDev*>(w);
-  const int32_t* dtile = reinterpret_cast<const int32_t*>(w + rel_b);
+  if (!inl) {
+    PYG_HIP_CHECK(hipMemcpyAsync(w, hr, rel_b + tile_b, hipMemcpyHostToDevice, stream));
+    int rc = pinned_stage().commit(stream);
+    if (rc != PYG_HIP_OK) return rc;
+    desc.rels = reinterpret_cast<const RelDev*>(w);
+    desc.tile_start = reinterpret_cast<const int32_t*>(w + rel_b);
+  }
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
   if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
-  bool big = false;  // a feature table of 4 GB or more: 64-bit row offsets
-  for (int64_t r = 0; r < R; ++r) big = big || hr[r].x_rows >= (1LL << 24);
   const void* kern;
   {
-#define PYG_RGCN_PICK(BF, CK, BG) ((const void*)&rgcn_fused_kernel<BF, CK, BG>)
+#define PYG_RGCN_PICK3(BF, CK, BG) (inl ? (const void*)&rgcn_fused_kernel<BF, CK, BG, true> : (const void*)&rgcn_fused_kernel<BF, CK, BG, false>)
+#define PYG_RGCN_PICK(BF, CK, BG) PYG_RGCN_PICK3(BF, CK, BG)
     const bool bf = dtype == PYG_BF16, ck = checked != 0;
     kern = bf ? (ck ? (big ? PYG_RGCN_PICK(true, true, true) : PYG_RGCN_PICK(true, true, false))
                     : (big ? PYG_RGCN_PICK(true, false, true) : PYG_RGCN_PICK(true, false, false)))
               : (ck ? (big ? PYG_RGCN_PICK(false, true, true) : PYG_RGCN_PICK(false, true, false))
                     : (big ? PYG_RGCN_PICK(false, false, true) : PYG_RGCN_PICK(false, false, false)));
 #undef PYG_RGCN_PICK
+#undef PYG_RGCN_PICK3
   }
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   // persistent grid: two workgroups per CU (64 KB of LDS each), every one a contiguous range of >= 2 tiles
@@ -501,7 +532,7 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((tiles + min_tiles - 1) / min_tiles, per_cu * (int64_t)device_info().num_cus));
   char* outc = static_cast<char*>(out);
   int Ri = (int)R;
-  void* args[] = {(void*)&drel, (void*)&dtile, (void*)&Ri, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev, (void*)&dbg};
+  void* args[] = {(void*)&desc, (void*)&Ri, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev, (void*)&dbg};
   PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, stream));
   if (checked) {  // checked mode synchronises: the caller asked for a verdict
     int host_err = 0;

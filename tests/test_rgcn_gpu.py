@@ -172,6 +172,34 @@ def test_fused_rgcn_integer_valued_inputs_are_exact():
     assert torch.equal(y.double().cpu(), want)
 
 
+def test_fused_rgcn_more_relations_than_the_kernel_argument_holds():
+    """Up to 24 relation records travel in the kernel argument; longer lists are staged in the workspace (rgcn.hip,
+    RgcnDesc).  30 relations (some empty, some shorter than a wave's 32 edges), integer data, exact result."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(13)
+    n, F, R = 900, 128, 30
+    x = torch.randint(-3, 4, (n, F), generator=g).float()
+    counts = [int(c) for c in torch.randint(0, 700, (R,), generator=g)]
+    counts[3] = 0
+    counts[7] = 5
+    counts[29] = 1300
+    ets = [('a', f'r{i}', 'a') for i in range(R)]
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in range(R)])
+    W = torch.zeros(R, F, F)
+    W[torch.arange(R)[:, None], perm, torch.arange(F)[None, :]] = (torch.randint(0, 2, (R, F), generator=g) * 2 - 1).float()
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        rows[et] = torch.sort(torch.randint(0, 50, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    y = rgcn.rgcn_layer_fused(x.bfloat16().cuda(), off, rows, cols, ets, W.bfloat16().cuda())
+    want = torch.zeros(n, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), x[cols[et].cpu()].double() @ W[i].double())
+    assert want.abs().max() <= 256
+    assert torch.equal(y.double().cpu(), want)
+
+
 def test_fused_rgcn_feature_table_of_more_than_4_gib():
     """Row offsets need 64 bits once a feature table reaches 4 GiB (2^24 rows of 256 bytes): the kernel is instantiated
     for both widths (rgcn.hip, BIG).  Rows on either side of the 4 GiB line are gathered -- directly and through a node-id

@@ -45,7 +45,7 @@ args = ([feat[t] for t in types], [out[2][t] for t in types], [tidx[e[2]] for e 
         [out[0][e] for e in ets], [off[e[0]] for e in ets], W)
 for wgs in ('2',):
     for mt in ('2',):
-        for dbg in ('0', '2', '10', '18', '26'):  # +8 no scatter walk, +16 one MFMA step instead of eight  # 1 no atomics, 2 no row gathers, 4 no MFMAs / scatter, 6 indices only
+        for dbg in ('0', '1', '2', '8'):  # 1 no atomics, 2 no row gathers, 8 no scatter walk
             os.environ['PYG_HIP_RGCN_WGS'] = wgs
             os.environ['PYG_HIP_RGCN_MIN_TILES'] = mt
             os.environ['PYG_HIP_RGCN_DBG'] = dbg
