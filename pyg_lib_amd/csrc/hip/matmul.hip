@@ -61,30 +61,48 @@ __global__ void plan_segments_kernel(const int64_t* __restrict__ ptr, int64_t B,
     tiles2 += (r + 2 * kTileRows - 1) / (2 * kTileRows);
     tiles3 += (r + kPairRows - 1) / kPairRows;
   }
-  s_tiles[tid] = tiles;
-  s_tiles2[tid] = tiles2;
-  s_tiles3[tid] = tiles3;
-  s_rows[tid] = rows;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t t = 0, t2 = 0, t3 = 0, r = 0;
-    for (int i = 0; i < nthr; ++i) {
-      int64_t tt = s_tiles[i], tt2 = s_tiles2[i], tt3 = s_tiles3[i], rr = s_rows[i];
-      s_tiles[i] = t;
-      s_tiles2[i] = t2;
-      s_tiles3[i] = t3;
-      s_rows[i] = r;
-      t += tt;
-      t2 += tt2;
-      t3 += tt3;
-      r += rr;
+  // exclusive scan of the four per-thread sums over the block: wave shuffles + the wave totals through LDS (a serial
+  // walk of thread 0 over 256 LDS entries made this kernel 15 us in front of every segment_matmul call)
+  {
+    const int lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+    int64_t v[4] = {tiles, tiles2, tiles3, rows};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lo = __shfl_up((int)(uint32_t)v[q], d), hi = __shfl_up((int)(uint32_t)((uint64_t)v[q] >> 32), d);
+        if (lane >= d) v[q] += (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+      }
     }
-    tile_start[B] = (int32_t)t;
-    tile_start2[B] = (int32_t)t2;
-    tile_start3[B] = (int32_t)t3;
-    row_start[B] = r;
+    if (lane == 63) {  // wave totals (inclusive value of the last lane)
+      s_tiles[wv] = v[0];
+      s_tiles2[wv] = v[1];
+      s_tiles3[wv] = v[2];
+      s_rows[wv] = v[3];
+    }
+    __syncthreads();
+    int64_t base[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nw; ++i) {
+      const int64_t w4[4] = {s_tiles[i], s_tiles2[i], s_tiles3[i], s_rows[i]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i < wv) base[q] += w4[q];
+        all[q] += w4[q];
+      }
+    }
+    __syncthreads();
+    // exclusive prefix of this thread = waves in front + inclusive value - own sum
+    s_tiles[tid] = base[0] + v[0] - tiles;
+    s_tiles2[tid] = base[1] + v[1] - tiles2;
+    s_tiles3[tid] = base[2] + v[2] - tiles3;
+    s_rows[tid] = base[3] + v[3] - rows;
+    if (tid == 0) {
+      tile_start[B] = (int32_t)all[0];
+      tile_start2[B] = (int32_t)all[1];
+      tile_start3[B] = (int32_t)all[2];
+      row_start[B] = all[3];
+    }
   }
-  __syncthreads();
   int64_t t = s_tiles[tid], t2 = s_tiles2[tid], t3 = s_tiles3[tid], rs = s_rows[tid];
   for (int64_t b = beg; b < end; ++b) {
     const int64_t p0 = ptr[b];
