@@ -79,6 +79,7 @@ struct FTables {
   int64_t word0;      // engine position at the start of the call
   int units0;
   int L, R, T;
+  int is32;           // some relation's rowptr / col are int32 (a call's relations share the index type)
 };
 
 struct FConsumer {  // a relation of the NEXT hop that expands the segment's node type
@@ -252,20 +253,31 @@ __device__ __forceinline__ int64_t part_count(const FScanLaunch& L, const FPart&
 template <int NC>
 struct FCons {
   FConsumer c[NC > 0 ? NC : 1];
+  // I64: the call's graphs are int64 -- said to the compiler by overwriting the (then known to be 0) width flags of the
+  // local copies.  IdxArr::operator[] otherwise is a branch per access whose 32-bit arm converts what it loaded right
+  // away, i.e. waits for it: the 24 row-bound gathers of a 3-consumer scan ran one after the other (47 -> 24 us was the
+  // scratch copy, the rest of the distance to the 1-consumer scan's 14 us was this).
+  template <bool I64>
   __device__ __forceinline__ void load(const FScanLaunch& L, int first) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) c[i] = L.cons[first + i];
+    for (int i = 0; i < NC; ++i) {
+      c[i] = L.cons[first + i];
+      if constexpr (I64) {
+        c[i].range.rowptr.is32 = 0;
+        c[i].range.col.is32 = 0;
+      }
+    }
   }
 };
 
 // ---- reduce: tile aggregates of (first-occurrence flag, next-hop counts) -----------------------------------------
-template <int NC>
+template <int NC, bool I64>
 __device__ __forceinline__ void fused_reduce(const FScanLaunch& L, const FPart& pt, int lt) {
   typedef FusedAgg<NC> T;
   typedef FusedOp<NC> Op;
   __shared__ T lds[8];
   FCons<NC> cons;
-  cons.load(L, pt.cons0);
+  cons.template load<I64>(L, pt.cons0);
   const int64_t n = part_count(L, pt);
   const int64_t base = (int64_t)lt * kScanTile + threadIdx.x * kScanItems;
   Op op;
@@ -331,13 +343,13 @@ __device__ __forceinline__ void fused_reduce(const FScanLaunch& L, const FPart& 
 }
 
 // ---- apply: ids, node-list append, the next hop's per-node prefixes; the segment's last block publishes its totals
-template <int NC>
+template <int NC, bool I64>
 __device__ __forceinline__ void fused_apply(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
   typedef FusedAgg<NC> T;
   typedef FusedOp<NC> Op;
   __shared__ T lds[8];
   FCons<NC> cons;
-  cons.load(L, pt.cons0);
+  cons.template load<I64>(L, pt.cons0);
   const int64_t n = part_count(L, pt);
   const int64_t size0 = pt.h.seeds ? 0 : *pt.h.size_in;
   const int64_t id0 = pt.h.seeds ? 0 : size0 - *pt.h.dup;
@@ -443,13 +455,13 @@ __device__ __forceinline__ void fused_tables_init(const FTables& tb, int i) {
   if (i == 0) *tb.wide = 0;
 }
 
-template <int NC, bool FOLD>
+template <int NC, bool FOLD, bool I64>
 __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
   typedef FusedAgg<NC> T;
   typedef FusedOp<NC> Op;
   __shared__ T lds[8];
   FCons<NC> cons;
-  cons.load(L, pt.cons0);
+  cons.template load<I64>(L, pt.cons0);
   const int tid = (int)threadIdx.x;
   const int64_t n = FOLD ? pt.n_fixed : part_count(L, pt);
   const int64_t base = (int64_t)lt * kScanTile + tid * kScanItems;
@@ -684,7 +696,7 @@ __device__ __forceinline__ FResolved fused_resolve(const FTables& tb, int ell, i
   return uniform_record(&r);
 }
 
-template <int G>
+template <int G, bool I64>
 __device__ __forceinline__ void fused_sample(const FSampleLaunch& L, const FSampleRec& rec, int blk, int64_t avail_blocks,
                                              const u64* words) {
   const FResolved r = fused_resolve(L.tb, rec.ell, rec.e, rec.t_src, avail_blocks, blk == 0);
@@ -697,6 +709,11 @@ __device__ __forceinline__ void fused_sample(const FSampleLaunch& L, const FSamp
   a.frontier = r.frontier;
   a.range = rec.range;
   a.col = rec.range.col;
+  if constexpr (I64) {  // (see FCons::load)
+    a.range.rowptr.is32 = 0;
+    a.range.col.is32 = 0;
+    a.col.is32 = 0;
+  }
   a.count = rec.count;
   a.replace = rec.replace;
   a.num_batches = rec.num_batches;
@@ -741,7 +758,8 @@ __global__ void fused_init_kernel(FTables tb, unsigned* __restrict__ sync, int s
 
 // launch kind 1: [finalize of the previous hop | sampling of this hop] (+ the engine fold behind the last hop)
 // GMAX = the widest lane group of any sampling item of the launch (registers of the 64-lane variant only where needed)
-template <int GMAX>
+// I64: the call's graphs are int64 (see FCons::load)
+template <int GMAX, bool I64>
 __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L, int64_t avail_blocks,
                                                            const u64* __restrict__ words) {
   const int bx = (int)blockIdx.x;
@@ -752,15 +770,15 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
   const int role = L.role[k];
   const int idx = L.idx[k];
   switch (role) {
-    case kRoleSample8: fused_sample<8>(L, L.s[idx], b, avail_blocks, words); break;
+    case kRoleSample8: fused_sample<8, I64>(L, L.s[idx], b, avail_blocks, words); break;
     case kRoleSample16:
-      if constexpr (GMAX >= 16) fused_sample<16>(L, L.s[idx], b, avail_blocks, words);
+      if constexpr (GMAX >= 16) fused_sample<16, I64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleSample32:
-      if constexpr (GMAX >= 32) fused_sample<32>(L, L.s[idx], b, avail_blocks, words);
+      if constexpr (GMAX >= 32) fused_sample<32, I64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleSample64:
-      if constexpr (GMAX >= 64) fused_sample<64>(L, L.s[idx], b, avail_blocks, words);
+      if constexpr (GMAX >= 64) fused_sample<64, I64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleFinalize: fused_finalize(L, L.f[idx], b); break;
     default: {  // kRoleFold: the engine position, the tables and the engine hand-back, written where the host reads them
@@ -823,7 +841,7 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
 // MODE 0 = reduce, 1 = apply (the two-pass form: PYG_HIP_SAMPLER_ONEPASS=0), 2 = one pass, 3 = one pass of a single
 // block with the call's initialisation and the seeds' insertion folded in
 constexpr int kScanReduce = 0, kScanApply = 1, kScanOnePass = 2, kScanSeedFold = 3;
-template <int MAXNC, int MODE>
+template <int MAXNC, int MODE, bool I64>
 __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
   int bx = (int)blockIdx.x;
   if constexpr (MODE == kScanOnePass) {
@@ -851,9 +869,9 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
 #define PYG_FUSED_CASE(N)                                                           \
   if (MAXNC >= N && nc == N) {                                                      \
     if constexpr (MAXNC >= N) {                                                     \
-      if constexpr (MODE == kScanReduce) fused_reduce<N>(L, pt, b);                 \
-      else if constexpr (MODE == kScanApply) fused_apply<N>(L, pt, b, nblocks);     \
-      else fused_onepass<N, MODE == kScanSeedFold>(L, pt, b, nblocks);              \
+      if constexpr (MODE == kScanReduce) fused_reduce<N, I64>(L, pt, b);                 \
+      else if constexpr (MODE == kScanApply) fused_apply<N, I64>(L, pt, b, nblocks);     \
+      else fused_onepass<N, MODE == kScanSeedFold, I64>(L, pt, b, nblocks);              \
     }                                                                               \
     return;                                                                         \
   }

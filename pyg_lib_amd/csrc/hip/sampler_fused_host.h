@@ -185,6 +185,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   tb.L = L;
   tb.R = R;
   tb.T = T;
+  tb.is32 = 0;
+  for (int e = 0; e < R; ++e) tb.is32 |= rels[e].index_is32 ? 1 : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(carve(sync_bytes));
   char* sync_next = reinterpret_cast<char*>(sync) + 64 * (size_t)(L + 1);
   auto ticket_of = [&](int launch) { return sync + 16 * (size_t)launch; };  // 0: seeds, 1 + l: hop l
@@ -231,10 +233,16 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       if (l.role[k] <= kRoleSample64) gmax = std::max(gmax, 8 << l.role[k]);
     const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
     const u64* words = rng.dev;
-    if (gmax <= 8) hipLaunchKernelGGL(fused_sample_kernel<8>, grid, block, 0, stream, l, avail_blocks, words);
-    else if (gmax <= 16) hipLaunchKernelGGL(fused_sample_kernel<16>, grid, block, 0, stream, l, avail_blocks, words);
-    else if (gmax <= 32) hipLaunchKernelGGL(fused_sample_kernel<32>, grid, block, 0, stream, l, avail_blocks, words);
-    else hipLaunchKernelGGL(fused_sample_kernel<64>, grid, block, 0, stream, l, avail_blocks, words);
+#define PYG_FUSED_SAMPLE_LAUNCH(G)                                                                                  \
+  do {                                                                                                              \
+    if (tb.is32) hipLaunchKernelGGL((fused_sample_kernel<G, false>), grid, block, 0, stream, l, avail_blocks, words); \
+    else hipLaunchKernelGGL((fused_sample_kernel<G, true>), grid, block, 0, stream, l, avail_blocks, words);         \
+  } while (0)
+    if (gmax <= 8) PYG_FUSED_SAMPLE_LAUNCH(8);
+    else if (gmax <= 16) PYG_FUSED_SAMPLE_LAUNCH(16);
+    else if (gmax <= 32) PYG_FUSED_SAMPLE_LAUNCH(32);
+    else PYG_FUSED_SAMPLE_LAUNCH(64);
+#undef PYG_FUSED_SAMPLE_LAUNCH
     PYG_HIP_CHECK(hipGetLastError());
     return PYG_HIP_OK;
   };
@@ -243,12 +251,17 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     int maxnc = 0;
     for (int k = 0; k < l.n; ++k) maxnc = std::max(maxnc, l.nc[k]);
     const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
-#define PYG_FUSED_LAUNCH(N)                                                                                      \
-  case N:                                                                                                        \
-    if (mode == kScanReduce) hipLaunchKernelGGL((fused_scan_kernel<N, kScanReduce>), grid, block, 0, stream, l); \
-    else if (mode == kScanApply) hipLaunchKernelGGL((fused_scan_kernel<N, kScanApply>), grid, block, 0, stream, l); \
-    else if (mode == kScanOnePass) hipLaunchKernelGGL((fused_scan_kernel<N, kScanOnePass>), grid, block, 0, stream, l); \
-    else hipLaunchKernelGGL((fused_scan_kernel<N, kScanSeedFold>), grid, block, 0, stream, l);                   \
+#define PYG_FUSED_LAUNCH2(N, I64)                                                                                       \
+  do {                                                                                                                  \
+    if (mode == kScanReduce) hipLaunchKernelGGL((fused_scan_kernel<N, kScanReduce, I64>), grid, block, 0, stream, l);    \
+    else if (mode == kScanApply) hipLaunchKernelGGL((fused_scan_kernel<N, kScanApply, I64>), grid, block, 0, stream, l); \
+    else if (mode == kScanOnePass) hipLaunchKernelGGL((fused_scan_kernel<N, kScanOnePass, I64>), grid, block, 0, stream, l); \
+    else hipLaunchKernelGGL((fused_scan_kernel<N, kScanSeedFold, I64>), grid, block, 0, stream, l);                     \
+  } while (0)
+#define PYG_FUSED_LAUNCH(N)                 \
+  case N:                                   \
+    if (tb.is32) PYG_FUSED_LAUNCH2(N, false); \
+    else PYG_FUSED_LAUNCH2(N, true);        \
     break;
     switch (maxnc) {
       PYG_FUSED_LAUNCH(0)
@@ -258,6 +271,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
         PYG_FUSED_LAUNCH(3)
     }
 #undef PYG_FUSED_LAUNCH
+#undef PYG_FUSED_LAUNCH2
     PYG_HIP_CHECK(hipGetLastError());
     return PYG_HIP_OK;
   };
