@@ -57,6 +57,10 @@ constexpr int pitch_bytes(int cols) {
   return (16 + 64 * extra) * 4;
 }
 
+// global_* loads (the descriptors hold generic pointers: through them the compiler emits flat_* accesses, which also count
+// on lgkmcnt -- every LDS wait then waits for the rows in flight as well)
+typedef const __attribute__((address_space(1))) u32x4 GU32x4;
+
 // One relation / group: `rows` rows of X [rows, K] and dY [rows, M] (row-major, M = row pitch of dY).
 struct DwGroup {
   const uint16_t* x;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
       const int p = it * 64 + lane;
       const int64_t row = row0 + p / CX;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.x + row * K + (p % CX) * 8);
+      if (row < gd.rows) v = *(GU32x4*)(gd.x + row * K + (p % CX) * 8);
       xr[it] = v;
     }
 #pragma unroll
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
       const int p = it * 64 + lane;
       const int64_t row = row0 + p / CY;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.dy + row * M + col0 + (p % CY) * 8);
+      if (row < gd.rows) v = *(GU32x4*)(gd.dy + row * M + col0 + (p % CY) * 8);
       yr[it] = v;
     }
   };
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* _
       const int p = it * 256 + tid;
       const int64_t row = row0 + p / CX;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.x + row * K + (p % CX) * 8);
+      if (row < gd.rows) v = *(GU32x4*)(gd.x + row * K + (p % CX) * 8);
       xr[it] = v;
     }
 #pragma unroll
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* _
       const int p = it * 256 + tid;
       const int64_t row = row0 + p / CY;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < gd.rows) v = *reinterpret_cast<const u32x4*>(gd.dy + row * M + col0 + (p % CY) * 8);
+      if (row < gd.rows) v = *(GU32x4*)(gd.dy + row * M + col0 + (p % CY) * 8);
       yr[it] = v;
     }
   };
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
       vecA v;
 #pragma unroll
       for (int e = 0; e < VA; ++e) v[e] = 0.0f;
-      if (ok) v = *reinterpret_cast<const vecA*>(xp + row * K + 32 * VA * h + VA * li);
+      if (ok) v = *(const __attribute__((address_space(1))) vecA*)(xp + row * K + 32 * VA * h + VA * li);
 #pragma unroll
       for (int e = 0; e < VA; ++e) a[VA * h + e] = v[e];
     }
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
       vecB v;
 #pragma unroll
       for (int e = 0; e < VB; ++e) v[e] = 0.0f;
-      if (ok) v = *reinterpret_cast<const vecB*>(yp + row * M + col0 + 32 * VB * h + VB * li);
+      if (ok) v = *(const __attribute__((address_space(1))) vecB*)(yp + row * M + col0 + 32 * VB * h + VB * li);
 #pragma unroll
       for (int e = 0; e < VB; ++e) b[VB * h + e] = v[e];
     }

@@ -85,25 +85,26 @@ constexpr int gen_pitch(int cols) {
 // whole number of pieces.  No branch arm holds more than a load: the compiler needs no copy (and hence no wait) between
 // the loads and their use a tile later.  (LG = 1 assembles dwords from halves and is only used un-pipelined.)
 template <int ELT, int LG>
+// (global_* loads: see matmul_dw.hip)
 __device__ __forceinline__ u32x4 load_chunk(const char* rowp, int c0, int n, bool row_ok) {
   u32x4 v = {0u, 0u, 0u, 0u};
   const int vb = row_ok ? (n - c0) * ELT : 0;  // valid bytes from the chunk start (<= 0: nothing, >= 16: all)
   const char* p = rowp + (int64_t)c0 * ELT;
   if constexpr (LG >= 4) {
-    if (vb >= 16) v = *reinterpret_cast<const u32x4*>(p);
+    if (vb >= 16) v = *(const __attribute__((address_space(1))) u32x4*)(p);
   } else if constexpr (LG == 3) {
     u32x2 a = {0u, 0u}, b = {0u, 0u};
-    if (vb >= 8) a = *reinterpret_cast<const u32x2*>(p);
-    if (vb >= 16) b = *reinterpret_cast<const u32x2*>(p + 8);
+    if (vb >= 8) a = *(const __attribute__((address_space(1))) u32x2*)(p);
+    if (vb >= 16) b = *(const __attribute__((address_space(1))) u32x2*)(p + 8);
     v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1];
   } else if constexpr (LG == 2) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (vb >= 4 * (e + 1)) v[e] = *reinterpret_cast<const uint32_t*>(p + 4 * e);
+      if (vb >= 4 * (e + 1)) v[e] = *(const __attribute__((address_space(1))) uint32_t*)(p + 4 * e);
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      if (vb >= 2 * (e + 1)) v[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t*>(p + 2 * e) << (16 * (e & 1));
+      if (vb >= 2 * (e + 1)) v[e >> 1] |= (uint32_t) * (const __attribute__((address_space(1))) uint16_t*)(p + 2 * e) << (16 * (e & 1));
   }
   return v;
 }
