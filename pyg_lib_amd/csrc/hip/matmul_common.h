@@ -126,8 +126,8 @@ int launch_ring_k256(int dtype, const void* descs, const int32_t* tile_start3, i
 int launch_ring_k128(int dtype, const void* descs, const int32_t* tile_start3, int B, int64_t tiles3_upper, hipStream_t stream);
 int launch_ring_f32x3(const void* descs, const int32_t* tile_start3, int B, int64_t tiles3_upper, hipStream_t stream);
 // matmul_dw_gen.hip: the general-shape weight gradient (per-group K, M, alignment class; bf16 / f16 / f32).  The
-// workspace is carved as [B + 1 ptr copy][descriptors][tile prefix][fp32 image of the outputs (16-bit types only)].
-size_t dw_gen_workspace_bytes(int64_t B, int64_t out_elems);
+// workspace is carved as [B + 1 ptr copy][descriptors][tile prefix][two fp32 partial slabs per workgroup].
+size_t dw_gen_workspace_bytes(int64_t B);
 int dw_gen_segment(int dtype, const void* input, const int64_t* ptr, int ptr_on_device, const void* grad_out,
                    void* grad_other, int64_t N, int64_t K, int64_t M, int64_t B, void* workspace, hipStream_t stream);
 int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void* out_pool, void* workspace,

@@ -17,9 +17,11 @@
 //     4-row columns): 2 reads per MFMA operand instead of 8 two-byte reads.  The image pitch is
 //     16 (mod 64) dwords, which keeps the two 16-lane groups of a 32-lane service group and the 4 rows
 //     of a block on disjoint banks.
-//   * Accumulators are flushed with native global_atomic_add_f32 into an fp32 [B, K, M] scratch
-//     (43 M atomics for C2, L2-resident) and rounded once to the storage type by a tiny epilogue.
-#include "matmul_common.h"
+//   * No atomics (matmul_dw_out.h): when a relation ends the four waves add their accumulator sets through LDS in a
+//     fixed order; a relation that lies inside the workgroup's range is rounded and stored at once, the (at most two)
+//     partial ones per workgroup go to fp32 slabs that a small fix-up launch adds in workgroup order.  dW is the same
+//     bits in every run, like the reference's per-relation at::matmul.
+#include "matmul_dw_out.h"
 
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,6 +44,16 @@ constexpr int kTile = 128;  // rows per workgroup tile (4 waves x 32)
 
 struct bf16_tag {};
 struct f16_tag {};
+template <typename Tag>
+struct OutOf;
+template <>
+struct OutOf<bf16_tag> {
+  using type = bf16_t;
+};
+template <>
+struct OutOf<f16_tag> {
+  using type = f16_t;
+};
 
 __device__ __forceinline__ f32x16 mfma16(bf16_tag, v8i16 a, v8i16 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -110,7 +122,8 @@ __global__ void dw_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, const
 template <typename Tag, int K, int MC>
 __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restrict__ groups,
                                                          const int32_t* __restrict__ tile_start, int B, int M,
-                                                         float* __restrict__ acc_out) {
+                                                         float* __restrict__ slabs,
+                                                         typename OutOf<Tag>::type* __restrict__ out) {
   constexpr int IB = K / 32, JB = MC / 32;
   constexpr int PX = pitch_bytes(K), PY = pitch_bytes(MC);
   constexpr int CX = K / 8, CY = MC / 8;          // 16-byte chunks per row
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
   static_assert(IB * JB <= 16, "accumulators must fit the register file");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
   char* xs = smem + wave * 32 * (PX + PY);
   char* ys = xs + 32 * PX;
   // XCD-aware decode of the 1-D grid: the M / MC column-chunk workgroups of one tile range get ids 8 apart
@@ -151,20 +165,25 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   int acc_g = -1;  // relation the accumulators belong to
 
+  // a relation ends: waves combined through LDS (the images are dead: every wave is past the MFMAs of the previous tile),
+  // then stored (whole relation inside [t_beg, t_end)) or parked in the head / tail slab (matmul_dw_out.h)
   auto flush = [&]() {
     if (acc_g < 0) return;
-    float* base = acc_out + ((int64_t)acc_g * K) * M + col0;
+    using Pos = DwPosRows<IB, JB>;
+    const int u0 = tile_start[acc_g], u1 = tile_start[acc_g + 1];
+    const bool head = u0 < t_beg, tail = !head && u1 > t_end;
+    float* slab = dw_slab(slabs, (int64_t)IB * JB * kDwBlockFloats, ncol, bx, by, head ? 0 : 1);
+    typename OutOf<Tag>::type* base = out + ((int64_t)acc_g * K) * M + col0;
+    dw_combine_waves<IB, JB>(acc, smem, swave, lane, [&](int bt, int q, dwf4 s) __attribute__((always_inline)) {
+      if (head || tail) dw_quarter_to_slab(slab, bt, q, s, lane);
+      else dw_quarter_to_out<Pos>(base, M, K, MC, bt, q, s, lane);
+    });
 #pragma unroll
     for (int i = 0; i < IB; ++i)
 #pragma unroll
       for (int j = 0; j < JB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int col = j * 32 + (lane & 31);
-          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[i][j][r] = 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
 
   // software pipeline: rows of tile t+1 travel to registers while tile t is multiplied
@@ -260,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void seg_dw_kernel(const DwGroup* __restric
 template <typename Tag>
 __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* __restrict__ groups,
                                                                 const int32_t* __restrict__ tile_start, int B, int M,
-                                                                float* __restrict__ acc_out) {
+                                                                float* __restrict__ slabs,
+                                                                typename OutOf<Tag>::type* __restrict__ out) {
   constexpr int K = 256, MC = 256, IB = K / 32, JB = 2;
   constexpr int PX = pitch_bytes(K), PY = pitch_bytes(MC);
   constexpr int CX = K / 8, CY = MC / 8;                 // 16-byte chunks per row
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* _
   constexpr int IMG = 32 * (PX + PY);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int ncol = M / MC;
   const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
   const int by = ncol > 1 ? ((int)blockIdx.x / 8) % ncol : 0;
@@ -296,20 +317,46 @@ __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   int acc_g = -1;
+  // the waves own disjoint COLUMNS of dW: nothing to combine; whole relation -> dW, partial -> this wave's part of the slab
   auto flush = [&]() {
     if (acc_g < 0) return;
-    float* base = acc_out + ((int64_t)acc_g * K) * M + col0 + 64 * wave;
+    const int u0 = tile_start[acc_g], u1 = tile_start[acc_g + 1];
+    const bool head = u0 < t_beg, tail = !head && u1 > t_end;
+    float* slab = dw_slab(slabs, (int64_t)DwPosWide::kBlocks * kDwBlockFloats, ncol, bx, by, head ? 0 : 1);
+    typename OutOf<Tag>::type* base = out + ((int64_t)acc_g * K) * M + col0;
+    // Through a wave-private 16 KiB staging area behind the two images (both hold live slabs here), four blocks at a
+    // time: the registers are written with constant indices, the stores walk the area in a ROLLED loop -- the direct
+    // form (64 blocks x 4 quarters of address arithmetic next to 256 live accumulators) spilled 2 KB per lane.
+    char* stage = smem + 2 * IMG + wave * 16384 + lane * 16;
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {
+#pragma unroll
+      for (int L = 0; L < 4; ++L) {
+        const int b = Q * 4 + L;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const dwf4 v = {acc[b / JB][b % JB][4 * q], acc[b / JB][b % JB][4 * q + 1], acc[b / JB][b % JB][4 * q + 2],
+                          acc[b / JB][b % JB][4 * q + 3]};
+          *reinterpret_cast<dwf4*>(stage + (L * 4 + q) * 1024) = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int it = 0; it < 16; ++it) {
+        const dwf4 v = *reinterpret_cast<const dwf4*>(stage + it * 1024);
+        const int bt = swave * 16 + Q * 4 + (it >> 2), q = it & 3;
+        if (head || tail) dw_quarter_to_slab(slab, bt, q, v, lane);
+        else dw_quarter_to_out<DwPosWide>(base, M, K, MC, bt, q, v, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int i = 0; i < IB; ++i)
 #pragma unroll
       for (int j = 0; j < JB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int col = j * 32 + (lane & 31);
-          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[i][j][r] = 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
 
   // slab index space: 4 slabs of 32 rows per 128-row tile
@@ -422,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void seg_dw_wide256_kernel(const DwGroup* _
 template <int K, int MC>
 __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __restrict__ groups,
                                                              const int32_t* __restrict__ tile_start, int B, int M,
-                                                             float* __restrict__ acc_out) {
+                                                             float* __restrict__ slabs, float* __restrict__ out) {
   constexpr int IB = K / 32, JB = MC / 32;
   static_assert(IB * JB <= 16, "accumulators must fit the register file");
   // The MFMA wants ONE value per lane and block, but nothing ties block i to the columns 32 i .. 32 i + 31:
@@ -430,7 +477,9 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
   // different blocks (block VA h + e = columns 32 VA h + VA li + e) -- 16-byte instead of 4-byte accesses,
   // whole 512-byte rows per wave instruction; the permutation is undone when the accumulators are flushed.
   constexpr int VA = IB >= 4 ? 4 : IB, VB = JB >= 4 ? 4 : JB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // IB * JB * 4 KiB: the waves' combine area (flush only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
   const int li = lane & 31, kk = lane >> 5;
   const int ncol = M / MC;
   const int bx = ncol > 1 ? ((int)blockIdx.x / (8 * ncol)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
@@ -458,22 +507,24 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   int acc_g = -1;
+  // block i = VA h + e holds the X columns 32 VA h + VA * (MFMA row) + e (see the loads below): DwPosF32 undoes that
   auto flush = [&]() {
     if (acc_g < 0) return;
-    float* base = acc_out + ((int64_t)acc_g * K) * M + col0;
+    using Pos = DwPosF32<IB, JB>;
+    const int u0 = tile_start[acc_g], u1 = tile_start[acc_g + 1];
+    const bool head = u0 < t_beg, tail = !head && u1 > t_end;
+    float* slab = dw_slab(slabs, (int64_t)IB * JB * kDwBlockFloats, ncol, bx, by, head ? 0 : 1);
+    float* base = out + ((int64_t)acc_g * K) * M + col0;
+    dw_combine_waves<IB, JB>(acc, smem, swave, lane, [&](int bt, int q, dwf4 s) __attribute__((always_inline)) {
+      if (head || tail) dw_quarter_to_slab(slab, bt, q, s, lane);
+      else dw_quarter_to_out<Pos>(base, M, K, MC, bt, q, s, lane);
+    });
 #pragma unroll
     for (int i = 0; i < IB; ++i)
 #pragma unroll
       for (int j = 0; j < JB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // block i = VA h + e holds the X columns 32 VA h + VA * (MFMA row) + e (see the loads below)
-          const int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int row = 32 * VA * (i / VA) + VA * mrow + (i % VA);
-          const int col = 32 * VB * (j / VB) + VB * (lane & 31) + (j % VB);
-          __hip_atomic_fetch_add(base + (int64_t)row * M + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[i][j][r] = 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
   // Software pipeline over the flattened (tile, row pair) sequence: the operands of step it + D are requested
   // while step it is multiplied (one wave per SIMD and 16 MFMAs = 1 k cycles per step: without the ring an HBM
@@ -537,92 +588,151 @@ __global__ __launch_bounds__(256, 1) void seg_dw_f32_kernel(const DwGroup* __res
   flush();
 }
 
-// dW[b, k, m] = round(acc[b, k, m])
-template <typename Tag>
-__global__ void dw_round_kernel(const float* __restrict__ acc, uint16_t* __restrict__ out, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if constexpr (sizeof(Tag) && __is_same(Tag, bf16_tag)) out[i] = __builtin_bit_cast(uint16_t, (__bf16)acc[i]);
-  else out[i] = __builtin_bit_cast(uint16_t, (_Float16)acc[i]);
+// The launch behind the main kernel.  Workgroups [0, fix_blocks): wave v = 4 blockIdx + wave is (logical main workgroup
+// m = v / (4 NBT), slab block bt, quarter q); if a split relation STARTS in m's tile range, the wave adds that relation's
+// slabs in workgroup order (dw_chain_sum) and stores 4 x 64 rounded values.  Workgroups behind them: relation
+// blockIdx - fix_blocks; one without rows gets its zeros here (nothing else ever writes it).
+template <typename Pos, typename OutT>
+__global__ __launch_bounds__(256) void seg_dw_fixup_kernel(const int32_t* __restrict__ tile_start, int B, int K, int M, int MC,
+                                                          int G, int fix_blocks, const float* __restrict__ slabs,
+                                                          OutT* __restrict__ out) {
+  constexpr int NBT = Pos::kBlocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= fix_blocks) {
+    const int g = (int)blockIdx.x - fix_blocks;
+    if (tile_start[g + 1] != tile_start[g]) return;
+    OutT* base = out + (int64_t)g * K * M;
+    for (int i = threadIdx.x; i < K * M; i += 256) dw_put(base + i, 0.0f);
+    return;
+  }
+  const int ncol = M / MC;
+  const int v = (int)blockIdx.x * 4 + wave;
+  const int m = v / (4 * NBT), piece = v - m * (4 * NBT);
+  const int bt = piece >> 2, q = piece & 3;
+  const int bx = m / ncol, by = m - bx * ncol;
+  const int total = tile_start[B];
+  const int t_beg = (int)((int64_t)bx * total / G), t_end = (int)((int64_t)(bx + 1) * total / G);
+  if (t_beg >= t_end) return;
+  int lo = 0, hi = B;  // relation of the range's last tile
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= t_end - 1) lo = mid; else hi = mid;
+  }
+  const int u0 = tile_start[lo], u1 = tile_start[lo + 1];
+  if (!(u1 > t_end && u0 >= t_beg)) return;  // no split relation starts here
+  const dwf4 s = dw_chain_sum(slabs, (int64_t)NBT * kDwBlockFloats, ncol, bx, by, G, total, u1, bt, q, lane);
+  dw_quarter_to_out<Pos>(out + (int64_t)lo * K * M + by * MC, M, K, MC, bt, q, s, lane);
 }
 
 inline size_t dw_groups_bytes(int64_t B) { return align_up(sizeof(DwGroup) * (size_t)(B > 0 ? B : 1), 256); }
 inline size_t dw_tiles_bytes(int64_t B) { return align_up(sizeof(int32_t) * (size_t)(B + 1), 256); }
+
+// column chunk of the kernel a (dtype, K, M) runs (run_dw / run_dw_f32 below) and the grid it gets
+inline int dw_mc(bool f32, int64_t K, int64_t M) {
+  if (!f32 && K == 256 && M % 256 == 0) return 256;
+  if (K == 256) return 64;
+  return M % 128 == 0 ? 128 : 64;
+}
+inline int64_t dw_grid_x(int64_t tiles_upper, int64_t ncol) {
+  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, device_info().num_cus / ncol));
+  if (ncol > 1) gx = (gx + 7) / 8 * 8;  // the kernels' XCD-aware decode works on groups of 8 ids
+  return gx;
+}
+// two fp32 slabs of K x MC per main workgroup; the bound holds for every tile count and for both the 16-bit and the
+// fp32 kernel of the shape
+inline size_t dw_slab_bytes(int64_t K, int64_t M) {
+  if (!((K == 64 || K == 128 || K == 256) && M > 0 && M % 64 == 0)) return 0;  // (dw_fast_shape: the other shapes run matmul_dw_gen.hip)
+  size_t worst = 0;
+  for (int f32 = 0; f32 < 2; ++f32) {
+    const int64_t mc = dw_mc(f32 != 0, K, M), ncol = M / mc;
+    const int64_t gx = dw_grid_x(INT64_MAX, ncol);
+    worst = std::max(worst, (size_t)(gx * ncol) * 2 * (size_t)K * (size_t)mc * sizeof(float));
+  }
+  return worst;
+}
 inline size_t dw_ws_bytes(int64_t B, int64_t K, int64_t M) {
-  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + dw_groups_bytes(B) + dw_tiles_bytes(B) +
-         align_up(sizeof(float) * (size_t)B * (size_t)K * (size_t)M, 256);
+  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + dw_groups_bytes(B) + dw_tiles_bytes(B) + dw_slab_bytes(K, M);
+}
+
+template <typename Pos, typename OutT>
+int launch_fixup(const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int MC, int64_t gx, const float* slabs,
+                 OutT* out, hipStream_t stream) {
+  const int64_t ncol = M / MC;
+  const int64_t fix_blocks = gx * ncol * Pos::kBlocks;  // 4 NBT waves per main workgroup, 4 waves per block
+  hipLaunchKernelGGL((seg_dw_fixup_kernel<Pos, OutT>), dim3((unsigned)(fix_blocks + B)), dim3(256), 0, stream, tile_start,
+                     (int)B, (int)K, (int)M, MC, (int)gx, (int)fix_blocks, slabs, out);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
 }
 
 template <typename Tag, int K, int MC>
-int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* acc,
-              hipStream_t stream) {
+int launch_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* slabs,
+              void* out_, hipStream_t stream) {
+  using OutT = typename OutOf<Tag>::type;
+  OutT* out = static_cast<OutT*>(out_);
   constexpr int lds = 4 * 32 * (pitch_bytes(K) + pitch_bytes(MC));
+  static_assert(lds >= (K / 32) * (MC / 32) * 4096, "the combine area must fit the row images");
   const void* kern = reinterpret_cast<const void*>(&seg_dw_kernel<Tag, K, MC>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
-  const int64_t cus = device_info().num_cus;
   const int64_t ncol = M / MC;
-  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
-  if (ncol > 1) gx = (gx + 7) / 8 * 8;  // the kernel's XCD-aware decode works on groups of 8 ids
+  const int64_t gx = dw_grid_x(tiles_upper, ncol);
   hipLaunchKernelGGL((seg_dw_kernel<Tag, K, MC>), dim3((unsigned)(gx * ncol)), dim3(256), lds, stream, groups,
-                     tile_start, (int)B, (int)M, acc);
+                     tile_start, (int)B, (int)M, slabs, out);
   PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return launch_fixup<DwPosRows<K / 32, MC / 32>, OutT>(tile_start, B, K, M, MC, gx, slabs, out, stream);
 }
 
 template <typename Tag>
 int launch_dw_wide256(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper,
-                      float* acc, hipStream_t stream) {
-  constexpr int lds = 2 * 32 * (pitch_bytes(256) + pitch_bytes(256));
+                      float* slabs, void* out_, hipStream_t stream) {
+  using OutT = typename OutOf<Tag>::type;
+  OutT* out = static_cast<OutT*>(out_);
+  constexpr int lds = 2 * 32 * (pitch_bytes(256) + pitch_bytes(256)) + 4 * 16384;  // two images + the flush staging area
   const void* kern = reinterpret_cast<const void*>(&seg_dw_wide256_kernel<Tag>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
-  const int64_t cus = device_info().num_cus;
   const int64_t ncol = M / 256;
-  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
-  if (ncol > 1) gx = (gx + 7) / 8 * 8;
+  const int64_t gx = dw_grid_x(tiles_upper, ncol);
   hipLaunchKernelGGL((seg_dw_wide256_kernel<Tag>), dim3((unsigned)(gx * ncol)), dim3(256), lds, stream, groups, tile_start,
-                     (int)B, (int)M, acc);
+                     (int)B, (int)M, slabs, out);
   PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return launch_fixup<DwPosWide, OutT>(tile_start, B, 256, M, 256, gx, slabs, out, stream);
 }
 
 template <typename Tag>
 int run_dw(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
-           float* acc, hipStream_t stream) {
-#ifdef PYG_HIP_MM_EXPERIMENTS
-  static const bool nowide = getenv("PYG_HIP_MM_NOWIDE") != nullptr;
-#else
-  constexpr bool nowide = false;
-#endif
-  if (K == 256 && M % 256 == 0 && !nowide) return launch_dw_wide256<Tag>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 64 == 0) return launch_dw<Tag, 64, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 256 && M % 64 == 0) return launch_dw<Tag, 256, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+           float* slabs, void* out, hipStream_t stream) {
+  if (K == 256 && M % 256 == 0) return launch_dw_wide256<Tag>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 128 && M % 128 == 0) return launch_dw<Tag, 128, 128>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 128 && M % 64 == 0) return launch_dw<Tag, 128, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 64 && M % 128 == 0) return launch_dw<Tag, 64, 128>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 64 && M % 64 == 0) return launch_dw<Tag, 64, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 256 && M % 64 == 0) return launch_dw<Tag, 256, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
   return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: K=%lld, M=%lld has no MFMA kernel (K in {64,128,256}, M %% 64 == 0)",
               (long long)K, (long long)M);
 }
 
 template <int K, int MC>
-int launch_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* acc,
-                  hipStream_t stream) {
-  const int64_t cus = device_info().num_cus;
+int launch_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t M, int64_t tiles_upper, float* slabs,
+                  void* out_, hipStream_t stream) {
+  float* out = static_cast<float*>(out_);
+  constexpr int lds = (K / 32) * (MC / 32) * 4096;  // the waves' combine area
+  const void* kern = reinterpret_cast<const void*>(&seg_dw_f32_kernel<K, MC>);
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const int64_t ncol = M / MC;
-  int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, cus / ncol));
-  if (ncol > 1) gx = (gx + 7) / 8 * 8;
-  hipLaunchKernelGGL((seg_dw_f32_kernel<K, MC>), dim3((unsigned)(gx * ncol)), dim3(256), 0, stream, groups, tile_start,
-                     (int)B, (int)M, acc);
+  const int64_t gx = dw_grid_x(tiles_upper, ncol);
+  hipLaunchKernelGGL((seg_dw_f32_kernel<K, MC>), dim3((unsigned)(gx * ncol)), dim3(256), lds, stream, groups, tile_start,
+                     (int)B, (int)M, slabs, out);
   PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return launch_fixup<DwPosF32<K / 32, MC / 32>, float>(tile_start, B, K, M, MC, gx, slabs, out, stream);
 }
 
 int run_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int64_t K, int64_t M, int64_t tiles_upper,
-               float* acc, hipStream_t stream) {
-  if (K == 128 && M % 128 == 0) return launch_dw_f32<128, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 128 && M % 64 == 0) return launch_dw_f32<128, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 128 == 0) return launch_dw_f32<64, 128>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 64 && M % 64 == 0) return launch_dw_f32<64, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
-  if (K == 256 && M % 64 == 0) return launch_dw_f32<256, 64>(groups, tile_start, B, M, tiles_upper, acc, stream);
+               float* slabs, void* out, hipStream_t stream) {
+  if (K == 128 && M % 128 == 0) return launch_dw_f32<128, 128>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 128 && M % 64 == 0) return launch_dw_f32<128, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 64 && M % 128 == 0) return launch_dw_f32<64, 128>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 64 && M % 64 == 0) return launch_dw_f32<64, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
+  if (K == 256 && M % 64 == 0) return launch_dw_f32<256, 64>(groups, tile_start, B, M, tiles_upper, slabs, out, stream);
   return fail(PYG_HIP_ERR_UNSUPPORTED, "segment_matmul_dw: K=%lld, M=%lld has no MFMA kernel (K in {64,128,256}, M %% 64 == 0)",
               (long long)K, (long long)M);
 }
@@ -630,21 +740,6 @@ int run_dw_f32(const DwGroup* groups, const int32_t* tile_start, int64_t B, int6
 // shapes of the specialised kernels above; everything else (and operands that are not 16-byte aligned) runs
 // matmul_dw_gen.hip
 inline bool dw_fast_shape(int64_t K, int64_t M) { return (K == 64 || K == 128 || K == 256) && M > 0 && M % 64 == 0; }
-
-int round_out(int dtype, const float* acc, void* out, int64_t n, hipStream_t stream) {
-  if (dtype == PYG_F32) {  // the accumulators ARE the result
-    PYG_HIP_CHECK(hipMemcpyAsync(out, acc, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream));
-    return PYG_HIP_OK;
-  }
-  if (dtype == PYG_BF16)
-    hipLaunchKernelGGL(dw_round_kernel<bf16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(out), n);
-  else
-    hipLaunchKernelGGL(dw_round_kernel<f16_tag>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(out), n);
-  PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
-}
 
 }  // namespace
 }  // namespace pyg_hip
@@ -667,18 +762,14 @@ void pyg_hip_matmul_dw_counters(int64_t* specialised, int64_t* general) {
 
 size_t pyg_hip_segment_matmul_dw_workspace_size(int64_t B, int64_t K, int64_t M) {
   B = B < 0 ? 0 : B, K = K < 0 ? 0 : K, M = M < 0 ? 0 : M;
-  return std::max(dw_ws_bytes(B, K, M), dw_gen_workspace_bytes(B, B * K * M));
+  return std::max(dw_ws_bytes(B, K, M), dw_gen_workspace_bytes(B));
 }
 
 size_t pyg_hip_grouped_matmul_dw_workspace_size(const pyg_hip_group* groups, int64_t G) {
-  if (G <= 0 || groups == nullptr) return dw_gen_workspace_bytes(0, 0);
-  int64_t elems = 0;
+  if (G <= 0 || groups == nullptr) return dw_gen_workspace_bytes(0);
   bool uniform = true;
-  for (int64_t i = 0; i < G; ++i) {
-    elems += (int64_t)std::max(groups[i].k, 0) * std::max(groups[i].m, 0);
-    uniform = uniform && groups[i].k == groups[0].k && groups[i].m == groups[0].m;
-  }
-  const size_t gen = dw_gen_workspace_bytes(G, elems);
+  for (int64_t i = 0; i < G; ++i) uniform = uniform && groups[i].k == groups[0].k && groups[i].m == groups[0].m;
+  const size_t gen = dw_gen_workspace_bytes(G);
   return uniform ? std::max(gen, dw_ws_bytes(G, std::max(groups[0].k, 0), std::max(groups[0].m, 0))) : gen;
 }
 
@@ -707,7 +798,7 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
   w += dw_groups_bytes(B);
   int32_t* tile_start = reinterpret_cast<int32_t*>(w);
   w += dw_tiles_bytes(B);
-  float* acc = reinterpret_cast<float*>(w);
+  float* slabs = reinterpret_cast<float*>(w);
   const int64_t* dptr = ptr;
   if (!ptr_on_device) {
     void* staged = nullptr;
@@ -719,18 +810,15 @@ int pyg_hip_segment_matmul_dw(int dtype, const void* input, const int64_t* ptr, 
     if (rc != PYG_HIP_OK) return rc;
     dptr = ptr_dev;
   }
-  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)B * (size_t)K * (size_t)M, stream));
   // descriptors address the tensors in 2-byte units: an fp32 row is 2 K of them
   const int64_t u = dtype == PYG_F32 ? 2 : 1;
   hipLaunchKernelGGL(dw_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, static_cast<const uint16_t*>(input),
                      static_cast<const uint16_t*>(grad_out), K * u, M * u, groups, tile_start);
   PYG_HIP_CHECK(hipGetLastError());
   const int64_t tiles_upper = (N + kTile - 1) / kTile + B;
-  int rc = dtype == PYG_F32    ? run_dw_f32(groups, tile_start, B, K, M, tiles_upper, acc, stream)
-           : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream)
-                               : run_dw<f16_tag>(groups, tile_start, B, K, M, tiles_upper, acc, stream);
-  if (rc != PYG_HIP_OK) return rc;
-  return round_out(dtype, acc, grad_other, B * K * M, stream);
+  return dtype == PYG_F32    ? run_dw_f32(groups, tile_start, B, K, M, tiles_upper, slabs, grad_other, stream)
+         : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, B, K, M, tiles_upper, slabs, grad_other, stream)
+                             : run_dw<f16_tag>(groups, tile_start, B, K, M, tiles_upper, slabs, grad_other, stream);
 }
 
 int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64_t G, void* out_pool, void* workspace,
@@ -767,7 +855,7 @@ int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64
   w += dw_groups_bytes(G);
   int32_t* tile_start = reinterpret_cast<int32_t*>(w);
   w += dw_tiles_bytes(G);
-  float* acc = reinterpret_cast<float*>(w);
+  float* slabs = reinterpret_cast<float*>(w);
   // host-side plan (G is small): descriptors + tile prefix in one pinned H2D copy
   void* staged = nullptr;
   int rc = pinned_stage().acquire(dw_groups_bytes(G) + dw_tiles_bytes(G), &staged);
@@ -786,12 +874,9 @@ int pyg_hip_grouped_matmul_dw(int dtype, const pyg_hip_group* host_groups, int64
   PYG_HIP_CHECK(hipMemcpyAsync(groups, staged, dw_groups_bytes(G) + dw_tiles_bytes(G), hipMemcpyHostToDevice, stream));
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;
-  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)G * (size_t)K * (size_t)M, stream));
-  rc = dtype == PYG_F32    ? run_dw_f32(groups, tile_start, G, K, M, tiles + 1, acc, stream)
-       : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream)
-                           : run_dw<f16_tag>(groups, tile_start, G, K, M, tiles + 1, acc, stream);
-  if (rc != PYG_HIP_OK) return rc;
-  return round_out(dtype, acc, out_pool, G * K * M, stream);
+  return dtype == PYG_F32    ? run_dw_f32(groups, tile_start, G, K, M, tiles + 1, slabs, out_pool, stream)
+         : dtype == PYG_BF16 ? run_dw<bf16_tag>(groups, tile_start, G, K, M, tiles + 1, slabs, out_pool, stream)
+                             : run_dw<f16_tag>(groups, tile_start, G, K, M, tiles + 1, slabs, out_pool, stream);
 }
 
 }  // extern "C"

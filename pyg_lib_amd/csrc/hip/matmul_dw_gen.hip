@@ -9,7 +9,9 @@
 //   * The output of a group is cut into blocks of KB x MB = 128 x 128 (fp32: 128 x 64) entries; a work tile is
 //     (group, block, 128 consecutive rows).  Tiles are numbered group-major, block-major, row-tile-minor, every
 //     workgroup walks a contiguous range of them: it keeps a block's fp32 accumulators in registers across its row
-//     tiles and flushes them (global_atomic_add_f32 into a zeroed fp32 image of dW) only when the block changes.
+//     tiles and hands them over only when the block changes -- without atomics (matmul_dw_out.h): the waves are added
+//     through LDS in a fixed order, a block that lies inside the workgroup's range is rounded and stored at once, the
+//     (at most two) partial ones per workgroup go to fp32 slabs that the fix-up launch adds in workgroup order.
 //     K <= 128 and M <= 128 read X and dY exactly once; wider outputs re-read X per column block and dY per row block.
 //   * As in seg_dw_kernel each of the 4 waves owns 32 rows of the tile and a full block of accumulators (1 wave per
 //     SIMD), parks its rows in a wave-private row-major LDS image -- columns beyond K / M zero-filled, so the
@@ -22,7 +24,7 @@
 //     no separate path.
 //   * fp32 runs v_mfma_f32_32x32x2_f32 (IEEE fp32 products and sums, like the exact forward kernel): its operands are
 //     "2 rows x 32 columns", read from the same row-major image with plain 4-byte LDS reads (no transpose).
-#include "matmul_common.h"
+#include "matmul_dw_out.h"
 
 #include <stdint.h>
 #include <string.h>
@@ -137,13 +139,14 @@ struct TileKey {
   int blk;     // block of the group (kb * nmb + mb)
   int kb, mb;  // block coordinates
   int k, m;    // the group's shape
+  int u0, u1;  // tiles of this (group, block): the unit the accumulators belong to
   int64_t acc_off;
 };
 
 template <typename T, int LG>
 __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __restrict__ groups,
                                                          const int32_t* __restrict__ tile_start, int B,
-                                                         float* __restrict__ acc_out) {
+                                                         float* __restrict__ slabs, T* __restrict__ out) {
   constexpr int ELT = Elem<T>::kSize, E = 16 / ELT;
   constexpr int IB = GenCfg<T>::IB, JB = GenCfg<T>::JB;
   constexpr int KB = 32 * IB, MB = 32 * JB;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
   constexpr int NX = 32 * CX / 64, NY = 32 * CY / 64;  // chunk loads per lane and tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
   char* xs = smem + wave * 32 * (PX + PY);
   char* ys = xs + 32 * PX;
 
@@ -179,32 +183,27 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   TileKey ak;  // block the accumulators belong to
   ak.g = -1;
-  ak.blk = 0, ak.kb = 0, ak.mb = 0, ak.k = 0, ak.m = 0, ak.acc_off = 0;
+  ak.blk = 0, ak.kb = 0, ak.mb = 0, ak.k = 0, ak.m = 0, ak.u0 = 0, ak.u1 = 0, ak.acc_off = 0;
 
-  // Accumulators -> fp32 image.  Addresses are a workgroup-uniform base + a 32-bit byte offset per lane (k m < 2^28 is
-  // checked on the host): one offset register per atomic, no 64-bit address arithmetic next to 256 live accumulators.
+  // A block ends: the waves are combined through LDS (the images are dead: every wave is past the MFMAs of the
+  // previous tile), then the block is stored (it lies inside [t_beg, t_end)) or parked in the head / tail slab.
   auto flush = [&]() {
     if (ak.g < 0) return;
-    char* base = reinterpret_cast<char*>(acc_out + ak.acc_off);
-    const int k = ak.k, m = ak.m;
-    const int row_l = ak.kb * KB + 4 * (lane >> 5), col_l = ak.mb * MB + (lane & 31);
+    using Pos = DwPosRows<IB, JB>;
+    const bool head = ak.u0 < t_beg, tail = !head && ak.u1 > t_end;
+    float* slab = dw_slab(slabs, (int64_t)IB * JB * kDwBlockFloats, 1, (int)blockIdx.x, 0, head ? 0 : 1);
+    T* base = out + ak.acc_off + (int64_t)ak.kb * KB * ak.m + ak.mb * MB;
+    const int pitch = ak.m, k_lim = ak.k - ak.kb * KB, m_lim = ak.m - ak.mb * MB;
+    dw_combine_waves<IB, JB>(acc, smem, swave, lane, [&](int bt, int q, dwf4 s) __attribute__((always_inline)) {
+      if (head || tail) dw_quarter_to_slab(slab, bt, q, s, lane);
+      else dw_quarter_to_out<Pos>(base, pitch, k_lim, m_lim, bt, q, s, lane);
+    });
 #pragma unroll
-    for (int i = 0; i < IB; ++i) {
+    for (int i = 0; i < IB; ++i)
 #pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        const int row0 = row_l + 32 * i, col = col_l + 32 * j;
-        const bool live = ak.kb * KB + 32 * i < k && ak.mb * MB + 32 * j < m;  // uniform: the sub-block holds data
-        const uint32_t off0 = ((uint32_t)row0 * (uint32_t)m + (uint32_t)col) * 4u;
+      for (int j = 0; j < JB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          if (live && col < m && row0 + dr < k)
-            __hip_atomic_fetch_add(reinterpret_cast<float*>(base + (off0 + (uint32_t)(dr * m) * 4u)), acc[i][j][r],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[i][j][r] = 0.0f;
-        }
-      }
-    }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   };
 
   // software pipeline: rows of tile t + 1 travel to registers while tile t is multiplied
@@ -227,6 +226,8 @@ __global__ __launch_bounds__(256, 1) void dw_gen_kernel(const DwGenGroup* __rest
     nk.k = gd.k;
     nk.m = gd.m;
     nk.acc_off = gd.acc_off;
+    nk.u0 = tile_start[n_g] + blk * rt_n;
+    nk.u1 = nk.u0 + rt_n;
     const int64_t row0 = (int64_t)rt * kTile + wave * 32;
     const int kc0 = nk.kb * KB, mc0 = nk.mb * MB;
     load_rows<ELT, LG, CX, NX>(xr, gd.x, row0, gd.rows, gd.k, kc0, lane);
@@ -364,56 +365,87 @@ __global__ void dw_gen_plan_kernel(const int64_t* __restrict__ ptr, int64_t B, c
   }
 }
 
+// The launch behind dw_gen_kernel (see seg_dw_fixup_kernel in matmul_dw.hip): workgroups [0, fix_blocks) add the slabs
+// of the (group, block) units that are split over main workgroups, in workgroup order; the ones behind them write the
+// zeros of groups without rows.
 template <typename T>
-__global__ void dw_gen_round_kernel(const float* __restrict__ acc, uint16_t* __restrict__ out, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if constexpr (__is_same(T, bf16_t)) out[i] = __builtin_bit_cast(uint16_t, (__bf16)acc[i]);
-  else out[i] = __builtin_bit_cast(uint16_t, (_Float16)acc[i]);
+__global__ __launch_bounds__(256) void dw_gen_fixup_kernel(const DwGenGroup* __restrict__ groups,
+                                                          const int32_t* __restrict__ tile_start, int B, int G,
+                                                          int fix_blocks, const float* __restrict__ slabs,
+                                                          T* __restrict__ out) {
+  constexpr int IB = GenCfg<T>::IB, JB = GenCfg<T>::JB, KB = 32 * IB, MB = 32 * JB, NBT = IB * JB;
+  using Pos = DwPosRows<IB, JB>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= fix_blocks) {
+    const DwGenGroup gd = groups[(int)blockIdx.x - fix_blocks];
+    if (gd.rows > 0) return;
+    T* base = out + gd.acc_off;
+    const int64_t n = (int64_t)gd.k * gd.m;
+    for (int64_t i = threadIdx.x; i < n; i += 256) dw_put(base + i, 0.0f);
+    return;
+  }
+  const int v = (int)blockIdx.x * 4 + wave;
+  const int bx = v / (4 * NBT), piece = v - bx * (4 * NBT);
+  const int bt = piece >> 2, q = piece & 3;
+  const int total = tile_start[B];
+  const int t_beg = (int)((int64_t)bx * total / G), t_end = (int)((int64_t)(bx + 1) * total / G);
+  if (t_beg >= t_end) return;
+  int lo = 0, hi = B;  // group of the range's last tile
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= t_end - 1) lo = mid; else hi = mid;
+  }
+  const DwGenGroup gd = groups[lo];
+  const int rt_n = (int)((gd.rows + kTile - 1) / kTile);
+  const int blk = (t_end - 1 - tile_start[lo]) / rt_n;
+  const int u0 = tile_start[lo] + blk * rt_n, u1 = u0 + rt_n;
+  if (!(u1 > t_end && u0 >= t_beg)) return;  // no split unit starts here
+  const int kb = blk / gd.nmb, mb = blk - kb * gd.nmb;
+  const dwf4 s = dw_chain_sum(slabs, (int64_t)NBT * kDwBlockFloats, 1, bx, 0, G, total, u1, bt, q, lane);
+  dw_quarter_to_out<Pos>(out + gd.acc_off + (int64_t)kb * KB * gd.m + mb * MB, gd.m, gd.k - kb * KB, gd.m - mb * MB, bt, q, s,
+                         lane);
 }
 
 template <typename T, int LG>
-int launch_gen_lg(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* acc, hipStream_t stream) {
+int launch_gen_lg(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* slabs, void* out_,
+                  hipStream_t stream) {
   constexpr int ELT = Elem<T>::kSize;
   constexpr int lds = 4 * 32 * (gen_pitch<ELT>(32 * GenCfg<T>::IB) + gen_pitch<ELT>(32 * GenCfg<T>::JB));
   static_assert(lds <= 160 * 1024, "dw_gen_kernel: LDS");
+  static_assert(lds >= GenCfg<T>::IB * GenCfg<T>::JB * 4096, "the combine area must fit the row images");
+  T* out = static_cast<T*>(out_);
   const void* kern = reinterpret_cast<const void*>(&dw_gen_kernel<T, LG>);
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(tiles_upper, device_info().num_cus));
-  hipLaunchKernelGGL((dw_gen_kernel<T, LG>), dim3((unsigned)gx), dim3(256), lds, stream, groups, tile_start, B, acc);
+  hipLaunchKernelGGL((dw_gen_kernel<T, LG>), dim3((unsigned)gx), dim3(256), lds, stream, groups, tile_start, B, slabs, out);
+  PYG_HIP_CHECK(hipGetLastError());
+  const int64_t fix_blocks = gx * GenCfg<T>::IB * GenCfg<T>::JB;
+  hipLaunchKernelGGL((dw_gen_fixup_kernel<T>), dim3((unsigned)(fix_blocks + B)), dim3(256), 0, stream, groups, tile_start, B,
+                     (int)gx, (int)fix_blocks, slabs, out);
   PYG_HIP_CHECK(hipGetLastError());
   return PYG_HIP_OK;
 }
 
 // `lg`: alignment class of the launch = the smallest over its groups' operands (log2 of the vector bytes)
 template <typename T>
-int launch_gen(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* acc, int lg,
+int launch_gen(const DwGenGroup* groups, const int32_t* tile_start, int B, int64_t tiles_upper, float* slabs, void* out, int lg,
                hipStream_t stream) {
-  if (lg >= 4) return launch_gen_lg<T, 4>(groups, tile_start, B, tiles_upper, acc, stream);
-  if (lg == 3) return launch_gen_lg<T, 3>(groups, tile_start, B, tiles_upper, acc, stream);
+  if (lg >= 4) return launch_gen_lg<T, 4>(groups, tile_start, B, tiles_upper, slabs, out, stream);
+  if (lg == 3) return launch_gen_lg<T, 3>(groups, tile_start, B, tiles_upper, slabs, out, stream);
   if constexpr (Elem<T>::kSize == 2) {
-    if (lg <= 1) return launch_gen_lg<T, 1>(groups, tile_start, B, tiles_upper, acc, stream);
+    if (lg <= 1) return launch_gen_lg<T, 1>(groups, tile_start, B, tiles_upper, slabs, out, stream);
   }
-  return launch_gen_lg<T, 2>(groups, tile_start, B, tiles_upper, acc, stream);
+  return launch_gen_lg<T, 2>(groups, tile_start, B, tiles_upper, slabs, out, stream);
 }
 
 inline int gen_kb(int dtype) { return dtype == PYG_F32 ? 32 * GenCfg<float>::IB : 32 * GenCfg<bf16_t>::IB; }
 inline int gen_mb(int dtype) { return dtype == PYG_F32 ? 32 * GenCfg<float>::JB : 32 * GenCfg<bf16_t>::JB; }
 
-int run_gen(int dtype, const DwGenGroup* groups, const int32_t* tile_start, int64_t B, int64_t tiles_upper, float* acc,
-            void* out, int64_t out_elems, int lg, hipStream_t stream) {
-  int rc = dtype == PYG_F32    ? launch_gen<float>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream)
-           : dtype == PYG_BF16 ? launch_gen<bf16_t>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream)
-                               : launch_gen<f16_t>(groups, tile_start, (int)B, tiles_upper, acc, lg, stream);
-  if (rc != PYG_HIP_OK || dtype == PYG_F32) return rc;  // fp32: the atomics went straight into the (zeroed) result
-  if (dtype == PYG_BF16)
-    hipLaunchKernelGGL(dw_gen_round_kernel<bf16_t>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(out), out_elems);
-  else
-    hipLaunchKernelGGL(dw_gen_round_kernel<f16_t>, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, stream, acc,
-                       static_cast<uint16_t*>(out), out_elems);
-  PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+int run_gen(int dtype, const DwGenGroup* groups, const int32_t* tile_start, int64_t B, int64_t tiles_upper, float* slabs,
+            void* out, int lg, hipStream_t stream) {
+  return dtype == PYG_F32    ? launch_gen<float>(groups, tile_start, (int)B, tiles_upper, slabs, out, lg, stream)
+         : dtype == PYG_BF16 ? launch_gen<bf16_t>(groups, tile_start, (int)B, tiles_upper, slabs, out, lg, stream)
+                             : launch_gen<f16_t>(groups, tile_start, (int)B, tiles_upper, slabs, out, lg, stream);
 }
 
 inline size_t gen_groups_bytes(int64_t B) { return align_up(sizeof(DwGenGroup) * (size_t)(B > 0 ? B : 1), 256); }
@@ -421,9 +453,11 @@ inline size_t gen_tiles_bytes(int64_t B) { return align_up(sizeof(int32_t) * (si
 
 }  // namespace
 
-size_t dw_gen_workspace_bytes(int64_t B, int64_t out_elems) {
-  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + gen_groups_bytes(B) + gen_tiles_bytes(B) +
-         align_up(sizeof(float) * (size_t)(out_elems > 0 ? out_elems : 1), 256);
+size_t dw_gen_workspace_bytes(int64_t B) {
+  // two fp32 slabs of one 128 x 128 block per main workgroup (the 16-bit configuration is the larger one)
+  const size_t slabs = (size_t)device_info().num_cus * 2 * (size_t)(GenCfg<bf16_t>::IB * GenCfg<bf16_t>::JB) * kDwBlockFloats *
+                       sizeof(float);
+  return align_up(sizeof(int64_t) * (size_t)(B + 1), 256) + gen_groups_bytes(B) + gen_tiles_bytes(B) + slabs;
 }
 
 int dw_gen_segment(int dtype, const void* input, const int64_t* ptr, int ptr_on_device, const void* grad_out,
@@ -445,7 +479,7 @@ int dw_gen_segment(int dtype, const void* input, const int64_t* ptr, int ptr_on_
   w += gen_groups_bytes(B);
   int32_t* tile_start = reinterpret_cast<int32_t*>(w);
   w += gen_tiles_bytes(B);
-  float* acc = dtype == PYG_F32 ? static_cast<float*>(grad_other) : reinterpret_cast<float*>(w);
+  float* slabs = reinterpret_cast<float*>(w);
   const int64_t* dptr = ptr;
   if (!ptr_on_device) {
     void* staged = nullptr;
@@ -457,14 +491,13 @@ int dw_gen_segment(int dtype, const void* input, const int64_t* ptr, int ptr_on_
     if (rc != PYG_HIP_OK) return rc;
     dptr = ptr_dev;
   }
-  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)B * (size_t)K * (size_t)M, stream));
   hipLaunchKernelGGL(dw_gen_plan_kernel, dim3(1), dim3(256), 0, stream, dptr, B, static_cast<const char*>(input),
                      static_cast<const char*>(grad_out), K, M, elt, kb, mb, groups, tile_start);
   PYG_HIP_CHECK(hipGetLastError());
   // a relation starts ptr[b] rows into the tensors: its alignment is at least that of the base and the row pitch
   const int lg = std::min(std::min(gen_log2_align((uint64_t)input), gen_log2_align((uint64_t)(K * elt))),
                           std::min(gen_log2_align((uint64_t)grad_out), gen_log2_align((uint64_t)(M * elt))));
-  return run_gen(dtype, groups, tile_start, B, tiles_upper, acc, grad_other, B * K * M, lg, stream);
+  return run_gen(dtype, groups, tile_start, B, tiles_upper, slabs, grad_other, lg, stream);
 }
 
 int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void* out_pool, void* workspace,
@@ -476,7 +509,7 @@ int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void*
   w += gen_groups_bytes(G);
   int32_t* tile_start = reinterpret_cast<int32_t*>(w);
   w += gen_tiles_bytes(G);
-  float* acc = dtype == PYG_F32 ? static_cast<float*>(out_pool) : reinterpret_cast<float*>(w);
+  float* slabs = reinterpret_cast<float*>(w);
   void* staged = nullptr;
   int rc = pinned_stage().acquire(gen_groups_bytes(G) + gen_tiles_bytes(G), &staged);
   if (rc != PYG_HIP_OK) return rc;
@@ -514,12 +547,11 @@ int dw_gen_grouped(int dtype, const pyg_hip_group* host_groups, int64_t G, void*
   rc = pinned_stage().commit(stream);
   if (rc != PYG_HIP_OK) return rc;
   if (off == 0) return PYG_HIP_OK;
-  PYG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(float) * (size_t)off, stream));
   if (t == 0) {  // no rows anywhere: the result is all zeros
-    if (dtype != PYG_F32) PYG_HIP_CHECK(hipMemsetAsync(out_pool, 0, (size_t)elt * (size_t)off, stream));
+    PYG_HIP_CHECK(hipMemsetAsync(out_pool, 0, (size_t)elt * (size_t)off, stream));
     return PYG_HIP_OK;
   }
-  return run_gen(dtype, groups, tile_start, G, t, acc, out_pool, off, lg, stream);
+  return run_gen(dtype, groups, tile_start, G, t, slabs, out_pool, lg, stream);
 }
 
 }  // namespace pyg_hip
