@@ -55,6 +55,15 @@ typedef enum {
 
 /* ---- library ----------------------------------------------------------------------------- */
 
+/* Version of THIS interface: bumped whenever a signature or the meaning of an argument changes, so that a caller built
+ * against an older header can tell (pyg_hip_abi_version() != the PYG_HIP_ABI_VERSION it was compiled with).
+ *   5: round 5 -- pyg_hip_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
+ *      pyg_hip_rgcn_fused became a bit field), pyg_hip_set_float_atomic_mode, pyg_hip_atomic_selftest,
+ *      pyg_hip_sampler_table_cache_release; the weight-gradient workspace holds partial slabs instead of an fp32 image.
+ *   4: round 4 -- `flags` in front of `stream` in pyg_hip_segment_matmul / pyg_hip_grouped_matmul, `index_sorted` of
+ *      pyg_hip_scatter became a bit field, pyg_hip_matmul_set_schedule / _set_f32_split removed, fp32 default = IEEE MFMAs. */
+#define PYG_HIP_ABI_VERSION 5
+PYG_HIP_API int pyg_hip_abi_version(void);
 /* Replaces pyg::cuda_version (pyg_lib/csrc/library.cpp:19-29): returns the HIP runtime version
  * the library was built against (HIP_VERSION), never -1. */
 PYG_HIP_API int64_t pyg_hip_version(void);
@@ -62,6 +71,32 @@ PYG_HIP_API int64_t pyg_hip_version(void);
 PYG_HIP_API const char* pyg_hip_last_error(void);
 /* Name of the offload architecture the kernels were compiled for ("gfx950"). */
 PYG_HIP_API const char* pyg_hip_arch(void);
+
+/*
+ * Floating-point accumulation through atomics.  The weight gradients, the large scatter / COO sums and the CSR family are
+ * atomic-free and bit-reproducible (as the reference's sequential CPU loops, ops/cpu/scatter_kernel.cpp:29-127,
+ * ops/autograd/matmul_kernel.cpp:92-107).  What still adds through atomics -- small or element-wise indexed
+ * scatter sums, float64 sums, pyg_hip_rgcn_fused -- uses the hardware's floating-point atomic adds by default
+ * (global_atomic_add_f32 / _f64 / _pk_add_bf16 / _pk_add_f16) and can be switched to compare-and-swap loops on the containing
+ * word: per call (PYG_HIP_SCATTER_CAS, PYG_HIP_RGCN_CAS) or as the process-wide default below (0 = hardware adds,
+ * 1 = CAS loops; initial value from the environment, PYG_HIP_FLOAT_ATOMICS=hw|cas).  Same sums up to the order the adds
+ * land in; the CAS form is 1.5 - 3x slower on contended rows.  Returns the previous default.
+ */
+PYG_HIP_API int pyg_hip_set_float_atomic_mode(int mode);
+/* What the calling process's LAST launch of an atomically accumulating kernel was (thread-local text buffer): operator,
+ * accumulator address / bytes / hipPointerGetAttributes, who cleared it and how, stream, flavour.  For failure reports. */
+PYG_HIP_API const char* pyg_hip_last_accumulate_info(void);
+/*
+ * In-process health check of "clear an accumulator, add to it from all over the chip, read it back" on the CALLER'S memory
+ * and stream: 5 add flavours (hw f32 / packed bf16 / f64, CAS f32, int32) x 3 ways of clearing (hipMemsetAsync, fill kernel
+ * with plain stores, fill kernel with write-through stores) x 2 readbacks (copy kernel + D2H, D2H), `rounds` times each,
+ * the accumulator scribbled with NaN patterns before every round.  `scratch`: >= 64 KiB of 16-byte aligned device memory
+ * (up to 16 MiB are used).  Writes a text report (one line per failing variant, classified: NaN = the clear never
+ * arrived, low = updates lost / clear late / stale read, high = doubled) and returns the number of failing variants
+ * (0 = healthy) or a negative pyg_hip_status.  Synchronises `stream`.
+ */
+PYG_HIP_API int pyg_hip_atomic_selftest(void* scratch, size_t scratch_bytes, int rounds, char* report, size_t report_cap,
+                                        void* stream);
 
 /* ---- segment_matmul / grouped_matmul ------------------------------------------------------ */
 
@@ -231,11 +266,14 @@ PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int6
  *   x [num_x_rows, K], out [num_out_rows, M] (ACCUMULATED into: zero it for a plain aggregation), both `dtype`
  *   (PYG_BF16 / PYG_F16) row-major; K = M = 128 (other shapes: PYG_HIP_ERR_UNSUPPORTED, the caller keeps the
  *   three-op chain).  Messages are rounded to `dtype` once (as the chain does), runs of equal destination are
- *   summed in fp32 and added with packed 16-bit atomics.  `relations` is a host array.  Never synchronises --
- *   unless `checked` != 0: then every gather / scatter index is validated against num_x_rows (x_rows, gather_map_len)
+ *   summed in fp32 and added with packed 16-bit atomics.  `relations` is a host array.  `checked` is a bit field
+ *   (PYG_HIP_RGCN_*): PYG_HIP_RGCN_CAS makes the packed adds compare-and-swap loops (see pyg_hip_set_float_atomic_mode).
+ *   Never synchronises -- unless PYG_HIP_RGCN_CHECKED is set: then every gather / scatter index is validated against num_x_rows (x_rows, gather_map_len)
  *   / num_out_rows on the device, offenders are redirected to row 0, and the call waits for the stream and returns
  *   PYG_HIP_ERR_INVALID if there was one (unchecked, a bad index is an out-of-bounds read / an atomic into foreign memory).
  */
+#define PYG_HIP_RGCN_CHECKED 1
+#define PYG_HIP_RGCN_CAS 2
 PYG_HIP_API int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* relations,
                                    int64_t num_relations, void* out, int64_t num_out_rows, int64_t K, int64_t M,
                                    int checked, void* workspace, size_t workspace_bytes, void* stream);
@@ -505,9 +543,12 @@ typedef enum {
  *             order -- deterministic, fp32 accumulation with one rounding per output, every output row written
  *             once; min / max: no CAS loops, no second arg pass, same exact values and first-match arg.  Without it
  *             (and for small or element-wise indexed inputs, float64 sums) the atomic kernels run.
+ *             Bit 2 (PYG_HIP_SCATTER_CAS): the atomic kernels add floats / doubles / packed 16-bit pairs through
+ *             compare-and-swap loops instead of the hardware's floating-point atomic adds.
  */
 #define PYG_HIP_SCATTER_SORTED 1
 #define PYG_HIP_SCATTER_FRESH_SUM 2
+#define PYG_HIP_SCATTER_CAS 4
 PYG_HIP_API size_t pyg_hip_scatter_workspace_size(int64_t B, int64_t E, int64_t N);
 PYG_HIP_API int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index,
                                 int64_t index_stride_b, int64_t index_stride_e,

@@ -12,6 +12,7 @@ _HERE = osp.dirname(osp.abspath(__file__))
 _LIB = None
 
 OK = 0
+ABI_VERSION = 5  # PYG_HIP_ABI_VERSION of the include/pyg_hip.h these bindings were written against
 DTYPES = {
     torch.float32: 0,
     torch.float64: 1,
@@ -46,6 +47,11 @@ def lib() -> ctypes.CDLL:
                 f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         L = ctypes.CDLL(path)
         c = ctypes
+        # a library built from another revision of the header would take `stream` for `flags`: refuse it
+        if not hasattr(L, 'pyg_hip_abi_version') or L.pyg_hip_abi_version() != ABI_VERSION:
+            got = L.pyg_hip_abi_version() if hasattr(L, 'pyg_hip_abi_version') else '< 5'
+            raise ImportError(f"pyg_lib_amd: '{path}' implements C-ABI version {got}, these bindings need {ABI_VERSION}; "
+                              f"rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
         L.pyg_hip_version.restype = c.c_int64
         L.pyg_hip_last_error.restype = c.c_char_p
         L.pyg_hip_arch.restype = c.c_char_p
@@ -58,6 +64,11 @@ def lib() -> ctypes.CDLL:
                                              c.c_size_t, c.c_int, c.c_void_p]
         L.pyg_hip_grouped_matmul.restype = c.c_int
         L.pyg_hip_grouped_matmul.argtypes = [c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_size_t, c.c_int, c.c_void_p]
+        L.pyg_hip_set_float_atomic_mode.restype = c.c_int
+        L.pyg_hip_set_float_atomic_mode.argtypes = [c.c_int]
+        L.pyg_hip_last_accumulate_info.restype = c.c_char_p
+        L.pyg_hip_atomic_selftest.restype = c.c_int
+        L.pyg_hip_atomic_selftest.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_char_p, c.c_size_t, c.c_void_p]
         _LIB = L
     return _LIB
 

@@ -85,6 +85,15 @@ struct PinnedStage {
 };
 PinnedStage& pinned_stage();
 
+// Float-atomic flavour of the kernels that still accumulate through atomics (reduce.hip's small / element-wise sums, the
+// fused R-GCN kernel): 0 = hardware adds (global_atomic_add_f32 / _f64 / _pk_add_bf16 / _pk_add_f16), 1 = compare-and-swap
+// loops on the containing 32- / 64-bit word.  Process-wide DEFAULT (environment PYG_HIP_FLOAT_ATOMICS=hw|cas, read once;
+// pyg_hip_set_float_atomic_mode overrides it): a call's own flag bit (PYG_HIP_SCATTER_CAS, PYG_HIP_RGCN_CAS) also selects
+// the CAS form.
+int float_atomic_mode();
+// remembered for pyg_hip_last_accumulate_info (failure reports): what the last atomically accumulating launch was
+void note_accumulate(const char* op, const void* ptr, size_t bytes, const char* cleared, hipStream_t stream, int cas);
+
 // int64 key sort shared between index_sort and the sort-based scatter (index_sort.hip).  `max_value`
 // bounds the (non-negative) keys, so no device->host read is needed.
 size_t index_sort_ws_bytes_i64(int64_t n);

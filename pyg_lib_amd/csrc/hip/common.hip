@@ -1,6 +1,10 @@
 // Library-level entry points and shared host helpers (see include/pyg_hip.h).
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -11,6 +15,36 @@ namespace pyg_hip {
 char* last_error_buffer() {
   static thread_local char buf[kErrLen] = {0};
   return buf;
+}
+
+namespace {
+std::atomic<int> g_float_atomic_mode{-1};  // -1: not read yet
+}
+int float_atomic_mode() {
+  int m = g_float_atomic_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("PYG_HIP_FLOAT_ATOMICS");
+    m = (e && (!strcmp(e, "cas") || !strcmp(e, "CAS") || !strcmp(e, "1"))) ? 1 : 0;
+    g_float_atomic_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+
+namespace {
+struct AccumNote {
+  const char* op = nullptr;
+  const void* ptr = nullptr;
+  size_t bytes = 0;
+  const char* cleared = nullptr;
+  void* stream = nullptr;
+  int cas = 0;
+};
+std::mutex g_note_mu;
+AccumNote g_note;
+}  // namespace
+void note_accumulate(const char* op, const void* ptr, size_t bytes, const char* cleared, hipStream_t stream, int cas) {
+  std::lock_guard<std::mutex> lock(g_note_mu);
+  g_note.op = op, g_note.ptr = ptr, g_note.bytes = bytes, g_note.cleared = cleared, g_note.stream = (void*)stream, g_note.cas = cas;
 }
 
 const DeviceInfo& device_info() {
@@ -88,6 +122,37 @@ PinnedStage& pinned_stage() {
 extern "C" {
 
 int64_t pyg_hip_version(void) { return (int64_t)HIP_VERSION; }
+
+int pyg_hip_abi_version(void) { return PYG_HIP_ABI_VERSION; }
+
+int pyg_hip_set_float_atomic_mode(int mode) {
+  const int before = pyg_hip::float_atomic_mode();
+  pyg_hip::g_float_atomic_mode.store(mode ? 1 : 0, std::memory_order_relaxed);
+  return before;
+}
+
+const char* pyg_hip_last_accumulate_info(void) {
+  static thread_local char buf[512];
+  pyg_hip::AccumNote n;
+  {
+    std::lock_guard<std::mutex> lock(pyg_hip::g_note_mu);
+    n = pyg_hip::g_note;
+  }
+  if (n.op == nullptr) {
+    snprintf(buf, sizeof(buf), "no atomically accumulating kernel has been launched by this process");
+    return buf;
+  }
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  const hipError_t pa = hipPointerGetAttributes(&attr, n.ptr);
+  if (pa != hipSuccess) (void)hipGetLastError();  // (a freed accumulator is not an error of the caller's next launch)
+  snprintf(buf, sizeof(buf), "%s: accumulator %p (%zu bytes; %s, device %d, managed %d, allocation flags 0x%x), cleared by %s, stream %p, %s adds",
+           n.op, n.ptr, n.bytes,
+           pa != hipSuccess ? "attributes unavailable" : (attr.type == hipMemoryTypeDevice ? "device memory" : "NOT plain device memory"),
+           pa == hipSuccess ? attr.device : -1, pa == hipSuccess ? (int)attr.isManaged : -1, pa == hipSuccess ? attr.allocationFlags : 0u,
+           n.cleared, n.stream, n.cas ? "compare-and-swap" : "hardware floating-point atomic");
+  return buf;
+}
 
 const char* pyg_hip_last_error(void) { return pyg_hip::last_error_buffer(); }
 

@@ -78,9 +78,16 @@ __device__ void atomic_rmw(T* addr, F f) {
   }
 }
 
-template <typename T>
+// CAS = true (PYG_HIP_SCATTER_CAS / PYG_HIP_FLOAT_ATOMICS=cas): float and double adds through a compare-and-swap loop
+// instead of the hardware's floating-point atomic unit (same sum, same one rounding per add).
+template <typename T, bool CAS = false>
 __device__ void atomic_add(T* addr, typename Math<T>::acc_t v) {
-  if constexpr (std::is_same<T, float>::value) {
+  if constexpr (CAS && (std::is_same<T, float>::value || std::is_same<T, double>::value)) {
+    atomic_rmw(addr, [v](T cur, T* nv) {
+      *nv = cur + v;
+      return true;
+    });
+  } else if constexpr (std::is_same<T, float>::value) {
     unsafeAtomicAdd(addr, v);  // global_atomic_add_f32
   } else if constexpr (std::is_same<T, double>::value) {
     unsafeAtomicAdd(addr, v);  // global_atomic_add_f64
@@ -132,7 +139,7 @@ __device__ __forceinline__ int64_t index_at(const int64_t* index, const Shape& s
 }
 
 // ---- generic element-per-thread kernels -------------------------------------------------------------
-template <typename T, int OP>
+template <typename T, int OP, bool CAS = false>
 __global__ void scatter_elem_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* out,
                                     Shape s) {
   const int64_t total = s.B * s.E * s.K;
@@ -144,7 +151,7 @@ __global__ void scatter_elem_kernel(const T* __restrict__ src, const int64_t* __
     const int64_t idx = index_at(index, s, b, e, k);
     T* dst = out + (b * s.N + idx) * s.K + k;
     const T v = src[i];
-    if (OP == OP_SUM) atomic_add<T>(dst, Math<T>::up(v));
+    if (OP == OP_SUM) atomic_add<T, CAS>(dst, Math<T>::up(v));
     else if (OP == OP_MUL) atomic_mul<T>(dst, v);
     else if (OP == OP_MIN) atomic_minmax<T, true>(dst, v);
     else atomic_minmax<T, false>(dst, v);
@@ -213,6 +220,9 @@ struct Vec<float> {
   __device__ static void flush(float* dst, const float* a) {
     for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, a[i]);
   }
+  __device__ static void flush_cas(float* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) atomic_add<float, true>(dst + i, a[i]);
+  }
   __device__ static void add_plain(float* dst, const float* a) {  // rows owned by this thread only
     float4 v = *reinterpret_cast<float4*>(dst);
     v.x += a[0]; v.y += a[1]; v.z += a[2]; v.w += a[3];
@@ -235,6 +245,18 @@ struct Vec<bf16_t> {
       // global_atomic_pk_add_bf16
       (void)__builtin_amdgcn_global_atomic_fadd_v2bf16(
           (__attribute__((address_space(1))) bf16x2*)(dst + 2 * i), p);
+    }
+  }
+  // the same packed add as a CAS loop on the pair's 32-bit word: each half = round(bf16(half) + bf16(a))
+  __device__ static void flush_cas(bf16_t* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) {
+      const float p0 = (float)(__bf16)a[2 * i], p1 = (float)(__bf16)a[2 * i + 1];
+      atomic_rmw(reinterpret_cast<uint32_t*>(dst + 2 * i), [p0, p1](uint32_t cur, uint32_t* nv) {
+        const uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)(__builtin_bit_cast(float, cur << 16) + p0));
+        const uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)(__builtin_bit_cast(float, cur & 0xffff0000u) + p1));
+        *nv = (uint32_t)lo | ((uint32_t)hi << 16);
+        return true;
+      });
     }
   }
   __device__ static void add_plain(bf16_t* dst, const float* a) {
@@ -266,6 +288,17 @@ struct Vec<f16_t> {
           (__attribute__((address_space(1))) f16x2*)(dst + 2 * i), p);
     }
   }
+  __device__ static void flush_cas(f16_t* dst, const float* a) {
+    for (int i = 0; i < 4; ++i) {
+      const float p0 = (float)(_Float16)a[2 * i], p1 = (float)(_Float16)a[2 * i + 1];
+      atomic_rmw(reinterpret_cast<uint32_t*>(dst + 2 * i), [p0, p1](uint32_t cur, uint32_t* nv) {
+        const uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, (uint16_t)(cur & 0xffffu)) + p0));
+        const uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, (uint16_t)(cur >> 16)) + p1));
+        *nv = (uint32_t)lo | ((uint32_t)hi << 16);
+        return true;
+      });
+    }
+  }
   __device__ static void add_plain(f16_t* dst, const float* a) {
     float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unpack(*reinterpret_cast<const u32x4*>(dst), cur);
@@ -285,7 +318,7 @@ struct Vec<f16_t> {
 // added with a plain 16-byte read-modify-write; only the first and last run of a chunk (which may
 // continue in the neighbouring chunks) use atomics.  Unsorted input: 8 positions, every flush atomic.
 // perm (optional): source row of sorted position e (scatter via index_sort); index is then the SORTED key.
-template <typename T, bool SORTED>
+template <typename T, bool SORTED, bool CAS = false>
 __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restrict__ src,
                                                               const int64_t* __restrict__ index,
                                                               const int64_t* __restrict__ perm, T* out,
@@ -327,6 +360,7 @@ __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restric
         if (idx != cur) {
           T* dst = out + (b * s.N + cur) * s.K + c * VN;
           if (SORTED && !first) Vec<T>::add_plain(dst, acc);
+          else if (CAS) Vec<T>::flush_cas(dst, acc);
           else Vec<T>::flush(dst, acc);
           first = false;
 #pragma unroll
@@ -336,7 +370,8 @@ __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restric
         Vec<T>::unpack(val[u], acc);
       }
     }
-    Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
+    if (CAS) Vec<T>::flush_cas(out + (b * s.N + cur) * s.K + c * VN, acc);
+    else Vec<T>::flush(out + (b * s.N + cur) * s.K + c * VN, acc);
   }
 }
 
@@ -425,6 +460,7 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
   // PYG_HIP_SCATTER_FRESH_SUM: `out` of a sum is uninitialised.  The sorted (CSR-row) path writes every slot and never
   // reads it; every other path accumulates into zeros, cleared here.
   const bool fresh_sum = op == OP_SUM && (sorted & PYG_HIP_SCATTER_FRESH_SUM) != 0;
+  const bool cas = (sorted & PYG_HIP_SCATTER_CAS) != 0 || float_atomic_mode() == 1;
   sorted &= PYG_HIP_SCATTER_SORTED;
   const bool csr_rows = op == OP_SUM && sorted && s.isk == 0 && ws && ws_bytes >= scatter_indptr_bytes(s.B, s.N) && total > 0;
   // one large unsorted index vector, rows of >= 64 bytes: sort the E indices once (3-4 radix passes over 16 E bytes),
@@ -436,6 +472,9 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
                          ws_bytes >= scatter_sort_ws_bytes(s.E) + scatter_indptr_bytes(1, s.N);
   if (fresh_sum && !csr_rows && !sort_rows && outn > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(T) * (size_t)outn, stream));
   if (total == 0) return PYG_HIP_OK;
+  if (op == OP_SUM && !csr_rows && !sort_rows && (std::is_floating_point<T>::value || float_t))
+    note_accumulate("pyg_hip_scatter (sum, atomic kernels)", out, sizeof(T) * (size_t)outn,
+                    fresh_sum ? "this call (hipMemsetAsync on the call's stream)" : "the caller (`out=` accumulation)", stream, cas ? 1 : 0);
   const unsigned grid = grid_for(total);
   if (csr_rows) {
     // COO contract (index ascending along e): buckets are CSR rows -- summed in source order in opmath,
@@ -468,14 +507,29 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
       if (s.isk == 0 && s.K % Vec<T>::N == 0 && aligned16(src) && aligned16(out)) {
         if (sorted) {
           const int64_t threads = s.B * ((s.E + 31) / 32) * (s.K / Vec<T>::N);
-          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
-                             src, index, (const int64_t*)nullptr, out, s);
+          if (cas)
+            hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true, true>), dim3(grid_for(threads)), dim3(256), 0, stream, src,
+                               index, (const int64_t*)nullptr, out, s);
+          else
+            hipLaunchKernelGGL((scatter_sum_vec_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream,
+                               src, index, (const int64_t*)nullptr, out, s);
           PYG_HIP_CHECK(hipGetLastError());
           return PYG_HIP_OK;
         }
         const int64_t threads = s.B * ((s.E + 7) / 8) * (s.K / Vec<T>::N);
-        hipLaunchKernelGGL((scatter_sum_vec_kernel<T, false>), dim3(grid_for(threads)), dim3(256), 0, stream,
-                           src, index, (const int64_t*)nullptr, out, s);
+        if (cas)
+          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, false, true>), dim3(grid_for(threads)), dim3(256), 0, stream, src,
+                             index, (const int64_t*)nullptr, out, s);
+        else
+          hipLaunchKernelGGL((scatter_sum_vec_kernel<T, false>), dim3(grid_for(threads)), dim3(256), 0, stream,
+                             src, index, (const int64_t*)nullptr, out, s);
+        PYG_HIP_CHECK(hipGetLastError());
+        return PYG_HIP_OK;
+      }
+    }
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, double>::value) {
+      if (cas) {
+        hipLaunchKernelGGL((scatter_elem_kernel<T, OP_SUM, true>), dim3(grid), dim3(256), 0, stream, src, index, out, s);
         PYG_HIP_CHECK(hipGetLastError());
         return PYG_HIP_OK;
       }

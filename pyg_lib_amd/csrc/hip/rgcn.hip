@@ -115,6 +115,22 @@ __device__ __forceinline__ void atomic_add_pk_bits(char* addr, uint32_t packed) 
   }
 }
 
+// The same add as a compare-and-swap loop on the pair's word (PYG_HIP_RGCN_CAS / PYG_HIP_FLOAT_ATOMICS=cas: the diagnostic
+// flavour that does not use the hardware's floating-point atomic unit).
+template <bool BF16>
+__device__ __forceinline__ void cas_add_pk_bits(char* addr, uint32_t packed) {
+  unsigned int* p = reinterpret_cast<unsigned int*>(addr);
+  float a, b;
+  unpack2<BF16>(packed, &a, &b);
+  unsigned int old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    float c, d;
+    unpack2<BF16>(old, &c, &d);
+    const unsigned int want = pack2<BF16>(c + a, d + b);
+    if (__hip_atomic_compare_exchange_strong(p, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  }
+}
+
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 
 // K = M = 128, 16-bit T
@@ -163,7 +179,8 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RgcnDesc desc, in
     if constexpr (INL) return desc.irels[i];
     else return desc.rels[i];
   };
-  // dbg (0 in the product; PYG_HIP_RGCN_DBG of an experiment build): 1 no atomics, 2 no row gathers, 4 no MFMAs / scatter,
+  // dbg bit 5 (32): the packed adds as CAS loops (PYG_HIP_RGCN_CAS).  The other bits are 0 in the product
+  // (PYG_HIP_RGCN_DBG of an experiment build): 1 no atomics, 2 no row gathers, 4 no MFMAs / scatter,
   // 8 no scatter walk, 16 one MFMA k-step instead of eight
   constexpr int NT = 4, NI = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -414,7 +431,8 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RgcnDesc desc, in
       const int r = __builtin_ctz(m);
       const int64_t d = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(si_hi, r) << 32) |
                                   (uint32_t)__builtin_amdgcn_readlane(si_lo, r));
-      if (!(dbg & 1)) atomic_add_pk_bits<BF16>(out + d * 256 + (uint32_t)(lane * 4), mv[r]);
+      if (dbg & 32) cas_add_pk_bits<BF16>(out + d * 256 + (uint32_t)(lane * 4), mv[r]);
+      else if (!(dbg & 1)) atomic_add_pk_bits<BF16>(out + d * 256 + (uint32_t)(lane * 4), mv[r]);
     }
   }
 }
@@ -506,12 +524,14 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   }
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
+  const bool cas = (checked & PYG_HIP_RGCN_CAS) != 0 || float_atomic_mode() == 1;
+  checked &= PYG_HIP_RGCN_CHECKED;
   if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
   const void* kern;
   {
 #define PYG_RGCN_PICK3(BF, CK, BG) (inl ? (const void*)&rgcn_fused_kernel<BF, CK, BG, true> : (const void*)&rgcn_fused_kernel<BF, CK, BG, false>)
 #define PYG_RGCN_PICK(BF, CK, BG) PYG_RGCN_PICK3(BF, CK, BG)
-    const bool bf = dtype == PYG_BF16, ck = checked != 0;
+    const bool bf = dtype == PYG_BF16, ck = (checked & PYG_HIP_RGCN_CHECKED) != 0;
     kern = bf ? (ck ? (big ? PYG_RGCN_PICK(true, true, true) : PYG_RGCN_PICK(true, true, false))
                     : (big ? PYG_RGCN_PICK(true, false, true) : PYG_RGCN_PICK(true, false, false)))
               : (ck ? (big ? PYG_RGCN_PICK(false, true, true) : PYG_RGCN_PICK(false, true, false))
@@ -529,6 +549,8 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   if (const char* e = getenv("PYG_HIP_RGCN_MIN_TILES")) min_tiles = std::max(1, atoi(e));
   if (const char* e = getenv("PYG_HIP_RGCN_DBG")) dbg = atoi(e);
 #endif
+  if (cas) dbg |= 32;
+  note_accumulate("pyg_hip_rgcn_fused", out, (size_t)num_out_rows * 256, "the caller (`out` is accumulated into)", stream, cas ? 1 : 0);
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((tiles + min_tiles - 1) / min_tiles, per_cu * (int64_t)device_info().num_cus));
   char* outc = static_cast<char*>(out);
   int Ri = (int)R;

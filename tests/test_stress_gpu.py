@@ -422,3 +422,82 @@ def test_bench_two_ranks_on_one_device_exercises_the_sharded_branch():
     assert 'ms' in r['allgather'] and r['allgather']['backend'] == 'gloo', r['allgather']
     assert r['c4']['n_gpus'] == 2 and 'incl_allgather' in r['c4'] and r['c4']['compute_only']['ms'] > 0, r['c4']
     assert r['roofline']['kernel'].startswith('mfma_')
+
+
+# ---- the compare-and-swap flavour of the remaining float atomics, the in-process self-test --------
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16, torch.float64])
+@pytest.mark.parametrize('K', [128, 5])
+def test_scatter_sum_cas_mode_is_exact(dtype, K):
+    """`PYG_HIP_FLOAT_ATOMICS=cas` / pyg_hip_set_float_atomic_mode(1): scatter_sum_vec_kernel (16-byte rows) and
+    scatter_elem_kernel (K = 5, float64) add through compare-and-swap loops on the containing word instead of the
+    hardware's floating-point atomic unit.  Integer-valued data: both flavours must give the float64 sums exactly."""
+    from pyg_lib_amd import diagnostics
+    g = torch.Generator().manual_seed(K + 1)
+    E, N = 20000, 700
+    src = torch.randint(-2, 3, (E, K), generator=g).float()
+    index = torch.randint(0, N, (E,), generator=g)
+    want = torch.zeros(N, K, dtype=torch.float64).index_add_(0, index, src.double())
+    sd, idx = src.to(dtype).to(DEV), index.to(DEV)
+    before = diagnostics.set_float_atomic_mode('cas')
+    try:
+        _repeat_exact(lambda: ops.scatter_sum(sd, idx, 0, None, N), want, reps=6)
+        assert 'compare-and-swap' in diagnostics.last_accumulate_info()
+        base = torch.randint(-4, 5, (N, K), generator=g).float()
+        out = ops.scatter_sum(sd, idx, 0, base.to(dtype).to(DEV), N)
+        assert torch.equal(out.double().cpu(), base.double() + want)
+    finally:
+        assert diagnostics.set_float_atomic_mode(before) == 'cas'
+    _repeat_exact(lambda: ops.scatter_sum(sd, idx, 0, None, N), want, reps=2)
+    assert 'hardware' in diagnostics.last_accumulate_info()
+
+
+def test_fused_rgcn_cas_mode_is_exact():
+    from pyg_lib_amd import diagnostics, rgcn
+    g = torch.Generator().manual_seed(5)
+    n, F = 3000, 128
+    x = torch.randint(-3, 4, (n, F), generator=g).float()
+    counts = [20_000, 0, 17, 4096 + 33]
+    ets = [('a', f'r{i}', 'a') for i in range(len(counts))]
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in counts])
+    W = torch.zeros(len(counts), F, F)
+    W[torch.arange(len(counts))[:, None], perm, torch.arange(F)[None, :]] = \
+        (torch.randint(0, 2, (len(counts), F), generator=g) * 2 - 1).float()
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        rows[et] = torch.sort(torch.randint(0, 1500, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    want = torch.zeros(n, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), x[cols[et].cpu()].double() @ W[i].double())
+    assert want.abs().max() <= 256
+    for dtype in (torch.bfloat16, torch.float16):
+        xd, Wd = x.to(dtype).cuda(), W.to(dtype).cuda()
+        before = diagnostics.set_float_atomic_mode('cas')
+        try:
+            for rep in range(4):
+                y = rgcn.rgcn_layer_fused(xd, off, rows, cols, ets, Wd)
+                assert torch.equal(y.double().cpu(), want), (dtype, rep)
+            assert 'pyg_hip_rgcn_fused' in diagnostics.last_accumulate_info() and 'compare-and-swap' in diagnostics.last_accumulate_info()
+        finally:
+            diagnostics.set_float_atomic_mode(before)
+        y = rgcn.rgcn_layer_fused(xd, off, rows, cols, ets, Wd)
+        assert torch.equal(y.double().cpu(), want)
+
+
+def test_atomic_selftest_is_clean_and_reports_the_memory_it_ran_on():
+    """pyg_hip_atomic_selftest on a block of the caching allocator and torch's current stream: 30 variants (5 add flavours x
+    3 ways of clearing x 2 readbacks), every one must deliver every update -- also on a side stream with a noise stream
+    next to it."""
+    from pyg_lib_amd import diagnostics
+    bad, text = diagnostics.atomic_selftest(rounds=3)
+    assert bad == 0, text
+    assert 'device memory' in text and '0 of 30 variants bad' in text
+    noise = Noise()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        noise.burst(8)
+        bad, text = diagnostics.atomic_selftest(rounds=2, megabytes=4)
+    assert bad == 0, text
+    torch.cuda.synchronize()
