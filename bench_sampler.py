@@ -25,7 +25,7 @@ def make_graph(device, seed=0):
     return rowptr, col
 
 
-def run(device, batches=50, warmup=5, cpu_batches=2):
+def run(device, batches=48, warmup=5, cpu_batches=2, batched_k=16):
     from pyg_lib_amd import sampler
     rowptr, col = make_graph(device)
     g = torch.Generator(device='cpu').manual_seed(1)
@@ -53,6 +53,28 @@ def run(device, batches=50, warmup=5, cpu_batches=2):
     alg = 16 * F + 32 * sum(eh) + 8 * sum(nh)
     res['alg_bytes_per_batch'] = int(alg)
     res['alg_GBps'] = round(alg / (dt / batches) / 1e9, 2)
+    # K independent batches per call (pyg_hip_hetero_neighbor_sample_batched): the epoch loop handed over K batches at a
+    # time, one generator seed per batch (BASELINE.md's C3 protocol reseeds per batch); results bit-exact per batch
+    # (tests/test_sampler_batched_gpu.py)
+    if batched_k > 1:
+        K = batched_k
+        calls = max(1, batches // K)
+        lists = [[seeds[warmup + (c * K + k) % batches] for k in range(K)] for c in range(calls)]
+        gs = [[12345 + c * K + k for k in range(K)] for c in range(calls)]
+        for c in range(min(2, calls)):
+            sampler.neighbor_sample_batched(rowptr, col, lists[c], FANOUT, gs[c])
+        torch.cuda.synchronize()
+        be = 0
+        t0 = time.perf_counter()
+        for c in range(calls):
+            outs = sampler.neighbor_sample_batched(rowptr, col, lists[c], FANOUT, gs[c])
+            be += sum(sum(o[5]) for o in outs)
+        torch.cuda.synchronize()
+        bdt = time.perf_counter() - t0
+        res['batched'] = dict(K=K, calls=calls, value=round(be / bdt, 1), unit='edges/s',
+                              ms_per_batch=round(bdt / (calls * K) * 1e3, 4), speedup_vs_single=round(be / bdt / res['value'], 2),
+                              alg_GBps=round(alg / (bdt / (calls * K)) / 1e9, 2),
+                              what='neighbor_sample_batched: K batches per call on private streams, one host thread per lane')
     if cpu_batches > 0:
         import oracle
         rp, cl = rowptr.cpu().numpy(), col.cpu().numpy()

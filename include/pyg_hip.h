@@ -57,7 +57,7 @@ typedef enum {
 
 /* Version of THIS interface: bumped whenever a signature or the meaning of an argument changes, so that a caller built
  * against an older header can tell (pyg_hip_abi_version() != the PYG_HIP_ABI_VERSION it was compiled with).
- *   5: round 5 -- pyg_hip_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
+ *   5: round 5 -- pyg_hip_hetero_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
  *      pyg_hip_rgcn_fused became a bit field), pyg_hip_set_float_atomic_mode, pyg_hip_atomic_selftest,
  *      pyg_hip_sampler_table_cache_release; the weight-gradient workspace holds partial slabs instead of an fp32 image.
  *   4: round 4 -- `flags` in front of `stream` in pyg_hip_segment_matmul / pyg_hip_grouped_matmul, `index_sorted` of
@@ -403,6 +403,10 @@ PYG_HIP_API const char* pyg_hip_sampler_last_mode(void);
  * `limit` = epochs per clear (0: the default 2^20 - 1); returns the number of tables cached for the current device.
  * PYG_HIP_SAMPLER_TABLE_CACHE=0 disables the cache (every call clears a fresh table, as before round 4). */
 PYG_HIP_API int pyg_hip_sampler_table_cache(int64_t limit);
+/* Frees the cached tables of the current device that no call is using, through host->free (the allocator they came
+ * from); returns how many stay (busy ones).  The cache holds at most 8 tables of <= 128 MiB per device; an idle table
+ * of another node count is evicted when a new size needs room. */
+PYG_HIP_API int pyg_hip_sampler_table_cache_release(const pyg_hip_sampler_host* host);
 
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                                const pyg_hip_relation* relations_host,
@@ -413,6 +417,35 @@ PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relat
                                                int disjoint, int return_edge_id,
                                                const pyg_hip_sampler_host* host,
                                                pyg_hip_sample_result* result, void* stream);
+
+/*
+ * K independent sampler calls on one graph at once (the epoch loop of the reference's benchmark,
+ * benchmark/sampler/neighbor.py:101-121, handed over as a whole; semantics per batch: sampler/cpu/neighbor_kernel.cpp
+ * :332-514 / :518-841).  Batch b = its own seed sets, its own `host` (allocator context + generator state: every batch
+ * continues ITS OWN mt19937 stream -- torch.manual_seed(s_b) per batch is the reference benchmark's protocol) and its own
+ * result; everything else is shared.  Results are bit for bit those of pyg_hip_hetero_neighbor_sample on each batch alone.
+ * Batches that name different `stream`s are driven by different host threads of a persistent pool inside the library and
+ * overlap on the device (a single batch is a chain of ~12 small dependent launches that cannot fill 256 CUs); batches on the
+ * same stream run one after the other.  host->alloc of a batch must allocate for THAT batch's stream.  `stream` = the
+ * caller's stream: work queued on it before the call is ordered in front of every batch; all batches are complete (their
+ * streams synchronised) when the call returns.  Returns the first failing batch's status; `status` / `error` / `mode`
+ * (pyg_hip_sampler_last_mode of that batch) are filled per batch.
+ */
+typedef struct {
+  int num_seed_sets;
+  const pyg_hip_seed_set* seeds_host;
+  const pyg_hip_sampler_host* host;
+  pyg_hip_sample_result* result;
+  void* stream;
+  int status;         /* out */
+  const char* mode;   /* out */
+  char error[256];    /* out */
+} pyg_hip_sample_batch;
+PYG_HIP_API int pyg_hip_hetero_neighbor_sample_batched(int num_node_types, int num_relations,
+                                                       const pyg_hip_relation* relations_host,
+                                                       const int64_t* const* node_time_by_type, int temporal_last,
+                                                       int L, int csc, int replace, int disjoint, int return_edge_id,
+                                                       int num_batches, pyg_hip_sample_batch* batches, void* stream);
 
 /*
  * The float32 logarithm biased sampling evaluates (key = log(u) / weight), element-wise over device arrays.

@@ -676,6 +676,118 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
   return out;
 }
 
+// ---- K independent batches at once (pyg_hip_hetero_neighbor_sample_batched) ----------------------------------------
+// Private streams of the batched sampler, per device: batch b runs on lane b % lanes.  Blocks the lanes allocate go back to
+// the caching allocator's pools of THESE streams when the caller drops the outputs; every batched call first orders its
+// lanes behind the caller's current stream (the C-ABI call does), so a block is never reused under a consumer the caller
+// queued before the call.
+static std::vector<hipStream_t> batch_lanes(int device, int want) {
+  static std::mutex mu;
+  static std::vector<std::vector<hipStream_t>> per_device(64);
+  std::lock_guard<std::mutex> lock(mu);
+  auto& v = per_device[(size_t)(device < 0 || device >= 64 ? 0 : device)];
+  while ((int)v.size() < want) {
+    hipStream_t st = nullptr;
+    TORCH_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess, "pyg (HIP): hipStreamCreate failed");
+    v.push_back(st);
+  }
+  return std::vector<hipStream_t>(v.begin(), v.begin() + want);
+}
+
+static int batch_lane_count(size_t K) {
+  static const int cap = [] {
+    const char* e = getenv("PYG_HIP_SAMPLER_LANES");
+    const int v = e ? atoi(e) : 8;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return (int)std::min<size_t>(K, (size_t)cap);
+}
+
+// Batch b continues the mt19937 stream torch.manual_seed(generator_seeds[b]) would start (CPUGeneratorImpl::set_current_seed
+// installs at::mt19937(seed)); the process's default generator is not touched.
+static std::vector<SampleOutput> run_sampler_batched(const std::vector<pyg_hip_relation>& rels,
+                                                     const std::vector<std::vector<pyg_hip_seed_set>>& seeds,
+                                                     const std::vector<int64_t>& generator_seeds,
+                                                     const std::vector<const int64_t*>& node_time, bool temporal_last,
+                                                     int num_node_types, int L, bool csc, bool replace, bool disjoint,
+                                                     bool return_edge_id, const at::Device& device) {
+  const size_t K = seeds.size();
+  TORCH_CHECK(generator_seeds.size() == K, "neighbor_sample_batched: one generator seed per batch expected (", K, " batches, ",
+              generator_seeds.size(), " seeds)");
+  DeviceGuard guard(device);
+  const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
+  const int T = num_node_types, E = (int)rels.size();
+  const auto lanes = batch_lanes(device.index(), batch_lane_count(K));
+  struct PerBatch {
+    SamplerHost host;
+    pyg_hip_mt19937 mt;
+    pyg_hip_sampler_host cb;
+    std::vector<int64_t*> node_id, row, col, eid;
+    std::vector<int64_t> num_nodes, num_edges, nph, eph;
+    pyg_hip_sample_result res;
+  };
+  std::vector<PerBatch> pb(K);
+  std::vector<pyg_hip_sample_batch> batches(K);
+  for (size_t b = 0; b < K; ++b) {
+    PerBatch& p = pb[b];
+    p.host.stream = lanes[b % lanes.size()];
+    at::mt19937 engine((uint64_t)generator_seeds[b]);
+    const at::mt19937_data_pod pod = engine.data();
+    std::memcpy(p.mt.state, pod.state_.data(), sizeof(p.mt.state));
+    p.mt.left = pod.left_;
+    p.mt.next = pod.next_;
+    p.cb = pyg_hip_sampler_host{&p.host, &host_alloc, &host_free, &host_rng_blocks, &p.mt};
+    p.node_id.assign((size_t)T, nullptr);
+    p.row.assign((size_t)std::max(E, 1), nullptr);
+    p.col.assign((size_t)std::max(E, 1), nullptr);
+    p.eid.assign((size_t)std::max(E, 1), nullptr);
+    p.num_nodes.assign((size_t)T, 0);
+    p.num_edges.assign((size_t)std::max(E, 1), 0);
+    p.nph.assign((size_t)T * (L + 1), 0);
+    p.eph.assign((size_t)std::max(E * L, 1), 0);
+    p.res.node_id = p.node_id.data();
+    p.res.num_nodes = p.num_nodes.data();
+    p.res.nodes_per_hop_host = p.nph.data();
+    p.res.row = p.row.data();
+    p.res.col = p.col.data();
+    p.res.edge_id = p.eid.data();
+    p.res.num_edges = p.num_edges.data();
+    p.res.edges_per_hop_host = p.eph.data();
+    p.res.rng_blocks = 0;
+    batches[b].num_seed_sets = (int)seeds[b].size();
+    batches[b].seeds_host = seeds[b].data();
+    batches[b].host = &p.cb;
+    batches[b].result = &p.res;
+    batches[b].stream = p.host.stream;
+  }
+  const int rc = pyg_hip_hetero_neighbor_sample_batched(T, E, rels.data(), node_time.empty() ? nullptr : node_time.data(),
+                                                        temporal_last, L, csc, replace, disjoint, return_edge_id, (int)K,
+                                                        batches.data(), current_hip_stream(device.index()));
+  // adopt whatever was handed out (also on failure: the blocks must go back to the allocator)
+  std::vector<SampleOutput> outs(K);
+  for (size_t b = 0; b < K; ++b) {
+    PerBatch& p = pb[b];
+    const bool ok = batches[b].status == PYG_HIP_OK;
+    for (int t = 0; t < T; ++t) {
+      if (!ok || !p.node_id[(size_t)t]) continue;
+      const int64_t n = p.num_nodes[(size_t)t];
+      outs[b].node_id.push_back(disjoint ? adopt(p.node_id[(size_t)t], {n, 2}, opts) : adopt(p.node_id[(size_t)t], {n}, opts));
+      outs[b].nodes_per_hop.emplace_back(p.nph.begin() + (size_t)t * (L + 1), p.nph.begin() + (size_t)(t + 1) * (L + 1));
+    }
+    for (int e = 0; e < E; ++e) {
+      if (!ok) continue;
+      const int64_t n = p.num_edges[(size_t)e];
+      outs[b].row.push_back(adopt(p.row[(size_t)e], {n}, opts));
+      outs[b].col.push_back(adopt(p.col[(size_t)e], {n}, opts));
+      if (return_edge_id) outs[b].edge_id.push_back(adopt(p.eid[(size_t)e], {n}, opts));
+      outs[b].edges_per_hop.emplace_back(p.eph.begin() + (size_t)e * L, p.eph.begin() + (size_t)(e + 1) * L);
+    }
+    TORCH_CHECK(p.host.error.empty(), p.host.error);
+  }
+  check_status(rc);
+  return outs;
+}
+
 static void check_modes(bool has_node_time, bool has_edge_time, bool has_seed_time, bool has_weight,
                         bool directed, bool disjoint, const std::string& temporal_strategy) {
   // precondition checks of the reference kernel, sampler/cpu/neighbor_kernel.cpp:34-36,354-380,501
@@ -745,6 +857,150 @@ neighbor_sample_kernel(const Tensor& rowptr, const Tensor& col, const Tensor& se
   if (return_edge_id) eid = ix.narrow(out.edge_id[0]);
   return std::make_tuple(ix.narrow(out.row[0]), ix.narrow(out.col[0]), ix.narrow(out.node_id[0]), eid,
                          out.nodes_per_hop[0], out.edges_per_hop[0]);
+}
+
+// This build only: K mini-batches of pyg::neighbor_sample in one call.  Batch b = neighbor_sample(rowptr, col, seeds[b], ...)
+// under torch.manual_seed(generator_seeds[b]) -- bit for bit -- but the batches overlap on the device.  Returns the
+// per-batch row / col / node_id / edge_id lists and the per-hop counts as [K, L + 1] / [K, L] CPU tensors.
+std::tuple<std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, std::vector<Tensor>, Tensor, Tensor>
+neighbor_sample_batched_kernel(const Tensor& rowptr, const Tensor& col, const std::vector<Tensor>& seeds,
+                               const std::vector<int64_t>& num_neighbors, const std::vector<int64_t>& generator_seeds,
+                               const c10::optional<Tensor>& node_time, const c10::optional<Tensor>& edge_time,
+                               const c10::optional<std::vector<Tensor>>& seed_times, const c10::optional<Tensor>& edge_weight,
+                               bool csc, bool replace, bool directed, bool disjoint, std::string temporal_strategy,
+                               bool return_edge_id) {
+  PYG_TRACE("pyg::neighbor_sample_batched");
+  check_modes(node_time.has_value(), edge_time.has_value(), seed_times.has_value(), edge_weight.has_value(), directed,
+              disjoint, temporal_strategy);
+  const size_t K = seeds.size();
+  TORCH_CHECK(!seed_times.has_value() || seed_times.value().size() == K, "neighbor_sample_batched: one seed_time per batch");
+  const int64_t L = (int64_t)num_neighbors.size();
+  const auto cpu_long = at::TensorOptions().dtype(at::kLong);
+  if (K == 0)
+    return std::make_tuple(std::vector<Tensor>(), std::vector<Tensor>(), std::vector<Tensor>(), std::vector<Tensor>(),
+                           at::zeros({0, L + 1}, cpu_long), at::zeros({0, L}, cpu_long));
+  IndexArgs ix;
+  ix.dtype = index_dtype(seeds[0]);
+  std::vector<pyg_hip_relation> rels(1);
+  rels[0].rowptr = ix.graph(rowptr, "rowptr");
+  rels[0].num_rows = rowptr.numel() - 1;
+  rels[0].col = ix.graph(col, "col");
+  rels[0].num_cols = col.numel();
+  rels[0].src_type = 0;
+  rels[0].dst_type = 0;
+  rels[0].num_neighbors_host = num_neighbors.data();
+  rels[0].edge_time = edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr;
+  rels[0].edge_weight = nullptr;
+  rels[0].edge_weight_dtype = 0;
+  rels[0].index_is32 = ix.is32();
+  if (edge_weight.has_value()) set_weight(rels[0], edge_weight.value(), col.numel());
+  std::vector<std::vector<pyg_hip_seed_set>> sets(K, std::vector<pyg_hip_seed_set>(1));
+  for (size_t b = 0; b < K; ++b) {
+    sets[b][0].node_type = 0;
+    sets[b][0].reserved = 0;
+    sets[b][0].seed = ix.ptr(seeds[b], "seed");
+    sets[b][0].num_seed = seeds[b].numel();
+    sets[b][0].seed_time = seed_times.has_value() ? time_ptr(seed_times.value()[b], "seed_time") : nullptr;
+  }
+  std::vector<const int64_t*> ntime;
+  if (node_time.has_value()) ntime.push_back(time_ptr(node_time.value(), "node_time"));
+  auto outs = run_sampler_batched(rels, sets, generator_seeds, ntime, temporal_strategy == "last", 1, (int)L, csc, replace,
+                                  disjoint, return_edge_id, rowptr.device());
+  std::vector<Tensor> row, colv, node, eid;
+  Tensor nph = at::zeros({(int64_t)K, L + 1}, cpu_long), eph = at::zeros({(int64_t)K, L}, cpu_long);
+  for (size_t b = 0; b < K; ++b) {
+    row.push_back(ix.narrow(outs[b].row[0]));
+    colv.push_back(ix.narrow(outs[b].col[0]));
+    node.push_back(ix.narrow(outs[b].node_id[0]));
+    if (return_edge_id) eid.push_back(ix.narrow(outs[b].edge_id[0]));
+    std::memcpy(nph.data_ptr<int64_t>() + b * (size_t)(L + 1), outs[b].nodes_per_hop[0].data(), sizeof(int64_t) * (size_t)(L + 1));
+    if (L > 0) std::memcpy(eph.data_ptr<int64_t>() + b * (size_t)L, outs[b].edges_per_hop[0].data(), sizeof(int64_t) * (size_t)L);
+  }
+  return std::make_tuple(row, colv, node, eid, nph, eph);
+}
+
+// This build only: K mini-batches of pyg::hetero_neighbor_sample (uniform sampling; no temporal / biased options here).
+std::tuple<std::vector<c10::Dict<rel_type, Tensor>>, std::vector<c10::Dict<rel_type, Tensor>>,
+           std::vector<c10::Dict<node_type, Tensor>>, std::vector<c10::Dict<rel_type, Tensor>>,
+           std::vector<c10::Dict<node_type, std::vector<int64_t>>>, std::vector<c10::Dict<rel_type, std::vector<int64_t>>>>
+hetero_neighbor_sample_batched_kernel(const std::vector<node_type>& node_types, const std::vector<edge_type>& edge_types,
+                                      const c10::Dict<rel_type, Tensor>& rowptr_dict, const c10::Dict<rel_type, Tensor>& col_dict,
+                                      const std::vector<c10::Dict<node_type, Tensor>>& seed_dicts,
+                                      const c10::Dict<rel_type, std::vector<int64_t>>& num_neighbors_dict,
+                                      const std::vector<int64_t>& generator_seeds, bool csc, bool replace, bool disjoint,
+                                      bool return_edge_id) {
+  PYG_TRACE("pyg::hetero_neighbor_sample_batched");
+  std::unordered_map<std::string, int> nt_index;
+  for (size_t i = 0; i < node_types.size(); ++i) nt_index[node_types[i]] = (int)i;
+  const size_t K = seed_dicts.size();
+  TORCH_CHECK(K > 0 && seed_dicts[0].size() > 0, "hetero_neighbor_sample_batched: no seeds given");
+  IndexArgs ix;
+  ix.dtype = index_dtype(seed_dicts[0].begin()->value());
+  size_t L = 0;
+  std::vector<pyg_hip_relation> rels(edge_types.size());
+  std::vector<std::vector<int64_t>> fanouts(edge_types.size());
+  c10::optional<at::Device> device;
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    const auto& k = edge_types[e];
+    const auto rel = to_rel_type(k);
+    const Tensor& rowptr = rowptr_dict.at(rel);
+    const Tensor& col = col_dict.at(rel);
+    if (!device.has_value()) device = rowptr.device();
+    fanouts[e] = num_neighbors_dict.at(rel);
+    L = std::max(L, fanouts[e].size());
+    TORCH_CHECK(nt_index.count(std::get<0>(k)) && nt_index.count(std::get<2>(k)),
+                "hetero_neighbor_sample_batched: edge type names an unknown node type");
+    rels[e] = pyg_hip_relation{};
+    rels[e].rowptr = ix.graph(rowptr, "rowptr");
+    rels[e].num_rows = rowptr.numel() - 1;
+    rels[e].col = ix.graph(col, "col");
+    rels[e].num_cols = col.numel();
+    rels[e].src_type = nt_index[std::get<0>(k)];
+    rels[e].dst_type = nt_index[std::get<2>(k)];
+    rels[e].index_is32 = ix.is32();
+  }
+  for (size_t e = 0; e < edge_types.size(); ++e) {
+    TORCH_CHECK(fanouts[e].size() == L, "hetero_neighbor_sample_batched: all relations must list ", L, " hops");
+    rels[e].num_neighbors_host = fanouts[e].data();
+  }
+  TORCH_CHECK(device.has_value(), "hetero_neighbor_sample_batched: no tensors given");
+  std::vector<std::vector<pyg_hip_seed_set>> sets(K);
+  for (size_t b = 0; b < K; ++b)
+    for (const auto& kv : seed_dicts[b]) {
+      TORCH_CHECK(nt_index.count(kv.key()), "hetero_neighbor_sample_batched: seed type '", kv.key(), "' is not a node type");
+      pyg_hip_seed_set st;
+      st.node_type = nt_index[kv.key()];
+      st.reserved = 0;
+      st.seed = ix.ptr(kv.value(), "seed");
+      st.num_seed = kv.value().numel();
+      st.seed_time = nullptr;
+      sets[b].push_back(st);
+    }
+  auto outs = run_sampler_batched(rels, sets, generator_seeds, {}, false, (int)node_types.size(), (int)L, csc, replace, disjoint,
+                                  return_edge_id, device.value());
+  std::vector<c10::Dict<rel_type, Tensor>> o_row, o_col, o_eid;
+  std::vector<c10::Dict<node_type, Tensor>> o_node;
+  std::vector<c10::Dict<node_type, std::vector<int64_t>>> o_nph;
+  std::vector<c10::Dict<rel_type, std::vector<int64_t>>> o_eph;
+  for (size_t b = 0; b < K; ++b) {
+    c10::Dict<rel_type, Tensor> r, c, ei;
+    c10::Dict<node_type, Tensor> n;
+    c10::Dict<node_type, std::vector<int64_t>> np;
+    c10::Dict<rel_type, std::vector<int64_t>> ep;
+    for (size_t t = 0; t < node_types.size(); ++t) {
+      n.insert(node_types[t], ix.narrow(outs[b].node_id[t]));
+      np.insert(node_types[t], outs[b].nodes_per_hop[t]);
+    }
+    for (size_t e = 0; e < edge_types.size(); ++e) {
+      const auto rel = to_rel_type(edge_types[e]);
+      r.insert(rel, ix.narrow(outs[b].row[e]));
+      c.insert(rel, ix.narrow(outs[b].col[e]));
+      ep.insert(rel, outs[b].edges_per_hop[e]);
+      if (return_edge_id) ei.insert(rel, ix.narrow(outs[b].edge_id[e]));
+    }
+    o_row.push_back(r), o_col.push_back(c), o_node.push_back(n), o_eid.push_back(ei), o_nph.push_back(np), o_eph.push_back(ep);
+  }
+  return std::make_tuple(o_row, o_col, o_node, o_eid, o_nph, o_eph);
 }
 
 // pyg_binding_cpu.cpp
@@ -873,6 +1129,17 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
   return std::make_tuple(out_row, out_col, out_node, out_eid, out_nph, out_eph);
 }
 
+// This build only: frees the idle node tables the library keeps between sampler calls (current device) through the caching
+// allocator they came from; returns the number still lent to running calls.
+int64_t sampler_release_table_cache_kernel() {
+  SamplerHost host;
+  host.stream = nullptr;
+  pyg_hip_sampler_host cb{&host, &host_alloc, &host_free, &host_rng_blocks, nullptr};
+  const int rc = pyg_hip_sampler_table_cache_release(&cb);
+  TORCH_CHECK(rc >= 0, pyg_hip_last_error());
+  return rc;
+}
+
 // pyg::dist_neighbor_sample (sampler/cpu/neighbor_kernel.cpp:957-978)
 std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
     const Tensor& rowptr, const Tensor& col, const Tensor& seed, const int64_t num_neighbors,
@@ -956,6 +1223,20 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
       "str temporal_strategy = 'uniform', bool return_edge_id = True) -> "
       "(Dict(str, Tensor), Dict(str, Tensor), Dict(str, Tensor), "
       "Dict(str, Tensor)?, Dict(str, int[]), Dict(str, int[]))"));
+  m.def("sampler_release_table_cache() -> int", &sampler_release_table_cache_kernel);
+  // this build only: K independent mini-batches in one call, overlapped on the device (pyg_hip_hetero_neighbor_sample_batched)
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::neighbor_sample_batched(Tensor rowptr, Tensor col, Tensor[] seeds, int[] num_neighbors, int[] generator_seeds, "
+      "Tensor? node_time = None, Tensor? edge_time = None, Tensor[]? seed_times = None, Tensor? edge_weight = None, "
+      "bool csc = False, bool replace = False, bool directed = True, bool disjoint = False, "
+      "str temporal_strategy = 'uniform', bool return_edge_id = True) -> "
+      "(Tensor[], Tensor[], Tensor[], Tensor[], Tensor, Tensor)"));
+  m.def(TORCH_SELECTIVE_SCHEMA(
+      "pyg::hetero_neighbor_sample_batched(str[] node_types, (str, str, str)[] edge_types, Dict(str, Tensor) rowptr_dict, "
+      "Dict(str, Tensor) col_dict, Dict(str, Tensor)[] seed_dicts, Dict(str, int[]) num_neighbors_dict, "
+      "int[] generator_seeds, bool csc = False, bool replace = False, bool disjoint = False, bool return_edge_id = True) -> "
+      "(Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, int[])[], "
+      "Dict(str, int[])[])"));
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::dist_neighbor_sample(Tensor rowptr, Tensor col, Tensor seed, int "
       "num_neighbors, Tensor? node_time = None, Tensor? edge_time = None, "
@@ -974,6 +1255,7 @@ TORCH_LIBRARY_IMPL(pyg, CUDA, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused_tables"), TORCH_FN(rgcn_fused_tables_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::rgcn_fused"), TORCH_FN(rgcn_fused_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample"), TORCH_FN(neighbor_sample_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::neighbor_sample_batched"), TORCH_FN(neighbor_sample_batched_kernel));
   m.impl(TORCH_SELECTIVE_NAME("pyg::dist_neighbor_sample"), TORCH_FN(dist_neighbor_sample_kernel));
 }
 
@@ -986,6 +1268,7 @@ TORCH_LIBRARY_IMPL(pyg, Autograd, m) {
 // kernel checks the device itself and refuses CPU graphs.
 TORCH_LIBRARY_IMPL(pyg, BackendSelect, m) {
   m.impl(TORCH_SELECTIVE_NAME("pyg::hetero_neighbor_sample"), TORCH_FN(hetero_neighbor_sample_kernel));
+  m.impl(TORCH_SELECTIVE_NAME("pyg::hetero_neighbor_sample_batched"), TORCH_FN(hetero_neighbor_sample_batched_kernel));
 }
 
 }  // namespace pyg_amd

@@ -30,6 +30,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <atomic>
 #include <functional>
 #include <mutex>
@@ -551,8 +553,10 @@ __device__ __forceinline__ void emit(const HopArgs& a, int64_t pos, int64_t edge
   if (!a.table.keys) return;  // dist_neighbor_sample: no relabelling (neighbor_kernel.cpp:296-303)
   const u64 s = table_slot(a.table, make_key(w, src_batch, a.num_batches));
   a.e_slot[pos] = s;
+#ifndef PYG_HIP_EXPERIMENT_NO_TABLE_ATOMIC  // (timing ablation of an experiment build: results are wrong without it)
   __hip_atomic_fetch_min(&a.table.vals[s], a.table.prov + (u64)(a.pos_base + pos), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // Run-ahead guard: true (for every thread of the launch alike) when the hop would read random words
@@ -996,6 +1000,7 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0, bool epo
       PYG_HIP_CHECK(hipGetDevice(&dev));
       bool room = false;
       u64* block = nullptr;
+      u64* evict = nullptr;
       u64 epoch = 0;
       {
         std::lock_guard<std::mutex> lock(dense_cache_mutex());
@@ -1010,7 +1015,20 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0, bool epo
           }
         }
         room = count < kDenseCacheEntries;
+        if (!block && !room) {
+          // full, none of this size free: drop an idle table of ANOTHER node count (graphs that come and go must not
+          // leave the cache full of dead blocks); tables of this size that are merely busy stay
+          auto& v = dense_cache();
+          for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].device == dev && !v[i].busy && v[i].dense_n != ns.dense_n) {
+              evict = v[i].ptr;
+              v.erase(v.begin() + (long)i);
+              room = true;
+              break;
+            }
+        }
       }
+      if (evict) c.host->free(c.host->user, evict);  // idle: its last user synchronised before handing it back
       if (block) {
         if (epoch == 1) {  // wrapped around: stale entries of the old numbering would look current
           int rc = clear(block);
@@ -2419,6 +2437,30 @@ extern "C" int pyg_hip_sampler_table_cache(int64_t limit) {
   return n;
 }
 
+extern "C" int pyg_hip_sampler_table_cache_release(const pyg_hip_sampler_host* host) {
+  PYG_HIP_REQUIRE(host && host->free, "sampler: table_cache_release needs the allocator the tables came from");
+  int dev = 0;
+  PYG_HIP_CHECK(hipGetDevice(&dev));
+  std::vector<u64*> drop;
+  int kept = 0;
+  {
+    std::lock_guard<std::mutex> lock(dense_cache_mutex());
+    auto& v = dense_cache();
+    for (size_t i = 0; i < v.size();) {
+      if (v[i].device == dev && !v[i].busy) {
+        drop.push_back(v[i].ptr);
+        v.erase(v.begin() + (long)i);
+      } else {
+        kept += v[i].device == dev ? 1 : 0;
+        ++i;
+      }
+    }
+  }
+  // (an idle entry's last user synchronised its stream before it handed the table back: nothing on the device uses it)
+  for (u64* p : drop) host->free(host->user, p);
+  return kept;
+}
+
 extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                               const pyg_hip_relation* relations, int num_seed_sets,
                                               const pyg_hip_seed_set* seeds,
@@ -2473,6 +2515,147 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   }
   c.release_all();  // scratch (and, on failure, everything)
   return rc;
+}
+
+// ---- K independent calls at once ------------------------------------------------------------------------------------
+// A mini-batch is a chain of ~12 dependent launches of 10 - 45 us, most of them far too small for 256 CUs, plus ~50 us of
+// host work to queue them: one call after the other leaves the chip idle most of the time.  Independent batches (each its
+// own seeds, its own generator stream -- the reference's benchmark loop reseeds per batch, benchmark/sampler/neighbor.py)
+// have no such dependence: batches that were given different streams are driven by different host threads of a small
+// persistent pool, so their chains overlap on the device and their host work overlaps on the cores.  Every batch runs the
+// unchanged single-batch code: its results are bit for bit those of pyg_hip_hetero_neighbor_sample on that batch alone.
+namespace {
+
+class SamplePool {
+ public:
+  static SamplePool& get() {
+    static SamplePool* p = new SamplePool();  // (never destroyed: its threads may outlive static destruction order)
+    return *p;
+  }
+  // runs task(i) for i in [0, n) -- the caller's thread takes part -- and returns when all are done
+  void run(int n, const std::function<void(int)>& task) {
+    std::unique_lock<std::mutex> lock(mu_);
+    while (busy_) idle_cv_.wait(lock);  // one batched call at a time
+    busy_ = true;
+    grow(n - 1);
+    task_ = &task;
+    n_ = n;
+    next_ = 0;
+    pending_ = n;
+    ++generation_;
+    lock.unlock();
+    work_cv_.notify_all();
+    drain();
+    lock.lock();
+    while (pending_ > 0) done_cv_.wait(lock);
+    task_ = nullptr;
+    busy_ = false;
+    lock.unlock();
+    idle_cv_.notify_one();
+  }
+
+ private:
+  void grow(int want) {  // mu_ held
+    while ((int)threads_.size() < want && threads_.size() < 15) {
+      threads_.emplace_back([this] { loop(); });
+      threads_.back().detach();
+    }
+  }
+  void drain() {
+    while (true) {
+      int i;
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (task_ == nullptr || next_ >= n_) return;
+        i = next_++;
+      }
+      (*task_)(i);
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        while (generation_ == seen || task_ == nullptr || next_ >= n_) {
+          seen = generation_;
+          work_cv_.wait(lock);
+        }
+        seen = generation_;
+      }
+      drain();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable work_cv_, done_cv_, idle_cv_;
+  std::vector<std::thread> threads_;
+  const std::function<void(int)>* task_ = nullptr;
+  int n_ = 0, next_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  bool busy_ = false;
+};
+
+}  // namespace
+
+extern "C" int pyg_hip_hetero_neighbor_sample_batched(int num_node_types, int num_relations,
+                                                      const pyg_hip_relation* relations,
+                                                      const int64_t* const* node_time, int temporal_last, int L, int csc,
+                                                      int replace, int disjoint, int return_edge_id, int num_batches,
+                                                      pyg_hip_sample_batch* batches, void* stream_) {
+  PYG_HIP_REQUIRE(num_batches >= 0 && (num_batches == 0 || batches != nullptr), "sampler (batched): bad batch list");
+  if (num_batches == 0) return PYG_HIP_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int dev = 0;
+  PYG_HIP_CHECK(hipGetDevice(&dev));
+  // lanes = batches that share a stream, in call order; one host thread per lane
+  std::vector<std::vector<int>> lanes;
+  {
+    std::vector<void*> lane_stream;
+    for (int b = 0; b < num_batches; ++b) {
+      batches[b].status = PYG_HIP_OK;
+      batches[b].error[0] = 0;
+      batches[b].mode = "none";
+      PYG_HIP_REQUIRE(batches[b].host && batches[b].result && (batches[b].num_seed_sets == 0 || batches[b].seeds_host),
+                      "sampler (batched): batch %d is incomplete", b);
+      size_t k = 0;
+      while (k < lane_stream.size() && lane_stream[k] != batches[b].stream) ++k;
+      if (k == lane_stream.size()) {
+        lane_stream.push_back(batches[b].stream);
+        lanes.emplace_back();
+      }
+      lanes[k].push_back(b);
+    }
+    // what the caller queued on `stream` (seeds, graph updates) is ordered in front of every lane
+    hipEvent_t ev = nullptr;
+    bool need = false;
+    for (void* ls : lane_stream) need = need || ls != stream_;
+    if (need) {
+      PYG_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      PYG_HIP_CHECK(hipEventRecord(ev, stream));
+      for (void* ls : lane_stream)
+        if (ls != stream_) PYG_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(ls), ev, 0));
+      PYG_HIP_CHECK(hipEventDestroy(ev));
+    }
+  }
+  const std::function<void(int)> task = [&](int lane) {
+    (void)hipSetDevice(dev);
+    for (int b : lanes[(size_t)lane]) {
+      pyg_hip_sample_batch& B = batches[b];
+      B.status = pyg_hip_hetero_neighbor_sample(num_node_types, num_relations, relations, B.num_seed_sets, B.seeds_host,
+                                                node_time, temporal_last, L, csc, replace, disjoint, return_edge_id, B.host,
+                                                B.result, B.stream);
+      B.mode = g_sampler_mode;
+      if (B.status != PYG_HIP_OK) snprintf(B.error, sizeof(B.error), "%s", last_error_buffer());
+    }
+  };
+  SamplePool::get().run((int)lanes.size(), task);
+  for (int b = 0; b < num_batches; ++b)
+    if (batches[b].status != PYG_HIP_OK) return fail(batches[b].status, "sampler (batched): batch %d: %s", b, batches[b].error);
+  return PYG_HIP_OK;
 }
 
 extern "C" int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, void* stream) {

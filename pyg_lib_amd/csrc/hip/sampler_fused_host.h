@@ -435,7 +435,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       const int64_t Fb = fbh[(size_t)ell][(size_t)src];
       int64_t* e_node = reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb));
       int64_t* e_batch = disjoint ? reinterpret_cast<int64_t*>(carve(8 * (size_t)Eb)) : nullptr;
-      u64* e_slot = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
+      // a direct-address table's slot IS the node id (table_slot; non-disjoint keys are plain ids): the slot array is the
+      // node array -- one store, one line per 8 emissions instead of two in the sampling launch, and the scan's and the
+      // finalize step's slot reads hit what the node reads fetched (24 - 32 bytes per emission less HBM traffic)
+      u64* e_slot = (dn.table.dense && !disjoint) ? reinterpret_cast<u64*>(e_node) : reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
       u64* cache = reinterpret_cast<u64*>(carve(8 * (size_t)Eb));
       const ConsArr& ca = cons_arr[(size_t)ell * R + e];
       PYG_HIP_REQUIRE(ca.edge_off != nullptr, "sampler: internal error (no producer for a queued relation)");

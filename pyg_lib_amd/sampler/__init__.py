@@ -91,6 +91,57 @@ def hetero_neighbor_sample(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[E
             to_edge_keys(edges_per_hop))
 
 
+def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], num_neighbors: List[int],
+                            generator_seeds: List[int], node_time: Optional[Tensor] = None,
+                            edge_time: Optional[Tensor] = None, seed_times: Optional[List[Tensor]] = None,
+                            edge_weight: Optional[Tensor] = None, csc: bool = False, replace: bool = False,
+                            directed: bool = True, disjoint: bool = False, temporal_strategy: str = 'uniform',
+                            return_edge_id: bool = True) -> List[HomoOut]:
+    """``K = len(seeds)`` independent mini-batches in ONE call (this build only; the reference samples its epoch one batch
+    at a time, benchmark/sampler/neighbor.py:101-121).
+
+    Batch ``b`` is exactly ``torch.manual_seed(generator_seeds[b]); neighbor_sample(rowptr, col, seeds[b], ...)`` -- every
+    output bit for bit -- but the batches are driven by a pool of host threads on private streams, so their chains of small
+    dependent launches overlap on the device (a single batch cannot fill 256 CUs).  The process's default generator is
+    not touched.  Returns the list of the ``K`` usual 6-tuples.  ``PYG_HIP_SAMPLER_LANES`` (default 8) caps the number of
+    batches in flight.
+    """
+    rows, cols, nodes, eids, nph, eph = torch.ops.pyg.neighbor_sample_batched(
+        rowptr, col, seeds, num_neighbors, generator_seeds, node_time, edge_time, seed_times, edge_weight, csc, replace,
+        directed, disjoint, temporal_strategy, return_edge_id)
+    nph, eph = nph.tolist(), eph.tolist()
+    return [(rows[b], cols[b], nodes[b], eids[b] if return_edge_id else None, nph[b], eph[b]) for b in range(len(seeds))]
+
+
+def hetero_neighbor_sample_batched(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
+                                   seed_dicts: List[Dict[NodeType, Tensor]],
+                                   num_neighbors_dict: Dict[EdgeType, List[int]], generator_seeds: List[int],
+                                   csc: bool = False, replace: bool = False, disjoint: bool = False,
+                                   return_edge_id: bool = True) -> List[HeteroOut]:
+    """Heterogeneous counterpart of :func:`neighbor_sample_batched` (uniform sampling; the temporal / biased options of
+    :func:`hetero_neighbor_sample` are not offered here).  Batch ``b`` equals ``torch.manual_seed(generator_seeds[b]);
+    hetero_neighbor_sample(rowptr_dict, col_dict, seed_dicts[b], num_neighbors_dict, ...)`` bit for bit."""
+    edge_types = list(rowptr_dict)
+    node_types = sorted({t for e in edge_types for t in (e[0], e[-1])} | {t for d in seed_dicts for t in d})
+    back = {_rel(e): e for e in edge_types}
+    rows, cols, nodes, eids, nph, eph = torch.ops.pyg.hetero_neighbor_sample_batched(
+        node_types, edge_types, _to_rel_keys(rowptr_dict), _to_rel_keys(col_dict), seed_dicts,
+        _to_rel_keys(num_neighbors_dict), generator_seeds, csc, replace, disjoint, return_edge_id)
+
+    def to_edge_keys(d):
+        return {back[k]: v for k, v in d.items()}
+
+    return [(to_edge_keys(rows[b]), to_edge_keys(cols[b]), nodes[b], to_edge_keys(eids[b]) if return_edge_id else None,
+             nph[b], to_edge_keys(eph[b])) for b in range(len(seed_dicts))]
+
+
+def release_table_cache() -> int:
+    """Hands the node tables the sampler keeps between calls (up to 8 x 128 MiB per device) back to the caching allocator;
+    returns how many are still in use by running calls.  ``torch.cuda.empty_cache()`` afterwards returns the memory to
+    the driver."""
+    return int(torch.ops.pyg.sampler_release_table_cache())
+
+
 def last_mode() -> str:
     """Driver of the calling thread's last sampler call: 'fused', 'queued' or 'synchronising' (diagnostics; see
     ``pyg_hip_sampler_last_mode`` in include/pyg_hip.h)."""
@@ -101,4 +152,5 @@ def last_mode() -> str:
     return L.pyg_hip_sampler_last_mode().decode()
 
 
-__all__ = ['neighbor_sample', 'hetero_neighbor_sample', 'last_mode']
+__all__ = ['neighbor_sample', 'hetero_neighbor_sample', 'neighbor_sample_batched', 'hetero_neighbor_sample_batched',
+           'release_table_cache', 'last_mode']
