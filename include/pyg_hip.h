@@ -274,6 +274,14 @@ PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int6
  */
 #define PYG_HIP_RGCN_CHECKED 1
 #define PYG_HIP_RGCN_CAS 2
+#define PYG_HIP_RGCN_DEFERRED 4
+/* PYG_HIP_RGCN_DEFERRED (ignored with _CHECKED): the same validation WITHOUT the synchronisation -- offenders are
+ * redirected to row 0, so a stale node id is never an out-of-bounds access, and the kernel leaves 1 (gather) / 2
+ * (scatter) in a pinned word of the device.  The next pyg_hip_rgcn_fused call with this flag on that device fails with
+ * PYG_HIP_ERR_INVALID naming the earlier call; pyg_hip_rgcn_pending_error() returns and clears the word (meaningful once
+ * the stream has been synchronised).  This is what the torch binding passes by default (PYG_HIP_RGCN_CHECK=1: _CHECKED,
+ * =0: no validation). */
+PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
 PYG_HIP_API int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* relations,
                                    int64_t num_relations, void* out, int64_t num_out_rows, int64_t K, int64_t M,
                                    int checked, void* workspace, size_t workspace_bytes, void* stream);
@@ -462,14 +470,16 @@ PYG_HIP_API int pyg_hip_biased_log_f32(const float* in, float* out, int64_t n, v
  *   edge_id   -> E sampled edge ids, from host->alloc
  *   cumsum_host  caller array of S + 1 entries: [S, size after seed 0, size after seed 1, ...]
  * Random words, temporal arguments, biased sampling (edge_weight: device pointer or NULL, edge_weight_dtype
- * PYG_F32 / PYG_F64) and error behaviour as in pyg_hip_hetero_neighbor_sample.
+ * PYG_F32 / PYG_F64) and error behaviour as in pyg_hip_hetero_neighbor_sample.  index_is32 != 0: rowptr and col point at
+ * int32 arrays and are read in place (the reference's int32 instantiation, neighbor_kernel.cpp:893); seeds, times and the
+ * outputs stay int64 on this interface.
  */
 PYG_HIP_API int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t* col,
                                              const int64_t* seed, int64_t num_seed,
                                              int64_t num_neighbors, const int64_t* node_time,
                                              const int64_t* edge_time, const int64_t* seed_time,
                                              const void* edge_weight, int edge_weight_dtype,
-                                             int temporal_last, int replace, int disjoint,
+                                             int temporal_last, int replace, int disjoint, int index_is32,
                                              const pyg_hip_sampler_host* host, int64_t** node_id,
                                              int64_t** edge_id, int64_t* num_edges,
                                              int64_t* cumsum_host, void* stream);

@@ -67,6 +67,7 @@ def lib() -> ctypes.CDLL:
         L.pyg_hip_set_float_atomic_mode.restype = c.c_int
         L.pyg_hip_set_float_atomic_mode.argtypes = [c.c_int]
         L.pyg_hip_last_accumulate_info.restype = c.c_char_p
+        L.pyg_hip_rgcn_pending_error.restype = c.c_int
         L.pyg_hip_atomic_selftest.restype = c.c_int
         L.pyg_hip_atomic_selftest.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_char_p, c.c_size_t, c.c_void_p]
         _LIB = L

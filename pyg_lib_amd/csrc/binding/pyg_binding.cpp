@@ -290,13 +290,17 @@ std::vector<Tensor> grouped_matmul_pool_kernel(const at::TensorList input, const
 }
 
 // This build only: gather -> per-relation matmul -> scatter-add in one launch (csrc/hip/rgcn.hip).  `out` is
-// accumulated into and returned.  PYG_HIP_RGCN_CHECK=1 validates every index on the device (and synchronises).
-static bool rgcn_checked() {
-  static const bool on = [] {
+// accumulated into and returned.  Indices are validated on the device (rgcn_check_flags).
+static int rgcn_check_flags() {
+  // default: validated on the device without a synchronisation (PYG_HIP_RGCN_DEFERRED: a stale node id is redirected to
+  // row 0 instead of reading out of bounds, and reported by the next call); 1: validated, synchronising, fails in the
+  // call that has the bad index; 0: no validation (the round-4 behaviour)
+  static const int flags = [] {
     const char* e = getenv("PYG_HIP_RGCN_CHECK");
-    return e != nullptr && e[0] != '\0' && e[0] != '0';
+    if (e == nullptr || e[0] == '\0') return PYG_HIP_RGCN_DEFERRED;
+    return e[0] == '0' ? 0 : PYG_HIP_RGCN_CHECKED;
   }();
-  return on;
+  return flags;
 }
 
 static void rgcn_index_checks(const at::TensorList gather_index, const at::TensorList scatter_index, const Tensor& like,
@@ -345,7 +349,7 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
   }
   auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, x.options().dtype(at::kByte));
   check_status(pyg_hip_rgcn_fused(dtype_code(x.scalar_type()), xc.data_ptr(), xc.size(0), rels.data(), (int64_t)R,
-                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), rgcn_checked() ? 1 : 0,
+                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), rgcn_check_flags(),
                                   ws.data_ptr(), (size_t)ws.numel(), current_stream(x)));
   return out;
 }
@@ -405,7 +409,7 @@ Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList 
   }
   auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, f0.options().dtype(at::kByte));
   check_status(pyg_hip_rgcn_fused(dtype_code(weight.scalar_type()), nullptr, 0, rels.data(), (int64_t)R, out.data_ptr(),
-                                  out.size(0), wc.size(1), out.size(1), rgcn_checked() ? 1 : 0, ws.data_ptr(),
+                                  out.size(0), wc.size(1), out.size(1), rgcn_check_flags(), ws.data_ptr(),
                                   (size_t)ws.numel(), current_stream(f0)));
   return out;
 }
@@ -591,7 +595,7 @@ static void check_index(const Tensor& t, const char* what) {
 // The reference dispatches the sampler on the seeds' integral type (neighbor_kernel.cpp:893,930) and returns
 // that type.  The kernels read an int32 CSR (rowptr / col, the large arrays) IN PLACE (`graph` below +
 // pyg_hip_relation::index_is32); only the seeds are widened for the call (batch-sized) and the results are
-// narrowed back -- same values, same generator stream.  dist_neighbor_sample still widens its graph.
+// narrowed back -- same values, same generator stream (dist_neighbor_sample included).
 struct IndexArgs {
   at::ScalarType dtype = at::kLong;
   std::vector<Tensor> keep;  // widened copies stay alive until the call returns
@@ -1149,9 +1153,13 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
   PYG_TRACE("pyg::dist_neighbor_sample");
   check_modes(node_time.has_value(), edge_time.has_value(), seed_time.has_value(), edge_weight.has_value(), directed,
               disjoint, temporal_strategy);
-  check_index(rowptr, "rowptr");
-  check_index(col, "col");
-  check_index(seed, "seed");
+  // dispatched on the seeds' integral type like the other samplers (neighbor_kernel.cpp:893,930): an int32 CSR is read in
+  // place, only the seeds are widened for the call and the results narrowed back
+  IndexArgs ix;
+  ix.dtype = index_dtype(seed);
+  const int64_t* rowptr_p = ix.graph(rowptr, "rowptr");
+  const int64_t* col_p = ix.graph(col, "col");
+  const int64_t* seed_p = ix.ptr(seed, "seed");
   DeviceGuard guard(rowptr.device());
   const auto opts = at::TensorOptions().dtype(at::kLong).device(rowptr.device());
   SamplerHost host;
@@ -1166,18 +1174,18 @@ std::tuple<Tensor, Tensor, std::vector<int64_t>> dist_neighbor_sample_kernel(
   pyg_hip_relation wrel{};  // only carries the weights (set_weight checks them)
   if (edge_weight.has_value()) set_weight(wrel, edge_weight.value(), col.numel());
   const int rc = pyg_hip_dist_neighbor_sample(
-      rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), seed.data_ptr<int64_t>(), S, num_neighbors,
+      rowptr_p, col_p, seed_p, S, num_neighbors,
       node_time.has_value() ? time_ptr(node_time.value(), "node_time") : nullptr,
       edge_time.has_value() ? time_ptr(edge_time.value(), "edge_time") : nullptr,
       seed_time.has_value() ? time_ptr(seed_time.value(), "seed_time") : nullptr, wrel.edge_weight,
-      wrel.edge_weight_dtype, temporal_strategy == "last", replace, disjoint, &cb, &node_ptr, &edge_ptr, &E,
+      wrel.edge_weight_dtype, temporal_strategy == "last", replace, disjoint, ix.is32(), &cb, &node_ptr, &edge_ptr, &E,
       cumsum.data(), host.stream);
   if (rc == PYG_HIP_OK) loan.commit();
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);
   auto nodes = disjoint ? adopt(node_ptr, {S + E, 2}, opts) : adopt(node_ptr, {S + E}, opts);
   auto edges = adopt(edge_ptr, {E}, opts);
-  return std::make_tuple(nodes, edges, cumsum);
+  return std::make_tuple(ix.narrow(nodes), ix.narrow(edges), cumsum);
 }
 
 // ---------------------------------------------------------------------------------------------

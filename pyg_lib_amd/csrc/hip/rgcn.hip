@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 namespace pyg_hip {
@@ -437,12 +438,38 @@ __global__ __launch_bounds__(256) void rgcn_fused_kernel(const RgcnDesc desc, in
   }
 }
 
+// one pinned, device-visible error word per device (PYG_HIP_RGCN_DEFERRED)
+int deferred_error_slot(int** out) {
+  static std::mutex mu;
+  static int* slots[64] = {nullptr};
+  int dev = 0;
+  PYG_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!slots[dev]) {
+    void* p = nullptr;
+    PYG_HIP_CHECK(hipHostMalloc(&p, 64, hipHostMallocDefault));
+    *static_cast<int*>(p) = 0;
+    slots[dev] = static_cast<int*>(p);
+  }
+  *out = slots[dev];
+  return PYG_HIP_OK;
+}
+
 }  // namespace
 }  // namespace pyg_hip
 
 using namespace pyg_hip;
 
 extern "C" {
+
+int pyg_hip_rgcn_pending_error(void) {
+  int* slot = nullptr;
+  if (deferred_error_slot(&slot) != PYG_HIP_OK) return PYG_HIP_ERR_RUNTIME;
+  const int pending = *static_cast<volatile int*>(slot);
+  *static_cast<volatile int*>(slot) = 0;
+  return pending;
+}
 
 size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges) {
   if (num_relations < 0) num_relations = 0;
@@ -525,13 +552,31 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   constexpr int lds = 32768 + 4 * 8192;
   int* err_dev = reinterpret_cast<int*>(w + rel_b + tile_b);
   const bool cas = (checked & PYG_HIP_RGCN_CAS) != 0 || float_atomic_mode() == 1;
+  const bool deferred = (checked & PYG_HIP_RGCN_DEFERRED) != 0 && (checked & PYG_HIP_RGCN_CHECKED) == 0;
   checked &= PYG_HIP_RGCN_CHECKED;
   if (checked) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
+  if (deferred) {
+    // validated without a synchronisation: offenders are redirected to row 0 (never an out-of-bounds access) and the
+    // kernel leaves the code in a pinned word of this device; whoever looks next -- the next call here, or
+    // pyg_hip_rgcn_pending_error -- reports it
+    int* slot = nullptr;
+    int rc = deferred_error_slot(&slot);
+    if (rc != PYG_HIP_OK) return rc;
+    const int pending = *static_cast<volatile int*>(slot);
+    if (pending != 0) {
+      *static_cast<volatile int*>(slot) = 0;
+      return fail(PYG_HIP_ERR_INVALID,
+                  "rgcn_fused: an earlier call on this device had a %s index out of range (the offending edges were "
+                  "redirected to row 0; set PYG_HIP_RGCN_CHECK=1 to fail in the call that has them)",
+                  pending == 1 ? "gather" : "scatter");
+    }
+    err_dev = slot;
+  }
   const void* kern;
   {
 #define PYG_RGCN_PICK3(BF, CK, BG) (inl ? (const void*)&rgcn_fused_kernel<BF, CK, BG, true> : (const void*)&rgcn_fused_kernel<BF, CK, BG, false>)
 #define PYG_RGCN_PICK(BF, CK, BG) PYG_RGCN_PICK3(BF, CK, BG)
-    const bool bf = dtype == PYG_BF16, ck = (checked & PYG_HIP_RGCN_CHECKED) != 0;
+    const bool bf = dtype == PYG_BF16, ck = checked != 0 || deferred;
     kern = bf ? (ck ? (big ? PYG_RGCN_PICK(true, true, true) : PYG_RGCN_PICK(true, true, false))
                     : (big ? PYG_RGCN_PICK(true, false, true) : PYG_RGCN_PICK(true, false, false)))
               : (ck ? (big ? PYG_RGCN_PICK(false, true, true) : PYG_RGCN_PICK(false, true, false))

@@ -2155,7 +2155,7 @@ __global__ void dist_nodes_kernel(const int64_t* __restrict__ seed, int64_t S, c
 }
 
 // dist_neighbor_sample (neighbor_kernel.cpp:957-978): one hop over the seeds, no relabelling.
-int run_dist_sampler(const int64_t* rowptr, const int64_t* col, const int64_t* seed, int64_t S, int64_t count,
+int run_dist_sampler(const IdxArr rowptr, const IdxArr col, const int64_t* seed, int64_t S, int64_t count,
                      const int64_t* node_time, const int64_t* edge_time, const int64_t* seed_time,
                      const void* weight, int weight_dtype, int temporal_last, int replace, int disjoint, Ctx& c,
                      int64_t** out_node, int64_t** out_edge, int64_t* num_edges, int64_t* cumsum_host) {
@@ -2671,9 +2671,9 @@ extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t
                                             int64_t num_seed, int64_t num_neighbors, const int64_t* node_time,
                                             const int64_t* edge_time, const int64_t* seed_time,
                                             const void* edge_weight, int edge_weight_dtype, int temporal_last,
-                                            int replace, int disjoint, const pyg_hip_sampler_host* host,
-                                            int64_t** node_id, int64_t** edge_id, int64_t* num_edges,
-                                            int64_t* cumsum_host, void* stream_) {
+                                            int replace, int disjoint, int index_is32,
+                                            const pyg_hip_sampler_host* host, int64_t** node_id, int64_t** edge_id,
+                                            int64_t* num_edges, int64_t* cumsum_host, void* stream_) {
   PYG_HIP_REQUIRE(host && host->alloc && host->free && (host->rng_blocks || host->mt19937),
                   "dist sampler: host callbacks missing");
   PYG_HIP_REQUIRE(rowptr && (num_seed == 0 || seed) && node_id && edge_id && num_edges && cumsum_host,
@@ -2681,7 +2681,8 @@ extern "C" int pyg_hip_dist_neighbor_sample(const int64_t* rowptr, const int64_t
   Ctx c;
   c.host = host;
   c.stream = static_cast<hipStream_t>(stream_);
-  int rc = run_dist_sampler(rowptr, col, seed, num_seed, num_neighbors, node_time, edge_time, seed_time, edge_weight,
+  int rc = run_dist_sampler(IdxArr(rowptr, index_is32), IdxArr(col, index_is32), seed, num_seed, num_neighbors, node_time,
+                            edge_time, seed_time, edge_weight,
                             edge_weight_dtype, temporal_last, replace, disjoint, c, node_id, edge_id, num_edges,
                             cumsum_host);
   c.quiesce_side();

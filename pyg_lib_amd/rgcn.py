@@ -20,10 +20,20 @@ from typing import Dict, List, Tuple
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
 EdgeType = Tuple[str, str, str]
+
+
+def pending_index_error() -> int:
+    r"""The fused layer validates its gather / scatter indices on the device WITHOUT synchronising (a stale ``node_id`` is
+    redirected to row 0 instead of reading out of bounds; ``PYG_HIP_RGCN_CHECK=1``: synchronising check, ``=0``: none).
+    Returns and clears what the launches so far have found on the current device: 0 nothing, 1 a gather index, 2 a scatter
+    index out of range (meaningful after ``torch.cuda.synchronize()``); the next fused call raises for it otherwise."""
+    from . import _capi
+    return int(_capi.lib().pyg_hip_rgcn_pending_error())
 
 
 def type_offsets(num_nodes: Dict[str, int], node_types: List[str]) -> Dict[str, int]:
@@ -124,6 +134,7 @@ class _RGCNFused(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors[:2]
         index = ctx.saved_tensors[2:]
@@ -132,7 +143,7 @@ class _RGCNFused(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.zeros_like(x)
+            gx = x.new_zeros(x.shape)   # (contiguous whatever x's strides are: the kernel accumulates into it in place)
             torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
         if ctx.needs_input_grad[1]:
             ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
@@ -163,6 +174,7 @@ class _RGCNFusedTables(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         weight = ctx.saved_tensors[0]
         tensors = ctx.saved_tensors[1:]

@@ -305,6 +305,13 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
         want.index_add_(0, row_d[(s, r, d)] + off[s], msg)
     scale = want.abs().max().item()
     assert scale > 1.0 and (y.double() - want).abs().max().item() <= 2e-2 * scale
+    # the variant bench_legs.leg_c5 TIMES: rows gathered from the global feature tables through the sampler's node ids
+    # inside the kernel (no per-batch x) -- same float64 restatement, same bar, and close to the materialised form
+    # (only the 2 k-node case had this check)
+    yt = rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W)
+    assert yt.shape == y.shape
+    assert (yt.double() - want).abs().max().item() <= 2e-2 * scale
+    assert (yt.double() - y.double()).abs().max().item() <= 2e-2 * scale   # (atomic order differs between two launches)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
@@ -395,6 +402,44 @@ def test_checked_mode_reports_bad_indices(monkeypatch):
     assert call(g, bad_s, 1) != 0 and b'scatter index out of range' in L.pyg_hip_last_error()
     with pytest.raises(RuntimeError, match='must live on the device'):
         torch.ops.pyg.rgcn_fused(x, [g.cpu()], [s], [0], [0], w, out)
+
+
+def test_default_mode_validates_indices_without_synchronising():
+    """VERDICT r4 weak 4 / ADVICE r3: by default (no PYG_HIP_RGCN_CHECK in the environment) a stale node id must not be an
+    out-of-bounds read.  The kernel validates every index, redirects offenders to row 0 and leaves a code in a pinned
+    word: `pending_index_error()` returns it once the stream is synchronised, and a later fused call raises for it."""
+    import os
+    from pyg_lib_amd import rgcn
+    if os.environ.get('PYG_HIP_RGCN_CHECK') not in (None, ''):
+        pytest.skip('PYG_HIP_RGCN_CHECK is set: not the default mode')
+    n_table = 1000
+    feat = {'a': torch.randn(n_table, 128, device='cuda').bfloat16()}
+    w = torch.eye(128, device='cuda').bfloat16().unsqueeze(0).contiguous()
+    node_id = {'a': torch.arange(0, 60, device='cuda')}
+    et = ('a', 'r', 'a')
+    rows = {et: torch.sort(torch.randint(0, 60, (500,), device='cuda')).values}
+    cols = {et: torch.randint(0, 60, (500,), device='cuda')}
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    good = rgcn.rgcn_layer_fused_tables(feat, node_id, ['a'], rows, cols, [et], w)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    stale = {'a': node_id['a'].clone()}
+    stale['a'][7] = 10 ** 12                              # a node id far outside the table: would fault unchecked
+    y = rgcn.rgcn_layer_fused_tables(feat, stale, ['a'], rows, cols, [et], w)   # does not raise, does not fault
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert rgcn.pending_index_error() == 1                # gather index, reported once ...
+    assert rgcn.pending_index_error() == 0                # ... and cleared
+    y = rgcn.rgcn_layer_fused_tables(feat, stale, ['a'], rows, cols, [et], w)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='earlier call'):   # unpolled: the next call reports it
+        rgcn.rgcn_layer_fused_tables(feat, node_id, ['a'], rows, cols, [et], w)
+    again = rgcn.rgcn_layer_fused_tables(feat, node_id, ['a'], rows, cols, [et], w)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    assert torch.equal(again.view(torch.int16), good.view(torch.int16)) or \
+        (again.float() - good.float()).abs().max() <= 2e-2 * good.float().abs().max()
 
 
 def _hetero_case(g, dtype, integer):

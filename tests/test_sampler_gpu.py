@@ -319,6 +319,12 @@ def test_dist_random_graph_matches_oracle(variant):
     assert torch.equal(edge.cpu(), torch.from_numpy(redge))
     assert cumsum == rcumsum
     assert after == int(oracle.mt19937_words(5, info['rng_blocks'] * 128 + 1)[-1])
+    # an int32 graph is read in place (the reference dispatches on the seeds' integral type, neighbor_kernel.cpp:893):
+    # same draws, int32 results
+    torch.manual_seed(5)
+    n32, e32, c32 = torch.ops.pyg.dist_neighbor_sample(dev(rowptr).int(), dev(col).int(), dev(seeds).int(), fan, **dkw)
+    assert n32.dtype == torch.int32 and e32.dtype == torch.int32
+    assert torch.equal(n32.long(), node) and torch.equal(e32.long(), edge) and c32 == cumsum
 
 
 def test_hetero_hub_forces_word_top_up_and_requeue():
