@@ -211,6 +211,29 @@ def leg_segment_short(device, rows=1 << 22, seg_rows=256, F=128, dtype=torch.bfl
                 frac=round(alg / (ms * 1e-3) / 8e12, 4), ticket=dict(kernel=kern_t, kernel_ms=round(ms_t, 4)))
 
 
+def _clock_under(fn, ms_per_call, device, window_ms=40.0):
+    """Average shader clock (MHz) over ~window_ms of back-to-back `fn` launches (pyg_hip_clock_probe on a side stream)."""
+    import ctypes
+    from pyg_lib_amd import _capi
+    L = _capi.lib()
+    L.pyg_hip_clock_probe.restype = ctypes.c_int
+    L.pyg_hip_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    out = torch.zeros(2, dtype=torch.int64, device=device)
+    side = torch.cuda.Stream(device)
+    n = max(3, int(window_ms * 1.5 / max(ms_per_call, 1e-3)))
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize(device)
+    for _ in range(2):   # the probe starts once the load is running
+        fn()
+    _capi.check(L.pyg_hip_clock_probe(out.data_ptr(), float(window_ms), side.cuda_stream))
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(device)
+    c, r = [int(v) for v in out.tolist()]
+    return c / r * 100.0 if r > 0 else 0.0
+
+
 def leg_segment_matmul_f32(device, make_c2, iters=5):
     """BASELINE configs[1] in fp32: north_star's 1e-5 parity configuration.  `exact` = torch's default precision
     ('highest'): IEEE fp32 MFMAs (AI = 32 flop/B is above the fp32 ridge of 157 TF / 8 TB/s = 20, so that kernel is bound by
@@ -224,6 +247,9 @@ def leg_segment_matmul_f32(device, make_c2, iters=5):
     with ops.matmul_f32_split(False):  # torch's default precision ('highest')
         ms_e = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
         kern_e = ops.matmul_last_variant()
+        # the shader clock WHILE this kernel runs: a one-wave probe on a side stream watches the shader-clock counter against
+        # the constant 100 MHz counter over a window of back-to-back launches (the data-sheet peak is quoted at 2.4 GHz)
+        clock_mhz = _clock_under(lambda: ops.segment_matmul(x, ptr, w), ms_e, device)
     with ops.matmul_f32_split(True):   # torch.set_float32_matmul_precision('high')
         ms = _kernel_ms(lambda: ops.segment_matmul(x, ptr, w), iters=iters, warmup=2)
         kern_s = ops.matmul_last_variant()
@@ -234,7 +260,9 @@ def leg_segment_matmul_f32(device, make_c2, iters=5):
                 bound='hbm', achieved=round(gbps, 1), peak=8000.0, unit='GB/s', frac=round(gbps / 8000.0, 4),
                 kernel_ms=round(ms, 4), alg_bytes=int(alg), tflops=round(tf, 1), vs_f32_mfma_peak=round(tf / 157.0, 4),
                 exact=dict(kernel=kern_e, bound='mfma', achieved=round(tf_e, 1), peak=157.0, unit='TFLOP/s',
-                           frac=round(tf_e / 157.0, 4), kernel_ms=round(ms_e, 4)))
+                           frac=round(tf_e / 157.0, 4), kernel_ms=round(ms_e, 4), clock_MHz_under_load=round(clock_mhz, 0),
+                           peak_at_that_clock=round(157.0 * clock_mhz / 2400.0, 1),
+                           frac_of_peak_at_that_clock=round(tf_e / (157.0 * clock_mhz / 2400.0), 4) if clock_mhz > 0 else None))
 
 
 # ---------------------------------------------------------------------------------------------------

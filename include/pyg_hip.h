@@ -683,6 +683,12 @@ PYG_HIP_API int pyg_hip_profile_collect(float* ms_out, int capacity);
  * segment_matmul tile schedules without the arithmetic.  Measurement support; no operator calls it. */
 PYG_HIP_API int pyg_hip_stream_copy(const void* src, void* dst, size_t bytes, int mode, void* stream);
 
+/* The shader clock the chip actually runs at while other streams load it: one wave on `stream` watches the shader-clock
+ * counter and the constant 100 MHz counter for `milliseconds` and leaves {shader cycles, 100 MHz ticks} in out2 (device
+ * memory, 2 x uint64): MHz = out2[0] / out2[1] * 100.  The fp32 MFMA peak of the data sheet (157 TFLOP/s) is quoted at
+ * 2.4 GHz; under a sustained MFMA + HBM load the chip clocks lower, and bench.py prices the fp32 kernel against both. */
+PYG_HIP_API int pyg_hip_clock_probe(uint64_t* out2, double milliseconds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,10 +60,34 @@ __global__ void copy_tail_kernel(const char* __restrict__ in, char* __restrict__
   if (i < end) out[i] = in[i];
 }
 
+// One wave that watches both clocks for `real_ticks` ticks of the constant 100 MHz counter: out[0] = shader-clock cycles
+// elapsed (s_memtime), out[1] = constant-clock ticks elapsed (s_memrealtime).  It sleeps between looks (a spinning wave
+// would add to the load it is meant to observe).
+__global__ void clock_probe_kernel(uint64_t* out, uint64_t real_ticks) {
+  if (threadIdx.x != 0) return;
+  const uint64_t r0 = wall_clock64();
+  const uint64_t c0 = __builtin_readcyclecounter();
+  uint64_t r1 = r0;
+  while (r1 - r0 < real_ticks) {
+    __builtin_amdgcn_s_sleep(127);
+    r1 = wall_clock64();
+  }
+  out[0] = __builtin_readcyclecounter() - c0;
+  out[1] = r1 - r0;
+}
+
 }  // namespace
 }  // namespace pyg_hip
 
 using namespace pyg_hip;
+
+extern "C" int pyg_hip_clock_probe(uint64_t* out2_dev, double milliseconds, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PYG_HIP_REQUIRE(out2_dev != nullptr && milliseconds > 0 && milliseconds < 10000, "clock_probe: bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out2_dev, (uint64_t)(milliseconds * 1e5));
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
 
 extern "C" int pyg_hip_stream_copy(const void* src, void* dst, size_t bytes, int mode, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
