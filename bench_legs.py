@@ -328,6 +328,25 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
         sample(i)
     torch.cuda.synchronize()
     samp_ms = (time.perf_counter() - t0) / iters * 1e3
+    # K batches per call (hetero_neighbor_sample_batched: the batches' launch chains overlap on private streams; bit for bit
+    # the single-batch results, tests/test_sampler_batched_gpu.py), each followed by its layer
+    K = min(8, iters)
+    sd = [{'paper': seeds[3 + k]} for k in range(K)]
+    gseeds = [100 + k for k in range(K)]
+    sampler.hetero_neighbor_sample_batched(rp, cl, sd, fan, gseeds)
+    torch.cuda.synchronize()
+    reps = max(1, iters // K)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sampler.hetero_neighbor_sample_batched(rp, cl, sd, fan, gseeds)
+    torch.cuda.synchronize()
+    samp_b_ms = (time.perf_counter() - t0) / (reps * K) * 1e3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for o in sampler.hetero_neighbor_sample_batched(rp, cl, sd, fan, gseeds):
+            layer(o)
+    torch.cuda.synchronize()
+    total_b_ms = (time.perf_counter() - t0) / (reps * K) * 1e3
     out = state['last']
     layer_ms = _event_ms(lambda: layer(out), iters)
     e = sum(v.numel() for v in out[0].values())
@@ -339,6 +358,8 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
                          'entries), batch 1024 papers, fanout [15, 10], F=128 bf16 (BASELINE.json configs[4])',
                 layer_impl='rgcn_layer_fused_tables', sampler_mode=sampler.last_mode(), edges_per_batch=edges // iters, nodes_last_batch=n,
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
+                batched=dict(K=K, ms_sampler_per_batch=round(samp_b_ms, 4), ms_end_to_end_per_batch=round(total_b_ms, 4),
+                             what='hetero_neighbor_sample_batched (K batches per call) + one fused layer per batch'),
                 layer=_rate(alg, layer_ms))
 
 

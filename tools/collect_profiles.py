@@ -34,6 +34,9 @@ cp('prof_bench/bench_kernel_stats.csv', 'bench_kernel_stats.csv')
 cp('prof_c2/c2_kernel_stats.csv', 'c2_kernel_stats.csv')
 cp('prof_samp/samp_kernel_stats.csv', 'sampler_c3_kernel_stats.csv')
 cp('bench_2rank_debug.json', 'bench_2rank_debug_one_device.json')
+cp('sampler_batched.txt', 'sampler_batched.txt')
+cp('sampler_batched_overlap.txt', 'sampler_batched_overlap.txt')
+cp('clock_probe.txt', 'clock_probe.txt')
 
 
 def rows(d):

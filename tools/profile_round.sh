@@ -17,4 +17,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/pmc_ops_$c -o p -- python /root/repo/tools/pmc_targets.py > $R/pmc_ops_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_samp -o samp -- python /root/repo/tools/profile_sampler.py 20 > $R/prof_samp.log 2>&1
+# K batches per call: throughput (un-profiled) and how much the lanes' kernels overlap (kernel trace)
+python /root/repo/tools/bench_sampler_batched.py 8 16 32 > $R/sampler_batched.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/trace_batched -o t -- python /root/repo/tools/bench_sampler_batched.py 16 > $R/trace_batched.log 2>&1
+python /root/repo/tools/trace_overlap.py $(find $R/trace_batched -name "*kernel_trace.csv" | head -1) 1600 > $R/sampler_batched_overlap.txt 2>&1
+rm -rf $R/trace_batched
+python /root/repo/tools/clock_probe.py > $R/clock_probe.txt 2>&1
+cp /root/repo/gpurun_out/gpu_health.txt $R/gpu_health.txt 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 /root/repo/bench.py --gpus 2 --debug-one-device --no-cpu-baseline > $R/bench_2rank_debug.json 2> $R/bench_2rank_debug.err
