@@ -1087,6 +1087,8 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0, bool epo
 }
 
 
+constexpr int kWideSlackWords = 64;  // random words per (hop, relation) the speculation adds for rows of degree >= 2^16
+                                    // (their draws take 32 bits: two per word instead of four)
 constexpr int kNeedSlow = 1000;    // internal: repeat the call in the synchronising mode
 constexpr int kNeedQueued = 1001;  // internal: repeat the call through round 2's fully queued chain (no fused chain)
 
@@ -1245,6 +1247,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         }
         draws += fb[(size_t)src] * (double)count;
         nf[(size_t)dst] += fb[(size_t)src] * (double)count;
+        if (fb[(size_t)src] > 0 && count > 0) cum += (double)kWideSlackWords;  // (the fused chain's allowance for 32-bit draws)
       }
       cum += draws / 4.0 + 128.0;
       spec.push_back((int64_t)std::min<double>(cum, (double)kSpecCapWords));

@@ -50,9 +50,11 @@ struct FusedOp {
     r.rank = a.rank + b.rank;
     if constexpr (NC > 0) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {  // 16-bit draws only (see consumer_count_bounds): tables compose by addition
+      for (int c = 0; c < NC; ++c) {
+        // pure (16-bit draws only) tables compose by addition, inline; a table that holds a wider draw -- a row of degree
+        // >= 2^16 -- takes the out-of-line general composition (NOT commutative: every reduction below keeps input order)
         r.next[c].edges = a.next[c].edges + b.next[c].edges;
-        r.next[c].tab = a.next[c].tab + (b.next[c].tab & ~kPureTab);
+        r.next[c].tab = rng_compose(a.next[c].tab, b.next[c].tab);
       }
     }
     return r;
@@ -212,6 +214,18 @@ __device__ __forceinline__ T uniform_record(const T* p) {
   return out;
 }
 
+// transition table of `count` draws from a row of `deg` >= 2^16 neighbours (CountLoad::operator(), sampler.hip)
+__device__ __attribute__((noinline)) RngTab wide_row_table(int64_t deg, int64_t count, int replace) {
+  RngTab t = rng_identity();
+  if (replace) {
+    const int n = need_units((u64)deg);
+    for (int64_t j = 0; j < count; ++j) rng_push_draw(t, n);
+  } else {
+    for (int64_t j = deg - count; j < deg; ++j) rng_push_draw(t, need_units((u64)(j + 1)));
+  }
+  return t;
+}
+
 // (edges, RNG table) of node v for one consumer: CountLoad::operator() for a node that is being appended
 __device__ __forceinline__ CountAgg consumer_count_bounds(const FConsumer& cs, int64_t rs0, int64_t re0, int64_t batch_id,
                                                           int32_t* wide) {
@@ -228,18 +242,19 @@ __device__ __forceinline__ CountAgg consumer_count_bounds(const FConsumer& cs, i
     return r;
   }
   r.edges = count;
-  r.tab = tab_pure(count);
-  // a draw wider than 16 bits needs the packed 5-state tables (and more words than the speculation generated): not
-  // carried here -- with them inlined the scan kernels needed 250 registers + 2.4 KB of scratch per lane
-  if ((u64)deg >= (1ull << 16)) *wide = 1;
+  // a row of degree >= 2^16 draws 32-bit numbers (rand_engine.h:44-50): its table is the packed 5-state form, built out
+  // of line (inlined, the table arithmetic cost the scan kernels 250 registers + 2.4 KB of scratch per lane)
+  r.tab = (u64)deg < (1ull << 16) ? tab_pure(count) : wide_row_table(deg, count, cs.replace);
+  (void)wide;
   return r;
 }
 
 // cache word of an emission: bit 0 = first occurrence; consumer c at bits [1 + 15 c, 16 + 15 c): edges (7 bits, <= 64),
-// bit 7 = sampled (count 16-bit draws)
+// bit 7 = sampled (count 16-bit draws), bit 8 = sampled from a row of degree >= 2^16 (wider draws)
 __device__ __forceinline__ u64 cons_encode(const CountAgg& a) {
   u64 code = (u64)a.edges & 0x7f;
   if (a.tab != rng_identity()) code |= 1u << 7;
+  if (!tab_is_pure(a.tab)) code |= 1u << 8;  // a wide row: the apply pass rebuilds its table from the row bounds
   return code;
 }
 
@@ -371,6 +386,12 @@ __device__ __forceinline__ void fused_apply(const FScanLaunch& L, const FPart& p
           const u64 code = (word[k] >> (1 + 15 * c)) & 0x7fff;
           v[k].next[c].edges = (int64_t)(code & 0x7f);
           v[k].next[c].tab = (code & (1u << 7)) ? tab_pure(cons.c[c].count) : rng_identity();
+          if (code & (1u << 8)) {  // rare: a wide row -- its table depends on the degree: fetch the row bounds again
+            const int64_t nd = pt.e_node[p];
+            const int64_t bt = pt.e_batch ? pt.e_batch[p] : 0;
+            v[k].next[c] = consumer_count_bounds(cons.c[c], cons.c[c].range.rowptr[nd], cons.c[c].range.rowptr[nd + 1], bt,
+                                                 L.tb.wide);
+          }
         }
       }
     }
@@ -380,15 +401,17 @@ __device__ __forceinline__ void fused_apply(const FScanLaunch& L, const FPart& p
   for (int k = 0; k < kScanItems; ++k) agg = op(agg, v[k]);
   T total;
   T run = block_exclusive<T, Op>(agg, lds, op, &total);
-  // every block reduces the aggregates of the tiles in front of it (of the whole segment) for itself
-  // (the operator is plain addition here -- ranks, edge counts, 16-bit draw counts --, so the order does not matter:
-  // strided partial sums, then ONE block reduction, instead of a block scan per 256 tiles)
+  // every block reduces the aggregates of the tiles in front of it (of the whole segment) for itself: every thread a
+  // CONTIGUOUS run of tiles, then ONE ordered block reduction (instead of a block scan per 256 tiles) -- tile order is
+  // kept, because the composition of tables that hold wide draws does not commute
   T before = Op::identity();
   const int ntb = pt.tile0 + lt;
   const T* tiles = static_cast<const T*>(pt.h.tile_agg);
   {
     T part = Op::identity();
-    for (int i = (int)threadIdx.x; i < ntb; i += kScanThreads) part = op(part, tiles[i]);
+    const int per = (ntb + kScanThreads - 1) / kScanThreads;
+    const int i0 = (int)threadIdx.x * per, i1 = min(i0 + per, ntb);
+    for (int i = i0; i < i1; ++i) part = op(part, tiles[i]);
     (void)block_exclusive<T, Op>(part, lds, op, &before);
   }
   run = op(before, run);

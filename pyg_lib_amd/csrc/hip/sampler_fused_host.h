@@ -493,7 +493,9 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       cur.push_back(s);
     }
     // ---- queue the hop: [finalize(l - 1) | sample(l)] -> reduce -> apply (+ carry) ----
-    for (const Step& s : cur) spec_word += (s.Eb + 3) / 4 + 1;
+    // (16-bit draws: four per word; a row of degree >= 2^16 draws 32-bit numbers, two per word -- the slack covers a few
+    // hundred such draws per relation and hop, more of them end in the overflow flag and the synchronising repeat)
+    for (const Step& s : cur) spec_word += (s.Eb + 3) / 4 + 1 + kWideSlackWords;
     int rc = PYG_HIP_OK;
     if (!cur.empty()) {  // order the words this hop may read (16-bit draws, cumulative bound) before its sampling launch
       pt.mark("hop_built");

@@ -132,7 +132,35 @@ def test_wide_draws_above_65535():
     seeds = np.array([17, 3, 123, 500, 9, 17])
     for kw in ({}, dict(replace=True), dict(disjoint=True)):
         out, after, ref = run_both(rowptr, col, seeds, [25, 10], 99, **kw)
+        # round 5: the fused chain carries the general transition tables itself -- a hub no longer sends
+        # the call to the queued chain; degree 65536 with fan-out 25 mixes 16- and 32-bit draws inside one row
+        assert sampler.last_mode() == 'fused'
         assert_same(out, after, ref, 99)
+
+
+def test_every_row_a_hub_exceeds_the_word_allowance_and_repeats_synchronising():
+    """The fused chain speculates four 16-bit draws per random word (+ 64 words per relation and hop for rows of degree
+    >= 2^16, whose draws take 32 bits).  A graph in which EVERY row is such a hub needs twice the words: the chain's
+    overflow flag sends the call to the synchronising driver -- same bits, same generator state."""
+    rng = np.random.default_rng(15)
+    n = 500
+    deg = np.full(n, 66_000, dtype=np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n, int(rowptr[-1]), dtype=np.int64)
+    seeds = rng.permutation(n).astype(np.int64)
+    out, after, ref = run_both(rowptr, col, seeds, [64, 4], 7)   # 32,000 wide draws = 16,000 words in hop 0: 8,000 + slack speculated
+    assert_same(out, after, ref, 7)
+    assert sampler.last_mode() == 'synchronising'
+    out, after, ref = run_both(rowptr, col, seeds[:200], [12, 6], 7)   # (fewer of them still fit what was generated)
+    assert_same(out, after, ref, 7)
+    # a few hubs among ordinary rows stay inside the allowance: fused
+    deg2 = rng.poisson(12, n).astype(np.int64)
+    deg2[[3, 77, 300]] = 66_000
+    rowptr2 = np.concatenate([[0], np.cumsum(deg2)]).astype(np.int64)
+    col2 = rng.integers(0, n, int(rowptr2[-1]), dtype=np.int64)
+    out, after, ref = run_both(rowptr2, col2, np.array([3, 5, 77, 300, 9]), [12, 6], 8)
+    assert sampler.last_mode() == 'fused'
+    assert_same(out, after, ref, 8)
 
 
 @pytest.mark.parametrize('csc', [False, True])
