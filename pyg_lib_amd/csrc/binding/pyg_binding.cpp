@@ -786,8 +786,9 @@ static std::vector<SampleOutput> run_sampler_batched(const std::vector<pyg_hip_r
       if (return_edge_id) outs[b].edge_id.push_back(adopt(p.eid[(size_t)e], {n}, opts));
       outs[b].edges_per_hop.emplace_back(p.eph.begin() + (size_t)e * L, p.eph.begin() + (size_t)(e + 1) * L);
     }
-    TORCH_CHECK(p.host.error.empty(), p.host.error);
   }
+  // (errors only after every block that was handed out has an owner)
+  for (size_t b = 0; b < K; ++b) TORCH_CHECK(pb[b].host.error.empty(), pb[b].host.error);
   check_status(rc);
   return outs;
 }

@@ -112,7 +112,7 @@ def pytest_runtest_makereport(item, call):
                     item.runtest()
                     torch.cuda.synchronize()
                     lines.append(f'same test body again, float atomics = {mode}: PASSED')
-                except BaseException as e:  # noqa: BLE001
+                except (Exception, pytest.fail.Exception, pytest.skip.Exception) as e:  # noqa: BLE001
                     lines.append(f'same test body again, float atomics = {mode}: FAILED ({type(e).__name__}: {str(e)[:200]})')
                 finally:
                     diagnostics.set_float_atomic_mode(before)
