@@ -398,12 +398,13 @@ typedef struct {
  * missing host->mt19937 fail with PYG_HIP_ERR_UNSUPPORTED.
  * Synchronises `stream` (output sizes are data dependent).
  */
-/* Driver the calling thread's last neighbor / hetero sampler call ran: "fused" (bounded fan-outs <= 64: 2 - 3 launches per
- * hop -- scans of up to 256 tiles are one launch, PYG_HIP_SAMPLER_ONEPASS=0: always a reduce + apply pair --,
+/* Driver the calling thread's last neighbor / hetero sampler call ran: "fused" (bounded fan-outs <= 1024: 2 - 3 launches
+ * per hop -- scans of up to 256 tiles are one launch, PYG_HIP_SAMPLER_ONEPASS=0: always a reduce + apply pair --,
  * csrc/hip/sampler_fused.h; since round 5 also with rows of degree >= 2^16, whose 32-bit draws the chain's transition
- * tables carry), "queued" (round 2's chain: PYG_HIP_SAMPLER_FUSED=0 or more than 3 relations expanding one node
- * type), "synchronising" (unbounded / > 64 fan-outs, weighted relations, more wide draws than the speculated random
- * words allow, or PYG_HIP_SAMPLER_SYNC_MODE=1).  Diagnostics only; every driver returns the same bits. */
+ * tables carry, and with fan-outs above 64, sampled one wave per node), "queued" (round 2's chain:
+ * PYG_HIP_SAMPLER_FUSED=0 or more than 3 relations expanding one node type; fan-outs <= 64), "synchronising"
+ * (unbounded / > 1024 fan-outs, weighted relations, more wide draws than the speculated random words allow, or
+ * PYG_HIP_SAMPLER_SYNC_MODE=1).  Diagnostics only; every driver returns the same bits. */
 PYG_HIP_API const char* pyg_hip_sampler_last_mode(void);
 /* Direct-address node tables of the fused chain are kept between calls (per device and node count; blocks come from
  * host->alloc and are never freed): a call's values carry an epoch in their upper bits, so what an earlier call left

@@ -589,12 +589,9 @@ __device__ __forceinline__ void resolve_device_state(HopArgs& a) {
   }
 }
 
-// One wave per frontier node (_sample, neighbor_kernel.cpp:177-243).
-__global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
-  if (hop_overflow(a)) return;
-  resolve_device_state(a);
+// One wave per frontier node (_sample, neighbor_kernel.cpp:177-243): any fan-out.  `i` = frontier index of this wave's node.
+__device__ __forceinline__ void sample_wave_body(const HopArgs& a, int64_t i) {
   const int lane = threadIdx.x & 63;
-  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (i >= a.frontier) return;
   const int64_t src_pos = a.begin + i;
   const int64_t v = a.nodes[src_pos];
@@ -611,7 +608,17 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
     return;
   }
 
-  RngCursor rng{a.rng_word[i], a.rng_units[i], a.word_src()};
+  int64_t w0;
+  int u0;
+  if (a.tab_prefix) {  // fused chain: the node's engine position = the relation's start advanced by its prefix table
+    const RngTab tp = a.tab_prefix[i];
+    w0 = a.w0 + tab_dw(tp, a.u0);
+    u0 = tab_nb(tp, a.u0);
+  } else {
+    w0 = a.rng_word[i];
+    u0 = a.rng_units[i];
+  }
+  RngCursor rng{w0, u0, a.word_src()};
   if (a.replace) {
     // `count` independent draws from [0, deg) (:196-210); lanes take turns holding a draw
     int64_t mine = 0;
@@ -646,6 +653,12 @@ __global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
       if (j != count - 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
   }
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(HopArgs a) {
+  if (hop_overflow(a)) return;
+  resolve_device_state(a);
+  sample_wave_body(a, (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
 }
 
 // G lanes per frontier node, 64 / G nodes per wave, for fan-outs 0 < count <= G: lane g owns draw g.
@@ -1087,6 +1100,7 @@ int table_reserve(Ctx& c, NodeSet& ns, int64_t extra, int64_t hint = 0, bool epo
 }
 
 
+constexpr int kMaxFusedCount = 1024;  // largest fan-out the fused chain samples (12 bits of its cached word; > 64: one wave per node)
 constexpr int kWideSlackWords = 64;  // random words per (hop, relation) the speculation adds for rows of degree >= 2^16
                                     // (their draws take 32 bits: two per word instead of four)
 constexpr int kNeedSlow = 1000;    // internal: repeat the call in the synchronising mode
@@ -1184,6 +1198,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   std::vector<std::vector<int64_t>> eb((size_t)L, std::vector<int64_t>((size_t)num_relations, 0));
   std::vector<std::vector<int64_t>> fbh((size_t)L, std::vector<int64_t>((size_t)num_node_types, 0));
   std::vector<int64_t> node_bound((size_t)num_node_types, 0), rel_bound((size_t)num_relations, 0);
+  bool big_count = false;
   if (fast) {
     std::vector<int64_t> fb((size_t)num_node_types, 0);
     for (int s = 0; s < num_seed_sets; ++s)
@@ -1197,7 +1212,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
         const int src = !csc ? rels[e].src_type : rels[e].dst_type;
         const int dst = !csc ? rels[e].dst_type : rels[e].src_type;
         const int64_t count = rels[e].num_neighbors_host[ell];
-        if (count < 0 || count > 64) fast = false;
+        // (fan-outs of 65 ... kMaxFusedCount: one wave per node -- inside the fused chain only, decided below)
+        if (count < 0 || count > kMaxFusedCount) fast = false;
+        else if (count > 64) big_count = true;
         if (count <= 0 || fb[(size_t)src] == 0 || rels[e].num_cols == 0) continue;
         const int64_t b = fb[(size_t)src] * count;
         eb[(size_t)ell][(size_t)e] = b;
@@ -1212,6 +1229,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   }
 
   const bool fused = fast && allow_fused && fused_eligible(rels, num_relations, num_node_types, num_seed_sets, csc, L, eb);
+  if (big_count && !fused) fast = false;  // the queued chain keeps its limit of 64 draws per node
   std::vector<FusedSeed> fseeds;
   if (!fused) {
     // the chains below read and advance the device-resident engine position / type states; the fused chain keeps its

@@ -173,7 +173,7 @@ struct FFinalRec {  // local ids of relation e's emissions of hop l
   int ell, e;
 };
 
-enum FRole { kRoleSample8 = 0, kRoleSample16, kRoleSample32, kRoleSample64, kRoleFinalize, kRoleFold };
+enum FRole { kRoleSample8 = 0, kRoleSample16, kRoleSample32, kRoleSample64, kRoleFinalize, kRoleFold, kRoleSampleWave };
 
 struct FFoldRec {  // what the fold role hands to the host, straight into pinned memory (no copies behind the last launch)
   MtHandBack* hb;            // engine hand-back (nullptr: the caller's engine is not device-resident)
@@ -249,12 +249,12 @@ __device__ __forceinline__ CountAgg consumer_count_bounds(const FConsumer& cs, i
   return r;
 }
 
-// cache word of an emission: bit 0 = first occurrence; consumer c at bits [1 + 15 c, 16 + 15 c): edges (7 bits, <= 64),
-// bit 7 = sampled (count 16-bit draws), bit 8 = sampled from a row of degree >= 2^16 (wider draws)
+// cache word of an emission: bit 0 = first occurrence; consumer c at bits [1 + 15 c, 16 + 15 c): edges (12 bits, <=
+// kMaxFusedCount), bit 12 = sampled (count 16-bit draws), bit 13 = sampled from a row of degree >= 2^16 (wider draws)
 __device__ __forceinline__ u64 cons_encode(const CountAgg& a) {
-  u64 code = (u64)a.edges & 0x7f;
-  if (a.tab != rng_identity()) code |= 1u << 7;
-  if (!tab_is_pure(a.tab)) code |= 1u << 8;  // a wide row: the apply pass rebuilds its table from the row bounds
+  u64 code = (u64)a.edges & 0xfff;
+  if (a.tab != rng_identity()) code |= 1u << 12;
+  if (!tab_is_pure(a.tab)) code |= 1u << 13;  // a wide row: the apply pass rebuilds its table from the row bounds
   return code;
 }
 
@@ -384,9 +384,9 @@ __device__ __forceinline__ void fused_apply(const FScanLaunch& L, const FPart& p
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const u64 code = (word[k] >> (1 + 15 * c)) & 0x7fff;
-          v[k].next[c].edges = (int64_t)(code & 0x7f);
-          v[k].next[c].tab = (code & (1u << 7)) ? tab_pure(cons.c[c].count) : rng_identity();
-          if (code & (1u << 8)) {  // rare: a wide row -- its table depends on the degree: fetch the row bounds again
+          v[k].next[c].edges = (int64_t)(code & 0xfff);
+          v[k].next[c].tab = (code & (1u << 12)) ? tab_pure(cons.c[c].count) : rng_identity();
+          if (code & (1u << 13)) {  // rare: a wide row -- its table depends on the degree: fetch the row bounds again
             const int64_t nd = pt.e_node[p];
             const int64_t bt = pt.e_batch ? pt.e_batch[p] : 0;
             v[k].next[c] = consumer_count_bounds(cons.c[c], cons.c[c].range.rowptr[nd], cons.c[c].range.rowptr[nd + 1], bt,
@@ -754,7 +754,8 @@ __device__ __forceinline__ void fused_sample(const FSampleLaunch& L, const FSamp
   a.tab_prefix = rec.tabp;
   a.w0 = r.word;
   a.u0 = r.units;
-  sample_group_body<G>(a, blk);
+  if constexpr (G == 0) sample_wave_body(a, ((int64_t)blk * blockDim.x + threadIdx.x) >> 6);  // fan-outs > 64: a wave per node
+  else sample_group_body<G>(a, blk);
 }
 
 __device__ __forceinline__ void fused_finalize(const FSampleLaunch& L, const FFinalRec& ff, int blk) {
@@ -802,6 +803,9 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
       break;
     case kRoleSample64:
       if constexpr (GMAX >= 64) fused_sample<64, I64>(L, L.s[idx], b, avail_blocks, words);
+      break;
+    case kRoleSampleWave:
+      if constexpr (GMAX >= 64) fused_sample<0, I64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleFinalize: fused_finalize(L, L.f[idx], b); break;
     default: {  // kRoleFold: the engine position, the tables and the engine hand-back, written where the host reads them

@@ -229,8 +229,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   auto launch_sample = [&](const FSampleLaunch& l) -> int {
     if (l.n == 0) return PYG_HIP_OK;
     int gmax = 8;
-    for (int k = 0; k < l.n; ++k)
+    for (int k = 0; k < l.n; ++k) {
       if (l.role[k] <= kRoleSample64) gmax = std::max(gmax, 8 << l.role[k]);
+      if (l.role[k] == kRoleSampleWave) gmax = 64;
+    }
     const dim3 grid((unsigned)l.cum[l.n - 1]), block(256);
     const u64* words = rng.dev;
 #define PYG_FUSED_SAMPLE_LAUNCH(G)                                                                                  \
@@ -461,7 +463,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       sr.ell = ell;
       sr.e = e;
       sr.t_src = src;
-      const int role = count <= 8 ? kRoleSample8 : count <= 16 ? kRoleSample16 : count <= 32 ? kRoleSample32 : kRoleSample64;
+      const int role = count <= 8 ? kRoleSample8 : count <= 16 ? kRoleSample16 : count <= 32 ? kRoleSample32
+                       : count <= 64 ? kRoleSample64 : kRoleSampleWave;
       const int64_t per = count <= 8 ? 32 : count <= 16 ? 16 : count <= 32 ? 8 : 4;  // frontier nodes per block
       add_sample(p1, role, (Fb + per - 1) / per, nsmp++);
       FPart pp;

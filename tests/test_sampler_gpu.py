@@ -113,9 +113,25 @@ def test_large_fanout_uses_history_of_earlier_rounds():
     rowptr, col = random_csr(2000, 400, seed=4, zero_frac=0.0)
     seeds = np.arange(0, 2000, 97)
     out, after, ref = run_both(rowptr, col, seeds, [150, 3], 11)
+    assert sampler.last_mode() == 'fused'   # round 5: fan-outs of 65 ... 1024 sample one wave per node INSIDE the fused chain
     assert_same(out, after, ref, 11)
     out, after, ref = run_both(rowptr, col, seeds, [200], 11, replace=True)
+    assert sampler.last_mode() == 'fused'
     assert_same(out, after, ref, 11)
+    # rows shorter than the fan-out (whole neighbourhoods of up to 1023 edges), a hub, disjoint, three hops
+    rng = np.random.default_rng(41)
+    n = 3000
+    deg = rng.integers(0, 900, n).astype(np.int64)
+    deg[11] = 70_000
+    rowptr2 = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col2 = rng.integers(0, n, int(rowptr2[-1]), dtype=np.int64)
+    for kw in ({}, dict(disjoint=True), dict(replace=True)):
+        out, after, ref = run_both(rowptr2, col2, np.array([11, 5, 2999, 40]), [700, 65, 2], 12, **kw)
+        assert sampler.last_mode() == 'fused'
+        assert_same(out, after, ref, 12)
+    out, after, ref = run_both(rowptr2, col2, np.array([11, 5]), [1025, 2], 13)   # beyond the chain's limit: another driver, same bits
+    assert sampler.last_mode() != 'fused'
+    assert_same(out, after, ref, 13)
 
 
 def test_wide_draws_above_65535():
