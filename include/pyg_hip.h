@@ -590,10 +590,17 @@ typedef enum {
  *             (and for small or element-wise indexed inputs, float64 sums) the atomic kernels run.
  *             Bit 2 (PYG_HIP_SCATTER_CAS): the atomic kernels add floats / doubles / packed 16-bit pairs through
  *             compare-and-swap loops instead of the hardware's floating-point atomic adds.
+ *             Bit 3 (PYG_HIP_SCATTER_DETERMINISTIC, floating SUM): no float atomics at all -- an unsorted index vector
+ *             broadcast along k (one vector, B == 1) takes the stable-sort + CSR-row path WHATEVER its size, row width
+ *             or floating type (needs the workspace): sums in source order, the same bits in every run, like the
+ *             reference's sequential CPU loop (ops/cpu/scatter_kernel.cpp:29-127).  Layouts without an atomic-free
+ *             kernel (element-wise indices, B > 1 unsorted) and floating MUL return PYG_HIP_ERR_UNSUPPORTED with the
+ *             bit set.  The torch binding sets it when torch.are_deterministic_algorithms_enabled().
  */
 #define PYG_HIP_SCATTER_SORTED 1
 #define PYG_HIP_SCATTER_FRESH_SUM 2
 #define PYG_HIP_SCATTER_CAS 4
+#define PYG_HIP_SCATTER_DETERMINISTIC 8
 PYG_HIP_API size_t pyg_hip_scatter_workspace_size(int64_t B, int64_t E, int64_t N);
 PYG_HIP_API int pyg_hip_scatter(int op, int dtype, const void* src, const int64_t* index,
                                 int64_t index_stride_b, int64_t index_stride_e,

@@ -17,6 +17,7 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/autograd.h>
+#include <ATen/Context.h>
 #include <torch/library.h>
 
 #include <cstdlib>
@@ -316,6 +317,9 @@ static void rgcn_index_checks(const at::TensorList gather_index, const at::Tenso
 Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, const at::TensorList scatter_index,
                          at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
   PYG_TRACE("pyg::rgcn_fused");
+  // packed 16-bit atomic adds: the result depends on the order they land in (pyg_lib_amd.rgcn takes the atomic-free
+  // three-op chain under torch.use_deterministic_algorithms(True) instead of calling this operator)
+  at::globalContext().alertNotDeterministic("pyg::rgcn_fused");
   const size_t R = gather_index.size();
   TORCH_CHECK(scatter_index.size() == R && gather_offset.size() == R && scatter_offset.size() == R,
               "rgcn_fused: one gather / scatter index vector and offset per relation expected");
@@ -361,6 +365,7 @@ Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList 
                                 const at::TensorList gather_index, const at::TensorList scatter_index,
                                 at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
   PYG_TRACE("pyg::rgcn_fused_tables");
+  at::globalContext().alertNotDeterministic("pyg::rgcn_fused_tables");  // (see rgcn_fused_kernel)
   const size_t R = gather_index.size(), T = feat.size();
   TORCH_CHECK(T > 0 && node_id.size() == T, "rgcn_fused_tables: one node-id vector per feature table expected");
   TORCH_CHECK(scatter_index.size() == R && gather_type.size() == R && scatter_offset.size() == R,

@@ -5,6 +5,7 @@
 // (pyg_lib/csrc/ops/autograd/scatter_kernel.cpp, segment_coo_kernel.cpp) on top of these ops.
 #include <ATen/core/dispatch/Dispatcher.h>
 #include <torch/autograd.h>
+#include <ATen/Context.h>
 #include <torch/library.h>
 
 #include <optional>
@@ -179,14 +180,30 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
   // min / max: atomic-free CSR walk for a sorted (COO) index or one large unsorted index vector
   const bool csr_minmax = minmax && l.isk == 0 && (coo || (l.B == 1 && l.ise == 1 && l.E >= (1 << 15)));
   const bool csr_sum = op == OP_SUM && coo && l.isk == 0;  // sorted index: atomic-free CSR row sums
-  if (sort_sum || csr_minmax || csr_sum)
+  // torch.use_deterministic_algorithms(True): floating sums / products must not go through atomics (their result would
+  // depend on the order the adds land in).  Sums have an atomic-free kernel for a sorted index and for one unsorted index
+  // vector of ANY size (stable sort + CSR rows, source order); where there is none, torch's own convention applies:
+  // alertNotDeterministic raises, or warns under warn_only and the atomic kernel runs.
+  const bool floating = at::isFloatingType(src_c.scalar_type());
+  bool det = at::globalContext().deterministicAlgorithms() && floating && (op == OP_SUM || op == OP_MUL);
+  const bool det_sort = det && op == OP_SUM && !coo && l.B == 1 && l.isk == 0 && l.ise == 1;
+  if (sort_sum || csr_minmax || csr_sum || det_sort)
     ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.B, l.E, l.N)}, src_c.options().dtype(at::kByte));
-  check_status(pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk,
-                               out.data_ptr(), minmax ? arg.data_ptr<int64_t>() : nullptr,
-                               init.defined() ? init.data_ptr() : nullptr, l.B, l.E, l.K, l.N,
-                               (coo ? PYG_HIP_SCATTER_SORTED : 0) | (fresh && op == OP_SUM ? PYG_HIP_SCATTER_FRESH_SUM : 0),
-                               ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0,
-                               stream));
+  const int base_flags = (coo ? PYG_HIP_SCATTER_SORTED : 0) | (fresh && op == OP_SUM ? PYG_HIP_SCATTER_FRESH_SUM : 0);
+  int rc = pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk, out.data_ptr(),
+                           minmax ? arg.data_ptr<int64_t>() : nullptr, init.defined() ? init.data_ptr() : nullptr, l.B, l.E,
+                           l.K, l.N, base_flags | (det ? PYG_HIP_SCATTER_DETERMINISTIC : 0),
+                           ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0, stream);
+  if (rc == PYG_HIP_ERR_UNSUPPORTED && det) {
+    at::globalContext().alertNotDeterministic(
+        op == OP_MUL ? "pyg::scatter_mul on floating-point HIP tensors"
+                     : "pyg::scatter_sum / scatter_mean on HIP tensors with an element-wise (or batched unsorted) index");
+    rc = pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk, out.data_ptr(),
+                         minmax ? arg.data_ptr<int64_t>() : nullptr, init.defined() ? init.data_ptr() : nullptr, l.B, l.E,
+                         l.K, l.N, base_flags, ws.defined() ? ws.data_ptr() : nullptr,
+                         ws.defined() ? (size_t)ws.numel() : 0, stream);
+  }
+  check_status(rc);
   return std::make_tuple(out, arg);
 }
 

@@ -461,15 +461,22 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
   // reads it; every other path accumulates into zeros, cleared here.
   const bool fresh_sum = op == OP_SUM && (sorted & PYG_HIP_SCATTER_FRESH_SUM) != 0;
   const bool cas = (sorted & PYG_HIP_SCATTER_CAS) != 0 || float_atomic_mode() == 1;
+  const bool det = (sorted & PYG_HIP_SCATTER_DETERMINISTIC) != 0;
   sorted &= PYG_HIP_SCATTER_SORTED;
   const bool csr_rows = op == OP_SUM && sorted && s.isk == 0 && ws && ws_bytes >= scatter_indptr_bytes(s.B, s.N) && total > 0;
   // one large unsorted index vector, rows of >= 64 bytes: sort the E indices once (3-4 radix passes over 16 E bytes),
   // buckets become CSR rows summed through the permutation in SOURCE order (the stable sort keeps it): no atomics,
   // deterministic, every output row written once
   const bool float_t = std::is_same<T, float>::value || std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value;
-  const bool sort_rows = op == OP_SUM && !sorted && float_t && s.isk == 0 && s.B == 1 && s.ise == 1 && s.E >= (1 << 15) &&
-                         s.K * (int64_t)sizeof(T) >= 64 && ws &&
-                         ws_bytes >= scatter_sort_ws_bytes(s.E) + scatter_indptr_bytes(1, s.N);
+  // PYG_HIP_SCATTER_DETERMINISTIC: the same path for ANY size, row width and floating type (float64 included)
+  const bool floating = float_t || std::is_same<T, double>::value;
+  const bool sort_rows = op == OP_SUM && !sorted && s.isk == 0 && s.B == 1 && s.ise == 1 && ws &&
+                         ws_bytes >= scatter_sort_ws_bytes(s.E) + scatter_indptr_bytes(1, s.N) &&
+                         ((float_t && s.E >= (1 << 15) && s.K * (int64_t)sizeof(T) >= 64) || (det && floating && s.E > 0));
+  if (det && floating && total > 0 && ((op == OP_SUM && !csr_rows && !sort_rows) || op == OP_MUL))
+    return fail(PYG_HIP_ERR_UNSUPPORTED,
+                "scatter: no atomic-free kernel for this reduction / index layout (PYG_HIP_SCATTER_DETERMINISTIC: floating sums "
+                "need an index broadcast along k -- sorted, or one unsorted vector -- and the caller's workspace)");
   if (fresh_sum && !csr_rows && !sort_rows && outn > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(T) * (size_t)outn, stream));
   if (total == 0) return PYG_HIP_OK;
   if (op == OP_SUM && !csr_rows && !sort_rows && (std::is_floating_point<T>::value || float_t))

@@ -219,9 +219,12 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     (:class:`_RGCNFused`).  Accumulation: messages are rounded to the storage type (what the chain materialises),
     summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with one packed
     16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile boundaries) is
-    rounded once per run, where ``scatter_sum`` rounds once per destination."""
+    rounded once per run, where ``scatter_sum`` rounds once per destination.  Under
+    ``torch.use_deterministic_algorithms(True)`` the atomic-free chain (:func:`rgcn_layer`) runs instead."""
     total = offsets['__total__']
-    if not _fusable(x, weight):
+    # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
+    # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
+    if not _fusable(x, weight) or torch.are_deterministic_algorithms_enabled():
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:
@@ -260,7 +263,7 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     ok = _fusable(f0, weight) and all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
                                       for f in feats) and \
         all(n.device == f0.device and n.dtype == torch.long and n.dim() == 1 for n in nids)
-    if not ok:
+    if not ok or torch.are_deterministic_algorithms_enabled():   # (deterministic mode: see rgcn_layer_fused)
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
         return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc)
     tidx = {t: i for i, t in enumerate(node_types)}
