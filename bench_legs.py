@@ -287,7 +287,7 @@ def make_mag_graph(device, seed=0):
     return rp, cl
 
 
-def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
+def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=True):
     from pyg_lib_amd import sampler, rgcn
     types = list(MAG_SIZES)
     ets = [(s, r, d) for s, r, d, _ in MAG_RELS]
@@ -304,7 +304,9 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
 
     def layer(out):
         # features are gathered from the global tables inside the kernel: no per-batch feature matrix
-        return rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W)
+        # (grouped: the sampler emits every relation's edges grouped by the node they were sampled for -- the atomic-free
+        # owner-computes kernel, its promise verified on the device; `pending` below)
+        return rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=grouped)
 
     def one(i):
         out = sample(i)
@@ -349,6 +351,12 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
     total_b_ms = (time.perf_counter() - t0) / (reps * K) * 1e3
     out = state['last']
     layer_ms = _event_ms(lambda: layer(out), iters)
+    grouped_was = grouped
+    grouped = not grouped_was
+    other_ms = _event_ms(lambda: layer(out), iters)   # the other kernel (atomic adds into a zero-filled output / atomic-free)
+    grouped = grouped_was
+    torch.cuda.synchronize()
+    pending = rgcn.pending_index_error()
     e = sum(v.numel() for v in out[0].values())
     n = sum(v.numel() for v in out[2].values())
     esz = W.element_size()
@@ -356,7 +364,8 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16):
     alg = e * (F * esz + 16) + n * F * esz + len(ets) * F * F * esz
     return dict(workload='hetero_neighbor_sample + R-GCN layer, MAG-shaped graph (4 node types, 7 relations, ~42 M '
                          'entries), batch 1024 papers, fanout [15, 10], F=128 bf16 (BASELINE.json configs[4])',
-                layer_impl='rgcn_layer_fused_tables', sampler_mode=sampler.last_mode(), edges_per_batch=edges // iters, nodes_last_batch=n,
+                layer_impl='rgcn_layer_fused_tables(grouped=%s)' % grouped, layer_index_check=pending,
+                layer_other=dict(impl='grouped=%s' % (not grouped), ms=round(other_ms, 4)), sampler_mode=sampler.last_mode(), edges_per_batch=edges // iters, nodes_last_batch=n,
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
                 batched=dict(K=K, ms_sampler_per_batch=round(samp_b_ms, 4), ms_end_to_end_per_batch=round(total_b_ms, 4),
                              what='hetero_neighbor_sample_batched (K batches per call) + one fused layer per batch'),

@@ -57,12 +57,13 @@ typedef enum {
 
 /* Version of THIS interface: bumped whenever a signature or the meaning of an argument changes, so that a caller built
  * against an older header can tell (pyg_hip_abi_version() != the PYG_HIP_ABI_VERSION it was compiled with).
+ *   6: round 5 -- PYG_HIP_RGCN_GROUPED + pyg_hip_rgcn_grouped_workspace_size (atomic-free fused layer), PYG_HIP_SCATTER_DETERMINISTIC.
  *   5: round 5 -- pyg_hip_hetero_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
  *      pyg_hip_rgcn_fused became a bit field), pyg_hip_set_float_atomic_mode, pyg_hip_atomic_selftest,
  *      pyg_hip_sampler_table_cache_release; the weight-gradient workspace holds partial slabs instead of an fp32 image.
  *   4: round 4 -- `flags` in front of `stream` in pyg_hip_segment_matmul / pyg_hip_grouped_matmul, `index_sorted` of
  *      pyg_hip_scatter became a bit field, pyg_hip_matmul_set_schedule / _set_f32_split removed, fp32 default = IEEE MFMAs. */
-#define PYG_HIP_ABI_VERSION 5
+#define PYG_HIP_ABI_VERSION 6
 PYG_HIP_API int pyg_hip_abi_version(void);
 /* Replaces pyg::cuda_version (pyg_lib/csrc/library.cpp:19-29): returns the HIP runtime version
  * the library was built against (HIP_VERSION), never -1. */
@@ -277,11 +278,27 @@ PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int6
 #define PYG_HIP_RGCN_DEFERRED 4
 /* PYG_HIP_RGCN_DEFERRED (ignored with _CHECKED): the same validation WITHOUT the synchronisation -- offenders are
  * redirected to row 0, so a stale node id is never an out-of-bounds access, and the kernel leaves 1 (gather) / 2
- * (scatter) in a pinned word of the device.  The next pyg_hip_rgcn_fused call with this flag on that device fails with
+ * (scatter) / 3 (not grouped, PYG_HIP_RGCN_GROUPED) in a pinned word of the device.  The next pyg_hip_rgcn_fused call with this flag on that device fails with
  * PYG_HIP_ERR_INVALID naming the earlier call; pyg_hip_rgcn_pending_error() returns and clears the word (meaningful once
  * the stream has been synchronised).  This is what the torch binding passes by default (PYG_HIP_RGCN_CHECK=1: _CHECKED,
  * =0: no validation). */
 PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
+/* PYG_HIP_RGCN_GROUPED: the caller promises that every relation's scatter_index is NONDECREASING (edges grouped by
+ * destination -- what the neighbour samplers emit: `row` of every edge type, csc = false).  Then no atomics are needed:
+ * a small launch finds every destination's first edge, and an owner-computes kernel (32 rows of `out` per workgroup)
+ * sums every row's source features in fp32 in edge order, multiplies the 32 sums of a relation with its weight in one
+ * MFMA tile, accumulates the relations of a row in fp32 and WRITES every row of `out` once (rows without edges: zeros).
+ *   - `out` is OVERWRITTEN, not accumulated into (do not zero it); it must be 16-byte aligned;
+ *   - the same bits on every run; rounding: the per-relation feature sum and the result are each rounded once;
+ *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of `out` at and behind every
+ *     relation's scatter_offset: row starts, touched only where edges arrive);
+ *   - fewer than 2^31 rows of `out` and edges per relation (PYG_HIP_ERR_UNSUPPORTED otherwise);
+ *   - with _CHECKED / _DEFERRED the promise is verified on the device: a descent in a scatter_index is error 3
+ *     (PYG_HIP_ERR_INVALID "not grouped"; the result of such a call is unspecified but every access stays in bounds),
+ *     an out-of-range scatter index drops its edge (error 2), a gather index is redirected to row 0 (error 1). */
+#define PYG_HIP_RGCN_GROUPED 8
+PYG_HIP_API size_t pyg_hip_rgcn_grouped_workspace_size(const pyg_hip_rgcn_relation* relations, int64_t num_relations,
+                                                       int64_t num_out_rows);
 PYG_HIP_API int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* relations,
                                    int64_t num_relations, void* out, int64_t num_out_rows, int64_t K, int64_t M,
                                    int checked, void* workspace, size_t workspace_bytes, void* stream);

@@ -314,12 +314,22 @@ static void rgcn_index_checks(const at::TensorList gather_index, const at::Tenso
               scatter_index[r].device(), " vs ", like.device(), ")");
 }
 
+// `grouped`: every scatter_index is nondecreasing (the samplers' `row`): the atomic-free owner-computes kernel
+// (PYG_HIP_RGCN_GROUPED) WRITES `out` -- deterministic, no zero fill needed; verified on the device (rgcn_check_flags)
+static at::Tensor rgcn_workspace(const std::vector<pyg_hip_rgcn_relation>& rels, int64_t E, int64_t out_rows, bool grouped,
+                                 const at::TensorOptions& like) {
+  const size_t bytes = grouped ? pyg_hip_rgcn_grouped_workspace_size(rels.data(), (int64_t)rels.size(), out_rows)
+                               : pyg_hip_rgcn_fused_workspace_size((int64_t)rels.size(), E);
+  return at::empty({(int64_t)bytes}, like.dtype(at::kByte));
+}
+
 Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, const at::TensorList scatter_index,
-                         at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
+                         at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out,
+                         bool grouped) {
   PYG_TRACE("pyg::rgcn_fused");
   // packed 16-bit atomic adds: the result depends on the order they land in (pyg_lib_amd.rgcn takes the atomic-free
-  // three-op chain under torch.use_deterministic_algorithms(True) instead of calling this operator)
-  at::globalContext().alertNotDeterministic("pyg::rgcn_fused");
+  // three-op chain under torch.use_deterministic_algorithms(True) instead of calling this operator); grouped: no atomics
+  if (!grouped) at::globalContext().alertNotDeterministic("pyg::rgcn_fused");
   const size_t R = gather_index.size();
   TORCH_CHECK(scatter_index.size() == R && gather_offset.size() == R && scatter_offset.size() == R,
               "rgcn_fused: one gather / scatter index vector and offset per relation expected");
@@ -351,10 +361,11 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
     keep.push_back(g);
     keep.push_back(s);
   }
-  auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, x.options().dtype(at::kByte));
+  auto ws = rgcn_workspace(rels, E, out.size(0), grouped, x.options());
   check_status(pyg_hip_rgcn_fused(dtype_code(x.scalar_type()), xc.data_ptr(), xc.size(0), rels.data(), (int64_t)R,
-                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1), rgcn_check_flags(),
-                                  ws.data_ptr(), (size_t)ws.numel(), current_stream(x)));
+                                  out.data_ptr(), out.size(0), xc.size(1), out.size(1),
+                                  rgcn_check_flags() | (grouped ? PYG_HIP_RGCN_GROUPED : 0), ws.data_ptr(), (size_t)ws.numel(),
+                                  current_stream(x)));
   return out;
 }
 
@@ -363,9 +374,9 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
 // computes, minus the ATen gathers, the cat and the [sum n_t, K] intermediate.
 Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList node_id, at::IntArrayRef gather_type,
                                 const at::TensorList gather_index, const at::TensorList scatter_index,
-                                at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out) {
+                                at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out, bool grouped) {
   PYG_TRACE("pyg::rgcn_fused_tables");
-  at::globalContext().alertNotDeterministic("pyg::rgcn_fused_tables");  // (see rgcn_fused_kernel)
+  if (!grouped) at::globalContext().alertNotDeterministic("pyg::rgcn_fused_tables");  // (see rgcn_fused_kernel)
   const size_t R = gather_index.size(), T = feat.size();
   TORCH_CHECK(T > 0 && node_id.size() == T, "rgcn_fused_tables: one node-id vector per feature table expected");
   TORCH_CHECK(scatter_index.size() == R && gather_type.size() == R && scatter_offset.size() == R,
@@ -412,10 +423,10 @@ Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList 
     keep.push_back(g);
     keep.push_back(s);
   }
-  auto ws = at::empty({(int64_t)pyg_hip_rgcn_fused_workspace_size((int64_t)R, E)}, f0.options().dtype(at::kByte));
+  auto ws = rgcn_workspace(rels, E, out.size(0), grouped, f0.options());
   check_status(pyg_hip_rgcn_fused(dtype_code(weight.scalar_type()), nullptr, 0, rels.data(), (int64_t)R, out.data_ptr(),
-                                  out.size(0), wc.size(1), out.size(1), rgcn_check_flags(), ws.data_ptr(),
-                                  (size_t)ws.numel(), current_stream(f0)));
+                                  out.size(0), wc.size(1), out.size(1), rgcn_check_flags() | (grouped ? PYG_HIP_RGCN_GROUPED : 0),
+                                  ws.data_ptr(), (size_t)ws.numel(), current_stream(f0)));
   return out;
 }
 
@@ -1211,10 +1222,10 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   // this build only: fused R-GCN aggregation (gather -> per-relation matmul -> scatter-add), csrc/hip/rgcn.hip
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused(Tensor x, Tensor[] gather_index, Tensor[] scatter_index, int[] gather_offset, "
-      "int[] scatter_offset, Tensor weight, Tensor(a!) out) -> Tensor(a!)"));
+      "int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False) -> Tensor(a!)"));
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused_tables(Tensor[] feat, Tensor[] node_id, int[] gather_type, Tensor[] gather_index, "
-      "Tensor[] scatter_index, int[] scatter_offset, Tensor weight, Tensor(a!) out) -> Tensor(a!)"));
+      "Tensor[] scatter_index, int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False) -> Tensor(a!)"));
   // this build only: grouped_matmul writing into a caller-provided [sum rows, M] pool (sharded driver)
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::grouped_matmul_pool(Tensor[] input, Tensor[] other, Tensor(a!) pool) -> Tensor[]"));

@@ -29,7 +29,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace pyg_hip {
@@ -456,6 +459,156 @@ int deferred_error_slot(int** out) {
   return PYG_HIP_OK;
 }
 
+#include "rgcn_grouped.h"
+
+const char* rgcn_error_text(int code) {
+  return code == 1 ? "a gather index out of range" : code == 2 ? "a scatter index out of range"
+                                                                : "scatter indices that are not grouped (nondecreasing) although PYG_HIP_RGCN_GROUPED promised so";
+}
+
+// PYG_HIP_RGCN_GROUPED: the row-start launch, then the owner-computes kernel (rgcn_grouped.h).  `out` is WRITTEN.
+int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R, void* out,
+                        int64_t num_out_rows, int checked, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (num_out_rows == 0) return PYG_HIP_OK;
+  PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
+  PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "rgcn_fused: 'out' must be 16-byte aligned in grouped mode");
+  if (num_out_rows >= (1LL << 31) - 64)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: grouped mode handles fewer than 2^31 output rows");
+  if (R > kGroupedMaxRel)
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: grouped mode handles up to %d relations", kGroupedMaxRel);
+  int64_t E = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    if (rels[r].num_edges >= (1LL << 31) - 64)
+      return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: grouped mode handles fewer than 2^31 edges per relation");
+    if (rels[r].num_edges > 0) {
+      PYG_HIP_REQUIRE(rels[r].scatter_offset >= 0 && rels[r].scatter_offset < num_out_rows,
+                      "rgcn_fused: relation %lld: scatter_offset outside of 'out'", (long long)r);
+      PYG_HIP_REQUIRE((rels[r].x ? rels[r].x_rows : num_x_rows) > 0, "rgcn_fused: relation %lld gathers from an empty table", (long long)r);
+    }
+    E += rels[r].num_edges;
+  }
+  if (E == 0) {  // nothing arrives anywhere
+    PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * 256, stream));
+    return PYG_HIP_OK;
+  }
+  const size_t need = grouped_workspace_bytes(rels, R, num_out_rows);
+  if (workspace == nullptr || workspace_bytes < need)
+    return fail(PYG_HIP_ERR_WORKSPACE, "rgcn_fused: grouped mode needs a workspace of %zu bytes (pyg_hip_rgcn_grouped_workspace_size), got %zu",
+                need, workspace_bytes);
+  const size_t rel_b = align_up(sizeof(RelDev) * (size_t)R, 256);
+  const size_t vec_b = align_up(sizeof(int64_t) * (size_t)(3 * R + 1), 256);
+  const size_t meta_b = align_up(sizeof(int32_t) * 2 * (size_t)R, 256);
+  const bool inl = R <= kRgcnInline;
+  GroupedDesc desc;
+  ::memset(&desc, 0, sizeof(desc));
+  RelDev* hr = desc.irels;
+  int64_t* hp = desc.ieprefix;
+  int64_t* ho = desc.irp_off;
+  int64_t* hs = desc.ispan;
+  if (!inl) {
+    void* staged = nullptr;
+    int rc = pinned_stage().acquire(rel_b + vec_b, &staged);
+    if (rc != PYG_HIP_OK) return rc;
+    hr = static_cast<RelDev*>(staged);
+    hp = reinterpret_cast<int64_t*>(static_cast<char*>(staged) + rel_b);
+    ho = hp + (R + 1);
+    hs = ho + R;
+  }
+  bool big = false;
+  int64_t e = 0, rp_entries = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    hr[r].gather_index = rels[r].gather_index;
+    hr[r].scatter_index = rels[r].scatter_index;
+    hr[r].weight = static_cast<const char*>(rels[r].weight);
+    hr[r].num_edges = rels[r].num_edges;
+    hr[r].gather_offset = rels[r].gather_offset;
+    hr[r].scatter_offset = rels[r].scatter_offset;
+    hr[r].x = static_cast<const char*>(rels[r].x ? rels[r].x : x);
+    hr[r].gather_map = rels[r].gather_map;
+    hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
+    hr[r].map_len = rels[r].gather_map_len;
+    big = big || hr[r].x_rows >= (1LL << 24);
+    hp[r] = e;
+    e += rels[r].num_edges;
+    const int64_t span = rels[r].num_edges > 0 ? num_out_rows - rels[r].scatter_offset : 0;
+    ho[r] = rp_entries;
+    hs[r] = span;
+    rp_entries += span;
+  }
+  hp[R] = e;
+  char* w = static_cast<char*>(workspace);
+  if (!inl) {
+    PYG_HIP_CHECK(hipMemcpyAsync(w, hr, rel_b + vec_b, hipMemcpyHostToDevice, stream));
+    int rc = pinned_stage().commit(stream);
+    if (rc != PYG_HIP_OK) return rc;
+    desc.rels = reinterpret_cast<const RelDev*>(w);
+    desc.eprefix = reinterpret_cast<const int64_t*>(w + rel_b);
+    desc.rp_off = desc.eprefix + (R + 1);
+    desc.span = desc.rp_off + R;
+  }
+  desc.meta = reinterpret_cast<int32_t*>(w + rel_b + vec_b);
+  int* err_dev = reinterpret_cast<int*>(w + rel_b + vec_b + meta_b);
+  desc.rp = reinterpret_cast<int32_t*>(w + rel_b + vec_b + meta_b + 256);
+  desc.long_rows = reinterpret_cast<uint64_t*>(w + rel_b + vec_b + meta_b + 64);
+  {  // an id that no earlier call of this process and no stale word of the workspace holds
+    static std::atomic<uint64_t> counter{0};
+    static const uint64_t salt = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() << 24;
+    desc.call_id = (salt ^ 0x9e3779b97f4a7c15ull) + counter.fetch_add(1) + 1;
+  }
+  const bool deferred = (checked & PYG_HIP_RGCN_DEFERRED) != 0 && (checked & PYG_HIP_RGCN_CHECKED) == 0;
+  const bool sync_check = (checked & PYG_HIP_RGCN_CHECKED) != 0;
+  if (sync_check) PYG_HIP_CHECK(hipMemsetAsync(err_dev, 0, sizeof(int), stream));
+  if (deferred) {
+    int* slot = nullptr;
+    int rc = deferred_error_slot(&slot);
+    if (rc != PYG_HIP_OK) return rc;
+    const int pending = *static_cast<volatile int*>(slot);
+    if (pending != 0) {
+      *static_cast<volatile int*>(slot) = 0;
+      return fail(PYG_HIP_ERR_INVALID,
+                  "rgcn_fused: an earlier call on this device had %s (set PYG_HIP_RGCN_CHECK=1 to fail in the call that has them)",
+                  rgcn_error_text(pending));
+    }
+    err_dev = slot;
+  }
+  const bool bf = dtype == PYG_BF16, ck = sync_check || deferred;
+  const void* prep = ck ? (inl ? (const void*)&rgcn_rowstart_kernel<true, true> : (const void*)&rgcn_rowstart_kernel<true, false>)
+                        : (inl ? (const void*)&rgcn_rowstart_kernel<false, true> : (const void*)&rgcn_rowstart_kernel<false, false>);
+  const void* kern;
+  {
+#define PYG_RGCN_GPICK(BF, CK, BG) (inl ? (const void*)&rgcn_grouped_kernel<BF, CK, BG, true> : (const void*)&rgcn_grouped_kernel<BF, CK, BG, false>)
+    kern = bf ? (ck ? (big ? PYG_RGCN_GPICK(true, true, true) : PYG_RGCN_GPICK(true, true, false))
+                    : (big ? PYG_RGCN_GPICK(true, false, true) : PYG_RGCN_GPICK(true, false, false)))
+              : (ck ? (big ? PYG_RGCN_GPICK(false, true, true) : PYG_RGCN_GPICK(false, true, false))
+                    : (big ? PYG_RGCN_GPICK(false, false, true) : PYG_RGCN_GPICK(false, false, false)));
+#undef PYG_RGCN_GPICK
+  }
+  constexpr int lds = 32768 + 8192 + 2 * 4 * kGroupedMaxRel;
+  if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
+  int Ri = (int)R;
+  {
+    void* args[] = {(void*)&desc, (void*)&Ri, (void*)&err_dev};
+    PYG_HIP_CHECK(hipLaunchKernel(prep, dim3((unsigned)((E + 255) / 256)), dim3(256), args, 0, stream));
+  }
+  {
+    char* outc = static_cast<char*>(out);
+    void* args[] = {(void*)&desc, (void*)&Ri, (void*)&outc, (void*)&num_out_rows, (void*)&err_dev};
+    // persistent: three workgroups of 256 threads per CU (<= 168 VGPRs, 44 KB of LDS), blocks of 16 rows dealt round-robin (the rows with
+    // edges are the first ones of every node type: neighbours in the grid, spread over the chip)
+    const int64_t nblocks = (num_out_rows + 15) / 16;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(nblocks, 3 * (int64_t)device_info().num_cus));
+    PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, stream));
+  }
+  if (sync_check) {
+    int host_err = 0;
+    PYG_HIP_CHECK(hipMemcpyAsync(&host_err, err_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    if (host_err != 0) return fail(PYG_HIP_ERR_INVALID, "rgcn_fused: the call has %s", rgcn_error_text(host_err));
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
 }  // namespace
 }  // namespace pyg_hip
 
@@ -469,6 +622,11 @@ int pyg_hip_rgcn_pending_error(void) {
   const int pending = *static_cast<volatile int*>(slot);
   *static_cast<volatile int*>(slot) = 0;
   return pending;
+}
+
+size_t pyg_hip_rgcn_grouped_workspace_size(const pyg_hip_rgcn_relation* relations, int64_t num_relations, int64_t num_out_rows) {
+  if (relations == nullptr || num_relations <= 0 || num_out_rows <= 0) return 256;
+  return grouped_workspace_bytes(relations, num_relations, num_out_rows);
 }
 
 size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges) {
@@ -486,7 +644,11 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   if (K != 128 || M != 128) return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (got %lld x %lld)", (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");
-  if (R == 0) return PYG_HIP_OK;
+  const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
+  if (R == 0) {
+    if (grouped && out && num_out_rows > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * 256, stream));
+    return PYG_HIP_OK;
+  }
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
   int64_t E = 0, tiles = 0;
   for (int64_t r = 0; r < R; ++r) {
@@ -497,13 +659,15 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     E += rels[r].num_edges;
     tiles += (rels[r].num_edges + 127) / 128;
   }
-  if (E == 0) return PYG_HIP_OK;
+  if (E == 0 && !grouped) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
   for (int64_t r = 0; r < R; ++r) {
     const void* xr = rels[r].x ? rels[r].x : x;
     PYG_HIP_REQUIRE(rels[r].num_edges == 0 || xr != nullptr, "rgcn_fused: relation %lld has no feature table", (long long)r);
     PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(xr) & 15) == 0, "rgcn_fused: misaligned feature table");
   }
+  if (grouped)
+    return rgcn_grouped_launch(dtype, x, num_x_rows, rels, R, out, num_out_rows, checked, workspace, workspace_bytes, stream);
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "rgcn_fused: misaligned tensor");
   PYG_HIP_REQUIRE(tiles < (1LL << 31), "rgcn_fused: too many tiles");
   if (workspace == nullptr || workspace_bytes < pyg_hip_rgcn_fused_workspace_size(R, E))
@@ -566,9 +730,9 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     if (pending != 0) {
       *static_cast<volatile int*>(slot) = 0;
       return fail(PYG_HIP_ERR_INVALID,
-                  "rgcn_fused: an earlier call on this device had a %s index out of range (the offending edges were "
-                  "redirected to row 0; set PYG_HIP_RGCN_CHECK=1 to fail in the call that has them)",
-                  pending == 1 ? "gather" : "scatter");
+                  "rgcn_fused: an earlier call on this device had %s (out-of-range edges were redirected to row 0 or "
+                  "dropped; set PYG_HIP_RGCN_CHECK=1 to fail in the call that has them)",
+                  rgcn_error_text(pending));
     }
     err_dev = slot;
   }

@@ -1,0 +1,468 @@
+// The fused R-GCN layer WITHOUT atomics, for edge lists that are grouped by destination (PYG_HIP_RGCN_GROUPED) --
+// included by rgcn.hip inside its namespace.
+//
+//     out[o] = sum over relations r, edges e of r with scatter_index_r[e] + scatter_offset_r == o of
+//              x_r[gather(e)] @ W_r            = sum_r ( sum_e x_r[gather(e)] ) @ W_r
+//
+// The samplers emit every relation's edges grouped by the node they were sampled for (sampler/cpu/neighbor_kernel.cpp:
+// 332-514: one frontier node after the other, a later hop's frontier has larger local ids), so `row` -- the scatter
+// index of the layer -- is nondecreasing per relation.  Then a destination row can be OWNED: a workgroup takes 32
+// consecutive rows of `out`, one row per 16-lane group, and for every relation with edges into its rows
+//   * every group finds its row's edges (one lookup in the row-start table a small launch in front of this one builds
+//     from scatter_index: rgcn_rowstart_kernel), walks them 16 at a time -- lane c of the group fetches 16 bytes of each
+//     source row, a whole 256-byte row per group and instruction -- and sums them in fp32 registers in edge order;
+//   * the 32 sums, rounded to T once, are the A tile of ONE 32 x 128 x 128 product with W_r (aggregate first, transform
+//     second: E / fan-out matrix rows instead of E), accumulated in fp32 across the relations of the block;
+//   * the block's rows are written once, rounded once -- rows without edges as zeros.
+// No atomics, no zero fill of `out` in front, no read-modify-write of `out`, the same bits on every run (the sums of a
+// row are taken in edge order, relations in list order).  Rounding: one rounding of the per-relation feature sum
+// (relative 2^-9 for bf16, where the chain rounds every message) and one of the result (where scatter_sum of the chain
+// rounds once per destination as well).
+//
+// A group's dependent loads (row start -> indices -> gather_map -> feature rows) are issued stage by stage for up to four
+// relations at once, so a block pays three round trips for its indices plus one per relation for the rows.
+
+// lane I of every 16-lane DPP row to all lanes of the row (v_mov_b32_dpp row_newbcast:I)
+template <int I>
+__device__ __forceinline__ int row_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, false);
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+struct GroupedDesc {
+  const RelDev* rels;        // R > kRgcnInline: the records and the three vectors below live in the workspace
+  const int64_t* eprefix;    // [R + 1] running edge count
+  const int64_t* rp_off;     // [R] first entry of the relation's row starts in `rp`
+  const int64_t* span;       // [R] rows of `out` at and behind the relation's scatter_offset
+  int32_t* rp;               // row starts: rp[rp_off[r] + d] = first edge of relation r with scatter index d (only for d that occur)
+  int32_t* meta;             // [2 r] the first, [2 r + 1] the last scatter index of relation r (written by the row-start launch)
+  uint64_t* long_rows;       // == call_id: some row of this call has more than 16 edges (set by the row-start launch; the
+  uint64_t call_id;          //  workspace is not cleared: an id no earlier call and no stale word can hold)
+  RelDev irels[kRgcnInline];
+  int64_t ieprefix[kRgcnInline + 1];
+  int64_t irp_off[kRgcnInline];
+  int64_t ispan[kRgcnInline];
+};
+static_assert(sizeof(GroupedDesc) <= 3072, "kernel argument");
+constexpr int kGroupedMaxRel = 512;    // relations whose row ranges the owner-computes kernel keeps in LDS
+
+// One thread per edge: an edge whose scatter index differs from its predecessor's starts a row.  Rows that do not occur
+// keep whatever the workspace held: the consumer verifies scatter_index[rp[d]] == d, which no stale value can satisfy for
+// a row without edges.  CHECK: indices outside [0, span) -> *error = 2, a descent -> *error = 3 (not grouped).
+template <bool CHECK, bool INL>
+__global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc desc, int R, int* __restrict__ error) {
+  auto ep = [&](int i) -> int64_t {
+    if constexpr (INL) return desc.ieprefix[i];
+    else return desc.eprefix[i];
+  };
+  // (every index into the argument arrays is wave-uniform: a per-lane index would copy the struct to scratch)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t w0 = (int64_t)blockIdx.x * 256 + wv * 64;
+  const int64_t gid = w0 + (threadIdx.x & 63);
+  const int64_t total = ep(R);
+  if (w0 >= total) return;
+  int lo = 0, hi = R;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ep(mid) <= w0) lo = mid; else hi = mid;
+  }
+  for (int r = lo; r < R; ++r) {
+    const int64_t e0 = ep(r), e1 = ep(r + 1);
+    if (e0 >= w0 + 64) break;
+    if (gid < e0 || gid >= e1) continue;
+    const int64_t* sidx;
+    int64_t span, off;
+    if constexpr (INL) sidx = desc.irels[r].scatter_index, span = desc.ispan[r], off = desc.irp_off[r];
+    else sidx = desc.rels[r].scatter_index, span = desc.span[r], off = desc.rp_off[r];
+    const int64_t e = gid - e0;
+    const int64_t d = ((GI64*)sidx)[e];
+    const int64_t prev = e > 0 ? ((GI64*)sidx)[e - 1] : -1;
+    const bool ok = d >= 0 && d < span;
+    if (CHECK) {
+      if (!ok) *error = 2;
+      else if (d < prev) *error = 3;
+    }
+    if (ok && d != prev) desc.rp[off + d] = (int32_t)e;
+    if (e >= 16 && ((GI64*)sidx)[e - 16] == d) *desc.long_rows = desc.call_id;   // a row of 17 or more edges
+    const int64_t dc = d < 0 ? 0 : (d >= span ? span - 1 : d);
+    if (e == 0) desc.meta[2 * r] = (int32_t)dc;
+    if (e == e1 - e0 - 1) desc.meta[2 * r + 1] = (int32_t)dc;
+  }
+}
+
+// K = M = 128, 16-bit T; 512 threads = 32 groups of 16 lanes = 32 rows of `out` per block.
+//
+// Persistent launch (two workgroups per CU), blocks dealt round-robin.  The unit of work is an ITEM = (block, relation with
+// edges into the block); a block without items costs its 8 KB of zero stores and nothing else.  An item needs four
+// DEPENDENT memory round trips -- row start -> the two indices -> gather_map -> feature rows, 3 - 5 us each on this chip
+// under load -- so the items of a workgroup run through a four-deep software pipeline: every iteration first uses what
+// the previous iteration requested (one wait at its top), then issues, back to back,
+//     rows of item i + 1 | gather_map lookups of item i + 2 | indices of item i + 3 | row starts of item i + 4 | W of item i + 1
+// and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave 0 - 3, barrier, the block's stores when its
+// last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on the C5
+// batch where the atomic kernel + its zero fill take 66.)
+template <bool BF16, bool CHECK, bool BIG, bool INL>
+__device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
+                                                  int* __restrict__ error) {
+  constexpr int U = 16;   // edges of a row per batch (one per lane of the group)
+  // Rows of more than 16 edges (fan-outs above 16, full neighbourhoods) need further batches.  That loop inside the pipeline
+  // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
+  // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
+  // function instead (same registers, no pipeline; the choice is uniform over the launch).
+  const bool long_rows = *desc.long_rows == desc.call_id;
+  auto rel_at = [&](int i) __attribute__((always_inline)) -> const RelDev& {
+    if constexpr (INL) return desc.irels[i];
+    else return desc.rels[i];
+  };
+  auto rp_off_at = [&](int i) __attribute__((always_inline)) -> int64_t {
+    if constexpr (INL) return desc.irp_off[i];
+    else return desc.rp_off[i];
+  };
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem + 32768;   // the A tile: 32 rows (16 used) x 16 chunks of 16 bytes, chunk index XOR-swizzled with the row
+  int* rlo = reinterpret_cast<int*>(smem + 40960);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
+  int* rhi = rlo + kGroupedMaxRel;
+  const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = tid >> 4, c = tid & 15;
+  const int gbase = lane & 48;  // first lane of the group inside its wave
+  // the relations' row ranges, once per workgroup
+  for (int r0 = 0; r0 < R; r0 += 256) {
+    const int r = r0 + tid;
+    int64_t so = 0;
+    bool has = false;
+    if constexpr (INL) {  // (a per-lane index into the kernel argument would copy it to scratch)
+      for (int i = r0; i < R && i < r0 + 256; ++i) {
+        const int64_t so_i = desc.irels[i].scatter_offset;
+        const bool has_i = desc.irels[i].num_edges > 0;
+        if (i == r) so = so_i, has = has_i;
+      }
+    } else if (r < R) {
+      so = desc.rels[r].scatter_offset;
+      has = desc.rels[r].num_edges > 0;
+    }
+    if (r < R) {
+      int lo = 1, hi = 0;
+      if (has) lo = (int)(so + desc.meta[2 * r]), hi = (int)(so + desc.meta[2 * r + 1]);
+      rlo[r] = lo;
+      rhi[r] = hi;
+    }
+  }
+  {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(xs + 4096 + tid * 16) = z;
+  }
+  __syncthreads();
+
+  // W of relation `g` into LDS buffer `buf`: the layout of rgcn_fused_kernel (32 blocks of 4 k-rows, 16-byte chunks
+  // permuted inside a block), this wave's 4 blocks
+  auto load_w = [&](int g) __attribute__((always_inline)) {
+    const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
+    const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
+    const char* wsrc = rel_at(g).weight + dma_r * 256 + dma_c * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kb = wave * 8 + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
+                                       (LDSV*)(smem + kb * 1024), 16, 0, 0);
+    }
+  };
+  // edges of the group's row among the 16 at `start`: lane c looks at edge start + c; the row's edges are a prefix
+  auto prefix_count = [&](bool match) __attribute__((always_inline)) -> int {
+    const uint64_t m = __ballot(match);
+    const uint32_t g16 = (uint32_t)(m >> gbase) & 0xffffu;
+    return __builtin_ctz(~g16 | 0x10000u);
+  };
+  typedef typename std::conditional<BIG, int64_t, int>::type RowT;   // (tables of fewer than 2^24 rows: 32 bits do)
+  auto feature_row = [&](const RelDev& rel, int64_t g1, bool on) __attribute__((always_inline)) -> RowT {
+    if (!on) return 0;
+    int64_t g2;
+    if (rel.gather_map) {
+      if (CHECK && (g1 < 0 || g1 >= rel.map_len)) {
+        *error = 1;
+        g1 = 0;
+      }
+      g2 = ((GI64*)rel.gather_map)[g1];
+    } else {
+      g2 = g1 + rel.gather_offset;
+    }
+    return (RowT)g2;
+  };
+  u32x4 xr[U];
+  // the n <= 16 rows of one batch on their way (rows the batch does not have: zeros)
+  auto issue_rows = [&](const RelDev& rel, int n, RowT g2) __attribute__((always_inline)) {
+    if (CHECK && (g2 < 0 || g2 >= rel.x_rows)) {   // (what the map returned; lanes past n hold 0)
+      *error = 1;
+      g2 = 0;
+    }
+    // lane i of the group holds the row of edge i: a broadcast inside the 16-lane DPP row (v_mov_b32_dpp row_newbcast:i --
+    // no LDS traffic and no per-edge address registers, which __shfl's ds_bpermute costs)
+    if constexpr (BIG) {
+      const int lo = (int)(uint32_t)g2, hi = (int)(uint32_t)((uint64_t)g2 >> 32);
+      static_for<0, U>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t rl = (uint32_t)row_bcast<i>(lo), rh = (uint32_t)row_bcast<i>(hi);
+        const int64_t row = (int64_t)(((uint64_t)rh << 32) | rl);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (i < n) v = *(GU32x4*)(rel.x + row * 256 + c * 16);
+        xr[i] = v;
+      });
+    } else {
+      const int rowb = (int)((uint32_t)g2 << 8);  // < 4 GB tables (checked on the host)
+      static_for<0, U>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t off = (uint32_t)row_bcast<i>(rowb) + (uint32_t)(c * 16);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (i < n) v = *(GU32x4*)(rel.x + off);
+        xr[i] = v;
+      });
+    }
+  };
+  float sum[8];
+  auto add_rows = [&]() __attribute__((always_inline)) {  // in edge order
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a, b;
+        unpack2<BF16>(xr[i][k], &a, &b);
+        sum[2 * k] += a;
+        sum[2 * k + 1] += b;
+      }
+    }
+  };
+
+  // ---- the items of this workgroup, in order (wave-uniform state) ---------------------------------------------------
+  const int nblocks = (int)((out_rows + 15) >> 4);
+  const int G = (int)gridDim.x;
+  // (no flags in this state: two bools set in sibling branches were merged into one store through a selected pointer,
+  // which kept them -- and with them the whole walk -- in scratch and in vector registers)
+  // Workgroup w owns blocks w, w + G, w + 2 G, ... (the rows with edges are the first ones of every node type: contiguous
+  // ranges, dealt out evenly this way) and walks them from a workgroup-specific START, wrapping around: walked from the
+  // front by everybody, the whole chip alternated between phases that only gather (latency bound) and phases that only
+  // write zeros (bandwidth bound).  (A scrambled block order mixes the phases too but deals the active blocks unevenly:
+  // 0.152 ms instead of 0.070.)
+  const int it_n = nblocks > (int)blockIdx.x ? (nblocks - (int)blockIdx.x + G - 1) / G : 0;   // blocks of this workgroup
+  const int it_k0 = it_n > 0 ? (int)(((uint32_t)blockIdx.x * 2654435761u >> 12) % (uint32_t)it_n) : 0;
+  int it_j = -1, it_blk = -1, it_c0 = R;
+  uint64_t it_mask = 0;
+  auto chunk_mask = [&](int blk, int c0) __attribute__((always_inline)) -> uint64_t {
+    const int row0 = blk * 16;
+    bool relv = false;
+    if (c0 + lane < R) relv = rhi[c0 + lane] >= row0 && rlo[c0 + lane] <= row0 + 15;
+    return __ballot(relv);
+  };
+  auto next_item = [&](int& blk, int& rel) __attribute__((always_inline)) -> bool {
+    while (true) {
+      if (it_mask != 0) {
+        rel = it_c0 + __builtin_ctzll(it_mask);
+        it_mask &= it_mask - 1;
+        blk = it_blk;
+        return true;
+      }
+      if (it_j >= it_n) return false;        // (stays there)
+      if (it_j >= 0 && it_c0 + 64 < R) {      // the next 64 relations of the same block
+        it_c0 += 64;
+        it_mask = chunk_mask(it_blk, it_c0);
+        continue;
+      }
+      if (++it_j >= it_n) return false;
+      {
+        int k = it_k0 + it_j;
+        if (k >= it_n) k -= it_n;
+        it_blk = (int)blockIdx.x + k * G;
+      }
+      it_c0 = 0;
+      it_mask = chunk_mask(it_blk, 0);
+      while (it_mask == 0 && it_c0 + 64 < R) {
+        it_c0 += 64;
+        it_mask = chunk_mask(it_blk, it_c0);
+      }
+      if (it_mask == 0) {  // nothing arrives in the block's rows
+        const int64_t o = (int64_t)it_blk * 16 + grp;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = z;
+        it_c0 = R;
+      }
+    }
+  };
+
+  // ---- pipeline registers -------------------------------------------------------------------------------------------
+  bool v0 = false, v1 = false, v2 = false, v3 = false;   // item i, i + 1, i + 2, i + 3 exist (uniform)
+  int blk0 = 0, blk1 = 0, blk2 = 0, blk3 = 0, rel0 = 0, rel1 = 0, rel2 = 0, rel3 = 0;
+  int st0 = -1, st1 = -1, st2 = -1, st3 = -1;            // first edge of the group's row (-1: the row has none)
+  int n0 = 0, n1 = 0;                                    // edges of the row in its first batch
+  RowT g2_1 = 0;                                         // feature row of lane c's edge of item i + 1
+  int64_t g1_2 = 0;                                      // the two indices of lane c's edge of item i + 2 (the scatter index:
+  int s1_2 = -1;                                         //  its low word -- the row-start launch has seen all 64 bits)
+  // the group's row as relation `rel`'s scatter index (recomputed where it is needed: four pipeline registers less)
+  auto row_of = [&](int blk, int rel) __attribute__((always_inline)) -> int {
+    return (int)((int64_t)blk * 16 + grp - rel_at(rel).scatter_offset);
+  };
+  auto issue_start = [&](int blk, int rel, int& st) __attribute__((always_inline)) {
+    const int64_t o = (int64_t)blk * 16 + grp;
+    st = -1;
+    if (o < out_rows && o >= rlo[rel] && o <= rhi[rel]) st = desc.rp[rp_off_at(rel) + (o - rel_at(rel).scatter_offset)];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int q = lane & 15, grp16 = lane >> 4;
+  const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+  // A tile (rows = the block's 16 destinations) x W in LDS -> acc: wave t the 32 output columns of its n-tile
+  auto product = [&]() __attribute__((always_inline)) {
+#pragma unroll 2   // (not 8: the operands of all steps at once, next to the rows in flight, do not fit the register budget)
+    for (int s = 0; s < 8; ++s) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((8 * h + s) ^ (xl & 15))) * 16);
+      const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + wave * 256));
+      const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + wave * 256));
+      const u32x4 wa = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      acc = mfma16<BF16>(wa, xa, acc);
+    }
+  };
+  // the block's 16 x 128 results, rounded once, through the tile: wave t holds columns (8 h + 2 t + j) * 8 ... + 7 of row xl
+  auto store_block = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[8 * j + 2 * i], acc[8 * j + 2 * i + 1]);
+      const int ch = 8 * h + 2 * wave + j;
+      *reinterpret_cast<u32x4*>(xs + (xl * 16 + (ch ^ (xl & 15))) * 16) = pk;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+    // (every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
+    const int64_t o = (int64_t)blk * 16 + grp;
+    if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = v;
+  };
+  auto a_tile_from_sums = [&]() __attribute__((always_inline)) {
+    u32x4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] = pack2<BF16>(sum[2 * k], sum[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16) = pk;
+  };
+
+  if (long_rows) {
+    // ---- item at a time: row start -> indices -> gather_map -> rows, 16 edges per batch, as many batches as the longest
+    //      row of the wave needs ----------------------------------------------------------------------------------------
+    int blk = 0, rel = 0, cur = -1;
+    while (next_item(blk, rel)) {
+      blk = __builtin_amdgcn_readfirstlane(blk);
+      rel = __builtin_amdgcn_readfirstlane(rel);
+      if (cur >= 0 && blk != cur) store_block(cur);
+      cur = blk;
+      const RelDev& r = rel_at(rel);
+      load_w(rel);   // (the previous item's products are behind a barrier)
+      int sc = -1;
+      issue_start(blk, rel, sc);
+      const int d = row_of(blk, rel);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+      bool more = sc >= 0;
+      do {
+        const bool onc = more && (int64_t)sc + c < r.num_edges;
+        int64_t s1c = -1, g1c = 0;
+        if (onc) {
+          s1c = ((GI64*)r.scatter_index)[sc + c];
+          g1c = ((GI64*)r.gather_index)[sc + c];
+        }
+        const int nc = prefix_count(onc && s1c == d);
+        const RowT g2c = feature_row(r, g1c, c < nc);
+        issue_rows(r, nc, g2c);
+        add_rows();
+        more = more && nc == U;
+        sc += U;
+      } while (__any(more));
+      a_tile_from_sums();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
+      __syncthreads();
+      product();
+      __syncthreads();
+    }
+    if (cur >= 0) store_block(cur);
+    return;
+  }
+  bool primed = false;  // (the first iteration only fetches: one call site for the item walk, so that it is inlined and its
+                        // state stays in scalar registers -- as a called function it lived in scratch, and every relation
+                        // record was fetched with vector loads the row gathers had to wait behind)
+  while (!primed || v0 || v1 || v2 || v3) {
+    primed = true;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what the previous iteration asked for is here (W's DMA included)
+    // (Every value the previous iteration loaded is USED here, in front of this iteration's first load: a use further down
+    // would make the compiler wait for all loads issued in between -- it cannot count them across the conditional row
+    // loads -- i.e. for the rows just requested.)
+    asm volatile("" ::"v"(st3), "v"(g1_2), "v"(s1_2), "v"(g2_1));
+    // ---- item i: its first batch of rows has landed --------------------------------------------------------------------
+    if (v0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+      add_rows();
+      a_tile_from_sums();   // (the previous item's products are behind a barrier)
+    }
+    // ---- item i + 2: its indices have landed -> the row's edge count ----------------------------------------------------
+    const int n2 = prefix_count(v2 && st2 >= 0 && s1_2 == row_of(blk2, rel2));
+    // ---- issue: nothing requested below is touched before the next iteration's top ----------------------------------------
+    if (v1) {
+      issue_rows(rel_at(rel1), n1, g2_1);
+    }
+    RowT g2n = 0;
+    if (v2) g2n = feature_row(rel_at(rel2), g1_2, c < n2);
+    int64_t g1n = 0;
+    int s1n = -1;
+    if (v3) {
+      const RelDev& rel = rel_at(rel3);
+      if (st3 >= 0 && (int64_t)st3 + c < rel.num_edges) {  // (a stale start of a row without edges may point anywhere)
+        s1n = *(const __attribute__((address_space(1))) int*)(rel.scatter_index + (st3 + c));
+        g1n = ((GI64*)rel.gather_index)[st3 + c];
+      } else {
+        st3 = -1;
+      }
+    }
+    int blk4 = 0, rel4 = 0, st4 = -1;
+    const bool v4 = next_item(blk4, rel4);
+    blk4 = __builtin_amdgcn_readfirstlane(blk4);
+    rel4 = __builtin_amdgcn_readfirstlane(rel4);
+    if (v4) issue_start(blk4, rel4, st4);
+    // ---- item i: A tile, product; the block's rows when this was its last item -------------------------------------------
+    if (!v0 && v1) load_w(rel1);   // (the pipeline is filling: nobody reads W)
+    if (v0) {
+      __syncthreads();
+      product();
+      __syncthreads();  // the A tile and W are free again
+      if (v1) load_w(rel1);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
+      if (!v1 || blk1 != blk0) store_block(blk0);
+    }
+    // ---- rotate --------------------------------------------------------------------------------------------------------
+    v0 = v1, blk0 = blk1, rel0 = rel1, st0 = st1, n0 = n1;
+    v1 = v2, blk1 = blk2, rel1 = rel2, st1 = st2, n1 = n2, g2_1 = g2n;
+    v2 = v3, blk2 = blk3, rel2 = rel3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
+    v3 = v4, blk3 = blk4, rel3 = rel4, st3 = st4;
+  }
+}
+
+template <bool BF16, bool CHECK, bool BIG, bool INL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+                                                                                              int64_t out_rows, int* __restrict__ error) {
+  rgcn_grouped_body<BF16, CHECK, BIG, INL>(desc, R, out, out_rows, error);
+}
+
+size_t grouped_workspace_bytes(const pyg_hip_rgcn_relation* rels, int64_t R, int64_t out_rows) {
+  size_t rp = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    const int64_t span = out_rows - rels[r].scatter_offset;
+    if (rels[r].num_edges > 0 && span > 0) rp += (size_t)span;
+  }
+  const size_t Rz = (size_t)std::max<int64_t>(R, 1);
+  return align_up(sizeof(RelDev) * Rz, 256) + align_up(sizeof(int64_t) * (3 * Rz + 1), 256) + align_up(sizeof(int32_t) * 2 * Rz, 256) + 256 +
+         align_up(sizeof(int32_t) * rp, 256);
+}

@@ -31,7 +31,7 @@ def pending_index_error() -> int:
     r"""The fused layer validates its gather / scatter indices on the device WITHOUT synchronising (a stale ``node_id`` is
     redirected to row 0 instead of reading out of bounds; ``PYG_HIP_RGCN_CHECK=1``: synchronising check, ``=0``: none).
     Returns and clears what the launches so far have found on the current device: 0 nothing, 1 a gather index, 2 a scatter
-    index out of range (meaningful after ``torch.cuda.synchronize()``); the next fused call raises for it otherwise."""
+    index out of range, 3 scatter indices that were promised grouped (``grouped=True``) and are not (meaningful after ``torch.cuda.synchronize()``); the next fused call raises for it otherwise."""
     from . import _capi
     return int(_capi.lib().pyg_hip_rgcn_pending_error())
 
@@ -102,6 +102,11 @@ def _fusable(x: Tensor, weight: Tensor) -> bool:
             weight.device == x.device)
 
 
+def _fresh_out(like: Tensor, rows: int, cols: int, grouped: bool) -> Tensor:
+    # the grouped kernel writes every row once; the atomic kernel accumulates into zeros
+    return like.new_empty(rows, cols) if grouped else like.new_zeros(rows, cols)
+
+
 def _rel_ptr_and_indices(gather: List[Tensor], scatter: List[Tensor], goff: List[int], soff: List[int]):
     counts = [0]
     for g in gather:
@@ -124,11 +129,11 @@ class _RGCNFused(torch.autograd.Function):
     ops/autograd/scatter_kernel.cpp ScatterSum) with the [E, F] intermediates of the dX path never materialised."""
 
     @staticmethod
-    def forward(ctx, x, weight, total, goff, soff, *index):
+    def forward(ctx, x, weight, total, goff, soff, grouped, *index):
         R = len(index) // 2
         gather, scatter = list(index[:R]), list(index[R:])
-        out = x.new_zeros(total, weight.size(-1))
-        torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)
+        out = _fresh_out(x, total, weight.size(-1), grouped)
+        torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped)
         ctx.save_for_backward(x, weight, *index)
         ctx.meta = (goff, soff, R)
         return out
@@ -151,7 +156,7 @@ class _RGCNFused(torch.autograd.Function):
                 gw = torch.zeros_like(weight)
             else:
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(x, gidx), ptr, ops.gather_coo(grad_out, sidx))
-        return (gx, gw, None, None, None) + (None,) * len(index)
+        return (gx, gw, None, None, None, None) + (None,) * len(index)
 
 
 class _RGCNFusedTables(torch.autograd.Function):
@@ -161,14 +166,14 @@ class _RGCNFusedTables(torch.autograd.Function):
     fallback ``cat([feat[t][node_id[t]]])``."""
 
     @staticmethod
-    def forward(ctx, weight, T, gtype, soff, *tensors):
+    def forward(ctx, weight, T, gtype, soff, grouped, *tensors):
         feat, node_id = list(tensors[:T]), list(tensors[T:2 * T])
         index = tensors[2 * T:]
         R = len(index) // 2
         gather, scatter = list(index[:R]), list(index[R:])
         n_t = [t.numel() for t in node_id]
-        out = feat[0].new_zeros(sum(n_t), weight.size(-1))
-        torch.ops.pyg.rgcn_fused_tables(feat, node_id, gtype, gather, scatter, soff, weight, out)
+        out = _fresh_out(feat[0], sum(n_t), weight.size(-1), grouped)
+        torch.ops.pyg.rgcn_fused_tables(feat, node_id, gtype, gather, scatter, soff, weight, out, grouped)
         ctx.save_for_backward(weight, *tensors)
         ctx.meta = (T, gtype, soff, R, n_t)
         return out
@@ -196,18 +201,18 @@ class _RGCNFusedTables(torch.autograd.Function):
             else:
                 xb = torch.cat([f[n] for f, n in zip(feat, node_id)])   # the per-batch matrix the tables stand for
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(xb, gidx), ptr, ops.gather_coo(grad_out, sidx))
-        if any(ctx.needs_input_grad[4 + t] for t in range(T)):
+        if any(ctx.needs_input_grad[5 + t] for t in range(T)):
             gx = grad_out.new_zeros(toff[-1], weight.size(1))
             torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
             for t in range(T):
-                if ctx.needs_input_grad[4 + t]:
+                if ctx.needs_input_grad[5 + t]:
                     gfeat[t] = torch.zeros_like(feat[t]).index_add_(0, node_id[t], gx[toff[t]:toff[t + 1]])
-        return (gw, None, None, None) + tuple(gfeat) + (None,) * (len(tensors) - T)
+        return (gw, None, None, None, None) + tuple(gfeat) + (None,) * (len(tensors) - T)
 
 
 def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                      col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
-                     csc: bool = False) -> Tensor:
+                     csc: bool = False, grouped: bool = False) -> Tensor:
     r"""Same result as :func:`rgcn_layer` from ONE launch (``pyg::rgcn_fused``, csrc/hip/rgcn.hip): source rows are
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
@@ -220,11 +225,19 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with one packed
     16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile boundaries) is
     rounded once per run, where ``scatter_sum`` rounds once per destination.  Under
-    ``torch.use_deterministic_algorithms(True)`` the atomic-free chain (:func:`rgcn_layer`) runs instead."""
+    ``torch.use_deterministic_algorithms(True)`` the atomic-free chain (:func:`rgcn_layer`) runs instead.
+
+    ``grouped=True`` promises that every ``row_dict[et]`` is NONDECREASING -- true for what ``hetero_neighbor_sample`` /
+    ``neighbor_sample`` return (``csc=False``: the edges of a relation come grouped by the node they were sampled for).
+    Then the forward is the ATOMIC-FREE kernel (``PYG_HIP_RGCN_GROUPED``, csrc/hip/rgcn_grouped.h): a workgroup owns 32
+    output rows, sums every row's source features in fp32 in edge order, multiplies the sums of a relation with its
+    weight in one MFMA tile and writes each row once -- no zero fill, no atomics, the same bits on every run (also the
+    path under ``torch.use_deterministic_algorithms(True)``), feature sums and results rounded once each.  The promise is
+    verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``)."""
     total = offsets['__total__']
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
-    if not _fusable(x, weight) or torch.are_deterministic_algorithms_enabled():
+    if not _fusable(x, weight) or (torch.are_deterministic_algorithms_enabled() and not grouped):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:
@@ -235,14 +248,15 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
         goff.append(offsets[col_t])
         soff.append(offsets[row_t])
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return _RGCNFused.apply(x, weight, total, goff, soff, *gather, *scatter)
-    out = x.new_zeros(total, weight.size(-1))
-    return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out)
+        return _RGCNFused.apply(x, weight, total, goff, soff, grouped, *gather, *scatter)
+    out = _fresh_out(x, total, weight.size(-1), grouped)
+    return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped)
 
 
 def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str, Tensor], node_types: List[str],
                             row_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
-                            edge_types: List[EdgeType], weight: Tensor, csc: bool = False) -> Tensor:
+                            edge_types: List[EdgeType], weight: Tensor, csc: bool = False,
+                            grouped: bool = False) -> Tensor:
     r"""The fused layer straight from the GLOBAL feature tables: what
 
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
@@ -252,7 +266,8 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     inside the kernel (``pyg::rgcn_fused_tables``), so the per-batch feature matrix, the ATen gathers and the ``cat``
     disappear.  Returns ``[sum_t len(node_id_dict[t]), F_out]`` in ``node_types`` order.  Same conditions (16-bit,
     ``F = 128``) as :func:`rgcn_layer_fused`, otherwise the chain above runs; differentiable in ``weight`` and in every
-    feature table that requires a gradient (:class:`_RGCNFusedTables`)."""
+    feature table that requires a gradient (:class:`_RGCNFusedTables`).  ``grouped=True``: the atomic-free kernel, see
+    :func:`rgcn_layer_fused`."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
     f0 = feat_dict[node_types[0]]
     feats = [feat_dict[t] for t in node_types]
@@ -263,9 +278,9 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     ok = _fusable(f0, weight) and all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
                                       for f in feats) and \
         all(n.device == f0.device and n.dtype == torch.long and n.dim() == 1 for n in nids)
-    if not ok or torch.are_deterministic_algorithms_enabled():   # (deterministic mode: see rgcn_layer_fused)
+    if not ok or (torch.are_deterministic_algorithms_enabled() and not grouped):   # (deterministic mode: see rgcn_layer_fused)
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
-        return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc)
+        return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc, grouped)
     tidx = {t: i for i, t in enumerate(node_types)}
     gather, scatter, gtype, soff = [], [], [], []
     for et in edge_types:
@@ -276,6 +291,6 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
         gtype.append(tidx[col_t])
         soff.append(off[row_t])
     if needs_grad:
-        return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, *feats, *nids, *gather, *scatter)
-    out = f0.new_zeros(off['__total__'], weight.size(-1))
-    return torch.ops.pyg.rgcn_fused_tables(feats, nids, gtype, gather, scatter, soff, weight, out)
+        return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, grouped, *feats, *nids, *gather, *scatter)
+    out = _fresh_out(f0, off['__total__'], weight.size(-1), grouped)
+    return torch.ops.pyg.rgcn_fused_tables(feats, nids, gtype, gather, scatter, soff, weight, out, grouped)

@@ -312,6 +312,13 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
     assert yt.shape == y.shape
     assert (yt.double() - want).abs().max().item() <= 2e-2 * scale
     assert (yt.double() - y.double()).abs().max().item() <= 2e-2 * scale   # (atomic order differs between two launches)
+    # ... and the atomic-free kernel bench_legs.leg_c5 times since round 5 (grouped=True: the sampler's rows are
+    # nondecreasing per relation, verified on the device): same bar, the same bits on a second run
+    yg = rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    assert (yg.double() - want).abs().max().item() <= 2e-2 * scale
+    assert torch.equal(yg, rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W, grouped=True))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

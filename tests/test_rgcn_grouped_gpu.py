@@ -1,0 +1,294 @@
+"""The atomic-free fused R-GCN layer (PYG_HIP_RGCN_GROUPED, csrc/hip/rgcn_grouped.h): `grouped=True` promises scatter
+indices that are nondecreasing per relation -- what the samplers emit -- and the layer is computed owner-computes: no
+atomics, no zero fill, every row written once.  Checked here: exact results on integer data (rows of 0 ... 70 edges, rows
+of exactly 16 / 32 edges, several node types at offsets that are no multiples of 32, empty relations, more relations than
+the kernel argument holds, a feature table beyond 4 GiB), float data against a float64 restatement on a sampled
+MAG-shaped neighbourhood, bit-reproducibility, the device-side verification of the promise, autograd, deterministic mode."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def signed_permutations(R, F, g):
+    perm = torch.stack([torch.randperm(F, generator=g) for _ in range(R)])
+    W = torch.zeros(R, F, F)
+    W[torch.arange(R)[:, None], perm, torch.arange(F)[None, :]] = (torch.randint(0, 2, (R, F), generator=g) * 2 - 1).float()
+    return W
+
+
+def exact_want(n_out, F, ets, rows, cols, x, W, soff, goff):
+    want = torch.zeros(n_out, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu() + soff[i], x[cols[et].cpu() + goff[i]].double() @ W[i].double())
+    return want
+
+
+def test_grouped_integer_valued_inputs_are_exact():
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(21)
+    F = 128
+    types = ['a', 'b', 'c']
+    n = {'a': 301, 'b': 77, 'c': 1000}           # type offsets 0, 301, 378: blocks of 32 rows straddle the types
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b'), ('c', 'r3', 'c'), ('c', 'r4', 'a'), ('a', 'r5', 'c'), ('b', 'r6', 'b')]
+    #        rows of ~17 edges   empty          17 edges total     ~70 per row        exactly 16 / 32 / 48    one edge       long tail
+    counts = [1000, 0, 17, 4096 + 33, None, 1, 129]
+    x = {t: torch.randint(-1, 2, (n[t], F), generator=g).float() for t in types}
+    W = signed_permutations(len(ets), F, g)
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        s, _, d = et
+        if c is None:   # rows with exactly 16, 32 and 48 edges next to each other, then rows of 1, then the array's end
+            r = torch.cat([torch.full((16,), 3), torch.full((32,), 4), torch.full((48,), 5), torch.arange(6, 40), torch.full((16,), n[s] - 1)])
+        else:
+            r = torch.sort(torch.randint(0, min(60, n[s]), (c,), generator=g)).values
+        rows[et] = r.cuda()
+        cols[et] = torch.randint(0, n[d], (r.numel(),), generator=g).cuda()
+    off = rgcn.type_offsets(n, types)
+    xc = torch.cat([x[t] for t in types])
+    soff = [off[s] for s, _, _ in ets]
+    goff = [off[d] for _, _, d in ets]
+    want = exact_want(off['__total__'], F, ets, rows, cols, xc, W, soff, goff)
+    assert want.abs().max() <= 256   # every feature sum and every result exactly representable in bf16
+    for dtype in (torch.bfloat16, torch.float16):
+        y = rgcn.rgcn_layer_fused(xc.to(dtype).cuda(), off, rows, cols, ets, W.to(dtype).cuda(), grouped=True)
+        assert y.dtype == dtype and torch.equal(y.double().cpu(), want)
+        # ... and the atomic kernel agrees bit for bit on such data
+        y2 = rgcn.rgcn_layer_fused(xc.to(dtype).cuda(), off, rows, cols, ets, W.to(dtype).cuda())
+        assert torch.equal(y, y2)
+    # from the global tables through node ids
+    n_glob = {'a': 5000, 'b': 900, 'c': 20000}
+    nid = {t: torch.randperm(n_glob[t], generator=g)[:n[t]] for t in types}
+    tab = {t: torch.randint(-3, 4, (n_glob[t], F), generator=g).float() for t in types}
+    for t in types:
+        tab[t][nid[t]] = x[t]
+    yt = rgcn.rgcn_layer_fused_tables({t: tab[t].bfloat16().cuda() for t in types}, {t: nid[t].cuda() for t in types}, types,
+                                      rows, cols, ets, W.bfloat16().cuda(), grouped=True)
+    assert torch.equal(yt.double().cpu(), want)
+    assert rgcn.pending_index_error() == 0
+
+
+def test_grouped_more_relations_than_the_kernel_argument_holds():
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(13)
+    n, F, R = 900, 128, 30
+    x = torch.randint(-1, 2, (n, F), generator=g).float()
+    counts = [int(c) for c in torch.randint(0, 300, (R,), generator=g)]
+    counts[3] = 0
+    counts[7] = 5
+    counts[29] = 700
+    ets = [('a', f'r{i}', 'a') for i in range(R)]
+    W = signed_permutations(R, F, g)
+    rows, cols = {}, {}
+    for i, (et, c) in enumerate(zip(ets, counts)):
+        rows[et] = torch.sort(torch.randint(0, 50 + 25 * i, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    y = rgcn.rgcn_layer_fused(x.bfloat16().cuda(), off, rows, cols, ets, W.bfloat16().cuda(), grouped=True)
+    want = exact_want(n, F, ets, rows, cols, x, W, [0] * R, [0] * R)
+    assert want.abs().max() <= 256
+    assert torch.equal(y.double().cpu(), want)
+
+
+def test_grouped_without_edges_writes_zeros():
+    from pyg_lib_amd import rgcn
+    ets = [('a', 'x', 'a'), ('a', 'y', 'a')]
+    e = torch.zeros(0, dtype=torch.long, device='cuda')
+    x = torch.randn(70, 128, device='cuda').bfloat16()
+    w = torch.randn(2, 128, 128, device='cuda').bfloat16()
+    off = rgcn.type_offsets({'a': 70}, ['a'])
+    for _ in range(3):   # (the output is NOT zero-filled by the caller in this mode: stale allocator blocks must not show)
+        torch.full((70, 128), 7.0, device='cuda').bfloat16()
+        y = rgcn.rgcn_layer_fused(x, off, {et: e for et in ets}, {et: e for et in ets}, ets, w, grouped=True)
+        assert y.shape == (70, 128) and not y.any()
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_grouped_on_a_sampled_mag_neighbourhood(dtype):
+    """The sampler's output IS grouped (row nondecreasing per edge type): verified by the device-side check of the call,
+    result against a float64 restatement with the kernel's two roundings (feature sum per relation, result), against the
+    atomic kernel and the three-op chain, untouched rows exactly zero, the same bits on every run."""
+    from pyg_lib_amd import sampler, rgcn
+    from tests.test_rgcn_gpu import MAG_TYPES, MAG_ETS, build_graph
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(3)
+    sizes = {'paper': 40_000, 'author': 60_000, 'institution': 900, 'field_of_study': 4_000}
+    rp, cl = build_graph(rng, sizes, MAG_ETS, 12)
+    seeds = {'paper': rng.permutation(sizes['paper'])[:1024].astype(np.int64)}
+    fan = {e: [15, 10] for e in MAG_ETS}
+    F = 128
+    torch.manual_seed(9)
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                         {k: dev(v) for k, v in seeds.items()}, fan)
+    row_d, col_d, node_d = out[0], out[1], out[2]
+    for e in MAG_ETS:
+        assert bool((row_d[e][1:] >= row_d[e][:-1]).all()), e   # the promise holds for sampler output
+    g = torch.Generator(device='cuda').manual_seed(4)
+    feat = {t: torch.randn(sizes[t], F, device='cuda', generator=g).to(dtype) for t in MAG_TYPES}
+    W = (torch.randn(len(MAG_ETS), F, F, device='cuda', generator=g) / F ** 0.5).to(dtype)
+    off = rgcn.type_offsets({t: node_d[t].numel() for t in MAG_TYPES}, MAG_TYPES)
+    x = torch.cat([feat[t][node_d[t]] for t in MAG_TYPES])
+    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W, grouped=True)
+    yt = rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    assert torch.equal(y, yt)           # same sums in the same order, wherever the rows come from
+    want = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
+    touched = torch.zeros(off['__total__'], dtype=torch.bool, device='cuda')
+    for i, (s, r, d) in enumerate(MAG_ETS):
+        agg = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
+        agg.index_add_(0, row_d[(s, r, d)] + off[s], x[col_d[(s, r, d)] + off[d]].double())
+        want += agg.to(dtype).double() @ W[i].double()           # the feature sum is rounded to T once
+        touched[row_d[(s, r, d)] + off[s]] = True
+    scale = want.abs().max().item()
+    assert scale > 1.0
+    # one rounding of the result (half an ulp: 2^-8 / 2^-11 relative) on top of the restated feature-sum rounding (an fp32
+    # sum next to a rounding boundary may land on the other side of it than the float64 sum: one ulp of one feature sum)
+    assert (y.double() - want).abs().max().item() <= (8e-3 if dtype == torch.bfloat16 else 1.5e-3) * scale
+    assert not y[~touched].any()
+    ya = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W)     # atomic kernel: messages rounded, runs added
+    y3 = rgcn.rgcn_layer(x, off, row_d, col_d, MAG_ETS, W)           # three-op chain
+    tol = (3e-2 if dtype == torch.bfloat16 else 4e-3) * scale
+    assert (y.double() - ya.double()).abs().max().item() <= tol and (y.double() - y3.double()).abs().max().item() <= tol
+    for _ in range(3):
+        assert torch.equal(rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True), y)
+
+
+def test_grouped_promise_is_verified_on_the_device():
+    """Not grouped -> error 3: reported without a synchronisation by default (pending_index_error / the next call), in
+    the call itself with PYG_HIP_RGCN_CHECKED; an out-of-range scatter index is 2, a gather index 1; nothing is read or
+    written out of bounds (the arrays sit at the end of their allocations here)."""
+    from pyg_lib_amd import rgcn, _capi
+    g = torch.Generator().manual_seed(5)
+    n, F = 500, 128
+    ets = [('a', 'r', 'a')]
+    x = torch.randn(n, F, generator=g).bfloat16().cuda()
+    w = torch.randn(1, F, F, generator=g).bfloat16().cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    rows = torch.sort(torch.randint(0, n, (3000,), generator=g)).values
+    cols = torch.randint(0, n, (3000,), generator=g)
+    assert rgcn.pending_index_error() == 0
+    rgcn.rgcn_layer_fused(x, off, {ets[0]: rows.cuda()}, {ets[0]: cols.cuda()}, ets, w, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    shuffled = rows[torch.randperm(3000, generator=g)]
+    rgcn.rgcn_layer_fused(x, off, {ets[0]: shuffled.cuda()}, {ets[0]: cols.cuda()}, ets, w, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 3
+    bad_rows = rows.clone()
+    bad_rows[-1] = n + 5
+    rgcn.rgcn_layer_fused(x, off, {ets[0]: bad_rows.cuda()}, {ets[0]: cols.cuda()}, ets, w, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 2
+    bad_cols = cols.clone()
+    bad_cols[17] = -3
+    y = rgcn.rgcn_layer_fused(x, off, {ets[0]: rows.cuda()}, {ets[0]: bad_cols.cuda()}, ets, w, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 1 and bool(torch.isfinite(y.float()).all())
+    # unpolled: the next call raises
+    rgcn.rgcn_layer_fused(x, off, {ets[0]: shuffled.cuda()}, {ets[0]: cols.cuda()}, ets, w, grouped=True)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='not grouped'):
+        rgcn.rgcn_layer_fused(x, off, {ets[0]: rows.cuda()}, {ets[0]: cols.cuda()}, ets, w, grouped=True)
+    assert rgcn.pending_index_error() == 0
+
+    # the C entry point with PYG_HIP_RGCN_CHECKED | PYG_HIP_RGCN_GROUPED fails in the call that has them
+    L = _capi.lib()
+
+    class Rel(ctypes.Structure):
+        _fields_ = [('gather_index', ctypes.c_void_p), ('scatter_index', ctypes.c_void_p), ('num_edges', ctypes.c_int64),
+                    ('gather_offset', ctypes.c_int64), ('scatter_offset', ctypes.c_int64), ('weight', ctypes.c_void_p),
+                    ('x', ctypes.c_void_p), ('gather_map', ctypes.c_void_p), ('x_rows', ctypes.c_int64), ('gather_map_len', ctypes.c_int64)]
+
+    L.pyg_hip_rgcn_grouped_workspace_size.restype = ctypes.c_size_t
+    L.pyg_hip_rgcn_grouped_workspace_size.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    L.pyg_hip_rgcn_fused.restype = ctypes.c_int
+    L.pyg_hip_rgcn_fused.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    out = torch.empty(n, F, dtype=torch.bfloat16, device='cuda')
+
+    def call(s, gidx, flags):
+        sd, gd = s.cuda(), gidx.cuda()
+        rel = Rel(gd.data_ptr(), sd.data_ptr(), sd.numel(), 0, 0, w.data_ptr(), 0, 0, 0, 0)
+        need = L.pyg_hip_rgcn_grouped_workspace_size(ctypes.addressof(rel), 1, n)
+        ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+        rc = L.pyg_hip_rgcn_fused(3, x.data_ptr(), n, ctypes.addressof(rel), 1, out.data_ptr(), n, F, F, flags, ws.data_ptr(), need,
+                                  torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return rc
+
+    assert call(rows, cols, 1 | 8) == 0
+    assert call(shuffled, cols, 1 | 8) != 0 and b'not grouped' in L.pyg_hip_last_error()
+    assert call(bad_rows, cols, 1 | 8) != 0 and b'scatter index out of range' in L.pyg_hip_last_error()
+    assert call(rows, bad_cols, 1 | 8) != 0 and b'gather index out of range' in L.pyg_hip_last_error()
+    # too small a workspace is refused before anything is launched
+    sd, gd = rows.cuda(), cols.cuda()
+    rel = Rel(gd.data_ptr(), sd.data_ptr(), sd.numel(), 0, 0, w.data_ptr(), 0, 0, 0, 0)
+    ws = torch.empty(256, dtype=torch.uint8, device='cuda')
+    assert L.pyg_hip_rgcn_fused(3, x.data_ptr(), n, ctypes.addressof(rel), 1, out.data_ptr(), n, F, F, 8, ws.data_ptr(), 256,
+                                torch.cuda.current_stream().cuda_stream) != 0
+    assert b'workspace' in L.pyg_hip_last_error()
+
+
+def test_grouped_feature_table_of_more_than_4_gib():
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(9)
+    F = 128
+    n_big = (1 << 24) + 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n_big * F * 2:
+        pytest.skip('not enough device memory for a 4 GiB table')
+    picks = torch.cat([1 + 50_000 * torch.randperm(300, generator=g), (1 << 24) + 1 + torch.randperm(4000, generator=g)[:300],
+                       torch.tensor([0, (1 << 24) - 1, 1 << 24, n_big - 1])])
+    table = torch.empty(n_big, F, dtype=torch.bfloat16, device='cuda')
+    vals = torch.randint(-1, 2, (picks.numel(), F), generator=g).float()
+    table[picks.cuda()] = vals.bfloat16().cuda()
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'a')]
+    W = signed_permutations(2, F, g)
+    rows, cols = {}, {}
+    for et, c in zip(ets, [5000, 77]):
+        rows[et] = torch.sort(torch.randint(0, 40, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, picks.numel(), (c,), generator=g).cuda()
+    want = exact_want(picks.numel(), F, ets, rows, cols, vals, W, [0, 0], [0, 0])
+    assert want.abs().max() <= 256
+    y = rgcn.rgcn_layer_fused_tables({'a': table}, {'a': picks.cuda()}, ['a'], rows, cols, ets, W.bfloat16().cuda(), grouped=True)
+    assert torch.equal(y.double().cpu(), want)
+    del table
+
+
+def test_grouped_is_differentiable_and_runs_in_deterministic_mode():
+    from pyg_lib_amd import rgcn, diagnostics
+    g = torch.Generator().manual_seed(31)
+    n, F = 400, 128
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'a')]
+    rows = {et: torch.sort(torch.randint(0, 90, (1500,), generator=g)).values.cuda() for et in ets}
+    cols = {et: torch.randint(0, n, (1500,), generator=g).cuda() for et in ets}
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    x0 = torch.randn(n, F, generator=g).bfloat16().cuda()
+    w0 = (torch.randn(2, F, F, generator=g) / F ** 0.5).bfloat16().cuda()
+    grads = []
+    for grouped in (False, True):
+        x = x0.clone().requires_grad_()
+        w = w0.clone().requires_grad_()
+        y = rgcn.rgcn_layer_fused(x, off, rows, cols, ets, w, grouped=grouped)
+        y.float().square().sum().backward()
+        grads.append((y.detach(), x.grad, w.grad))
+    scale = grads[0][0].float().abs().max().item()
+    assert (grads[0][0].float() - grads[1][0].float()).abs().max().item() <= 3e-2 * scale
+    for a, b in zip(grads[0][1:], grads[1][1:]):   # backward: the same kernels on slightly different dOut
+        assert (a.float() - b.float()).abs().max().item() <= 5e-2 * a.float().abs().max().item()
+    # deterministic mode: grouped stays on the fused kernel (it has no atomics), ungrouped takes the chain
+    marker = diagnostics.last_accumulate_info()
+    torch.use_deterministic_algorithms(True)
+    try:
+        yd = rgcn.rgcn_layer_fused(x0, off, rows, cols, ets, w0, grouped=True)
+        assert torch.equal(yd, grads[1][0])
+        assert diagnostics.last_accumulate_info() == marker
+        yo = torch.ops.pyg.rgcn_fused(x0, [cols[e] for e in ets], [rows[e] for e in ets], [0, 0], [0, 0], w0, torch.empty_like(x0), True)
+        assert torch.equal(yo, yd)
+    finally:
+        torch.use_deterministic_algorithms(False)

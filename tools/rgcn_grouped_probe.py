@@ -1,0 +1,32 @@
+"""C5 layer alone, both kernels (atomic adds into a zero-filled output / atomic-free grouped), for rocprofv3:
+python tools/rgcn_grouped_probe.py [iters]"""
+import sys
+import time
+
+import torch
+
+import bench_legs
+from pyg_lib_amd import sampler, rgcn
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device('cuda:0')
+types = list(bench_legs.MAG_SIZES)
+ets = [(s, r, d) for s, r, d, _ in bench_legs.MAG_RELS]
+rp, cl = bench_legs.make_mag_graph(dev)
+F = 128
+feat = {t: torch.randn(bench_legs.MAG_SIZES[t], F, device=dev).bfloat16() for t in types}
+W = (torch.randn(len(ets), F, F, device=dev) / F ** 0.5).bfloat16()
+seeds = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=torch.Generator().manual_seed(1))[:1024].to(dev)
+torch.manual_seed(100)
+out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds}, {e: [15, 10] for e in ets})
+for grouped in (False, True):
+    f = lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=grouped)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f()
+    torch.cuda.synchronize()
+    print(f'grouped={grouped}: {(time.perf_counter() - t0) / iters * 1e3:.4f} ms per layer', flush=True)
+print('pending', rgcn.pending_index_error())
