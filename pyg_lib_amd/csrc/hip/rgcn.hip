@@ -576,11 +576,14 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
                         : (inl ? (const void*)&rgcn_rowstart_kernel<false, true> : (const void*)&rgcn_rowstart_kernel<false, false>);
   const void* kern;
   {
-#define PYG_RGCN_GPICK(BF, CK, BG) (inl ? (const void*)&rgcn_grouped_kernel<BF, CK, BG, true> : (const void*)&rgcn_grouped_kernel<BF, CK, BG, false>)
-    kern = bf ? (ck ? (big ? PYG_RGCN_GPICK(true, true, true) : PYG_RGCN_GPICK(true, true, false))
-                    : (big ? PYG_RGCN_GPICK(true, false, true) : PYG_RGCN_GPICK(true, false, false)))
-              : (ck ? (big ? PYG_RGCN_GPICK(false, true, true) : PYG_RGCN_GPICK(false, true, false))
-                    : (big ? PYG_RGCN_GPICK(false, false, true) : PYG_RGCN_GPICK(false, false, false)));
+#define PYG_RGCN_GPICK(K, BF, CK, BG) (inl ? (const void*)&K<BF, CK, BG, true> : (const void*)&K<BF, CK, BG, false>)
+#define PYG_RGCN_GPICK4(K)                                                                                                       \
+  (bf ? (ck ? (big ? PYG_RGCN_GPICK(K, true, true, true) : PYG_RGCN_GPICK(K, true, true, false))                                \
+            : (big ? PYG_RGCN_GPICK(K, true, false, true) : PYG_RGCN_GPICK(K, true, false, false)))                              \
+      : (ck ? (big ? PYG_RGCN_GPICK(K, false, true, true) : PYG_RGCN_GPICK(K, false, true, false))                              \
+            : (big ? PYG_RGCN_GPICK(K, false, false, true) : PYG_RGCN_GPICK(K, false, false, false))))
+    kern = PYG_RGCN_GPICK4(rgcn_grouped_kernel);
+#undef PYG_RGCN_GPICK4
 #undef PYG_RGCN_GPICK
   }
   constexpr int lds = 32768 + 8192 + 2 * 4 * kGroupedMaxRel;

@@ -107,10 +107,17 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
 // and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave 0 - 3, barrier, the block's stores when its
 // last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on the C5
 // batch where the atomic kernel + its zero fill take 66.)
-template <bool BF16, bool CHECK, bool BIG, bool INL>
+template <bool BF16, bool CHECK, bool BIG, bool INL, int NW>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
   constexpr int U = 16;   // edges of a row per batch (one per lane of the group)
+  constexpr int ROWS = 4 * NW;          // rows of `out` per block: one per 16-lane group
+  // (NW = 8 -- 32 rows per block, 512 threads, 128 registers with the accumulators parked in LDS between the items of a
+  // block, half the items per workgroup -- was built and measured: 0.0673 ms on the C5 batch against 0.0657 - 0.0679 for
+  // NW = 4.  Neither is latency bound any more: 145 MB of random 256-byte rows + 110 MB of zero rows + 10 MB of indices in
+  // 57 us is what the chip delivers for this access mix -- random-row gathers run at 3.7 - 4.7 TB/s in every kernel of
+  // this library.)
+  constexpr int kWBytes = 32768;
   // Rows of more than 16 edges (fan-outs above 16, full neighbourhoods) need further batches.  That loop inside the pipeline
   // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
   // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
@@ -125,20 +132,20 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     else return desc.rp_off[i];
   };
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xs = smem + 32768;   // the A tile: 32 rows (16 used) x 16 chunks of 16 bytes, chunk index XOR-swizzled with the row
-  int* rlo = reinterpret_cast<int*>(smem + 40960);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
+  char* xs = smem + kWBytes;   // the A tile: 32 rows (ROWS used) x 16 chunks of 16 bytes, chunk index XOR-swizzled with the row
+  int* rlo = reinterpret_cast<int*>(smem + kWBytes + 8192);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
   int* rhi = rlo + kGroupedMaxRel;
   const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = tid >> 4, c = tid & 15;
   const int gbase = lane & 48;  // first lane of the group inside its wave
   // the relations' row ranges, once per workgroup
-  for (int r0 = 0; r0 < R; r0 += 256) {
+  for (int r0 = 0; r0 < R; r0 += 64 * NW) {
     const int r = r0 + tid;
     int64_t so = 0;
     bool has = false;
     if constexpr (INL) {  // (a per-lane index into the kernel argument would copy it to scratch)
-      for (int i = r0; i < R && i < r0 + 256; ++i) {
+      for (int i = r0; i < R && i < r0 + 64 * NW; ++i) {
         const int64_t so_i = desc.irels[i].scatter_offset;
         const bool has_i = desc.irels[i].num_edges > 0;
         if (i == r) so = so_i, has = has_i;
@@ -154,7 +161,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       rhi[r] = hi;
     }
   }
-  {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
+  if constexpr (ROWS < 32) {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
     const u32x4 z = {0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(xs + 4096 + tid * 16) = z;
   }
@@ -162,15 +169,24 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 
   // W of relation `g` into LDS buffer `buf`: the layout of rgcn_fused_kernel (32 blocks of 4 k-rows, 16-byte chunks
   // permuted inside a block), this wave's 4 blocks
-  auto load_w = [&](int g) __attribute__((always_inline)) {
+  // (Lane constants of the phases behind the row loads -- W's DMA addresses, the MFMA operand base, the store addresses --
+  // are recomputed from an opaque copy of the thread id where they are used: kept in registers over the loop they do not
+  // fit, and as spills they are reloaded from scratch behind the row loads, i.e. the reload waits for the rows.)
+  auto opaque_tid = [&]() __attribute__((always_inline)) -> int {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  auto load_w = [&](int g, int buf) __attribute__((always_inline)) {
+    const int lane = opaque_tid() & 63;
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
     const char* wsrc = rel_at(g).weight + dma_r * 256 + dma_c * 16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kb = wave * 8 + j;
+    for (int j = 0; j < 32 / NW; ++j) {
+      const int kb = wave * (32 / NW) + j;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
-                                       (LDSV*)(smem + kb * 1024), 16, 0, 0);
+                                       (LDSV*)(smem + buf * 32768 + kb * 1024), 16, 0, 0);
     }
   };
   // edges of the group's row among the 16 at `start`: lane c looks at edge start + c; the row's edges are a prefix
@@ -239,7 +255,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
 
   // ---- the items of this workgroup, in order (wave-uniform state) ---------------------------------------------------
-  const int nblocks = (int)((out_rows + 15) >> 4);
+  const int nblocks = (int)((out_rows + ROWS - 1) / ROWS);
   const int G = (int)gridDim.x;
   // (no flags in this state: two bools set in sibling branches were merged into one store through a selected pointer,
   // which kept them -- and with them the whole walk -- in scratch and in vector registers)
@@ -253,9 +269,9 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   int it_j = -1, it_blk = -1, it_c0 = R;
   uint64_t it_mask = 0;
   auto chunk_mask = [&](int blk, int c0) __attribute__((always_inline)) -> uint64_t {
-    const int row0 = blk * 16;
+    const int row0 = blk * ROWS;
     bool relv = false;
-    if (c0 + lane < R) relv = rhi[c0 + lane] >= row0 && rlo[c0 + lane] <= row0 + 15;
+    if (c0 + lane < R) relv = rhi[c0 + lane] >= row0 && rlo[c0 + lane] <= row0 + ROWS - 1;
     return __ballot(relv);
   };
   auto next_item = [&](int& blk, int& rel) __attribute__((always_inline)) -> bool {
@@ -285,8 +301,11 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         it_mask = chunk_mask(it_blk, it_c0);
       }
       if (it_mask == 0) {  // nothing arrives in the block's rows
-        const int64_t o = (int64_t)it_blk * 16 + grp;
-        const u32x4 z = {0u, 0u, 0u, 0u};
+        const int t = opaque_tid(), grp = t >> 4, c = t & 15;
+        const int64_t o = (int64_t)it_blk * ROWS + grp;
+        uint32_t z0 = 0;
+        asm volatile("" : "+v"(z0));   // (materialised here: hoisted, the four zero registers were spilled and reloaded)
+        const u32x4 z = {z0, z0, z0, z0};
         if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = z;
         it_c0 = R;
       }
@@ -303,10 +322,10 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   int s1_2 = -1;                                         //  its low word -- the row-start launch has seen all 64 bits)
   // the group's row as relation `rel`'s scatter index (recomputed where it is needed: four pipeline registers less)
   auto row_of = [&](int blk, int rel) __attribute__((always_inline)) -> int {
-    return (int)((int64_t)blk * 16 + grp - rel_at(rel).scatter_offset);
+    return (int)((int64_t)blk * ROWS + grp - rel_at(rel).scatter_offset);
   };
   auto issue_start = [&](int blk, int rel, int& st) __attribute__((always_inline)) {
-    const int64_t o = (int64_t)blk * 16 + grp;
+    const int64_t o = (int64_t)blk * ROWS + grp;
     st = -1;
     if (o < out_rows && o >= rlo[rel] && o <= rhi[rel]) st = desc.rp[rp_off_at(rel) + (o - rel_at(rel).scatter_offset)];
   };
@@ -314,21 +333,24 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int q = lane & 15, grp16 = lane >> 4;
-  const char* wb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
   // A tile (rows = the block's 16 destinations) x W in LDS -> acc: wave t the 32 output columns of its n-tile
-  auto product = [&]() __attribute__((always_inline)) {
+  auto product = [&](f32x16& acc, int buf) __attribute__((always_inline)) {
+    if (NW > 4 && wave >= 4) return;
+    const int lane = opaque_tid() & 63, xl = lane & 31, h = lane >> 5, q = lane & 15, grp16 = lane >> 4;
+    const char* wbb = smem + buf * 32768 + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
 #pragma unroll 2   // (not 8: the operands of all steps at once, next to the rows in flight, do not fit the register budget)
     for (int s = 0; s < 8; ++s) {
       const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((8 * h + s) ^ (xl & 15))) * 16);
-      const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s) * 1024 + wave * 256));
-      const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wb + (2 * s + 1) * 1024 + wave * 256));
+      const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wbb + (2 * s) * 1024 + wave * 256));
+      const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wbb + (2 * s + 1) * 1024 + wave * 256));
       const u32x4 wa = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
       acc = mfma16<BF16>(wa, xa, acc);
     }
   };
   // the block's 16 x 128 results, rounded once, through the tile: wave t holds columns (8 h + 2 t + j) * 8 ... + 7 of row xl
-  auto store_block = [&](int blk) __attribute__((always_inline)) {
+  auto store_block = [&](f32x16& acc, int blk) __attribute__((always_inline)) {
+    const int t = opaque_tid(), lane = t & 63, xl = lane & 31, h = lane >> 5, grp = t >> 4, c = t & 15;
+    if (NW == 4 || wave < 4) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       u32x4 pk;
@@ -339,13 +361,15 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
     __syncthreads();
     // (every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
     const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
-    const int64_t o = (int64_t)blk * 16 + grp;
+    const int64_t o = (int64_t)blk * ROWS + grp;
     if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = v;
   };
   auto a_tile_from_sums = [&]() __attribute__((always_inline)) {
+    const int t = opaque_tid(), grp = t >> 4, c = t & 15;
     u32x4 pk;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pk[k] = pack2<BF16>(sum[2 * k], sum[2 * k + 1]);
@@ -359,10 +383,10 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     while (next_item(blk, rel)) {
       blk = __builtin_amdgcn_readfirstlane(blk);
       rel = __builtin_amdgcn_readfirstlane(rel);
-      if (cur >= 0 && blk != cur) store_block(cur);
+      if (cur >= 0 && blk != cur) store_block(acc, cur);
       cur = blk;
       const RelDev& r = rel_at(rel);
-      load_w(rel);   // (the previous item's products are behind a barrier)
+      load_w(rel, 0);   // (the previous item's products are behind a barrier)
       int sc = -1;
       issue_start(blk, rel, sc);
       const int d = row_of(blk, rel);
@@ -386,10 +410,10 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       a_tile_from_sums();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
       __syncthreads();
-      product();
+      product(acc, 0);
       __syncthreads();
     }
-    if (cur >= 0) store_block(cur);
+    if (cur >= 0) store_block(acc, cur);
     return;
   }
   bool primed = false;  // (the first iteration only fetches: one call site for the item walk, so that it is inlined and its
@@ -434,13 +458,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     rel4 = __builtin_amdgcn_readfirstlane(rel4);
     if (v4) issue_start(blk4, rel4, st4);
     // ---- item i: A tile, product; the block's rows when this was its last item -------------------------------------------
-    if (!v0 && v1) load_w(rel1);   // (the pipeline is filling: nobody reads W)
+    if (!v0 && v1) load_w(rel1, 0);   // (the pipeline is filling: nobody reads W)
     if (v0) {
+      const bool last = !v1 || blk1 != blk0;   // of its block
       __syncthreads();
-      product();
+      product(acc, 0);
       __syncthreads();  // the A tile and W are free again
-      if (v1) load_w(rel1);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
-      if (!v1 || blk1 != blk0) store_block(blk0);
+      if (v1) load_w(rel1, 0);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
+      if (last) store_block(acc, blk0);
     }
     // ---- rotate --------------------------------------------------------------------------------------------------------
     v0 = v1, blk0 = blk1, rel0 = rel1, st0 = st1, n0 = n1;
@@ -453,9 +478,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 template <bool BF16, bool CHECK, bool BIG, bool INL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                               int64_t out_rows, int* __restrict__ error) {
-  rgcn_grouped_body<BF16, CHECK, BIG, INL>(desc, R, out, out_rows, error);
+  rgcn_grouped_body<BF16, CHECK, BIG, INL, 4>(desc, R, out, out_rows, error);
 }
-
 size_t grouped_workspace_bytes(const pyg_hip_rgcn_relation* rels, int64_t R, int64_t out_rows) {
   size_t rp = 0;
   for (int64_t r = 0; r < R; ++r) {
