@@ -116,6 +116,23 @@ def _rel_ptr_and_indices(gather: List[Tensor], scatter: List[Tensor], goff: List
     return torch.tensor(counts, dtype=torch.long), gidx, sidx
 
 
+def _dx_scatter(grad_out: Tensor, weight: Tensor, gather: List[Tensor], scatter: List[Tensor], goff: List[int],
+                soff: List[int], rows: int) -> Tensor:
+    r"""dX[g_e] += dOut[s_e] @ W_r^T: the atomic fused kernel with the two index vectors swapped -- the gather index of the
+    forward is the scatter index here, and it is not grouped -- or, under ``torch.use_deterministic_algorithms(True)``,
+    the atomic-free chain gather -> segment_matmul -> scatter_sum (stable sort + CSR rows)."""
+    wt = weight.transpose(1, 2).contiguous()
+    if torch.are_deterministic_algorithms_enabled():
+        ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
+        if gidx.numel() == 0:
+            return grad_out.new_zeros(rows, weight.size(1))
+        msgs = ops.segment_matmul(ops.gather_coo(grad_out, sidx), ptr, wt)   # (the kernel takes any index order)
+        return ops.scatter_sum(msgs, gidx, dim=0, dim_size=rows)
+    gx = grad_out.new_zeros(rows, weight.size(1))   # (contiguous whatever x's strides are: the kernel accumulates into it in place)
+    torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, wt, gx)
+    return gx
+
+
 class _RGCNFused(torch.autograd.Function):
     r"""out = rgcn_fused(x, W) with gradients.  Per edge e of relation r:  out[s_e] += x[g_e] @ W_r, hence
 
@@ -148,8 +165,7 @@ class _RGCNFused(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = x.new_zeros(x.shape)   # (contiguous whatever x's strides are: the kernel accumulates into it in place)
-            torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
+            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, x.size(0))
         if ctx.needs_input_grad[1]:
             ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
             if gidx.numel() == 0:
@@ -202,8 +218,7 @@ class _RGCNFusedTables(torch.autograd.Function):
                 xb = torch.cat([f[n] for f, n in zip(feat, node_id)])   # the per-batch matrix the tables stand for
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(xb, gidx), ptr, ops.gather_coo(grad_out, sidx))
         if any(ctx.needs_input_grad[5 + t] for t in range(T)):
-            gx = grad_out.new_zeros(toff[-1], weight.size(1))
-            torch.ops.pyg.rgcn_fused(grad_out, scatter, gather, soff, goff, weight.transpose(1, 2).contiguous(), gx)
+            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, toff[-1])
             for t in range(T):
                 if ctx.needs_input_grad[5 + t]:
                     gfeat[t] = torch.zeros_like(feat[t]).index_add_(0, node_id[t], gx[toff[t]:toff[t + 1]])

@@ -290,5 +290,17 @@ def test_grouped_is_differentiable_and_runs_in_deterministic_mode():
         assert diagnostics.last_accumulate_info() == marker
         yo = torch.ops.pyg.rgcn_fused(x0, [cols[e] for e in ets], [rows[e] for e in ets], [0, 0], [0, 0], w0, torch.empty_like(x0), True)
         assert torch.equal(yo, yd)
+        # ... and so does training: the backward takes the atomic-free chain for dX (its scatter index is the forward's
+        # gather index: not grouped), the weight gradient has no atomics anyway -- the same bits on every run
+        runs = []
+        for _ in range(2):
+            x = x0.clone().requires_grad_()
+            w = w0.clone().requires_grad_()
+            rgcn.rgcn_layer_fused(x, off, rows, cols, ets, w, grouped=True).float().square().sum().backward()
+            runs.append((x.grad.clone(), w.grad.clone()))
+        assert diagnostics.last_accumulate_info() == marker
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        for a, b in zip(grads[1][1:], runs[0]):
+            assert (a.float() - b.float()).abs().max().item() <= 5e-2 * a.float().abs().max().item()
     finally:
         torch.use_deterministic_algorithms(False)
