@@ -468,7 +468,9 @@ const char* rgcn_error_text(int code) {
 
 // PYG_HIP_RGCN_GROUPED: the row-start launch, then the owner-computes kernel (rgcn_grouped.h).  `out` is WRITTEN.
 int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R, void* out,
-                        int64_t num_out_rows, int checked, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace, size_t workspace_bytes,
+                        hipStream_t stream) {
+  const int KC = (int)(K / 128), MC = (int)(M / 128);
   if (num_out_rows == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "rgcn_fused: 'out' must be 16-byte aligned in grouped mode");
@@ -488,7 +490,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     E += rels[r].num_edges;
   }
   if (E == 0) {  // nothing arrives anywhere
-    PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * 256, stream));
+    PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * 2, stream));
     return PYG_HIP_OK;
   }
   const size_t need = grouped_workspace_bytes(rels, R, num_out_rows);
@@ -527,7 +529,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     hr[r].gather_map = rels[r].gather_map;
     hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
     hr[r].map_len = rels[r].gather_map_len;
-    big = big || hr[r].x_rows >= (1LL << 24);
+    big = big || hr[r].x_rows * (K * 2) >= (1LL << 32);
     hp[r] = e;
     e += rels[r].num_edges;
     const int64_t span = rels[r].num_edges > 0 ? num_out_rows - rels[r].scatter_offset : 0;
@@ -583,10 +585,19 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
       : (ck ? (big ? PYG_RGCN_GPICK(K, false, true, true) : PYG_RGCN_GPICK(K, false, true, false))                              \
             : (big ? PYG_RGCN_GPICK(K, false, false, true) : PYG_RGCN_GPICK(K, false, false, false))))
     kern = PYG_RGCN_GPICK4(rgcn_grouped_kernel);
+#define PYG_RGCN_SPICK(KC_, MC_)                                                                                                        \
+  (bf ? (big ? (inl ? (const void*)&rgcn_grouped_shape_kernel<true, true, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<true, true, false, KC_, MC_>)    \
+             : (inl ? (const void*)&rgcn_grouped_shape_kernel<true, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<true, false, false, KC_, MC_>)) \
+      : (big ? (inl ? (const void*)&rgcn_grouped_shape_kernel<false, true, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, true, false, KC_, MC_>)  \
+             : (inl ? (const void*)&rgcn_grouped_shape_kernel<false, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, false, false, KC_, MC_>)))
+    if (KC == 2 && MC == 2) kern = PYG_RGCN_SPICK(2, 2);
+    else if (KC == 1 && MC == 2) kern = PYG_RGCN_SPICK(1, 2);
+    else if (KC == 2 && MC == 1) kern = PYG_RGCN_SPICK(2, 1);
+#undef PYG_RGCN_SPICK
 #undef PYG_RGCN_GPICK4
 #undef PYG_RGCN_GPICK
   }
-  constexpr int lds = 32768 + 8192 + 2 * 4 * kGroupedMaxRel;
+  const int lds = 32768 + 8192 * KC + 2 * 4 * kGroupedMaxRel;
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   int Ri = (int)R;
   {
@@ -644,12 +655,14 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
                        size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16, "rgcn_fused: bfloat16 / float16 only");
-  if (K != 128 || M != 128) return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (got %lld x %lld)", (long long)K, (long long)M);
+  const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
+  if (grouped ? !((K == 128 || K == 256) && (M == 128 || M == 256)) : (K != 128 || M != 128))
+    return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M in {128, 256}); got %lld x %lld",
+                (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");
-  const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
   if (R == 0) {
-    if (grouped && out && num_out_rows > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * 256, stream));
+    if (grouped && out && num_out_rows > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * 2, stream));
     return PYG_HIP_OK;
   }
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");
@@ -670,7 +683,7 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
     PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(xr) & 15) == 0, "rgcn_fused: misaligned feature table");
   }
   if (grouped)
-    return rgcn_grouped_launch(dtype, x, num_x_rows, rels, R, out, num_out_rows, checked, workspace, workspace_bytes, stream);
+    return rgcn_grouped_launch(dtype, x, num_x_rows, rels, R, out, num_out_rows, K, M, checked, workspace, workspace_bytes, stream);
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "rgcn_fused: misaligned tensor");
   PYG_HIP_REQUIRE(tiles < (1LL << 31), "rgcn_fused: too many tiles");
   if (workspace == nullptr || workspace_bytes < pyg_hip_rgcn_fused_workspace_size(R, E))

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
 // and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave 0 - 3, barrier, the block's stores when its
 // last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on the C5
 // batch where the atomic kernel + its zero fill take 66.)
-template <bool BF16, bool CHECK, bool BIG, bool INL, int NW>
+template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
   constexpr int U = 16;   // edges of a row per batch (one per lane of the group)
@@ -118,11 +118,15 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // 57 us is what the chip delivers for this access mix -- random-row gathers run at 3.7 - 4.7 TB/s in every kernel of
   // this library.)
   constexpr int kWBytes = 32768;
+  // K = 128 KC input features (rows of 256 KC bytes), M = 128 MC output features: the feature rows are walked once per
+  // 128-feature slice (the indices come from L2 the second time), W travels through LDS in 128 x 128 chunks.  The pipeline
+  // exists for KC = MC = 1; the other shapes take the item-at-a-time walk (2 % slower on the C5 batch where both run).
+  constexpr int RB = 256 * KC, OB = 256 * MC;   // bytes of a feature row / of a row of `out`
   // Rows of more than 16 edges (fan-outs above 16, full neighbourhoods) need further batches.  That loop inside the pipeline
   // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
   // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
   // function instead (same registers, no pipeline; the choice is uniform over the launch).
-  const bool long_rows = *desc.long_rows == desc.call_id;
+  const bool long_rows = KC * MC > 1 || *desc.long_rows == desc.call_id;
   auto rel_at = [&](int i) __attribute__((always_inline)) -> const RelDev& {
     if constexpr (INL) return desc.irels[i];
     else return desc.rels[i];
@@ -133,7 +137,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem + kWBytes;   // the A tile: 32 rows (ROWS used) x 16 chunks of 16 bytes, chunk index XOR-swizzled with the row
-  int* rlo = reinterpret_cast<int*>(smem + kWBytes + 8192);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
+  int* rlo = reinterpret_cast<int*>(smem + kWBytes + 8192 * KC);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
   int* rhi = rlo + kGroupedMaxRel;
   const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +167,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   }
   if constexpr (ROWS < 32) {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
     const u32x4 z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(xs + 4096 + tid * 16) = z;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) *reinterpret_cast<u32x4*>(xs + kc * 8192 + 4096 + tid * 16) = z;
   }
   __syncthreads();
 
@@ -177,16 +182,16 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     asm volatile("" : "+v"(t));
     return t;
   };
-  auto load_w = [&](int g, int buf) __attribute__((always_inline)) {
+  auto load_w = [&](int g, int kc, int mc) __attribute__((always_inline)) {
     const int lane = opaque_tid() & 63;
     const int dma_r = (lane & 15) >> 2, dma_ii = lane & 3, dma_u = lane >> 4;
     const int dma_c = 2 * dma_u + (dma_ii & 1) + 8 * (dma_ii >> 1);
-    const char* wsrc = rel_at(g).weight + dma_r * 256 + dma_c * 16;
+    const char* wsrc = rel_at(g).weight + (size_t)(128 * kc + dma_r) * OB + mc * 256 + dma_c * 16;
 #pragma unroll
     for (int j = 0; j < 32 / NW; ++j) {
       const int kb = wave * (32 / NW) + j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 1024),
-                                       (LDSV*)(smem + buf * 32768 + kb * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
+                                       (LDSV*)(smem + kb * 1024), 16, 0, 0);
     }
   };
   // edges of the group's row among the 16 at `start`: lane c looks at edge start + c; the row's edges are a prefix
@@ -212,7 +217,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
   u32x4 xr[U];
   // the n <= 16 rows of one batch on their way (rows the batch does not have: zeros)
-  auto issue_rows = [&](const RelDev& rel, int n, RowT g2) __attribute__((always_inline)) {
+  auto issue_rows = [&](const RelDev& rel, int n, RowT g2, int kc) __attribute__((always_inline)) {
     if (CHECK && (g2 < 0 || g2 >= rel.x_rows)) {   // (what the map returned; lanes past n hold 0)
       *error = 1;
       g2 = 0;
@@ -226,14 +231,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         const uint32_t rl = (uint32_t)row_bcast<i>(lo), rh = (uint32_t)row_bcast<i>(hi);
         const int64_t row = (int64_t)(((uint64_t)rh << 32) | rl);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < n) v = *(GU32x4*)(rel.x + row * 256 + c * 16);
+        if (i < n) v = *(GU32x4*)(rel.x + row * RB + kc * 256 + c * 16);
         xr[i] = v;
       });
     } else {
-      const int rowb = (int)((uint32_t)g2 << 8);  // < 4 GB tables (checked on the host)
+      const int rowb = (int)((uint32_t)g2 * (uint32_t)RB);  // < 4 GB tables (checked on the host)
       static_for<0, U>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        const uint32_t off = (uint32_t)row_bcast<i>(rowb) + (uint32_t)(c * 16);
+        const uint32_t off = (uint32_t)row_bcast<i>(rowb) + (uint32_t)(kc * 256 + c * 16);
         u32x4 v = {0u, 0u, 0u, 0u};
         if (i < n) v = *(GU32x4*)(rel.x + off);
         xr[i] = v;
@@ -306,7 +311,10 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         uint32_t z0 = 0;
         asm volatile("" : "+v"(z0));   // (materialised here: hoisted, the four zero registers were spilled and reloaded)
         const u32x4 z = {z0, z0, z0, z0};
-        if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = z;
+        if (o < out_rows) {
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) *reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16) = z;
+        }
         it_c0 = R;
       }
     }
@@ -330,17 +338,20 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     if (o < out_rows && o >= rlo[rel] && o <= rhi[rel]) st = desc.rp[rp_off_at(rel) + (o - rel_at(rel).scatter_offset)];
   };
 
-  f32x16 acc;
+  f32x16 acc[MC];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mc][r] = 0.f;
   // A tile (rows = the block's 16 destinations) x W in LDS -> acc: wave t the 32 output columns of its n-tile
-  auto product = [&](f32x16& acc, int buf) __attribute__((always_inline)) {
+  auto product = [&](f32x16& acc, int kc) __attribute__((always_inline)) {
     if (NW > 4 && wave >= 4) return;
     const int lane = opaque_tid() & 63, xl = lane & 31, h = lane >> 5, q = lane & 15, grp16 = lane >> 4;
-    const char* wbb = smem + buf * 32768 + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+    const char* wbb = smem + 16384 * h + (4 * (q >> 2) + (grp16 & 1) + 2 * (q & 1)) * 16 + ((q & 3) >> 1) * 8;
+    const char* xk = xs + kc * 8192;
 #pragma unroll 2   // (not 8: the operands of all steps at once, next to the rows in flight, do not fit the register budget)
     for (int s = 0; s < 8; ++s) {
-      const u32x4 xa = *reinterpret_cast<const u32x4*>(xs + (xl * 16 + ((8 * h + s) ^ (xl & 15))) * 16);
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(xk + (xl * 16 + ((8 * h + s) ^ (xl & 15))) * 16);
       const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wbb + (2 * s) * 1024 + wave * 256));
       const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(wbb + (2 * s + 1) * 1024 + wave * 256));
       const u32x4 wa = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -348,32 +359,36 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     }
   };
   // the block's 16 x 128 results, rounded once, through the tile: wave t holds columns (8 h + 2 t + j) * 8 ... + 7 of row xl
-  auto store_block = [&](f32x16& acc, int blk) __attribute__((always_inline)) {
+  auto store_block = [&](f32x16 (&acc)[MC], int blk) __attribute__((always_inline)) {
     const int t = opaque_tid(), lane = t & 63, xl = lane & 31, h = lane >> 5, grp = t >> 4, c = t & 15;
-    if (NW == 4 || wave < 4) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      u32x4 pk;
+    for (int mc = 0; mc < MC; ++mc) {
+      if (NW == 4 || wave < 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[8 * j + 2 * i], acc[8 * j + 2 * i + 1]);
-      const int ch = 8 * h + 2 * wave + j;
-      *reinterpret_cast<u32x4*>(xs + (xl * 16 + (ch ^ (xl & 15))) * 16) = pk;
+        for (int j = 0; j < 2; ++j) {
+          u32x4 pk;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pk[i] = pack2<BF16>(acc[mc][8 * j + 2 * i], acc[mc][8 * j + 2 * i + 1]);
+          const int ch = 8 * h + 2 * wave + j;
+          *reinterpret_cast<u32x4*>(xs + (xl * 16 + (ch ^ (xl & 15))) * 16) = pk;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mc][r] = 0.f;
+      }
+      __syncthreads();
+      // (MC = 1: every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
+      const int64_t o = (int64_t)blk * ROWS + grp;
+      if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16) = v;
+      if (MC > 1) __syncthreads();   // (the next 128 columns go through the same tile)
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    }
-    __syncthreads();
-    // (every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
-    const int64_t o = (int64_t)blk * ROWS + grp;
-    if (o < out_rows) *reinterpret_cast<u32x4*>(out + o * 256 + c * 16) = v;
   };
-  auto a_tile_from_sums = [&]() __attribute__((always_inline)) {
+  auto a_tile_from_sums = [&](int kc) __attribute__((always_inline)) {
     const int t = opaque_tid(), grp = t >> 4, c = t & 15;
     u32x4 pk;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pk[k] = pack2<BF16>(sum[2 * k], sum[2 * k + 1]);
-    *reinterpret_cast<u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16) = pk;
+    *reinterpret_cast<u32x4*>(xs + kc * 8192 + (grp * 16 + (c ^ (grp & 15))) * 16) = pk;
   };
 
   if (long_rows) {
@@ -386,36 +401,48 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       if (cur >= 0 && blk != cur) store_block(acc, cur);
       cur = blk;
       const RelDev& r = rel_at(rel);
-      load_w(rel, 0);   // (the previous item's products are behind a barrier)
-      int sc = -1;
-      issue_start(blk, rel, sc);
+      load_w(rel, 0, 0);   // (the previous item's products are behind a barrier)
+      int st = -1;
+      issue_start(blk, rel, st);
       const int d = row_of(blk, rel);
+#pragma unroll 1
+      for (int kc = 0; kc < KC; ++kc) {   // one walk over the row's edges per 128-feature slice
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum[k] = 0.f;
-      bool more = sc >= 0;
-      do {
-        const bool onc = more && (int64_t)sc + c < r.num_edges;
-        int64_t s1c = -1, g1c = 0;
-        if (onc) {
-          s1c = ((GI64*)r.scatter_index)[sc + c];
-          g1c = ((GI64*)r.gather_index)[sc + c];
+        for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+        int sc = st;
+        bool more = sc >= 0;
+        do {
+          const bool onc = more && (int64_t)sc + c < r.num_edges;
+          int64_t s1c = -1, g1c = 0;
+          if (onc) {
+            s1c = ((GI64*)r.scatter_index)[sc + c];
+            g1c = ((GI64*)r.gather_index)[sc + c];
+          }
+          const int nc = prefix_count(onc && s1c == d);
+          const RowT g2c = feature_row(r, g1c, c < nc);
+          issue_rows(r, nc, g2c, kc);
+          add_rows();
+          more = more && nc == U;
+          sc += U;
+        } while (__any(more));
+        a_tile_from_sums(kc);
+      }
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) {
+#pragma unroll 1
+        for (int kc = 0; kc < KC; ++kc) {
+          if (kc + mc > 0) load_w(rel, kc, mc);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
+          __syncthreads();
+          product(acc[mc], kc);
+          __syncthreads();
         }
-        const int nc = prefix_count(onc && s1c == d);
-        const RowT g2c = feature_row(r, g1c, c < nc);
-        issue_rows(r, nc, g2c);
-        add_rows();
-        more = more && nc == U;
-        sc += U;
-      } while (__any(more));
-      a_tile_from_sums();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
-      __syncthreads();
-      product(acc, 0);
-      __syncthreads();
+      }
     }
     if (cur >= 0) store_block(acc, cur);
     return;
   }
+  if constexpr (KC * MC == 1) {
   bool primed = false;  // (the first iteration only fetches: one call site for the item walk, so that it is inlined and its
                         // state stays in scalar registers -- as a called function it lived in scratch, and every relation
                         // record was fetched with vector loads the row gathers had to wait behind)
@@ -431,13 +458,13 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll
       for (int k = 0; k < 8; ++k) sum[k] = 0.f;
       add_rows();
-      a_tile_from_sums();   // (the previous item's products are behind a barrier)
+      a_tile_from_sums(0);   // (the previous item's products are behind a barrier)
     }
     // ---- item i + 2: its indices have landed -> the row's edge count ----------------------------------------------------
     const int n2 = prefix_count(v2 && st2 >= 0 && s1_2 == row_of(blk2, rel2));
     // ---- issue: nothing requested below is touched before the next iteration's top ----------------------------------------
     if (v1) {
-      issue_rows(rel_at(rel1), n1, g2_1);
+      issue_rows(rel_at(rel1), n1, g2_1, 0);
     }
     RowT g2n = 0;
     if (v2) g2n = feature_row(rel_at(rel2), g1_2, c < n2);
@@ -458,13 +485,13 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     rel4 = __builtin_amdgcn_readfirstlane(rel4);
     if (v4) issue_start(blk4, rel4, st4);
     // ---- item i: A tile, product; the block's rows when this was its last item -------------------------------------------
-    if (!v0 && v1) load_w(rel1, 0);   // (the pipeline is filling: nobody reads W)
+    if (!v0 && v1) load_w(rel1, 0, 0);   // (the pipeline is filling: nobody reads W)
     if (v0) {
       const bool last = !v1 || blk1 != blk0;   // of its block
       __syncthreads();
-      product(acc, 0);
+      product(acc[0], 0);
       __syncthreads();  // the A tile and W are free again
-      if (v1) load_w(rel1, 0);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
+      if (v1) load_w(rel1, 0, 0);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
       if (last) store_block(acc, blk0);
     }
     // ---- rotate --------------------------------------------------------------------------------------------------------
@@ -473,13 +500,21 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     v2 = v3, blk2 = blk3, rel2 = rel3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
     v3 = v4, blk3 = blk4, rel3 = rel4, st3 = st4;
   }
+  }  // KC = MC = 1
 }
 
 template <bool BF16, bool CHECK, bool BIG, bool INL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                               int64_t out_rows, int* __restrict__ error) {
-  rgcn_grouped_body<BF16, CHECK, BIG, INL, 4>(desc, R, out, out_rows, error);
+  rgcn_grouped_body<BF16, CHECK, BIG, INL, 4, 1, 1>(desc, R, out, out_rows, error);
 }
+// K = 128 KC, M = 128 MC (indices always validated: one instantiation less per shape)
+template <bool BF16, bool BIG, bool INL, int KC, int MC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_shape_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+                                                                                                    int64_t out_rows, int* __restrict__ error) {
+  rgcn_grouped_body<BF16, true, BIG, INL, 4, KC, MC>(desc, R, out, out_rows, error);
+}
+
 size_t grouped_workspace_bytes(const pyg_hip_rgcn_relation* rels, int64_t R, int64_t out_rows) {
   size_t rp = 0;
   for (int64_t r = 0; r < R; ++r) {

@@ -96,9 +96,11 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
 
 
-def _fusable(x: Tensor, weight: Tensor) -> bool:
-    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 2 and x.size(1) == 128 and
-            weight.dim() == 3 and weight.size(1) == 128 and weight.size(2) == 128 and weight.dtype == x.dtype and
+def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
+    # the atomic kernel: F_in = F_out = 128; the grouped (atomic-free) kernel: each of them 128 or 256
+    sizes = (128, 256) if grouped else (128,)
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 2 and x.size(1) in sizes and
+            weight.dim() == 3 and weight.size(1) == x.size(1) and weight.size(2) in sizes and weight.dtype == x.dtype and
             weight.device == x.device)
 
 
@@ -122,7 +124,7 @@ def _dx_scatter(grad_out: Tensor, weight: Tensor, gather: List[Tensor], scatter:
     forward is the scatter index here, and it is not grouped -- or, under ``torch.use_deterministic_algorithms(True)``,
     the atomic-free chain gather -> segment_matmul -> scatter_sum (stable sort + CSR rows)."""
     wt = weight.transpose(1, 2).contiguous()
-    if torch.are_deterministic_algorithms_enabled():
+    if torch.are_deterministic_algorithms_enabled() or weight.size(1) != 128 or weight.size(2) != 128:   # (the atomic kernel: 128 x 128)
         ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
         if gidx.numel() == 0:
             return grad_out.new_zeros(rows, weight.size(1))
@@ -231,8 +233,8 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     r"""Same result as :func:`rgcn_layer` from ONE launch (``pyg::rgcn_fused``, csrc/hip/rgcn.hip): source rows are
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
-    index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128``; anything else
-    takes the three-op chain.
+    index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128`` (``grouped=True``:
+    each of them 128 or 256); anything else takes the three-op chain.
 
     Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
     backward runs the same kernel with swapped roles for dX and the weight-gradient kernel on the gathered rows for dW
@@ -252,7 +254,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     total = offsets['__total__']
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
-    if not _fusable(x, weight) or (torch.are_deterministic_algorithms_enabled() and not grouped):
+    if not _fusable(x, weight, grouped) or (torch.are_deterministic_algorithms_enabled() and not grouped):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
     gather, scatter, goff, soff = [], [], [], []
     for et in edge_types:
@@ -290,8 +292,8 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     needs_grad = torch.is_grad_enabled() and (weight.requires_grad or any(f.requires_grad for f in feats))
     # every table and the weight: one device, one 16-bit type, F = 128 (anything else: the chain, which checks nothing
     # more than its own ops do)
-    ok = _fusable(f0, weight) and all(f.dim() == 2 and f.size(1) == 128 and f.dtype == f0.dtype and f.device == f0.device
-                                      for f in feats) and \
+    ok = _fusable(f0, weight, grouped) and all(f.dim() == 2 and f.size(1) == f0.size(1) and f.dtype == f0.dtype and
+                                               f.device == f0.device for f in feats) and \
         all(n.device == f0.device and n.dtype == torch.long and n.dim() == 1 for n in nids)
     if not ok or (torch.are_deterministic_algorithms_enabled() and not grouped):   # (deterministic mode: see rgcn_layer_fused)
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])

@@ -157,6 +157,78 @@ def test_grouped_on_a_sampled_mag_neighbourhood(dtype):
         assert torch.equal(rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True), y)
 
 
+def column_selectors(R, K, M, g):
+    # one +-1 per column: out[:, n] = +- x[:, k(n)], exact whatever the sizes
+    W = torch.zeros(R, K, M)
+    k = torch.randint(0, K, (R, M), generator=g)
+    W[torch.arange(R)[:, None], k, torch.arange(M)[None, :]] = (torch.randint(0, 2, (R, M), generator=g) * 2 - 1).float()
+    return W
+
+
+@pytest.mark.parametrize('K,M', [(256, 256), (128, 256), (256, 128)])
+def test_grouped_feature_widths_of_256(K, M):
+    """K and M of the atomic-free kernel may each be 128 or 256 (C4's width): the feature rows are walked once per
+    128-feature slice, W travels through LDS in 128 x 128 chunks.  Exact on integer data (rows of 0 ... 70 edges, several
+    node types, through x and through the global tables), a float64 restatement on random data, autograd (the backward
+    takes the chain for these shapes), and the ungrouped call still falls back to the three-op chain."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(77 + K + 2 * M)
+    types = ['a', 'b']
+    n = {'a': 333, 'b': 90}
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b'), ('b', 'r3', 'b')]
+    counts = [3000, 40, 4096 + 33, 0]
+    x = {t: torch.randint(-1, 2, (n[t], K), generator=g).float() for t in types}
+    W = column_selectors(len(ets), K, M, g)
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        s, _, d = et
+        rows[et] = torch.sort(torch.randint(0, min(60, n[s]), (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n[d], (c,), generator=g).cuda()
+    off = rgcn.type_offsets(n, types)
+    xc = torch.cat([x[t] for t in types])
+    soff = [off[s] for s, _, _ in ets]
+    goff = [off[d] for _, _, d in ets]
+    want = exact_want(off['__total__'], M, ets, rows, cols, xc, W, soff, goff)
+    assert want.abs().max() <= 256
+    for dtype in (torch.bfloat16, torch.float16):
+        y = rgcn.rgcn_layer_fused(xc.to(dtype).cuda(), off, rows, cols, ets, W.to(dtype).cuda(), grouped=True)
+        assert y.shape == (off['__total__'], M) and y.dtype == dtype
+        assert torch.equal(y.double().cpu(), want)
+    n_glob = {'a': 4000, 'b': 700}
+    nid = {t: torch.randperm(n_glob[t], generator=g)[:n[t]] for t in types}
+    tab = {t: torch.randint(-3, 4, (n_glob[t], K), generator=g).float() for t in types}
+    for t in types:
+        tab[t][nid[t]] = x[t]
+    yt = rgcn.rgcn_layer_fused_tables({t: tab[t].bfloat16().cuda() for t in types}, {t: nid[t].cuda() for t in types}, types,
+                                      rows, cols, ets, W.bfloat16().cuda(), grouped=True)
+    assert torch.equal(yt.double().cpu(), want)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    # random data: one rounding of every per-relation feature sum, one of the result
+    xr = torch.randn(off['__total__'], K, generator=g).bfloat16().cuda()
+    wr = (torch.randn(len(ets), K, M, generator=g) / K ** 0.5).bfloat16().cuda()
+    yr = rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True)
+    ref = torch.zeros(off['__total__'], M, dtype=torch.float64, device='cuda')
+    for i, et in enumerate(ets):
+        agg = torch.zeros(off['__total__'], K, dtype=torch.float64, device='cuda')
+        agg.index_add_(0, rows[et] + soff[i], xr[cols[et] + goff[i]].double())
+        ref += agg.bfloat16().double() @ wr[i].double()
+    scale = ref.abs().max().item()
+    assert scale > 1.0 and (yr.double() - ref).abs().max().item() <= 8e-3 * scale
+    assert torch.equal(yr, rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True))
+    y3 = rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr)          # not grouped: the three-op chain for these widths
+    assert (yr.double() - y3.double()).abs().max().item() <= 3e-2 * scale
+    # autograd
+    xg = xr.clone().requires_grad_()
+    wg = wr.clone().requires_grad_()
+    rgcn.rgcn_layer_fused(xg, off, rows, cols, ets, wg, grouped=True).float().square().sum().backward()
+    xg3 = xr.clone().requires_grad_()
+    wg3 = wr.clone().requires_grad_()
+    rgcn.rgcn_layer(xg3, off, rows, cols, ets, wg3).float().square().sum().backward()
+    for a, b in ((xg.grad, xg3.grad), (wg.grad, wg3.grad)):
+        assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() <= 6e-2 * b.float().abs().max().item()
+
+
 def test_grouped_promise_is_verified_on_the_device():
     """Not grouped -> error 3: reported without a synchronisation by default (pending_index_error / the next call), in
     the call itself with PYG_HIP_RGCN_CHECKED; an out-of-range scatter index is 2, a gather index 1; nothing is read or

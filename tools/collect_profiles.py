@@ -37,6 +37,9 @@ cp('bench_2rank_debug.json', 'bench_2rank_debug_one_device.json')
 cp('sampler_batched.txt', 'sampler_batched.txt')
 cp('sampler_batched_overlap.txt', 'sampler_batched_overlap.txt')
 cp('clock_probe.txt', 'clock_probe.txt')
+cp('c5_layer_probe.txt', 'c5_layer_probe.txt')
+cp('prof_layer/layer_kernel_stats.csv', 'c5_layer_kernel_stats.csv')
+cp('rocm_smi.txt', 'rocm_smi.txt')
 
 
 def rows(d):

@@ -1,5 +1,5 @@
 """C5 layer alone, both kernels (atomic adds into a zero-filled output / atomic-free grouped), for rocprofv3:
-python tools/rgcn_grouped_probe.py [iters]"""
+python tools/rgcn_grouped_probe.py [iters] [fan-out, e.g. 25,10]"""
 import sys
 import time
 
@@ -9,6 +9,7 @@ import bench_legs
 from pyg_lib_amd import sampler, rgcn
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+fan = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [15, 10]
 dev = torch.device('cuda:0')
 types = list(bench_legs.MAG_SIZES)
 ets = [(s, r, d) for s, r, d, _ in bench_legs.MAG_RELS]
@@ -18,7 +19,8 @@ feat = {t: torch.randn(bench_legs.MAG_SIZES[t], F, device=dev).bfloat16() for t 
 W = (torch.randn(len(ets), F, F, device=dev) / F ** 0.5).bfloat16()
 seeds = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=torch.Generator().manual_seed(1))[:1024].to(dev)
 torch.manual_seed(100)
-out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds}, {e: [15, 10] for e in ets})
+out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds}, {e: fan for e in ets})
+print('fan-out', fan, 'edges', sum(v.numel() for v in out[0].values()), 'nodes', sum(v.numel() for v in out[2].values()))
 for grouped in (False, True):
     f = lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=grouped)
     for _ in range(3):
