@@ -351,6 +351,14 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     total_b_ms = (time.perf_counter() - t0) / (reps * K) * 1e3
     out = state['last']
     layer_ms = _event_ms(lambda: layer(out), iters)
+    # C4's width on the same sample (informational; the atomic-free kernel takes K, M in {128, 256}, the atomic one 128 only):
+    # against the three-op chain gather -> segment_matmul -> scatter_sum, which is what this width took before round 5
+    F2 = 256
+    feat2 = {t: torch.randn(MAG_SIZES[t], F2, device=device).to(dtype) for t in types}
+    W2 = (torch.randn(len(ets), F2, F2, device=device) / F2 ** 0.5).to(dtype)
+    f256_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2, grouped=True), iters)
+    f256_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2), max(2, iters // 3))
+    del feat2
     grouped_was = grouped
     grouped = not grouped_was
     other_ms = _event_ms(lambda: layer(out), iters)   # the other kernel (atomic adds into a zero-filled output / atomic-free)
@@ -369,7 +377,10 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
                 batched=dict(K=K, ms_sampler_per_batch=round(samp_b_ms, 4), ms_end_to_end_per_batch=round(total_b_ms, 4),
                              what='hetero_neighbor_sample_batched (K batches per call) + one fused layer per batch'),
-                layer=_rate(alg, layer_ms))
+                layer=_rate(alg, layer_ms),
+                layer_f256=dict(_rate(e * (F2 * esz + 16) + n * F2 * esz + len(ets) * F2 * F2 * esz, f256_ms),
+                                what='the same sample with F = 256 (rgcn_layer_fused_tables, grouped=True)',
+                                three_op_chain_ms=round(f256_chain_ms, 4)))
 
 
 # ---------------------------------------------------------------------------------------------------
