@@ -359,6 +359,12 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     f256_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2, grouped=True), iters)
     f256_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2), max(2, iters // 3))
     del feat2
+    # ... and float32 at F = 128 (plain FMAs in fp32 after the aggregation; the reference's 1e-5 configuration)
+    feat4 = {t: torch.randn(MAG_SIZES[t], F, device=device) for t in types}
+    W4 = torch.randn(len(ets), F, F, device=device) / F ** 0.5
+    f32_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=True), iters)
+    f32_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4), max(2, iters // 3))
+    del feat4
     grouped_was = grouped
     grouped = not grouped_was
     other_ms = _event_ms(lambda: layer(out), iters)   # the other kernel (atomic adds into a zero-filled output / atomic-free)
@@ -380,7 +386,10 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
                 layer=_rate(alg, layer_ms),
                 layer_f256=dict(_rate(e * (F2 * esz + 16) + n * F2 * esz + len(ets) * F2 * F2 * esz, f256_ms),
                                 what='the same sample with F = 256 (rgcn_layer_fused_tables, grouped=True)',
-                                three_op_chain_ms=round(f256_chain_ms, 4)))
+                                three_op_chain_ms=round(f256_chain_ms, 4)),
+                layer_f32=dict(_rate(e * (F * 4 + 16) + n * F * 4 + len(ets) * F * F * 4, f32_ms),
+                               what='the same sample in float32, F = 128 (rgcn_layer_fused_tables, grouped=True)',
+                               three_op_chain_ms=round(f32_chain_ms, 4)))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -470,7 +470,8 @@ const char* rgcn_error_text(int code) {
 int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_hip_rgcn_relation* rels, int64_t R, void* out,
                         int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace, size_t workspace_bytes,
                         hipStream_t stream) {
-  const int KC = (int)(K / 128), MC = (int)(M / 128);
+  const size_t esz = dtype == PYG_F32 ? 4 : 2;
+  const int KC = (int)(K * esz / 256), MC = (int)(M * esz / 256);   // 256-byte slices of a feature row / of a row of `out`
   if (num_out_rows == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "rgcn_fused: 'out' must be 16-byte aligned in grouped mode");
@@ -490,7 +491,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     E += rels[r].num_edges;
   }
   if (E == 0) {  // nothing arrives anywhere
-    PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * 2, stream));
+    PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * esz, stream));
     return PYG_HIP_OK;
   }
   const size_t need = grouped_workspace_bytes(rels, R, num_out_rows);
@@ -529,7 +530,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     hr[r].gather_map = rels[r].gather_map;
     hr[r].x_rows = rels[r].x ? rels[r].x_rows : num_x_rows;
     hr[r].map_len = rels[r].gather_map_len;
-    big = big || hr[r].x_rows * (K * 2) >= (1LL << 32);
+    big = big || hr[r].x_rows * (int64_t)(K * esz) >= (1LL << 32);
     hp[r] = e;
     e += rels[r].num_edges;
     const int64_t span = rels[r].num_edges > 0 ? num_out_rows - rels[r].scatter_offset : 0;
@@ -590,7 +591,10 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
              : (inl ? (const void*)&rgcn_grouped_shape_kernel<true, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<true, false, false, KC_, MC_>)) \
       : (big ? (inl ? (const void*)&rgcn_grouped_shape_kernel<false, true, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, true, false, KC_, MC_>)  \
              : (inl ? (const void*)&rgcn_grouped_shape_kernel<false, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, false, false, KC_, MC_>)))
-    if (KC == 2 && MC == 2) kern = PYG_RGCN_SPICK(2, 2);
+    if (dtype == PYG_F32)
+      kern = big ? (inl ? (const void*)&rgcn_grouped_f32_kernel<true, true> : (const void*)&rgcn_grouped_f32_kernel<true, false>)
+                 : (inl ? (const void*)&rgcn_grouped_f32_kernel<false, true> : (const void*)&rgcn_grouped_f32_kernel<false, false>);
+    else if (KC == 2 && MC == 2) kern = PYG_RGCN_SPICK(2, 2);
     else if (KC == 1 && MC == 2) kern = PYG_RGCN_SPICK(1, 2);
     else if (KC == 2 && MC == 1) kern = PYG_RGCN_SPICK(2, 1);
 #undef PYG_RGCN_SPICK
@@ -654,15 +658,19 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
                        void* out, int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace,
                        size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16, "rgcn_fused: bfloat16 / float16 only");
   const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
-  if (grouped ? !((K == 128 || K == 256) && (M == 128 || M == 256)) : (K != 128 || M != 128))
-    return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M in {128, 256}); got %lld x %lld",
+  PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16 || (grouped && dtype == PYG_F32),
+                  "rgcn_fused: bfloat16 / float16 only (PYG_HIP_RGCN_GROUPED: float32 too)");
+  if (dtype == PYG_F32 ? (K != 128 || M != 128)
+                       : (grouped ? !((K == 128 || K == 256) && (M == 128 || M == 256)) : (K != 128 || M != 128)))
+    return fail(PYG_HIP_ERR_UNSUPPORTED,
+                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M in {128, 256} for the 16-bit types); got %lld x %lld",
                 (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");
   if (R == 0) {
-    if (grouped && out && num_out_rows > 0) PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * 2, stream));
+    if (grouped && out && num_out_rows > 0)
+      PYG_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)num_out_rows * (size_t)M * (dtype == PYG_F32 ? 4 : 2), stream));
     return PYG_HIP_OK;
   }
   PYG_HIP_REQUIRE(rels != nullptr, "rgcn_fused: 'relations' is NULL");

@@ -35,6 +35,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// (by value: __builtin_bit_cast applied to an ELEMENT of an ext_vector -- `bit_cast(float, v[k])` -- returned element 0
+// for every k)
+__device__ __forceinline__ float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ uint32_t f2u(float v) { return __builtin_bit_cast(uint32_t, v); }
+
 struct GroupedDesc {
   const RelDev* rels;        // R > kRgcnInline: the records and the three vectors below live in the workspace
   const int64_t* eprefix;    // [R + 1] running edge count
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
 // and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave 0 - 3, barrier, the block's stores when its
 // last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on the C5
 // batch where the atomic kernel + its zero fill take 66.)
-template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC>
+template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC, bool F32 = false>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
   constexpr int U = 16;   // edges of a row per batch (one per lane of the group)
@@ -122,6 +127,13 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // 128-feature slice (the indices come from L2 the second time), W travels through LDS in 128 x 128 chunks.  The pipeline
   // exists for KC = MC = 1; the other shapes take the item-at-a-time walk (2 % slower on the C5 batch where both run).
   constexpr int RB = 256 * KC, OB = 256 * MC;   // bytes of a feature row / of a row of `out`
+  // F32: K = M = 128 floats, i.e. KC = MC = 2 in BYTES (rows of 512 bytes, walked in two 256-byte slices like K = 256 of the
+  // 16-bit types); sums, the A tile and the product stay fp32 -- plain FMAs, IEEE like the reference's fp32 (no MFMA: after
+  // the aggregation the product is 16 x 128 x 128 per item, ~4 us of a CU's FMA and LDS time next to ~25 us of gathers) --
+  // and every thread stores its own 8 results (no pass through the tile).
+  static_assert(!F32 || (KC == 2 && MC == 2), "fp32: K = M = 128");
+  constexpr int kARow = 528;   // F32: bytes between the rows of the fp32 A tile (512 + 16: the four rows a wave reads fall
+                               // into different banks)
   // Rows of more than 16 edges (fan-outs above 16, full neighbourhoods) need further batches.  That loop inside the pipeline
   // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
   // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
@@ -249,12 +261,17 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   auto add_rows = [&]() __attribute__((always_inline)) {  // in edge order
 #pragma unroll
     for (int i = 0; i < U; ++i) {
+      if constexpr (F32) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float a, b;
-        unpack2<BF16>(xr[i][k], &a, &b);
-        sum[2 * k] += a;
-        sum[2 * k + 1] += b;
+        for (int k = 0; k < 4; ++k) sum[k] += u2f(xr[i][k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float a, b;
+          unpack2<BF16>(xr[i][k], &a, &b);
+          sum[2 * k] += a;
+          sum[2 * k + 1] += b;
+        }
       }
     }
   };
@@ -386,9 +403,58 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   auto a_tile_from_sums = [&](int kc) __attribute__((always_inline)) {
     const int t = opaque_tid(), grp = t >> 4, c = t & 15;
     u32x4 pk;
+    if constexpr (F32) {   // 64 floats of row grp: slice kc, lane c's four
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pk[k] = pack2<BF16>(sum[2 * k], sum[2 * k + 1]);
-    *reinterpret_cast<u32x4*>(xs + kc * 8192 + (grp * 16 + (c ^ (grp & 15))) * 16) = pk;
+      for (int k = 0; k < 4; ++k) pk[k] = f2u(sum[k]);
+      *reinterpret_cast<u32x4*>(xs + grp * kARow + kc * 256 + c * 16) = pk;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pk[k] = pack2<BF16>(sum[2 * k], sum[2 * k + 1]);
+      *reinterpret_cast<u32x4*>(xs + kc * 8192 + (grp * 16 + (c ^ (grp & 15))) * 16) = pk;
+    }
+  };
+  // F32: W[32 q ... 32 q + 31][0 ... 127] (16 KB, contiguous in memory) into buffer q & 1, as it lies: four DMA instructions
+  // per wave
+  auto load_w32 = [&](int g, int q) __attribute__((always_inline)) {
+    const int lane = opaque_tid() & 63;
+    const char* wsrc = rel_at(g).weight + q * 16384 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int blk1k = wave * 4 + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + blk1k * 1024),
+                                       (LDSV*)(smem + (q & 1) * 16384 + blk1k * 1024), 16, 0, 0);
+    }
+  };
+  float acc8[8];   // F32: row tid / 16, columns 8 (tid % 16) ... + 7 of the block's results
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc8[k] = 0.f;
+  auto product32 = [&](int q) __attribute__((always_inline)) {
+    const int t = opaque_tid(), r = t >> 4, cg = t & 15;
+    const char* a = xs + r * kARow + q * 128;
+    const char* w = smem + (q & 1) * 16384 + cg * 32;
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float av = *reinterpret_cast<const float*>(a + kk * 4);
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(w + kk * 512), w1 = *reinterpret_cast<const u32x4*>(w + kk * 512 + 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc8[k] = __builtin_fmaf(av, u2f(w0[k]), acc8[k]);
+        acc8[4 + k] = __builtin_fmaf(av, u2f(w1[k]), acc8[4 + k]);
+      }
+    }
+  };
+  auto store_block32 = [&](int blk) __attribute__((always_inline)) {
+    const int t = opaque_tid(), r = t >> 4, cg = t & 15;
+    const int64_t o = (int64_t)blk * ROWS + r;
+    u32x4 v0, v1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v0[k] = f2u(acc8[k]), v1[k] = f2u(acc8[4 + k]);
+    if (o < out_rows) {
+      *reinterpret_cast<u32x4*>(out + o * OB + cg * 32) = v0;
+      *reinterpret_cast<u32x4*>(out + o * OB + cg * 32 + 16) = v1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc8[k] = 0.f;
   };
 
   if (long_rows) {
@@ -398,10 +464,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     while (next_item(blk, rel)) {
       blk = __builtin_amdgcn_readfirstlane(blk);
       rel = __builtin_amdgcn_readfirstlane(rel);
-      if (cur >= 0 && blk != cur) store_block(acc, cur);
+      if (cur >= 0 && blk != cur) {
+        if constexpr (F32) store_block32(cur);
+        else store_block(acc, cur);
+      }
       cur = blk;
       const RelDev& r = rel_at(rel);
-      load_w(rel, 0, 0);   // (the previous item's products are behind a barrier)
+      if constexpr (F32) load_w32(rel, 0);   // (buffer 0 was last read two barriers ago)
+      else load_w(rel, 0, 0);   // (the previous item's products are behind a barrier)
       int st = -1;
       issue_start(blk, rel, st);
       const int d = row_of(blk, rel);
@@ -427,19 +497,34 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         } while (__any(more));
         a_tile_from_sums(kc);
       }
-#pragma unroll
-      for (int mc = 0; mc < MC; ++mc) {
+      if constexpr (F32) {
+        // W in four pieces of 32 k-rows through two buffers: piece q + 1 travels while piece q is multiplied.  (A thread
+        // reads the A rows its own wave wrote; the barrier is for W.)
 #pragma unroll 1
-        for (int kc = 0; kc < KC; ++kc) {
-          if (kc + mc > 0) load_w(rel, kc, mc);
+        for (int q = 0; q < 4; ++q) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
-          __syncthreads();
-          product(acc[mc], kc);
-          __syncthreads();
+          __syncthreads();   // piece q is there for everybody; everybody is done with piece q - 1
+          if (q < 3) load_w32(rel, q + 1);
+          product32(q);
+        }
+      } else {
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) {
+#pragma unroll 1
+          for (int kc = 0; kc < KC; ++kc) {
+            if (kc + mc > 0) load_w(rel, kc, mc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
+            __syncthreads();
+            product(acc[mc], kc);
+            __syncthreads();
+          }
         }
       }
     }
-    if (cur >= 0) store_block(acc, cur);
+    if (cur >= 0) {
+      if constexpr (F32) store_block32(cur);
+      else store_block(acc, cur);
+    }
     return;
   }
   if constexpr (KC * MC == 1) {
@@ -513,6 +598,13 @@ template <bool BF16, bool BIG, bool INL, int KC, int MC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_shape_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                                     int64_t out_rows, int* __restrict__ error) {
   rgcn_grouped_body<BF16, true, BIG, INL, 4, KC, MC>(desc, R, out, out_rows, error);
+}
+
+// fp32, K = M = 128
+template <bool BIG, bool INL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_f32_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+                                                                                                  int64_t out_rows, int* __restrict__ error) {
+  rgcn_grouped_body<false, true, BIG, INL, 4, 2, 2, true>(desc, R, out, out_rows, error);
 }
 
 size_t grouped_workspace_bytes(const pyg_hip_rgcn_relation* rels, int64_t R, int64_t out_rows) {

@@ -97,9 +97,14 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
 
 
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
-    # the atomic kernel: F_in = F_out = 128; the grouped (atomic-free) kernel: each of them 128 or 256
-    sizes = (128, 256) if grouped else (128,)
-    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 2 and x.size(1) in sizes and
+    # the atomic kernel: 16-bit, F_in = F_out = 128; the grouped (atomic-free) kernel: each of them 128 or 256, or float32
+    # with F_in = F_out = 128
+    if grouped and x.dtype == torch.float32:
+        sizes = (128,)
+    else:
+        sizes = (128, 256) if grouped else (128,)
+    dtypes = (torch.bfloat16, torch.float16, torch.float32) if grouped else (torch.bfloat16, torch.float16)
+    return (x.is_cuda and x.dtype in dtypes and x.dim() == 2 and x.size(1) in sizes and
             weight.dim() == 3 and weight.size(1) == x.size(1) and weight.size(2) in sizes and weight.dtype == x.dtype and
             weight.device == x.device)
 
@@ -124,7 +129,8 @@ def _dx_scatter(grad_out: Tensor, weight: Tensor, gather: List[Tensor], scatter:
     forward is the scatter index here, and it is not grouped -- or, under ``torch.use_deterministic_algorithms(True)``,
     the atomic-free chain gather -> segment_matmul -> scatter_sum (stable sort + CSR rows)."""
     wt = weight.transpose(1, 2).contiguous()
-    if torch.are_deterministic_algorithms_enabled() or weight.size(1) != 128 or weight.size(2) != 128:   # (the atomic kernel: 128 x 128)
+    if torch.are_deterministic_algorithms_enabled() or weight.size(1) != 128 or weight.size(2) != 128 or \
+            weight.dtype == torch.float32:   # (the atomic kernel: 16-bit, 128 x 128)
         ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
         if gidx.numel() == 0:
             return grad_out.new_zeros(rows, weight.size(1))
@@ -234,7 +240,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
     index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128`` (``grouped=True``:
-    each of them 128 or 256); anything else takes the three-op chain.
+    each of them 128 or 256, or float32 with 128 / 128); anything else takes the three-op chain.
 
     Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
     backward runs the same kernel with swapped roles for dX and the weight-gradient kernel on the gathered rows for dW

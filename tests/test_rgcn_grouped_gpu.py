@@ -229,6 +229,63 @@ def test_grouped_feature_widths_of_256(K, M):
         assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() <= 6e-2 * b.float().abs().max().item()
 
 
+def test_grouped_float32():
+    """float32, F = 128: sums, A tile and product in fp32 (plain FMAs, IEEE like the reference's fp32) -- 1e-5 of the
+    scale against a float64 restatement (the tolerance of the reference's own fp32 tests), exact on integer data, rows of
+    0 ... 70 edges, several node types, x and tables, the same bits on every run, autograd against the chain."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(404)
+    F = 128
+    types = ['a', 'b', 'c']
+    n = {'a': 301, 'b': 77, 'c': 1000}
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b'), ('c', 'r3', 'c'), ('c', 'r4', 'a'), ('a', 'r5', 'c'), ('b', 'r6', 'b')]
+    counts = [1000, 0, 17, 4096 + 33, 300, 1, 129]
+    rows, cols = {}, {}
+    for et, c in zip(ets, counts):
+        s, _, d = et
+        rows[et] = torch.sort(torch.randint(0, min(60, n[s]), (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n[d], (c,), generator=g).cuda()
+    off = rgcn.type_offsets(n, types)
+    soff = [off[s] for s, _, _ in ets]
+    goff = [off[d] for _, _, d in ets]
+    # integer data: exact
+    xi = torch.randint(-3, 4, (off['__total__'], F), generator=g).float()
+    Wi = signed_permutations(len(ets), F, g)
+    want = exact_want(off['__total__'], F, ets, rows, cols, xi, Wi, soff, goff)
+    y = rgcn.rgcn_layer_fused(xi.cuda(), off, rows, cols, ets, Wi.cuda(), grouped=True)
+    assert y.dtype == torch.float32 and torch.equal(y.double().cpu(), want)
+    # random data: 1e-5 of the scale
+    x = torch.randn(off['__total__'], F, generator=g).cuda()
+    W = (torch.randn(len(ets), F, F, generator=g) / F ** 0.5).cuda()
+    y = rgcn.rgcn_layer_fused(x, off, rows, cols, ets, W, grouped=True)
+    ref = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
+    for i, et in enumerate(ets):
+        ref.index_add_(0, rows[et] + soff[i], x[cols[et] + goff[i]].double() @ W[i].double())
+    scale = ref.abs().max().item()
+    assert scale > 1.0 and (y.double() - ref).abs().max().item() <= 1e-5 * scale
+    assert torch.equal(y, rgcn.rgcn_layer_fused(x, off, rows, cols, ets, W, grouped=True))
+    y3 = rgcn.rgcn_layer_fused(x, off, rows, cols, ets, W)          # not grouped: the three-op chain for this type
+    assert (y3.double() - ref).abs().max().item() <= 1e-5 * scale
+    # through the global tables
+    n_glob = {'a': 5000, 'b': 900, 'c': 20000}
+    nid = {t: torch.randperm(n_glob[t], generator=g)[:n[t]].cuda() for t in types}
+    tab = {t: torch.randn(n_glob[t], F, generator=g).cuda() for t in types}
+    xt = torch.cat([tab[t][nid[t]] for t in types])
+    yt = rgcn.rgcn_layer_fused_tables(tab, nid, types, rows, cols, ets, W, grouped=True)
+    assert torch.equal(yt, rgcn.rgcn_layer_fused(xt, off, rows, cols, ets, W, grouped=True))
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    # autograd
+    xg = x.clone().requires_grad_()
+    wg = W.clone().requires_grad_()
+    rgcn.rgcn_layer_fused(xg, off, rows, cols, ets, wg, grouped=True).square().sum().backward()
+    xg3 = x.clone().requires_grad_()
+    wg3 = W.clone().requires_grad_()
+    rgcn.rgcn_layer(xg3, off, rows, cols, ets, wg3).square().sum().backward()
+    for a, b in ((xg.grad, xg3.grad), (wg.grad, wg3.grad)):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+
+
 def test_grouped_promise_is_verified_on_the_device():
     """Not grouped -> error 3: reported without a synchronisation by default (pending_index_error / the next call), in
     the call itself with PYG_HIP_RGCN_CHECKED; an out-of-range scatter index is 2, a gather index 1; nothing is read or
