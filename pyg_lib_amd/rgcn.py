@@ -96,6 +96,9 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
 
 
+_GROUPED_MAX_RELATIONS = 512   # kGroupedMaxRel of csrc/hip/rgcn_grouped.h: the relations' row ranges live in LDS
+
+
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
     # the atomic kernel: 16-bit, F_in = F_out = 128; the grouped (atomic-free) kernel: each of them 128 or 256, or float32
     # with F_in = F_out = 128
@@ -258,6 +261,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     path under ``torch.use_deterministic_algorithms(True)``), feature sums and results rounded once each.  The promise is
     verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``)."""
     total = offsets['__total__']
+    grouped = grouped and len(edge_types) <= _GROUPED_MAX_RELATIONS
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
     if not _fusable(x, weight, grouped) or (torch.are_deterministic_algorithms_enabled() and not grouped):
@@ -292,6 +296,7 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     feature table that requires a gradient (:class:`_RGCNFusedTables`).  ``grouped=True``: the atomic-free kernel, see
     :func:`rgcn_layer_fused`."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
+    grouped = grouped and len(edge_types) <= _GROUPED_MAX_RELATIONS
     f0 = feat_dict[node_types[0]]
     feats = [feat_dict[t] for t in node_types]
     nids = [node_id_dict[t] for t in node_types]

@@ -20,6 +20,14 @@ def signed_permutations(R, F, g):
     return W
 
 
+def column_selectors(R, K, M, g):
+    # one +-1 per column: out[:, n] = +- x[:, k(n)], exact whatever the sizes
+    W = torch.zeros(R, K, M)
+    k = torch.randint(0, K, (R, M), generator=g)
+    W[torch.arange(R)[:, None], k, torch.arange(M)[None, :]] = (torch.randint(0, 2, (R, M), generator=g) * 2 - 1).float()
+    return W
+
+
 def exact_want(n_out, F, ets, rows, cols, x, W, soff, goff):
     want = torch.zeros(n_out, F, dtype=torch.float64)
     for i, et in enumerate(ets):
@@ -93,6 +101,73 @@ def test_grouped_more_relations_than_the_kernel_argument_holds():
     assert torch.equal(y.double().cpu(), want)
 
 
+@pytest.mark.parametrize('R', [70, 200, 512, 513])
+def test_grouped_many_relations(R):
+    """The relations with edges into a block are found 64 at a time (one ballot per 64 relations); 512 is the most the
+    kernel keeps row ranges for -- beyond that the layer function takes the atomic kernel.  Integer data, exact."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(1000 + R)
+    n, F = 500, 128
+    x = torch.randint(-1, 2, (n, F), generator=g).float()
+    ets = [('a', f'r{i}', 'a') for i in range(R)]
+    W = signed_permutations(R, F, g)
+    rows, cols = {}, {}
+    for i, et in enumerate(ets):
+        c = int(torch.randint(0, 40, (1,), generator=g)) if i % 7 else 0      # every seventh relation is empty
+        lo = int(torch.randint(0, n - 40, (1,), generator=g))                 # each relation touches its own stretch of rows
+        rows[et] = torch.sort(torch.randint(lo, lo + 40, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n, (c,), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    y = rgcn.rgcn_layer_fused(x.bfloat16().cuda(), off, rows, cols, ets, W.bfloat16().cuda(), grouped=True)
+    want = exact_want(n, F, ets, rows, cols, x, W, [0] * R, [0] * R)
+    assert want.abs().max() <= 256
+    assert torch.equal(y.double().cpu(), want)
+
+
+def test_grouped_random_configurations():
+    """Differential fuzz of the atomic-free kernels: random numbers of node types and relations, offsets that are no
+    multiples of 16, empty relations, rows of 0 ... 100 edges, edges at the very end of their arrays, every (dtype, K, M)
+    the kernels take, x or tables -- integer data, exact against float64."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(20260927)
+    shapes = [(torch.bfloat16, 128, 128), (torch.float16, 128, 128), (torch.bfloat16, 256, 256), (torch.float16, 128, 256),
+              (torch.bfloat16, 256, 128), (torch.float32, 128, 128)]
+    for case in range(36):
+        dtype, K, M = shapes[case % len(shapes)]
+        T = int(torch.randint(1, 4, (1,), generator=g))
+        types = [f't{i}' for i in range(T)]
+        n = {t: int(torch.randint(1, 300, (1,), generator=g)) for t in types}
+        R = int(torch.randint(1, 9, (1,), generator=g))
+        ets, rows, cols = [], {}, {}
+        for i in range(R):
+            s = types[int(torch.randint(0, T, (1,), generator=g))]
+            d = types[int(torch.randint(0, T, (1,), generator=g))]
+            et = (s, f'r{i}', d)
+            ets.append(et)
+            mode = int(torch.randint(0, 4, (1,), generator=g))
+            c = [0, int(torch.randint(1, 20, (1,), generator=g)), int(torch.randint(20, 400, (1,), generator=g)),
+                 int(torch.randint(400, 3000, (1,), generator=g))][mode]
+            hi = max(1, int(torch.randint(1, n[s] + 1, (1,), generator=g)))
+            r = torch.sort(torch.randint(0, hi, (c,), generator=g)).values
+            if c and mode == 3:
+                r[-1] = n[s] - 1            # an edge into the type's last row
+                r = torch.sort(r).values
+            rows[et] = r.cuda()
+            cols[et] = torch.randint(0, n[d], (c,), generator=g).cuda()
+        off = rgcn.type_offsets(n, types)
+        x = torch.cat([torch.randint(-1, 2, (n[t], K), generator=g).float() for t in types])
+        W = column_selectors(R, K, M, g)
+        soff = [off[s] for s, _, _ in ets]
+        goff = [off[d] for _, _, d in ets]
+        want = exact_want(off['__total__'], M, ets, rows, cols, x, W, soff, goff)
+        if want.abs().max() > 256:
+            continue
+        y = rgcn.rgcn_layer_fused(x.to(dtype).cuda(), off, rows, cols, ets, W.to(dtype).cuda(), grouped=True)
+        assert y.shape == (off['__total__'], M) and torch.equal(y.double().cpu(), want), (case, dtype, K, M, n, [(e, rows[e].numel()) for e in ets])
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+
+
 def test_grouped_without_edges_writes_zeros():
     from pyg_lib_amd import rgcn
     ets = [('a', 'x', 'a'), ('a', 'y', 'a')]
@@ -155,14 +230,6 @@ def test_grouped_on_a_sampled_mag_neighbourhood(dtype):
     assert (y.double() - ya.double()).abs().max().item() <= tol and (y.double() - y3.double()).abs().max().item() <= tol
     for _ in range(3):
         assert torch.equal(rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True), y)
-
-
-def column_selectors(R, K, M, g):
-    # one +-1 per column: out[:, n] = +- x[:, k(n)], exact whatever the sizes
-    W = torch.zeros(R, K, M)
-    k = torch.randint(0, K, (R, M), generator=g)
-    W[torch.arange(R)[:, None], k, torch.arange(M)[None, :]] = (torch.randint(0, 2, (R, M), generator=g) * 2 - 1).float()
-    return W
 
 
 @pytest.mark.parametrize('K,M', [(256, 256), (128, 256), (256, 128)])
