@@ -357,13 +357,13 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     feat2 = {t: torch.randn(MAG_SIZES[t], F2, device=device).to(dtype) for t in types}
     W2 = (torch.randn(len(ets), F2, F2, device=device) / F2 ** 0.5).to(dtype)
     f256_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2, grouped=True), iters)
-    f256_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2), max(2, iters // 3))
+    f256_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat2, out[2], types, out[0], out[1], ets, W2, grouped=False), max(2, iters // 3))
     del feat2
     # ... and float32 at F = 128 (plain FMAs in fp32 after the aggregation; the reference's 1e-5 configuration)
     feat4 = {t: torch.randn(MAG_SIZES[t], F, device=device) for t in types}
     W4 = torch.randn(len(ets), F, F, device=device) / F ** 0.5
     f32_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=True), iters)
-    f32_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4), max(2, iters // 3))
+    f32_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=False), max(2, iters // 3))
     del feat4
     grouped_was = grouped
     grouped = not grouped_was

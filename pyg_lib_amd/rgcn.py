@@ -16,7 +16,7 @@ expanded ``src``-type nodes, ``col`` local ids of the sampled ``dst``-type neigh
 (pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:587-602); messages flow col -> row.  With
 ``csc=True`` the roles of the two end types swap (row indexes ``dst``-type nodes).
 """
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -97,6 +97,14 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
 
 
 _GROUPED_MAX_RELATIONS = 512   # kGroupedMaxRel of csrc/hip/rgcn_grouped.h: the relations' row ranges live in LDS
+
+
+def _resolve_grouped(grouped: Optional[bool], row_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType]) -> bool:
+    # None: yes if every row vector is a `row` output of this package's samplers (csc=False: nondecreasing by construction)
+    if grouped is None:
+        from . import sampler
+        grouped = all(sampler.rows_are_grouped(row_dict[et]) for et in edge_types)
+    return bool(grouped) and len(edge_types) <= _GROUPED_MAX_RELATIONS
 
 
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
@@ -238,7 +246,7 @@ class _RGCNFusedTables(torch.autograd.Function):
 
 def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                      col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
-                     csc: bool = False, grouped: bool = False) -> Tensor:
+                     csc: bool = False, grouped: Optional[bool] = None) -> Tensor:
     r"""Same result as :func:`rgcn_layer` from ONE launch (``pyg::rgcn_fused``, csrc/hip/rgcn.hip): source rows are
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
@@ -255,13 +263,16 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
 
     ``grouped=True`` promises that every ``row_dict[et]`` is NONDECREASING -- true for what ``hetero_neighbor_sample`` /
     ``neighbor_sample`` return (``csc=False``: the edges of a relation come grouped by the node they were sampled for).
+    The default ``None`` means: yes, if every ``row_dict[et]`` IS such an output (the very tensor objects
+    ``pyg_lib_amd.sampler`` returned: ``sampler.rows_are_grouped``), so the usual pipeline sampler -> layer takes the
+    atomic-free kernel without a flag; copies, slices and hand-made edge lists take the atomic kernel unless promised.
     Then the forward is the ATOMIC-FREE kernel (``PYG_HIP_RGCN_GROUPED``, csrc/hip/rgcn_grouped.h): a workgroup owns 32
     output rows, sums every row's source features in fp32 in edge order, multiplies the sums of a relation with its
     weight in one MFMA tile and writes each row once -- no zero fill, no atomics, the same bits on every run (also the
     path under ``torch.use_deterministic_algorithms(True)``), feature sums and results rounded once each.  The promise is
     verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``)."""
     total = offsets['__total__']
-    grouped = grouped and len(edge_types) <= _GROUPED_MAX_RELATIONS
+    grouped = _resolve_grouped(grouped, row_dict, edge_types)
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
     if not _fusable(x, weight, grouped) or (torch.are_deterministic_algorithms_enabled() and not grouped):
@@ -283,7 +294,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
 def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str, Tensor], node_types: List[str],
                             row_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
                             edge_types: List[EdgeType], weight: Tensor, csc: bool = False,
-                            grouped: bool = False) -> Tensor:
+                            grouped: Optional[bool] = None) -> Tensor:
     r"""The fused layer straight from the GLOBAL feature tables: what
 
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
@@ -296,7 +307,7 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     feature table that requires a gradient (:class:`_RGCNFusedTables`).  ``grouped=True``: the atomic-free kernel, see
     :func:`rgcn_layer_fused`."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
-    grouped = grouped and len(edge_types) <= _GROUPED_MAX_RELATIONS
+    grouped = _resolve_grouped(grouped, row_dict, edge_types)
     f0 = feat_dict[node_types[0]]
     feats = [feat_dict[t] for t in node_types]
     nids = [node_id_dict[t] for t in node_types]

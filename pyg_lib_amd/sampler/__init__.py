@@ -10,6 +10,8 @@ reference's samples bit for bit.  There is no CPU path: CPU tensors are refused 
 """
 from typing import Dict, List, Optional, Tuple
 
+import weakref
+
 import torch
 from torch import Tensor
 
@@ -20,6 +22,28 @@ EdgeType = Tuple[str, str, str]
 HomoOut = Tuple[Tensor, Tensor, Tensor, Optional[Tensor], List[int], List[int]]
 HeteroOut = Tuple[Dict[EdgeType, Tensor], Dict[EdgeType, Tensor], Dict[NodeType, Tensor],
                   Optional[Dict[EdgeType, Tensor]], Dict[NodeType, List[int]], Dict[EdgeType, List[int]]]
+
+
+# ---- which tensors are `row` outputs of these samplers ------------------------------------------------------------------
+# With csc=False the samplers emit a relation's edges grouped by the node they were sampled for, so `row` is nondecreasing.
+# pyg_lib_amd.rgcn's fused layer has an atomic-free kernel for exactly that (grouped=True); so that the usual pipeline
+# sampler -> layer gets it without a flag, the wrappers below remember the row tensors they hand out (by identity, weakly:
+# a copy, a slice or a tensor moved to another device is a new tensor and not remembered; the kernel verifies the order
+# on the device in any case).
+_grouped_rows: Dict[int, "weakref.ref"] = {}
+
+
+def _mark_grouped(t: Optional[Tensor]) -> None:
+    if t is not None:
+        key = id(t)
+        _grouped_rows[key] = weakref.ref(t, lambda _r, k=key: _grouped_rows.pop(k, None))
+
+
+def rows_are_grouped(t: Tensor) -> bool:
+    r"""True if `t` is (the very tensor object of) a ``row`` output of one of this module's samplers called with
+    ``csc=False`` -- nondecreasing by construction."""
+    r = _grouped_rows.get(id(t))
+    return r is not None and r() is t
 
 
 def neighbor_sample(rowptr: Tensor, col: Tensor, seed: Tensor, num_neighbors: List[int],
@@ -45,7 +69,10 @@ def neighbor_sample(rowptr: Tensor, col: Tensor, seed: Tensor, num_neighbors: Li
     """
     args = (rowptr, col, seed, num_neighbors, node_time, edge_time, seed_time, edge_weight, csc, replace,
             directed, disjoint, temporal_strategy, return_edge_id)
-    return torch.ops.pyg.neighbor_sample(*args)
+    out = torch.ops.pyg.neighbor_sample(*args)
+    if not csc:
+        _mark_grouped(out[0])
+    return out
 
 
 def _rel(edge_type: EdgeType) -> RelType:
@@ -83,6 +110,9 @@ def hetero_neighbor_sample(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[E
         _to_rel_keys(num_neighbors_dict), node_time_dict, _to_rel_keys(edge_time_dict), seed_time_dict,
         _to_rel_keys(edge_weight_dict), csc, replace, directed, disjoint, temporal_strategy, return_edge_id)
     rows, cols, node_ids, edge_ids, nodes_per_hop, edges_per_hop = out
+    if not csc:
+        for t in rows.values():
+            _mark_grouped(t)
 
     def to_edge_keys(d):
         return None if d is None else {back[k]: v for k, v in d.items()}
@@ -110,6 +140,9 @@ def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], nu
         rowptr, col, seeds, num_neighbors, generator_seeds, node_time, edge_time, seed_times, edge_weight, csc, replace,
         directed, disjoint, temporal_strategy, return_edge_id)
     nph, eph = nph.tolist(), eph.tolist()
+    if not csc:
+        for t in rows:
+            _mark_grouped(t)
     return [(rows[b], cols[b], nodes[b], eids[b] if return_edge_id else None, nph[b], eph[b]) for b in range(len(seeds))]
 
 
@@ -127,6 +160,11 @@ def hetero_neighbor_sample_batched(rowptr_dict: Dict[EdgeType, Tensor], col_dict
     rows, cols, nodes, eids, nph, eph = torch.ops.pyg.hetero_neighbor_sample_batched(
         node_types, edge_types, _to_rel_keys(rowptr_dict), _to_rel_keys(col_dict), seed_dicts,
         _to_rel_keys(num_neighbors_dict), generator_seeds, csc, replace, disjoint, return_edge_id)
+
+    if not csc:
+        for d in rows:
+            for t in d.values():
+                _mark_grouped(t)
 
     def to_edge_keys(d):
         return {back[k]: v for k, v in d.items()}

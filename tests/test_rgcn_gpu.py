@@ -119,7 +119,7 @@ def test_fused_rgcn_layer_mag_shape_matches_oracle(dtype):
     featd = {t: dev(feat[t]).to(dtype) for t in MAG_TYPES}
     x = torch.cat([featd[t][node_d[t]] for t in MAG_TYPES])
     Wd = dev(W).to(dtype)
-    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, Wd)
+    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, Wd, grouped=False)   # the atomic kernel (sampler rows would default to the atomic-free one)
     assert y.shape == (off['__total__'], F) and y.dtype == dtype
     total_edges = sum(v.numel() for v in row_d.values())
     assert total_edges > 100_000
@@ -298,7 +298,7 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
     W = (torch.randn(len(ets), F, F, device='cuda', generator=g) / F ** 0.5).bfloat16()
     off = rgcn.type_offsets({t: node_d[t].numel() for t in types}, types)
     x = torch.cat([feat[t][node_d[t]] for t in types])
-    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, ets, W)
+    y = rgcn.rgcn_layer_fused(x, off, row_d, col_d, ets, W, grouped=False)   # the atomic kernel
     want = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
     for i, (s, r, d) in enumerate(ets):
         msg = (x[col_d[(s, r, d)] + off[d]].double() @ W[i].double()).bfloat16().double()
@@ -308,7 +308,7 @@ def test_full_size_c5_hetero_sample_is_bit_exact_and_layer_matches():
     # the variant bench_legs.leg_c5 TIMES: rows gathered from the global feature tables through the sampler's node ids
     # inside the kernel (no per-batch x) -- same float64 restatement, same bar, and close to the materialised form
     # (only the 2 k-node case had this check)
-    yt = rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W)
+    yt = rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W, grouped=False)
     assert yt.shape == y.shape
     assert (yt.double() - want).abs().max().item() <= 2e-2 * scale
     assert (yt.double() - y.double()).abs().max().item() <= 2e-2 * scale   # (atomic order differs between two launches)

@@ -224,7 +224,7 @@ def test_grouped_on_a_sampled_mag_neighbourhood(dtype):
     # sum next to a rounding boundary may land on the other side of it than the float64 sum: one ulp of one feature sum)
     assert (y.double() - want).abs().max().item() <= (8e-3 if dtype == torch.bfloat16 else 1.5e-3) * scale
     assert not y[~touched].any()
-    ya = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W)     # atomic kernel: messages rounded, runs added
+    ya = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W, grouped=False)     # atomic kernel: messages rounded, runs added
     y3 = rgcn.rgcn_layer(x, off, row_d, col_d, MAG_ETS, W)           # three-op chain
     tol = (3e-2 if dtype == torch.bfloat16 else 4e-3) * scale
     assert (y.double() - ya.double()).abs().max().item() <= tol and (y.double() - y3.double()).abs().max().item() <= tol
@@ -351,6 +351,48 @@ def test_grouped_float32():
     rgcn.rgcn_layer(xg3, off, rows, cols, ets, wg3).square().sum().backward()
     for a, b in ((xg.grad, xg3.grad), (wg.grad, wg3.grad)):
         assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+
+
+def test_sampler_rows_take_the_atomic_free_kernel_by_default():
+    """`grouped=None` (the default): rows that ARE outputs of this package's samplers (csc=False) are nondecreasing by
+    construction, so the layer runs the atomic-free kernel without a flag; a copy of them (or any hand-made edge list) is
+    not known to be grouped and takes the atomic kernel."""
+    from pyg_lib_amd import sampler, rgcn, diagnostics
+    from tests.test_rgcn_gpu import MAG_TYPES, MAG_ETS, build_graph
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(8)
+    sizes = {'paper': 4000, 'author': 6000, 'institution': 90, 'field_of_study': 400}
+    rp, cl = build_graph(rng, sizes, MAG_ETS, 12)
+    seeds = {'paper': dev(rng.permutation(sizes['paper'])[:64].astype(np.int64))}
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()}, seeds,
+                                         {e: [5, 4] for e in MAG_ETS})
+    row_d, col_d, node_d = out[0], out[1], out[2]
+    assert all(sampler.rows_are_grouped(row_d[e]) for e in MAG_ETS) and not sampler.rows_are_grouped(col_d[MAG_ETS[0]])
+    g = torch.Generator(device='cuda').manual_seed(4)
+    feat = {t: torch.randn(sizes[t], 128, device='cuda', generator=g).bfloat16() for t in MAG_TYPES}
+    W = (torch.randn(len(MAG_ETS), 128, 128, device='cuda', generator=g) / 11).bfloat16()
+    ya = rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=False)
+    marker = diagnostics.last_accumulate_info()
+    assert 'pyg_hip_rgcn_fused' in marker
+    torch.zeros(8, device='cuda').index_add_(0, torch.zeros(3, dtype=torch.long, device='cuda'), torch.ones(3, device='cuda'))
+    from pyg_lib_amd import ops
+    ops.scatter_sum(torch.ones(4, 2, device='cuda'), torch.tensor([[0, 1], [1, 0], [0, 0], [1, 1]], device='cuda'), 0, None, 2)
+    marker = diagnostics.last_accumulate_info()        # (an atomic scatter in between: the marker is no longer the layer's)
+    assert 'pyg_hip_rgcn_fused' not in marker
+    y = rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W)          # default: atomic-free
+    assert diagnostics.last_accumulate_info() == marker
+    assert torch.equal(y, rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True))
+    scale = ya.float().abs().max().item()
+    assert (y.float() - ya.float()).abs().max().item() <= 3e-2 * scale
+    copies = {e: row_d[e].clone() for e in MAG_ETS}
+    rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, copies, col_d, MAG_ETS, W)             # copies: the atomic kernel
+    assert 'pyg_hip_rgcn_fused' in diagnostics.last_accumulate_info()
+    # csc=True swaps the roles: those rows are the sampled neighbours, not grouped, not remembered
+    out_c = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()}, seeds,
+                                           {e: [5, 4] for e in MAG_ETS}, csc=True)
+    assert not any(sampler.rows_are_grouped(t) for t in out_c[0].values())
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
 
 
 def test_grouped_promise_is_verified_on_the_device():

@@ -66,7 +66,7 @@ fan = {e: [15, 10] for e in ets}
 for b in range(4):
     sd = torch.randperm(bench_legs.MAG_SIZES['paper'], generator=g)[:1024].to(dev)
     out = sampler.hetero_neighbor_sample(rp, cl, {'paper': sd}, fan)
-    rgcn.rgcn_layer_fused_tables(featm, out[2], types, out[0], out[1], ets, Wm)                 # atomic kernel (+ zero fill)
+    rgcn.rgcn_layer_fused_tables(featm, out[2], types, out[0], out[1], ets, Wm, grouped=False)  # atomic kernel (+ zero fill)
     rgcn.rgcn_layer_fused_tables(featm, out[2], types, out[0], out[1], ets, Wm, grouped=True)   # row-start + owner-computes kernel
 torch.cuda.synchronize()
 del rp, cl, featm

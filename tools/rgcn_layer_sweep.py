@@ -49,6 +49,6 @@ for wgs in ('2',):
             os.environ['PYG_HIP_RGCN_WGS'] = wgs
             os.environ['PYG_HIP_RGCN_MIN_TILES'] = mt
             os.environ['PYG_HIP_RGCN_DBG'] = dbg
-            t_layer = timed(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W))
+            t_layer = timed(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=False))
             t_kernel = timed(lambda: torch.ops.pyg.rgcn_fused_tables(*args, pre))
             print(f'wgs/CU {wgs} min tiles {mt} dbg {dbg}: layer {t_layer:7.1f} us   op without the fill {t_kernel:7.1f} us', flush=True)
