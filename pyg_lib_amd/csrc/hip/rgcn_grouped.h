@@ -6,21 +6,22 @@
 //
 // The samplers emit every relation's edges grouped by the node they were sampled for (sampler/cpu/neighbor_kernel.cpp:
 // 332-514: one frontier node after the other, a later hop's frontier has larger local ids), so `row` -- the scatter
-// index of the layer -- is nondecreasing per relation.  Then a destination row can be OWNED: a workgroup takes 32
-// consecutive rows of `out`, one row per 16-lane group, and for every relation with edges into its rows
+// index of the layer -- is nondecreasing per relation.  Then a destination row can be OWNED: a workgroup takes 16
+// consecutive rows of `out` (a block), one row per 16-lane group, and for every relation with edges into its rows
 //   * every group finds its row's edges (one lookup in the row-start table a small launch in front of this one builds
 //     from scatter_index: rgcn_rowstart_kernel), walks them 16 at a time -- lane c of the group fetches 16 bytes of each
 //     source row, a whole 256-byte row per group and instruction -- and sums them in fp32 registers in edge order;
-//   * the 32 sums, rounded to T once, are the A tile of ONE 32 x 128 x 128 product with W_r (aggregate first, transform
-//     second: E / fan-out matrix rows instead of E), accumulated in fp32 across the relations of the block;
+//   * the 16 sums, rounded to T once, are the A tile of ONE 32 x 128 x 128 MFMA product with W_r (half of its rows in
+//     use; aggregate first, transform second: E / fan-out matrix rows instead of E), accumulated in fp32 across the
+//     relations of the block;
 //   * the block's rows are written once, rounded once -- rows without edges as zeros.
 // No atomics, no zero fill of `out` in front, no read-modify-write of `out`, the same bits on every run (the sums of a
 // row are taken in edge order, relations in list order).  Rounding: one rounding of the per-relation feature sum
 // (relative 2^-9 for bf16, where the chain rounds every message) and one of the result (where scatter_sum of the chain
 // rounds once per destination as well).
 //
-// A group's dependent loads (row start -> indices -> gather_map -> feature rows) are issued stage by stage for up to four
-// relations at once, so a block pays three round trips for its indices plus one per relation for the rows.
+// bf16 / f16 with K, M in {128, 256}, float32 with K = M = 128 (fp32 sums, fp32 FMAs instead of MFMAs).  HBM traffic by the
+// counters (profiles/r5_pmc_ops.json): 169 MB fetched + 106 MB written per C5 batch = 1.07 x the formula's 263 MB.
 
 // lane I of every 16-lane DPP row to all lanes of the row (v_mov_b32_dpp row_newbcast:I)
 template <int I>
@@ -101,17 +102,18 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
   }
 }
 
-// K = M = 128, 16-bit T; 512 threads = 32 groups of 16 lanes = 32 rows of `out` per block.
+// 256 threads = 16 groups of 16 lanes = 16 rows of `out` per block.
 //
-// Persistent launch (two workgroups per CU), blocks dealt round-robin.  The unit of work is an ITEM = (block, relation with
-// edges into the block); a block without items costs its 8 KB of zero stores and nothing else.  An item needs four
+// Persistent launch (three workgroups per CU), blocks dealt round-robin.  The unit of work is an ITEM = (block, relation with
+// edges into the block); a block without items costs its 4 KB of zero stores and nothing else.  An item needs four
 // DEPENDENT memory round trips -- row start -> the two indices -> gather_map -> feature rows, 3 - 5 us each on this chip
 // under load -- so the items of a workgroup run through a four-deep software pipeline: every iteration first uses what
 // the previous iteration requested (one wait at its top), then issues, back to back,
 //     rows of item i + 1 | gather_map lookups of item i + 2 | indices of item i + 3 | row starts of item i + 4 | W of item i + 1
-// and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave 0 - 3, barrier, the block's stores when its
-// last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on the C5
-// batch where the atomic kernel + its zero fill take 66.)
+// and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave, barrier, W of item i + 1, the block's stores
+// when its last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on
+// the C5 batch where the atomic kernel + its zero fill take 66; this one 57.  An item-at-a-time walk with enough
+// workgroups per CU is only 2 % behind -- it serves rows of more than 16 edges and the other shapes / types.)
 template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC, bool F32 = false>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
