@@ -37,6 +37,12 @@ def _gpu_health():
             _HEALTH['uuid'] = ', '.join(sorted({ln.split()[-1] for ln in uuid.splitlines() if 'Uuid' in ln and 'GPU-' in ln}))
         except Exception:  # noqa: BLE001
             _HEALTH['uuid'] = '?'
+        try:   # partition modes of the box (C4's 0.60 vs 0.695 is a property of the box: recorded next to every pass)
+            smi = subprocess.run(['rocm-smi', '--showcomputepartition', '--showmemorypartition'], capture_output=True, text=True,
+                                 timeout=60).stdout
+            _HEALTH['partition'] = '; '.join(ln.split(':', 1)[1].strip() for ln in smi.splitlines() if 'Partition:' in ln)
+        except Exception:  # noqa: BLE001
+            _HEALTH['partition'] = '?'
         exe = osp.join(ROOT, 'tools', 'probe', 'atomic_probe')
         lines = []
         if osp.exists(exe):
@@ -55,7 +61,7 @@ def _gpu_health():
             _HEALTH['selftest'] = [f'in-process self-test failed to run: {e!r}']
         os.makedirs(osp.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(osp.join(ROOT, 'gpurun_out', 'gpu_health.txt'), 'a') as f:
-            f.write(f"gpu {_HEALTH.get('uuid')}: {_HEALTH['probe']}\n" + ''.join(ln + '\n' for ln in lines) +
+            f.write(f"gpu {_HEALTH.get('uuid')} ({_HEALTH.get('partition')}): {_HEALTH['probe']}\n" + ''.join(ln + '\n' for ln in lines) +
                     ''.join(ln + '\n' for ln in _HEALTH['selftest']))
     except Exception as e:  # noqa: BLE001 - diagnostics only
         _HEALTH['probe'] = f'probe failed to run: {e!r}'
@@ -72,7 +78,7 @@ def pytest_sessionstart(session):
 
 
 def _health_lines(h):
-    return ([f"GPU {h.get('uuid', '?')}", f"stand-alone float-atomic probe: {h['probe']}"] +
+    return ([f"GPU {h.get('uuid', '?')} ({h.get('partition', '?')})", f"stand-alone float-atomic probe: {h['probe']}"] +
             [f'    {ln}' for ln in h.get('lost', [])] + [f'in-process {ln}' if i == 0 else f'  {ln}'
                                                          for i, ln in enumerate(h.get('selftest', []))])
 
