@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, step p: round-end evidence (tools/profile_round.sh) + two full GPU passes
-R=/root/repo/gpurun_out/r5_p
+# round 5, last step: round-end evidence (tools/profile_round.sh) + two full GPU passes
+R=/root/repo/gpurun_out/r5_z
 mkdir -p $R
 cd /root/repo
-bash tools/profile_round.sh r5_p > $R/profile_round.log 2>&1
+bash tools/profile_round.sh r5_z > $R/profile_round.log 2>&1
 cd /root/repo
 for i in 1 2; do
   timeout 1500 python -m pytest tests -m gpu -x -q > $R/pytest_$i.txt 2>&1
