@@ -44,3 +44,46 @@ def test_segment_matmul_replays_from_a_captured_graph(dtype, F, rows, variant):
         ref = ops.segment_matmul(x, ptr, w, bias)
         view = torch.int32 if dtype == torch.float32 else torch.int16
         assert torch.equal(out.view(view), ref.view(view)), trial
+
+
+def test_atomic_free_fused_layer_replays_from_a_captured_graph():
+    """The grouped R-GCN layer makes no host round trip either (records in the kernel argument, index validation
+    deferred, the rows-longer-than-16 switch a device-side flag compared with an id baked into the launch): captured
+    once, replayed on new features, weights AND new edge lists of the same sizes -- including a replay whose rows are
+    longer than 16 edges although the captured call's were not."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator(device=DEV).manual_seed(11)
+    n, F, E = 3000, 128, 20_000
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'a')]
+    x = torch.randn(n, F, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(2, F, F, device=DEV, generator=g) / F ** 0.5).bfloat16()
+    rows = [torch.sort(torch.randint(0, n, (E,), device=DEV, generator=g)).values for _ in ets]    # ~7 edges per row
+    cols = [torch.randint(0, n, (E,), device=DEV, generator=g) for _ in ets]
+    out = torch.empty(n, F, device=DEV, dtype=torch.bfloat16)
+
+    def call():
+        return torch.ops.pyg.rgcn_fused(x, cols, rows, [0, 0], [0, 0], w, out, True)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            call()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for trial in range(4):
+        x.copy_(torch.randn(n, F, device=DEV, generator=g).bfloat16())
+        w.copy_((torch.randn(2, F, F, device=DEV, generator=g) / F ** 0.5).bfloat16())
+        hi = n if trial % 2 == 0 else 400          # odd trials: 50 edges per row -> the item-at-a-time walk
+        for r, c in zip(rows, cols):
+            r.copy_(torch.sort(torch.randint(0, hi, (E,), device=DEV, generator=g)).values)
+            c.copy_(torch.randint(0, n, (E,), device=DEV, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        ref = torch.ops.pyg.rgcn_fused(x, cols, rows, [0, 0], [0, 0], w, torch.empty_like(out), True)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), trial
+    assert rgcn.pending_index_error() == 0
