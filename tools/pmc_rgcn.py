@@ -14,4 +14,5 @@ seeds = torch.randperm(B.SIZES['paper'])[:1024].to(dev)
 out = sampler.hetero_neighbor_sample(rp, cl, {'paper': seeds}, {e: [15, 10] for e in ets})
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     y = rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=False)   # the atomic kernel
+    y = rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=True)    # row-start + atomic-free kernel
 torch.cuda.synchronize()
