@@ -289,8 +289,9 @@ PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
  * sums every row's source features in fp32 in edge order, multiplies the 32 sums of a relation with its weight in one
  * MFMA tile, accumulates the relations of a row in fp32 and WRITES every row of `out` once (rows without edges: zeros).
  *   - `out` is OVERWRITTEN, not accumulated into (do not zero it); it must be 16-byte aligned;
- *   - K and M may each be 128 or 256 (the feature rows are walked once per 128-feature slice, W travels through LDS in
- *     128 x 128 chunks); dtype may also be PYG_F32 with K = M = 128 (fp32 sums and fp32 FMAs);
+ *   - K and M may both be in {64, 128} or both in {128, 256} (the feature rows are walked once per 128-feature slice, W
+ *     travels through LDS in 128 x 128 chunks; 64: masked lanes); dtype may also be PYG_F32 with K = M = 128 (fp32 sums and
+ *     fp32 FMAs);
  *   - the same bits on every run; rounding: the per-relation feature sum and the result are each rounded once;
  *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of `out` at and behind every
  *     relation's scatter_offset: row starts, touched only where edges arrive);

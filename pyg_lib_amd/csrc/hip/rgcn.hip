@@ -471,7 +471,8 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
                         int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace, size_t workspace_bytes,
                         hipStream_t stream) {
   const size_t esz = dtype == PYG_F32 ? 4 : 2;
-  const int KC = (int)(K * esz / 256), MC = (int)(M * esz / 256);   // 256-byte slices of a feature row / of a row of `out`
+  const bool small = esz == 2 && (K == 64 || M == 64);
+  const int KC = small ? 1 : (int)(K * esz / 256), MC = small ? 1 : (int)(M * esz / 256);   // 256-byte slices of a feature row / of a row of `out`
   if (num_out_rows == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "rgcn_fused: 'out' must be 16-byte aligned in grouped mode");
@@ -553,6 +554,8 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
   int* err_dev = reinterpret_cast<int*>(w + rel_b + vec_b + meta_b);
   desc.rp = reinterpret_cast<int32_t*>(w + rel_b + vec_b + meta_b + 256);
   desc.long_rows = reinterpret_cast<uint64_t*>(w + rel_b + vec_b + meta_b + 64);
+  desc.row_bytes = (int)(K * esz);
+  desc.out_bytes = (int)(M * esz);
   {  // an id that no earlier call of this process and no stale word of the workspace holds
     static std::atomic<uint64_t> counter{0};
     static const uint64_t salt = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() << 24;
@@ -591,7 +594,12 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
              : (inl ? (const void*)&rgcn_grouped_shape_kernel<true, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<true, false, false, KC_, MC_>)) \
       : (big ? (inl ? (const void*)&rgcn_grouped_shape_kernel<false, true, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, true, false, KC_, MC_>)  \
              : (inl ? (const void*)&rgcn_grouped_shape_kernel<false, false, true, KC_, MC_> : (const void*)&rgcn_grouped_shape_kernel<false, false, false, KC_, MC_>)))
-    if (dtype == PYG_F32)
+    if (small)
+      kern = bf ? (big ? (inl ? (const void*)&rgcn_grouped_small_kernel<true, true, true> : (const void*)&rgcn_grouped_small_kernel<true, true, false>)
+                       : (inl ? (const void*)&rgcn_grouped_small_kernel<true, false, true> : (const void*)&rgcn_grouped_small_kernel<true, false, false>))
+                : (big ? (inl ? (const void*)&rgcn_grouped_small_kernel<false, true, true> : (const void*)&rgcn_grouped_small_kernel<false, true, false>)
+                       : (inl ? (const void*)&rgcn_grouped_small_kernel<false, false, true> : (const void*)&rgcn_grouped_small_kernel<false, false, false>));
+    else if (dtype == PYG_F32)
       kern = big ? (inl ? (const void*)&rgcn_grouped_f32_kernel<true, true> : (const void*)&rgcn_grouped_f32_kernel<true, false>)
                  : (inl ? (const void*)&rgcn_grouped_f32_kernel<false, true> : (const void*)&rgcn_grouped_f32_kernel<false, false>);
     else if (KC == 2 && MC == 2) kern = PYG_RGCN_SPICK(2, 2);
@@ -661,10 +669,10 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
   PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16 || (grouped && dtype == PYG_F32),
                   "rgcn_fused: bfloat16 / float16 only (PYG_HIP_RGCN_GROUPED: float32 too)");
-  if (dtype == PYG_F32 ? (K != 128 || M != 128)
-                       : (grouped ? !((K == 128 || K == 256) && (M == 128 || M == 256)) : (K != 128 || M != 128)))
+  const bool wide = (K == 128 || K == 256) && (M == 128 || M == 256), narrow = (K == 64 || K == 128) && (M == 64 || M == 128);
+  if (dtype == PYG_F32 ? (K != 128 || M != 128) : (grouped ? !(wide || narrow) : (K != 128 || M != 128)))
     return fail(PYG_HIP_ERR_UNSUPPORTED,
-                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M in {128, 256} for the 16-bit types); got %lld x %lld",
+                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M both in {64, 128} or both in {128, 256} for the 16-bit types); got %lld x %lld",
                 (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");

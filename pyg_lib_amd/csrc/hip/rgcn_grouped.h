@@ -52,6 +52,7 @@ struct GroupedDesc {
   int32_t* meta;             // [2 r] the first, [2 r + 1] the last scatter index of relation r (written by the row-start launch)
   uint64_t* long_rows;       // == call_id: some row of this call has more than 16 edges (set by the row-start launch; the
   uint64_t call_id;          //  workspace is not cleared: an id no earlier call and no stale word can hold)
+  int row_bytes, out_bytes;  // SMALL instances (K or M = 64): bytes of a feature row / of a row of `out`
   RelDev irels[kRgcnInline];
   int64_t ieprefix[kRgcnInline + 1];
   int64_t irp_off[kRgcnInline];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
 // when its last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on
 // the C5 batch where the atomic kernel + its zero fill take 66; this one 57.  An item-at-a-time walk with enough
 // workgroups per CU is only 2 % behind -- it serves rows of more than 16 edges and the other shapes / types.)
-template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC, bool F32 = false>
+template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC, bool F32 = false, bool SMALL = false>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
   constexpr int U = 16;   // edges of a row per batch (one per lane of the group)
@@ -130,7 +131,12 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // K = 128 KC input features (rows of 256 KC bytes), M = 128 MC output features: the feature rows are walked once per
   // 128-feature slice (the indices come from L2 the second time), W travels through LDS in 128 x 128 chunks.  The pipeline
   // exists for KC = MC = 1; the other shapes take the item-at-a-time walk (2 % slower on the C5 batch where both run).
-  constexpr int RB = 256 * KC, OB = 256 * MC;   // bytes of a feature row / of a row of `out`
+  constexpr int RB0 = 256 * KC, OB0 = 256 * MC;   // bytes of a feature row / of a row of `out`
+  // SMALL (KC = MC = 1): K or M is 64 -- rows of 128 bytes.  Lanes whose 16 bytes lie behind the row's end load nothing
+  // (their part of the A tile is zero), W's columns behind M and rows behind K are never copied (the W buffer is zeroed
+  // once), the stores behind M are dropped; the item-at-a-time walk.
+  static_assert(!SMALL || (KC == 1 && MC == 1 && !F32), "SMALL: 16-bit, K, M in {64, 128}");
+  const int RB = SMALL ? desc.row_bytes : RB0, OB = SMALL ? desc.out_bytes : OB0;
   // F32: K = M = 128 floats, i.e. KC = MC = 2 in BYTES (rows of 512 bytes, walked in two 256-byte slices like K = 256 of the
   // 16-bit types); sums, the A tile and the product stay fp32 -- plain FMAs, IEEE like the reference's fp32 (no MFMA: after
   // the aggregation the product is 16 x 128 x 128 per item, ~4 us of a CU's FMA and LDS time next to ~25 us of gathers) --
@@ -142,7 +148,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
   // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
   // function instead (same registers, no pipeline; the choice is uniform over the launch).
-  const bool long_rows = KC * MC > 1 || *desc.long_rows == desc.call_id;
+  const bool long_rows = KC * MC > 1 || SMALL || *desc.long_rows == desc.call_id;
   auto rel_at = [&](int i) __attribute__((always_inline)) -> const RelDev& {
     if constexpr (INL) return desc.irels[i];
     else return desc.rels[i];
@@ -181,6 +187,11 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       rhi[r] = hi;
     }
   }
+  if constexpr (SMALL) {   // 32 KB by 256 threads
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(smem + (i * 256 + tid) * 16) = z;
+  }
   if constexpr (ROWS < 32) {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -206,8 +217,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll
     for (int j = 0; j < 32 / NW; ++j) {
       const int kb = wave * (32 / NW) + j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
-                                       (LDSV*)(smem + kb * 1024), 16, 0, 0);
+      if constexpr (SMALL) {   // (K = RB / 2 rows of M = OB / 2 columns exist)
+        if (dma_c * 16 < OB && 2 * (4 * kb + dma_r) < RB)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
+                                           (LDSV*)(smem + kb * 1024), 16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
+                                         (LDSV*)(smem + kb * 1024), 16, 0, 0);
+      }
     }
   };
   // edges of the group's row among the 16 at `start`: lane c looks at edge start + c; the row's edges are a prefix
@@ -247,7 +264,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         const uint32_t rl = (uint32_t)row_bcast<i>(lo), rh = (uint32_t)row_bcast<i>(hi);
         const int64_t row = (int64_t)(((uint64_t)rh << 32) | rl);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < n) v = *(GU32x4*)(rel.x + row * RB + kc * 256 + c * 16);
+        if (i < n && (!SMALL || c * 16 < RB)) v = *(GU32x4*)(rel.x + row * RB + kc * 256 + c * 16);
         xr[i] = v;
       });
     } else {
@@ -256,7 +273,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         constexpr int i = decltype(I)::value;
         const uint32_t off = (uint32_t)row_bcast<i>(rowb) + (uint32_t)(kc * 256 + c * 16);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < n) v = *(GU32x4*)(rel.x + off);
+        if (i < n && (!SMALL || c * 16 < RB)) v = *(GU32x4*)(rel.x + off);
         xr[i] = v;
       });
     }
@@ -332,7 +349,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         uint32_t z0 = 0;
         asm volatile("" : "+v"(z0));   // (materialised here: hoisted, the four zero registers were spilled and reloaded)
         const u32x4 z = {z0, z0, z0, z0};
-        if (o < out_rows) {
+        if (o < out_rows && (!SMALL || c * 16 < OB)) {
 #pragma unroll
           for (int mc = 0; mc < MC; ++mc) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
         }
@@ -400,7 +417,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       // (MC = 1: every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
       const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
       const int64_t o = (int64_t)blk * ROWS + grp;
-      if (o < out_rows) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
+      if (o < out_rows && (!SMALL || c * 16 < OB)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
       if (MC > 1) __syncthreads();   // (the next 128 columns go through the same tile)
     }
   };
@@ -602,6 +619,13 @@ template <bool BF16, bool BIG, bool INL, int KC, int MC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_shape_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                                     int64_t out_rows, int* __restrict__ error) {
   rgcn_grouped_body<BF16, true, BIG, INL, 4, KC, MC>(desc, R, out, out_rows, error);
+}
+
+// 16-bit, K, M in {64, 128}, at least one of them 64
+template <bool BF16, bool BIG, bool INL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_small_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+                                                                                                    int64_t out_rows, int* __restrict__ error) {
+  rgcn_grouped_body<BF16, true, BIG, INL, 4, 1, 1, false, true>(desc, R, out, out_rows, error);
 }
 
 // fp32, K = M = 128

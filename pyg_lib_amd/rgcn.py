@@ -108,15 +108,17 @@ def _resolve_grouped(grouped: Optional[bool], row_dict: Dict[EdgeType, Tensor], 
 
 
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
-    # the atomic kernel: 16-bit, F_in = F_out = 128; the grouped (atomic-free) kernel: each of them 128 or 256, or float32
-    # with F_in = F_out = 128
-    if grouped and x.dtype == torch.float32:
-        sizes = (128,)
-    else:
-        sizes = (128, 256) if grouped else (128,)
+    # the atomic kernel: 16-bit, F_in = F_out = 128; the grouped (atomic-free) kernel: 16-bit with F_in, F_out both in
+    # {64, 128} or both in {128, 256}, or float32 with F_in = F_out = 128
+    if x.dim() != 2 or weight.dim() != 3:
+        return False
+    K, M = x.size(1), weight.size(2)
+    if not grouped or x.dtype == torch.float32:
+        shape_ok = K == 128 and M == 128
+    else:   # both in {64, 128} or both in {128, 256}
+        shape_ok = (K in (64, 128) and M in (64, 128)) or (K in (128, 256) and M in (128, 256))
     dtypes = (torch.bfloat16, torch.float16, torch.float32) if grouped else (torch.bfloat16, torch.float16)
-    return (x.is_cuda and x.dtype in dtypes and x.dim() == 2 and x.size(1) in sizes and
-            weight.dim() == 3 and weight.size(1) == x.size(1) and weight.size(2) in sizes and weight.dtype == x.dtype and
+    return (x.is_cuda and x.dtype in dtypes and shape_ok and weight.size(1) == K and weight.dtype == x.dtype and
             weight.device == x.device)
 
 
@@ -251,7 +253,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
     index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128`` (``grouped=True``:
-    each of them 128 or 256, or float32 with 128 / 128); anything else takes the three-op chain.
+    both in {64, 128} or both in {128, 256}, or float32 with 128 / 128); anything else takes the three-op chain.
 
     Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
     backward runs the same kernel with swapped roles for dX and the weight-gradient kernel on the gathered rows for dW
