@@ -361,8 +361,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // ---- pipeline registers -------------------------------------------------------------------------------------------
   bool v0 = false, v1 = false, v2 = false, v3 = false;   // item i, i + 1, i + 2, i + 3 exist (uniform)
   int blk0 = 0, blk1 = 0, blk2 = 0, blk3 = 0, rel0 = 0, rel1 = 0, rel2 = 0, rel3 = 0;
-  int st0 = -1, st1 = -1, st2 = -1, st3 = -1;            // first edge of the group's row (-1: the row has none)
-  int n0 = 0, n1 = 0;                                    // edges of the row in its first batch
+  int st2 = -1, st3 = -1;                                // first edge of the group's row (-1: the row has none), items i + 2, i + 3
+  int n1 = 0;                                            // edges of the row (<= 16 in this walk), item i + 1
   RowT g2_1 = 0;                                         // feature row of lane c's edge of item i + 1
   int64_t g1_2 = 0;                                      // the two indices of lane c's edge of item i + 2 (the scatter index:
   int s1_2 = -1;                                         //  its low word -- the row-start launch has seen all 64 bits)
@@ -601,8 +601,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       if (last) store_block(acc, blk0);
     }
     // ---- rotate --------------------------------------------------------------------------------------------------------
-    v0 = v1, blk0 = blk1, rel0 = rel1, st0 = st1, n0 = n1;
-    v1 = v2, blk1 = blk2, rel1 = rel2, st1 = st2, n1 = n2, g2_1 = g2n;
+    v0 = v1, blk0 = blk1, rel0 = rel1;
+    v1 = v2, blk1 = blk2, rel1 = rel2, n1 = n2, g2_1 = g2n;
     v2 = v3, blk2 = blk3, rel2 = rel3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
     v3 = v4, blk3 = blk4, rel3 = rel4, st3 = st4;
   }
