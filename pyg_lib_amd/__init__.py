@@ -4,8 +4,10 @@ Mirrors the reference package for that path (pyg_lib/__init__.py:10-49): ``libpy
 this file registers the reference's ``pyg::*`` operator schemas, and ``pyg_lib_amd.ops`` /
 ``pyg_lib_amd.sampler`` are the same thin wrappers over ``torch.ops.pyg`` as ``pyg_lib.ops`` /
 ``pyg_lib.sampler``.  The operators are implemented by hand-written HIP kernels behind the C-ABI
-of ``include/pyg_hip.h`` (``libpyg_hip.so``).  There is no CPU path and no Triton path: without
-the libraries the import fails loudly.
+of ``include/pyg_hip.h`` (``libpyg_hip.so``).  Device tensors never leave the device: there is no CPU fallback and no
+Triton path, and without the libraries the import fails loudly.  (CPU tensors dispatch to the ``CPU`` key's plain
+restatement of the same operators, csrc/binding/pyg_binding_cpu*.cpp -- host logic for tests and tooling, as the
+reference registers its own CPU kernels; a device call never reaches it.)
 """
 import os.path as osp
 

@@ -11,10 +11,17 @@ on the host without a synchronisation) and no ``index_sort`` by relation is need
 Node features of all types live in ONE ``[sum_t n_t, F]`` buffer (type offsets), so one gather and
 one scatter serve every relation.
 
-For ``csc=False`` sampler output and edge type ``(src, rel, dst)``: ``row`` holds local ids of the
-expanded ``src``-type nodes, ``col`` local ids of the sampled ``dst``-type neighbours
-(pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:587-602); messages flow col -> row.  With
-``csc=True`` the roles of the two end types swap (row indexes ``dst``-type nodes).
+For edge type ``(src, rel, dst)`` ``row`` always holds local ids of ``src``-type nodes and ``col`` local ids of
+``dst``-type nodes; what ``csc`` changes is which end was EXPANDED and which one SAMPLED
+(pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:715-719 picks the expanded type, :147-159 swaps the two vectors on return):
+
+    csc=False  the graph is CSR over ``src``: ``row`` = the expanded ``src`` nodes (nondecreasing), ``col`` = their sampled
+               ``dst`` neighbours; messages flow col -> row:   out[row + off[src]] += x[col + off[dst]] @ W_r
+    csc=True   the graph is CSC over ``dst`` (the reference's own MAG benchmark, benchmark/sampler/hetero_neighbor.py:106-124,
+               and PyG's loaders): ``col`` = the expanded ``dst`` nodes (nondecreasing), ``row`` = their sampled ``src``
+               neighbours; messages flow row -> col:           out[col + off[dst]] += x[row + off[src]] @ W_r
+
+so the type offsets never swap -- the index ROLES (gather / scatter) do (:func:`edge_roles`).
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -36,6 +43,16 @@ def pending_index_error() -> int:
     return int(_capi.lib().pyg_hip_rgcn_pending_error())
 
 
+_last_path = ['none']
+
+
+def last_layer_path() -> str:
+    r"""Which implementation the last layer call of this process took: ``'chain'`` (gather_coo -> segment_matmul ->
+    scatter_sum), ``'atomic'`` (``pyg::rgcn_fused`` with packed atomics) or ``'grouped'`` (the atomic-free kernel).
+    Diagnostics, like ``sampler.last_mode``."""
+    return _last_path[0]
+
+
 def type_offsets(num_nodes: Dict[str, int], node_types: List[str]) -> Dict[str, int]:
     off, acc = {}, 0
     for t in node_types:
@@ -43,6 +60,16 @@ def type_offsets(num_nodes: Dict[str, int], node_types: List[str]) -> Dict[str, 
         acc += int(num_nodes[t])
     off['__total__'] = acc
     return off
+
+
+def edge_roles(et: EdgeType, row_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor], csc: bool):
+    r"""``(gather index, gather node type, scatter index, scatter node type)`` of one relation's sampled edges: the
+    scatter index is the vector of EXPANDED nodes (``row`` / src for ``csc=False``, ``col`` / dst for ``csc=True``), the
+    gather index the vector of sampled neighbours."""
+    src, _, dst = et
+    if csc:
+        return row_dict[et], src, col_dict[et], dst
+    return col_dict[et], dst, row_dict[et], src
 
 
 class _GatherRows(torch.autograd.Function):
@@ -66,25 +93,25 @@ class _GatherRows(torch.autograd.Function):
 def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
                csc: bool = False) -> Tensor:
-    r"""out[row] += x[col] @ weight[r] over every sampled edge of every relation r.
+    r"""out[row] += x[col] @ weight[r] (``csc=True``: out[col] += x[row] @ weight[r]) over every sampled edge of every
+    relation r -- messages flow from the sampled neighbours to the nodes they were sampled for.
 
     Args:
         x: ``[sum_t n_t, F_in]`` features of the sampled nodes, types concatenated at `offsets`.
         offsets: first row of every node type in `x` (``type_offsets``).
-        row_dict, col_dict: local indices from ``hetero_neighbor_sample``.
+        row_dict, col_dict: local indices from ``hetero_neighbor_sample`` called with the same `csc`.
         edge_types: relation order; ``weight[i]`` belongs to ``edge_types[i]``.
         weight: ``[R, F_in, F_out]``.
     Returns:
         ``[sum_t n_t, F_out]`` aggregated messages (same type layout as `x`).
     """
+    _last_path[0] = 'chain'
     counts, gather_idx, scatter_idx = [0], [], []
     for et in edge_types:
-        src, _, dst = et
-        row_t, col_t = (src, dst) if not csc else (dst, src)
-        row, col = row_dict[et], col_dict[et]
-        counts.append(counts[-1] + row.numel())
-        gather_idx.append(col + offsets[col_t] if offsets[col_t] else col)
-        scatter_idx.append(row + offsets[row_t] if offsets[row_t] else row)
+        g, g_t, s, s_t = edge_roles(et, row_dict, col_dict, csc)
+        counts.append(counts[-1] + g.numel())
+        gather_idx.append(g + offsets[g_t] if offsets[g_t] else g)
+        scatter_idx.append(s + offsets[s_t] if offsets[s_t] else s)
     total = offsets['__total__']
     if counts[-1] == 0:
         return x.new_zeros(total, weight.size(-1))
@@ -99,12 +126,13 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
 _GROUPED_MAX_RELATIONS = 512   # kGroupedMaxRel of csrc/hip/rgcn_grouped.h: the relations' row ranges live in LDS
 
 
-def _resolve_grouped(grouped: Optional[bool], row_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType]) -> bool:
-    # None: yes if every row vector is a `row` output of this package's samplers (csc=False: nondecreasing by construction)
+def _resolve_grouped(grouped: Optional[bool], scatter: List[Tensor]) -> bool:
+    # None: yes if every scatter vector is an expanded-node output of this package's samplers (`row` for csc=False, `col`
+    # for csc=True: nondecreasing by construction) that has not been written to since
     if grouped is None:
         from . import sampler
-        grouped = all(sampler.rows_are_grouped(row_dict[et]) for et in edge_types)
-    return bool(grouped) and len(edge_types) <= _GROUPED_MAX_RELATIONS
+        grouped = all(sampler.rows_are_grouped(s) for s in scatter)
+    return bool(grouped) and len(scatter) <= _GROUPED_MAX_RELATIONS
 
 
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
@@ -263,30 +291,28 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     rounded once per run, where ``scatter_sum`` rounds once per destination.  Under
     ``torch.use_deterministic_algorithms(True)`` the atomic-free chain (:func:`rgcn_layer`) runs instead.
 
-    ``grouped=True`` promises that every ``row_dict[et]`` is NONDECREASING -- true for what ``hetero_neighbor_sample`` /
-    ``neighbor_sample`` return (``csc=False``: the edges of a relation come grouped by the node they were sampled for).
-    The default ``None`` means: yes, if every ``row_dict[et]`` IS such an output (the very tensor objects
-    ``pyg_lib_amd.sampler`` returned: ``sampler.rows_are_grouped``), so the usual pipeline sampler -> layer takes the
-    atomic-free kernel without a flag; copies, slices and hand-made edge lists take the atomic kernel unless promised.
+    ``grouped=True`` promises that every relation's SCATTER vector (``row_dict[et]`` for ``csc=False``, ``col_dict[et]``
+    for ``csc=True``: :func:`edge_roles`) is NONDECREASING -- true for what ``hetero_neighbor_sample`` /
+    ``neighbor_sample`` return (the edges of a relation come grouped by the node they were sampled for).
+    The default ``None`` means: yes, if every such vector IS a sampler output (the very tensor objects
+    ``pyg_lib_amd.sampler`` returned, not written to since: ``sampler.rows_are_grouped``), so the usual pipeline
+    sampler -> layer takes the atomic-free kernel without a flag; copies, slices, tensors modified in place and
+    hand-made edge lists take the atomic kernel unless promised.
     Then the forward is the ATOMIC-FREE kernel (``PYG_HIP_RGCN_GROUPED``, csrc/hip/rgcn_grouped.h): a workgroup owns 32
     output rows, sums every row's source features in fp32 in edge order, multiplies the sums of a relation with its
     weight in one MFMA tile and writes each row once -- no zero fill, no atomics, the same bits on every run (also the
     path under ``torch.use_deterministic_algorithms(True)``), feature sums and results rounded once each.  The promise is
     verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``)."""
     total = offsets['__total__']
-    grouped = _resolve_grouped(grouped, row_dict, edge_types)
+    roles = [edge_roles(et, row_dict, col_dict, csc) for et in edge_types]
+    grouped = _resolve_grouped(grouped, [r[2] for r in roles])
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
     if not _fusable(x, weight, grouped) or (torch.are_deterministic_algorithms_enabled() and not grouped):
         return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
-    gather, scatter, goff, soff = [], [], [], []
-    for et in edge_types:
-        src, _, dst = et
-        row_t, col_t = (src, dst) if not csc else (dst, src)
-        gather.append(col_dict[et])
-        scatter.append(row_dict[et])
-        goff.append(offsets[col_t])
-        soff.append(offsets[row_t])
+    gather, scatter = [r[0] for r in roles], [r[2] for r in roles]
+    goff, soff = [offsets[r[1]] for r in roles], [offsets[r[3]] for r in roles]
+    _last_path[0] = 'grouped' if grouped else 'atomic'
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         return _RGCNFused.apply(x, weight, total, goff, soff, grouped, *gather, *scatter)
     out = _fresh_out(x, total, weight.size(-1), grouped)
@@ -309,7 +335,8 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     feature table that requires a gradient (:class:`_RGCNFusedTables`).  ``grouped=True``: the atomic-free kernel, see
     :func:`rgcn_layer_fused`."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
-    grouped = _resolve_grouped(grouped, row_dict, edge_types)
+    roles = [edge_roles(et, row_dict, col_dict, csc) for et in edge_types]
+    grouped = _resolve_grouped(grouped, [r[2] for r in roles])
     f0 = feat_dict[node_types[0]]
     feats = [feat_dict[t] for t in node_types]
     nids = [node_id_dict[t] for t in node_types]
@@ -323,14 +350,9 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
         return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc, grouped)
     tidx = {t: i for i, t in enumerate(node_types)}
-    gather, scatter, gtype, soff = [], [], [], []
-    for et in edge_types:
-        src, _, dst = et
-        row_t, col_t = (src, dst) if not csc else (dst, src)
-        gather.append(col_dict[et])
-        scatter.append(row_dict[et])
-        gtype.append(tidx[col_t])
-        soff.append(off[row_t])
+    gather, scatter = [r[0] for r in roles], [r[2] for r in roles]
+    gtype, soff = [tidx[r[1]] for r in roles], [off[r[3]] for r in roles]
+    _last_path[0] = 'grouped' if grouped else 'atomic'
     if needs_grad:
         return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, grouped, *feats, *nids, *gather, *scatter)
     out = _fresh_out(f0, off['__total__'], weight.size(-1), grouped)

@@ -6,7 +6,8 @@ behind them is this repository's: the operators ``torch.ops.pyg.neighbor_sample`
 ``hetero_neighbor_sample`` are registered by ``libpyg.so`` and run the whole multi-hop expansion -- sampling,
 first-occurrence relabelling, per-hop bookkeeping -- on the HIP device that holds the graph.  The random
 stream is the global CPU generator's (continued on the device), so ``torch.manual_seed(s)`` reproduces the
-reference's samples bit for bit.  There is no CPU path: CPU tensors are refused by the dispatcher.
+reference's samples bit for bit.  CPU tensors take the ``CPU`` dispatch key's restatement of the same drivers
+(csrc/binding/pyg_binding_cpu.cpp: host logic for tests and tooling, not a performance path).
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -24,26 +25,29 @@ HeteroOut = Tuple[Dict[EdgeType, Tensor], Dict[EdgeType, Tensor], Dict[NodeType,
                   Optional[Dict[EdgeType, Tensor]], Dict[NodeType, List[int]], Dict[EdgeType, List[int]]]
 
 
-# ---- which tensors are `row` outputs of these samplers ------------------------------------------------------------------
-# With csc=False the samplers emit a relation's edges grouped by the node they were sampled for, so `row` is nondecreasing.
+# ---- which tensors are expanded-node outputs of these samplers -------------------------------------------------------
+# The samplers emit a relation's edges grouped by the node they were sampled FOR, so the vector of expanded nodes -- `row`
+# with csc=False, `col` with csc=True (pyg_lib/csrc/sampler/cpu/neighbor_kernel.cpp:147-159) -- is nondecreasing.
 # pyg_lib_amd.rgcn's fused layer has an atomic-free kernel for exactly that (grouped=True); so that the usual pipeline
-# sampler -> layer gets it without a flag, the wrappers below remember the row tensors they hand out (by identity, weakly:
-# a copy, a slice or a tensor moved to another device is a new tensor and not remembered; the kernel verifies the order
-# on the device in any case).
-_grouped_rows: Dict[int, "weakref.ref"] = {}
+# sampler -> layer gets it without a flag, the wrappers below remember those tensors as they hand them out: by identity,
+# weakly, together with the tensor's version counter -- a copy, a slice or a tensor moved to another device is a new
+# tensor and not remembered, and one written to in place afterwards (`sort_`, `copy_`, `t[mask] = ...`) no longer counts
+# (the kernel verifies the order on the device in any case).
+_grouped_rows: Dict[int, Tuple["weakref.ref", int]] = {}
 
 
 def _mark_grouped(t: Optional[Tensor]) -> None:
     if t is not None:
         key = id(t)
-        _grouped_rows[key] = weakref.ref(t, lambda _r, k=key: _grouped_rows.pop(k, None))
+        _grouped_rows[key] = (weakref.ref(t, lambda _r, k=key: _grouped_rows.pop(k, None)), t._version)
 
 
 def rows_are_grouped(t: Tensor) -> bool:
-    r"""True if `t` is (the very tensor object of) a ``row`` output of one of this module's samplers called with
-    ``csc=False`` -- nondecreasing by construction."""
-    r = _grouped_rows.get(id(t))
-    return r is not None and r() is t
+    r"""True if `t` is (the very tensor object of) an expanded-node output of one of this module's samplers -- ``row`` of a
+    ``csc=False`` call, ``col`` of a ``csc=True`` call: nondecreasing by construction -- and has not been modified in
+    place since it was returned."""
+    e = _grouped_rows.get(id(t))
+    return e is not None and e[0]() is t and e[1] == t._version
 
 
 def neighbor_sample(rowptr: Tensor, col: Tensor, seed: Tensor, num_neighbors: List[int],
@@ -70,8 +74,7 @@ def neighbor_sample(rowptr: Tensor, col: Tensor, seed: Tensor, num_neighbors: Li
     args = (rowptr, col, seed, num_neighbors, node_time, edge_time, seed_time, edge_weight, csc, replace,
             directed, disjoint, temporal_strategy, return_edge_id)
     out = torch.ops.pyg.neighbor_sample(*args)
-    if not csc:
-        _mark_grouped(out[0])
+    _mark_grouped(out[1] if csc else out[0])
     return out
 
 
@@ -110,9 +113,8 @@ def hetero_neighbor_sample(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[E
         _to_rel_keys(num_neighbors_dict), node_time_dict, _to_rel_keys(edge_time_dict), seed_time_dict,
         _to_rel_keys(edge_weight_dict), csc, replace, directed, disjoint, temporal_strategy, return_edge_id)
     rows, cols, node_ids, edge_ids, nodes_per_hop, edges_per_hop = out
-    if not csc:
-        for t in rows.values():
-            _mark_grouped(t)
+    for t in (cols if csc else rows).values():
+        _mark_grouped(t)
 
     def to_edge_keys(d):
         return None if d is None else {back[k]: v for k, v in d.items()}
@@ -140,9 +142,8 @@ def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], nu
         rowptr, col, seeds, num_neighbors, generator_seeds, node_time, edge_time, seed_times, edge_weight, csc, replace,
         directed, disjoint, temporal_strategy, return_edge_id)
     nph, eph = nph.tolist(), eph.tolist()
-    if not csc:
-        for t in rows:
-            _mark_grouped(t)
+    for t in (cols if csc else rows):
+        _mark_grouped(t)
     return [(rows[b], cols[b], nodes[b], eids[b] if return_edge_id else None, nph[b], eph[b]) for b in range(len(seeds))]
 
 
@@ -161,10 +162,9 @@ def hetero_neighbor_sample_batched(rowptr_dict: Dict[EdgeType, Tensor], col_dict
         node_types, edge_types, _to_rel_keys(rowptr_dict), _to_rel_keys(col_dict), seed_dicts,
         _to_rel_keys(num_neighbors_dict), generator_seeds, csc, replace, disjoint, return_edge_id)
 
-    if not csc:
-        for d in rows:
-            for t in d.values():
-                _mark_grouped(t)
+    for d in (cols if csc else rows):
+        for t in d.values():
+            _mark_grouped(t)
 
     def to_edge_keys(d):
         return {back[k]: v for k, v in d.items()}

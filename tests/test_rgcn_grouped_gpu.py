@@ -389,14 +389,15 @@ def test_sampler_rows_take_the_atomic_free_kernel_by_default():
     copies = {e: row_d[e].clone() for e in MAG_ETS}
     rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, copies, col_d, MAG_ETS, W)             # copies: the atomic kernel
     assert 'pyg_hip_rgcn_fused' in diagnostics.last_accumulate_info()
-    # csc=True swaps the roles: those rows are the sampled neighbours, not grouped, not remembered
+    # csc=True: `row` holds the sampled neighbours (not grouped, not remembered), `col` the expanded nodes (remembered)
     n = 3000
     deg = torch.randint(0, 9, (n,), generator=torch.Generator().manual_seed(2))
     ptr = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]).cuda()
     idx = torch.randint(0, n, (int(deg.sum()),), generator=torch.Generator().manual_seed(3)).cuda()
     sd = torch.arange(0, 200, 5).cuda()
     assert sampler.rows_are_grouped(sampler.neighbor_sample(ptr, idx, sd, [4, 3])[0])
-    assert not sampler.rows_are_grouped(sampler.neighbor_sample(ptr, idx, sd, [4, 3], csc=True)[0])
+    oc = sampler.neighbor_sample(ptr, idx, sd, [4, 3], csc=True)
+    assert not sampler.rows_are_grouped(oc[0]) and sampler.rows_are_grouped(oc[1]) and bool((oc[1][1:] >= oc[1][:-1]).all())
     torch.cuda.synchronize()
     assert rgcn.pending_index_error() == 0
 
