@@ -287,6 +287,56 @@ def make_mag_graph(device, seed=0):
     return rp, cl
 
 
+def make_mag_graph_csc(device, seed=0):
+    """The same edge counts as CSC (pointer over the DST nodes, values = SRC ids): what the reference's own MAG benchmark
+    feeds hetero_neighbor_sample(csc=True) (benchmark/sampler/hetero_neighbor.py:106-124)."""
+    g = torch.Generator(device=device).manual_seed(seed + 7)
+    cp, rw = {}, {}
+    for s, r, d, e in MAG_RELS:
+        dst = torch.randint(0, MAG_SIZES[d], (e,), device=device, generator=g)
+        deg = torch.bincount(dst, minlength=MAG_SIZES[d])
+        cp[(s, r, d)] = torch.cat([deg.new_zeros(1), deg.cumsum(0)])
+        rw[(s, r, d)] = torch.randint(0, MAG_SIZES[s], (e,), device=device, generator=g)
+    return cp, rw
+
+
+def leg_c5_csc(device, feat, W, seeds, iters, F, esz):
+    """C5 as the reference's benchmark runs it: csc=True.  `col` holds the expanded (dst-typed) nodes -- nondecreasing, so
+    the layer takes the atomic-free kernel by default (grouped=None resolves through the sampler's registry)."""
+    from pyg_lib_amd import sampler, rgcn
+    types = list(MAG_SIZES)
+    ets = [(s, r, d) for s, r, d, _ in MAG_RELS]
+    cp, rw = make_mag_graph_csc(device)
+    fan = {e: [15, 10] for e in ets}
+
+    def one(i):
+        out = sampler.hetero_neighbor_sample(cp, rw, {'paper': seeds[i]}, fan, csc=True)
+        return out, rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, csc=True)
+
+    for i in range(3):
+        out, _ = one(i)
+    path = rgcn.last_layer_path()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3, 3 + iters):
+        out, _ = one(i)
+    torch.cuda.synchronize()
+    total_ms = (time.perf_counter() - t0) / iters * 1e3
+    t0 = time.perf_counter()
+    for i in range(3, 3 + iters):
+        sampler.hetero_neighbor_sample(cp, rw, {'paper': seeds[i]}, fan, csc=True)
+    torch.cuda.synchronize()
+    samp_ms = (time.perf_counter() - t0) / iters * 1e3
+    layer_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, csc=True), iters)
+    torch.cuda.synchronize()
+    e = sum(v.numel() for v in out[0].values())
+    n = sum(v.numel() for v in out[2].values())
+    return dict(what='the same step with csc=True (CSC graph: pointer over dst nodes; col = expanded nodes, row = sampled '
+                     'neighbours; out[col] += x[row] @ W_r)', layer_path=path, layer_index_check=rgcn.pending_index_error(),
+                sampler_mode=sampler.last_mode(), edges_last_batch=e, nodes_last_batch=n, ms_end_to_end=round(total_ms, 4),
+                ms_sampler=round(samp_ms, 4), layer=_rate(e * (F * esz + 16) + n * F * esz + len(ets) * F * F * esz, layer_ms))
+
+
 def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=True):
     from pyg_lib_amd import sampler, rgcn
     types = list(MAG_SIZES)
@@ -365,6 +415,7 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     f32_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=True), iters)
     f32_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=False), max(2, iters // 3))
     del feat4
+    csc_leg = leg_c5_csc(device, feat, W, seeds, iters, F, W.element_size())
     grouped_was = grouped
     grouped = not grouped_was
     other_ms = _event_ms(lambda: layer(out), iters)   # the other kernel (atomic adds into a zero-filled output / atomic-free)
@@ -383,7 +434,7 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
                 batched=dict(K=K, ms_sampler_per_batch=round(samp_b_ms, 4), ms_end_to_end_per_batch=round(total_b_ms, 4),
                              what='hetero_neighbor_sample_batched (K batches per call) + one fused layer per batch'),
-                layer=_rate(alg, layer_ms),
+                layer=_rate(alg, layer_ms), csc=csc_leg,
                 layer_f256=dict(_rate(e * (F2 * esz + 16) + n * F2 * esz + len(ets) * F2 * F2 * esz, f256_ms),
                                 what='the same sample with F = 256 (rgcn_layer_fused_tables, grouped=True)',
                                 three_op_chain_ms=round(f256_chain_ms, 4)),
