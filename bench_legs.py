@@ -415,6 +415,12 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     f32_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=True), iters)
     f32_chain_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat4, out[2], types, out[0], out[1], ets, W4, grouped=False), max(2, iters // 3))
     del feat4
+    # the reductions' dim_size (ops/scatter.cpp:156-160): only the EXPANDED nodes can receive anything -- rows behind them are
+    # neither computed nor zero-filled (reported beside `layer`, with its own algorithmic bytes)
+    expanded = {t: int(sum(out[4][t][:-1])) for t in types}
+    trim_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=grouped,
+                                                           num_out_rows=expanded), iters)
+    n_trim = sum(expanded.values())
     csc_leg = leg_c5_csc(device, feat, W, seeds, iters, F, W.element_size())
     grouped_was = grouped
     grouped = not grouped_was
@@ -434,7 +440,11 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
                 ms_end_to_end=round(total_ms, 4), ms_sampler=round(samp_ms, 4), edges_per_s=round(edges / iters / (total_ms * 1e-3)),
                 batched=dict(K=K, ms_sampler_per_batch=round(samp_b_ms, 4), ms_end_to_end_per_batch=round(total_b_ms, 4),
                              what='hetero_neighbor_sample_batched (K batches per call) + one fused layer per batch'),
-                layer=_rate(alg, layer_ms), csc=csc_leg,
+                layer=_rate(alg, layer_ms),
+                layer_trimmed=dict(_rate(e * (F * esz + 16) + n_trim * F * esz + len(ets) * F * F * esz, trim_ms), out_rows=n_trim,
+                                   what='the same layer with num_out_rows = the expanded nodes per type (dim_size): the '
+                                        'zero rows of the last hop\'s discoveries are not written'),
+                csc=csc_leg,
                 layer_f256=dict(_rate(e * (F2 * esz + 16) + n * F2 * esz + len(ets) * F2 * F2 * esz, f256_ms),
                                 what='the same sample with F = 256 (rgcn_layer_fused_tables, grouped=True)',
                                 three_op_chain_ms=round(f256_chain_ms, 4)),

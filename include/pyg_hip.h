@@ -57,13 +57,14 @@ typedef enum {
 
 /* Version of THIS interface: bumped whenever a signature or the meaning of an argument changes, so that a caller built
  * against an older header can tell (pyg_hip_abi_version() != the PYG_HIP_ABI_VERSION it was compiled with).
+ *   7: round 6 -- pyg_hip_rgcn_relation::scatter_rows (rows of the relation's destination segment).
  *   6: round 5 -- PYG_HIP_RGCN_GROUPED + pyg_hip_rgcn_grouped_workspace_size (atomic-free fused layer), PYG_HIP_SCATTER_DETERMINISTIC.
  *   5: round 5 -- pyg_hip_hetero_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
  *      pyg_hip_rgcn_fused became a bit field), pyg_hip_set_float_atomic_mode, pyg_hip_atomic_selftest,
  *      pyg_hip_sampler_table_cache_release; the weight-gradient workspace holds partial slabs instead of an fp32 image.
  *   4: round 4 -- `flags` in front of `stream` in pyg_hip_segment_matmul / pyg_hip_grouped_matmul, `index_sorted` of
  *      pyg_hip_scatter became a bit field, pyg_hip_matmul_set_schedule / _set_f32_split removed, fp32 default = IEEE MFMAs. */
-#define PYG_HIP_ABI_VERSION 6
+#define PYG_HIP_ABI_VERSION 7
 PYG_HIP_API int pyg_hip_abi_version(void);
 /* Replaces pyg::cuda_version (pyg_lib/csrc/library.cpp:19-29): returns the HIP runtime version
  * the library was built against (HIP_VERSION), never -1. */
@@ -255,6 +256,12 @@ typedef struct {
   const int64_t* gather_map;
   int64_t x_rows;
   int64_t gather_map_len;
+  /* Rows of `out` this relation may write: [scatter_offset, scatter_offset + scatter_rows) -- the row count of its
+   * destination node type (the `dim_size` of the reference's reductions, pyg_lib/csrc/ops/scatter.cpp:156-160).  0: up to
+   * num_out_rows.  PYG_HIP_RGCN_GROUPED validates scatter_index against it (error 2) and sizes its row-start workspace by
+   * it (sum of scatter_rows over the relations instead of R x num_out_rows); the atomic kernel validates against
+   * num_out_rows only. */
+  int64_t scatter_rows;
 } pyg_hip_rgcn_relation;
 
 PYG_HIP_API size_t pyg_hip_rgcn_fused_workspace_size(int64_t num_relations, int64_t num_edges);
@@ -293,8 +300,9 @@ PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
  *     travels through LDS in 128 x 128 chunks; 64: masked lanes); dtype may also be PYG_F32 with K = M = 128 (fp32 sums and
  *     fp32 FMAs);
  *   - the same bits on every run; rounding: the per-relation feature sum and the result are each rounded once;
- *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of `out` at and behind every
- *     relation's scatter_offset: row starts, touched only where edges arrive);
+ *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of every relation's destination
+ *     segment -- scatter_rows, or the rows of `out` at and behind its scatter_offset if that is 0: row starts, touched
+ *     only where edges arrive);
  *   - fewer than 2^31 rows of `out` and edges per relation (PYG_HIP_ERR_UNSUPPORTED otherwise);
  *   - with _CHECKED / _DEFERRED the promise is verified on the device: a descent in a scatter_index is error 3
  *     (PYG_HIP_ERR_INVALID "not grouped"; the result of such a call is unspecified but every access stays in bounds),

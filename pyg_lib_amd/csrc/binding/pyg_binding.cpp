@@ -325,14 +325,15 @@ static at::Tensor rgcn_workspace(const std::vector<pyg_hip_rgcn_relation>& rels,
 
 Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, const at::TensorList scatter_index,
                          at::IntArrayRef gather_offset, at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out,
-                         bool grouped) {
+                         bool grouped, at::OptionalIntArrayRef scatter_rows) {
   PYG_TRACE("pyg::rgcn_fused");
   // packed 16-bit atomic adds: the result depends on the order they land in (pyg_lib_amd.rgcn takes the atomic-free
   // three-op chain under torch.use_deterministic_algorithms(True) instead of calling this operator); grouped: no atomics
   if (!grouped) at::globalContext().alertNotDeterministic("pyg::rgcn_fused");
   const size_t R = gather_index.size();
-  TORCH_CHECK(scatter_index.size() == R && gather_offset.size() == R && scatter_offset.size() == R,
-              "rgcn_fused: one gather / scatter index vector and offset per relation expected");
+  TORCH_CHECK(scatter_index.size() == R && gather_offset.size() == R && scatter_offset.size() == R &&
+                  (!scatter_rows.has_value() || scatter_rows->size() == R),
+              "rgcn_fused: one gather / scatter index vector and offset (and scatter_rows entry) per relation expected");
   TORCH_CHECK(x.is_cuda() && weight.is_cuda() && out.is_cuda() && x.device() == weight.device() && x.device() == out.device(),
               "rgcn_fused: tensors must live on the same HIP device");
   TORCH_CHECK(x.dim() == 2 && out.dim() == 2 && weight.dim() == 3 && (size_t)weight.size(0) == R &&
@@ -356,6 +357,7 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
     rels[r].num_edges = g.numel();
     rels[r].gather_offset = gather_offset[r];
     rels[r].scatter_offset = scatter_offset[r];
+    rels[r].scatter_rows = scatter_rows.has_value() ? (*scatter_rows)[r] : 0;
     rels[r].weight = static_cast<const char*>(wc.data_ptr()) + (int64_t)r * wc.size(1) * wc.size(2) * wc.element_size();
     E += g.numel();
     keep.push_back(g);
@@ -374,13 +376,15 @@ Tensor rgcn_fused_kernel(const Tensor& x, const at::TensorList gather_index, con
 // computes, minus the ATen gathers, the cat and the [sum n_t, K] intermediate.
 Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList node_id, at::IntArrayRef gather_type,
                                 const at::TensorList gather_index, const at::TensorList scatter_index,
-                                at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out, bool grouped) {
+                                at::IntArrayRef scatter_offset, const Tensor& weight, Tensor out, bool grouped,
+                                at::OptionalIntArrayRef scatter_rows) {
   PYG_TRACE("pyg::rgcn_fused_tables");
   if (!grouped) at::globalContext().alertNotDeterministic("pyg::rgcn_fused_tables");  // (see rgcn_fused_kernel)
   const size_t R = gather_index.size(), T = feat.size();
   TORCH_CHECK(T > 0 && node_id.size() == T, "rgcn_fused_tables: one node-id vector per feature table expected");
-  TORCH_CHECK(scatter_index.size() == R && gather_type.size() == R && scatter_offset.size() == R,
-              "rgcn_fused_tables: one gather type, gather / scatter index vector and offset per relation expected");
+  TORCH_CHECK(scatter_index.size() == R && gather_type.size() == R && scatter_offset.size() == R &&
+                  (!scatter_rows.has_value() || scatter_rows->size() == R),
+              "rgcn_fused_tables: one gather type, gather / scatter index vector and offset (and scatter_rows entry) per relation expected");
   const Tensor& f0 = feat[0];
   TORCH_CHECK(f0.is_cuda() && weight.is_cuda() && out.is_cuda() && f0.device() == weight.device() && f0.device() == out.device(),
               "rgcn_fused_tables: tensors must live on the same HIP device");
@@ -414,6 +418,7 @@ Tensor rgcn_fused_tables_kernel(const at::TensorList feat, const at::TensorList 
     rels[r].num_edges = g.numel();
     rels[r].gather_offset = 0;
     rels[r].scatter_offset = scatter_offset[r];
+    rels[r].scatter_rows = scatter_rows.has_value() ? (*scatter_rows)[r] : 0;
     rels[r].weight = static_cast<const char*>(wc.data_ptr()) + (int64_t)r * wc.size(1) * wc.size(2) * wc.element_size();
     rels[r].x = fc[t].data_ptr();
     rels[r].gather_map = nc[t].data_ptr<int64_t>();
@@ -1222,10 +1227,11 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   // this build only: fused R-GCN aggregation (gather -> per-relation matmul -> scatter-add), csrc/hip/rgcn.hip
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused(Tensor x, Tensor[] gather_index, Tensor[] scatter_index, int[] gather_offset, "
-      "int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False) -> Tensor(a!)"));
+      "int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False, int[]? scatter_rows = None) -> Tensor(a!)"));
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::rgcn_fused_tables(Tensor[] feat, Tensor[] node_id, int[] gather_type, Tensor[] gather_index, "
-      "Tensor[] scatter_index, int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False) -> Tensor(a!)"));
+      "Tensor[] scatter_index, int[] scatter_offset, Tensor weight, Tensor(a!) out, bool grouped = False, "
+      "int[]? scatter_rows = None) -> Tensor(a!)"));
   // this build only: grouped_matmul writing into a caller-provided [sum rows, M] pool (sharded driver)
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::grouped_matmul_pool(Tensor[] input, Tensor[] other, Tensor(a!) pool) -> Tensor[]"));

@@ -485,8 +485,8 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     if (rels[r].num_edges >= (1LL << 31) - 64)
       return fail(PYG_HIP_ERR_UNSUPPORTED, "rgcn_fused: grouped mode handles fewer than 2^31 edges per relation");
     if (rels[r].num_edges > 0) {
-      PYG_HIP_REQUIRE(rels[r].scatter_offset >= 0 && rels[r].scatter_offset < num_out_rows,
-                      "rgcn_fused: relation %lld: scatter_offset outside of 'out'", (long long)r);
+      PYG_HIP_REQUIRE(rels[r].scatter_offset >= 0 && rels[r].scatter_offset < num_out_rows && rels[r].scatter_rows >= 0,
+                      "rgcn_fused: relation %lld: scatter_offset outside of 'out' (or negative scatter_rows)", (long long)r);
       PYG_HIP_REQUIRE((rels[r].x ? rels[r].x_rows : num_x_rows) > 0, "rgcn_fused: relation %lld gathers from an empty table", (long long)r);
     }
     E += rels[r].num_edges;
@@ -534,7 +534,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     big = big || hr[r].x_rows * (int64_t)(K * esz) >= (1LL << 32);
     hp[r] = e;
     e += rels[r].num_edges;
-    const int64_t span = rels[r].num_edges > 0 ? num_out_rows - rels[r].scatter_offset : 0;
+    const int64_t span = grouped_span(rels[r], num_out_rows);
     ho[r] = rp_entries;
     hs[r] = span;
     rp_entries += span;

@@ -47,7 +47,7 @@ struct GroupedDesc {
   const RelDev* rels;        // R > kRgcnInline: the records and the three vectors below live in the workspace
   const int64_t* eprefix;    // [R + 1] running edge count
   const int64_t* rp_off;     // [R] first entry of the relation's row starts in `rp`
-  const int64_t* span;       // [R] rows of `out` at and behind the relation's scatter_offset
+  const int64_t* span;       // [R] rows of the relation's destination segment (scatter_rows; 0: `out` at and behind its scatter_offset)
   int32_t* rp;               // row starts: rp[rp_off[r] + d] = first edge of relation r with scatter index d (only for d that occur)
   int32_t* meta;             // [2 r] the first, [2 r + 1] the last scatter index of relation r (written by the row-start launch)
   uint64_t* long_rows;       // == call_id: some row of this call has more than 16 edges (set by the row-start launch; the
@@ -635,12 +635,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   rgcn_grouped_body<false, true, BIG, INL, 4, 2, 2, true>(desc, R, out, out_rows, error);
 }
 
+// rows of `out` relation r may write: its destination segment (scatter_rows), cut at the end of `out`
+inline int64_t grouped_span(const pyg_hip_rgcn_relation& rel, int64_t out_rows) {
+  if (rel.num_edges <= 0) return 0;
+  const int64_t to_end = out_rows - rel.scatter_offset;
+  const int64_t span = rel.scatter_rows > 0 ? std::min(rel.scatter_rows, to_end) : to_end;
+  return span > 0 ? span : 0;
+}
+
 size_t grouped_workspace_bytes(const pyg_hip_rgcn_relation* rels, int64_t R, int64_t out_rows) {
   size_t rp = 0;
-  for (int64_t r = 0; r < R; ++r) {
-    const int64_t span = out_rows - rels[r].scatter_offset;
-    if (rels[r].num_edges > 0 && span > 0) rp += (size_t)span;
-  }
+  for (int64_t r = 0; r < R; ++r) rp += (size_t)grouped_span(rels[r], out_rows);
   const size_t Rz = (size_t)std::max<int64_t>(R, 1);
   return align_up(sizeof(RelDev) * Rz, 256) + align_up(sizeof(int64_t) * (3 * Rz + 1), 256) + align_up(sizeof(int32_t) * 2 * Rz, 256) + 256 +
          align_up(sizeof(int32_t) * rp, 256);

@@ -72,6 +72,39 @@ def edge_roles(et: EdgeType, row_dict: Dict[EdgeType, Tensor], col_dict: Dict[Ed
     return col_dict[et], dst, row_dict[et], src
 
 
+def out_offsets(offsets: Dict[str, int], num_out_rows: Optional[Dict[str, int]]) -> Dict[str, int]:
+    r"""Row layout of the layer's OUTPUT.  ``None``: the layout of `x` (every sampled node gets a row).  Otherwise the
+    reference's ``dim_size`` (pyg_lib/csrc/ops/scatter.cpp:156-160: the caller sizes the reduction's output), per node
+    type: type ``t`` gets ``num_out_rows[t]`` rows (types not named: none) in the order of `offsets`, and rows behind them
+    are neither computed nor zero-filled -- a layer only needs the nodes that were EXPANDED (they come first in every
+    type's list: ``sum(num_sampled_nodes_per_hop[t][:-1])``), the last hop's discoveries receive nothing."""
+    if num_out_rows is None:
+        return offsets
+    types = sorted((t for t in offsets if t != '__total__'), key=lambda t: offsets[t])
+    for t in num_out_rows:
+        if t not in offsets:
+            raise ValueError(f"num_out_rows names an unknown node type '{t}'")
+    return type_offsets({t: int(num_out_rows.get(t, 0)) for t in types}, types)
+
+
+def _scatter_rows(ooff: Dict[str, int], roles, edge_types: List[EdgeType]) -> List[int]:
+    # rows of every relation's destination type = the bound of its scatter index (pyg_hip_rgcn_relation::scatter_rows; 0
+    # would mean "up to the end of out" there: a relation WITH edges into a type without rows is refused here)
+    trows = _type_rows(ooff)
+    srows = [trows[r[3]] for r in roles]
+    for et, r, n in zip(edge_types, roles, srows):
+        if n == 0 and r[2].numel() > 0:
+            raise RuntimeError(f"rgcn_layer: {et} has edges into node type '{r[3]}', which has no output rows (num_out_rows)")
+    return srows
+
+
+def _type_rows(offsets: Dict[str, int]) -> Dict[str, int]:
+    # rows of every node type in an offsets dict (types in offset order; the last one ends at '__total__')
+    types = sorted((t for t in offsets if t != '__total__'), key=lambda t: offsets[t])
+    ends = [offsets[t] for t in types[1:]] + [offsets['__total__']]
+    return {t: e - offsets[t] for t, e in zip(types, ends)}
+
+
 class _GatherRows(torch.autograd.Function):
     r"""``x[index]`` for an UNSORTED index: forward = the ``gather_coo`` kernel, backward = ``scatter_sum`` of the
     gradient.  ``pyg::gather_coo``'s own autograd formula is ``segment_sum_coo`` -- the reference's
@@ -92,7 +125,7 @@ class _GatherRows(torch.autograd.Function):
 
 def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
-               csc: bool = False) -> Tensor:
+               csc: bool = False, num_out_rows: Optional[Dict[str, int]] = None) -> Tensor:
     r"""out[row] += x[col] @ weight[r] (``csc=True``: out[col] += x[row] @ weight[r]) over every sampled edge of every
     relation r -- messages flow from the sampled neighbours to the nodes they were sampled for.
 
@@ -102,17 +135,24 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
         row_dict, col_dict: local indices from ``hetero_neighbor_sample`` called with the same `csc`.
         edge_types: relation order; ``weight[i]`` belongs to ``edge_types[i]``.
         weight: ``[R, F_in, F_out]``.
+        num_out_rows: rows of the output per node type (:func:`out_offsets`; a scatter index at or behind its type's
+            count is an error, as a ``dim_size`` that is too small is for ``scatter_sum``).
     Returns:
-        ``[sum_t n_t, F_out]`` aggregated messages (same type layout as `x`).
+        ``[sum_t n_t, F_out]`` aggregated messages (same type layout as `x`), or ``[sum_t num_out_rows[t], F_out]``.
     """
     _last_path[0] = 'chain'
+    ooff = out_offsets(offsets, num_out_rows)
     counts, gather_idx, scatter_idx = [0], [], []
     for et in edge_types:
         g, g_t, s, s_t = edge_roles(et, row_dict, col_dict, csc)
         counts.append(counts[-1] + g.numel())
         gather_idx.append(g + offsets[g_t] if offsets[g_t] else g)
-        scatter_idx.append(s + offsets[s_t] if offsets[s_t] else s)
-    total = offsets['__total__']
+        if num_out_rows is not None and s.numel() and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # (the chain's scatter would otherwise write another type's rows; the fused kernels check on the device)
+            if int(s.max()) >= int(num_out_rows.get(s_t, 0)):
+                raise RuntimeError(f"rgcn_layer: a scatter index of {et} is not below num_out_rows['{s_t}']")
+        scatter_idx.append(s + ooff[s_t] if ooff[s_t] else s)
+    total = ooff['__total__']
     if counts[-1] == 0:
         return x.new_zeros(total, weight.size(-1))
     gidx = torch.cat(gather_idx)
@@ -195,11 +235,11 @@ class _RGCNFused(torch.autograd.Function):
     ops/autograd/scatter_kernel.cpp ScatterSum) with the [E, F] intermediates of the dX path never materialised."""
 
     @staticmethod
-    def forward(ctx, x, weight, total, goff, soff, grouped, *index):
+    def forward(ctx, x, weight, total, goff, soff, grouped, srows, *index):
         R = len(index) // 2
         gather, scatter = list(index[:R]), list(index[R:])
         out = _fresh_out(x, total, weight.size(-1), grouped)
-        torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped)
+        torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped, srows)
         ctx.save_for_backward(x, weight, *index)
         ctx.meta = (goff, soff, R)
         return out
@@ -221,7 +261,7 @@ class _RGCNFused(torch.autograd.Function):
                 gw = torch.zeros_like(weight)
             else:
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(x, gidx), ptr, ops.gather_coo(grad_out, sidx))
-        return (gx, gw, None, None, None, None) + (None,) * len(index)
+        return (gx, gw, None, None, None, None, None) + (None,) * len(index)
 
 
 class _RGCNFusedTables(torch.autograd.Function):
@@ -231,14 +271,14 @@ class _RGCNFusedTables(torch.autograd.Function):
     fallback ``cat([feat[t][node_id[t]]])``."""
 
     @staticmethod
-    def forward(ctx, weight, T, gtype, soff, grouped, *tensors):
+    def forward(ctx, weight, T, gtype, soff, grouped, out_rows, srows, *tensors):
         feat, node_id = list(tensors[:T]), list(tensors[T:2 * T])
         index = tensors[2 * T:]
         R = len(index) // 2
         gather, scatter = list(index[:R]), list(index[R:])
         n_t = [t.numel() for t in node_id]
-        out = _fresh_out(feat[0], sum(n_t), weight.size(-1), grouped)
-        torch.ops.pyg.rgcn_fused_tables(feat, node_id, gtype, gather, scatter, soff, weight, out, grouped)
+        out = _fresh_out(feat[0], out_rows, weight.size(-1), grouped)
+        torch.ops.pyg.rgcn_fused_tables(feat, node_id, gtype, gather, scatter, soff, weight, out, grouped, srows)
         ctx.save_for_backward(weight, *tensors)
         ctx.meta = (T, gtype, soff, R, n_t)
         return out
@@ -266,17 +306,18 @@ class _RGCNFusedTables(torch.autograd.Function):
             else:
                 xb = torch.cat([f[n] for f, n in zip(feat, node_id)])   # the per-batch matrix the tables stand for
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(xb, gidx), ptr, ops.gather_coo(grad_out, sidx))
-        if any(ctx.needs_input_grad[5 + t] for t in range(T)):
+        if any(ctx.needs_input_grad[7 + t] for t in range(T)):
             gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, toff[-1])
             for t in range(T):
-                if ctx.needs_input_grad[5 + t]:
+                if ctx.needs_input_grad[7 + t]:
                     gfeat[t] = torch.zeros_like(feat[t]).index_add_(0, node_id[t], gx[toff[t]:toff[t + 1]])
-        return (gw, None, None, None, None) + tuple(gfeat) + (None,) * (len(tensors) - T)
+        return (gw, None, None, None, None, None, None) + tuple(gfeat) + (None,) * (len(tensors) - T)
 
 
 def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tensor],
                      col_dict: Dict[EdgeType, Tensor], edge_types: List[EdgeType], weight: Tensor,
-                     csc: bool = False, grouped: Optional[bool] = None) -> Tensor:
+                     csc: bool = False, grouped: Optional[bool] = None,
+                     num_out_rows: Optional[Dict[str, int]] = None) -> Tensor:
     r"""Same result as :func:`rgcn_layer` from ONE launch (``pyg::rgcn_fused``, csrc/hip/rgcn.hip): source rows are
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
@@ -302,27 +343,33 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     output rows, sums every row's source features in fp32 in edge order, multiplies the sums of a relation with its
     weight in one MFMA tile and writes each row once -- no zero fill, no atomics, the same bits on every run (also the
     path under ``torch.use_deterministic_algorithms(True)``), feature sums and results rounded once each.  The promise is
-    verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``)."""
-    total = offsets['__total__']
+    verified on the device like the indices (:func:`pending_index_error` = 3 / ``PYG_HIP_RGCN_CHECK=1``).
+
+    ``num_out_rows`` (the reductions' ``dim_size``, per node type: :func:`out_offsets`): only that many rows per type are
+    computed and written -- on a C5 batch 427 k rows exist and 29 k can receive anything; the rest of the full-size
+    result is zero rows nobody reads."""
+    ooff = out_offsets(offsets, num_out_rows)
+    total = ooff['__total__']
     roles = [edge_roles(et, row_dict, col_dict, csc) for et in edge_types]
     grouped = _resolve_grouped(grouped, [r[2] for r in roles])
     # torch.use_deterministic_algorithms(True): the fused kernel adds with packed 16-bit atomics (order-dependent); the
     # three-op chain is atomic-free in that mode (gather, per-relation MFMA tiles, scatter_sum through a stable sort)
     if not _fusable(x, weight, grouped) or (torch.are_deterministic_algorithms_enabled() and not grouped):
-        return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc)
+        return rgcn_layer(x, offsets, row_dict, col_dict, edge_types, weight, csc, num_out_rows)
     gather, scatter = [r[0] for r in roles], [r[2] for r in roles]
-    goff, soff = [offsets[r[1]] for r in roles], [offsets[r[3]] for r in roles]
+    goff, soff = [offsets[r[1]] for r in roles], [ooff[r[3]] for r in roles]
+    srows = _scatter_rows(ooff, roles, edge_types)
     _last_path[0] = 'grouped' if grouped else 'atomic'
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return _RGCNFused.apply(x, weight, total, goff, soff, grouped, *gather, *scatter)
+        return _RGCNFused.apply(x, weight, total, goff, soff, grouped, srows, *gather, *scatter)
     out = _fresh_out(x, total, weight.size(-1), grouped)
-    return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped)
+    return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped, srows)
 
 
 def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str, Tensor], node_types: List[str],
                             row_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
                             edge_types: List[EdgeType], weight: Tensor, csc: bool = False,
-                            grouped: Optional[bool] = None) -> Tensor:
+                            grouped: Optional[bool] = None, num_out_rows: Optional[Dict[str, int]] = None) -> Tensor:
     r"""The fused layer straight from the GLOBAL feature tables: what
 
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
@@ -333,8 +380,9 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
     disappear.  Returns ``[sum_t len(node_id_dict[t]), F_out]`` in ``node_types`` order.  Same conditions (16-bit,
     ``F = 128``) as :func:`rgcn_layer_fused`, otherwise the chain above runs; differentiable in ``weight`` and in every
     feature table that requires a gradient (:class:`_RGCNFusedTables`).  ``grouped=True``: the atomic-free kernel, see
-    :func:`rgcn_layer_fused`."""
+    :func:`rgcn_layer_fused`; ``num_out_rows``: rows of the output per node type (:func:`out_offsets`)."""
     off = type_offsets({t: node_id_dict[t].numel() for t in node_types}, node_types)
+    ooff = out_offsets(off, num_out_rows)
     roles = [edge_roles(et, row_dict, col_dict, csc) for et in edge_types]
     grouped = _resolve_grouped(grouped, [r[2] for r in roles])
     f0 = feat_dict[node_types[0]]
@@ -348,12 +396,13 @@ def rgcn_layer_fused_tables(feat_dict: Dict[str, Tensor], node_id_dict: Dict[str
         all(n.device == f0.device and n.dtype == torch.long and n.dim() == 1 for n in nids)
     if not ok or (torch.are_deterministic_algorithms_enabled() and not grouped):   # (deterministic mode: see rgcn_layer_fused)
         x = torch.cat([feat_dict[t][node_id_dict[t]] for t in node_types])
-        return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc, grouped)
+        return rgcn_layer_fused(x, off, row_dict, col_dict, edge_types, weight, csc, grouped, num_out_rows)
     tidx = {t: i for i, t in enumerate(node_types)}
     gather, scatter = [r[0] for r in roles], [r[2] for r in roles]
-    gtype, soff = [tidx[r[1]] for r in roles], [off[r[3]] for r in roles]
+    gtype, soff = [tidx[r[1]] for r in roles], [ooff[r[3]] for r in roles]
+    srows = _scatter_rows(ooff, roles, edge_types)
     _last_path[0] = 'grouped' if grouped else 'atomic'
     if needs_grad:
-        return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, grouped, *feats, *nids, *gather, *scatter)
-    out = _fresh_out(f0, off['__total__'], weight.size(-1), grouped)
-    return torch.ops.pyg.rgcn_fused_tables(feats, nids, gtype, gather, scatter, soff, weight, out, grouped)
+        return _RGCNFusedTables.apply(weight, len(feats), gtype, soff, grouped, ooff['__total__'], srows, *feats, *nids, *gather, *scatter)
+    out = _fresh_out(f0, ooff['__total__'], weight.size(-1), grouped)
+    return torch.ops.pyg.rgcn_fused_tables(feats, nids, gtype, gather, scatter, soff, weight, out, grouped, srows)

@@ -82,3 +82,44 @@ def test_edge_roles():
     row, col = torch.tensor([1]), torch.tensor([2])
     assert rgcn.edge_roles(et, {et: row}, {et: col}, csc=False) == (col, 'd', row, 's')
     assert rgcn.edge_roles(et, {et: row}, {et: col}, csc=True) == (row, 's', col, 'd')
+
+
+@pytest.mark.parametrize('csc', [True, False])
+def test_num_out_rows_trims_the_output_to_the_expanded_nodes(csc):
+    """`num_out_rows` = the reductions' dim_size per node type (pyg_lib/csrc/ops/scatter.cpp:156-160): rows behind it are
+    not produced; the rows in front of it equal the untrimmed result bit for bit (CPU key: the chain)."""
+    rng = np.random.default_rng(9)
+    types = ['a', 'b', 'c']
+    sizes = {'a': 30, 'b': 400, 'c': 90}
+    ets = [('a', 'r0', 'b'), ('b', 'r1', 'a'), ('b', 'r2', 'c'), ('c', 'r3', 'b'), ('b', 'r4', 'b')]
+    rp, cl = {}, {}
+    for (s, r, d) in ets:
+        p, v = (d, s) if csc else (s, d)
+        rp[(s, r, d)], cl[(s, r, d)] = random_csc(rng, sizes[p], sizes[v], 5)
+    t = torch.from_numpy
+    torch.manual_seed(3)
+    out = sampler.hetero_neighbor_sample({e: t(v) for e, v in rp.items()}, {e: t(v) for e, v in cl.items()},
+                                         {'b': t(rng.permutation(sizes['b'])[:20].astype(np.int64))}, {e: [3, 2] for e in ets}, csc=csc)
+    row_d, col_d, node_d, nph = out[0], out[1], out[2], out[4]
+    nn = {ty: node_d[ty].numel() for ty in types}
+    off = rgcn.type_offsets(nn, types)
+    expanded = {ty: int(sum(nph[ty][:-1])) for ty in types}   # the last hop's discoveries are never expanded
+    assert sum(expanded.values()) < sum(nn.values())
+    F = 8
+    x = torch.from_numpy(rng.integers(-4, 5, (off['__total__'], F)).astype(np.float32))
+    W = torch.from_numpy(rng.integers(-2, 3, (len(ets), F, F)).astype(np.float32))
+    full = rgcn.rgcn_layer(x, off, row_d, col_d, ets, W, csc=csc)
+    trim = rgcn.rgcn_layer(x, off, row_d, col_d, ets, W, csc=csc, num_out_rows=expanded)
+    ooff = rgcn.out_offsets(off, expanded)
+    assert trim.shape == (sum(expanded.values()), F) and ooff['__total__'] == trim.size(0)
+    for ty in types:
+        assert torch.equal(trim[ooff[ty]:ooff[ty] + expanded[ty]], full[off[ty]:off[ty] + expanded[ty]])
+        assert not full[off[ty] + expanded[ty]:off[ty] + nn[ty]].any()   # what the trimmed form leaves out is zero rows
+    assert torch.equal(rgcn.rgcn_layer_fused(x, off, row_d, col_d, ets, W, csc=csc, num_out_rows=expanded), trim)
+    # a count that is too small is an error, as a dim_size that is too small is for the reductions
+    small = dict(expanded)
+    small['b'] = 1
+    with pytest.raises(RuntimeError, match='num_out_rows'):
+        rgcn.rgcn_layer(x, off, row_d, col_d, ets, W, csc=csc, num_out_rows=small)
+    with pytest.raises(ValueError, match='unknown node type'):
+        rgcn.out_offsets(off, {'zzz': 3})

@@ -253,3 +253,67 @@ def test_full_size_c5_csc_sample_is_bit_exact_and_layer_matches():
     assert torch.equal(yt, rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W, csc=True))
     ya = rgcn.rgcn_layer_fused_tables(feat, node_d, types, row_d, col_d, ets, W, csc=True, grouped=False)
     assert (ya.double() - yt.double()).abs().max().item() <= 3e-2 * scale
+
+
+@pytest.mark.parametrize('csc', [True, False])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_num_out_rows_trimmed_layer_equals_the_untrimmed_rows_bit_for_bit(csc, dtype):
+    """`num_out_rows` (the reductions' dim_size, pyg_lib/csrc/ops/scatter.cpp:156-160) = the EXPANDED nodes per type: the
+    trimmed result is the untrimmed one without its zero tail -- same bits (float data: the atomic-free kernel sums in the
+    same order either way) -- through every form of the layer; the rows left out are zeros; gradients agree."""
+    from pyg_lib_amd import sampler, rgcn
+    from tests.test_rgcn_gpu import build_graph
+    rng = np.random.default_rng(3)
+    if csc:
+        ptr, idx = build_csc_graph(rng, SIZES, MAG_ETS, 12)
+    else:
+        ptr, idx = build_graph(rng, SIZES, MAG_ETS, 12)
+    seeds = {'paper': dev(rng.permutation(SIZES['paper'])[:1024].astype(np.int64))}
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in ptr.items()}, {e: dev(v) for e, v in idx.items()}, seeds,
+                                         {e: [15, 10] for e in MAG_ETS}, csc=csc)
+    row_d, col_d, node_d, nph = out[0], out[1], out[2], out[4]
+    nn = {t: node_d[t].numel() for t in MAG_TYPES}
+    expanded = {t: int(sum(nph[t][:-1])) for t in MAG_TYPES}
+    assert 0 < sum(expanded.values()) < sum(nn.values()) // 3
+    F = 128
+    g = torch.Generator(device='cuda').manual_seed(4)
+    feat = {t: torch.randn(SIZES[t], F, device='cuda', generator=g).to(dtype) for t in MAG_TYPES}
+    W = (torch.randn(len(MAG_ETS), F, F, device='cuda', generator=g) / F ** 0.5).to(dtype)
+    off = rgcn.type_offsets(nn, MAG_TYPES)
+    ooff = rgcn.out_offsets(off, expanded)
+    x = torch.cat([feat[t][node_d[t]] for t in MAG_TYPES])
+
+    def rows_match(trim, full):
+        assert trim.shape == (ooff['__total__'], F)
+        for t in MAG_TYPES:
+            assert torch.equal(trim[ooff[t]:ooff[t] + expanded[t]], full[off[t]:off[t] + expanded[t]]), t
+            assert not full[off[t] + expanded[t]:off[t] + nn[t]].any(), t
+
+    full = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W, csc=csc)
+    assert rgcn.last_layer_path() == 'grouped'
+    trim = rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W, csc=csc, num_out_rows=expanded)
+    assert rgcn.last_layer_path() == 'grouped'
+    rows_match(trim, full)
+    rows_match(rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, csc=csc, num_out_rows=expanded), full)
+    rows_match(rgcn.rgcn_layer(x, off, row_d, col_d, MAG_ETS, W, csc=csc, num_out_rows=expanded),
+               rgcn.rgcn_layer(x, off, row_d, col_d, MAG_ETS, W, csc=csc))
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    # gradients: a loss on the trimmed rows = the same loss on the untrimmed result's first rows
+    c = torch.randn(ooff['__total__'], F, device='cuda', generator=g)
+    cf = torch.zeros(off['__total__'], F, device='cuda')
+    for t in MAG_TYPES:
+        cf[off[t]:off[t] + expanded[t]] = c[ooff[t]:ooff[t] + expanded[t]]
+    grads = []
+    for nrows, cc in ((expanded, c), (None, cf)):
+        xg, wg = x.clone().requires_grad_(), W.clone().requires_grad_()
+        (rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, wg, csc=csc, num_out_rows=nrows).float() * cc).sum().backward()
+        grads.append((xg.grad, wg.grad))
+    for a, b in zip(*grads):
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * b.float().abs().max().item()
+    # a count that is too small: reported like any scatter index out of range (error 2), nothing written out of bounds
+    small = dict(expanded)
+    small['paper'] = 5
+    rgcn.rgcn_layer_fused(x, off, row_d, col_d, MAG_ETS, W, csc=csc, num_out_rows=small)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 2

@@ -383,7 +383,7 @@ def test_checked_mode_reports_bad_indices(monkeypatch):
         _fields_ = [('gather_index', ctypes.c_void_p), ('scatter_index', ctypes.c_void_p), ('num_edges', ctypes.c_int64),
                     ('gather_offset', ctypes.c_int64), ('scatter_offset', ctypes.c_int64), ('weight', ctypes.c_void_p),
                     ('x', ctypes.c_void_p), ('gather_map', ctypes.c_void_p), ('x_rows', ctypes.c_int64),
-                    ('gather_map_len', ctypes.c_int64)]
+                    ('gather_map_len', ctypes.c_int64), ('scatter_rows', ctypes.c_int64)]
 
     L.pyg_hip_rgcn_fused_workspace_size.restype = ctypes.c_size_t
     L.pyg_hip_rgcn_fused_workspace_size.argtypes = [ctypes.c_int64, ctypes.c_int64]
