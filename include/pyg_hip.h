@@ -445,6 +445,19 @@ PYG_HIP_API int pyg_hip_sampler_table_cache(int64_t limit);
  * from); returns how many stay (busy ones).  The cache holds at most 8 tables of <= 128 MiB per device; an idle table
  * of another node count is evicted when a new size needs room. */
 PYG_HIP_API int pyg_hip_sampler_table_cache_release(const pyg_hip_sampler_host* host);
+/*
+ * The random-word stream kept between calls.  A data loader samples batch after batch on ONE generator
+ * (benchmark/sampler/neighbor.py:101-121 seeds once per run): the engine a call hands back through host->mt19937 is the
+ * engine the next call presents, and the words the library generated beyond a call's own consumption are exactly the next
+ * call's words.  The fused chain keeps them per device (buffer of <= 64 MiB from host->alloc, the handed-back engine) and
+ * adopts them when the presented engine equals the kept one bit for bit: then no generation launch and no cross-stream
+ * wait lies in front of any hop, and the next round is generated in the background, two calls' worth ahead.  Any other
+ * engine (reseeded, used elsewhere in between) misses and the call starts cold -- same bits either way, the generator
+ * ends where the reference's engine leaves it.  PYG_HIP_SAMPLER_RNG_CARRY=0 disables it;
+ * pyg_hip_sampler_table_cache_release also frees the idle stream.  Counters since process start: calls that adopted a
+ * kept stream / calls that looked for one and started cold.
+ */
+PYG_HIP_API int pyg_hip_sampler_rng_carry_stats(int64_t* adopted, int64_t* cold);
 
 PYG_HIP_API int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                                const pyg_hip_relation* relations_host,

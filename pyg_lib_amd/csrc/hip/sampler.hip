@@ -1242,7 +1242,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   // The word generation (side stream).  Round 2's chain queues it behind the seed kernels (which do not need it; its
   // launches would otherwise sit in front of them on the host); the fused chain, whose hops follow each other within
   // ~40 us, needs the round's later segments as early as possible and starts it first.
-  auto start_rng = [&]() -> int {
+  auto start_rng = [&](bool prepare_only) -> int {
   if (c.host->mt19937) {
     // upper bounds of the words each hop can consume: every frontier node draws `count` 16-bit numbers
     std::vector<int64_t> spec;
@@ -1272,7 +1272,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
       if (open_ended || cum >= (double)kSpecCapWords) break;  // later frontiers are unbounded / too far ahead
       fb.swap(nf);
     }
-    int rc = rng_begin(c, rng, pinned, spec);
+    int rc = prepare_only ? rng_begin_prepare(c, rng, pinned, spec, true) : rng_begin(c, rng, pinned, spec);
     if (rc != PYG_HIP_OK) return rc;
   } else {
     // The engine constructor always prefetches one block (rand_engine.h:27-29), sampled or not.
@@ -1283,8 +1283,13 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     return PYG_HIP_OK;
   };
   pt.mark("bounds");
+  // Fused chain: the round's launches (three kernels, two events: ~12 us of host time) go BEHIND the seeds' scan launch
+  // (run_fused_chain) -- the scan is the head of the main stream's critical path and needs no random word, hop 0 needs
+  // the prefix kernel only, and the later segments have ~30 us of slack before hop 1 reads them (kernel timeline,
+  // profiles/NOTES_r6.md).  Here: engine adopted, blocks allocated, side stream ordered behind this point.
+  const bool rng_late = fused && c.host->mt19937 != nullptr;
   if (fused) {
-    int rc = start_rng();
+    int rc = start_rng(rng_late);
     if (rc != PYG_HIP_OK) return rc;
   }
   pt.mark("rng_started");
@@ -1355,8 +1360,8 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     c.release(tile_buf);
     batch0 += S;
   }
-  if (!fused) {  // the fused chain started it before the seeds (its rounds are the critical path of hops 1 ...)
-    int rc = start_rng();
+  if (!fused) {  // (the fused chain prepared it before the seeds and launches it behind their scan)
+    int rc = start_rng(false);
     if (rc != PYG_HIP_OK) return rc;
   }
   for (int t = 0; t < num_node_types; ++t) nodes_per_hop[(size_t)t].push_back(ns[(size_t)t].nodes.size);
@@ -1383,7 +1388,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   if (fused) {
     int rc = run_fused_chain(c, num_node_types, num_relations, rels, L, csc, replace, disjoint, num_batches, node_time,
                              temporal_last, seed_times, err_flag, ns, rs, eb, fbh, node_bound, rel_bound, fseeds, rng,
-                             chain,
+                             rng_late, chain,
                              static_cast<char*>(pinned) + fused_tables_offset,
                              reinterpret_cast<MtHandBack*>(static_cast<char*>(pinned) + hand_back_offset), &hand_back,
                              nodes_per_hop, pt);
@@ -2146,6 +2151,9 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   if (hand_back && hand_back->status == 0 && hand_back->n32 == rng.blocks * 256 + rng.raw_used) {
     // already on the host (it arrived with the hop totals): nothing left to wait for
     ::memcpy(c.host->mt19937, &hand_back->st, sizeof(MtDev));
+    // the words generated beyond this call's consumption are the next call's words if it presents this very engine
+    // (sampler_rng.h, RngCarry): kept, with everything still queued on the side stream completed instead of cancelled
+    if (rng_late) rng_carry_commit(c, rng, hand_back->st, hand_back->n32);
     c.quiesce_side();
   } else {
     int rc = rng_finish(c, rng);  // hand the advanced engine back
@@ -2479,8 +2487,20 @@ extern "C" int pyg_hip_sampler_table_cache_release(const pyg_hip_sampler_host* h
   }
   // (an idle entry's last user synchronised its stream before it handed the table back: nothing on the device uses it)
   for (u64* p : drop) host->free(host->user, p);
+  kept += rng_carry_release_idle(host);   // the random-word stream kept between calls (sampler_rng.h, RngCarry)
   return kept;
 }
+
+extern "C" int pyg_hip_sampler_rng_carry_stats(int64_t* adopted, int64_t* cold) {
+  PYG_HIP_REQUIRE(adopted && cold, "sampler: rng_carry_stats needs two counters");
+  long long a = 0, k = 0;
+  rng_carry_stats(&a, &k);
+  *adopted = a;
+  *cold = k;
+  return PYG_HIP_OK;
+}
+
+static thread_local bool g_lane_call = false;   // set around the per-batch calls of pyg_hip_hetero_neighbor_sample_batched
 
 extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relations,
                                               const pyg_hip_relation* relations, int num_seed_sets,
@@ -2509,6 +2529,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   Ctx c;
   c.host = host;
   c.stream = static_cast<hipStream_t>(stream_);
+  c.no_carry = g_lane_call;   // (a batched lane: every batch brings a fresh engine -- nothing to continue, nothing to keep)
   const bool allow_fast = getenv("PYG_HIP_SAMPLER_SYNC_MODE") == nullptr;  // experiment / test knob
   int rc = run_sampler(num_node_types, num_relations, relations, num_seed_sets, seeds, node_time,
                        temporal_last, L, csc, replace, disjoint, return_edge_id, c, result, allow_fast);
@@ -2537,6 +2558,20 @@ extern "C" int pyg_hip_hetero_neighbor_sample(int num_node_types, int num_relati
   c.release_all();  // scratch (and, on failure, everything)
   return rc;
 }
+
+#ifdef PYG_HIP_FOLD_TIMING
+extern "C" __attribute__((visibility("default"))) int pyg_hip_debug_fold_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fold_stamps), sizeof(unsigned long long) * 16);
+}
+extern "C" __attribute__((visibility("default"))) int pyg_hip_debug_kstamps(unsigned long long* out) {
+  unsigned n = 0;
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_kstamp_n), sizeof(unsigned));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstamps), sizeof(unsigned long long) * 128);
+  unsigned z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp_n), &z, sizeof(unsigned));
+  return (int)n;
+}
+#endif
 
 // ---- K independent calls at once ------------------------------------------------------------------------------------
 // A mini-batch is a chain of ~12 dependent launches of 10 - 45 us, most of them far too small for 256 CUs, plus ~50 us of
@@ -2664,6 +2699,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample_batched(int num_node_types, int nu
   }
   const std::function<void(int)> task = [&](int lane) {
     (void)hipSetDevice(dev);
+    g_lane_call = true;
     for (int b : lanes[(size_t)lane]) {
       pyg_hip_sample_batch& B = batches[b];
       B.status = pyg_hip_hetero_neighbor_sample(num_node_types, num_relations, relations, B.num_seed_sets, B.seeds_host,
@@ -2672,6 +2708,7 @@ extern "C" int pyg_hip_hetero_neighbor_sample_batched(int num_node_types, int nu
       B.mode = g_sampler_mode;
       if (B.status != PYG_HIP_OK) snprintf(B.error, sizeof(B.error), "%s", last_error_buffer());
     }
+    g_lane_call = false;
   };
   SamplePool::get().run((int)lanes.size(), task);
   for (int b = 0; b < num_batches; ++b)

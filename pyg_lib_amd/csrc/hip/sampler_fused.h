@@ -478,6 +478,20 @@ __device__ __forceinline__ void fused_tables_init(const FTables& tb, int i) {
   if (i == 0) *tb.wide = 0;
 }
 
+#ifdef PYG_HIP_FOLD_TIMING  // experiment builds only: 100 MHz stamps of the seeds launch's phases (thread 0)
+__device__ unsigned long long g_fold_stamps[16];
+__device__ unsigned long long g_kstamps[2 * 64];
+__device__ unsigned int g_kstamp_n;
+__device__ __forceinline__ void dbg_kstamp(unsigned long long id) {
+  const unsigned i = atomicAdd(&g_kstamp_n, 1u) & 63u;
+  g_kstamps[2 * i] = id;
+  g_kstamps[2 * i + 1] = wall_clock64();
+}
+#define PYG_FOLD_STAMP(i) do { if (FOLD && threadIdx.x == 0) g_fold_stamps[i] = wall_clock64(); } while (0)
+#else
+#define PYG_FOLD_STAMP(i) do { } while (0)
+#endif
+
 template <int NC, bool FOLD, bool I64>
 __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart& pt, int lt, int nblocks) {
   typedef FusedAgg<NC> T;
@@ -499,6 +513,7 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
     bt[k] = 0;
     v[k] = Op::identity();
   }
+  PYG_FOLD_STAMP(0);
   if constexpr (FOLD) {
     const FSeedFold& f = L.fold;
     const int cells = max((L.tb.L + 1) * L.tb.T, L.tb.L * L.tb.R);
@@ -508,6 +523,7 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
       f.ts->size = n;
       f.ts->slice_e = n;
     }
+    PYG_FOLD_STAMP(1);
     if (base < n) {
 #pragma unroll
       for (int k = 0; k < kScanItems; ++k) {
@@ -526,10 +542,15 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
         }
       }
     }
-    // every initialising store and every insertion has been performed before anybody reads a table value or
-    // overwrites a table cell (the segment's totals go where the initialisation wrote)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    // every initialising store and every insertion has been performed before anybody (of this single block) reads a table
+    // value or overwrites a table cell (the segment's totals go where the initialisation wrote).  Workgroup scope: the wait
+    // for the stores' and atomics' acknowledgements in front of the barrier is what orders them -- the insertions are
+    // agent-scope atomics and the reads below agent-scope atomic loads, both performed at L2; an AGENT-scope fence here
+    // additionally wrote back and invalidated this XCD's whole L2 (whatever the previous kernels left dirty in it).
+    PYG_FOLD_STAMP(2);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
+    PYG_FOLD_STAMP(3);
   }
   T agg = Op::identity();
   if (base < n) {
@@ -570,8 +591,10 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
       agg = op(agg, v[k]);
     }
   }
+  PYG_FOLD_STAMP(4);
   T total;
   T run = block_exclusive<T, Op>(agg, lds, op, &total);
+  PYG_FOLD_STAMP(5);
   T before = Op::identity();
   if constexpr (!FOLD) {
     // Aggregates travel as relaxed agent-scope atomics of self-validating words (rank + 1, edges + 1, a pure table has
@@ -617,6 +640,7 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
   const int64_t size0 = pt.h.seeds ? 0 : *pt.h.size_in;
   const int64_t id0 = pt.h.seeds ? 0 : size0 - *pt.h.dup;
   run = op(before, run);
+  PYG_FOLD_STAMP(6);
   if (pt.last && lt == nblocks - 1 && tid == 0) {
     const T grand = op(before, total);
     if (pt.h.seeds) {
@@ -655,6 +679,10 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
     }
     run = op(run, v[k]);
   }
+  PYG_FOLD_STAMP(7);
+#ifdef PYG_HIP_FOLD_TIMING
+  if (FOLD && threadIdx.x == 0) dbg_kstamp(999);
+#endif
 }
 
 // ---- sample: relation e of hop l; everything position-dependent is resolved from the tables ------------------------
@@ -787,6 +815,9 @@ template <int GMAX, bool I64>
 __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L, int64_t avail_blocks,
                                                            const u64* __restrict__ words) {
   const int bx = (int)blockIdx.x;
+#ifdef PYG_HIP_FOLD_TIMING
+  if (bx == 0 && threadIdx.x == 0) dbg_kstamp(100 + GMAX);
+#endif
   int k = 0;
 #pragma unroll
   for (int j = 0; j < 2 * kMaxParts + 2; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
@@ -871,6 +902,9 @@ constexpr int kScanReduce = 0, kScanApply = 1, kScanOnePass = 2, kScanSeedFold =
 template <int MAXNC, int MODE, bool I64>
 __global__ __launch_bounds__(256) void fused_scan_kernel(const FScanLaunch L) {
   int bx = (int)blockIdx.x;
+#ifdef PYG_HIP_FOLD_TIMING
+  if (bx == 0 && threadIdx.x == 0) dbg_kstamp(200 + 10 * MAXNC + MODE);
+#endif
   if constexpr (MODE == kScanOnePass) {
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = (int)__hip_atomic_fetch_add(L.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -81,7 +81,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
                     int64_t* seed_times, int* err_flag, std::vector<NodeSet>& ns, std::vector<RelState>& rs,
                     const std::vector<std::vector<int64_t>>& eb, const std::vector<std::vector<int64_t>>& fbh,
                     const std::vector<int64_t>& node_bound, const std::vector<int64_t>& rel_bound,
-                    const std::vector<FusedSeed>& fseeds, RngHost& rng, ChainState* chain, char* tables_host,
+                    const std::vector<FusedSeed>& fseeds, RngHost& rng, bool rng_late, ChainState* chain, char* tables_host,
                     MtHandBack* hand_back_host, MtHandBack** hand_back_out,
                     std::vector<std::vector<int64_t>>& nodes_per_hop, PhaseTimer& pt) {
   hipStream_t stream = c.stream;
@@ -379,6 +379,11 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     }
     if (rc != PYG_HIP_OK) return rc;
   }
+  if (rng_late) {  // the first round of the word generation, behind the seeds' launch (run_sampler: rng_begin_prepare)
+    int rc = rng_begin_launch(c, rng);
+    if (rc != PYG_HIP_OK) return rc;
+    pt.mark("rng_launched");
+  }
 
   // ---- hops ----
   struct Step {
@@ -557,6 +562,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       }
     }
     int rc = launch_sample(fin);
+    if (rc != PYG_HIP_OK) return rc;
+  }
+  if (rng_late) {  // a carried stream that covers this call: its next round (for the NEXT call) goes out now, off the critical path
+    int rc = rng_topup_deferred(c, rng);
     if (rc != PYG_HIP_OK) return rc;
   }
   pt.lap(4);

@@ -72,6 +72,7 @@ __device__ __forceinline__ uint32_t mt_output_at(const uint32_t* __restrict__ ou
 
 // ---- host context ---------------------------------------------------------------------------------
 void dense_cache_release(void* ptr);  // sampler.hip
+void rng_carry_abandon(int device);   // sampler_rng.hip
 
 struct Ctx {
   const pyg_hip_sampler_host* host;
@@ -84,6 +85,15 @@ struct Ctx {
     (void)hipStreamSynchronize(side);
     side = nullptr;
   }
+  void finish_side() {            // wait WITHOUT cancelling: what was queued is completed (the stream carry keeps it)
+    if (!side) return;
+    (void)hipStreamSynchronize(side);
+    side = nullptr;
+  }
+  // Random-word stream carried over from the previous call on this device (sampler_rng.hip, RngCarry): -1 none, else the
+  // device whose carry this call has adopted and must either commit (rng_carry_commit) or give back (release_all).
+  int carry_device = -1;
+  bool no_carry = false;          // this call never adopts / leaves a carry (batched lanes: a fresh engine per batch)
   std::vector<void*> live;  // every block obtained from host->alloc and not yet handed out/freed
   void* alloc(size_t bytes) {
     void* p = host->alloc(host->user, bytes ? bytes : 16);
@@ -106,6 +116,8 @@ struct Ctx {
     live.clear();
     for (void* p : cached_tables) dense_cache_release(p);
     cached_tables.clear();
+    if (carry_device >= 0) rng_carry_abandon(carry_device);   // adopted but not committed (a failed or repeated call)
+    carry_device = -1;
   }
 };
 
@@ -140,8 +152,12 @@ int get_side_stream(SideStream** out);
 
 struct RngHost {
   int64_t blocks = 0;         // 128-word blocks consumed (prefetched, in the reference's terms) so far
-  u64* dev = nullptr;         // device copy of all blocks
-  int64_t dev_cap_blocks = 0;
+  u64* dev = nullptr;         // device copy of all blocks (word 0 of THIS call)
+  u64* dev_base = nullptr;    // the allocation `dev` points into (== dev unless the stream was carried over)
+  int64_t dev_cap_blocks = 0; // blocks from `dev` to the end of the allocation
+  bool carried = false;       // this call continues the previous call's stream (RngCarry): outputs [0, marks[0].upto32)
+                              // were complete before it started
+  bool topup_deferred = false;  // carried and fully covered: the next round is queued behind the call's last launch
   int64_t word = 0;           // engine state: linear word index
   int units = 4;              //               16-bit units left in that word
   int64_t raw_used = 0;       // generator outputs consumed directly so far (biased sampling's uniform_)
@@ -163,6 +179,9 @@ struct RngHost {
   };
   std::vector<Mark> marks;
   size_t waited = 0;          // marks[0 .. waited) are already ordered before the main stream
+  // rng_begin in two halves (fused chain): the first round is LAUNCHED behind the seeds' scan launch of the main stream
+  hipEvent_t begin_ev = nullptr;   // main-stream point the side stream is ordered behind (block reuse)
+  int64_t begin_target32 = 0;      // outputs the first round must cover
   // outputs [0, generated32) exist once the last launched round has finished
   int64_t generated32() const { return started ? o_r0 + 624 : 0; }
 };
@@ -173,6 +192,22 @@ constexpr int64_t kSpecCapWords = (int64_t)kMtMaxSeg * kMtSeg / 2;  // one round
 int rng_generate(Ctx& c, RngHost& r, int64_t target32);
 // Start of a call: adopts the caller's engine (or the callback path) and queues the speculative first round.
 int rng_begin(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec_words);
+// The same in two halves: _prepare adopts the engine, allocates and records the main-stream point the side stream has to
+// stay behind (cheap: no launch); _launch queues the first round.  Main-stream work queued in between runs CONCURRENTLY
+// with the round (the fused chain's seeds launch: its 1024 seeds otherwise sat ~20 us of host time behind the round).
+int rng_begin_prepare(Ctx& c, RngHost& r, void* pinned, const std::vector<int64_t>& spec_words, bool allow_carry = false);
+int rng_begin_launch(Ctx& c, RngHost& r);
+// The stream carry (RngCarry, sampler_rng.hip).  A data loader calls the sampler batch after batch on ONE generator: the
+// engine a call hands back is the engine the next call presents, and the words the previous call generated beyond its
+// own consumption ARE the next call's words.  rng_carry_commit keeps them (buffer, base windows, the handed-back engine)
+// per device; rng_begin_prepare(allow_carry) adopts them when the presented engine equals the kept one bit for bit -- then
+// no generation launch and no cross-stream wait lies in front of any hop; the next round is queued in the background.
+// Any other engine (reseeded, used elsewhere in between) misses, and the call starts cold as before.
+// PYG_HIP_SAMPLER_RNG_CARRY=0 disables it.
+void rng_carry_commit(Ctx& c, RngHost& r, const MtDev& handed_back, int64_t n32);
+int rng_topup_deferred(Ctx& c, RngHost& r);
+int rng_carry_release_idle(const pyg_hip_sampler_host* host);
+void rng_carry_stats(long long* adopted, long long* cold);
 // Orders the main stream behind the generation of everything up to `last_word` / `need32` outputs.
 int rng_wait(Ctx& c, RngHost& r, int64_t last_word, int64_t* avail_blocks);
 int rng_wait32(Ctx& c, RngHost& r, int64_t need32, int64_t* avail_blocks);

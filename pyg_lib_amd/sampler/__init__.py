@@ -180,6 +180,17 @@ def release_table_cache() -> int:
     return int(torch.ops.pyg.sampler_release_table_cache())
 
 
+def rng_carry_stats() -> Tuple[int, int]:
+    """``(adopted, cold)``: sampler calls of this process that continued the random-word stream the previous call left on
+    the device (same generator, untouched in between: no generation launch in front of any hop) / that looked for one and
+    started cold (``pyg_hip_sampler_rng_carry_stats`` in include/pyg_hip.h)."""
+    import ctypes
+    from .. import _capi
+    a, k = ctypes.c_int64(0), ctypes.c_int64(0)
+    _capi.check(_capi.lib().pyg_hip_sampler_rng_carry_stats(ctypes.byref(a), ctypes.byref(k)))
+    return int(a.value), int(k.value)
+
+
 def last_mode() -> str:
     """Driver of the calling thread's last sampler call: 'fused', 'queued' or 'synchronising' (diagnostics; see
     ``pyg_hip_sampler_last_mode`` in include/pyg_hip.h)."""
@@ -191,4 +202,4 @@ def last_mode() -> str:
 
 
 __all__ = ['neighbor_sample', 'hetero_neighbor_sample', 'neighbor_sample_batched', 'hetero_neighbor_sample_batched',
-           'release_table_cache', 'last_mode']
+           'release_table_cache', 'last_mode', 'rng_carry_stats']
