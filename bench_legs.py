@@ -421,6 +421,21 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
     trim_ms = _event_ms(lambda: rgcn.rgcn_layer_fused_tables(feat, out[2], types, out[0], out[1], ets, W, grouped=grouped,
                                                            num_out_rows=expanded), iters)
     n_trim = sum(expanded.values())
+    # training step of the layer on the same sample: forward + backward (dX through the atomic-free kernel on the transposed
+    # sample -- one stable sort per sample, shared by a model's layers --, dW through the weight-gradient kernel); against
+    # round 5's backward (dX through the atomic kernel with swapped roles)
+    off_b = rgcn.type_offsets({t: out[2][t].numel() for t in types}, types)
+    xb = torch.cat([feat[t][out[2][t]] for t in types])
+    cb = torch.randn(off_b['__total__'], F, device=device).to(dtype)
+
+    def train_step():
+        xg, wg = xb.detach().requires_grad_(), W.detach().requires_grad_()
+        (rgcn.rgcn_layer_fused(xg, off_b, out[0], out[1], ets, wg, grouped=grouped) * cb).sum().backward()
+
+    fb_atomic_ms = _event_ms(train_step, iters)   # (the default: dX through the atomic kernel)
+    rgcn.set_dx_mode('grouped')
+    fb_ms = _event_ms(train_step, iters)
+    rgcn.set_dx_mode('auto')
     csc_leg = leg_c5_csc(device, feat, W, seeds, iters, F, W.element_size())
     grouped_was = grouped
     grouped = not grouped_was
@@ -444,6 +459,12 @@ def leg_c5(device, iters=10, batch=1024, F=128, dtype=torch.bfloat16, grouped=Tr
                 layer_trimmed=dict(_rate(e * (F * esz + 16) + n_trim * F * esz + len(ets) * F * F * esz, trim_ms), out_rows=n_trim,
                                    what='the same layer with num_out_rows = the expanded nodes per type (dim_size): the '
                                         'zero rows of the last hop\'s discoveries are not written'),
+                backward=dict(ms_forward_backward=round(fb_atomic_ms, 4), ms_forward_backward_atomic_free=round(fb_ms, 4),
+                              what='rgcn_layer_fused on the materialised batch features, loss = sum(y * c): forward + dX + '
+                                   'dW + the autograd glue.  Default: dX through the atomic kernel with swapped roles; '
+                                   'atomic_free: dX through the atomic-free kernel on the transposed sample (one stable '
+                                   'sort per sample, cached) -- no float atomic anywhere in the step, bit-reproducible; the '
+                                   'default under torch.use_deterministic_algorithms(True)'),
                 csc=csc_leg,
                 layer_f256=dict(_rate(e * (F2 * esz + 16) + n * F2 * esz + len(ets) * F2 * F2 * esz, f256_ms),
                                 what='the same sample with F = 256 (rgcn_layer_fused_tables, grouped=True)',

@@ -38,13 +38,18 @@ struct AccumNote {
   const char* cleared = nullptr;
   void* stream = nullptr;
   int cas = 0;
+  unsigned long long serial = 0;   // launches noted so far: two reports are equal exactly when no launch lies between them
 };
 std::mutex g_note_mu;
 AccumNote g_note;
+unsigned long long g_note_serial = 0;
+unsigned long long g_note_text_serial = 0;   // the launch the cached report text describes
+char g_note_text[512];
 }  // namespace
 void note_accumulate(const char* op, const void* ptr, size_t bytes, const char* cleared, hipStream_t stream, int cas) {
   std::lock_guard<std::mutex> lock(g_note_mu);
   g_note.op = op, g_note.ptr = ptr, g_note.bytes = bytes, g_note.cleared = cleared, g_note.stream = (void*)stream, g_note.cas = cas;
+  g_note.serial = ++g_note_serial;
 }
 
 const DeviceInfo& device_info() {
@@ -133,24 +138,29 @@ int pyg_hip_set_float_atomic_mode(int mode) {
 
 const char* pyg_hip_last_accumulate_info(void) {
   static thread_local char buf[512];
-  pyg_hip::AccumNote n;
-  {
-    std::lock_guard<std::mutex> lock(pyg_hip::g_note_mu);
-    n = pyg_hip::g_note;
-  }
+  std::lock_guard<std::mutex> lock(pyg_hip::g_note_mu);
+  const pyg_hip::AccumNote n = pyg_hip::g_note;
   if (n.op == nullptr) {
     snprintf(buf, sizeof(buf), "no atomically accumulating kernel has been launched by this process");
     return buf;
   }
-  hipPointerAttribute_t attr;
-  memset(&attr, 0, sizeof(attr));
-  const hipError_t pa = hipPointerGetAttributes(&attr, n.ptr);
-  if (pa != hipSuccess) (void)hipGetLastError();  // (a freed accumulator is not an error of the caller's next launch)
-  snprintf(buf, sizeof(buf), "%s: accumulator %p (%zu bytes; %s, device %d, managed %d, allocation flags 0x%x), cleared by %s, stream %p, %s adds",
-           n.op, n.ptr, n.bytes,
-           pa != hipSuccess ? "attributes unavailable" : (attr.type == hipMemoryTypeDevice ? "device memory" : "NOT plain device memory"),
-           pa == hipSuccess ? attr.device : -1, pa == hipSuccess ? (int)attr.isManaged : -1, pa == hipSuccess ? attr.allocationFlags : 0u,
-           n.cleared, n.stream, n.cas ? "compare-and-swap" : "hardware floating-point atomic");
+  // The text of a launch is made ONCE (its first report) and kept: the accumulator's pointer attributes are those of that
+  // moment -- asked again later they describe whoever owns the address by then (freed, reallocated), and two reports of the
+  // same launch would differ.
+  if (pyg_hip::g_note_text_serial != n.serial) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const hipError_t pa = hipPointerGetAttributes(&attr, n.ptr);
+    if (pa != hipSuccess) (void)hipGetLastError();  // (a freed accumulator is not an error of the caller's next launch)
+    snprintf(pyg_hip::g_note_text, sizeof(pyg_hip::g_note_text),
+             "%s (accumulating launch #%llu): accumulator %p (%zu bytes; %s, device %d, managed %d, allocation flags 0x%x), cleared by %s, stream %p, %s adds",
+             n.op, n.serial, n.ptr, n.bytes,
+             pa != hipSuccess ? "attributes unavailable" : (attr.type == hipMemoryTypeDevice ? "device memory" : "NOT plain device memory"),
+             pa == hipSuccess ? attr.device : -1, pa == hipSuccess ? (int)attr.isManaged : -1, pa == hipSuccess ? attr.allocationFlags : 0u,
+             n.cleared, n.stream, n.cas ? "compare-and-swap" : "hardware floating-point atomic");
+    pyg_hip::g_note_text_serial = n.serial;
+  }
+  memcpy(buf, pyg_hip::g_note_text, sizeof(buf));
   return buf;
 }
 

@@ -23,6 +23,8 @@ For edge type ``(src, rel, dst)`` ``row`` always holds local ids of ``src``-type
 
 so the type offsets never swap -- the index ROLES (gather / scatter) do (:func:`edge_roles`).
 """
+import os
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -163,6 +165,26 @@ def rgcn_layer(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType, Tens
     return ops.scatter_sum(msgs, sidx, dim=0, dim_size=total)  # [sum_t n_t, F_out]
 
 
+# dX of the fused layer: 'atomic' (the fused kernel with swapped roles and packed atomics: fastest, sums in arrival order),
+# 'grouped' (the atomic-free kernel on the transposed sample: the same bits on every run; C5: 2.1 x the atomic kernel's
+# time -- the transposed sample has ~1.3 edges per (row, relation), so W is fetched per handful of edges), 'auto' (default):
+# 'grouped' under torch.use_deterministic_algorithms(True), 'atomic' otherwise.  PYG_RGCN_DX / set_dx_mode().
+_DX_MODE = [os.environ.get('PYG_RGCN_DX', 'auto')]
+
+
+def set_dx_mode(mode: str) -> str:
+    r"""``'auto'`` | ``'grouped'`` | ``'atomic'`` (see above); returns the previous mode."""
+    if mode not in ('auto', 'grouped', 'atomic'):
+        raise ValueError("dX mode must be 'auto', 'grouped' or 'atomic'")
+    before, _DX_MODE[0] = _DX_MODE[0], mode
+    return before
+
+
+def _dx_grouped() -> bool:
+    m = _DX_MODE[0]
+    return m == 'grouped' or (m != 'atomic' and torch.are_deterministic_algorithms_enabled())
+
+
 _GROUPED_MAX_RELATIONS = 512   # kGroupedMaxRel of csrc/hip/rgcn_grouped.h: the relations' row ranges live in LDS
 
 
@@ -195,26 +217,77 @@ def _fresh_out(like: Tensor, rows: int, cols: int, grouped: bool) -> Tensor:
     return like.new_empty(rows, cols) if grouped else like.new_zeros(rows, cols)
 
 
+_flat_indices: Dict[Tuple, Tuple] = {}
+
+
 def _rel_ptr_and_indices(gather: List[Tensor], scatter: List[Tensor], goff: List[int], soff: List[int]):
+    # (relation pointer, concatenated global gather / scatter indices) of a sample: what the weight gradient and the chain
+    # need; remembered per sample like the transposed sample (identity + version, weakly) -- 2 R + 2 small launches that
+    # every layer of a model and every step on the same batch would otherwise repeat
+    key = tuple((id(t), t._version) for t in gather) + tuple((id(t), t._version) for t in scatter) + tuple(goff) + tuple(soff)
+    hit = _flat_indices.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], list(gather) + list(scatter))):
+        return hit[1]
     counts = [0]
     for g in gather:
         counts.append(counts[-1] + g.numel())
     gidx = torch.cat([g + o if o else g for g, o in zip(gather, goff)])
     sidx = torch.cat([s + o if o else s for s, o in zip(scatter, soff)])
-    return torch.tensor(counts, dtype=torch.long), gidx, sidx
+    val = (torch.tensor(counts, dtype=torch.long), gidx, sidx)
+    if len(_flat_indices) >= 8:
+        _flat_indices.pop(next(iter(_flat_indices)))
+    _flat_indices[key] = ([weakref.ref(t) for t in list(gather) + list(scatter)], val)
+    return val
+
+
+# ---- the transposed sample: every relation's edges grouped by their SOURCE row -------------------------------------------
+# The backward of the layer scatters through the forward's gather index (dX[g_e] += dOut[s_e] @ W_r^T), which is not grouped:
+# sampled neighbours come in draw order.  ONE stable sort of all relations' edges by (relation, gather index) per sample makes
+# it so -- then the atomic-free owner-computes kernel serves the backward too (no float atomics anywhere in training, the same
+# bits on every run).  The sort depends on the sample only, not on the layer: it is remembered for the tensors it was
+# made from (identity + version, weakly -- like sampler.rows_are_grouped), so the layers of a model share it.
+_transposed: Dict[Tuple, Tuple] = {}
+
+
+def _transposed_sample(gather: List[Tensor], scatter: List[Tensor], gather_rows: int):
+    key = tuple((id(t), t._version) for t in gather) + tuple((id(t), t._version) for t in scatter)
+    hit = _transposed.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], list(gather) + list(scatter))):
+        return hit[1], hit[2]
+    counts = [g.numel() for g in gather]
+    R = len(gather)
+    # key = relation * rows + gather index (< rows): relations stay in list order, edges of a relation come out grouped by
+    # source row and, inside a row, in edge order (stable)
+    keys = torch.cat([g + r * gather_rows if r else g for r, g in enumerate(gather)])
+    skeys, perm = ops.index_sort(keys, max_value=max(R * gather_rows, 1))
+    g_sorted = list(torch.split(skeys % gather_rows if R > 1 else skeys, counts))
+    s_perm = list(torch.split(torch.cat(scatter)[perm], counts))
+    if len(_transposed) >= 8:   # a handful of live samples at most
+        _transposed.pop(next(iter(_transposed)))
+    refs = [weakref.ref(t) for t in list(gather) + list(scatter)]
+    _transposed[key] = (refs, g_sorted, s_perm)
+    return g_sorted, s_perm
 
 
 def _dx_scatter(grad_out: Tensor, weight: Tensor, gather: List[Tensor], scatter: List[Tensor], goff: List[int],
-                soff: List[int], rows: int) -> Tensor:
-    r"""dX[g_e] += dOut[s_e] @ W_r^T: the atomic fused kernel with the two index vectors swapped -- the gather index of the
-    forward is the scatter index here, and it is not grouped -- or, under ``torch.use_deterministic_algorithms(True)``,
-    the atomic-free chain gather -> segment_matmul -> scatter_sum (stable sort + CSR rows)."""
+                soff: List[int], rows: int, grows: Optional[List[int]] = None) -> Tensor:
+    r"""dX[g_e] += dOut[s_e] @ W_r^T.  Shapes the atomic-free kernel takes: on the TRANSPOSED sample (edges grouped by source
+    row, :func:`_transposed_sample`) with the two index roles swapped and W_r^T as weight -- no atomics, bit-reproducible.
+    That is the path under ``torch.use_deterministic_algorithms(True)`` and with ``set_dx_mode('grouped')``; otherwise the
+    atomic fused kernel with swapped roles (16-bit, 128 x 128), and for the remaining shapes the chain gather ->
+    segment_matmul -> scatter_sum (atomic-free in deterministic mode: stable sort + CSR rows)."""
     wt = weight.transpose(1, 2).contiguous()
+    E = sum(g.numel() for g in gather)
+    if E == 0:
+        return grad_out.new_zeros(rows, weight.size(1))
+    if _dx_grouped() and _fusable(grad_out, wt, True) and len(gather) <= _GROUPED_MAX_RELATIONS:
+        g_sorted, s_perm = _transposed_sample(gather, scatter, rows)
+        gx = grad_out.new_empty(rows, weight.size(1))   # (written once per row by the grouped kernel)
+        torch.ops.pyg.rgcn_fused(grad_out, s_perm, g_sorted, soff, goff, wt, gx, True, grows)
+        return gx
     if torch.are_deterministic_algorithms_enabled() or weight.size(1) != 128 or weight.size(2) != 128 or \
             weight.dtype == torch.float32:   # (the atomic kernel: 16-bit, 128 x 128)
         ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
-        if gidx.numel() == 0:
-            return grad_out.new_zeros(rows, weight.size(1))
         msgs = ops.segment_matmul(ops.gather_coo(grad_out, sidx), ptr, wt)   # (the kernel takes any index order)
         return ops.scatter_sum(msgs, gidx, dim=0, dim_size=rows)
     gx = grad_out.new_zeros(rows, weight.size(1))   # (contiguous whatever x's strides are: the kernel accumulates into it in place)
@@ -235,13 +308,13 @@ class _RGCNFused(torch.autograd.Function):
     ops/autograd/scatter_kernel.cpp ScatterSum) with the [E, F] intermediates of the dX path never materialised."""
 
     @staticmethod
-    def forward(ctx, x, weight, total, goff, soff, grouped, srows, *index):
+    def forward(ctx, x, weight, total, goff, soff, grouped, srows, grows, *index):
         R = len(index) // 2
         gather, scatter = list(index[:R]), list(index[R:])
         out = _fresh_out(x, total, weight.size(-1), grouped)
         torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped, srows)
         ctx.save_for_backward(x, weight, *index)
-        ctx.meta = (goff, soff, R)
+        ctx.meta = (goff, soff, R, grows)
         return out
 
     @staticmethod
@@ -249,19 +322,19 @@ class _RGCNFused(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors[:2]
         index = ctx.saved_tensors[2:]
-        goff, soff, R = ctx.meta
+        goff, soff, R, grows = ctx.meta
         gather, scatter = list(index[:R]), list(index[R:])
         grad_out = grad_out.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, x.size(0))
+            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, x.size(0), grows)
         if ctx.needs_input_grad[1]:
             ptr, gidx, sidx = _rel_ptr_and_indices(gather, scatter, goff, soff)
             if gidx.numel() == 0:
                 gw = torch.zeros_like(weight)
             else:
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(x, gidx), ptr, ops.gather_coo(grad_out, sidx))
-        return (gx, gw, None, None, None, None, None) + (None,) * len(index)
+        return (gx, gw, None, None, None, None, None, None) + (None,) * len(index)
 
 
 class _RGCNFusedTables(torch.autograd.Function):
@@ -307,7 +380,7 @@ class _RGCNFusedTables(torch.autograd.Function):
                 xb = torch.cat([f[n] for f, n in zip(feat, node_id)])   # the per-batch matrix the tables stand for
                 gw = torch.ops.pyg.segment_matmul_grad_other(ops.gather_coo(xb, gidx), ptr, ops.gather_coo(grad_out, sidx))
         if any(ctx.needs_input_grad[7 + t] for t in range(T)):
-            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, toff[-1])
+            gx = _dx_scatter(grad_out, weight, gather, scatter, goff, soff, toff[-1], [max(n_t[t], 1) for t in gtype])
             for t in range(T):
                 if ctx.needs_input_grad[7 + t]:
                     gfeat[t] = torch.zeros_like(feat[t]).index_add_(0, node_id[t], gx[toff[t]:toff[t + 1]])
@@ -325,8 +398,9 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     both in {64, 128} or both in {128, 256}, or float32 with 128 / 128); anything else takes the three-op chain.
 
     Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
-    backward runs the same kernel with swapped roles for dX and the weight-gradient kernel on the gathered rows for dW
-    (:class:`_RGCNFused`).  Accumulation: messages are rounded to the storage type (what the chain materialises),
+    backward runs the fused kernel with swapped roles for dX (atomic adds; under
+    ``torch.use_deterministic_algorithms(True)`` / ``set_dx_mode('grouped')`` the atomic-free kernel on the transposed
+    sample: :func:`_dx_scatter`) and the weight-gradient kernel on the gathered rows for dW (:class:`_RGCNFused`).  Accumulation: messages are rounded to the storage type (what the chain materialises),
     summed in fp32 per run of equal destinations inside a 32-edge wave tile and added to ``out`` with one packed
     16-bit atomic per run -- a destination whose edges are split over many runs (many relations, tile boundaries) is
     rounded once per run, where ``scatter_sum`` rounds once per destination.  Under
@@ -361,7 +435,9 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     srows = _scatter_rows(ooff, roles, edge_types)
     _last_path[0] = 'grouped' if grouped else 'atomic'
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return _RGCNFused.apply(x, weight, total, goff, soff, grouped, srows, *gather, *scatter)
+        trows = _type_rows(offsets)
+        grows = [max(trows[r[1]], 1) for r in roles]   # rows of every relation's SOURCE type: the bound of the backward's scatter
+        return _RGCNFused.apply(x, weight, total, goff, soff, grouped, srows, grows, *gather, *scatter)
     out = _fresh_out(x, total, weight.size(-1), grouped)
     return torch.ops.pyg.rgcn_fused(x, gather, scatter, goff, soff, weight, out, grouped, srows)
 

@@ -549,3 +549,86 @@ def test_grouped_is_differentiable_and_runs_in_deterministic_mode():
             assert (a.float() - b.float()).abs().max().item() <= 5e-2 * a.float().abs().max().item()
     finally:
         torch.use_deterministic_algorithms(False)
+
+
+def test_backward_runs_without_float_atomics_and_is_bit_reproducible():
+    """dX scatters through the forward's GATHER index (sampled neighbours, draw order: not grouped).  One stable sort per
+    sample groups the edges by source row (rgcn._transposed_sample), and the atomic-free kernel serves the backward with
+    the roles swapped and W^T (rgcn.set_dx_mode('grouped'); the default under torch.use_deterministic_algorithms(True)):
+    no accumulating launch in forward or backward, two runs give the same bits, exact on integer data, and the sort is
+    shared by the layers of a model."""
+    from pyg_lib_amd import sampler, rgcn, diagnostics, ops
+    from tests.test_rgcn_gpu import MAG_TYPES, MAG_ETS, build_graph
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(12)
+    sizes = {'paper': 40_000, 'author': 60_000, 'institution': 900, 'field_of_study': 4_000}
+    rp, cl = build_graph(rng, sizes, MAG_ETS, 12)
+    out = sampler.hetero_neighbor_sample({e: dev(v) for e, v in rp.items()}, {e: dev(v) for e, v in cl.items()},
+                                         {'paper': dev(rng.permutation(sizes['paper'])[:1024].astype(np.int64))},
+                                         {e: [15, 10] for e in MAG_ETS})
+    row_d, col_d, node_d = out[0], out[1], out[2]
+    off = rgcn.type_offsets({t: node_d[t].numel() for t in MAG_TYPES}, MAG_TYPES)
+    F = 128
+    g = torch.Generator().manual_seed(3)
+    # integer data: x, dOut small integers, W signed permutations -> dX = sum of +-dOut entries (exact), dW small sums
+    x0 = torch.randint(-2, 3, (off['__total__'], F), generator=g).bfloat16().cuda()
+    W0 = signed_permutations(len(MAG_ETS), F, g).bfloat16().cuda()
+    c = torch.randint(-1, 2, (off['__total__'], F), generator=g).bfloat16().cuda()
+    ops.scatter_sum(torch.ones(4, 2, device='cuda'), torch.tensor([[0, 1], [1, 0], [0, 0], [1, 1]], device='cuda'), 0, None, 2)
+    marker = diagnostics.last_accumulate_info()
+    before_mode = rgcn.set_dx_mode('grouped')
+    runs = []
+    for rep in range(2):
+        xg, wg = x0.clone().requires_grad_(), W0.clone().requires_grad_()
+        y = rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, wg)
+        assert rgcn.last_layer_path() == 'grouped'
+        (y * c).sum().backward()
+        runs.append((xg.grad.clone(), wg.grad.clone()))
+    assert diagnostics.last_accumulate_info() == marker        # nothing accumulated through atomics, forward or backward
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    want = torch.zeros(off['__total__'], F, dtype=torch.float64, device='cuda')
+    for i, (s, r, d) in enumerate(MAG_ETS):
+        want.index_add_(0, col_d[(s, r, d)] + off[d], c[row_d[(s, r, d)] + off[s]].double() @ W0[i].double().t())
+    assert 4 < want.abs().max().item() <= 256
+    assert torch.equal(runs[0][0].double(), want)
+    # a second layer on the same sample reuses the sort
+    n_cached = len(rgcn._transposed)
+    xg, wg = x0.clone().requires_grad_(), W0.clone().requires_grad_()
+    (rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, wg) * c).sum().backward()
+    assert len(rgcn._transposed) == n_cached and torch.equal(xg.grad, runs[0][0])
+    # float data: against round 5's path (the atomic kernel with swapped roles) and the chain
+    g2 = torch.Generator(device='cuda').manual_seed(4)
+    xf = torch.randn(off['__total__'], F, device='cuda', generator=g2).bfloat16()
+    Wf = (torch.randn(len(MAG_ETS), F, F, device='cuda', generator=g2) / F ** 0.5).bfloat16()
+    cf = torch.randn(off['__total__'], F, device='cuda', generator=g2)
+    grads = {}
+    for mode in ('grouped', 'atomic', 'chain'):
+        xg, wg = xf.clone().requires_grad_(), Wf.clone().requires_grad_()
+        rgcn.set_dx_mode('atomic' if mode == 'atomic' else 'grouped')
+        if mode == 'chain':
+            y = rgcn.rgcn_layer(xg, off, row_d, col_d, MAG_ETS, wg)
+        else:
+            y = rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, wg)
+        (y.float() * cf).sum().backward()
+        grads[mode] = xg.grad.float()
+    rgcn.set_dx_mode(before_mode)
+    # 'auto' (the default): the atomic kernel, unless torch.use_deterministic_algorithms(True)
+    assert before_mode == 'auto'
+    xg = xf.clone().requires_grad_()
+    (rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, Wf).float() * cf).sum().backward()
+    assert 'pyg_hip_rgcn_fused' in diagnostics.last_accumulate_info()
+    marker2 = diagnostics.last_accumulate_info()
+    torch.use_deterministic_algorithms(True)
+    try:
+        det = []
+        for _ in range(2):
+            xg = xf.clone().requires_grad_()
+            (rgcn.rgcn_layer_fused(xg, off, row_d, col_d, MAG_ETS, Wf).float() * cf).sum().backward()
+            det.append(xg.grad.clone())
+        assert diagnostics.last_accumulate_info() == marker2 and torch.equal(det[0], det[1])
+        assert torch.equal(det[0].float(), grads['grouped'])
+    finally:
+        torch.use_deterministic_algorithms(False)
+    scale = grads['chain'].abs().max().item()
+    assert (grads['grouped'] - grads['chain']).abs().max().item() <= 3e-2 * scale
+    assert (grads['grouped'] - grads['atomic']).abs().max().item() <= 5e-2 * scale
