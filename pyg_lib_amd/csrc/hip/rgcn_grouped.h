@@ -246,6 +246,12 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     } else {
       g2 = g1 + rel.gather_offset;
     }
+    // (validated here, on all 64 bits: narrowed to RowT first, an index of 2^32 + k would alias row k and pass issue_rows'
+    // range check -- memory-safe, but a bad index the atomic kernel reports would go unnoticed)
+    if (CHECK && (g2 < 0 || g2 >= rel.x_rows)) {
+      *error = 1;
+      g2 = 0;
+    }
     return (RowT)g2;
   };
   u32x4 xr[U];

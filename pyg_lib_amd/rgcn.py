@@ -40,7 +40,12 @@ def pending_index_error() -> int:
     r"""The fused layer validates its gather / scatter indices on the device WITHOUT synchronising (a stale ``node_id`` is
     redirected to row 0 instead of reading out of bounds; ``PYG_HIP_RGCN_CHECK=1``: synchronising check, ``=0``: none).
     Returns and clears what the launches so far have found on the current device: 0 nothing, 1 a gather index, 2 a scatter
-    index out of range, 3 scatter indices that were promised grouped (``grouped=True``) and are not (meaningful after ``torch.cuda.synchronize()``); the next fused call raises for it otherwise."""
+    index out of range, 3 scatter indices that were promised grouped (``grouped=True``) and are not (meaningful after ``torch.cuda.synchronize()``); the next fused call raises for it otherwise.
+
+    The word is ONE per device (pinned host memory, allocated by the first fused call of the process on that device --
+    make that call outside a HIP-graph capture, e.g. in the warm-up): an error of one call is reported by whichever
+    fused call or ``pending_index_error()`` comes next on the device, from any thread or model.  Where errors must be
+    attributed to their call, use ``PYG_HIP_RGCN_CHECK=1`` (synchronising, fails in the call that has the bad index)."""
     from . import _capi
     return int(_capi.lib().pyg_hip_rgcn_pending_error())
 

@@ -137,6 +137,11 @@ def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], nu
     dependent launches overlap on the device (a single batch cannot fill 256 CUs).  The process's default generator is
     not touched.  Returns the list of the ``K`` usual 6-tuples.  ``PYG_HIP_SAMPLER_LANES`` (default 8) caps the number of
     batches in flight.
+
+    Stream contract: the outputs are allocated on the lanes' private streams and are complete when the call returns (the
+    lanes are synchronised).  Consume them on the stream that was current when the call was made (or synchronise before
+    dropping them): a later batched call orders its lanes behind the THEN-current stream before it reuses their blocks, so
+    outputs read on another stream and dropped while that read is still queued could be handed out again under it.
     """
     rows, cols, nodes, eids, nph, eph = torch.ops.pyg.neighbor_sample_batched(
         rowptr, col, seeds, num_neighbors, generator_seeds, node_time, edge_time, seed_times, edge_weight, csc, replace,

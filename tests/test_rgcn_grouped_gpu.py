@@ -632,3 +632,21 @@ def test_backward_runs_without_float_atomics_and_is_bit_reproducible():
     scale = grads['chain'].abs().max().item()
     assert (grads['grouped'] - grads['chain']).abs().max().item() <= 3e-2 * scale
     assert (grads['grouped'] - grads['atomic']).abs().max().item() <= 5e-2 * scale
+
+
+def test_gather_index_beyond_32_bits_is_reported_not_aliased():
+    """the 32-bit row arithmetic of tables below 4 GiB must not let an index of 2^32 + k pass as row k."""
+    from pyg_lib_amd import rgcn
+    et = ('a', 'r', 'a')
+    n, F = 64, 128
+    x = torch.ones(n, F, dtype=torch.bfloat16, device='cuda')
+    w = torch.eye(F, dtype=torch.bfloat16, device='cuda')[None]
+    rows = torch.tensor([0, 0, 1], device='cuda')
+    cols = torch.tensor([3, (1 << 32) + 5, 7], device='cuda')
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    torch.cuda.synchronize()
+    rgcn.pending_index_error()
+    y = rgcn.rgcn_layer_fused(x, off, {et: rows}, {et: cols}, [et], w, grouped=True)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 1
+    assert y.shape == (n, F)

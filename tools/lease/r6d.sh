@@ -1,6 +1,6 @@
 #!/bin/bash
 # trimmed layer tests + rgcn tests, host timeline of the C3 sampler, c5 leg
-R=/root/repo/gpurun_out/r6_o
+R=/root/repo/gpurun_out/r6_u
 mkdir -p $R
 cd /root/repo
 timeout 900 python -m pytest tests/test_rgcn_csc_gpu.py tests/test_rgcn_grouped_gpu.py tests/test_rgcn_gpu.py tests/test_graph_capture_gpu.py tests/test_deterministic_gpu.py -m gpu -x -q > $R/pytest_rgcn.txt 2>&1
