@@ -1148,7 +1148,7 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
   const size_t hand_back_offset =
       align_up(1024 + sizeof(HopInfo) * (size_t)std::max(num_relations * std::max(L, 1), 96), 64);
   // fused chain (sampler_fused.h): host copy of its tables
-  const size_t fused_tables_offset = align_up(hand_back_offset + sizeof(MtHandBack), 256);
+  const size_t fused_tables_offset = align_up(hand_back_offset + sizeof(MtHandBack), 256) + 256;   // (the 64 bytes in front: its completion word)
   const size_t fused_tables_bytes =
       align_up(8 * (size_t)(L + 1) * num_node_types + 8 * (size_t)num_node_types + 20 * (size_t)std::max(L, 1) * num_relations + 64, 256);
   void* pinned = nullptr;
@@ -2156,10 +2156,12 @@ int run_sampler(int num_node_types, int num_relations, const pyg_hip_relation* r
     if (rng_late) rng_carry_commit(c, rng, hand_back->st, hand_back->n32);
     c.quiesce_side();
   } else {
+    c.main_idle = false;          // (the hand-back below is queued on the main stream: the closing synchronisation stays)
     int rc = rng_finish(c, rng);  // hand the advanced engine back
     if (rc != PYG_HIP_OK) return rc;
   }
-  PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  // (fused chain, nothing queued behind its closing launch: that launch was seen to finish -- run_fused_chain)
+  if (!(c.main_idle && !disjoint)) PYG_HIP_CHECK(hipStreamSynchronize(stream));
   pt.lap(7);
   return PYG_HIP_OK;
 }

@@ -86,6 +86,11 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
                     std::vector<std::vector<int64_t>>& nodes_per_hop, PhaseTimer& pt) {
   hipStream_t stream = c.stream;
   const int R = num_relations, T = num_node_types;
+  // completion word of the closing launch (pinned; polled at the end: see there).  A fresh sequence number per call.
+  static std::atomic<unsigned long long> done_counter{0};
+  unsigned long long* done_word = reinterpret_cast<unsigned long long*>(tables_host - 64);
+  const unsigned long long done_seq = 0x5eed000000000000ull | (done_counter.fetch_add(1) + 1);
+  *done_word = 0;
   auto tiles_of = [](int64_t n) { return (int)((n + kScanTile - 1) / kScanTile); };
   auto src_of = [&](int e) { return !csc ? rels[e].src_type : rels[e].dst_type; };
   auto dst_of = [&](int e) { return !csc ? rels[e].dst_type : rels[e].src_type; };
@@ -544,6 +549,8 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     fin.fold.tables_host = tables_host;
     fin.fold.tables_dev = tb_dev;
     fin.fold.tables_bytes = (int)tb_bytes;
+    fin.fold.done = done_word;
+    fin.fold.done_seq = done_seq;
     *hand_back_out = nullptr;
     if (rng.engine) {
       const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
@@ -570,7 +577,23 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   }
   pt.lap(4);
   pt.mark("all_queued");
-  PYG_HIP_CHECK(hipStreamSynchronize(stream));
+  {
+    // The closing launch writes `done_seq` behind the tables and the engine hand-back (pinned memory): seen here ~2 us after
+    // it is written, where the wake-up out of hipStreamSynchronize takes 6 - 8.  Everything the call queued lies in front of
+    // that launch on the stream; scratch goes back to a stream-ordered allocator.  A poll that outlasts 5 ms (a long
+    // queue in front of this call, a fault) falls back to the synchronisation, which also surfaces the error.
+    const auto t_poll = std::chrono::steady_clock::now();
+    bool seen = false;
+    unsigned spins = 0;
+    while (!seen) {
+      seen = __atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq;
+      if (!seen && (++spins & 1023u) == 0 &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_poll).count() > 5.0)
+        break;
+    }
+    if (!seen) PYG_HIP_CHECK(hipStreamSynchronize(stream));
+    c.main_idle = true;
+  }
   pt.lap(5);
   pt.mark("synced");
   if (err_flag)

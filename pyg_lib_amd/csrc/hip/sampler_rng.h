@@ -93,6 +93,8 @@ struct Ctx {
   // Random-word stream carried over from the previous call on this device (sampler_rng.hip, RngCarry): -1 none, else the
   // device whose carry this call has adopted and must either commit (rng_carry_commit) or give back (release_all).
   int carry_device = -1;
+  bool main_idle = false;         // the fused chain saw its closing launch finish (completion word) and queued nothing since:
+                                  // the call's last hipStreamSynchronize would only pay the wake-up again
   bool no_carry = false;          // this call never adopts / leaves a carry (batched lanes: a fresh engine per batch)
   std::vector<void*> live;  // every block obtained from host->alloc and not yet handed out/freed
   void* alloc(size_t bytes) {
