@@ -272,7 +272,7 @@ def main():
     traffic = None
     traffic_source = None
     if world == 1 and args.scale == 1.0 and args.dtype == 'bf16':
-        for name in ('r5_segment_matmul_c2_pmc.json', 'r4_segment_matmul_c2_pmc.json', 'r3_segment_matmul_c2_pmc.json', 'r2_segment_matmul_c2_pmc.json',
+        for name in ('r6_segment_matmul_c2_pmc.json', 'r5_segment_matmul_c2_pmc.json', 'r4_segment_matmul_c2_pmc.json', 'r3_segment_matmul_c2_pmc.json', 'r2_segment_matmul_c2_pmc.json',
                      'r1_segment_matmul_c2_pmc.json'):
             pmc = os.path.join(ROOT, 'profiles', name)
             if not os.path.exists(pmc):
