@@ -93,18 +93,30 @@ struct FConsumer {  // a relation of the NEXT hop that expands the segment's nod
   RngTab* tabp;       //                                  exclusive prefix of the RNG tables
 };
 
+struct LastTile {
+  u64 bits[16];        // bit b of word j: position 64 j + b of the tile is the first occurrence of a new node
+  uint32_t before[16]; // first occurrences of the tile in front of word j
+};
+
 struct FSegHdr {  // one node type in one phase: the emissions of every relation that appends to it, in relation order
   u64* vals;
-  u64 prov;                // value coding of the type's table (HashTable::prov / tag)
+  u64 prov;                // value coding of the type's table (HashTable::prov / tag / idmask)
   u64 tag;
+  u64 idmask;
   int64_t* nodes;
   int64_t* batch;          // disjoint: batch ids of the list, else nullptr
   const int64_t* size_in;  // hop: &size_at[l * T + t]; seeds: nullptr
   int64_t* size_out;       // hop: &size_at[(l + 1) * T + t]; seeds: &size_at[t]
   int64_t* dup;            // &dup[t]
   void* tile_agg;          // FusedAgg<NC>[tiles of all parts] (one-pass scan: zeroed at the start of the call)
+  // last hop (fused_last_*): per tile of the segment the bitmap of its first occurrences + their count in front of every
+  // 64-position word, and the tile's count -- written by the first pass, read by the second (no zeroing needed)
+  struct LastTile* last_meta;
+  uint32_t* last_cnt;
+  int ntiles;              // tiles of the segment
   int seeds;
   int ncons;
+  int pad;
 };
 
 struct FPart {  // one relation's emissions of the hop (or one seed set); carries its segment's header
@@ -133,6 +145,19 @@ struct FSeedFold {  // seeds launch of a call whose seeds are ONE tile: the tabl
   int disjoint;
 };
 
+struct FFoldRec {  // what the fold role hands to the host, straight into pinned memory (no copies behind the last launch)
+  MtHandBack* hb;            // engine hand-back (nullptr: the caller's engine is not device-resident)
+  int64_t a0, generated32;   // mt_finish_chain_kernel's arguments
+  char* tables_host;         // copy of the write-once tables
+  const char* tables_dev;
+  int tables_bytes;
+  int pad;
+  // completion word in pinned memory: set to `done_seq` when everything above has been written -- the host polls it
+  // instead of waiting for the stream (the wake-up of hipStreamSynchronize costs 6 - 8 us of a ~180 us call)
+  unsigned long long* done;
+  unsigned long long done_seq;
+};
+
 struct FScanLaunch {  // kernel argument of a phase's scan (one pass; or the reduce / apply pair)
   FTables tb;
   unsigned* ticket;        // one-pass scan: blocks take their position in the launch from here (zeroed with the aggregates)
@@ -144,7 +169,15 @@ struct FScanLaunch {  // kernel argument of a phase's scan (one pass; or the red
   int nc[kMaxParts + 1];   // consumers of the part's segment; -1: the carry block
   FPart part[kMaxParts];
   FConsumer cons[kMaxLaunchCons];
+  int64_t* out_col[kMaxParts];   // last hop (fused_last_apply): base of the part's relation's `col` output
+  // last hop: the closing role (engine position, tables and hand-back to pinned memory, completion word) rides in the
+  // second pass as one more block (item nc == -2): it needs nothing the other blocks of that launch produce -- the hop's
+  // node counts are the sums of the tile counts the FIRST pass wrote
+  ChainState* chain;
+  FFoldRec closing;
+  const u64* words;
 };
+static_assert(sizeof(FScanLaunch) <= 4096, "launch records travel in the kernel argument");
 
 struct FSampleRec {  // sampling of relation e in hop l: what does not depend on the tables
   const int64_t* nodes;  // src node list
@@ -175,18 +208,6 @@ struct FFinalRec {  // local ids of relation e's emissions of hop l
 
 enum FRole { kRoleSample8 = 0, kRoleSample16, kRoleSample32, kRoleSample64, kRoleFinalize, kRoleFold, kRoleSampleWave };
 
-struct FFoldRec {  // what the fold role hands to the host, straight into pinned memory (no copies behind the last launch)
-  MtHandBack* hb;            // engine hand-back (nullptr: the caller's engine is not device-resident)
-  int64_t a0, generated32;   // mt_finish_chain_kernel's arguments
-  char* tables_host;         // copy of the write-once tables
-  const char* tables_dev;
-  int tables_bytes;
-  int pad;
-  // completion word in pinned memory: set to `done_seq` when everything above has been written -- the host polls it
-  // instead of waiting for the stream (the wake-up of hipStreamSynchronize costs 6 - 8 us of a ~180 us call)
-  unsigned long long* done;
-  unsigned long long done_seq;
-};
 
 struct FSampleLaunch {  // kernel argument of [finalize(l - 1) | sample(l)] (+ the engine fold behind the last hop)
   FTables tb;
@@ -267,6 +288,17 @@ __device__ __forceinline__ int64_t part_count(const FScanLaunch& L, const FPart&
   const int over = L.tb.overflow[pt.tot_index];
   const int64_t edges = L.tb.tot[pt.tot_index].edges;
   return __builtin_amdgcn_readfirstlane(over) ? 0 : edges;
+}
+
+// where relation e's `col` of hop `ell` starts inside its output: behind its edges of the hops before (every lane the same)
+__device__ __forceinline__ int64_t part_col_offset(const FScanLaunch& L, const FPart& pt) {
+  const int lane = threadIdx.x & 63;
+  const int e = pt.tot_index - L.ell * L.tb.R;
+  int64_t mine = 0;
+  if (lane < L.ell) mine = L.tb.tot[lane * L.tb.R + e].edges;
+  int64_t off = 0;
+  for (int h = 0; h < L.ell; ++h) off += __shfl(mine, h);
+  return off;
 }
 
 template <int NC>
@@ -689,6 +721,285 @@ __device__ __forceinline__ void fused_onepass(const FScanLaunch& L, const FPart&
 #endif
 }
 
+// The closing role: engine position of the call folded over all (hop, relation) totals, the write-once tables and the engine
+// hand-back copied into pinned host memory (kernels write there directly: no copy launch behind the last hop) ...
+__device__ __forceinline__ void fused_fold_tables(const FTables& tb, ChainState* chain, const FFoldRec& fold, const u64* words) {
+  __shared__ int64_t fold_word;
+  if (threadIdx.x == 0) {
+    int64_t w = tb.word0;
+    int u = tb.units0;
+    bool ab = false;
+    for (int q = 0; q < tb.L * tb.R; ++q) {
+      const CountAgg t = tb.tot[q];
+      if (t.edges > 0) {
+        const int u0 = u;
+        w += tab_dw(t.tab, u0);
+        u = tab_nb(t.tab, u0);
+      }
+      ab = ab || tb.overflow[q] != 0;
+    }
+    chain->word = w;
+    chain->units = u;
+    chain->abort = ab ? 1 : 0;
+    fold_word = w;
+  }
+  __syncthreads();
+  if (fold.tables_host) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fold.tables_dev);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(fold.tables_host);
+    for (int i = threadIdx.x; i < fold.tables_bytes / 4; i += 256) dst[i] = src[i];
+  }
+  if (fold.hb) {  // mt_finish_chain_kernel (sampler_rng.hip), with the position just folded
+    MtHandBack* hb = fold.hb;
+    const uint32_t* out32 = reinterpret_cast<const uint32_t*>(words);
+    const int64_t a0 = fold.a0;
+    const int64_t n32 = (fold_word / 128 + 1) * 256;
+    int status = 0;
+    const int64_t mp = n32 - a0;
+    const int64_t k = (mp + 623) / 624;
+    if (n32 <= a0) status = 2;
+    else if (a0 + 624 * k > fold.generated32) status = 1;
+    if (status == 0) {
+      const int64_t o0 = a0 + 624 * (k - 1);
+      for (int i = threadIdx.x; i < 624; i += 256) hb->st.state[i] = mt_untemper(mt_output_at(out32, o0 + i));
+      if (threadIdx.x == 0) {
+        const int64_t nx = mp - 624 * (k - 1);
+        hb->st.next = (uint32_t)nx;
+        hb->st.left = (int32_t)(625 - nx);
+      }
+    }
+    if (threadIdx.x == 0) {
+      hb->n32 = n32;
+      hb->status = status;
+    }
+  }
+}
+// ... and, when everything the host reads is written (system scope), the word it waits for
+__device__ __forceinline__ void fused_fold_done(const FFoldRec& fold) {
+  if (fold.done) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(fold.done, fold.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- the LAST hop: two passes, no table writes, no finalize ---------------------------------------------------------------
+// The nodes the last hop discovers are never expanded: nobody looks them up in the table afterwards.  So the hop's
+// bookkeeping needs neither the apply pass's ~E random table stores nor the finalize role's ~E random table gathers:
+//   pass 1 (fused_last_reduce): one table gather per emission, as in fused_reduce; what it finds goes into the emission's
+//     cache word -- 1 = first occurrence (the table holds this very position), (id << 2) | 2 = a node of an earlier hop (the
+//     table holds its final id), (q << 2) = a node first seen at position q of THIS hop -- and, per tile, into a bitmap of
+//     the first occurrences with their counts in front of every 64-position word (LastTile) and the tile's count;
+//   pass 2 (fused_last_apply): every block scans the segment's tile counts (<= 8192 values, L2-resident), then knows the
+//     rank of ANY position of the hop from two small reads -- rank(q) = tiles in front + LastTile::before[word] +
+//     popcount(bits below q) -- and with it the local id of every emission: first occurrences append their node and
+//     write `col`, nodes of earlier hops write `col`, in-hop duplicates compute their owner's rank.  ~200 bytes per tile
+//     (C3: 140 KB) are what the duplicates read at random, instead of the 19.6 MB table.
+// Tiles are STRIPED (thread t holds positions t, t + 256, ...): a wave's ballot over item i IS bitmap word 4 i + wave.
+// C3: reduce 13.6 + apply 15.5 + finalize 14.3 us -> see profiles/NOTES_r6.md section 2f.
+__global__ __launch_bounds__(256) void fused_last_reduce_kernel(const FScanLaunch L) {
+  __shared__ uint32_t s_cnt[16];
+  const int bx = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxParts + 1; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
+  const int lt = bx - (k > 0 ? L.cum[k - 1] : 0);
+  const FPart& pt = L.part[k];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = part_count(L, pt);
+  const int64_t base = (int64_t)lt * kScanTile;
+  const u64 provbit = pt.h.prov ^ pt.h.tag;
+  u64 sl[kScanItems], vv[kScanItems];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) sl[i] = 0, vv[i] = 0;
+  if (base < n) {
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      const int64_t p = base + i * kScanThreads + tid;
+      sl[i] = pt.slots[p < n ? p : n - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) vv[i] = pt.h.vals[sl[i]];
+  }
+  LastTile* meta = pt.h.last_meta + (pt.tile0 + lt);
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const int64_t p = base + i * kScanThreads + tid;
+    const bool first = p < n && vv[i] == pt.h.prov + (u64)(pt.pos_base + p);
+    const u64 m = __ballot(first);
+    if (p < n) {
+      u64 word = 1ull;
+      if (!first) word = (vv[i] & provbit) == 0 ? (((vv[i] & pt.h.idmask) << 2) | 2ull) : ((vv[i] - pt.h.prov) << 2);
+      pt.cache[p] = word;
+    }
+    if (lane == 0) {
+      meta->bits[i * 4 + wave] = m;
+      s_cnt[i * 4 + wave] = (uint32_t)__popcll(m);
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {   // counts in front of every word: word order = position order
+    const uint32_t v = s_cnt[tid];
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (tid >= d) incl += up;
+    }
+    meta->before[tid] = incl - v;
+    if (tid == 15) pt.h.last_cnt[pt.tile0 + lt] = incl;
+  }
+}
+
+constexpr int kLastMaxTiles = 8192;   // tiles of a segment (fused_eligible): their counts are scanned in LDS by every block
+
+__global__ __launch_bounds__(256) void fused_last_apply_kernel(const FScanLaunch L) {
+  __shared__ uint32_t s_tp[kLastMaxTiles];   // tiles in front of tile t: first occurrences
+  __shared__ uint32_t s_red[8];
+  __shared__ uint32_t s_cnt[16], s_pre[16];
+  const int bx = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxParts + 1; ++j) k += (j < L.n - 1 && bx >= L.cum[j]) ? 1 : 0;
+  const int first_blk = k > 0 ? L.cum[k - 1] : 0;
+  const int lt = bx - first_blk;
+  const int nblocks = L.cum[k] - first_blk;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (L.nc[k] == -2) {
+    // the closing role.  The copy of the tables it sends to the host may catch this launch's other blocks half-way
+    // through writing the hop's node counts: it overwrites those cells of the HOST copy with what it computes itself --
+    // a segment's count = the sum of the tile counts of the first pass; a type without a segment keeps its size.
+    fused_fold_tables(L.tb, L.chain, L.closing, L.words);
+    __syncthreads();
+    if (L.closing.tables_host) {
+      int64_t* host_size = reinterpret_cast<int64_t*>(L.closing.tables_host);   // size_at is the first array of the tables
+      for (int j = 0; j < L.n; ++j) {
+        if (L.nc[j] < 0 || !L.part[j].last) continue;
+        const FSegHdr& h = L.part[j].h;
+        uint32_t sum = 0;
+        for (int i = tid; i < h.ntiles; i += kScanThreads) sum += h.last_cnt[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+        if (lane == 0) s_red[wave] = sum;
+        __syncthreads();
+        if (tid == 0) host_size[h.size_out - L.tb.size_at] = *h.size_in + (int64_t)(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+        __syncthreads();
+      }
+      if (tid < L.tb.T) {
+        const bool has = tid < 32 ? ((L.type_mask_lo >> tid) & 1u) != 0 : ((L.type_mask_hi >> (tid - 32)) & 1u) != 0;
+        if (!has) host_size[(L.ell + 1) * L.tb.T + tid] = L.tb.size_at[L.ell * L.tb.T + tid];
+      }
+    }
+    fused_fold_done(L.closing);
+    return;
+  }
+  if (L.nc[k] < 0) {  // carry: node types nobody appended to in this hop keep their size
+    if (tid < L.tb.T) {
+      const bool has = tid < 32 ? ((L.type_mask_lo >> tid) & 1u) != 0 : ((L.type_mask_hi >> (tid - 32)) & 1u) != 0;
+      if (!has) L.tb.size_at[(L.ell + 1) * L.tb.T + tid] = L.tb.size_at[L.ell * L.tb.T + tid];
+    }
+    return;
+  }
+  const FPart& pt = L.part[k];
+  const int nt = pt.h.ntiles;
+  // exclusive prefix of the segment's tile counts, by every block for itself: thread t scans a contiguous run
+  uint32_t grand;
+  {
+    const int per = (nt + kScanThreads - 1) / kScanThreads;
+    const int i0 = tid * per, i1 = min(i0 + per, nt);
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; ++i) sum += pt.h.last_cnt[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_red[wave] = incl;
+    __syncthreads();
+    uint32_t before_w = 0;
+    for (int w = 0; w < wave; ++w) before_w += s_red[w];
+    grand = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    uint32_t run = before_w + incl - sum;
+    for (int i = i0; i < i1; ++i) {
+      s_tp[i] = run;
+      run += pt.h.last_cnt[i];
+    }
+    __syncthreads();
+  }
+  const int64_t n = part_count(L, pt);
+  const int64_t base = (int64_t)lt * kScanTile;
+  const int64_t size0 = *pt.h.size_in;
+  const int64_t id0 = size0 - *pt.h.dup;
+  if (pt.last && lt == nblocks - 1 && tid == 0) *pt.h.size_out = size0 + grand;
+  if (base >= n) return;
+  const int ti = pt.tile0 + lt;
+  int64_t* __restrict__ out_col = L.out_col[k] + part_col_offset(L, pt);
+  u64 word[kScanItems];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const int64_t p = base + i * kScanThreads + tid;
+    word[i] = p < n ? pt.cache[p] : 2ull;
+  }
+  int rk[kScanItems];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const u64 m = __ballot(word[i] == 1ull);
+    rk[i] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (lane == 0) s_cnt[i * 4 + wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const uint32_t v = s_cnt[tid];
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (tid >= d) incl += up;
+    }
+    s_pre[tid] = incl - v;
+  }
+  __syncthreads();
+  const bool slot_is_node = reinterpret_cast<const void*>(pt.slots) == reinterpret_cast<const void*>(pt.e_node);
+  const uint32_t before = s_tp[ti];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    const int64_t p = base + i * kScanThreads + tid;
+    if (p >= n) continue;
+    const u64 w = word[i];
+    if (w == 1ull) {
+      const int64_t r = (int64_t)before + s_pre[i * 4 + wave] + rk[i];
+      pt.h.nodes[size0 + r] = slot_is_node ? (int64_t)pt.slots[p] : pt.e_node[p];
+      if (pt.h.batch) pt.h.batch[size0 + r] = pt.e_batch[p];
+      out_col[p] = id0 + r;
+    } else if (w & 2ull) {
+      out_col[p] = (int64_t)(w >> 2);
+    } else {
+      // first seen at position q of this hop's segment: the part that holds q, its tile, the word and the bit
+      const int64_t q = (int64_t)(w >> 2);
+      int64_t qb = -1;
+      int qt0 = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxParts; ++j) {   // (the part of this segment with the largest pos_base <= q; bases differ by the parts' bounds)
+        if (j < L.n && L.nc[j] >= 0 && L.part[j].h.vals == pt.h.vals) {
+          const int64_t pb = L.part[j].pos_base;
+          if (pb <= q && pb > qb) {
+            qb = pb;
+            qt0 = L.part[j].tile0;
+          }
+        }
+      }
+      const int64_t ql = q - qb;
+      const int t_o = qt0 + (int)(ql / kScanTile);
+      const int o = (int)(ql % kScanTile);
+      const LastTile* mt = pt.h.last_meta + t_o;
+      const u64 bits = mt->bits[o >> 6];
+      const int64_t r = (int64_t)s_tp[t_o] + mt->before[o >> 6] + __popcll(bits & ((1ull << (o & 63)) - 1ull));
+      out_col[p] = id0 + r;
+    }
+  }
+}
+
 // ---- sample: relation e of hop l; everything position-dependent is resolved from the tables ------------------------
 // Per block: ONE round of loads (lane k of the first wave reads total k and overflow flag k; L * R <= 64), then the fold
 // over the relations in front -- finalize_kernel's chain advance and hop_overflow()'s sticky abort -- runs on shuffles.
@@ -843,63 +1154,10 @@ __global__ __launch_bounds__(256) void fused_sample_kernel(const FSampleLaunch L
       if constexpr (GMAX >= 64) fused_sample<0, I64>(L, L.s[idx], b, avail_blocks, words);
       break;
     case kRoleFinalize: fused_finalize(L, L.f[idx], b); break;
-    default: {  // kRoleFold: the engine position, the tables and the engine hand-back, written where the host reads them
-      __shared__ int64_t fold_word;
-      if (threadIdx.x == 0) {
-        int64_t w = L.tb.word0;
-        int u = L.tb.units0;
-        bool ab = false;
-        for (int q = 0; q < L.tb.L * L.tb.R; ++q) {
-          const CountAgg t = L.tb.tot[q];
-          if (t.edges > 0) {
-            const int u0 = u;
-            w += tab_dw(t.tab, u0);
-            u = tab_nb(t.tab, u0);
-          }
-          ab = ab || L.tb.overflow[q] != 0;
-        }
-        L.chain->word = w;
-        L.chain->units = u;
-        L.chain->abort = ab ? 1 : 0;
-        fold_word = w;
-      }
-      __syncthreads();
-      if (L.fold.tables_host) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.fold.tables_dev);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(L.fold.tables_host);
-        for (int i = threadIdx.x; i < L.fold.tables_bytes / 4; i += 256) dst[i] = src[i];
-      }
-      if (L.fold.hb) {  // mt_finish_chain_kernel (sampler_rng.hip), with the position just folded
-        MtHandBack* hb = L.fold.hb;
-        const uint32_t* out32 = reinterpret_cast<const uint32_t*>(words);
-        const int64_t a0 = L.fold.a0;
-        const int64_t n32 = (fold_word / 128 + 1) * 256;
-        int status = 0;
-        const int64_t mp = n32 - a0;
-        const int64_t k = (mp + 623) / 624;
-        if (n32 <= a0) status = 2;
-        else if (a0 + 624 * k > L.fold.generated32) status = 1;
-        if (status == 0) {
-          const int64_t o0 = a0 + 624 * (k - 1);
-          for (int i = threadIdx.x; i < 624; i += 256) hb->st.state[i] = mt_untemper(mt_output_at(out32, o0 + i));
-          if (threadIdx.x == 0) {
-            const int64_t nx = mp - 624 * (k - 1);
-            hb->st.next = (uint32_t)nx;
-            hb->st.left = (int32_t)(625 - nx);
-          }
-        }
-        if (threadIdx.x == 0) {
-          hb->n32 = n32;
-          hb->status = status;
-        }
-      }
-      if (L.fold.done) {   // everything the host reads is written (system scope), then the word it waits for
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(L.fold.done, L.fold.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+    default:  // kRoleFold: the engine position, the tables and the engine hand-back, written where the host reads them
+      fused_fold_tables(L.tb, L.chain, L.fold, words);
+      fused_fold_done(L.fold);
       break;
-    }
   }
 }
 

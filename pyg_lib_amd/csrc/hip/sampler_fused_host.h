@@ -142,7 +142,10 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       seg_tiles[(size_t)dst_of(e)] += (size_t)tiles_of(Eb);
     }
     for (int t = 0; t < T; ++t)
-      if (seg_tiles[(size_t)t]) arena_bytes += align_up((8 + 16 * (size_t)kMaxCons) * (seg_tiles[(size_t)t] + 1), 256);
+      if (seg_tiles[(size_t)t]) {
+        arena_bytes += align_up((8 + 16 * (size_t)kMaxCons) * (seg_tiles[(size_t)t] + 1), 256);
+        if (ell == L - 1) arena_bytes += align_up(sizeof(LastTile) * seg_tiles[(size_t)t], 256) + align_up(4 * seg_tiles[(size_t)t], 256);
+      }
   }
   // Which scans run as one launch (fused_onepass: up to kOnePassMaxTiles tiles)?  Their tickets (own 64-byte lines) and
   // tile aggregates are cleared per call.
@@ -156,7 +159,15 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     if (seeds_onepass) sync_bytes += 8 * kAggStride * (tiles + fseeds.size());
   }
   std::vector<char> hop_onepass((size_t)L, 0);
+  // The last hop's bookkeeping runs as the two passes of fused_last_* (no table writes, no finalize role);
+  // PYG_HIP_SAMPLER_LAST=0: reduce / apply / finalize as for the other hops (A/B timing).
+  static const bool last_on = [] {
+    const char* e = getenv("PYG_HIP_SAMPLER_LAST");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  const bool last_two_pass = last_on && L > 0;
   for (int ell = 0; ell < L; ++ell) {
+    if (last_two_pass && ell == L - 1) continue;   // (neither the one-pass scan nor its sync words)
     size_t tiles = 0, parts = 0;
     for (int e = 0; e < R; ++e)
       if (eb[(size_t)ell][(size_t)e] != 0) {
@@ -328,6 +339,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     sh.vals = n.table.vals;
     sh.prov = n.table.prov;
     sh.tag = n.table.tag;
+    sh.idmask = n.table.idmask;
     sh.nodes = n.nodes.p;
     sh.batch = disjoint ? n.batch.p : nullptr;
     sh.dup = tb.dup + t;
@@ -390,6 +402,38 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     pt.mark("rng_launched");
   }
 
+  // The closing role's record: where the tables and the engine hand-back go in pinned host memory (kernels write there
+  // directly, as they do for the temporal error flag: no launch and no copy behind the last hop), the completion word.
+  // `spec_word` = the bound of the words the call may have consumed when the role runs.
+  int64_t spec_word = rng.word;
+  bool closed = false;   // the role rode in the last hop's second pass (fused_last_apply_kernel): no closing launch
+  auto fill_fold = [&](FFoldRec& f) -> int {
+    ::memset(&f, 0, sizeof(f));
+    f.tables_host = tables_host;
+    f.tables_dev = tb_dev;
+    f.tables_bytes = (int)tb_bytes;
+    f.done = done_word;
+    f.done_seq = done_seq;
+    *hand_back_out = nullptr;
+    if (rng.engine) {
+      const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
+      size_t k = 0;
+      while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
+      if (k < rng.marks.size()) {
+        hand_back_host->status = -1;
+        if (k >= rng.waited) {
+          if (rng.marks[k].ev) PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
+          rng.waited = k + 1;
+        }
+        f.hb = hand_back_host;
+        f.a0 = rng.a0;
+        f.generated32 = rng.marks[k].upto32;
+        *hand_back_out = hand_back_host;
+      }
+    }
+    return PYG_HIP_OK;
+  };
+
   // ---- hops ----
   struct Step {
     int ell, e;
@@ -398,7 +442,6 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
   };
   std::vector<Step> prev_steps;
   std::vector<std::vector<Step>> steps_by_hop((size_t)L);
-  int64_t spec_word = rng.word;
   for (int ell = 0; ell < L; ++ell) {
     FSampleLaunch p1;
     FScanLaunch p2;
@@ -432,7 +475,13 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       int nt = 0;
       for (int e = 0; e < R; ++e)
         if (dst_of(e) == t) nt += tiles_of(eb[(size_t)ell][(size_t)e]);
-      sh.tile_agg = tile_agg_of(hop_onepass[(size_t)ell] != 0, sh.ncons, nt);
+      sh.ntiles = nt;
+      if (last_two_pass && ell == L - 1) {
+        sh.last_meta = reinterpret_cast<LastTile*>(carve(sizeof(LastTile) * (size_t)nt));
+        sh.last_cnt = reinterpret_cast<uint32_t*>(carve(4 * (size_t)nt));
+      } else {
+        sh.tile_agg = tile_agg_of(hop_onepass[(size_t)ell] != 0, sh.ncons, nt);
+      }
     }
     std::vector<Step> cur;
     for (int e = 0; e < R; ++e) {
@@ -490,6 +539,7 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       pp.tot_index = ell * R + e;
       pp.tile0 = seg_tiles[(size_t)dst];
       pp.last = seg_last[(size_t)dst] == e ? 1 : 0;
+      p2.out_col[p2.n] = st.col.p;   // (add_part below takes slot p2.n)
       add_part(p2, pp.h.ncons, tiles_of(Eb), &pp);
       seg_pos[(size_t)dst] += Eb;
       seg_tiles[(size_t)dst] += tiles_of(Eb);
@@ -518,7 +568,22 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     }
     rc = launch_sample(p1);
     if (rc != PYG_HIP_OK) return rc;
-    if (hop_onepass[(size_t)ell]) {
+    const bool last_hop = last_two_pass && ell == L - 1;
+    if (last_hop) {
+      if (p2.n > 0) {
+        hipLaunchKernelGGL(fused_last_reduce_kernel, dim3((unsigned)p2.cum[p2.n - 1]), dim3(256), 0, stream, p2);
+        PYG_HIP_CHECK(hipGetLastError());
+      }
+      add_part(p2, -1, 1, nullptr);  // carry block: second pass only
+      add_part(p2, -2, 1, nullptr);  // the closing role (fold): one more block of the second pass
+      p2.chain = chain;
+      p2.words = rng.dev;
+      rc = fill_fold(p2.closing);
+      if (rc != PYG_HIP_OK) return rc;
+      closed = true;
+      hipLaunchKernelGGL(fused_last_apply_kernel, dim3((unsigned)p2.cum[p2.n - 1]), dim3(256), 0, stream, p2);
+      PYG_HIP_CHECK(hipGetLastError());
+    } else if (hop_onepass[(size_t)ell]) {
       add_part(p2, -1, 1, nullptr);  // carry block
       p2.ticket = ticket_of(1 + ell);
       rc = launch_scan(p2, kScanOnePass);
@@ -532,8 +597,9 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
     if (rc != PYG_HIP_OK) return rc;
     steps_by_hop[(size_t)ell] = cur;
     prev_steps = cur;
+    if (last_hop) prev_steps.clear();   // their `col` is written: nothing left for the finalize role of the closing launch
   }
-  {
+  if (!closed) {
     FSampleLaunch fin;
     ::memset(&fin, 0, sizeof(fin));
     fin.tb = tb;
@@ -544,31 +610,9 @@ int run_fused_chain(Ctx& c, int num_node_types, int num_relations, const pyg_hip
       add_sample(fin, kRoleFinalize, (s.Eb + 255) / 256, nf++);
     }
     add_sample(fin, kRoleFold, 1, 0);
-    // The fold block also leaves the tables and the engine hand-back in pinned host memory (kernels write there
-    // directly, as they do for the temporal error flag): no launch and no copy behind the last hop.
-    fin.fold.tables_host = tables_host;
-    fin.fold.tables_dev = tb_dev;
-    fin.fold.tables_bytes = (int)tb_bytes;
-    fin.fold.done = done_word;
-    fin.fold.done_seq = done_seq;
-    *hand_back_out = nullptr;
-    if (rng.engine) {
-      const int64_t need32 = (spec_word / 128 + 1) * 256 + 624;
-      size_t k = 0;
-      while (k < rng.marks.size() && rng.marks[k].upto32 < need32) ++k;
-      if (k < rng.marks.size()) {
-        hand_back_host->status = -1;
-        if (k >= rng.waited) {
-          PYG_HIP_CHECK(hipStreamWaitEvent(stream, rng.marks[k].ev, 0));
-          rng.waited = k + 1;
-        }
-        fin.fold.hb = hand_back_host;
-        fin.fold.a0 = rng.a0;
-        fin.fold.generated32 = rng.marks[k].upto32;
-        *hand_back_out = hand_back_host;
-      }
-    }
-    int rc = launch_sample(fin);
+    int rc = fill_fold(fin.fold);
+    if (rc != PYG_HIP_OK) return rc;
+    rc = launch_sample(fin);
     if (rc != PYG_HIP_OK) return rc;
   }
   if (rng_late) {  // a carried stream that covers this call: its next round (for the NEXT call) goes out now, off the critical path

@@ -1,6 +1,6 @@
 #!/bin/bash
 # RNG stream carry: tests, timeline, timing
-R=/root/repo/gpurun_out/r6_y
+R=/root/repo/gpurun_out/r6_ab
 mkdir -p $R
 cd /root/repo
 timeout 1200 python -m pytest tests/test_sampler_carry_gpu.py tests/test_sampler_gpu.py tests/test_sampler_fuzz_gpu.py tests/test_sampler_batched_gpu.py tests/test_biased_sampler_gpu.py tests/test_rgcn_gpu.py tests/test_stress_gpu.py tests/test_dist_helpers_gpu.py -m gpu -x -q > $R/pytest.txt 2>&1
