@@ -51,15 +51,44 @@ __device__ __forceinline__ void gen_load(uint32_t (&r)[16], const char* base, ui
                                          int bytes_valid, int tid, bool stream) {
   constexpr int NV = ROWBYTES / V;
   constexpr int PER = 64 / V;
+  constexpr int RPI = 256 / NV;  // rows per iteration: vector idx = i * 256 + tid -> row i * RPI + tid / NV, piece tid % NV
+  static_assert(256 % NV == 0, "a row's pieces belong to one iteration");
   typedef typename GenVec<V>::type VT;
   typedef __attribute__((address_space(1))) VT GVT;
+  // one multiply per call: the byte offset advances by the uniform RPI * pitch per iteration, the row test becomes a compare
+  // of the thread's first row against a constant (the counters showed this kernel bound by its VALU instructions -- ~40 per
+  // load with the row / piece arithmetic redone per vector --, not by HBM: profiles/NOTES_r6.md section 5)
+  const int r0 = tid / NV, v = tid % NV;
+  const bool col_ok = v * V < bytes_valid;
+  const int rows_left = rows_valid - r0;   // row i * RPI + r0 exists  <=>  i * RPI < rows_left
+  uint32_t off = (uint32_t)r0 * pitch + (uint32_t)(v * V);  // < 2^31: K, M bounded by the host
+  const uint32_t step = (uint32_t)RPI * pitch;
+  if (rows_valid >= RPI * PER && bytes_valid >= ROWBYTES) {
+    // the whole block exists (every chunk but a K / M tail, every tile but a group's last): no predicates at all -- the
+    // masked form below costs five VALU + five SALU instructions and a branch per vector
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const GVT* src = (const GVT*)(base + off);
+      off += step;
+      if constexpr (V == 16) {
+        const u32x4 q = stream ? __builtin_nontemporal_load(src) : *src;
+        r[4 * i] = q[0];
+        r[4 * i + 1] = q[1];
+        r[4 * i + 2] = q[2];
+        r[4 * i + 3] = q[3];
+      } else {
+        const u32x2 q = stream ? __builtin_nontemporal_load(src) : *src;
+        r[2 * i] = q[0];
+        r[2 * i + 1] = q[1];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int idx = i * 256 + tid;
-    const int row = idx / NV;
-    const int v = idx % NV;
-    const bool ok = row < rows_valid && v * V < bytes_valid;
-    const GVT* src = (const GVT*)(base + ((uint32_t)row * pitch + (uint32_t)(v * V)));  // < 2^31: K, M bounded by the host
+    const bool ok = col_ok && i * RPI < rows_left;
+    const GVT* src = (const GVT*)(base + off);
+    off += step;
     if constexpr (V == 16) {
       u32x4 q = {0u, 0u, 0u, 0u};
       if (ok) q = stream ? __builtin_nontemporal_load(src) : *src;
@@ -81,18 +110,16 @@ template <int V, int ROWBYTES, int PITCH>
 __device__ __forceinline__ void gen_stage(const uint32_t (&r)[16], char* img, int tid) {
   constexpr int NV = ROWBYTES / V;
   constexpr int PER = 64 / V;
+  constexpr int RPI = 256 / NV;
+  char* dst = img + (tid / NV) * PITCH + (tid % NV) * V;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int idx = i * 256 + tid;
-    const int row = idx / NV;
-    const int v = idx % NV;
-    char* dst = img + row * PITCH + v * V;
     if constexpr (V == 16) {
       const u32x4 q = {r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
-      *reinterpret_cast<u32x4*>(dst) = q;
+      *reinterpret_cast<u32x4*>(dst + i * (RPI * PITCH)) = q;
     } else {
       const u32x2 q = {r[2 * i], r[2 * i + 1]};
-      *reinterpret_cast<u32x2*>(dst) = q;
+      *reinterpret_cast<u32x2*>(dst + i * (RPI * PITCH)) = q;
     }
   }
 }
@@ -105,16 +132,21 @@ __device__ __forceinline__ void gen_copy(char* img, const char* base, uint32_t p
                                          int tid) {
   constexpr int NV = ROWBYTES / V;
   constexpr int PER = 64 / V;
+  constexpr int RPI = 256 / NV;
   typedef typename GenVec<V>::type VT;
   typedef __attribute__((address_space(1))) VT GVT;
+  const int r0 = tid / NV, v = tid % NV;
+  const bool col_ok = v * V < bytes_valid;
+  const int rows_left = rows_valid - r0;
+  uint32_t off = (uint32_t)r0 * pitch + (uint32_t)(v * V);
+  const uint32_t step = (uint32_t)RPI * pitch;
+  char* dst = img + r0 * PITCH + v * V;
 #pragma unroll 4
   for (int i = 0; i < PER; ++i) {
-    const int idx = i * 256 + tid;
-    const int row = idx / NV;
-    const int v = idx % NV;
     VT q = 0;
-    if (row < rows_valid && v * V < bytes_valid) q = *(const GVT*)(base + ((uint32_t)row * pitch + (uint32_t)(v * V)));
-    *reinterpret_cast<VT*>(img + row * PITCH + v * V) = q;
+    if (col_ok && i * RPI < rows_left) q = *(const GVT*)(base + off);
+    off += step;
+    *reinterpret_cast<VT*>(dst + i * (RPI * PITCH)) = q;
   }
 }
 
@@ -154,16 +186,47 @@ __device__ __forceinline__ void gen_store(const char* st, char* dst, uint32_t pi
   constexpr int PER = NV / 2;
   typedef typename GenVec<V>::type VT;
   typedef __attribute__((address_space(1))) VT GVT;
+  if constexpr (NV <= 64) {
+    // vector idx = i * 64 + lane -> row i * RPI + lane / NV, piece lane % NV: one multiply, uniform steps (see gen_load)
+    constexpr int RPI = 64 / NV;
+    const int r0 = lane / NV, v = lane % NV;
+    const bool col_ok = v * V < bytes_valid;
+    const int rows_left = rows_valid - r0;
+    uint32_t off = (uint32_t)r0 * pitch + (uint32_t)(v * V);
+    const uint32_t step = (uint32_t)RPI * pitch;
+    const char* src = st + r0 * kGenPS + v * V;
+    if (rows_valid >= 32 && bytes_valid >= 256) {   // the whole 32 x 256-byte stage exists: no predicates
 #pragma unroll 8
-  for (int i = 0; i < PER; ++i) {
-    const int idx = i * 64 + lane;
-    const int r = idx / NV;
-    const int v = idx % NV;
-    const VT val = *reinterpret_cast<const VT*>(st + r * kGenPS + v * V);
-    if (r < rows_valid && v * V < bytes_valid) {
-      GVT* p = (GVT*)(dst + ((uint32_t)r * pitch + (uint32_t)(v * V)));
-      if constexpr (V >= 8) __builtin_nontemporal_store(val, p);
-      else *p = val;
+      for (int i = 0; i < PER; ++i) {
+        const VT val = *reinterpret_cast<const VT*>(src + i * (RPI * kGenPS));
+        GVT* p = (GVT*)(dst + off);
+        if constexpr (V >= 8) __builtin_nontemporal_store(val, p);
+        else *p = val;
+        off += step;
+      }
+      return;
+    }
+#pragma unroll 8
+    for (int i = 0; i < PER; ++i) {
+      const VT val = *reinterpret_cast<const VT*>(src + i * (RPI * kGenPS));
+      if (col_ok && i * RPI < rows_left) {
+        GVT* p = (GVT*)(dst + off);
+        if constexpr (V >= 8) __builtin_nontemporal_store(val, p);
+        else *p = val;
+      }
+      off += step;
+    }
+  } else {   // 2-byte pieces: 128 per row, two iterations per row
+#pragma unroll 8
+    for (int i = 0; i < PER; ++i) {
+      const int idx = i * 64 + lane;
+      const int r = idx / NV;
+      const int v = idx % NV;
+      const VT val = *reinterpret_cast<const VT*>(st + r * kGenPS + v * V);
+      if (r < rows_valid && v * V < bytes_valid) {
+        GVT* p = (GVT*)(dst + ((uint32_t)r * pitch + (uint32_t)(v * V)));
+        *p = val;
+      }
     }
   }
 }
@@ -280,46 +343,46 @@ __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, 
   const bool xstream = ncb == 1;  // X is read once: streaming hint
 
   uint32_t xr[16], wr[16];
-  auto x_block = [&](int s) {
-    const int c = s % nchunks;
+  // (chunk c of column pass nb: the step counter is carried as the pair -- `s / nchunks`, `s % nchunks` by a run-time
+  // nchunks were three integer divisions per step, each a reciprocal sequence on the VALU)
+  auto x_block = [&](int c) {
     return GenBlock{xbase + c * 128, xpitch, rows_here, K * SZ - c * 128};
   };
-  auto w_block = [&](int s) {
-    const int nb = s / nchunks;
-    const int c = s - nb * nchunks;
+  auto w_block = [&](int c, int nb) {
     if (!trans) return GenBlock{d.w + ((int64_t)c * KC * M + nb * 128) * SZ, opitch, K - c * KC, (M - nb * 128) * SZ};
     return GenBlock{d.w + (int64_t)nb * 128 * xpitch + c * 128, xpitch, M - nb * 128, K * SZ - c * 128};
   };
   // The per-vector offsets of every (operand, class) pair are loop-invariant; hoisted out of the step loop they cost
   // ~150 registers (seen as 300 spilled VGPRs).  The thread id goes through an opaque asm per step instead: a handful
   // of integer instructions per chunk.
-  auto issue = [&](int s) {
+  auto issue = [&](int c, int nb) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    gen_load_cls<128, CLSX>(xr, x_block(s), t2, xstream);
-    if (!trans) gen_load_cls<WROWB, CLSW>(wr, w_block(s), t2, false);
-    else gen_load_cls<128, CLSW>(wr, w_block(s), t2, false);
+    gen_load_cls<128, CLSX>(xr, x_block(c), t2, xstream);
+    if (!trans) gen_load_cls<WROWB, CLSW>(wr, w_block(c, nb), t2, false);
+    else gen_load_cls<128, CLSW>(wr, w_block(c, nb), t2, false);
   };
-  auto stage = [&](int s) {
+  auto stage = [&](int c, int nb) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
     char* X = smem;
-    gen_stage_cls<128, kGenPX, CLSX>(lgx, xr, X, x_block(s), t2);
-    if (!trans) gen_stage_cls<WROWB, PW, CLSW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
-    else gen_stage_cls<128, kGenPX, CLSW>(lgw, wr, X + kGenXBytes, w_block(s), t2);
+    gen_stage_cls<128, kGenPX, CLSX>(lgx, xr, X, x_block(c), t2);
+    if (!trans) gen_stage_cls<WROWB, PW, CLSW>(lgw, wr, X + kGenXBytes, w_block(c, nb), t2);
+    else gen_stage_cls<128, kGenPX, CLSW>(lgw, wr, X + kGenXBytes, w_block(c, nb), t2);
   };
 
-  issue(0);
-  stage(0);
+  issue(0, 0);
+  stage(0, 0);
   __syncthreads();
 
   const bool active = wave * 32 < rows_here;  // waves without rows still load, stage and meet the barriers
   f32x16 acc[4];
 
+  int c = 0, nb = 0;   // chunk and column pass of step s
   for (int s = 0; s < nsteps; ++s) {
-    const int nb = s / nchunks;
-    const int c = s - nb * nchunks;
-    if (s + 1 < nsteps) issue(s + 1);
+    int c1 = c + 1, nb1 = nb;   // ... of step s + 1
+    if (c1 == nchunks) c1 = 0, nb1 = nb + 1;
+    if (s + 1 < nsteps) issue(c1, nb1);
     const char* X = smem;
     const char* W = X + kGenXBytes;
     const int mvalid = M - nb * 128 < 128 ? M - nb * 128 : 128;
@@ -387,9 +450,11 @@ __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, 
       if (s + 1 < nsteps) __syncthreads();  // everybody is done with its stage before the next chunk lands there
     }
     if (s + 1 < nsteps) {
-      stage(s + 1);
+      stage(c1, nb1);
       __syncthreads();
     }
+    c = c1;
+    nb = nb1;
   }
 }
 

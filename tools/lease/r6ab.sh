@@ -1,0 +1,10 @@
+#!/bin/bash
+R=/root/repo/gpurun_out/r6_ab3
+mkdir -p $R
+cd /root/repo
+cp pyg_lib_amd/libpyg_hip.so /tmp/new.so
+for rep in 1 2; do
+  cp /tmp/new.so pyg_lib_amd/libpyg_hip.so; echo "new $(python tools/gen_time.py 2>/dev/null | tail -1)" | tee -a $R/ab.txt
+  cp pyg_lib_amd/libpyg_hip_oldgen.so pyg_lib_amd/libpyg_hip.so; echo "old $(python tools/gen_time.py 2>/dev/null | tail -1)" | tee -a $R/ab.txt
+done
+cp /tmp/new.so pyg_lib_amd/libpyg_hip.so

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=/root/repo/gpurun_out/r6_pmc
+R=/root/repo/gpurun_out/r6_pmc2
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $R/p1 -o p -- python /root/repo/tools/pmc_gen.py 4 > $R/p1.log 2>&1

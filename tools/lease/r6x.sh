@@ -1,5 +1,5 @@
 #!/bin/bash
-R=/root/repo/gpurun_out/r6_x
+R=/root/repo/gpurun_out/r6_ad
 mkdir -p $R
 cd /root/repo
 for i in 1 2; do python tools/gen_time.py 2>/dev/null | tail -1 | tee -a $R/gen_time.txt; done
