@@ -148,7 +148,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // costs ~80 registers next to the pipeline's own (a third of the occupancy of every call), so the pipeline does without
   // it, and a call in which the row-start launch has seen such a row takes the item-at-a-time walk at the end of this
   // function instead (same registers, no pipeline; the choice is uniform over the launch).
-  const bool long_rows = KC * MC > 1 || SMALL || *desc.long_rows == desc.call_id;
+  const bool long_rows = SMALL || *desc.long_rows == desc.call_id;
   auto rel_at = [&](int i) __attribute__((always_inline)) -> const RelDev& {
     if constexpr (INL) return desc.irels[i];
     else return desc.rels[i];
@@ -554,10 +554,41 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     }
     return;
   }
-  if constexpr (KC * MC == 1) {
+  if constexpr (!SMALL) {
+  // The pipeline's unit is a SUB-ITEM (block, relation, 128-feature slice kc): KC of them per item, one after the other.  A
+  // sub-item gathers slice kc of the row's feature rows (sub-items behind the first copy the row start, the indices and the
+  // feature row from their predecessor -- one stage ahead of them in the pipeline, the same edge -- instead of fetching them
+  // again) and multiplies its 16 x 128 sums with W[128 kc ... 128 kc + 127][:]: the 16-bit types in MC chunks of 128 columns
+  // through the one W buffer (chunk 0 travels behind the previous sub-item's products like W of the K = M = 128 case, chunks
+  // 1 ... MC - 1 are fetched between the products: one exposed trip to L2 each, which the row loads of the next sub-item share),
+  // fp32 as the 64 k-rows x 128 columns of the slice (32 KB, both halves of the buffer).
   bool primed = false;  // (the first iteration only fetches: one call site for the item walk, so that it is inlined and its
                         // state stays in scalar registers -- as a called function it lived in scratch, and every relation
                         // record was fetched with vector loads the row gathers had to wait behind)
+  int kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0;   // the slices of the four sub-items (uniform; KC = 1: always 0)
+  int sub_blk = 0, sub_rel = 0, sub_kc = KC - 1;
+  bool sub_on = false;
+  auto next_sub = [&](int& blk, int& rel, int& kc) __attribute__((always_inline)) -> bool {
+    if (KC > 1 && sub_on && sub_kc + 1 < KC) {
+      ++sub_kc;
+    } else {
+      sub_on = next_item(sub_blk, sub_rel);
+      sub_blk = __builtin_amdgcn_readfirstlane(sub_blk);
+      sub_rel = __builtin_amdgcn_readfirstlane(sub_rel);
+      sub_kc = 0;
+    }
+    blk = sub_blk, rel = sub_rel, kc = sub_kc;
+    return sub_on;
+  };
+  // the first W chunk of sub-item (rel, kc) on its way
+  auto load_w_first = [&](int rel, int kc) __attribute__((always_inline)) {
+    if constexpr (F32) {
+      load_w32(rel, 2 * kc);
+      load_w32(rel, 2 * kc + 1);
+    } else {
+      load_w(rel, kc, 0);
+    }
+  };
   while (!primed || v0 || v1 || v2 || v3) {
     primed = true;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what the previous iteration asked for is here (W's DMA included)
@@ -565,54 +596,75 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     // would make the compiler wait for all loads issued in between -- it cannot count them across the conditional row
     // loads -- i.e. for the rows just requested.)
     asm volatile("" ::"v"(st3), "v"(g1_2), "v"(s1_2), "v"(g2_1));
-    // ---- item i: its first batch of rows has landed --------------------------------------------------------------------
+    // ---- sub-item i: its rows have landed ---------------------------------------------------------------------------------
     if (v0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) sum[k] = 0.f;
       add_rows();
-      a_tile_from_sums(0);   // (the previous item's products are behind a barrier)
+      a_tile_from_sums(F32 ? kc0 : 0);   // (the previous sub-item's products are behind a barrier)
     }
-    // ---- item i + 2: its indices have landed -> the row's edge count ----------------------------------------------------
+    // ---- sub-item i + 2: its indices have landed -> the row's edge count --------------------------------------------------
     const int n2 = prefix_count(v2 && st2 >= 0 && s1_2 == row_of(blk2, rel2));
     // ---- issue: nothing requested below is touched before the next iteration's top ----------------------------------------
     if (v1) {
-      issue_rows(rel_at(rel1), n1, g2_1, 0);
+      issue_rows(rel_at(rel1), n1, g2_1, kc1);
     }
     RowT g2n = 0;
-    if (v2) g2n = feature_row(rel_at(rel2), g1_2, c < n2);
+    if (v2) {
+      if (KC > 1 && kc2 > 0) g2n = g2_1;   // (sub-item i + 1 is the same edge list's previous slice)
+      else g2n = feature_row(rel_at(rel2), g1_2, c < n2);
+    }
     int64_t g1n = 0;
     int s1n = -1;
     if (v3) {
-      const RelDev& rel = rel_at(rel3);
-      if (st3 >= 0 && (int64_t)st3 + c < rel.num_edges) {  // (a stale start of a row without edges may point anywhere)
-        s1n = *(const __attribute__((address_space(1))) int*)(rel.scatter_index + (st3 + c));
-        g1n = ((GI64*)rel.gather_index)[st3 + c];
+      if (KC > 1 && kc3 > 0) {
+        st3 = st2, s1n = s1_2, g1n = g1_2;
       } else {
-        st3 = -1;
+        const RelDev& rel = rel_at(rel3);
+        if (st3 >= 0 && (int64_t)st3 + c < rel.num_edges) {  // (a stale start of a row without edges may point anywhere)
+          s1n = *(const __attribute__((address_space(1))) int*)(rel.scatter_index + (st3 + c));
+          g1n = ((GI64*)rel.gather_index)[st3 + c];
+        } else {
+          st3 = -1;
+        }
       }
     }
-    int blk4 = 0, rel4 = 0, st4 = -1;
-    const bool v4 = next_item(blk4, rel4);
-    blk4 = __builtin_amdgcn_readfirstlane(blk4);
-    rel4 = __builtin_amdgcn_readfirstlane(rel4);
-    if (v4) issue_start(blk4, rel4, st4);
-    // ---- item i: A tile, product; the block's rows when this was its last item -------------------------------------------
-    if (!v0 && v1) load_w(rel1, 0, 0);   // (the pipeline is filling: nobody reads W)
+    int blk4 = 0, rel4 = 0, kc4 = 0, st4 = -1;
+    const bool v4 = next_sub(blk4, rel4, kc4);
+    if (v4 && (KC == 1 || kc4 == 0)) issue_start(blk4, rel4, st4);
+    // ---- sub-item i: A tile, products; the block's rows when this was its last one ----------------------------------------
+    if (!v0 && v1) load_w_first(rel1, kc1);   // (the pipeline is filling: nobody reads W)
     if (v0) {
       const bool last = !v1 || blk1 != blk0;   // of its block
       __syncthreads();
-      product(acc[0], 0);
+      if constexpr (F32) {
+        product32(2 * kc0);
+        product32(2 * kc0 + 1);
+      } else {
+        product(acc[0], 0);
+#pragma unroll
+        for (int mc = 1; mc < MC; ++mc) {
+          __syncthreads();   // everybody is done with the previous chunk
+          load_w(rel0, kc0, mc);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          product(acc[mc], 0);
+        }
+      }
       __syncthreads();  // the A tile and W are free again
-      if (v1) load_w(rel1, 0, 0);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
-      if (last) store_block(acc, blk0);
+      if (v1) load_w_first(rel1, kc1);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
+      if (last) {
+        if constexpr (F32) store_block32(blk0);
+        else store_block(acc, blk0);
+      }
     }
     // ---- rotate --------------------------------------------------------------------------------------------------------
-    v0 = v1, blk0 = blk1, rel0 = rel1;
-    v1 = v2, blk1 = blk2, rel1 = rel2, n1 = n2, g2_1 = g2n;
-    v2 = v3, blk2 = blk3, rel2 = rel3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
-    v3 = v4, blk3 = blk4, rel3 = rel4, st3 = st4;
+    v0 = v1, blk0 = blk1, rel0 = rel1, kc0 = kc1;
+    v1 = v2, blk1 = blk2, rel1 = rel2, kc1 = kc2, n1 = n2, g2_1 = g2n;
+    v2 = v3, blk2 = blk3, rel2 = rel3, kc2 = kc3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
+    v3 = v4, blk3 = blk4, rel3 = rel4, kc3 = kc4, st3 = st4;
   }
-  }  // KC = MC = 1
+  }  // !SMALL
 }
 
 template <bool BF16, bool CHECK, bool BIG, bool INL>
