@@ -609,7 +609,10 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
 #undef PYG_RGCN_GPICK4
 #undef PYG_RGCN_GPICK
   }
-  const int lds = 32768 + 8192 * KC + 2 * 4 * kGroupedMaxRel;
+  // 16-bit: 32 KB of W, 32-row A tiles, three workgroups per CU; fp32: all 64 KB of W, an A tile of 16 rows of 528 bytes, two
+  // workgroups per CU (rgcn_grouped.h)
+  const bool wide = dtype == PYG_F32;
+  const int lds = (wide ? 65536 + 8704 : 32768 + 8192 * KC) + 2 * 4 * kGroupedMaxRel;
   if (int rc_ = ensure_dynamic_lds(kern, lds)) return rc_;
   int Ri = (int)R;
   {
@@ -622,7 +625,7 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
     // persistent: three workgroups of 256 threads per CU (<= 168 VGPRs, 44 KB of LDS), blocks of 16 rows dealt round-robin (the rows with
     // edges are the first ones of every node type: neighbours in the grid, spread over the chip)
     const int64_t nblocks = (num_out_rows + 15) / 16;
-    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(nblocks, 3 * (int64_t)device_info().num_cus));
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(nblocks, (wide ? 2 : 3) * (int64_t)device_info().num_cus));
     PYG_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, stream));
   }
   if (sync_check) {

@@ -43,6 +43,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ uint32_t f2u(float v) { return __builtin_bit_cast(uint32_t, v); }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct GroupedDesc {
   const RelDev* rels;        // R > kRgcnInline: the records and the three vectors below live in the workspace
   const int64_t* eprefix;    // [R + 1] running edge count
@@ -127,7 +129,11 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // NW = 4.  Neither is latency bound any more: 145 MB of random 256-byte rows + 110 MB of zero rows + 10 MB of indices in
   // 57 us is what the chip delivers for this access mix -- random-row gathers run at 3.7 - 4.7 TB/s in every kernel of
   // this library.)
-  constexpr int kWBytes = 32768;
+  // WIDE (fp32): both 256-byte slices of a feature row travel together (2 U loads per lane and batch in the pipeline), all of
+  // W (64 KB) has room in LDS, and the kernel runs with TWO workgroups per CU (256 registers per lane).
+  constexpr bool WIDE = F32;
+  constexpr int kWBytes = WIDE ? 65536 : 32768;
+  constexpr int KS = WIDE ? KC : 1;   // slices of a batch in registers at the same time (the pipeline; the item-at-a-time walk: 1)
   // K = 128 KC input features (rows of 256 KC bytes), M = 128 MC output features: the feature rows are walked once per
   // 128-feature slice (the indices come from L2 the second time), W travels through LDS in 128 x 128 chunks.  The pipeline
   // exists for KC = MC = 1; the other shapes take the item-at-a-time walk (2 % slower on the C5 batch where both run).
@@ -159,7 +165,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem + kWBytes;   // the A tile: 32 rows (ROWS used) x 16 chunks of 16 bytes, chunk index XOR-swizzled with the row
-  int* rlo = reinterpret_cast<int*>(smem + kWBytes + 8192 * KC);   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
+  int* rlo = reinterpret_cast<int*>(smem + kWBytes + (F32 ? 8704 : 8192 * KC));   // rows of `out` relation r has edges into: [rlo[r], rhi[r]] (empty: 1, 0)
   int* rhi = rlo + kGroupedMaxRel;
   const int tid = threadIdx.x, lane = tid & 63, xl = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,9 +260,9 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     }
     return (RowT)g2;
   };
-  u32x4 xr[U];
+  u32x4 xr[KS][U];
   // the n <= 16 rows of one batch on their way (rows the batch does not have: zeros)
-  auto issue_rows = [&](const RelDev& rel, int n, RowT g2, int kc) __attribute__((always_inline)) {
+  auto issue_rows = [&](const RelDev& rel, int n, RowT g2, int kc, u32x4 (&xr)[U]) __attribute__((always_inline)) {
     if (CHECK && (g2 < 0 || g2 >= rel.x_rows)) {   // (what the map returned; lanes past n hold 0)
       *error = 1;
       g2 = 0;
@@ -284,8 +290,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       });
     }
   };
-  float sum[8];
-  auto add_rows = [&]() __attribute__((always_inline)) {  // in edge order
+  float sum[KS][8];
+  auto add_rows = [&](const u32x4 (&xr)[U], float (&sum)[8]) __attribute__((always_inline)) {  // in edge order
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       if constexpr (F32) {
@@ -427,7 +433,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       if (MC > 1) __syncthreads();   // (the next 128 columns go through the same tile)
     }
   };
-  auto a_tile_from_sums = [&](int kc) __attribute__((always_inline)) {
+  auto a_tile_from_sums = [&](int kc, const float (&sum)[8]) __attribute__((always_inline)) {
     const int t = opaque_tid(), grp = t >> 4, c = t & 15;
     u32x4 pk;
     if constexpr (F32) {   // 64 floats of row grp: slice kc, lane c's four
@@ -484,6 +490,72 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     for (int k = 0; k < 8; ++k) acc8[k] = 0.f;
   };
 
+  // ---- fp32 in the pipeline: the product on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation) --------------------------
+  // (product32 above reads 36 bytes of LDS per thread and k: 590 KB per 64 k-rows, ~2 us of the CU's LDS time per item -- with
+  // three workgroups on the CU that was most of the kernel.  On the matrix pipe a wave reads its operands once: 48 KB.)
+  // All of W (128 k-rows of 512 bytes) into the 64 KB buffer, 16 DMA instructions per wave, two k-rows each.  The 16-byte chunks
+  // of row k are permuted -- chunk lc lies at lc ^ 4 ((k >> 2) & 3) -- so that the four k-rows one operand read touches fall
+  // into different banks.
+  auto load_w32m = [&](int g) __attribute__((always_inline)) {
+    const int lane = opaque_tid() & 63;
+    const int r = lane >> 5, pc = lane & 31;
+    const char* wbase = rel_at(g).weight;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = wave * 16 + j;          // k-rows 2 i, 2 i + 1
+      const int k = 2 * i + r;
+      const int lc = pc ^ (4 * ((k >> 2) & 3));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + k * 512 + lc * 16),
+                                       (LDSV*)(smem + i * 1024), 16, 0, 0);
+    }
+  };
+  // lane (m = lane % 16, kq = lane / 16) of wave t: rows m of the A tile, columns 32 t + 16 nt + m of W; MFMA step j of a group of
+  // 16 k-rows multiplies k = k0 + 4 kq + j (any assignment of k to the instruction's four slots does, as long as both operands
+  // use it: this one makes the A operand of four steps ONE 16-byte read)
+  f32x4 acc32[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc32[nt][k] = 0.f;
+  auto product32m = [&]() __attribute__((always_inline)) {
+    const int lane = opaque_tid() & 63, m = lane & 15, kq = lane >> 4;
+    const char* ap = xs + m * kARow + kq * 16;
+    // column 32 wave + 16 nt + m: chunk (8 wave + 4 nt + (m >> 2)) ^ 4 kq, float m & 3
+    const char* wp = smem + (4 * kq) * 512 + (m & 3) * 4;
+    const int ch0 = ((8 * wave + (m >> 2)) ^ (4 * kq)) * 16, ch1 = ((8 * wave + 4 + (m >> 2)) ^ (4 * kq)) * 16;
+#pragma unroll 2
+    for (int k0 = 0; k0 < 128; k0 += 16) {
+      const u32x4 a4 = *reinterpret_cast<const u32x4*>(ap + k0 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b0 = *reinterpret_cast<const float*>(wp + (k0 + j) * 512 + ch0);
+        const float b1 = *reinterpret_cast<const float*>(wp + (k0 + j) * 512 + ch1);
+        const uint32_t aw = a4[j];
+        acc32[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2f(aw), b0, acc32[0], 0, 0, 0);
+        acc32[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u2f(aw), b1, acc32[1], 0, 0, 0);
+      }
+    }
+  };
+  // results through the A tile's region (rows of kARow bytes): lane (m, kq) holds rows 4 kq ... 4 kq + 3 of column 32 t + 16 nt + m
+  auto store_block32m = [&](int blk) __attribute__((always_inline)) {
+    const int t = opaque_tid(), lane = t & 63, m = lane & 15, kq = lane >> 4, r = t >> 4, cg = t & 15;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<float*>(xs + (4 * kq + k) * kARow + (32 * wave + 16 * nt + m) * 4) = acc32[nt][k];
+        acc32[nt][k] = 0.f;
+      }
+    __syncthreads();
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(xs + r * kARow + cg * 32), v1 = *reinterpret_cast<const u32x4*>(xs + r * kARow + cg * 32 + 16);
+    const int64_t o = (int64_t)blk * ROWS + r;
+    if (o < out_rows) {
+      __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(out + o * OB + cg * 32));
+      __builtin_nontemporal_store(v1, reinterpret_cast<u32x4*>(out + o * OB + cg * 32 + 16));
+    }
+    __syncthreads();   // (the next A tile is written by other lanes than the ones that read here)
+  };
+
   if (long_rows) {
     // ---- item at a time: row start -> indices -> gather_map -> rows, 16 edges per batch, as many batches as the longest
     //      row of the wave needs ----------------------------------------------------------------------------------------
@@ -505,7 +577,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll 1
       for (int kc = 0; kc < KC; ++kc) {   // one walk over the row's edges per 128-feature slice
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+        for (int k = 0; k < 8; ++k) sum[0][k] = 0.f;
         int sc = st;
         bool more = sc >= 0;
         do {
@@ -517,12 +589,12 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
           }
           const int nc = prefix_count(onc && s1c == d);
           const RowT g2c = feature_row(r, g1c, c < nc);
-          issue_rows(r, nc, g2c, kc);
-          add_rows();
+          issue_rows(r, nc, g2c, kc, xr[0]);
+          add_rows(xr[0], sum[0]);
           more = more && nc == U;
           sc += U;
         } while (__any(more));
-        a_tile_from_sums(kc);
+        a_tile_from_sums(kc, sum[0]);
       }
       if constexpr (F32) {
         // W in four pieces of 32 k-rows through two buffers: piece q + 1 travels while piece q is multiplied.  (A thread
@@ -561,15 +633,16 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // again) and multiplies its 16 x 128 sums with W[128 kc ... 128 kc + 127][:]: the 16-bit types in MC chunks of 128 columns
   // through the one W buffer (chunk 0 travels behind the previous sub-item's products like W of the K = M = 128 case, chunks
   // 1 ... MC - 1 are fetched between the products: one exposed trip to L2 each, which the row loads of the next sub-item share),
-  // fp32 as the 64 k-rows x 128 columns of the slice (32 KB, both halves of the buffer).
+  // fp32 (WIDE) has no sub-items: both slices of the rows and all of W travel at once, one trip per item.
   bool primed = false;  // (the first iteration only fetches: one call site for the item walk, so that it is inlined and its
                         // state stays in scalar registers -- as a called function it lived in scratch, and every relation
                         // record was fetched with vector loads the row gathers had to wait behind)
-  int kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0;   // the slices of the four sub-items (uniform; KC = 1: always 0)
-  int sub_blk = 0, sub_rel = 0, sub_kc = KC - 1;
+  constexpr int KSUB = WIDE ? 1 : KC;        // sub-items of an item (WIDE: the slices travel together)
+  int kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0;   // the slices of the four sub-items (uniform; KSUB = 1: always 0)
+  int sub_blk = 0, sub_rel = 0, sub_kc = KSUB - 1;
   bool sub_on = false;
   auto next_sub = [&](int& blk, int& rel, int& kc) __attribute__((always_inline)) -> bool {
-    if (KC > 1 && sub_on && sub_kc + 1 < KC) {
+    if (KSUB > 1 && sub_on && sub_kc + 1 < KSUB) {
       ++sub_kc;
     } else {
       sub_on = next_item(sub_blk, sub_rel);
@@ -582,12 +655,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
   // the first W chunk of sub-item (rel, kc) on its way
   auto load_w_first = [&](int rel, int kc) __attribute__((always_inline)) {
-    if constexpr (F32) {
-      load_w32(rel, 2 * kc);
-      load_w32(rel, 2 * kc + 1);
-    } else {
-      load_w(rel, kc, 0);
-    }
+    if constexpr (F32) load_w32m(rel);
+    else load_w(rel, kc, 0);
   };
   while (!primed || v0 || v1 || v2 || v3) {
     primed = true;
@@ -599,25 +668,29 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     // ---- sub-item i: its rows have landed ---------------------------------------------------------------------------------
     if (v0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum[k] = 0.f;
-      add_rows();
-      a_tile_from_sums(F32 ? kc0 : 0);   // (the previous sub-item's products are behind a barrier)
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[ks][k] = 0.f;
+        add_rows(xr[ks], sum[ks]);
+        a_tile_from_sums(WIDE ? ks : 0, sum[ks]);   // (the previous sub-item's products are behind a barrier)
+      }
     }
     // ---- sub-item i + 2: its indices have landed -> the row's edge count --------------------------------------------------
     const int n2 = prefix_count(v2 && st2 >= 0 && s1_2 == row_of(blk2, rel2));
     // ---- issue: nothing requested below is touched before the next iteration's top ----------------------------------------
     if (v1) {
-      issue_rows(rel_at(rel1), n1, g2_1, kc1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) issue_rows(rel_at(rel1), n1, g2_1, WIDE ? ks : kc1, xr[ks]);
     }
     RowT g2n = 0;
     if (v2) {
-      if (KC > 1 && kc2 > 0) g2n = g2_1;   // (sub-item i + 1 is the same edge list's previous slice)
+      if (KSUB > 1 && kc2 > 0) g2n = g2_1;   // (sub-item i + 1 is the same edge list's previous slice)
       else g2n = feature_row(rel_at(rel2), g1_2, c < n2);
     }
     int64_t g1n = 0;
     int s1n = -1;
     if (v3) {
-      if (KC > 1 && kc3 > 0) {
+      if (KSUB > 1 && kc3 > 0) {
         st3 = st2, s1n = s1_2, g1n = g1_2;
       } else {
         const RelDev& rel = rel_at(rel3);
@@ -631,15 +704,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     }
     int blk4 = 0, rel4 = 0, kc4 = 0, st4 = -1;
     const bool v4 = next_sub(blk4, rel4, kc4);
-    if (v4 && (KC == 1 || kc4 == 0)) issue_start(blk4, rel4, st4);
+    if (v4 && (KSUB == 1 || kc4 == 0)) issue_start(blk4, rel4, st4);
     // ---- sub-item i: A tile, products; the block's rows when this was its last one ----------------------------------------
     if (!v0 && v1) load_w_first(rel1, kc1);   // (the pipeline is filling: nobody reads W)
     if (v0) {
       const bool last = !v1 || blk1 != blk0;   // of its block
       __syncthreads();
       if constexpr (F32) {
-        product32(2 * kc0);
-        product32(2 * kc0 + 1);
+        product32m();
       } else {
         product(acc[0], 0);
 #pragma unroll
@@ -654,7 +726,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       __syncthreads();  // the A tile and W are free again
       if (v1) load_w_first(rel1, kc1);   // (one W buffer: three workgroups per CU; it lands behind this iteration's rows)
       if (last) {
-        if constexpr (F32) store_block32(blk0);
+        if constexpr (F32) store_block32m(blk0);
         else store_block(acc, blk0);
       }
     }
@@ -688,7 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // fp32, K = M = 128
 template <bool BIG, bool INL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_f32_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rgcn_grouped_f32_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                                   int64_t out_rows, int* __restrict__ error) {
   rgcn_grouped_body<false, true, BIG, INL, 4, 2, 2, true>(desc, R, out, out_rows, error);
 }

@@ -298,8 +298,67 @@ def test_grouped_feature_widths_of_64_and_256(K, M):
         assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() <= 6e-2 * b.float().abs().max().item()
 
 
+@pytest.mark.parametrize('dtype,K,M', [(torch.bfloat16, 128, 128), (torch.bfloat16, 256, 256), (torch.float16, 256, 256),
+                                       (torch.float16, 128, 256), (torch.bfloat16, 256, 128), (torch.float32, 128, 128)])
+def test_grouped_short_rows_take_the_pipeline(dtype, K, M):
+    """Rows of at most 16 edges per relation -- what the samplers emit for fan-outs up to 16 -- run through the software
+    pipeline of the atomic-free kernel (one sub-item per 128-feature slice for the 16-bit shapes; float32 with both slices
+    and all of W at once, the product on fp32 MFMAs), the other tests' rows of up to 70 edges through the item-at-a-time
+    walk.  Enough blocks that every workgroup of the persistent launch owns several items (the pipeline is four deep),
+    degrees 0 ... 16 incl. exactly 16, type offsets that are no multiples of 16, an empty relation; exact on integer data
+    through x and through the global tables, float data against float64, the same bits on every run."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(1000 + K + 2 * M + (7 if dtype == torch.float32 else 0))
+    types = ['a', 'b', 'c']
+    n = {'a': 30011, 'b': 9973, 'c': 517}
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b'), ('c', 'r3', 'a'), ('b', 'r4', 'b'), ('a', 'r5', 'c'), ('c', 'r6', 'c')]
+    rows, cols = {}, {}
+    for i, et in enumerate(ets):
+        s, _, d = et
+        active = [n[s], n[s] // 2, 2000, 300, 0, n[s], 40][i]                  # rows 0 ... active - 1 may have edges
+        deg = torch.randint(0, 17, (active,), generator=g)
+        if active:
+            deg[torch.randint(0, active, (max(1, active // 8),), generator=g)] = 16
+        rows[et] = torch.repeat_interleave(torch.arange(active), deg).cuda()
+        cols[et] = torch.randint(0, n[d], (int(deg.sum()),), generator=g).cuda()
+    off = rgcn.type_offsets(n, types)
+    soff = [off[s] for s, _, _ in ets]
+    goff = [off[d] for _, _, d in ets]
+    x = {t: torch.randint(-1, 2, (n[t], K), generator=g).float() for t in types}
+    xc = torch.cat([x[t] for t in types])
+    W = column_selectors(len(ets), K, M, g)
+    want = exact_want(off['__total__'], M, ets, rows, cols, xc, W, soff, goff)
+    assert want.abs().max() <= 256
+    y = rgcn.rgcn_layer_fused(xc.to(dtype).cuda(), off, rows, cols, ets, W.to(dtype).cuda(), grouped=True)
+    assert y.shape == (off['__total__'], M) and y.dtype == dtype and torch.equal(y.double().cpu(), want)
+    n_glob = {'a': 50000, 'b': 12000, 'c': 600}
+    nid = {t: torch.randperm(n_glob[t], generator=g)[:n[t]] for t in types}
+    tab = {t: torch.randint(-3, 4, (n_glob[t], K), generator=g).float() for t in types}
+    for t in types:
+        tab[t][nid[t]] = x[t]
+    yt = rgcn.rgcn_layer_fused_tables({t: tab[t].to(dtype).cuda() for t in types}, {t: nid[t].cuda() for t in types}, types,
+                                      rows, cols, ets, W.to(dtype).cuda(), grouped=True)
+    assert torch.equal(yt.double().cpu(), want)
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+    # float data
+    xr = torch.randn(off['__total__'], K, generator=g).to(dtype).cuda()
+    wr = (torch.randn(len(ets), K, M, generator=g) / K ** 0.5).to(dtype).cuda()
+    yr = rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True)
+    ref = torch.zeros(off['__total__'], M, dtype=torch.float64, device='cuda')
+    for i, et in enumerate(ets):
+        agg = torch.zeros(off['__total__'], K, dtype=torch.float64, device='cuda')
+        agg.index_add_(0, rows[et] + soff[i], xr[cols[et] + goff[i]].double())
+        ref += (agg if dtype == torch.float32 else agg.to(dtype).double()) @ wr[i].double()   # (16-bit: the feature sum is rounded once)
+    scale = ref.abs().max().item()
+    tol = {torch.float32: 1e-5, torch.bfloat16: 8e-3, torch.float16: 1.5e-3}[dtype]
+    assert scale > 1.0 and (yr.double() - ref).abs().max().item() <= tol * scale
+    assert torch.equal(yr, rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True))
+
+
 def test_grouped_float32():
-    """float32, F = 128: sums, A tile and product in fp32 (plain FMAs, IEEE like the reference's fp32) -- 1e-5 of the
+    """float32, F = 128: sums, A tile and product in fp32 (rows of more than 16 edges: plain FMAs; the pipeline of the short
+    rows: fp32 MFMAs -- fp32 operands and accumulation either way) -- 1e-5 of the
     scale against a float64 restatement (the tolerance of the reference's own fp32 tests), exact on integer data, rows of
     0 ... 70 edges, several node types, x and tables, the same bits on every run, autograd against the chain."""
     from pyg_lib_amd import rgcn

@@ -1,6 +1,6 @@
 #!/bin/bash
 # sub-item pipeline of the atomic-free layer (F = 256, fp32): tests, stress, probe
-R=/root/repo/gpurun_out/r6_ba
+R=/root/repo/gpurun_out/r6_bd
 mkdir -p $R
 cd /root/repo
 timeout 900 python -m pytest tests/test_rgcn_grouped_gpu.py tests/test_rgcn_gpu.py tests/test_rgcn_csc_gpu.py -m gpu -x -q > $R/pytest.txt 2>&1
