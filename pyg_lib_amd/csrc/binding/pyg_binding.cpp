@@ -953,9 +953,18 @@ hetero_neighbor_sample_batched_kernel(const std::vector<node_type>& node_types, 
                                       const c10::Dict<rel_type, Tensor>& rowptr_dict, const c10::Dict<rel_type, Tensor>& col_dict,
                                       const std::vector<c10::Dict<node_type, Tensor>>& seed_dicts,
                                       const c10::Dict<rel_type, std::vector<int64_t>>& num_neighbors_dict,
-                                      const std::vector<int64_t>& generator_seeds, bool csc, bool replace, bool disjoint,
-                                      bool return_edge_id) {
+                                      const std::vector<int64_t>& generator_seeds,
+                                      const c10::optional<c10::Dict<node_type, Tensor>>& node_time_dict,
+                                      const c10::optional<c10::Dict<rel_type, Tensor>>& edge_time_dict,
+                                      const c10::optional<std::vector<c10::Dict<node_type, Tensor>>>& seed_time_dicts,
+                                      const c10::optional<c10::Dict<rel_type, Tensor>>& edge_weight_dict, bool csc, bool replace,
+                                      bool directed, bool disjoint, std::string temporal_strategy, bool return_edge_id) {
   PYG_TRACE("pyg::hetero_neighbor_sample_batched");
+  // the modes of pyg::hetero_neighbor_sample (sampler/neighbor.cpp:137-147 is one entry for all of them)
+  check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), seed_time_dicts.has_value(), edge_weight_dict.has_value(),
+              directed, disjoint, temporal_strategy);
+  TORCH_CHECK(!seed_time_dicts.has_value() || seed_time_dicts.value().size() == seed_dicts.size(),
+              "hetero_neighbor_sample_batched: one seed_time dict per batch");
   std::unordered_map<std::string, int> nt_index;
   for (size_t i = 0; i < node_types.size(); ++i) nt_index[node_types[i]] = (int)i;
   const size_t K = seed_dicts.size();
@@ -984,6 +993,10 @@ hetero_neighbor_sample_batched_kernel(const std::vector<node_type>& node_types, 
     rels[e].src_type = nt_index[std::get<0>(k)];
     rels[e].dst_type = nt_index[std::get<2>(k)];
     rels[e].index_is32 = ix.is32();
+    if (edge_time_dict.has_value() && edge_time_dict.value().contains(rel))
+      rels[e].edge_time = time_ptr(edge_time_dict.value().at(rel), "edge_time");
+    if (edge_weight_dict.has_value() && edge_weight_dict.value().contains(rel))
+      set_weight(rels[e], edge_weight_dict.value().at(rel), col.numel());
   }
   for (size_t e = 0; e < edge_types.size(); ++e) {
     TORCH_CHECK(fanouts[e].size() == L, "hetero_neighbor_sample_batched: all relations must list ", L, " hops");
@@ -1000,10 +1013,19 @@ hetero_neighbor_sample_batched_kernel(const std::vector<node_type>& node_types, 
       st.seed = ix.ptr(kv.value(), "seed");
       st.num_seed = kv.value().numel();
       st.seed_time = nullptr;
+      if (seed_time_dicts.has_value()) st.seed_time = time_ptr(seed_time_dicts.value()[b].at(kv.key()), "seed_time");
       sets[b].push_back(st);
     }
-  auto outs = run_sampler_batched(rels, sets, generator_seeds, {}, false, (int)node_types.size(), (int)L, csc, replace, disjoint,
-                                  return_edge_id, device.value());
+  std::vector<const int64_t*> ntime;
+  if (node_time_dict.has_value()) {
+    ntime.assign(node_types.size(), nullptr);
+    for (const auto& kv : node_time_dict.value()) {
+      TORCH_CHECK(nt_index.count(kv.key()), "hetero_neighbor_sample_batched: time given for unknown node type '", kv.key(), "'");
+      ntime[(size_t)nt_index[kv.key()]] = time_ptr(kv.value(), "node_time");
+    }
+  }
+  auto outs = run_sampler_batched(rels, sets, generator_seeds, ntime, temporal_strategy == "last", (int)node_types.size(), (int)L,
+                                  csc, replace, disjoint, return_edge_id, device.value());
   std::vector<c10::Dict<rel_type, Tensor>> o_row, o_col, o_eid;
   std::vector<c10::Dict<node_type, Tensor>> o_node;
   std::vector<c10::Dict<node_type, std::vector<int64_t>>> o_nph;
@@ -1265,7 +1287,10 @@ TORCH_LIBRARY_FRAGMENT(pyg, m) {
   m.def(TORCH_SELECTIVE_SCHEMA(
       "pyg::hetero_neighbor_sample_batched(str[] node_types, (str, str, str)[] edge_types, Dict(str, Tensor) rowptr_dict, "
       "Dict(str, Tensor) col_dict, Dict(str, Tensor)[] seed_dicts, Dict(str, int[]) num_neighbors_dict, "
-      "int[] generator_seeds, bool csc = False, bool replace = False, bool disjoint = False, bool return_edge_id = True) -> "
+      "int[] generator_seeds, Dict(str, Tensor)? node_time_dict = None, Dict(str, Tensor)? edge_time_dict = None, "
+      "Dict(str, Tensor)[]? seed_time_dicts = None, Dict(str, Tensor)? edge_weight_dict = None, bool csc = False, "
+      "bool replace = False, bool directed = True, bool disjoint = False, str temporal_strategy = 'uniform', "
+      "bool return_edge_id = True) -> "
       "(Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, Tensor)[], Dict(str, int[])[], "
       "Dict(str, int[])[])"));
   m.def(TORCH_SELECTIVE_SCHEMA(

@@ -155,17 +155,23 @@ def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], nu
 def hetero_neighbor_sample_batched(rowptr_dict: Dict[EdgeType, Tensor], col_dict: Dict[EdgeType, Tensor],
                                    seed_dicts: List[Dict[NodeType, Tensor]],
                                    num_neighbors_dict: Dict[EdgeType, List[int]], generator_seeds: List[int],
-                                   csc: bool = False, replace: bool = False, disjoint: bool = False,
-                                   return_edge_id: bool = True) -> List[HeteroOut]:
-    """Heterogeneous counterpart of :func:`neighbor_sample_batched` (uniform sampling; the temporal / biased options of
-    :func:`hetero_neighbor_sample` are not offered here).  Batch ``b`` equals ``torch.manual_seed(generator_seeds[b]);
-    hetero_neighbor_sample(rowptr_dict, col_dict, seed_dicts[b], num_neighbors_dict, ...)`` bit for bit."""
+                                   node_time_dict: Optional[Dict[NodeType, Tensor]] = None,
+                                   edge_time_dict: Optional[Dict[EdgeType, Tensor]] = None,
+                                   seed_time_dicts: Optional[List[Dict[NodeType, Tensor]]] = None,
+                                   edge_weight_dict: Optional[Dict[EdgeType, Tensor]] = None,
+                                   csc: bool = False, replace: bool = False, directed: bool = True, disjoint: bool = False,
+                                   temporal_strategy: str = 'uniform', return_edge_id: bool = True) -> List[HeteroOut]:
+    """Heterogeneous counterpart of :func:`neighbor_sample_batched`, with every mode of :func:`hetero_neighbor_sample`
+    (node- / edge-level temporal sampling with one ``seed_time`` dict per batch, biased sampling; the reference has one entry
+    for all of them, sampler/neighbor.cpp:137-147).  Batch ``b`` equals ``torch.manual_seed(generator_seeds[b]);
+    hetero_neighbor_sample(rowptr_dict, col_dict, seed_dicts[b], num_neighbors_dict, ..., seed_time_dicts[b], ...)`` bit for bit."""
     edge_types = list(rowptr_dict)
     node_types = sorted({t for e in edge_types for t in (e[0], e[-1])} | {t for d in seed_dicts for t in d})
     back = {_rel(e): e for e in edge_types}
     rows, cols, nodes, eids, nph, eph = torch.ops.pyg.hetero_neighbor_sample_batched(
         node_types, edge_types, _to_rel_keys(rowptr_dict), _to_rel_keys(col_dict), seed_dicts,
-        _to_rel_keys(num_neighbors_dict), generator_seeds, csc, replace, disjoint, return_edge_id)
+        _to_rel_keys(num_neighbors_dict), generator_seeds, node_time_dict, _to_rel_keys(edge_time_dict), seed_time_dicts,
+        _to_rel_keys(edge_weight_dict), csc, replace, directed, disjoint, temporal_strategy, return_edge_id)
 
     for d in (cols if csc else rows):
         for t in d.values():

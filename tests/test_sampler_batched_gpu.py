@@ -126,6 +126,73 @@ def test_hetero_batched_equals_single_calls():
             assert torch.equal(outs[b][2][t], one[2][t]) and outs[b][4][t] == one[4][t]
 
 
+@pytest.mark.parametrize('mode', ['node_time', 'node_time_last', 'edge_time', 'weight'])
+def test_hetero_batched_temporal_and_biased_equal_single_calls(mode):
+    """The batched hetero entry takes every mode of hetero_neighbor_sample (the reference has one entry for all of them,
+    sampler/neighbor.cpp:137-147): node-level / edge-level temporal sampling with one seed_time dict per batch, the 'last'
+    strategy, biased sampling -- each batch bit for bit the single call under torch.manual_seed(generator_seeds[b]) (the
+    single calls are pinned on the oracle in tests/test_sampler_gpu.py / test_biased_sampler_gpu.py)."""
+    rng = np.random.default_rng(21)
+    sizes = {'paper': 9_000, 'author': 6_000, 'inst': 300}
+    ets = [('author', 'writes', 'paper'), ('paper', 'cites', 'paper'), ('paper', 'rev_writes', 'author'),
+           ('author', 'at', 'inst'), ('inst', 'rev_at', 'author')]
+    rowptr, col, fan, etime, weight = {}, {}, {}, {}, {}
+    ntime_np = {t: rng.integers(0, 1000, n, dtype=np.int64) for t, n in sizes.items()}
+    for et in ets:
+        ns, nd = sizes[et[0]], sizes[et[2]]
+        deg = rng.poisson(6, ns).astype(np.int64)
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        c = rng.integers(0, nd, int(deg.sum()), dtype=np.int64)
+        te = rng.integers(0, 1000, int(deg.sum()), dtype=np.int64)
+        rowid = np.repeat(np.arange(ns), deg)
+        # the reference requires every neighbourhood sorted by time (sampler/cpu/neighbor_kernel.cpp: "Found invalid non-sorted
+        # temporal neighborhood"): by the neighbour's node time / by the edge time
+        if mode.startswith('node_time'):
+            c = c[np.lexsort((ntime_np[et[2]][c], rowid))]
+        te = te[np.lexsort((te, rowid))]
+        rowptr[et] = dev(rp)
+        col[et] = dev(c)
+        etime[et] = dev(te)
+        w = rng.random(int(deg.sum()))
+        w[rng.random(w.size) < 0.2] = 0.0
+        weight[et] = dev(w)
+        fan[et] = [4, 3]
+    ntime = {t: dev(v) for t, v in ntime_np.items()}
+    K = 5
+    seed_dicts = [{'paper': dev(rng.integers(0, sizes['paper'], 120, dtype=np.int64)),
+                   'author': dev(rng.integers(0, sizes['author'], 30 + 7 * b, dtype=np.int64))} for b in range(K)]
+    stimes = [{t: dev(rng.integers(200, 1000, v.numel(), dtype=np.int64)) for t, v in d.items()} for d in seed_dicts]
+    gseeds = [500 + b for b in range(K)]
+    if mode.startswith('node_time'):
+        kw = dict(node_time_dict=ntime, disjoint=True, temporal_strategy='last' if mode.endswith('last') else 'uniform')
+        per_batch = [dict(seed_time_dict=stimes[b]) for b in range(K)]
+        outs = sampler.hetero_neighbor_sample_batched(rowptr, col, seed_dicts, fan, gseeds, seed_time_dicts=stimes, **kw)
+    elif mode == 'edge_time':
+        kw = dict(edge_time_dict=etime, disjoint=True)
+        per_batch = [dict(seed_time_dict=stimes[b]) for b in range(K)]
+        outs = sampler.hetero_neighbor_sample_batched(rowptr, col, seed_dicts, fan, gseeds, seed_time_dicts=stimes, **kw)
+    else:
+        kw = dict(edge_weight_dict=weight)
+        per_batch = [dict() for _ in range(K)]
+        outs = sampler.hetero_neighbor_sample_batched(rowptr, col, seed_dicts, fan, gseeds, **kw)
+    edges = 0
+    for b in range(K):
+        torch.manual_seed(gseeds[b])
+        one = sampler.hetero_neighbor_sample(rowptr, col, seed_dicts[b], fan, **kw, **per_batch[b])
+        for et in ets:
+            assert torch.equal(outs[b][0][et], one[0][et]) and torch.equal(outs[b][1][et], one[1][et])
+            assert torch.equal(outs[b][3][et], one[3][et]) and outs[b][5][et] == one[5][et]
+            edges += one[0][et].numel()
+        for t in sizes:
+            assert torch.equal(outs[b][2][t], one[2][t]) and outs[b][4][t] == one[4][t]
+    assert edges > 1000
+    with pytest.raises(RuntimeError, match='disjoint'):
+        sampler.hetero_neighbor_sample_batched(rowptr, col, seed_dicts, fan, gseeds, node_time_dict=ntime)
+    with pytest.raises(RuntimeError, match='one seed_time dict per batch'):
+        sampler.hetero_neighbor_sample_batched(rowptr, col, seed_dicts, fan, gseeds, edge_time_dict=etime, disjoint=True,
+                                               seed_time_dicts=stimes[:2])
+
+
 def test_table_cache_release_returns_the_memory():
     rng = np.random.default_rng(3)
     n = 300_000
