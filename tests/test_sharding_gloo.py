@@ -13,9 +13,13 @@ import torch.multiprocessing as mp
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
+    """Rendezvous token of one test: a fresh file for a FileStore (a TCP port picked here could be taken by another pytest
+    worker between the probe and the bind: `pytest -n` runs these tests side by side)."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix='pyg_gloo_rdzv_')
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 def _oracle_matmul(x, ptr, w, bias=None):
@@ -26,8 +30,7 @@ def _oracle_matmul(x, ptr, w, bias=None):
 
 def _worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method=f'file://{port}', rank=rank, world_size=world)
     try:
         from pyg_lib_amd import sharding
         g = torch.Generator().manual_seed(0)
@@ -73,8 +76,7 @@ def _oracle_grouped_into(inputs, others, slot):
 
 def _grouped_worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method=f'file://{port}', rank=rank, world_size=world)
     try:
         from pyg_lib_amd import sharding
         g = torch.Generator().manual_seed(0)
@@ -141,8 +143,7 @@ def test_all_gather_rows_uneven_shards_world_size_2():
 
 def _uneven_worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method=f'file://{port}', rank=rank, world_size=world)
     try:
         from pyg_lib_amd import sharding
         ok = True
@@ -169,8 +170,7 @@ def test_shard_rows_partition():
 
 def _empty_rank_worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method=f'file://{port}', rank=rank, world_size=world)
     try:
         from pyg_lib_amd import sharding
         g = torch.Generator().manual_seed(0)
