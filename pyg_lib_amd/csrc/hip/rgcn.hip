@@ -554,6 +554,9 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
   int* err_dev = reinterpret_cast<int*>(w + rel_b + vec_b + meta_b);
   desc.rp = reinterpret_cast<int32_t*>(w + rel_b + vec_b + meta_b + 256);
   desc.long_rows = reinterpret_cast<uint64_t*>(w + rel_b + vec_b + meta_b + 64);
+#if PYG_ABL_ & 16
+  desc.dbg = reinterpret_cast<uint64_t*>(w + need - 65536);
+#endif
   desc.row_bytes = (int)(K * esz);
   desc.out_bytes = (int)(M * esz);
   {  // an id that no earlier call of this process and no stale word of the workspace holds

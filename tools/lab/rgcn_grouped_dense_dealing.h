@@ -333,12 +333,113 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // front by everybody, the whole chip alternated between phases that only gather (latency bound) and phases that only
   // write zeros (bandwidth bound).  (A scrambled block order mixes the phases too but deals the active blocks unevenly:
   // 0.152 ms instead of 0.070.)
-  // (Dealing the blocks that can have items -- the union of the relations' row ranges -- by a dense number instead of by
-  // position evens out the items per workgroup, 4 ... 8 instead of 3 ... 10 on the C5 sample, and made the launch SLOWER, 72 us
-  // instead of 55: profiles/NOTES_r6.md section 4.  The launch is bound by what the memory system does with the random rows,
-  // not by the longest chain of a workgroup.)
-  const int it_n = nblocks > (int)blockIdx.x ? (nblocks - (int)blockIdx.x + G - 1) / G : 0;   // blocks of this workgroup
-  const int it_k0 = it_n > 0 ? (int)(((uint32_t)blockIdx.x * 2654435761u >> 12) % (uint32_t)it_n) : 0;
+  //
+  // Which blocks can have items is known from the relations' row ranges: the CANDIDATE ranges -- the union of [rlo[r], rhi[r]] in
+  // blocks, merged where they touch (after a sampler: one prefix of every node type that receives anything).  Dealt by
+  // position like everything else, the prefixes start at arbitrary workgroups and overlap: on the C5 sample a workgroup
+  // owned 3 ... 9 items (mean 5.9), and the launch takes as long as the one with 9.  So the candidate blocks are numbered
+  // DENSELY across their ranges and dealt by that number (4 ... 7 items), the others by position as before; a workgroup walks
+  // its two sequences interleaved -- `per` position-dealt blocks, nearly all of them zero rows, per candidate block.  Up to
+  // kMaxRanges ranges of up to 64 relations; otherwise there are no candidates and everything is dealt by position.
+  constexpr int kMaxRanges = 8;
+  int* crt = rhi + kGroupedMaxRel;   // [i] first block, [8 + i] end of candidate range i, [16 + i] candidate blocks in front of it
+  int cr_n = 0, cr_total = 0;
+#ifdef PYG_RGCN_NO_DENSE
+  if (false) {
+#else
+  if (R <= 64) {
+#endif
+    // (every wave for itself, the same values: no barrier; lane r holds relation r's range in blocks)
+    int lo = 1, hi = 0;
+    if (lane < R) lo = rlo[lane], hi = rhi[lane];
+    const bool val = hi >= lo;
+    lo = val ? lo / ROWS : 0x7fffffff;
+    hi = val ? hi / ROWS : -2;
+    int end = hi;   // how far the chain of touching ranges that starts at `lo` reaches to the right
+    bool changed = true;
+    while (__any(changed)) {
+      changed = false;
+      for (int j = 0; j < R; ++j) {
+        const int lj = __builtin_amdgcn_readlane(lo, j), ej = __builtin_amdgcn_readlane(end, j);
+        if (val && ej >= 0 && lj >= lo && lj <= end + 1 && ej > end) end = ej, changed = true;
+      }
+    }
+    bool start = val;   // no other range reaches `lo` from the left (ties: the lower relation starts)
+    int rank = 0;
+    for (int j = 0; j < R; ++j) {
+      const int lj = __builtin_amdgcn_readlane(lo, j), ej = __builtin_amdgcn_readlane(end, j);
+      if (j != lane && ej >= 0 && (lj < lo || (lj == lo && j < lane)) && ej + 1 >= lo) start = false;
+    }
+    const uint64_t smask = __ballot(start);
+    for (int j = 0; j < R; ++j) {
+      const int lj = __builtin_amdgcn_readlane(lo, j);
+      if (((smask >> j) & 1) && lj < lo) ++rank;
+    }
+    cr_n = __builtin_popcountll(smask);
+    if (cr_n <= kMaxRanges) {
+      if (start) crt[rank] = lo, crt[8 + rank] = (end + 1 < nblocks ? end + 1 : nblocks);
+      for (int i = 0; i < cr_n; ++i) {
+        const int b0 = __builtin_amdgcn_readfirstlane(crt[i]), b1 = __builtin_amdgcn_readfirstlane(crt[8 + i]);
+        if (lane == 0) crt[16 + i] = cr_total;
+        cr_total += b1 > b0 ? b1 - b0 : 0;
+      }
+    } else {
+      cr_n = 0;
+    }
+  }
+  cr_n = __builtin_amdgcn_readfirstlane(cr_n);
+  cr_total = __builtin_amdgcn_readfirstlane(cr_total);
+  // the table in scalar registers (constant indices only: a lookup is a handful of scalar compares; read from LDS per block,
+  // every lookup waited for eight dependent LDS round trips -- 15 us per workgroup)
+  int cr_b[kMaxRanges], cr_e[kMaxRanges], cr_p[kMaxRanges];
+#pragma unroll
+  for (int i = 0; i < kMaxRanges; ++i) {
+    cr_b[i] = cr_e[i] = cr_p[i] = 0;
+    if (i < cr_n) {
+      cr_b[i] = __builtin_amdgcn_readfirstlane(crt[i]);
+      cr_e[i] = __builtin_amdgcn_readfirstlane(crt[8 + i]);
+      cr_p[i] = __builtin_amdgcn_readfirstlane(crt[16 + i]);
+      if (cr_e[i] < cr_b[i]) cr_e[i] = cr_b[i];
+    }
+  }
+  const int it_bn = nblocks > (int)blockIdx.x ? (nblocks - (int)blockIdx.x + G - 1) / G : 0;   // blocks of this workgroup by position
+  const int it_k0 = it_bn > 0 ? (int)(((uint32_t)blockIdx.x * 2654435761u >> 12) % (uint32_t)it_bn) : 0;
+  const int it_an = cr_total > (int)blockIdx.x ? (cr_total - (int)blockIdx.x + G - 1) / G : 0;  // its candidate blocks
+#ifdef PYG_RGCN_AFIRST
+  const int it_per = 0;
+#else
+  const int it_per = it_bn / (it_an + 1);
+#endif
+  const int it_ak0 = it_an > 0 ? (int)(((uint32_t)blockIdx.x * 3266489917u >> 12) % (uint32_t)it_an) : 0;
+  int it_ak = 0, it_bk = 0;
+  int it_credit = (int)(((uint32_t)blockIdx.x * 2246822519u >> 12) % (uint32_t)(it_per + 1));   // (the workgroups do not gather in step)
+  auto next_block = [&]() __attribute__((always_inline)) -> int {
+    while (true) {
+      if (it_ak < it_an && (it_bk >= it_bn || it_credit <= 0)) {
+        int ka = it_ak + it_ak0;   // (from a workgroup-specific start, like the others: the ranges are node types, and workgroups
+        if (ka >= it_an) ka -= it_an;   //  that all walk the same type at the same time are slower)
+        const int dense = (int)blockIdx.x + ka * G;
+        ++it_ak;
+        it_credit += it_per;
+        int blk = -1;
+#pragma unroll
+        for (int i = 0; i < kMaxRanges; ++i)
+          if (dense >= cr_p[i] && dense < cr_p[i] + (cr_e[i] - cr_b[i])) blk = cr_b[i] + (dense - cr_p[i]);
+        return blk;
+      }
+      if (it_bk >= it_bn) return -1;
+      int k = it_k0 + it_bk;
+      if (k >= it_bn) k -= it_bn;
+      ++it_bk;
+      --it_credit;
+      const int blk = (int)blockIdx.x + k * G;
+      bool cand = false;
+#pragma unroll
+      for (int i = 0; i < kMaxRanges; ++i) cand = cand || (blk >= cr_b[i] && blk < cr_e[i]);
+      if (!cand) return blk;
+    }
+  };
+  constexpr int it_n = 1;   // it_j: -1 in front of the first block, 0 walking, it_n behind the last
   int it_j = -1, it_blk = -1, it_c0 = R;
   uint64_t it_mask = 0;
   auto chunk_mask = [&](int blk, int c0) __attribute__((always_inline)) -> uint64_t {
@@ -361,11 +462,14 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         it_mask = chunk_mask(it_blk, it_c0);
         continue;
       }
-      if (++it_j >= it_n) return false;
       {
-        int k = it_k0 + it_j;
-        if (k >= it_n) k -= it_n;
-        it_blk = (int)blockIdx.x + k * G;
+        const int nb = next_block();
+        if (nb < 0) {
+          it_j = it_n;
+          return false;
+        }
+        it_j = 0;
+        it_blk = nb;
       }
       it_c0 = 0;
       it_mask = chunk_mask(it_blk, 0);
@@ -757,15 +861,13 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     v2 = v3, blk2 = blk3, rel2 = rel3, kc2 = kc3, st2 = st3, g1_2 = g1n, s1_2 = s1n;
     v3 = v4, blk3 = blk4, rel3 = rel4, kc3 = kc4, st3 = st4;
   }
-#if PYG_ABL_ & 16
-  {   // per workgroup: start, end (100 MHz), sub-items, iterations -- into the workspace behind `meta`
+  if constexpr ((PYG_ABL_ & 16) != 0) {   // per workgroup: start, end (100 MHz), sub-items, iterations -- into the workspace behind `meta`
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
       uint64_t* dbg = desc.dbg + 4 * blockIdx.x;
       dbg[0] = abl_t0, dbg[1] = wall_clock64(), dbg[2] = (uint64_t)abl_items, dbg[3] = (uint64_t)abl_iters;
     }
   }
-#endif
   }  // !SMALL
 }
 
