@@ -296,9 +296,9 @@ PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
  * sums every row's source features in fp32 in edge order, multiplies the 32 sums of a relation with its weight in one
  * MFMA tile, accumulates the relations of a row in fp32 and WRITES every row of `out` once (rows without edges: zeros).
  *   - `out` is OVERWRITTEN, not accumulated into (do not zero it); it must be 16-byte aligned;
- *   - K and M may both be in {64, 128} or both in {128, 256} (the feature rows are walked once per 128-feature slice, W
- *     travels through LDS in 128 x 128 chunks; 64: masked lanes); dtype may also be PYG_F32 with K = M = 128 (fp32 sums and
- *     fp32 FMAs);
+ *   - K and M may be any multiples of 8 up to 256 (the feature rows are walked per 128-feature slice, W travels through
+ *     LDS in 128 x 128 chunks; K, M in {128, 256} have pipelined instances, the others one instance with run-time row sizes
+ *     and masked lanes); dtype may also be PYG_F32 with K = M = 128 (fp32 sums, fp32 MFMAs / FMAs);
  *   - the same bits on every run; rounding: the per-relation feature sum and the result are each rounded once;
  *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of every relation's destination
  *     segment -- scatter_rows, or the rows of `out` at and behind its scatter_offset if that is 0: row starts, touched

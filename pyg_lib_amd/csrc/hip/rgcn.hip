@@ -471,8 +471,10 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
                         int64_t num_out_rows, int64_t K, int64_t M, int checked, void* workspace, size_t workspace_bytes,
                         hipStream_t stream) {
   const size_t esz = dtype == PYG_F32 ? 4 : 2;
-  const bool small = esz == 2 && (K == 64 || M == 64);
-  const int KC = small ? 1 : (int)(K * esz / 256), MC = small ? 1 : (int)(M * esz / 256);   // 256-byte slices of a feature row / of a row of `out`
+  // 16-bit: K, M both in {128, 256} have their own instances; every other pair of multiples of 8 up to 256 takes the instance
+  // with run-time row sizes (rgcn_grouped_small_kernel: KC = MC = 2 slices, those that do not exist skipped)
+  const bool small = esz == 2 && !((K == 128 || K == 256) && (M == 128 || M == 256));
+  const int KC = small ? 2 : (int)(K * esz / 256), MC = small ? 2 : (int)(M * esz / 256);   // 256-byte slices of a feature row / of a row of `out`
   if (num_out_rows == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(out, "rgcn_fused: NULL tensor");
   PYG_HIP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "rgcn_fused: 'out' must be 16-byte aligned in grouped mode");
@@ -675,10 +677,10 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   const bool grouped = (checked & PYG_HIP_RGCN_GROUPED) != 0;
   PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16 || (grouped && dtype == PYG_F32),
                   "rgcn_fused: bfloat16 / float16 only (PYG_HIP_RGCN_GROUPED: float32 too)");
-  const bool wide = (K == 128 || K == 256) && (M == 128 || M == 256), narrow = (K == 64 || K == 128) && (M == 64 || M == 128);
-  if (dtype == PYG_F32 ? (K != 128 || M != 128) : (grouped ? !(wide || narrow) : (K != 128 || M != 128)))
+  const bool any8 = K >= 8 && K <= 256 && M >= 8 && M <= 256 && K % 8 == 0 && M % 8 == 0;
+  if (dtype == PYG_F32 ? (K != 128 || M != 128) : (grouped ? !any8 : (K != 128 || M != 128)))
     return fail(PYG_HIP_ERR_UNSUPPORTED,
-                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M both in {64, 128} or both in {128, 256} for the 16-bit types); got %lld x %lld",
+                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M any multiples of 8 up to 256 for the 16-bit types); got %lld x %lld",
                 (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");

@@ -147,14 +147,16 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   constexpr int kWBytes = WIDE ? 65536 : 32768;
   constexpr int KS = WIDE ? KC : 1;   // slices of a batch in registers at the same time (the pipeline; the item-at-a-time walk: 1)
   // K = 128 KC input features (rows of 256 KC bytes), M = 128 MC output features: the feature rows are walked once per
-  // 128-feature slice (the indices come from L2 the second time), W travels through LDS in 128 x 128 chunks.  The pipeline
-  // exists for KC = MC = 1; the other shapes take the item-at-a-time walk (2 % slower on the C5 batch where both run).
+  // 128-feature slice, W travels through LDS in 128 x 128 chunks (the pipeline at the end of this function: one SUB-ITEM per
+  // slice; the item-at-a-time walk: one pass over the row's edges per slice, the indices come from L2 the second time).
   constexpr int RB0 = 256 * KC, OB0 = 256 * MC;   // bytes of a feature row / of a row of `out`
-  // SMALL (KC = MC = 1): K or M is 64 -- rows of 128 bytes.  Lanes whose 16 bytes lie behind the row's end load nothing
-  // (their part of the A tile is zero), W's columns behind M and rows behind K are never copied (the W buffer is zeroed
-  // once), the stores behind M are dropped; the item-at-a-time walk.
-  static_assert(!SMALL || (KC == 1 && MC == 1 && !F32), "SMALL: 16-bit, K, M in {64, 128}");
+  // SMALL (instantiated with KC = MC = 2): K and M are any multiples of 8 up to 256 -- rows of RB = 2 K / OB = 2 M bytes known at
+  // run time, kcn / mcn slices of them.  Lanes whose 16 bytes lie behind the row's end load nothing
+  // (their part of the A tile is zero), W's columns behind M and rows behind K are written as zeros instead of copied, the
+  // stores behind M are dropped, slices that do not exist are skipped; the item-at-a-time walk.
+  static_assert(!SMALL || (KC == 2 && MC == 2 && !F32), "SMALL: 16-bit, K, M multiples of 8 up to 256");
   const int RB = SMALL ? desc.row_bytes : RB0, OB = SMALL ? desc.out_bytes : OB0;
+  const int kcn = SMALL ? (RB + 255) >> 8 : KC, mcn = SMALL ? (OB + 255) >> 8 : MC;   // slices of a feature row / of a row of `out` that exist
   // F32: K = M = 128 floats, i.e. KC = MC = 2 in BYTES (rows of 512 bytes, walked in two 256-byte slices like K = 256 of the
   // 16-bit types); sums, the A tile and the product stay fp32 -- plain FMAs, IEEE like the reference's fp32 (no MFMA: after
   // the aggregation the product is 16 x 128 x 128 per item, ~4 us of a CU's FMA and LDS time next to ~25 us of gathers) --
@@ -207,11 +209,6 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       rhi[r] = hi;
     }
   }
-  if constexpr (SMALL) {   // 32 KB by 256 threads
-    const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(smem + (i * 256 + tid) * 16) = z;
-  }
   if constexpr (ROWS < 32) {  // rows 16 ... 31 of the A tile are never written: zeros (their products are not stored)
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -237,10 +234,15 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll
     for (int j = 0; j < 32 / NW; ++j) {
       const int kb = wave * (32 / NW) + j;
-      if constexpr (SMALL) {   // (K = RB / 2 rows of M = OB / 2 columns exist)
-        if (dma_c * 16 < OB && 2 * (4 * kb + dma_r) < RB)
+      if constexpr (SMALL) {   // (K = RB / 2 rows of M = OB / 2 columns exist; what lies behind them is written as zeros: the
+                               //  A tile is zero there, but 0 x a stale Inf of the previous chunk would be NaN)
+        if (mc * 256 + dma_c * 16 < OB && 2 * (128 * kc + 4 * kb + dma_r) < RB) {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
                                            (LDSV*)(smem + kb * 1024), 16, 0, 0);
+        } else {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(smem + kb * 1024 + lane * 16) = z;
+        }
       } else {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kb * 4 * OB),
                                          (LDSV*)(smem + kb * 1024), 16, 0, 0);
@@ -290,7 +292,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         const uint32_t rl = (uint32_t)row_bcast<i>(lo), rh = (uint32_t)row_bcast<i>(hi);
         const int64_t row = (int64_t)(((uint64_t)rh << 32) | rl);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < n && (!SMALL || c * 16 < RB)) v = *(GU32x4*)(rel.x + row * RB + kc * 256 + c * 16);
+        if (i < n && (!SMALL || kc * 256 + c * 16 < RB)) v = *(GU32x4*)(rel.x + row * RB + kc * 256 + c * 16);
         xr[i] = v;
       });
     } else {
@@ -299,7 +301,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         constexpr int i = decltype(I)::value;
         const uint32_t off = (uint32_t)row_bcast<i>(rowb) + (uint32_t)(kc * 256 + c * 16);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (i < n && (!SMALL || c * 16 < RB)) v = *(GU32x4*)(rel.x + off);
+        if (i < n && (!SMALL || kc * 256 + c * 16 < RB)) v = *(GU32x4*)(rel.x + off);
         xr[i] = v;
       });
     }
@@ -379,9 +381,10 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         uint32_t z0 = 0;
         asm volatile("" : "+v"(z0));   // (materialised here: hoisted, the four zero registers were spilled and reloaded)
         const u32x4 z = {z0, z0, z0, z0};
-        if (!(PYG_ABL_ & 8) && o < out_rows && (!SMALL || c * 16 < OB)) {
+        if (!(PYG_ABL_ & 8) && o < out_rows) {
 #pragma unroll
-          for (int mc = 0; mc < MC; ++mc) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
+          for (int mc = 0; mc < MC; ++mc)
+            if (!SMALL || mc * 256 + c * 16 < OB) __builtin_nontemporal_store(z, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
         }
         it_c0 = R;
       }
@@ -431,6 +434,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
     const int t = opaque_tid(), lane = t & 63, xl = lane & 31, h = lane >> 5, grp = t >> 4, c = t & 15;
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) {
+      if (SMALL && mc >= mcn) break;
       if (NW == 4 || wave < 4) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -447,7 +451,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       // (MC = 1: every lane reads back the very 16 bytes it writes as its group's part of the next A tile: no barrier behind it)
       const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (grp * 16 + (c ^ (grp & 15))) * 16);
       const int64_t o = (int64_t)blk * ROWS + grp;
-      if (o < out_rows && (!SMALL || c * 16 < OB)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
+      if (o < out_rows && (!SMALL || mc * 256 + c * 16 < OB)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + o * OB + mc * 256 + c * 16));
       if (MC > 1) __syncthreads();   // (the next 128 columns go through the same tile)
     }
   };
@@ -594,6 +598,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       const int d = row_of(blk, rel);
 #pragma unroll 1
       for (int kc = 0; kc < KC; ++kc) {   // one walk over the row's edges per 128-feature slice
+        if (SMALL && kc >= kcn) break;
 #pragma unroll
         for (int k = 0; k < 8; ++k) sum[0][k] = 0.f;
         int sc = st;
@@ -629,6 +634,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
         for (int mc = 0; mc < MC; ++mc) {
 #pragma unroll 1
           for (int kc = 0; kc < KC; ++kc) {
+            if (SMALL && (kc >= kcn || mc >= mcn)) continue;
             if (kc + mc > 0) load_w(rel, kc, mc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
             __syncthreads();
@@ -781,11 +787,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   rgcn_grouped_body<BF16, true, BIG, INL, 4, KC, MC>(desc, R, out, out_rows, error);
 }
 
-// 16-bit, K, M in {64, 128}, at least one of them 64
+// 16-bit, K, M multiples of 8 up to 256 that the kernels above do not take
 template <bool BF16, bool BIG, bool INL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rgcn_grouped_small_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void rgcn_grouped_small_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                                     int64_t out_rows, int* __restrict__ error) {
-  rgcn_grouped_body<BF16, true, BIG, INL, 4, 1, 1, false, true>(desc, R, out, out_rows, error);
+  rgcn_grouped_body<BF16, true, BIG, INL, 4, 2, 2, false, true>(desc, R, out, out_rows, error);
 }
 
 // fp32, K = M = 128

@@ -132,8 +132,8 @@ def test_grouped_random_configurations():
     g = torch.Generator().manual_seed(20260927)
     shapes = [(torch.bfloat16, 128, 128), (torch.float16, 128, 128), (torch.bfloat16, 256, 256), (torch.float16, 128, 256),
               (torch.bfloat16, 256, 128), (torch.float32, 128, 128), (torch.bfloat16, 64, 64), (torch.float16, 128, 64),
-              (torch.bfloat16, 64, 128)]
-    for case in range(54):
+              (torch.bfloat16, 64, 128), (torch.float16, 40, 216), (torch.bfloat16, 192, 24), (torch.float16, 256, 16)]
+    for case in range(72):
         dtype, K, M = shapes[case % len(shapes)]
         T = int(torch.randint(1, 4, (1,), generator=g))
         types = [f't{i}' for i in range(T)]
@@ -233,11 +233,12 @@ def test_grouped_on_a_sampled_mag_neighbourhood(dtype):
         assert torch.equal(rgcn.rgcn_layer_fused_tables(feat, node_d, MAG_TYPES, row_d, col_d, MAG_ETS, W, grouped=True), y)
 
 
-@pytest.mark.parametrize('K,M', [(256, 256), (128, 256), (256, 128), (64, 64), (128, 64), (64, 128)])
+@pytest.mark.parametrize('K,M', [(256, 256), (128, 256), (256, 128), (64, 64), (128, 64), (64, 128), (32, 32), (8, 256), (96, 160),
+                                 (200, 72), (256, 64), (64, 256), (248, 8), (136, 136)])
 def test_grouped_feature_widths_of_64_and_256(K, M):
-    """K and M of the atomic-free kernel may both be in {64, 128} or both in {128, 256} (C4's width): the feature rows are
-    walked once per 128-feature slice, W travels through LDS in 128 x 128 chunks; for 64, lanes / columns / rows behind the
-    end are masked.  Exact on integer data (rows of 0 ... 70 edges, several
+    """K and M of the atomic-free kernel may be any multiples of 8 up to 256 (256: C4's width): the feature rows are
+    walked once per 128-feature slice, W travels through LDS in 128 x 128 chunks; outside {128, 256} lanes / columns / rows
+    behind the end are masked (one instance with run-time row sizes).  Exact on integer data (rows of 0 ... 70 edges, several
     node types, through x and through the global tables), a float64 restatement on random data, autograd (the backward
     takes the chain for these shapes), and the ungrouped call still falls back to the three-op chain."""
     from pyg_lib_amd import rgcn
