@@ -298,7 +298,8 @@ PYG_HIP_API int pyg_hip_rgcn_pending_error(void);
  *   - `out` is OVERWRITTEN, not accumulated into (do not zero it); it must be 16-byte aligned;
  *   - K and M may be any multiples of 8 up to 256 (the feature rows are walked per 128-feature slice, W travels through
  *     LDS in 128 x 128 chunks; K, M in {128, 256} have pipelined instances, the others one instance with run-time row sizes
- *     and masked lanes); dtype may also be PYG_F32 with K = M = 128 (fp32 sums, fp32 MFMAs / FMAs);
+ *     and masked lanes); dtype may also be PYG_F32 with K, M multiples of 4 up to 128 (fp32 sums; 128 x 128: fp32
+ *     MFMAs, otherwise FMAs);
  *   - the same bits on every run; rounding: the per-relation feature sum and the result are each rounded once;
  *   - the workspace is pyg_hip_rgcn_grouped_workspace_size() bytes (4 bytes per row of every relation's destination
  *     segment -- scatter_rows, or the rows of `out` at and behind its scatter_offset if that is 0: row starts, touched

@@ -604,6 +604,9 @@ int rgcn_grouped_launch(int dtype, const void* x, int64_t num_x_rows, const pyg_
                        : (inl ? (const void*)&rgcn_grouped_small_kernel<true, false, true> : (const void*)&rgcn_grouped_small_kernel<true, false, false>))
                 : (big ? (inl ? (const void*)&rgcn_grouped_small_kernel<false, true, true> : (const void*)&rgcn_grouped_small_kernel<false, true, false>)
                        : (inl ? (const void*)&rgcn_grouped_small_kernel<false, false, true> : (const void*)&rgcn_grouped_small_kernel<false, false, false>));
+    else if (dtype == PYG_F32 && (K != 128 || M != 128))
+      kern = big ? (inl ? (const void*)&rgcn_grouped_f32_small_kernel<true, true> : (const void*)&rgcn_grouped_f32_small_kernel<true, false>)
+                 : (inl ? (const void*)&rgcn_grouped_f32_small_kernel<false, true> : (const void*)&rgcn_grouped_f32_small_kernel<false, false>);
     else if (dtype == PYG_F32)
       kern = big ? (inl ? (const void*)&rgcn_grouped_f32_kernel<true, true> : (const void*)&rgcn_grouped_f32_kernel<true, false>)
                  : (inl ? (const void*)&rgcn_grouped_f32_kernel<false, true> : (const void*)&rgcn_grouped_f32_kernel<false, false>);
@@ -678,9 +681,10 @@ int pyg_hip_rgcn_fused(int dtype, const void* x, int64_t num_x_rows, const pyg_h
   PYG_HIP_REQUIRE(dtype == PYG_BF16 || dtype == PYG_F16 || (grouped && dtype == PYG_F32),
                   "rgcn_fused: bfloat16 / float16 only (PYG_HIP_RGCN_GROUPED: float32 too)");
   const bool any8 = K >= 8 && K <= 256 && M >= 8 && M <= 256 && K % 8 == 0 && M % 8 == 0;
-  if (dtype == PYG_F32 ? (K != 128 || M != 128) : (grouped ? !any8 : (K != 128 || M != 128)))
+  const bool any4 = K >= 4 && K <= 128 && M >= 4 && M <= 128 && K % 4 == 0 && M % 4 == 0;   // (fp32: rows of multiples of 16 bytes up to 512)
+  if (dtype == PYG_F32 ? !any4 : (grouped ? !any8 : (K != 128 || M != 128)))
     return fail(PYG_HIP_ERR_UNSUPPORTED,
-                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M any multiples of 8 up to 256 for the 16-bit types); got %lld x %lld",
+                "rgcn_fused: K = M = 128 only (PYG_HIP_RGCN_GROUPED: K, M any multiples of 8 up to 256 for the 16-bit types, of 4 up to 128 for float32); got %lld x %lld",
                 (long long)K, (long long)M);
   PYG_HIP_REQUIRE(R >= 0 && R < (1 << 30), "rgcn_fused: bad relation count");
   PYG_HIP_REQUIRE(num_x_rows >= 0 && num_out_rows >= 0, "rgcn_fused: negative size");

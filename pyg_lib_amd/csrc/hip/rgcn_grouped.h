@@ -154,7 +154,7 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   // run time, kcn / mcn slices of them.  Lanes whose 16 bytes lie behind the row's end load nothing
   // (their part of the A tile is zero), W's columns behind M and rows behind K are written as zeros instead of copied, the
   // stores behind M are dropped, slices that do not exist are skipped; the item-at-a-time walk.
-  static_assert(!SMALL || (KC == 2 && MC == 2 && !F32), "SMALL: 16-bit, K, M multiples of 8 up to 256");
+  static_assert(!SMALL || (KC == 2 && MC == 2), "SMALL: 16-bit with K, M multiples of 8 up to 256; fp32 with multiples of 4 up to 128");
   const int RB = SMALL ? desc.row_bytes : RB0, OB = SMALL ? desc.out_bytes : OB0;
   const int kcn = SMALL ? (RB + 255) >> 8 : KC, mcn = SMALL ? (OB + 255) >> 8 : MC;   // slices of a feature row / of a row of `out` that exist
   // F32: K = M = 128 floats, i.e. KC = MC = 2 in BYTES (rows of 512 bytes, walked in two 256-byte slices like K = 256 of the
@@ -470,14 +470,26 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
   };
   // F32: W[32 q ... 32 q + 31][0 ... 127] (16 KB, contiguous in memory) into buffer q & 1, as it lies: four DMA instructions
   // per wave
+  // (SMALL: rows of OB <= 512 bytes, K = RB / 4 of them: the piece is 32 OB bytes, its rows behind K are written as zeros)
   auto load_w32 = [&](int g, int q) __attribute__((always_inline)) {
     const int lane = opaque_tid() & 63;
-    const char* wsrc = rel_at(g).weight + q * 16384 + lane * 16;
+    const int pbytes = SMALL ? 32 * OB : 16384;
+    const char* wsrc = rel_at(g).weight + (size_t)q * pbytes + lane * 16;
+    int valid = pbytes;
+    if constexpr (SMALL) {
+      const int krows = (RB >> 2) - 32 * q;
+      valid = (krows >= 32 ? 32 : (krows > 0 ? krows : 0)) * OB;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int blk1k = wave * 4 + j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + blk1k * 1024),
-                                       (LDSV*)(smem + (q & 1) * 16384 + blk1k * 1024), 16, 0, 0);
+      if (!SMALL || blk1k * 1024 + lane * 16 < valid) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + blk1k * 1024),
+                                         (LDSV*)(smem + (q & 1) * 16384 + blk1k * 1024), 16, 0, 0);
+      } else if (blk1k * 1024 + lane * 16 < pbytes) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + (q & 1) * 16384 + blk1k * 1024 + lane * 16) = z;
+      }
     }
   };
   float acc8[8];   // F32: row tid / 16, columns 8 (tid % 16) ... + 7 of the block's results
@@ -490,7 +502,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll 8
     for (int kk = 0; kk < 32; ++kk) {
       const float av = *reinterpret_cast<const float*>(a + kk * 4);
-      const u32x4 w0 = *reinterpret_cast<const u32x4*>(w + kk * 512), w1 = *reinterpret_cast<const u32x4*>(w + kk * 512 + 16);
+      const int wp = SMALL ? OB : 512;   // (a thread whose 8 columns lie behind M reads into the next row: results nobody stores)
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(w + kk * wp), w1 = *reinterpret_cast<const u32x4*>(w + kk * wp + 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         acc8[k] = __builtin_fmaf(av, u2f(w0[k]), acc8[k]);
@@ -505,8 +518,8 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
 #pragma unroll
     for (int k = 0; k < 4; ++k) v0[k] = f2u(acc8[k]), v1[k] = f2u(acc8[4 + k]);
     if (o < out_rows) {
-      __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(out + o * OB + cg * 32));
-      __builtin_nontemporal_store(v1, reinterpret_cast<u32x4*>(out + o * OB + cg * 32 + 16));
+      if (!SMALL || cg * 32 < OB) __builtin_nontemporal_store(v0, reinterpret_cast<u32x4*>(out + o * OB + cg * 32));
+      if (!SMALL || cg * 32 + 16 < OB) __builtin_nontemporal_store(v1, reinterpret_cast<u32x4*>(out + o * OB + cg * 32 + 16));
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc8[k] = 0.f;
@@ -622,11 +635,12 @@ __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R
       if constexpr (F32) {
         // W in four pieces of 32 k-rows through two buffers: piece q + 1 travels while piece q is multiplied.  (A thread
         // reads the A rows its own wave wrote; the barrier is for W.)
+        const int nq = SMALL ? ((RB >> 2) + 31) >> 5 : 4;
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < nq; ++q) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (W's DMA is invisible to the compiler's counters)
           __syncthreads();   // piece q is there for everybody; everybody is done with piece q - 1
-          if (q < 3) load_w32(rel, q + 1);
+          if (q + 1 < nq) load_w32(rel, q + 1);
           product32(q);
         }
       } else {
@@ -792,6 +806,13 @@ template <bool BF16, bool BIG, bool INL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void rgcn_grouped_small_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
                                                                                                     int64_t out_rows, int* __restrict__ error) {
   rgcn_grouped_body<BF16, true, BIG, INL, 4, 2, 2, false, true>(desc, R, out, out_rows, error);
+}
+
+// fp32, K, M multiples of 4 up to 128 other than 128 x 128 (run-time row sizes, the item-at-a-time walk, plain FMAs)
+template <bool BIG, bool INL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rgcn_grouped_f32_small_kernel(const GroupedDesc desc, int R, char* __restrict__ out,
+                                                                                                        int64_t out_rows, int* __restrict__ error) {
+  rgcn_grouped_body<false, true, BIG, INL, 4, 2, 2, true, true>(desc, R, out, out_rows, error);
 }
 
 // fp32, K = M = 128

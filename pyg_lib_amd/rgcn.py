@@ -204,12 +204,14 @@ def _resolve_grouped(grouped: Optional[bool], scatter: List[Tensor]) -> bool:
 
 def _fusable(x: Tensor, weight: Tensor, grouped: bool = False) -> bool:
     # the atomic kernel: 16-bit, F_in = F_out = 128; the grouped (atomic-free) kernel: 16-bit with F_in, F_out any multiples
-    # of 8 up to 256, or float32 with F_in = F_out = 128
+    # of 8 up to 256, or float32 with multiples of 4 up to 128
     if x.dim() != 2 or weight.dim() != 3:
         return False
     K, M = x.size(1), weight.size(2)
-    if not grouped or x.dtype == torch.float32:
+    if not grouped:
         shape_ok = K == 128 and M == 128
+    elif x.dtype == torch.float32:   # rows of multiples of 16 bytes up to 512
+        shape_ok = 4 <= K <= 128 and 4 <= M <= 128 and K % 4 == 0 and M % 4 == 0
     else:
         shape_ok = 8 <= K <= 256 and 8 <= M <= 256 and K % 8 == 0 and M % 8 == 0
     dtypes = (torch.bfloat16, torch.float16, torch.float32) if grouped else (torch.bfloat16, torch.float16)
@@ -400,7 +402,7 @@ def rgcn_layer_fused(x: Tensor, offsets: Dict[str, int], row_dict: Dict[EdgeType
     gathered straight into the matmul's operand tile, messages are summed per destination run inside the workgroup
     and added with packed atomics -- neither ``feats`` nor ``msgs`` exist in HBM, and the sampler's per-relation
     index vectors are read in place (no ``torch.cat``).  16-bit features with ``F_in = F_out = 128`` (``grouped=True``:
-    any multiples of 8 up to 256, or float32 with 128 / 128); anything else takes the three-op chain.
+    any multiples of 8 up to 256, or float32 with multiples of 4 up to 128); anything else takes the three-op chain.
 
     Differentiable: with gradients recorded for ``x`` or ``weight`` the forward still is the one fused launch, and the
     backward runs the fused kernel with swapped roles for dX (atomic adds; under

@@ -415,6 +415,53 @@ def test_grouped_float32():
         assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
 
 
+@pytest.mark.parametrize('K,M', [(64, 64), (32, 128), (128, 32), (4, 4), (100, 52), (124, 128), (72, 12)])
+def test_grouped_float32_other_widths(K, M):
+    """float32 with K, M any multiples of 4 up to 128 (rows of multiples of 16 bytes): the instance with run-time row sizes --
+    lanes, W rows and columns behind the ends masked, W's masked rows written as zeros.  Exact on integer data (rows of 0 ... 70
+    edges and rows of at most 16, x and tables), 1e-5 against float64 on random data, the same bits on every run."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(900 + K + 3 * M)
+    types = ['a', 'b']
+    n = {'a': 333, 'b': 90}
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b'), ('b', 'r3', 'b')]
+    for counts, hi in (([3000, 40, 4096 + 33, 0], 60), ([300, 40, 400, 7], 10 ** 6)):
+        rows, cols = {}, {}
+        for et, c in zip(ets, counts):
+            s, _, d = et
+            rows[et] = torch.sort(torch.randint(0, min(hi, n[s]), (c,), generator=g)).values.cuda()
+            cols[et] = torch.randint(0, n[d], (c,), generator=g).cuda()
+        off = rgcn.type_offsets(n, types)
+        soff = [off[s] for s, _, _ in ets]
+        goff = [off[d] for _, _, d in ets]
+        x = {t: torch.randint(-3, 4, (n[t], K), generator=g).float() for t in types}
+        xc = torch.cat([x[t] for t in types])
+        W = column_selectors(len(ets), K, M, g)
+        want = exact_want(off['__total__'], M, ets, rows, cols, xc, W, soff, goff)
+        y = rgcn.rgcn_layer_fused(xc.cuda(), off, rows, cols, ets, W.cuda(), grouped=True)
+        assert rgcn.last_layer_path() == 'grouped'
+        assert y.shape == (off['__total__'], M) and y.dtype == torch.float32 and torch.equal(y.double().cpu(), want)
+        n_glob = {'a': 4000, 'b': 700}
+        nid = {t: torch.randperm(n_glob[t], generator=g)[:n[t]] for t in types}
+        tab = {t: torch.randint(-3, 4, (n_glob[t], K), generator=g).float() for t in types}
+        for t in types:
+            tab[t][nid[t]] = x[t]
+        yt = rgcn.rgcn_layer_fused_tables({t: tab[t].cuda() for t in types}, {t: nid[t].cuda() for t in types}, types, rows, cols, ets,
+                                          W.cuda(), grouped=True)
+        assert torch.equal(yt.double().cpu(), want)
+        xr = torch.randn(off['__total__'], K, generator=g).cuda()
+        wr = (torch.randn(len(ets), K, M, generator=g) / K ** 0.5).cuda()
+        yr = rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True)
+        ref = torch.zeros(off['__total__'], M, dtype=torch.float64, device='cuda')
+        for i, et in enumerate(ets):
+            ref.index_add_(0, rows[et] + soff[i], xr[cols[et] + goff[i]].double() @ wr[i].double())
+        scale = ref.abs().max().item()
+        assert scale > 0.5 and (yr.double() - ref).abs().max().item() <= 1e-5 * scale
+        assert torch.equal(yr, rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True))
+    torch.cuda.synchronize()
+    assert rgcn.pending_index_error() == 0
+
+
 def test_sampler_rows_take_the_atomic_free_kernel_by_default():
     """`grouped=None` (the default): rows that ARE outputs of this package's samplers (csc=False) are nondecreasing by
     construction, so the layer runs the atomic-free kernel without a flag; a copy of them (or any hand-made edge list) is

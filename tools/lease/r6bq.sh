@@ -1,6 +1,6 @@
 #!/bin/bash
 # general (K, M) of the atomic-free layer: tests, stress, probes
-R=/root/repo/gpurun_out/r6_bp
+R=/root/repo/gpurun_out/r6_bq
 mkdir -p $R
 cd /root/repo
 timeout 900 python -m pytest tests/test_rgcn_grouped_gpu.py tests/test_rgcn_gpu.py tests/test_rgcn_csc_gpu.py tests/test_capi_raw_gpu.py tests/test_deterministic_gpu.py -m gpu -x -q > $R/pytest.txt 2>&1

@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(seed)
 shapes = [(torch.bfloat16, 128, 128), (torch.float16, 128, 128), (torch.bfloat16, 256, 256), (torch.float16, 128, 256),
           (torch.bfloat16, 256, 128), (torch.float32, 128, 128), (torch.bfloat16, 64, 64), (torch.float16, 128, 64),
           (torch.bfloat16, 64, 128), (torch.float16, 40, 216), (torch.bfloat16, 192, 24), (torch.float16, 256, 16),
-          (torch.bfloat16, 8, 8), (torch.bfloat16, 104, 104)]
+          (torch.bfloat16, 8, 8), (torch.bfloat16, 104, 104), (torch.float32, 64, 64), (torch.float32, 20, 128), (torch.float32, 128, 36)]
 
 
 def ri(lo, hi):
