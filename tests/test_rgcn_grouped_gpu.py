@@ -300,10 +300,13 @@ def test_grouped_feature_widths_of_64_and_256(K, M):
 
 
 @pytest.mark.parametrize('dtype,K,M', [(torch.bfloat16, 128, 128), (torch.bfloat16, 256, 256), (torch.float16, 256, 256),
-                                       (torch.float16, 128, 256), (torch.bfloat16, 256, 128), (torch.float32, 128, 128)])
+                                       (torch.float16, 128, 256), (torch.bfloat16, 256, 128), (torch.float32, 128, 128),
+                                       (torch.bfloat16, 64, 64), (torch.float16, 192, 40), (torch.bfloat16, 32, 200), (torch.float32, 64, 64)])
 def test_grouped_short_rows_take_the_pipeline(dtype, K, M):
     """Rows of at most 16 edges per relation -- what the samplers emit for fan-outs up to 16 -- run through the software
-    pipeline of the atomic-free kernel (one sub-item per 128-feature slice for the 16-bit shapes; float32 with both slices
+    pipeline of the atomic-free kernel (K, M in {128, 256} and float32 128 x 128; the other widths in the list keep the
+    item-at-a-time walk whatever the rows are: built with the pipeline they need 169 - 173 registers, two waves per SIMD,
+    and are 1.3 - 1.45 x slower) (one sub-item per 128-feature slice for the 16-bit shapes; float32 with both slices
     and all of W at once, the product on fp32 MFMAs), the other tests' rows of up to 70 edges through the item-at-a-time
     walk.  Enough blocks that every workgroup of the persistent launch owns several items (the pipeline is four deep),
     degrees 0 ... 16 incl. exactly 16, type offsets that are no multiples of 16, an empty relation; exact on integer data
