@@ -40,6 +40,11 @@ cp('clock_probe.txt', 'clock_probe.txt')
 cp('c5_layer_probe.txt', 'c5_layer_probe.txt')
 cp('prof_layer/layer_kernel_stats.csv', 'c5_layer_kernel_stats.csv')
 cp('rocm_smi.txt', 'rocm_smi.txt')
+cp('prof_layer_256/layer_kernel_stats.csv', 'c5_layer_f256_kernel_stats.csv')
+cp('prof_layer_128_f32/layer_kernel_stats.csv', 'c5_layer_f32_kernel_stats.csv')
+cp('c5_layer_256_under_rocprof.log', 'c5_layer_f256_probe.txt')
+cp('c5_layer_128_f32_under_rocprof.log', 'c5_layer_f32_probe.txt')
+cp('c5_item_balance.txt', 'c5_item_balance.txt')
 
 
 def rows(d):

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round-end evidence (tools/profile_round.sh) + one full GPU pass
+R=/root/repo/gpurun_out/r6_zz
+mkdir -p $R
+cd /root/repo
+bash tools/profile_round.sh r6_zz > $R/profile_round.log 2>&1
+cd /root/repo
+timeout 1500 python -m pytest tests -m gpu -x -q > $R/pytest_1.txt 2>&1
+echo "pytest rc=$?" >> $R/pytest_1.txt
+tail -3 $R/pytest_1.txt | grep -v "^$"
+cp gpurun_out/gpu_health.txt $R/gpu_health.txt 2>/dev/null
+tail -c 700 $R/bench_full_1.json

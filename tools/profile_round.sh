@@ -26,6 +26,11 @@ python /root/repo/tools/clock_probe.py > $R/clock_probe.txt 2>&1
 # C5 layer alone: atomic kernel + zero fill against the atomic-free grouped kernel (wall clock, then the kernels' own times)
 PYTHONPATH=/root/repo python /root/repo/tools/rgcn_grouped_probe.py 50 > $R/c5_layer_probe.txt 2>&1
 PYTHONPATH=/root/repo rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_layer -o layer -- python /root/repo/tools/rgcn_grouped_probe.py 20 > $R/c5_layer_under_rocprof.log 2>&1
+# the same layer at F = 256 and in float32 (kernel times), and the per-workgroup balance of the sample
+for a in "256" "128 f32"; do
+  PYTHONPATH=/root/repo rocprofv3 --kernel-trace --stats --output-format csv -d "$R/prof_layer_${a// /_}" -o layer -- python /root/repo/tools/rgcn_grouped_probe.py 20 15,10 $a > "$R/c5_layer_${a// /_}_under_rocprof.log" 2>&1
+done
+PYTHONPATH=/root/repo python /root/repo/tools/rgcn_item_balance.py 768 > $R/c5_item_balance.txt 2>&1
 rocm-smi --showmemorypartition --showcomputepartition --showclocks --showpower --showperflevel > $R/rocm_smi.txt 2>&1
 cp /root/repo/gpurun_out/gpu_health.txt $R/gpu_health.txt 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 /root/repo/bench.py --gpus 2 --debug-one-device --no-cpu-baseline > $R/bench_2rank_debug.json 2> $R/bench_2rank_debug.err
