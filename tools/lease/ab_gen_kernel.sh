@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of two builds of one translation unit on the same box (here: the general-shape matmul kernel, K = 100); variants from tools/build_variant.sh
 R=/root/repo/gpurun_out/r6_ab3
 mkdir -p $R
 cd /root/repo

@@ -1,4 +1,5 @@
 #!/bin/bash
+# forward + backward of the C5 layer under rocprofv3 --stats (tools/c5_train_step.py), default and atomic-free dX
 R=/root/repo/gpurun_out/r6_p
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# SQ / TCC counter passes of one driver script (tools/pmc_*.py)
 R=/root/repo/gpurun_out/r6_pmc2
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
