@@ -254,8 +254,11 @@ __device__ __forceinline__ u32x2 gen_pack4(f16_t, const float* v) {
 
 // One chunk of the contraction for one wave: acc[b] += W^T[32 b ... 32 b + 31][chunk] * X^T[chunk][32 rows], b < NBLK.
 // `xp` = the lane's row of the X image (+ 16 h), `W` = the W image ([k][128 columns], or [128 columns][k] if TRANS).
+// `first`: the tile's first chunk -- the accumulators start at zero, which the first MFMA of every block takes as its C operand
+// (an inline constant) instead of 16 v_mov per block in front of the loop.
 template <typename T, int NBLK, bool TRANS>
-__device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const char* W, int kvalid, int lane) {
+__device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const char* W, int kvalid, int lane, bool first) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int SZ = Elem<T>::kSize;
   constexpr int PW = 128 * SZ + 64;
   typedef short v4i16 __attribute__((ext_vector_type(4)));
@@ -266,7 +269,19 @@ __device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const 
     if constexpr (!TRANS) {
       const int q = lane & 15, g1 = (lane >> 4) & 1;
       const char* wp = W + (h * 8 + (q >> 2)) * PW + (g1 * 16 + (q & 3) * 4) * 2;
-      for (int ks = 0; ks < nks; ++ks) {
+      int ks0 = 0;
+      if (first) {   // (kvalid >= 1: there is a step 0)
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xp);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          const v4i16 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wp + b * 64));
+          const v4i16 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wp + 4 * PW + b * 64));
+          const u32x4 wa = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[b] = mfma_chunk(T{}, wa, xa, zero);
+        }
+        ks0 = 1;
+      }
+      for (int ks = ks0; ks < nks; ++ks) {
         const u32x4 xa = *reinterpret_cast<const u32x4*>(xp + ks * 32);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
@@ -278,7 +293,17 @@ __device__ __forceinline__ void gen_mma(f32x16 (&acc)[4], const char* xp, const 
       }
     } else {
       const char* wp = W + j * kGenPX + h * 16;
-      for (int ks = 0; ks < nks; ++ks) {
+      int ks0 = 0;
+      if (first) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xp);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          const u32x4 wa = *reinterpret_cast<const u32x4*>(wp + b * 32 * kGenPX);
+          acc[b] = mfma_chunk(T{}, wa, xa, zero);
+        }
+        ks0 = 1;
+      }
+      for (int ks = ks0; ks < nks; ++ks) {
         const u32x4 xa = *reinterpret_cast<const u32x4*>(xp + ks * 32);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
@@ -388,18 +413,20 @@ __device__ __forceinline__ void gen_tile(const DevGroup& d, const int64_t row0, 
     const int mvalid = M - nb * 128 < 128 ? M - nb * 128 : 128;
     const int nblk = (mvalid + 31) >> 5;
     if (active) {
-      if (c == 0) {
+      if constexpr (SZ == 4) {   // (fp32: zeroed here -- through gen_mma's first step the kernel spilled; the 16-bit types: see gen_mma)
+        if (c == 0) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 4; ++b)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        }
       }
       const int kvalid = K - c * KC < KC ? K - c * KC : KC;
       int l1 = lane;
       asm volatile("" : "+v"(l1));  // as in issue(): keep the lane-derived LDS offsets of all variants out of registers
       const char* xp = X + (wave * 32 + (l1 & 31)) * kGenPX + (l1 >> 5) * 16;
       // column blocks behind M multiply the zero-filled part of the W image
-      gen_mma<T, NBLK, TRANS>(acc, xp, W, kvalid, l1);
+      gen_mma<T, NBLK, TRANS>(acc, xp, W, kvalid, l1, c == 0);
     }
     if (s + 1 < nsteps || c == nchunks - 1) __syncthreads();  // everybody has multiplied: the buffer is free
     if (c == nchunks - 1) {
