@@ -744,6 +744,51 @@ def test_backward_runs_without_float_atomics_and_is_bit_reproducible():
     assert (grads['grouped'] - grads['atomic']).abs().max().item() <= 5e-2 * scale
 
 
+@pytest.mark.parametrize('dtype,K,M', [(torch.bfloat16, 96, 40), (torch.float16, 64, 64), (torch.bfloat16, 256, 24), (torch.float32, 64, 32)])
+def test_backward_of_other_widths_is_atomic_free_too(dtype, K, M):
+    """The run-time-size instances serve the backward as well: dX[g_e] += dOut[s_e] @ W_r^T is the same kernel with the roles
+    swapped (K and M exchanged) on the transposed sample (rgcn.set_dx_mode('grouped')).  No accumulating launch in forward or
+    backward, two runs give the same bits, dX exact on integer data, dW against float64."""
+    from pyg_lib_amd import rgcn, diagnostics, ops
+    g = torch.Generator().manual_seed(31 + K + M)
+    types = ['a', 'b']
+    n = {'a': 700, 'b': 260}
+    ets = [('a', 'r0', 'a'), ('b', 'r1', 'a'), ('a', 'r2', 'b')]
+    rows, cols = {}, {}
+    for et, c in zip(ets, [4000, 900, 2500]):
+        s, _, d = et
+        rows[et] = torch.sort(torch.randint(0, n[s] // 2, (c,), generator=g)).values.cuda()
+        cols[et] = torch.randint(0, n[d], (c,), generator=g).cuda()
+    off = rgcn.type_offsets(n, types)
+    x0 = torch.randint(-2, 3, (off['__total__'], K), generator=g).to(dtype).cuda()
+    W0 = column_selectors(len(ets), K, M, g).to(dtype).cuda()
+    c0 = torch.randint(-1, 2, (off['__total__'], M), generator=g).to(dtype).cuda()
+    ops.scatter_sum(torch.ones(4, 2, device='cuda'), torch.tensor([[0, 1], [1, 0], [0, 0], [1, 1]], device='cuda'), 0, None, 2)
+    marker = diagnostics.last_accumulate_info()
+    before = rgcn.set_dx_mode('grouped')
+    try:
+        runs = []
+        for _ in range(2):
+            xg, wg = x0.clone().requires_grad_(), W0.clone().requires_grad_()
+            y = rgcn.rgcn_layer_fused(xg, off, rows, cols, ets, wg, grouped=True)
+            assert rgcn.last_layer_path() == 'grouped'
+            (y * c0).sum().backward()
+            runs.append((xg.grad.clone(), wg.grad.clone()))
+        assert diagnostics.last_accumulate_info() == marker
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    finally:
+        rgcn.set_dx_mode(before)
+    want_x = torch.zeros(off['__total__'], K, dtype=torch.float64, device='cuda')
+    want_w = torch.zeros(len(ets), K, M, dtype=torch.float64, device='cuda')
+    for i, (s, r, d) in enumerate(ets):
+        gi, si = cols[(s, r, d)] + off[d], rows[(s, r, d)] + off[s]
+        want_x.index_add_(0, gi, c0[si].double() @ W0[i].double().t())
+        want_w[i] = x0[gi].double().t() @ c0[si].double()
+    assert want_x.abs().max().item() <= 256 and torch.equal(runs[0][0].double(), want_x)
+    tol = {torch.float32: 1e-5, torch.bfloat16: 8e-3, torch.float16: 1.5e-3}[dtype] * max(want_w.abs().max().item(), 1.0)
+    assert (runs[0][1].double() - want_w).abs().max().item() <= tol
+
+
 def test_gather_index_beyond_32_bits_is_reported_not_aliased():
     """the 32-bit row arithmetic of tables below 4 GiB must not let an index of 2^32 + k pass as row k."""
     from pyg_lib_amd import rgcn
