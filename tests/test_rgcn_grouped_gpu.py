@@ -465,6 +465,39 @@ def test_grouped_float32_other_widths(K, M):
     assert rgcn.pending_index_error() == 0
 
 
+@pytest.mark.parametrize('short_rows', [True, False])
+def test_grouped_float32_special_values(short_rows):
+    """float32 through both products of the atomic-free kernel (rows of at most 16 edges: the pipeline's fp32 MFMAs; longer
+    rows: plain FMAs): denormal features stay denormal (their sums and +-1 weights are exact), Inf and NaN propagate to the
+    rows that gather them and to no others -- the same as the float64 restatement rounded to float32."""
+    from pyg_lib_amd import rgcn
+    g = torch.Generator().manual_seed(77 if short_rows else 78)
+    F = 128
+    n = 20000 if short_rows else 600
+    ets = [('a', 'r0', 'a'), ('a', 'r1', 'a')]
+    rows, cols = {}, {}
+    for et in ets:
+        deg = torch.randint(0, 17 if short_rows else 60, (n // 2,), generator=g)
+        rows[et] = torch.repeat_interleave(torch.arange(n // 2), deg).cuda()
+        cols[et] = torch.randint(0, n, (int(deg.sum()),), generator=g).cuda()
+    off = rgcn.type_offsets({'a': n}, ['a'])
+    tiny = 2.0 ** -149
+    x = (torch.randint(-40, 41, (n, F), generator=g).double() * tiny)
+    x[3, 5], x[7, 100], x[11, 64] = float('inf'), float('nan'), float('-inf')
+    W = signed_permutations(len(ets), F, g)
+    want = torch.zeros(n, F, dtype=torch.float64)
+    for i, et in enumerate(ets):
+        want.index_add_(0, rows[et].cpu(), x[cols[et].cpu()] @ W[i].double())
+    y = rgcn.rgcn_layer_fused(x.float().cuda(), off, rows, cols, ets, W.cuda(), grouped=True).cpu()
+    assert rgcn.last_layer_path() == 'grouped'
+    wf = want.float()
+    assert torch.equal(torch.isnan(y), torch.isnan(wf))
+    assert int(torch.isnan(wf).sum()) > 0 and int(torch.isinf(wf).sum()) > 0
+    ok = ~torch.isnan(wf)
+    assert torch.equal(y[ok], wf[ok])
+    assert float(wf[ok & ~torch.isinf(wf)].abs().max()) < 1e-40 and float(wf[ok & ~torch.isinf(wf)].abs().max()) > 0   # all denormal
+
+
 def test_sampler_rows_take_the_atomic_free_kernel_by_default():
     """`grouped=None` (the default): rows that ARE outputs of this package's samplers (csc=False) are nondecreasing by
     construction, so the layer runs the atomic-free kernel without a flag; a copy of them (or any hand-made edge list) is
