@@ -10,6 +10,7 @@
 // (pyg_binding_cpu.cpp, dispatch key `CPU`); every other op of this library is device-only and a CPU tensor
 // reaches the dispatcher's "could not run ... with arguments from the 'CPU' backend" error.  A device tensor
 // never takes a CPU path: there is no fallback of any kind.
+#include <chrono>
 #include <ATen/ATen.h>
 #include <ATen/CPUGeneratorImpl.h>
 #include <ATen/core/dispatch/Dispatcher.h>
@@ -650,6 +651,28 @@ struct SampleOutput {
   std::vector<std::vector<int64_t>> nodes_per_hop, edges_per_hop;
 };
 
+// PYG_HIP_OP_TIMING=1: host time of the sampler operators' parts on stderr (arguments -> library call -> results adopted ->
+// Dict results built), microseconds since the operator was entered
+struct OpTiming {
+  static bool on() {
+    static const bool v = [] { const char* e = getenv("PYG_HIP_OP_TIMING"); return e && atoi(e) != 0; }();
+    return v;
+  }
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::string line;
+  void mark(const char* what) {
+    if (!on()) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %s=%.1f", what, us);
+    line += buf;
+  }
+  ~OpTiming() {
+    if (on() && !line.empty()) fprintf(stderr, "[pyg op timing] us:%s\n", line.c_str());
+  }
+};
+static thread_local OpTiming* g_op_timing = nullptr;
+
 static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
                                 const std::vector<pyg_hip_seed_set>& seeds,
                                 const std::vector<const int64_t*>& node_time, bool temporal_last,
@@ -682,6 +705,7 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
                                                 node_time.empty() ? nullptr : node_time.data(),
                                                 temporal_last, L, csc, replace, disjoint, return_edge_id,
                                                 &cb, &res, host.stream);
+  if (g_op_timing) g_op_timing->mark("library_done");
   if (rc == PYG_HIP_OK) loan.commit();
   TORCH_CHECK(host.error.empty(), host.error);
   check_status(rc);
@@ -698,6 +722,7 @@ static SampleOutput run_sampler(const std::vector<pyg_hip_relation>& rels,
     if (return_edge_id) out.edge_id.push_back(adopt(eid[(size_t)e], {n}, opts));
     out.edges_per_hop.emplace_back(eph.begin() + (size_t)e * L, eph.begin() + (size_t)(e + 1) * L);
   }
+  if (g_op_timing) g_op_timing->mark("adopted");
   return out;
 }
 
@@ -1092,6 +1117,8 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
                                            directed, disjoint, temporal_strategy, return_edge_id);
   }
   PYG_TRACE("pyg::hetero_neighbor_sample");
+  OpTiming timing;
+  g_op_timing = OpTiming::on() ? &timing : nullptr;
   check_modes(node_time_dict.has_value(), edge_time_dict.has_value(), seed_time_dict.has_value(),
               edge_weight_dict.has_value(), directed, disjoint, temporal_strategy);
   std::unordered_map<std::string, int> nt_index;
@@ -1155,6 +1182,7 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     }
   }
   TORCH_CHECK(device.has_value(), "hetero_neighbor_sample: no tensors given");
+  timing.mark("args_ready");
   auto out = run_sampler(rels, seeds, ntime, temporal_strategy == "last", (int)node_types.size(), (int)L, csc,
                          replace, disjoint, return_edge_id, device.value());
   c10::Dict<rel_type, Tensor> out_row, out_col;
@@ -1174,6 +1202,8 @@ hetero_neighbor_sample_kernel(const std::vector<node_type>& node_types, const st
     out_eph.insert(rel, out.edges_per_hop[e]);
     if (return_edge_id) out_eid.value().insert(rel, ix.narrow(out.edge_id[e]));
   }
+  timing.mark("dicts_built");
+  g_op_timing = nullptr;
   return std::make_tuple(out_row, out_col, out_node, out_eid, out_nph, out_eph);
 }
 
