@@ -22,8 +22,11 @@
 //
 // `out` is written with non-temporal stores (it is not read again here, and 40 % of the kernel's traffic: 0.0666 -> 0.0589 ms
 // on the C5 batch; non-temporal LOADS of the feature rows cost 4 %: neighbouring groups share lines).
-// bf16 / f16 with K, M in {128, 256}, float32 with K = M = 128 (fp32 sums, fp32 FMAs instead of MFMAs).  HBM traffic by the
-// counters (profiles/r5_pmc_ops.json): 169 MB fetched + 106 MB written per C5 batch = 1.07 x the formula's 263 MB.
+// Shapes: bf16 / f16 with K, M any multiples of 8 up to 256 -- 128 x 128 is the pipeline described below, K, M in {128, 256} the
+// same pipeline over 128-feature sub-items, every other pair one instance with run-time row sizes (item at a time); float32
+// with K, M multiples of 4 up to 128 -- 128 x 128 with both slices of the rows and all of W per item and the product on fp32
+// MFMAs, the others item at a time with FMAs.  HBM traffic by the counters (profiles/r5_pmc_ops.json): 169 MB fetched + 106 MB
+// written per C5 batch = 1.07 x the formula's 263 MB.
 
 // lane I of every 16-lane DPP row to all lanes of the row (v_mov_b32_dpp row_newbcast:I)
 template <int I>
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void rgcn_rowstart_kernel(const GroupedDesc de
 // and only then does item i's arithmetic (A tile, barrier, 8 MFMAs per wave, barrier, W of item i + 1, the block's stores
 // when its last item is done).  (The first version walked one block at a time, its stages one after the other: 104 us on
 // the C5 batch where the atomic kernel + its zero fill take 66; this one 57.  An item-at-a-time walk with enough
-// workgroups per CU is only 2 % behind -- it serves rows of more than 16 edges and the other shapes / types.)
+// workgroups per CU is only 2 % behind at 128 x 128 -- it serves rows of more than 16 edges and the run-time-size instances.)
 template <bool BF16, bool CHECK, bool BIG, bool INL, int NW, int KC, int MC, bool F32 = false, bool SMALL = false>
 __device__ __forceinline__ void rgcn_grouped_body(const GroupedDesc& desc, int R, char* __restrict__ out, int64_t out_rows,
                                                   int* __restrict__ error) {
