@@ -744,13 +744,18 @@ static std::vector<hipStream_t> batch_lanes(int device, int want) {
   return std::vector<hipStream_t>(v.begin(), v.begin() + want);
 }
 
-static int batch_lane_count(size_t K) {
+// Lanes = batches in flight.  PYG_HIP_SAMPLER_LANES, default 8 -- 2 for heterogeneous graphs: a hetero batch's launches carry
+// several relations each and already fill most of the chip, more than two of them in flight only slow one another down
+// (C5 graph, K = 8: 2 lanes 1.13 x the single-batch loop, 8 lanes 0.86 x; the C3 graph gives 1.07 - 1.09 x from 2 lanes up:
+// profiles/NOTES_r6.md section 2g)
+static int batch_lane_count(size_t K, bool hetero) {
   static const int cap = [] {
     const char* e = getenv("PYG_HIP_SAMPLER_LANES");
-    const int v = e ? atoi(e) : 8;
-    return v < 1 ? 1 : (v > 16 ? 16 : v);
+    const int v = e ? atoi(e) : 0;
+    return v < 1 ? 0 : (v > 16 ? 16 : v);
   }();
-  return (int)std::min<size_t>(K, (size_t)cap);
+  const int c = cap ? cap : (hetero ? 2 : 8);
+  return (int)std::min<size_t>(K, (size_t)c);
 }
 
 // Batch b continues the mt19937 stream torch.manual_seed(generator_seeds[b]) would start (CPUGeneratorImpl::set_current_seed
@@ -767,7 +772,7 @@ static std::vector<SampleOutput> run_sampler_batched(const std::vector<pyg_hip_r
   DeviceGuard guard(device);
   const auto opts = at::TensorOptions().dtype(at::kLong).device(device);
   const int T = num_node_types, E = (int)rels.size();
-  const auto lanes = batch_lanes(device.index(), batch_lane_count(K));
+  const auto lanes = batch_lanes(device.index(), batch_lane_count(K, rels.size() > 1));
   struct PerBatch {
     SamplerHost host;
     pyg_hip_mt19937 mt;

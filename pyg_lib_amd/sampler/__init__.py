@@ -135,8 +135,8 @@ def neighbor_sample_batched(rowptr: Tensor, col: Tensor, seeds: List[Tensor], nu
     Batch ``b`` is exactly ``torch.manual_seed(generator_seeds[b]); neighbor_sample(rowptr, col, seeds[b], ...)`` -- every
     output bit for bit -- but the batches are driven by a pool of host threads on private streams, so their chains of small
     dependent launches overlap on the device (a single batch cannot fill 256 CUs).  The process's default generator is
-    not touched.  Returns the list of the ``K`` usual 6-tuples.  ``PYG_HIP_SAMPLER_LANES`` (default 8) caps the number of
-    batches in flight.
+    not touched.  Returns the list of the ``K`` usual 6-tuples.  ``PYG_HIP_SAMPLER_LANES`` (default 8; 2 for heterogeneous
+    graphs) caps the number of batches in flight.
 
     Stream contract: the outputs are allocated on the lanes' private streams and are complete when the call returns (the
     lanes are synchronised).  Consume them on the stream that was current when the call was made (or synchronise before
