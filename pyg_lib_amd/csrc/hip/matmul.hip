@@ -2754,7 +2754,13 @@ int run_planned(int dtype, const Workspace& w, int B, int64_t K, int64_t M, bool
                 int64_t tiles_upper, int64_t out_elems_upper, hipStream_t stream) {
   // schedules 4 / 5 (measurement only): every float shape through the general-shape kernel / the one-thread-per-output one
   if (g_schedule == 5) return dispatch_naive(dtype, w, B, out_elems_upper, stream);
-  if (uniform && mfma_shape_ok(dtype, K, M) && g_schedule != 4) {
+  // Wide contractions go to the general-shape kernel (128-row tiles, K in 64-value chunks through a double-buffered LDS image):
+  // the LDS-weight kernel keeps ALL of W's K rows in LDS -- at K = 512, and in fp32 from K = 256, that leaves one small
+  // column chunk per pass and every pass re-reads X.  Measured (tools/mm_shape_sweep2.py, long / short / few segments): bf16
+  // K = 512 4 - 6 x faster through the general kernel for every M, K = 256 with M not a multiple of 256 1.15 - 3 x, fp32 K >= 256
+  // 1.5 - 2.9 x.  (K = 256 with M % 256 == 0 keeps the register-W / 256-column kernels; explicit schedules keep their kernels.)
+  const bool wide_k = g_schedule == 0 && w.gen_ok && (K == 512 || (K == 256 && (dtype == PYG_F32 || M % 256 != 0)));
+  if (uniform && mfma_shape_ok(dtype, K, M) && g_schedule != 4 && !wide_k) {
     bool handled = false;
     int rc = PYG_HIP_OK;
     if (dtype == PYG_BF16)
