@@ -375,6 +375,49 @@ __global__ __launch_bounds__(256) void scatter_sum_vec_kernel(const T* __restric
   }
 }
 
+// Unsorted 16-bit rows of an EVEN number of elements that the 16-byte-slice kernel above does not take (K = 2, 4, 6, 10, ...,
+// and the narrow rows K <= 32): one (edge, pair) per thread, neighbouring lanes on neighbouring words, one packed atomic per
+// pair instead of two 16-bit CAS loops on the same word (bf16 K = 4, 20 M edges: 2.5 ms -> 1.0).
+template <typename T, bool CAS = false>
+__global__ __launch_bounds__(256) void scatter_sum_pair_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                                               T* out, Shape s) {
+  const int64_t kp = s.K / 2;
+  const int64_t total = s.B * s.E * kp;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = t % kp;
+    const int64_t e = (t / kp) % s.E;
+    const int64_t b = t / (kp * s.E);
+    const int64_t idx = index[b * s.isb + e * s.ise];
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(src + (b * s.E + e) * s.K + 2 * c);
+    T* dst = out + (b * s.N + idx) * s.K + 2 * c;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (CAS) {
+        const float p0 = __builtin_bit_cast(float, w << 16), p1 = __builtin_bit_cast(float, w & 0xffff0000u);
+        atomic_rmw(reinterpret_cast<uint32_t*>(dst), [p0, p1](uint32_t cur, uint32_t* nv) {
+          const uint16_t lo = __builtin_bit_cast(uint16_t, (__bf16)(__builtin_bit_cast(float, cur << 16) + p0));
+          const uint16_t hi = __builtin_bit_cast(uint16_t, (__bf16)(__builtin_bit_cast(float, cur & 0xffff0000u) + p1));
+          *nv = (uint32_t)lo | ((uint32_t)hi << 16);
+          return true;
+        });
+      } else {
+        (void)__builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2*)dst, __builtin_bit_cast(bf16x2, w));
+      }
+    } else {
+      if (CAS) {
+        const float p0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)), p1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+        atomic_rmw(reinterpret_cast<uint32_t*>(dst), [p0, p1](uint32_t cur, uint32_t* nv) {
+          const uint16_t lo = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, (uint16_t)(cur & 0xffffu)) + p0));
+          const uint16_t hi = __builtin_bit_cast(uint16_t, (_Float16)((float)__builtin_bit_cast(_Float16, (uint16_t)(cur >> 16)) + p1));
+          *nv = (uint32_t)lo | ((uint32_t)hi << 16);
+          return true;
+        });
+      } else {
+        (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) f16x2*)dst, __builtin_bit_cast(f16x2, w));
+      }
+    }
+  }
+}
+
 // ---- gather_coo -----------------------------------------------------------------------------------------
 template <typename T>
 __global__ void gather_elem_kernel(const T* __restrict__ src, const int64_t* __restrict__ index, T* out,
@@ -511,7 +554,13 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
   if (op == OP_SUM) {
     if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
                   std::is_same<T, f16_t>::value) {
-      if (s.isk == 0 && s.K % Vec<T>::N == 0 && aligned16(src) && aligned16(out)) {
+      // (unsorted NARROW rows -- up to four 16-byte slices -- do not come here: a thread of the kernel below owns 8 consecutive
+      // edges of one slice, so with few slices per row its lanes are 128+ bytes apart on every load, and every lane's four
+      // atomics hit a line of their own.  One element / one packed pair per thread -- the kernels further down -- puts
+      // neighbouring lanes on neighbouring words of the same row: K = 4 floats, 20 M edges: 3.9 ms here, 0.96 there (=
+      // torch.index_add_); bf16 K = 16: 3.9 -> 1.0.)
+      const bool narrow = !sorted && s.K / Vec<T>::N <= 4;
+      if (s.isk == 0 && s.K % Vec<T>::N == 0 && aligned16(src) && aligned16(out) && !narrow) {
         if (sorted) {
           const int64_t threads = s.B * ((s.E + 31) / 32) * (s.K / Vec<T>::N);
           if (cas)
@@ -530,6 +579,18 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
         else
           hipLaunchKernelGGL((scatter_sum_vec_kernel<T, false>), dim3(grid_for(threads)), dim3(256), 0, stream,
                              src, index, (const int64_t*)nullptr, out, s);
+        PYG_HIP_CHECK(hipGetLastError());
+        return PYG_HIP_OK;
+      }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value) {
+      // 16-bit rows of an even number of elements: packed pairs (4-byte aligned: K even, bases 4-byte aligned)
+      if (s.isk == 0 && s.K % 2 == 0 && !sorted && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        const int64_t threads = s.B * s.E * (s.K / 2);
+        if (cas)
+          hipLaunchKernelGGL((scatter_sum_pair_kernel<T, true>), dim3(grid_for(threads)), dim3(256), 0, stream, src, index, out, s);
+        else
+          hipLaunchKernelGGL((scatter_sum_pair_kernel<T, false>), dim3(grid_for(threads)), dim3(256), 0, stream, src, index, out, s);
         PYG_HIP_CHECK(hipGetLastError());
         return PYG_HIP_OK;
       }
