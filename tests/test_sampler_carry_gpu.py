@@ -114,6 +114,33 @@ def test_many_small_calls_of_varying_size(disjoint, replace):
     assert a1 - a0 >= 30 and k1 - k0 >= 1      # adopted but for the cold start (and wherever the buffer ended)
 
 
+def test_growing_batches_outgrow_the_kept_stream():
+    """Small batches, then much larger ones on the same generator: a call that adopted the kept words and needs more than
+    the kept buffer holds moves them to a larger one (the adopted mark has no event to wait for: that wait was issued on a
+    null handle -- `invalid resource handle` -- before tools/sampler_sweep.py found it).  Every call against the oracle on the
+    same generator, incl. the generator state at the end."""
+    import oracle
+    from pyg_lib_amd import sampler
+    rng = np.random.default_rng(9)
+    n = 200_000
+    rp, cl = random_csr(rng, n, 30)
+    rpd, cld = torch.from_numpy(rp).cuda(), torch.from_numpy(cl).cuda()
+    fan = [15, 10, 5]
+    sizes = [64, 64, 64, 64, 1024, 1024, 8192, 8192, 8192, 128, 8192, 20000, 20000]
+    calls = []
+    for b in sizes:
+        s = rng.permutation(n)[:b].astype(np.int64)
+        calls.append((lambda s=s: sampler.neighbor_sample(rpd, cld, torch.from_numpy(s).cuda(), fan),
+                      lambda s=s: oracle.neighbor_sample(rp, cl, s, fan, fill=torch_fill)))
+    a0, _ = sampler.rng_carry_stats()
+    got, ref = run_pair(calls, 777)
+    for g, r in zip(got, ref):
+        same(g, r)
+    a1, _ = sampler.rng_carry_stats()
+    assert a1 - a0 >= 4                       # the stream was adopted along the way (the largest batches run 'queued')
+    assert sampler.last_mode() in ('fused', 'queued')
+
+
 def test_hetero_and_homogeneous_calls_share_the_stream_and_release_drops_it():
     import oracle
     from pyg_lib_amd import sampler
