@@ -1,9 +1,9 @@
 #!/bin/bash
 # round-end evidence (tools/profile_round.sh) + one full GPU pass
-R=/root/repo/gpurun_out/r6_zz
+R=/root/repo/gpurun_out/r6_zy
 mkdir -p $R
 cd /root/repo
-bash tools/profile_round.sh r6_zz > $R/profile_round.log 2>&1
+bash tools/profile_round.sh r6_zy > $R/profile_round.log 2>&1
 cd /root/repo
 timeout 1500 python -m pytest tests -m gpu -x -q > $R/pytest_1.txt 2>&1
 echo "pytest rc=$?" >> $R/pytest_1.txt
