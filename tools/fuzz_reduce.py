@@ -1,0 +1,90 @@
+"""Differential fuzz of scatter_sum / scatter_mean / scatter_max / scatter_min / segment_sum_coo / gather_coo against torch in
+float64 on integer-valued data (sums exact in every dtype): random leading dims, row widths 1 ... 300 (the narrow-row, packed
+pair, 16-byte slice and sorted-CSR paths), index 1-D (broadcast) or full-shape, fresh or given `out`, hardware and CAS atomics,
+deterministic mode.   python tools/fuzz_reduce.py [cases] [seed]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyg_lib_amd import ops  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+g = torch.Generator().manual_seed(seed)
+dev = torch.device('cuda:0')
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi, (1,), generator=g))
+
+
+bad = 0
+for case in range(cases):
+    dtype = [torch.float32, torch.bfloat16, torch.float16, torch.float64][ri(0, 4)]
+    K = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 64, 100, 128, 300][ri(0, 15)]
+    E = [1, 7, 100, 5000, 40_000, 200_000][ri(0, 6)]
+    if E * K > 8_000_000:
+        E = 8_000_000 // K
+    N = max(1, [1, 3, 50, 1000, 30_000][ri(0, 5)])
+    lead = [(), (2,), (3,)][ri(0, 3)] if E * K < 500_000 else ()
+    full_index = ri(0, 4) == 0 and K <= 32
+    sorted_idx = ri(0, 3) == 0
+    det = ri(0, 6) == 0
+    given_out = ri(0, 4) == 0
+    # few contributions per bucket -> sums stay small integers (exact in bf16: |sum| <= 256)
+    vals = torch.randint(-2, 3, lead + (E, K), generator=g).double()
+    idx1 = torch.randint(0, N, (E,), generator=g)
+    if sorted_idx:
+        idx1 = torch.sort(idx1).values
+    if full_index:
+        idx = idx1.view((1,) * len(lead) + (E, 1)).expand(lead + (E, K)).contiguous()
+        idx = (idx + torch.randint(0, N, lead + (E, K), generator=g)) % N if not sorted_idx else idx
+    else:
+        idx = idx1
+    dim = len(lead)
+    src = vals.to(dtype).to(dev)
+    full = idx if idx.dim() > 1 else idx.view((1,) * len(lead) + (E, 1)).expand(lead + (E, K))
+    want = torch.zeros(lead + (N, K), dtype=torch.float64)
+    init = torch.randint(-3, 4, lead + (N, K), generator=g).double() if given_out else None
+    if given_out:
+        want = init.clone()
+    want.scatter_add_(dim, full, vals)
+    if want.abs().max() > 256:
+        continue
+    idx_d = idx.to(dev)
+    out_arg = init.to(dtype).to(dev) if given_out else None
+    if idx.dim() == 1 and len(lead) > 0:
+        idx_call = idx_d.view((1,) * len(lead) + (E,)).expand(lead + (E,))   # broadcast along the leading dims
+    else:
+        idx_call = idx_d
+    torch.use_deterministic_algorithms(det, warn_only=True)
+    try:
+        idx_k = idx_call if idx_call.dim() == src.dim() else idx_call.unsqueeze(-1).expand_as(src)
+        got = ops.scatter_sum(src, idx_k if full_index or len(lead) else idx_d, dim, out_arg, N)
+        if not torch.equal(got.double().cpu(), want):
+            bad += 1
+            print('MISMATCH scatter_sum', case, dtype, K, E, N, lead, full_index, sorted_idx, det, given_out, flush=True)
+        if sorted_idx and not full_index and not len(lead):
+            got2 = ops.segment_sum_coo(src, idx_d, None, N)
+            w2 = torch.zeros(N, K, dtype=torch.float64).index_add_(0, idx1, vals)
+            if not torch.equal(got2.double().cpu(), w2):
+                bad += 1
+                print('MISMATCH segment_sum_coo', case, dtype, K, E, N, flush=True)
+        if not full_index and not len(lead):
+            mx, arg = ops.scatter_max(src, idx_d, 0, None, N)
+            ref = torch.full((N, K), float('-inf'), dtype=torch.float64).scatter_reduce_(0, idx1[:, None].expand(E, K), vals, 'amax')
+            ref[ref == float('-inf')] = 0
+            if not torch.equal(mx.double().cpu(), ref):
+                bad += 1
+                print('MISMATCH scatter_max', case, dtype, K, E, N, flush=True)
+            gat = ops.gather_coo(got, idx_d) if sorted_idx else None
+            if gat is not None and not torch.equal(gat.double().cpu(), want[idx1]):
+                bad += 1
+                print('MISMATCH gather_coo', case, dtype, K, E, N, flush=True)
+    finally:
+        torch.use_deterministic_algorithms(False)
+torch.cuda.synchronize()
+print(f'fuzz_reduce: {cases} cases (seed {seed}), {bad} mismatches')
+sys.exit(1 if bad else 0)

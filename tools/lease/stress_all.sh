@@ -11,4 +11,5 @@ run stress_sampler python tools/stress_sampler.py 3000
 run stress_sampler_batched python tools/stress_sampler_batched.py 150
 run stress python tools/stress.py 300
 run stress_atomics python tools/stress_atomics.py
+run fuzz_reduce python tools/fuzz_reduce.py 500 1
 for s in 1 2 3; do run stress_sampler_state_$s python tools/stress_sampler_state.py 150 $s; done
