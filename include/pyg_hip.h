@@ -57,6 +57,8 @@ typedef enum {
 
 /* Version of THIS interface: bumped whenever a signature or the meaning of an argument changes, so that a caller built
  * against an older header can tell (pyg_hip_abi_version() != the PYG_HIP_ABI_VERSION it was compiled with).
+ *   8: round 6 -- pyg_hip_segment_csr_ws / pyg_hip_gather_csr_ws / pyg_hip_csr_hub_workspace_size (scratch for hub rows);
+ *      pyg_hip_scatter uses the dead parts of its workspace for the same purpose (no change for its callers).
  *   7: round 6 -- pyg_hip_rgcn_relation::scatter_rows (rows of the relation's destination segment).
  *   6: round 5 -- PYG_HIP_RGCN_GROUPED + pyg_hip_rgcn_grouped_workspace_size (atomic-free fused layer), PYG_HIP_SCATTER_DETERMINISTIC.
  *   5: round 5 -- pyg_hip_hetero_neighbor_sample_batched, PYG_HIP_SCATTER_CAS / PYG_HIP_RGCN_* flag bits (`checked` of
@@ -64,7 +66,7 @@ typedef enum {
  *      pyg_hip_sampler_table_cache_release; the weight-gradient workspace holds partial slabs instead of an fp32 image.
  *   4: round 4 -- `flags` in front of `stream` in pyg_hip_segment_matmul / pyg_hip_grouped_matmul, `index_sorted` of
  *      pyg_hip_scatter became a bit field, pyg_hip_matmul_set_schedule / _set_f32_split removed, fp32 default = IEEE MFMAs. */
-#define PYG_HIP_ABI_VERSION 7
+#define PYG_HIP_ABI_VERSION 8
 PYG_HIP_API int pyg_hip_abi_version(void);
 /* Replaces pyg::cuda_version (pyg_lib/csrc/library.cpp:19-29): returns the HIP runtime version
  * the library was built against (HIP_VERSION), never -1. */
@@ -687,6 +689,23 @@ PYG_HIP_API int pyg_hip_segment_csr(int op, int dtype, const void* src, const in
                                     int64_t leading, int64_t rows, int64_t E, int64_t K, void* stream);
 
 /*
+ * The same with scratch for HUB rows.  The row kernels give a row to 1 / 8 / 64 lanes; a row of more than 512 positions per
+ * lane (a power-law graph's popular destination) is skipped there.  Without scratch a second launch gives every such row to
+ * ONE workgroup (~9 GB/s per row: a row holding 2.5 % of 8 M positions of 256 bytes then takes 6 ms of a 0.5 ms call).
+ * With `workspace` (pyg_hip_csr_hub_workspace_size() bytes of device memory, contents irrelevant, not kept) the skipped rows
+ * are registered there in chunks of 2048 positions, a second launch deals the chunks to all workgroups, and the workgroup
+ * that finishes a row's last chunk combines the chunks' partial results in chunk order: no float atomics, the same bits on
+ * every run; sums of hub rows differ from the sequential order by rounding (like the lane-split rows), min / max / arg
+ * stay exact.  A smaller workspace is legal: the chunk length doubles until the partial results fit, too small means "without".
+ * pyg_hip_csr_hub_workspace_size: op 0 ... 3 as above, 4 = gather_csr; 0 when no row can be a hub (leading * E <= 512).
+ */
+PYG_HIP_API size_t pyg_hip_csr_hub_workspace_size(int op, int dtype, int64_t leading, int64_t E, int64_t K);
+PYG_HIP_API int pyg_hip_segment_csr_ws(int op, int dtype, const void* src, const int64_t* indptr,
+                                       int64_t indptr_slice_stride, void* out, int64_t* arg_out, int fresh,
+                                       int64_t leading, int64_t rows, int64_t E, int64_t K, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+
+/*
  * out[slice, e, :] = src[slice, r, :] for every position e of row r; positions covered by no row keep
  * their contents.  src [leading, rows, K], out [leading, E, K].  Replaces pyg::gather_csr (schema
  * ops/segment_csr.cpp:170-172; CPU ops/cpu/segment_csr_kernel.cpp:551-648).
@@ -694,6 +713,10 @@ PYG_HIP_API int pyg_hip_segment_csr(int op, int dtype, const void* src, const in
 PYG_HIP_API int pyg_hip_gather_csr(int dtype, const void* src, const int64_t* indptr,
                                    int64_t indptr_slice_stride, void* out, int64_t leading, int64_t rows,
                                    int64_t E, int64_t K, void* stream);
+/* ... with scratch for hub rows (pyg_hip_csr_hub_workspace_size(4, ...)): their positions are written by all workgroups. */
+PYG_HIP_API int pyg_hip_gather_csr_ws(int dtype, const void* src, const int64_t* indptr,
+                                      int64_t indptr_slice_stride, void* out, int64_t leading, int64_t rows,
+                                      int64_t E, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Softmax over the groups ptr[g] .. ptr[g+1] along the middle axis of src [outer, D, inner], per

@@ -12,7 +12,7 @@ _HERE = osp.dirname(osp.abspath(__file__))
 _LIB = None
 
 OK = 0
-ABI_VERSION = 7  # PYG_HIP_ABI_VERSION of the include/pyg_hip.h these bindings were written against
+ABI_VERSION = 8  # PYG_HIP_ABI_VERSION of the include/pyg_hip.h these bindings were written against
 DTYPES = {
     torch.float32: 0,
     torch.float64: 1,

@@ -109,9 +109,13 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
   if (fresh && (op == CSR_MIN || op == CSR_MAX))
     check_status(pyg_hip_fill_reduce_identity(op == CSR_MIN ? PYG_REDUCE_MIN : PYG_REDUCE_MAX, code, out.data_ptr(),
                                               out.numel(), stream));
-  check_status(pyg_hip_segment_csr(op, code, src_c.data_ptr(), v.indptr.data_ptr<int64_t>(), v.stride, out.data_ptr(),
-                                   arg.defined() ? arg.data_ptr<int64_t>() : nullptr, fresh ? 1 : 0, v.leading,
-                                   out.size(dim), E, K, stream));
+  // scratch for hub rows (0 bytes when no row can be one): their chunks are dealt to all workgroups
+  const size_t hub_bytes = pyg_hip_csr_hub_workspace_size(op, code, v.leading, E, K);
+  Tensor hub_ws;
+  if (hub_bytes) hub_ws = at::empty({(int64_t)hub_bytes}, src_c.options().dtype(at::kByte));
+  check_status(pyg_hip_segment_csr_ws(op, code, src_c.data_ptr(), v.indptr.data_ptr<int64_t>(), v.stride, out.data_ptr(),
+                                      arg.defined() ? arg.data_ptr<int64_t>() : nullptr, fresh ? 1 : 0, v.leading,
+                                      out.size(dim), E, K, hub_bytes ? hub_ws.data_ptr() : nullptr, hub_bytes, stream));
   return std::make_tuple(out, arg);
 }
 
@@ -166,8 +170,13 @@ Tensor gather_csr_kernel(const Tensor& src, const Tensor& indptr, const std::opt
     cpu::gather_csr(src_c, v.indptr.data_ptr<int64_t>(), v.stride, out, v.leading, v.rows, out.size(dim), K);
     return out;
   }
-  check_status(pyg_hip_gather_csr(dtype_code(src_c.scalar_type()), src_c.data_ptr(), v.indptr.data_ptr<int64_t>(),
-                                  v.stride, out.data_ptr(), v.leading, v.rows, out.size(dim), K, current_stream(src_c)));
+  const int code = dtype_code(src_c.scalar_type());
+  const size_t hub_bytes = pyg_hip_csr_hub_workspace_size(4, code, v.leading, out.size(dim), K);   // the chunk list of hub rows
+  Tensor hub_ws;
+  if (hub_bytes) hub_ws = at::empty({(int64_t)hub_bytes}, src_c.options().dtype(at::kByte));
+  check_status(pyg_hip_gather_csr_ws(code, src_c.data_ptr(), v.indptr.data_ptr<int64_t>(), v.stride, out.data_ptr(), v.leading,
+                                     v.rows, out.size(dim), K, hub_bytes ? hub_ws.data_ptr() : nullptr, hub_bytes,
+                                     current_stream(src_c)));
   return out;
 }
 

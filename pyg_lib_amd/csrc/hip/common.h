@@ -114,11 +114,14 @@ int mt_jump_list(int k, int parts, const uint16_t** idx_dev, int* count, int* ma
 // optional: row r sums the source rows perm[indptr[r]] ... perm[indptr[r + 1] - 1] -- a scatter through its stable index sort,
 // i.e. in source order: deterministic, the order of the reference's sequential CPU loop)
 int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, const int64_t* perm, void* out,
-                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream);
+                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream, void* hub_ws = nullptr,
+                    size_t hub_ws_bytes = 0);
+// (`hub_ws`: scratch for rows of more than 512 positions -- with it their chunks are dealt to workgroups, without it each such
+// row is one workgroup's; any size: the chunk length adapts, too little of it means "without")
 // csr.hip: min / max (+ first-match arg) over CSR rows, optionally reading source position perm[e]
 // instead of e -- the atomic-free back end of sorted and sort-based scatter_min/max (reduce.hip).
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,
                        const int64_t* perm, void* out, int64_t* arg, int fresh, int64_t leading, int64_t rows,
-                       int64_t E, int64_t K, hipStream_t stream);
+                       int64_t E, int64_t K, hipStream_t stream, void* hub_ws = nullptr, size_t hub_ws_bytes = 0);
 
 }  // namespace pyg_hip

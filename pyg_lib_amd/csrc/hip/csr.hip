@@ -17,6 +17,8 @@
 #include "common.h"
 #include "elem.h"
 
+#include <algorithm>
+#include <cstdint>
 #include <type_traits>
 
 namespace pyg_hip {
@@ -49,7 +51,38 @@ __device__ __forceinline__ A shfl_xor_any(A v, int mask) {
 struct CsrShape {
   int64_t leading, rows, E, K;
   int64_t indptr_stride;  // elements between the indptr of consecutive slices (0 = broadcast)
+  int64_t long_cut = INT64_MAX;  // segment_csr_kernel: rows of more positions are left to the hub kernels below
+  void* hub_ws = nullptr;        // (host side) the caller's scratch for them: pyg_hip_csr_hub_workspace_size()
+  size_t hub_ws_bytes = 0;
 };
+
+// HUB rows (more than `long_cut` positions: a destination that collects 0.25 % of 8 M positions costs 8 ms in the row
+// kernels where the whole call takes 0.5 without it; power-law graphs have such nodes).  The row kernels skip them.  With
+// the caller's scratch the thread that skips one REGISTERS it here, cut into chunks of `CH` positions, and a second launch
+// deals the chunks to workgroups (hub_chunk kernels); without scratch a second launch finds the hubs again and gives each
+// to one workgroup (the *_long kernels: ~9 GB/s per hub row).
+struct HubRec {
+  int64_t n;            // flat row
+  int chunk_base, nch;  // its chunks: chunks[chunk_base ... chunk_base + nch)
+  int slot_base, done;  // nch > 1: its partial results' slots, and how many of them are written
+};
+struct HubWs {
+  int* counters = nullptr;  // [0] hubs, [1] chunks, [2] partial slots -- zeroed in front of the row kernel
+  HubRec* hubs = nullptr;
+  int2* chunks = nullptr;   // (hub, chunk of the hub)
+  char* partial = nullptr;  // slots of K accumulators ...
+  int64_t* partial_best = nullptr;  // ... and, for min / max, of K positions
+  int64_t CH = 0;
+};
+
+__device__ __forceinline__ void hub_register(const HubWs& hw, int64_t n, int64_t len) {
+  const int nch = (int)((len + hw.CH - 1) / hw.CH);
+  const int h = atomicAdd(&hw.counters[0], 1);
+  const int cb = atomicAdd(&hw.counters[1], nch);
+  const int sb = nch > 1 ? atomicAdd(&hw.counters[2], nch) : 0;
+  hw.hubs[h] = HubRec{n, cb, nch, sb, 0};
+  for (int j = 0; j < nch; ++j) hw.chunks[cb + j] = make_int2(h, j);
+}
 
 // OP: CSR_SUM / CSR_MEAN / CSR_MIN / CSR_MAX.  V elements (16 bytes, or 1) per thread, L lanes per item.
 // PERM: row positions are read through perm[e] (scatter_min/max after an index sort; perm is ascending
@@ -57,7 +90,7 @@ struct CsrShape {
 template <typename T, int OP, int V, int L, bool PERM>
 __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
                                                           const int64_t* __restrict__ perm, T* __restrict__ out,
-                                                          int64_t* __restrict__ arg, int fresh, CsrShape s) {
+                                                          int64_t* __restrict__ arg, int fresh, CsrShape s, HubWs hw) {
   using acc_t = typename Math<T>::acc_t;
   using P = Pack<T, V>;
   const int64_t kv = s.K / V;
@@ -72,6 +105,10 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   const int64_t row = n % s.rows;
   const int64_t a = indptr[slice * s.indptr_stride + row];
   const int64_t b = indptr[slice * s.indptr_stride + row + 1];
+  if (b - a > s.long_cut) {   // (all L lanes of the item alike) a hub row
+    if (hw.counters && live && lane == 0 && c == 0) hub_register(hw, n, b - a);
+    return;
+  }
   const T* sp = src + slice * s.E * s.K + c;
   T* op = out + n * s.K + c;
 
@@ -173,12 +210,259 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
   *reinterpret_cast<P*>(op) = res;
 }
 
+// The hub kernels.  256 threads take positions [pa, pb) of one row as S 16-byte slices x 256 / S position lanes (lane j
+// takes pa + j, pa + j + 256 / S, ..., eight loads in flight); the lanes' partial results are combined through LDS in lane
+// order: the same bits on every run; floating sums differ from the sequential order by rounding like the L > 1 variants
+// above; min / max and their first-match arg stay exact.
+template <typename T, int V>
+struct HubGeom {
+  int S, logS, EL, sl, lane;
+  __device__ explicit HubGeom(int64_t kv) {
+    S = 1, logS = 0;
+    while (S < kv && S < 256) S <<= 1, ++logS;
+    EL = 256 >> logS;                       // position lanes per slice
+    sl = (int)threadIdx.x & (S - 1), lane = (int)threadIdx.x >> logS;
+  }
+};
+
+// tot / tb of the threads with g.lane == 0 (and `on`): start (+) the span's positions; every thread of the workgroup calls it
+template <typename T, int OP, int V, bool PERM>
+__device__ __forceinline__ void hub_span(const T* __restrict__ sp, const int64_t* __restrict__ perm, int64_t pa, int64_t pb,
+                                         int64_t rowK, bool on, const HubGeom<T, V>& g,
+                                         const typename Math<T>::acc_t (&start)[V], typename Math<T>::acc_t* part,
+                                         int64_t* part_best, typename Math<T>::acc_t (&tot)[V], int64_t (&tb)[V], int64_t E) {
+  using acc_t = typename Math<T>::acc_t;
+  using P = Pack<T, V>;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  acc_t acc[V];
+  int64_t best[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = MINMAX ? start[i] : acc_t(0), best[i] = E;
+  if (on) {
+    constexpr int U = 8;
+    for (int64_t e0 = pa + g.lane; e0 < pb; e0 += (int64_t)U * g.EL) {
+      int64_t pp[U];
+      P xx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + (int64_t)u * g.EL;
+        const int64_t ec = e < pb ? e : e0;
+        pp[u] = PERM ? perm[ec] : ec;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) xx[u] = *reinterpret_cast<const P*>(sp + pp[u] * rowK);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e0 + (int64_t)u * g.EL >= pb) break;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const acc_t v = Math<T>::up(xx[u].v[i]);
+          if constexpr (!MINMAX) {
+            acc[i] += v;
+          } else if constexpr (OP == CSR_MIN) {
+            if (v < acc[i]) { acc[i] = v; best[i] = pp[u]; }
+          } else {
+            if (v > acc[i]) { acc[i] = v; best[i] = pp[u]; }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    part[threadIdx.x * V + i] = acc[i];
+    if constexpr (MINMAX) part_best[threadIdx.x * V + i] = best[i];
+  }
+  __syncthreads();
+  if (on && g.lane == 0) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      tot[i] = MINMAX ? acc[i] : start[i];
+      tb[i] = best[i];
+      for (int l = MINMAX ? 1 : 0; l < g.EL; ++l) {   // lane order
+        const acc_t ov = part[((l << g.logS) + g.sl) * V + i];
+        if constexpr (!MINMAX) {
+          tot[i] += ov;
+        } else {
+          const int64_t ob = part_best[((l << g.logS) + g.sl) * V + i];
+          const bool better = OP == CSR_MIN ? ov < tot[i] : ov > tot[i];
+          const bool worse = OP == CSR_MIN ? tot[i] < ov : tot[i] > ov;
+          if (better || (!worse && ob < tb[i])) tot[i] = ov, tb[i] = ob;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// the row's final value from (tot, tb) -> out / arg
+template <typename T, int OP, int V>
+__device__ __forceinline__ void hub_store(T* __restrict__ op, int64_t* __restrict__ ap, typename Math<T>::acc_t (&tot)[V],
+                                          int64_t (&tb)[V], int64_t len, int fresh, int64_t E) {
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  Pack<T, V> res;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    if constexpr (OP == CSR_MEAN) tot[i] = tot[i] / (acc_t)len;
+    res.v[i] = Math<T>::down(tot[i]);
+    if constexpr (MINMAX) {
+      if (fresh && tb[i] == E) res.v[i] = Math<T>::down(acc_t(0));
+      ap[i] = tb[i];
+    }
+  }
+  *reinterpret_cast<Pack<T, V>*>(op) = res;
+}
+
+// what a row's accumulation starts from: the caller's `out` slot (sum into an existing output; min / max always)
+template <typename T, int OP, int V>
+__device__ __forceinline__ void hub_seed(const T* __restrict__ op, bool on, int fresh, typename Math<T>::acc_t (&seed)[V]) {
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+#pragma unroll
+  for (int i = 0; i < V; ++i) seed[i] = acc_t(0);
+  if (on && (MINMAX || (OP == CSR_SUM && !fresh))) {
+    const Pack<T, V> cur = *reinterpret_cast<const Pack<T, V>*>(op);
+#pragma unroll
+    for (int i = 0; i < V; ++i) seed[i] = Math<T>::up(cur.v[i]);
+  }
+}
+
+// Without scratch: every workgroup looks at 256 rows at a time and takes the long ones among them, one after the other.
+template <typename T, int OP, int V, bool PERM>
+__global__ __launch_bounds__(256) void segment_csr_long_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                               const int64_t* __restrict__ perm, T* __restrict__ out,
+                                                               int64_t* __restrict__ arg, int fresh, CsrShape s) {
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  __shared__ int64_t long_rows[256];
+  __shared__ int n_long;
+  __shared__ acc_t part[256 * V];
+  __shared__ int64_t part_best[MINMAX ? 256 * V : 1];
+  const int64_t kv = s.K / V;
+  const int64_t nrows = s.leading * s.rows;
+  const HubGeom<T, V> g(kv);
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < nrows; base += (int64_t)gridDim.x * 256) {
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    {
+      const int64_t n = base + threadIdx.x;
+      if (n < nrows) {
+        const int64_t slice = n / s.rows, row = n % s.rows;
+        const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+        if (b - a > s.long_cut) long_rows[atomicAdd(&n_long, 1)] = n;   // (their order does not matter: rows are independent)
+      }
+    }
+    __syncthreads();
+    const int cnt = n_long;
+    for (int j = 0; j < cnt; ++j) {
+      const int64_t n = long_rows[j];
+      const int64_t slice = n / s.rows, row = n % s.rows;
+      const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+      for (int64_t c0 = 0; c0 < kv; c0 += g.S) {
+        const int64_t ci = c0 + g.sl;
+        const bool on = ci < kv;
+        const int64_t c = (on ? ci : 0) * V;
+        T* op = out + n * s.K + c;
+        acc_t seed[V], tot[V];
+        int64_t tb[V];
+        hub_seed<T, OP, V>(op, on, fresh, seed);
+        hub_span<T, OP, V, PERM>(src + slice * s.E * s.K + c, perm, a, b, s.K, on, g, seed, part, part_best, tot, tb, s.E);
+        if (on && g.lane == 0) hub_store<T, OP, V>(op, MINMAX ? arg + n * s.K + c : nullptr, tot, tb, b - a, fresh, s.E);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// With scratch: one registered chunk per workgroup and trip.  A hub of one chunk is finished on the spot; the chunks of a
+// longer one leave their results in the hub's slots, and the workgroup that writes the hub's last slot adds them up in
+// chunk order (the slots travel through the device-scope fences around the `done` count).
+template <typename T, int OP, int V, bool PERM>
+__global__ __launch_bounds__(256) void segment_csr_hub_chunk_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                                    const int64_t* __restrict__ perm, T* __restrict__ out,
+                                                                    int64_t* __restrict__ arg, int fresh, CsrShape s, HubWs hw) {
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  __shared__ acc_t part[256 * V];
+  __shared__ int64_t part_best[MINMAX ? 256 * V : 1];
+  __shared__ int last;
+  const int64_t kv = s.K / V;
+  const HubGeom<T, V> g(kv);
+  const int nchunks = hw.counters[1];
+  for (int q = blockIdx.x; q < nchunks; q += gridDim.x) {
+    const int2 cr = hw.chunks[q];
+    const HubRec hub = hw.hubs[cr.x];
+    const int64_t n = hub.n;
+    const int64_t slice = n / s.rows, row = n % s.rows;
+    const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+    const int64_t pa = a + (int64_t)cr.y * hw.CH, pb = pa + hw.CH < b ? pa + hw.CH : b;
+    const bool whole = hub.nch == 1;
+    const int64_t slot = (int64_t)(hub.slot_base + cr.y) * s.K;
+    for (int64_t c0 = 0; c0 < kv; c0 += g.S) {
+      const int64_t ci = c0 + g.sl;
+      const bool on = ci < kv;
+      const int64_t c = (on ? ci : 0) * V;
+      T* op = out + n * s.K + c;
+      acc_t seed[V], tot[V];
+      int64_t tb[V];
+      hub_seed<T, OP, V>(op, on && (whole || MINMAX), fresh, seed);   // (the sum of a chunk starts from 0)
+      hub_span<T, OP, V, PERM>(src + slice * s.E * s.K + c, perm, pa, pb, s.K, on, g, seed, part, part_best, tot, tb, s.E);
+      if (on && g.lane == 0) {
+        if (whole) {
+          hub_store<T, OP, V>(op, MINMAX ? arg + n * s.K + c : nullptr, tot, tb, b - a, fresh, s.E);
+        } else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            reinterpret_cast<acc_t*>(hw.partial)[slot + c + i] = tot[i];
+            if constexpr (MINMAX) hw.partial_best[slot + c + i] = tb[i];
+          }
+        }
+      }
+    }
+    if (whole) continue;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&hw.hubs[cr.x].done, 1) == hub.nch - 1;
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      for (int64_t ci = threadIdx.x; ci < kv; ci += 256) {
+        const int64_t c = ci * V;
+        T* op = out + n * s.K + c;
+        acc_t tot[V];
+        int64_t tb[V];
+        hub_seed<T, OP, V>(op, true, fresh, tot);
+#pragma unroll
+        for (int i = 0; i < V; ++i) tb[i] = s.E;
+        for (int j = 0; j < hub.nch; ++j) {   // chunk order
+          const int64_t sj = (int64_t)(hub.slot_base + j) * s.K + c;
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const acc_t ov = __builtin_nontemporal_load(reinterpret_cast<const acc_t*>(hw.partial) + sj + i);
+            if constexpr (!MINMAX) {
+              tot[i] += ov;
+            } else {
+              const int64_t ob = __builtin_nontemporal_load(hw.partial_best + sj + i);
+              const bool better = OP == CSR_MIN ? ov < tot[i] : ov > tot[i];
+              const bool worse = OP == CSR_MIN ? tot[i] < ov : tot[i] > ov;
+              if (better || (!worse && ob < tb[i])) tot[i] = ov, tb[i] = ob;
+            }
+          }
+        }
+        hub_store<T, OP, V>(op, MINMAX ? arg + n * s.K + c : nullptr, tot, tb, b - a, fresh, s.E);
+      }
+    }
+    __syncthreads();   // `last` is rewritten on the next trip
+  }
+}
+
 // out[slice, e, :] = src[slice, r, :] for every position e of row r: the mirror image of the sum kernel
 // (one thread per (row, 16-byte slice), L lanes per item for long rows).  Positions covered by no row
 // are never written.
 template <typename T, int V, int L>
 __global__ __launch_bounds__(256) void gather_csr_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
-                                                         T* __restrict__ out, CsrShape s) {
+                                                         T* __restrict__ out, CsrShape s, HubWs hw) {
   using P = Pack<T, V>;
   const int64_t kv = s.K / V;
   const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / L;
@@ -189,9 +473,77 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(const T* __restrict__ s
   const int64_t slice = n / s.rows, row = n % s.rows;
   const int64_t a = indptr[slice * s.indptr_stride + row];
   const int64_t b = indptr[slice * s.indptr_stride + row + 1];
+  if (b - a > s.long_cut) {   // a hub row: gather_csr_hub_chunk_kernel / gather_csr_long_kernel
+    if (hw.counters && lane == 0 && c == 0) hub_register(hw, n, b - a);
+    return;
+  }
   const P v = *reinterpret_cast<const P*>(src + n * s.K + c);
   T* op = out + slice * s.E * s.K + c;
   for (int64_t e = a + lane; e < b; e += L) *reinterpret_cast<P*>(op + e * s.K) = v;
+}
+
+// `len` positions of one row written by 256 threads: 16-byte (or one-element) pieces in memory order
+template <typename T, int V>
+__device__ __forceinline__ void gather_span(const T* __restrict__ sp, T* __restrict__ op, int64_t len, int64_t kv) {
+  using P = Pack<T, V>;
+  const int64_t total = len * kv;
+  if (kv <= 256 && 256 % kv == 0) {   // a thread's piece column never changes
+    const P v = *reinterpret_cast<const P*>(sp + ((int64_t)threadIdx.x % kv) * V);
+    for (int64_t i = threadIdx.x; i < total; i += 256) *reinterpret_cast<P*>(op + i * V) = v;
+  } else {
+    for (int64_t i = threadIdx.x; i < total; i += 256)
+      *reinterpret_cast<P*>(op + i * V) = *reinterpret_cast<const P*>(sp + (i % kv) * V);
+  }
+}
+
+// The hub rows of the kernel above (more than `long_cut` positions), a whole workgroup per row: the row's K values are
+// written to consecutive positions by consecutive threads (full lines), the workgroups scan the row lengths 256 at a time
+// like segment_csr_long_kernel.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gather_csr_long_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                              T* __restrict__ out, CsrShape s) {
+  using P = Pack<T, V>;
+  __shared__ int64_t long_rows[256];
+  __shared__ int n_long;
+  const int64_t kv = s.K / V;
+  const int64_t nrows = s.leading * s.rows;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < nrows; base += (int64_t)gridDim.x * 256) {
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    {
+      const int64_t n = base + threadIdx.x;
+      if (n < nrows) {
+        const int64_t slice = n / s.rows, row = n % s.rows;
+        const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+        if (b - a > s.long_cut) long_rows[atomicAdd(&n_long, 1)] = n;
+      }
+    }
+    __syncthreads();
+    const int cnt = n_long;
+    for (int j = 0; j < cnt; ++j) {
+      const int64_t n = long_rows[j];
+      const int64_t slice = n / s.rows, row = n % s.rows;
+      const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+      gather_span<T, V>(src + n * s.K, out + (slice * s.E + a) * s.K, b - a, kv);
+    }
+    __syncthreads();
+  }
+}
+
+// with scratch: one registered chunk of a hub row per workgroup and trip
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gather_csr_hub_chunk_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
+                                                                   T* __restrict__ out, CsrShape s, HubWs hw) {
+  const int64_t kv = s.K / V;
+  const int nchunks = hw.counters[1];
+  for (int q = blockIdx.x; q < nchunks; q += gridDim.x) {
+    const int2 cr = hw.chunks[q];
+    const int64_t n = hw.hubs[cr.x].n;
+    const int64_t slice = n / s.rows, row = n % s.rows;
+    const int64_t a = indptr[slice * s.indptr_stride + row], b = indptr[slice * s.indptr_stride + row + 1];
+    const int64_t pa = a + (int64_t)cr.y * hw.CH, pb = pa + hw.CH < b ? pa + hw.CH : b;
+    gather_span<T, V>(src + n * s.K, out + (slice * s.E + pa) * s.K, pb - pa, kv);
+  }
 }
 
 // ---- softmax over CSR groups (float / double) ------------------------------------------------------
@@ -367,6 +719,44 @@ __global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __rest
   }
 }
 
+// ---- hub scratch ------------------------------------------------------------------------------------
+constexpr int64_t kHubCut = 512;      // positions per lane of the row kernels above which a row is a hub
+constexpr int64_t kHubChunk = 2048;   // positions per chunk (doubled until the scratch holds the partial results)
+
+inline size_t hub_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Lays the hub scratch out for `total` positions in rows of K values.  More than total / kHubCut hubs cannot exist; a hub
+// of one chunk needs no slot, a longer one at most 2 * len / CH of them.  Returns the bytes used (0: disabled).
+inline size_t hub_plan(void* ws, size_t ws_bytes, int64_t total, int64_t K, size_t acc_bytes, bool minmax, HubWs* hw,
+                       int64_t* max_chunks_out) {
+  if (total <= kHubCut) return 0;
+  const int64_t max_hubs = total / kHubCut + 1;
+  for (int64_t CH = kHubChunk; CH <= (1ll << 22); CH <<= 1) {
+    const int64_t max_chunks = total / CH + max_hubs + 1;
+    const int64_t max_slots = acc_bytes ? 2 * (total / CH) + 2 : 0;
+    const size_t o_hubs = 256;
+    const size_t o_chunks = o_hubs + hub_align(sizeof(HubRec) * (size_t)max_hubs);
+    const size_t o_part = o_chunks + hub_align(sizeof(int2) * (size_t)max_chunks);
+    const size_t o_best = o_part + hub_align(acc_bytes * (size_t)max_slots * (size_t)K);
+    const size_t end = o_best + (minmax ? hub_align(sizeof(int64_t) * (size_t)max_slots * (size_t)K) : 0);
+    if (!hw) return end;   // sizing: the smallest chunk
+    const size_t skew = (256 - (reinterpret_cast<uintptr_t>(ws) & 255)) & 255;
+    if (ws && ws_bytes >= end + skew) {
+      char* w = static_cast<char*>(ws) + skew;
+      hw->counters = reinterpret_cast<int*>(w);
+      hw->hubs = reinterpret_cast<HubRec*>(w + o_hubs);
+      hw->chunks = reinterpret_cast<int2*>(w + o_chunks);
+      hw->partial = w + o_part;
+      hw->partial_best = reinterpret_cast<int64_t*>(w + o_best);
+      hw->CH = CH;
+      *max_chunks_out = max_chunks;
+      return end + skew;
+    }
+    if (!acc_bytes) break;   // (gather: nothing shrinks with longer chunks but the chunk list)
+  }
+  return 0;
+}
+
 // lanes per item: long rows + too few items to fill the chip
 int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
   if (units <= 0 || items <= 0) return 1;
@@ -384,14 +774,38 @@ int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, 
   const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
   const T* sp = static_cast<const T*>(src);
   T* op = static_cast<T*>(out);
+  // rows of more than 512 positions per lane are hubs, left to a second launch (skipped when no row can be that long)
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  CsrShape sc = s;
+  sc.hub_ws = nullptr, sc.hub_ws_bytes = 0;
+  const int64_t cut = kHubCut * (int64_t)L;
+  const bool hubs = s.E > cut && s.leading * s.rows > 1;
+  if (hubs) sc.long_cut = cut;
+  HubWs hw;
+  int64_t max_chunks = 0;
+  if (hubs && hub_plan(s.hub_ws, s.hub_ws_bytes, s.leading * s.E, s.K, sizeof(acc_t), MINMAX, &hw, &max_chunks))
+    PYG_HIP_CHECK(hipMemsetAsync(hw.counters, 0, 16, stream));
 #define PYG_CSR_LAUNCH(LL)                                                                                   \
   hipLaunchKernelGGL((segment_csr_kernel<T, OP, V, LL, PERM>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), \
-                     0, stream, sp, indptr, perm, op, arg, fresh, s)
+                     0, stream, sp, indptr, perm, op, arg, fresh, sc, hw)
   if (L == 64) PYG_CSR_LAUNCH(64);
   else if (L == 8) PYG_CSR_LAUNCH(8);
   else PYG_CSR_LAUNCH(1);
 #undef PYG_CSR_LAUNCH
   PYG_HIP_CHECK(hipGetLastError());
+  if (hubs && hw.counters) {
+    const int64_t grid = std::min<int64_t>(max_chunks, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((segment_csr_hub_chunk_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm,
+                       op, arg, fresh, sc, hw);
+    PYG_HIP_CHECK(hipGetLastError());
+  } else if (hubs) {
+    const int64_t batches = (s.leading * s.rows + 255) / 256;
+    const int64_t grid = std::min<int64_t>(batches, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((segment_csr_long_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm, op,
+                       arg, fresh, sc);
+    PYG_HIP_CHECK(hipGetLastError());
+  }
   return PYG_HIP_OK;
 }
 
@@ -449,14 +863,35 @@ template <typename T, int V>
 int launch_gather(const void* src, const int64_t* indptr, void* out, const CsrShape& s, hipStream_t stream) {
   const int64_t items = s.leading * s.rows * (s.K / V);
   const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
+  CsrShape sc = s;
+  sc.hub_ws = nullptr, sc.hub_ws_bytes = 0;
+  const int64_t cut = kHubCut * (int64_t)L;
+  const bool hubs = s.E > cut && s.leading * s.rows > 1;
+  if (hubs) sc.long_cut = cut;
+  HubWs hw;
+  int64_t max_chunks = 0;
+  if (hubs && hub_plan(s.hub_ws, s.hub_ws_bytes, s.leading * s.E, s.K, 0, false, &hw, &max_chunks))
+    PYG_HIP_CHECK(hipMemsetAsync(hw.counters, 0, 16, stream));
 #define PYG_CSR_LAUNCH(LL)                                                                                  \
   hipLaunchKernelGGL((gather_csr_kernel<T, V, LL>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), 0, \
-                     stream, static_cast<const T*>(src), indptr, static_cast<T*>(out), s)
+                     stream, static_cast<const T*>(src), indptr, static_cast<T*>(out), sc, hw)
   if (L == 64) PYG_CSR_LAUNCH(64);
   else if (L == 8) PYG_CSR_LAUNCH(8);
   else PYG_CSR_LAUNCH(1);
 #undef PYG_CSR_LAUNCH
   PYG_HIP_CHECK(hipGetLastError());
+  if (hubs && hw.counters) {
+    const int64_t grid = std::min<int64_t>(max_chunks, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((gather_csr_hub_chunk_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const T*>(src),
+                       indptr, static_cast<T*>(out), sc, hw);
+    PYG_HIP_CHECK(hipGetLastError());
+  } else if (hubs) {
+    const int64_t batches = (s.leading * s.rows + 255) / 256;
+    const int64_t grid = std::min<int64_t>(batches, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((gather_csr_long_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const T*>(src),
+                       indptr, static_cast<T*>(out), sc);
+    PYG_HIP_CHECK(hipGetLastError());
+  }
   return PYG_HIP_OK;
 }
 
@@ -522,18 +957,21 @@ int run_sum_perm(const void* src, const int64_t* indptr, const int64_t* perm, vo
 }
 
 int segment_csr_sum(int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride, const int64_t* perm, void* out,
-                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream) {
+                    int64_t leading, int64_t rows, int64_t E, int64_t K, int fresh, hipStream_t stream, void* hub_ws,
+                    size_t hub_ws_bytes) {
   if (leading * rows * K == 0) return PYG_HIP_OK;
-  const CsrShape s{leading, rows, E, K, indptr_stride};
+  CsrShape s{leading, rows, E, K, indptr_stride};
+  s.hub_ws = hub_ws, s.hub_ws_bytes = hub_ws_bytes;
   if (perm) PYG_DISPATCH_ALL(dtype, (run_sum_perm<scalar_t>(src, indptr, perm, out, fresh, s, stream)));
   PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(CSR_SUM, src, indptr, out, nullptr, fresh, s, stream)));
 }
 
 int segment_csr_minmax(int is_min, int dtype, const void* src, const int64_t* indptr, int64_t indptr_stride,
                        const int64_t* perm, void* out, int64_t* arg, int fresh, int64_t leading, int64_t rows,
-                       int64_t E, int64_t K, hipStream_t stream) {
+                       int64_t E, int64_t K, hipStream_t stream, void* hub_ws, size_t hub_ws_bytes) {
   if (leading * rows * K == 0) return PYG_HIP_OK;
-  const CsrShape s{leading, rows, E, K, indptr_stride};
+  CsrShape s{leading, rows, E, K, indptr_stride};
+  s.hub_ws = hub_ws, s.hub_ws_bytes = hub_ws_bytes;
   if (!perm) {  // plain rows: small K takes the LDS-streamed kernel
     PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(is_min ? CSR_MIN : CSR_MAX, src, indptr, out, arg, fresh, s, stream)));
   }
@@ -546,27 +984,56 @@ using namespace pyg_hip;
 
 extern "C" {
 
-int pyg_hip_segment_csr(int op, int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride,
-                        void* out, int64_t* arg_out, int fresh, int64_t leading, int64_t rows, int64_t E, int64_t K,
-                        void* stream_) {
+size_t pyg_hip_csr_hub_workspace_size(int op, int dtype, int64_t leading, int64_t E, int64_t K) {
+  if (leading < 0 || E < 0 || K <= 0 || op < 0 || op > 4) return 0;
+  size_t acc = 0;
+  switch (dtype) {
+    case PYG_F16: case PYG_BF16: case PYG_F32: case PYG_I32: acc = 4; break;
+    case PYG_F64: case PYG_I64: acc = 8; break;
+    case PYG_I16: acc = 2; break;
+    default: acc = 1; break;
+  }
+  const bool gather = op == 4;
+  return hub_plan(nullptr, 0, leading * E, K, gather ? 0 : acc, op == CSR_MIN || op == CSR_MAX, nullptr, nullptr) +
+         (leading * E > kHubCut ? 256 : 0);   // + alignment slack
+}
+
+int pyg_hip_segment_csr_ws(int op, int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride,
+                           void* out, int64_t* arg_out, int fresh, int64_t leading, int64_t rows, int64_t E, int64_t K,
+                           void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(leading >= 0 && rows >= 0 && E >= 0 && K >= 0, "segment_csr: negative size");
   if (leading * rows * K == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(indptr && out && (src || E == 0), "segment_csr: NULL tensor");
   PYG_HIP_REQUIRE((op != CSR_MIN && op != CSR_MAX) || arg_out, "segment_csr: min/max need arg_out");
   PYG_HIP_REQUIRE(indptr_slice_stride == 0 || indptr_slice_stride >= rows + 1, "segment_csr: bad indptr stride");
-  const CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  s.hub_ws = workspace, s.hub_ws_bytes = workspace ? workspace_bytes : 0;
   PYG_DISPATCH_ALL(dtype, (run_segment<scalar_t>(op, src, indptr, out, arg_out, fresh, s, stream)));
 }
 
-int pyg_hip_gather_csr(int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride, void* out,
-                       int64_t leading, int64_t rows, int64_t E, int64_t K, void* stream_) {
+int pyg_hip_segment_csr(int op, int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride,
+                        void* out, int64_t* arg_out, int fresh, int64_t leading, int64_t rows, int64_t E, int64_t K,
+                        void* stream_) {
+  return pyg_hip_segment_csr_ws(op, dtype, src, indptr, indptr_slice_stride, out, arg_out, fresh, leading, rows, E, K, nullptr, 0,
+                                stream_);
+}
+
+int pyg_hip_gather_csr_ws(int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride, void* out,
+                          int64_t leading, int64_t rows, int64_t E, int64_t K, void* workspace, size_t workspace_bytes,
+                          void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   PYG_HIP_REQUIRE(leading >= 0 && rows >= 0 && E >= 0 && K >= 0, "gather_csr: negative size");
   if (leading * E * K == 0 || rows == 0) return PYG_HIP_OK;
   PYG_HIP_REQUIRE(src && indptr && out, "gather_csr: NULL tensor");
-  const CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  CsrShape s{leading, rows, E, K, indptr_slice_stride};
+  s.hub_ws = workspace, s.hub_ws_bytes = workspace ? workspace_bytes : 0;
   PYG_DISPATCH_ALL(dtype, (run_gather_csr<scalar_t>(src, indptr, out, s, stream)));
+}
+
+int pyg_hip_gather_csr(int dtype, const void* src, const int64_t* indptr, int64_t indptr_slice_stride, void* out,
+                       int64_t leading, int64_t rows, int64_t E, int64_t K, void* stream_) {
+  return pyg_hip_gather_csr_ws(dtype, src, indptr, indptr_slice_stride, out, leading, rows, E, K, nullptr, 0, stream_);
 }
 
 int pyg_hip_softmax_csr(int dtype, const void* src, const int64_t* ptr, void* out, int64_t outer, int64_t D,

@@ -534,7 +534,10 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
     hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, index, s.isb, s.ise,
                        s.B, s.E, s.N, indptr);
     PYG_HIP_CHECK(hipGetLastError());
-    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, nullptr, out, s.B, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream);
+    // (what the workspace holds behind the offsets is scratch for hub rows)
+    const size_t ip_bytes = scatter_indptr_bytes(s.B, s.N);
+    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, nullptr, out, s.B, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream,
+                           static_cast<char*>(ws) + ip_bytes, ws_bytes - ip_bytes);
   }
   if (sort_rows) {
     char* w = static_cast<char*>(ws);
@@ -549,7 +552,9 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
     hipLaunchKernelGGL(coo_indptr_kernel, dim3((unsigned)((s.N + 1 + 255) / 256)), dim3(256), 0, stream,
                        (const int64_t*)keys, (int64_t)0, (int64_t)1, (int64_t)1, s.E, s.N, indptr);
     PYG_HIP_CHECK(hipGetLastError());
-    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, perm, out, 1, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream);
+    // (the sorted keys are dead once the offsets exist: scratch for hub rows)
+    return segment_csr_sum(dtype_of<T>(), src, indptr, s.N + 1, perm, out, 1, s.N, s.E, s.K, fresh_sum ? 1 : 0, stream, keys,
+                           align_up(sizeof(int64_t) * (size_t)s.E, 256));
   }
   if (op == OP_SUM) {
     if constexpr (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value ||
@@ -621,7 +626,7 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
                            s.ise, s.B, s.E, s.N, indptr);
         PYG_HIP_CHECK(hipGetLastError());
         return segment_csr_minmax(op == OP_MIN, dtype_of<T>(), src, indptr, s.N + 1, nullptr, out, arg, init ? 0 : 1,
-                                  s.B, s.N, s.E, s.K, stream);
+                                  s.B, s.N, s.E, s.K, stream, w + ip_bytes, ws_bytes - ip_bytes);
       }
       const size_t sort_bytes = scatter_sort_ws_bytes(s.E);
       if (!sorted && s.B == 1 && s.ise == 1 && s.E >= (1 << 15) && ws_bytes >= sort_bytes + scatter_indptr_bytes(1, s.N)) {
@@ -636,7 +641,7 @@ int run_scatter(int op, const void* src_, const int64_t* index, void* out_, int6
                            (const int64_t*)keys, (int64_t)0, (int64_t)1, (int64_t)1, s.E, s.N, indptr);
         PYG_HIP_CHECK(hipGetLastError());
         return segment_csr_minmax(op == OP_MIN, dtype_of<T>(), src, indptr, s.N + 1, perm, out, arg, init ? 0 : 1, 1,
-                                  s.N, s.E, s.K, stream);
+                                  s.N, s.E, s.K, stream, keys, align_up(sizeof(int64_t) * (size_t)s.E, 256));
       }
     }
     hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((outn + 255) / 256)), dim3(256), 0, stream, arg, outn,

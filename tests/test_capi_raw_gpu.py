@@ -94,3 +94,70 @@ def test_index_sort_raw_pointers(lib, n, max_value):
     torch.cuda.synchronize()
     ref_v, ref_i = oracle.index_sort(keys)
     assert np.array_equal(keys_out.cpu().numpy(), ref_v) and np.array_equal(idx_out.cpu().numpy(), ref_i)
+
+
+@pytest.mark.parametrize('dtype,K', [(torch.float32, 128), (torch.bfloat16, 64), (torch.int64, 3), (torch.float32, 1032)])
+def test_segment_and_gather_csr_hub_rows_with_and_without_scratch(lib, dtype, K):
+    """pyg_hip_segment_csr_ws / pyg_hip_gather_csr_ws: rows of more than 512 positions per lane are hubs.  No scratch: one
+    workgroup per hub row; the advertised scratch: chunks of 2048 positions dealt to all workgroups; a third of it: longer
+    chunks.  Integer-valued data: every variant must give the oracle's bits, arg included."""
+    c = ctypes
+    L = lib
+    L.pyg_hip_csr_hub_workspace_size.restype = c.c_size_t
+    L.pyg_hip_csr_hub_workspace_size.argtypes = [c.c_int, c.c_int, c.c_int64, c.c_int64, c.c_int64]
+    L.pyg_hip_segment_csr_ws.restype = c.c_int
+    L.pyg_hip_segment_csr_ws.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_int,
+                                         c.c_int64, c.c_int64, c.c_int64, c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p]
+    L.pyg_hip_gather_csr_ws.restype = c.c_int
+    L.pyg_hip_gather_csr_ws.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int64, c.c_int64,
+                                        c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p]
+    L.pyg_hip_fill_reduce_identity.restype = c.c_int
+    L.pyg_hip_fill_reduce_identity.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_void_p]
+    code = {torch.float32: PYG_F32, torch.bfloat16: PYG_BF16, torch.int64: PYG_I64}[dtype]
+    rng = np.random.default_rng(K)
+    lens = rng.integers(0, 10, 4000)
+    lens[[5, 1700, 3999]] = [30_000, 600, 9000] if K < 1000 else [5000, 600, 2100]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    E, N = int(indptr[-1]), len(lens)
+    src = torch.from_numpy(rng.integers(-6, 7, (E, K)).astype(np.float32)).to(dtype)
+    bf16 = dtype == torch.bfloat16
+    src_np = bits(src) if bf16 else src.numpy()
+    sd, ip = src.to(DEV), torch.from_numpy(indptr).to(DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.pyg_hip_csr_hub_workspace_size(0, code, 1, 512, K) == 0
+    for op in (0, 1, 2, 3):   # sum, mean, min, max
+        if op == 1 and not dtype.is_floating_point:
+            continue
+        want, warg = oracle.segment_csr(op, src_np, indptr, None, oracle.BF16 if bf16 else None)
+        full = L.pyg_hip_csr_hub_workspace_size(op, code, 1, E, K)
+        assert full > 0
+        for ws_bytes in (0, full, full // 3):
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+            out = torch.empty(N, K, dtype=dtype, device=DEV)
+            arg = torch.full((N, K), E, dtype=torch.int64, device=DEV)
+            if op >= 2:
+                assert L.pyg_hip_fill_reduce_identity(2 if op == 2 else 3, code, out.data_ptr(), out.numel(), stream) == 0
+            rc = L.pyg_hip_segment_csr_ws(op, code, sd.data_ptr(), ip.data_ptr(), 0, out.data_ptr(), arg.data_ptr() if op >= 2 else None,
+                                          1, 1, N, E, K, ws.data_ptr() if ws_bytes else None, ws_bytes, stream)
+            assert rc == 0, L.pyg_hip_last_error()
+            torch.cuda.synchronize()
+            got = bits(out) if bf16 else out.cpu().numpy()
+            if op == 1:
+                np.testing.assert_allclose(oracle.bf16_bits_to_f32(got) if bf16 else got,
+                                           oracle.bf16_bits_to_f32(want) if bf16 else want, rtol=2 ** -7 if bf16 else 1e-6)
+            else:
+                assert np.array_equal(got, want), (op, ws_bytes)
+            if op >= 2:
+                assert np.array_equal(arg.cpu().numpy(), warg), (op, ws_bytes)
+    rows = torch.from_numpy(rng.integers(-50, 50, (N, K)).astype(np.float32)).to(dtype)
+    want = torch.repeat_interleave(rows, torch.from_numpy(lens), dim=0)
+    full = L.pyg_hip_csr_hub_workspace_size(4, code, 1, E, K)
+    rd = rows.to(DEV)
+    for ws_bytes in (0, full):
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+        out = torch.zeros(E, K, dtype=dtype, device=DEV)
+        rc = L.pyg_hip_gather_csr_ws(code, rd.data_ptr(), ip.data_ptr(), 0, out.data_ptr(), 1, N, E, K,
+                                     ws.data_ptr() if ws_bytes else None, ws_bytes, stream)
+        assert rc == 0, L.pyg_hip_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), want), ws_bytes

@@ -136,6 +136,104 @@ def test_long_rows_use_lane_split_within_tolerance(K):
     assert torch.equal(arg.cpu()[:, 0], torch.tensor([0, int(indptr[-1]), 50_000, 170_000, 170_003]))
 
 
+def hub_csr(rng, n_short=6000, hubs=(700, 5000, 40_000)):
+    """Many short rows with a few hub rows between them (a power-law graph's destinations)."""
+    lens = rng.integers(0, 12, n_short)
+    at = np.sort(rng.choice(n_short, len(hubs), replace=False))
+    lens[at] = hubs
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), at
+
+
+@pytest.mark.parametrize('dtype,K', [(torch.float32, 1), (torch.float32, 5), (torch.float32, 128), (torch.float32, 1040),
+                                     (torch.bfloat16, 128), (torch.bfloat16, 24), (torch.float16, 3), (torch.int64, 3),
+                                     (torch.float64, 2)])
+def test_hub_rows_take_a_workgroup_each(dtype, K):
+    # rows of more than 512 positions are left to segment_csr_long_kernel / gather_csr_long_kernel (csr.hip): integer-valued
+    # data, so every order of the additions gives the oracle's bits; many ties, so the arg of min / max must be the FIRST match
+    rng = np.random.default_rng(31 + K)
+    indptr, at = hub_csr(rng, hubs=(700, 5000, 40_000) if K < 1000 else (600, 3000))
+    E = int(indptr[-1])
+    src_t = torch.from_numpy(rng.integers(-6, 7, (E, K)).astype(np.float32)).to(dtype)
+    bf16 = dtype == torch.bfloat16
+    code = oracle.BF16 if bf16 else None
+    src_np = src_t.view(torch.int16).numpy().view(np.uint16) if bf16 else src_t.numpy()
+    ip = torch.from_numpy(indptr).to(DEV)
+    for op in ('sum', 'mean', 'min', 'max'):
+        if op == 'mean' and not dtype.is_floating_point:
+            continue
+        want, warg = oracle.segment_csr(OPS[op], src_np, indptr, None, code)
+        res = getattr(ops, f'segment_{op}_csr')(src_t.to(DEV), ip)
+        val = res[0] if op in ('min', 'max') else res
+        if op == 'mean' and dtype != torch.float64:   # the quotient of an exact sum: the same bits unless acc_t differs
+            torch.testing.assert_close(val.cpu().float(), to_t(want, bf16).float(), rtol=1e-6 if dtype == torch.float32 else 2 ** -7, atol=0)
+        else:
+            assert same_bits(val, to_t(want, bf16)), (op, dtype, K)
+        if op in ('min', 'max'):
+            assert torch.equal(res[1].cpu(), torch.from_numpy(warg))
+    # into a caller's `out` (sum accumulates into it, min / max start from it)
+    N = len(indptr) - 1
+    base_t = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32)).to(dtype)
+    base_np = base_t.view(torch.int16).numpy().view(np.uint16) if bf16 else base_t.numpy()
+    for op in ('sum', 'max'):
+        want, warg = oracle.segment_csr(OPS[op], src_np, indptr, base_np, code)
+        res = getattr(ops, f'segment_{op}_csr')(src_t.to(DEV), ip, base_t.clone().to(DEV))
+        val = res[0] if op == 'max' else res
+        assert same_bits(val, to_t(want, bf16)), (op, dtype, K, 'out')
+        if op == 'max':
+            assert torch.equal(res[1].cpu(), torch.from_numpy(warg))
+    # the mirror image
+    rows_t = torch.from_numpy(rng.integers(-50, 50, (N, K)).astype(np.float32)).to(dtype)
+    got = ops.gather_csr(rows_t.to(DEV), ip)
+    assert same_bits(got, torch.repeat_interleave(rows_t, torch.from_numpy(np.diff(indptr)), dim=0))
+
+
+def test_hub_rows_float_sums_within_tolerance_and_repeatable():
+    rng = np.random.default_rng(33)
+    indptr, at = hub_csr(rng)
+    src = rng.standard_normal((int(indptr[-1]), 16)).astype(np.float32)
+    s, ip = torch.from_numpy(src).to(DEV), torch.from_numpy(indptr).to(DEV)
+    want, _ = oracle.segment_csr(oracle.CSR_SUM, src, indptr)
+    got = ops.segment_sum_csr(s, ip)
+    torch.testing.assert_close(got.cpu(), torch.from_numpy(want), rtol=1e-4, atol=2e-3)
+    short = np.ones(len(indptr) - 1, bool)
+    short[at] = False
+    assert torch.equal(got.cpu()[short], torch.from_numpy(want)[short])   # short rows: source order, the oracle's bits
+    assert torch.equal(got, ops.segment_sum_csr(s, ip))
+    want, _ = oracle.segment_csr(oracle.CSR_MEAN, src, indptr)
+    torch.testing.assert_close(ops.segment_mean_csr(s, ip).cpu(), torch.from_numpy(want), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_scatter_onto_a_hub_destination(dtype):
+    # unsorted scatter_sum / min / max with wide rows sort the index and walk the rows through perm[]: a destination that
+    # collects 30 000 of 200 000 edges is a hub row there
+    torch.manual_seed(35)
+    E, N, K = 200_000, 20_000, 64
+    index = torch.randint(0, N, (E,))
+    index[torch.randperm(E)[:30_000]] = 4321
+    src = torch.randint(-6, 7, (E, K)).to(dtype)
+    bf16 = dtype == torch.bfloat16
+    src_np = src.view(torch.int16).numpy().view(np.uint16) if bf16 else src.numpy()
+    code = oracle.BF16 if bf16 else None
+    got = ops.scatter_sum(src.to(DEV), index.to(DEV), 0, None, N)
+    # (the reference adds bf16 to bf16 position by position; the kernel keeps a float per row: exact sums of these integers)
+    exact = torch.zeros(N, K).index_add_(0, index, src.float())
+    assert torch.equal(got.cpu().float(), exact.to(dtype).float())
+    ref = to_t(oracle.scatter(oracle.SUM, src_np, index.numpy(), 0, None, N, code)[0], bf16)
+    if bf16:   # (not the hub: 30 000 bf16 additions into one bf16 stall far below the sum)
+        keep = torch.arange(N) != 4321
+        torch.testing.assert_close(got.cpu().float()[keep], ref.float()[keep], rtol=2e-2, atol=1.0)
+    else:
+        assert same_bits(got, ref)
+    for op, c in (('min', oracle.MIN), ('max', oracle.MAX)):
+        val, arg = getattr(ops, 'scatter_' + op)(src.to(DEV), index.to(DEV), 0, None, N)
+        rv, ra = oracle.scatter(c, src_np, index.numpy(), 0, None, N, code)
+        assert same_bits(val, to_t(rv, bf16)) and torch.equal(arg.cpu(), torch.from_numpy(ra))
+    sidx = torch.sort(index).values
+    got = ops.segment_sum_coo(src.to(DEV), sidx.to(DEV), None, N)
+    assert same_bits(got, to_t(oracle.segment_sum_coo(src_np, sidx.numpy(), None, N, code), bf16))
+
+
 def test_softmax_long_groups_and_oracle():
     rng = np.random.default_rng(23)
     ptr = np.array([0, 40_000, 40_001, 40_001, 100_000], dtype=np.int64)
