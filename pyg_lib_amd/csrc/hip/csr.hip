@@ -551,7 +551,8 @@ __global__ __launch_bounds__(256) void gather_csr_hub_chunk_kernel(const T* __re
 template <typename T, int L, bool BACKWARD>
 __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const int64_t* __restrict__ ptr, T* __restrict__ y,
-                                                          int64_t outer, int64_t D, int64_t inner, int64_t groups) {
+                                                          int64_t outer, int64_t D, int64_t inner, int64_t groups,
+                                                          int64_t long_cut) {
   const int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / L;
   const int lane = threadIdx.x & (L - 1);
   const bool live = t < groups * outer * inner;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ 
   const int64_t i = (tt / inner) % outer;
   const int64_t g = tt / (inner * outer);
   const int64_t a = ptr[g], b = ptr[g + 1];
+  if (b - a > long_cut) return;   // (all L lanes of the item alike) a hub group: softmax_csr_long_kernel
   const int64_t base = i * D * inner + sidx;
   auto reduce = [&](T v, bool is_max) {
 #pragma unroll
@@ -604,22 +606,152 @@ __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ 
   }
 }
 
+// Hub groups (more than `long_cut` positions) of both softmax kernels, one workgroup per group: the workgroups look at 256
+// groups at a time; a hub's [positions, inner] block is contiguous per outer index, its columns are taken 256 at a time by
+// 256 / width position lanes each, whose partial maxima / sums are combined through LDS in lane order (sums differ from the
+// sequential order by rounding, like the L > 1 variants).
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) void softmax_csr_long_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const int64_t* __restrict__ ptr, T* __restrict__ y,
+                                                               int64_t outer, int64_t D, int64_t inner, int64_t groups,
+                                                               int64_t long_cut) {
+  __shared__ int64_t long_groups[256];
+  __shared__ int n_long;
+  __shared__ T part[256];
+  __shared__ T colv[256];
+  for (int64_t g0 = (int64_t)blockIdx.x * 256; g0 < groups; g0 += (int64_t)gridDim.x * 256) {
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    {
+      const int64_t g = g0 + threadIdx.x;
+      if (g < groups && ptr[g + 1] - ptr[g] > long_cut) long_groups[atomicAdd(&n_long, 1)] = g;
+    }
+    __syncthreads();
+    const int cnt = n_long;
+    for (int j = 0; j < cnt; ++j) {
+      const int64_t g = long_groups[j];
+      const int64_t a = ptr[g], b = ptr[g + 1];
+      for (int64_t i = 0; i < outer; ++i) {
+        for (int64_t s0 = 0; s0 < inner; s0 += 256) {
+          const int width = (int)(inner - s0 < 256 ? inner - s0 : 256);
+          const int EL = 256 / width;
+          const int lane = (int)threadIdx.x / width, col = (int)threadIdx.x % width;
+          const bool on = lane < EL;
+          const int64_t base = i * D * inner + s0 + col;
+          // column-wise reduction of the lanes' values: the result is in colv[col] for everybody
+          auto combine = [&](T v, bool is_max) {
+            part[threadIdx.x] = v;
+            __syncthreads();
+            if (on && lane == 0) {
+              T r = v;
+              for (int l = 1; l < EL; ++l) {
+                const T o = part[l * width + col];
+                r = is_max ? (r < o ? o : r) : r + o;
+              }
+              colv[col] = r;
+            }
+            __syncthreads();
+            const T r = colv[on ? col : 0];
+            __syncthreads();
+            return r;
+          };
+          // eight positions per trip, their loads in flight together (one workgroup has the whole group to itself)
+          constexpr int U = 8;
+          auto walk = [&](auto&& body) {
+            if (!on) return;
+            for (int64_t p0 = a + lane; p0 < b; p0 += (int64_t)U * EL) {
+              T xv[U], dv[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * EL;
+                const int64_t pc = p < b ? p : p0;
+                xv[u] = x[base + pc * inner];
+                dv[u] = BACKWARD ? dy[base + pc * inner] : T(0);
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int64_t p = p0 + (int64_t)u * EL;
+                if (p >= b) break;
+                body(p, xv[u], dv[u]);
+              }
+            }
+          };
+          if constexpr (BACKWARD) {
+            T sum = 0;
+            walk([&](int64_t, T xv, T dv) { sum += xv * dv; });
+            sum = combine(sum, false);
+            walk([&](int64_t p, T xv, T dv) { y[base + p * inner] = xv * (dv - sum); });
+          } else {
+            T mx = type_lowest<T>();
+            walk([&](int64_t, T xv, T) { mx = mx < xv ? xv : mx; });
+            mx = combine(mx, true);
+            T sum = 0;
+            walk([&](int64_t, T xv, T) { sum += exp(xv - mx); });
+            sum = combine(sum, false);
+            walk([&](int64_t p, T xv, T) { y[base + p * inner] = exp(xv - mx) / sum; });
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- small K: rows streamed through LDS ----------------------------------------------------------
 // With K * sizeof(T) below a cache line, one thread per (row, column) reads 2-4 byte elements that lie
 // a whole row apart from its neighbour's (0.35 TB/s at K = 1).  Here a workgroup owns 256 / K consecutive
 // rows: their source range is one contiguous span, which is copied to LDS in chunks with fully coalesced
 // loads; every thread then walks ITS row's part of the chunk in source order -- same operation order
 // as the CPU kernel (bit-exact), HBM traffic = the span once.
+// Hub rows (more than `long_cut` positions) are not streamed: the chunk loop jumps over their spans, their threads stand
+// by, and the hub kernels take them (a thread walking 200 000 positions out of LDS: 7 ms of a 0.02 ms call).
+struct StreamHubs {
+  int64_t a[256], b[256];   // spans of this workgroup's hub rows, in row order
+  unsigned char flag[256];
+  int n;
+};
+// every thread of the workgroup; `hub`: this thread's row is one (threads of the same row alike), `first`: its k == 0 thread
+__device__ __forceinline__ void stream_hubs_collect(StreamHubs& h, bool hub, bool first, int rl, int rpb, const int64_t* ip,
+                                                    int64_t r0) {
+  if (threadIdx.x < 256) h.flag[threadIdx.x] = 0;
+  if (threadIdx.x == 0) h.n = 0;
+  if (!__syncthreads_or(hub)) return;
+  if (hub && first) h.flag[rl] = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int r = 0; r < rpb; ++r)
+      if (h.flag[r]) h.a[n] = ip[r0 + r], h.b[n] = ip[r0 + r + 1], ++n;
+    h.n = n;
+  }
+  __syncthreads();
+}
+// the next chunk [base, base + ce) of [.., b0) that touches no hub span; false at the end (uniform over the workgroup)
+__device__ __forceinline__ bool stream_next(const StreamHubs& h, int& hi, int64_t& base, int64_t& ce, int64_t b0, int64_t CE) {
+  while (hi < h.n && h.a[hi] <= base) {
+    if (h.b[hi] > base) base = h.b[hi];
+    ++hi;
+  }
+  if (base >= b0) return false;
+  const int64_t lim = hi < h.n ? h.a[hi] : b0;
+  ce = lim - base < CE ? lim - base : CE;
+  return true;
+}
+
 constexpr int kStreamValues = 8192;    // LDS values per chunk (32 KB of fp32)
 constexpr int kSoftmaxValues = 16384;  // softmax: bigger chunks so that typical spans need ONE pass over HBM
+// (float64 backward: two images of 16384 doubles are 256 KB -- more LDS than a CU has; half the values)
+template <typename T, bool BACKWARD>
+constexpr int softmax_values() { return sizeof(T) == 8 && BACKWARD ? kSoftmaxValues / 2 : kSoftmaxValues; }
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __restrict__ src,
                                                                  const int64_t* __restrict__ indptr,
                                                                  T* __restrict__ out, int64_t* __restrict__ arg,
-                                                                 int fresh, CsrShape s, int rpb) {
+                                                                 int fresh, CsrShape s, int rpb, HubWs hw) {
   using acc_t = typename Math<T>::acc_t;
   __shared__ T buf[kStreamValues];
+  __shared__ StreamHubs hubs;
   const int K = (int)s.K;
   const int rl = threadIdx.x / K, k = threadIdx.x % K;
   const int64_t bps = (s.rows + rpb - 1) / rpb;
@@ -629,16 +761,25 @@ __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __rest
   const int64_t* ip = indptr + slice * s.indptr_stride;
   const int64_t a0 = ip[r0], b0 = ip[rN];
   const int64_t row = r0 + rl;
-  const bool valid = rl < rpb && row < rN;
-  const int64_t a = valid ? ip[row] : 0, b = valid ? ip[row + 1] : 0;
+  bool valid = rl < rpb && row < rN;
+  int64_t a = valid ? ip[row] : 0, b = valid ? ip[row + 1] : 0;
   const int64_t n = slice * s.rows + row;
+  {
+    const bool hub = valid && b - a > s.long_cut;
+    stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ip, r0);
+    if (hub) {
+      if (hw.counters && k == 0) hub_register(hw, n, b - a);
+      valid = false, a = b = 0;
+    }
+  }
   acc_t acc = acc_t(0);
   int64_t best = s.E;
   if (valid && OP != CSR_MEAN && !(OP == CSR_SUM && fresh)) acc = Math<T>::up(out[n * K + k]);
   const int64_t CE = kStreamValues / K;
   const T* sp = src + slice * s.E * K;
-  for (int64_t base = a0; base < b0; base += CE) {
-    const int64_t ce = b0 - base < CE ? b0 - base : CE;
+  int hi_ = 0;
+  int64_t ce;
+  for (int64_t base = a0; stream_next(hubs, hi_, base, ce, b0, CE); base += ce) {
     const int64_t nv = ce * K;
     for (int64_t i = threadIdx.x; i < nv; i += 256) buf[i] = sp[base * K + i];
     __syncthreads();
@@ -671,8 +812,9 @@ __global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __rest
                                                                  const int64_t* __restrict__ ptr, T* __restrict__ y,
                                                                  CsrShape s, int rpb) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  __shared__ StreamHubs hubs;
   T* buf = reinterpret_cast<T*>(sm_raw);
-  T* buf2 = buf + kSoftmaxValues;  // backward only
+  T* buf2 = buf + softmax_values<T, BACKWARD>();  // backward only
   const int K = (int)s.K;
   const int rl = threadIdx.x / K, k = threadIdx.x % K;
   const int64_t bps = (s.rows + rpb - 1) / rpb;
@@ -682,18 +824,24 @@ __global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __rest
   const int64_t a0 = ptr[r0], b0 = ptr[rN];
   const int64_t row = r0 + rl;
   const bool valid = rl < rpb && row < rN;
-  const int64_t a = valid ? ptr[row] : 0, b = valid ? ptr[row + 1] : 0;
-  const int64_t CE = kSoftmaxValues / K;
+  int64_t a = valid ? ptr[row] : 0, b = valid ? ptr[row + 1] : 0;
+  {
+    const bool hub = valid && b - a > s.long_cut;   // softmax_csr_long_kernel's
+    stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ptr, r0);
+    if (hub) a = b = 0;
+  }
+  const int64_t CE = softmax_values<T, BACKWARD>() / K;
   const T* xp = x + slice * s.E * K;
   const T* dp = BACKWARD ? dy + slice * s.E * K : nullptr;
   T* yp = y + slice * s.E * K;
-  const bool single = b0 - a0 <= CE;
+  const bool single = b0 - a0 <= CE && hubs.n == 0;
   const bool one = !BACKWARD && b - a == 1;  // single-element groups are exactly 1
   T mx = type_lowest<T>(), sum = T(0);
   // pass p: 0 = max (forward only), 1 = sum, 2 = write
   for (int pass = BACKWARD ? 1 : 0; pass < 3; ++pass) {
-    for (int64_t base = a0; base < b0; base += CE) {
-      const int64_t ce = b0 - base < CE ? b0 - base : CE;
+    int hi_ = 0;
+    int64_t ce;
+    for (int64_t base = a0; stream_next(hubs, hi_, base, ce, b0, CE); base += ce) {
       const int64_t nv = ce * K;
       if (!single || pass == (BACKWARD ? 1 : 0)) {
         __syncthreads();
@@ -721,6 +869,7 @@ __global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __rest
 
 // ---- hub scratch ------------------------------------------------------------------------------------
 constexpr int64_t kHubCut = 512;      // positions per lane of the row kernels above which a row is a hub
+constexpr int64_t kHubCutStream = 4096;  // ... of the LDS-streamed kernels (a thread walks its row out of LDS: ~20 us at the cut)
 constexpr int64_t kHubChunk = 2048;   // positions per chunk (doubled until the scratch holds the partial results)
 
 inline size_t hub_align(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -767,6 +916,44 @@ int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
   return 1;
 }
 
+// The launches around a row kernel that skips hub rows: hub_begin() in front of it (cut, scratch layout, counters), then the
+// row kernel with st.sc / st.hw, then hub_end().
+struct HubStage {
+  CsrShape sc;
+  HubWs hw;
+  int64_t max_chunks = 0;
+  bool hubs = false;
+};
+template <typename T, int OP>
+int hub_begin(const CsrShape& s, int64_t cut, HubStage& st, hipStream_t stream) {
+  using acc_t = typename Math<T>::acc_t;
+  st.sc = s;
+  st.sc.hub_ws = nullptr, st.sc.hub_ws_bytes = 0;
+  st.hubs = s.E > cut && s.leading * s.rows > 1;   // (else no row can be that long: nothing is launched for them)
+  if (!st.hubs) return PYG_HIP_OK;
+  st.sc.long_cut = cut;
+  if (hub_plan(s.hub_ws, s.hub_ws_bytes, s.leading * s.E, s.K, sizeof(acc_t), OP == CSR_MIN || OP == CSR_MAX, &st.hw, &st.max_chunks))
+    PYG_HIP_CHECK(hipMemsetAsync(st.hw.counters, 0, 16, stream));
+  return PYG_HIP_OK;
+}
+template <typename T, int OP, int V, bool PERM>
+int hub_end(const T* sp, const int64_t* indptr, const int64_t* perm, T* op, int64_t* arg, int fresh, const HubStage& st,
+            hipStream_t stream) {
+  if (!st.hubs) return PYG_HIP_OK;
+  if (st.hw.counters) {
+    const int64_t grid = std::min<int64_t>(st.max_chunks, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((segment_csr_hub_chunk_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm,
+                       op, arg, fresh, st.sc, st.hw);
+  } else {
+    const int64_t batches = (st.sc.leading * st.sc.rows + 255) / 256;
+    const int64_t grid = std::min<int64_t>(batches, (int64_t)device_info().num_cus * 8);
+    hipLaunchKernelGGL((segment_csr_long_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm, op,
+                       arg, fresh, st.sc);
+  }
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
 template <typename T, int OP, int V, bool PERM = false>
 int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, void* out, int64_t* arg, int fresh,
                    const CsrShape& s, hipStream_t stream) {
@@ -774,39 +961,17 @@ int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, 
   const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
   const T* sp = static_cast<const T*>(src);
   T* op = static_cast<T*>(out);
-  // rows of more than 512 positions per lane are hubs, left to a second launch (skipped when no row can be that long)
-  using acc_t = typename Math<T>::acc_t;
-  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
-  CsrShape sc = s;
-  sc.hub_ws = nullptr, sc.hub_ws_bytes = 0;
-  const int64_t cut = kHubCut * (int64_t)L;
-  const bool hubs = s.E > cut && s.leading * s.rows > 1;
-  if (hubs) sc.long_cut = cut;
-  HubWs hw;
-  int64_t max_chunks = 0;
-  if (hubs && hub_plan(s.hub_ws, s.hub_ws_bytes, s.leading * s.E, s.K, sizeof(acc_t), MINMAX, &hw, &max_chunks))
-    PYG_HIP_CHECK(hipMemsetAsync(hw.counters, 0, 16, stream));
+  HubStage st;
+  if (int rc_ = hub_begin<T, OP>(s, kHubCut * (int64_t)L, st, stream)) return rc_;
 #define PYG_CSR_LAUNCH(LL)                                                                                   \
   hipLaunchKernelGGL((segment_csr_kernel<T, OP, V, LL, PERM>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), \
-                     0, stream, sp, indptr, perm, op, arg, fresh, sc, hw)
+                     0, stream, sp, indptr, perm, op, arg, fresh, st.sc, st.hw)
   if (L == 64) PYG_CSR_LAUNCH(64);
   else if (L == 8) PYG_CSR_LAUNCH(8);
   else PYG_CSR_LAUNCH(1);
 #undef PYG_CSR_LAUNCH
   PYG_HIP_CHECK(hipGetLastError());
-  if (hubs && hw.counters) {
-    const int64_t grid = std::min<int64_t>(max_chunks, (int64_t)device_info().num_cus * 8);
-    hipLaunchKernelGGL((segment_csr_hub_chunk_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm,
-                       op, arg, fresh, sc, hw);
-    PYG_HIP_CHECK(hipGetLastError());
-  } else if (hubs) {
-    const int64_t batches = (s.leading * s.rows + 255) / 256;
-    const int64_t grid = std::min<int64_t>(batches, (int64_t)device_info().num_cus * 8);
-    hipLaunchKernelGGL((segment_csr_long_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm, op,
-                       arg, fresh, sc);
-    PYG_HIP_CHECK(hipGetLastError());
-  }
-  return PYG_HIP_OK;
+  return hub_end<T, OP, V, PERM>(sp, indptr, perm, op, arg, fresh, st, stream);
 }
 
 template <typename T, int OP>
@@ -814,10 +979,12 @@ int launch_stream(const void* src, const int64_t* indptr, void* out, int64_t* ar
                   hipStream_t stream) {
   const int rpb = 256 / (int)s.K;
   const int64_t blocks = s.leading * ((s.rows + rpb - 1) / rpb);
+  HubStage st;
+  if (int rc_ = hub_begin<T, OP>(s, kHubCutStream, st, stream)) return rc_;
   hipLaunchKernelGGL((segment_csr_stream_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                     static_cast<const T*>(src), indptr, static_cast<T*>(out), arg, fresh, s, rpb);
+                     static_cast<const T*>(src), indptr, static_cast<T*>(out), arg, fresh, st.sc, rpb, st.hw);
   PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return hub_end<T, OP, 1, false>(static_cast<const T*>(src), indptr, nullptr, static_cast<T*>(out), arg, fresh, st, stream);
 }
 
 // rows of less than 64 bytes that are not very long on average take the LDS-streamed kernel
@@ -903,6 +1070,16 @@ int run_gather_csr(const void* src, const int64_t* indptr, void* out, const CsrS
 }
 
 template <typename T, bool BACKWARD>
+int launch_softmax_long(const void* x, const void* dy, const int64_t* ptr, void* y, int64_t outer, int64_t D, int64_t inner,
+                        int64_t groups, int64_t cut, hipStream_t stream) {
+  const int64_t grid = std::min<int64_t>((groups + 255) / 256, (int64_t)device_info().num_cus * 8);
+  hipLaunchKernelGGL((softmax_csr_long_kernel<T, BACKWARD>), dim3((unsigned)grid), dim3(256), 0, stream, static_cast<const T*>(x),
+                     static_cast<const T*>(dy), ptr, static_cast<T*>(y), outer, D, inner, groups, cut);
+  PYG_HIP_CHECK(hipGetLastError());
+  return PYG_HIP_OK;
+}
+
+template <typename T, bool BACKWARD>
 int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int64_t outer, int64_t D, int64_t inner,
                 int64_t groups, hipStream_t stream) {
   {
@@ -910,26 +1087,32 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
     if (use_stream<T>(s)) {
       const int rpb = 256 / (int)inner;
       const int64_t blocks = outer * ((groups + rpb - 1) / rpb);
-      const int lds = (int)(sizeof(T) * kSoftmaxValues * (BACKWARD ? 2 : 1));
+      const int lds = (int)(sizeof(T) * softmax_values<T, BACKWARD>() * (BACKWARD ? 2 : 1));
       if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&softmax_csr_stream_kernel<T, BACKWARD>), lds)) return rc_;
+      CsrShape sc = s;
+      const bool hubs = D > kHubCutStream && groups > 1;
+      if (hubs) sc.long_cut = kHubCutStream;
       hipLaunchKernelGGL((softmax_csr_stream_kernel<T, BACKWARD>), dim3((unsigned)blocks), dim3(256), lds, stream,
-                         static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), s, rpb);
+                         static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), sc, rpb);
       PYG_HIP_CHECK(hipGetLastError());
-      return PYG_HIP_OK;
+      return hubs ? launch_softmax_long<T, BACKWARD>(x, dy, ptr, y, outer, D, inner, groups, kHubCutStream, stream) : PYG_HIP_OK;
     }
   }
   const int64_t items = groups * outer * inner;
   const int L = pick_lanes(items, D * outer * inner, items);
+  const int64_t cut = kHubCut * (int64_t)L;
+  const bool hubs = D > cut && groups > 1;
+  const int64_t long_cut = hubs ? cut : INT64_MAX;
 #define PYG_SM_LAUNCH(LL)                                                                                         \
   hipLaunchKernelGGL((softmax_csr_kernel<T, LL, BACKWARD>), dim3((unsigned)((items * LL + 255) / 256)), dim3(256), \
                      0, stream, static_cast<const T*>(x), static_cast<const T*>(dy), ptr, static_cast<T*>(y), outer, \
-                     D, inner, groups)
+                     D, inner, groups, long_cut)
   if (L == 64) PYG_SM_LAUNCH(64);
   else if (L == 8) PYG_SM_LAUNCH(8);
   else PYG_SM_LAUNCH(1);
 #undef PYG_SM_LAUNCH
   PYG_HIP_CHECK(hipGetLastError());
-  return PYG_HIP_OK;
+  return hubs ? launch_softmax_long<T, BACKWARD>(x, dy, ptr, y, outer, D, inner, groups, cut, stream) : PYG_HIP_OK;
 }
 
 template <typename T>

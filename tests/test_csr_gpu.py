@@ -244,6 +244,49 @@ def test_softmax_long_groups_and_oracle():
     assert torch.equal(out[40_000].cpu(), torch.ones(2))
 
 
+@pytest.mark.parametrize('shape,dim', [((0, 1), 0), ((0, 3), 0), ((0, 64), 0), ((2, 0, 5), 1), ((0, 300), 0)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_softmax_hub_groups_forward_and_backward(shape, dim, dtype):
+    # groups of more than 512 positions among thousands of short ones: softmax_csr_long_kernel takes them (csr.hip), for the
+    # LDS-streamed kernel (inner < 16 values) and the lane kernel alike
+    rng = np.random.default_rng(41 + len(shape))
+    ptr, at = hub_csr(rng, n_short=3000, hubs=(600, 20_000, 3000))
+    D = int(ptr[-1])
+    shape = tuple(D if v == 0 else v for v in shape)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    src = (rng.standard_normal(shape) * 3).astype(npdt)
+    s = torch.from_numpy(src).to(DEV).requires_grad_()
+    out = ops.softmax_csr(s, torch.from_numpy(ptr).to(DEV), dim)
+
+    def per_group(fn, *arrs):   # float64: the formulas of ops/cpu/softmax_kernel.cpp:60-222 group by group in numpy
+        res = np.zeros_like(arrs[0])
+        mv = [np.moveaxis(v, dim, 0) for v in arrs]
+        rv = np.moveaxis(res, dim, 0)
+        for g0, g1 in zip(ptr[:-1], ptr[1:]):
+            if g1 > g0:
+                rv[g0:g1] = fn(*[v[g0:g1] for v in mv])
+        return res
+
+    def fwd(v):
+        e = np.exp(v - v.max(0, keepdims=True))
+        return e / e.sum(0, keepdims=True)
+
+    f32 = dtype == torch.float32
+    want = oracle.softmax_csr(src, ptr, dim) if f32 else per_group(fwd, src)
+    tol = dict(rtol=2e-4, atol=1e-9) if dtype == torch.float32 else dict(rtol=1e-11, atol=1e-300)
+    torch.testing.assert_close(out.detach().cpu(), torch.from_numpy(want), **tol)
+    gout = rng.standard_normal(shape).astype(npdt)
+    out.backward(torch.from_numpy(gout).to(DEV))
+    gwant = (oracle.softmax_csr_backward(want, gout, ptr, dim) if f32 else
+             per_group(lambda o, g: o * (g - (o * g).sum(0, keepdims=True)), want, gout))
+    torch.testing.assert_close(s.grad.cpu(), torch.from_numpy(gwant), rtol=2e-3 if dtype == torch.float32 else 1e-9,
+                               atol=2e-6 if dtype == torch.float32 else 1e-14)
+    # every group sums to one, the hubs included
+    sums = ops.segment_sum_csr(out.detach().movedim(dim, 0).reshape(D, -1).contiguous(), torch.from_numpy(ptr).to(DEV))
+    nonempty = torch.from_numpy(np.diff(ptr) > 0)
+    torch.testing.assert_close(sums.cpu()[nonempty], torch.ones_like(sums.cpu()[nonempty]), rtol=1e-4, atol=1e-4)
+
+
 def test_autograd_matches_dense_formulas():
     torch.manual_seed(0)
     indptr = torch.tensor([0, 2, 5, 5, 6], device=DEV)
