@@ -681,8 +681,9 @@ PYG_HIP_API int pyg_hip_gather_coo(int dtype, const void* src, const int64_t* in
  *              arg_out receives the winning source position or the sentinel E; fresh != 0 resets rows
  *              without a contribution to 0.
  * Rows are reduced in source order in the reference's opmath, so results are bit-identical to the CPU
- * kernel for every dtype unless rows are long and few (then lanes split a row and floating sums
- * differ by rounding; min/max/arg stay exact).
+ * kernel for every dtype unless rows are long and few (then lanes split a row) or longer than 512
+ * positions per lane (4096 for rows narrower than 64 bytes: hub rows, see pyg_hip_segment_csr_ws); floating
+ * sums of such rows differ by rounding, min/max/arg stay exact, and every run gives the same bits.
  */
 PYG_HIP_API int pyg_hip_segment_csr(int op, int dtype, const void* src, const int64_t* indptr,
                                     int64_t indptr_slice_stride, void* out, int64_t* arg_out, int fresh,

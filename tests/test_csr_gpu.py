@@ -3,7 +3,8 @@ outputs (tests/golden/csr_golden.npz) and with the oracle on larger random input
 
 Modelled on the reference's test/ops/test_segment_csr.py and test_softmax.py.  Rows are reduced in
 source order in the reference's opmath, so sums and means are compared BIT for bit as well (the
-lane-split path for long, few rows is checked separately with a tolerance); min/max values, arg
+lane-split path for long, few rows and the hub rows are checked separately: integer-valued data exact, floats with a
+tolerance); min/max values, arg
 indices and gathers are always exact.  softmax differs from glibc's expf by at most a few ulps.
 """
 import numpy as np
