@@ -64,7 +64,7 @@ struct CsrShape {
 struct HubRec {
   int64_t n;            // flat row
   int chunk_base, nch;  // its chunks: chunks[chunk_base ... chunk_base + nch)
-  int slot_base, done;  // nch > 1: its partial results' slots, and how many of them are written
+  int slot_base, pad;   // nch > 1: its partial results' slots
 };
 struct HubWs {
   int* counters = nullptr;  // [0] hubs, [1] chunks, [2] partial slots -- zeroed in front of the row kernel
@@ -376,8 +376,7 @@ __global__ __launch_bounds__(256) void segment_csr_long_kernel(const T* __restri
 }
 
 // With scratch: one registered chunk per workgroup and trip.  A hub of one chunk is finished on the spot; the chunks of a
-// longer one leave their results in the hub's slots, and the workgroup that writes the hub's last slot adds them up in
-// chunk order (the slots travel through the device-scope fences around the `done` count).
+// longer one leave their results in the hub's slots ...
 template <typename T, int OP, int V, bool PERM>
 __global__ __launch_bounds__(256) void segment_csr_hub_chunk_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
                                                                     const int64_t* __restrict__ perm, T* __restrict__ out,
@@ -386,7 +385,6 @@ __global__ __launch_bounds__(256) void segment_csr_hub_chunk_kernel(const T* __r
   constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
   __shared__ acc_t part[256 * V];
   __shared__ int64_t part_best[MINMAX ? 256 * V : 1];
-  __shared__ int last;
   const int64_t kv = s.K / V;
   const HubGeom<T, V> g(kv);
   const int nchunks = hw.counters[1];
@@ -420,40 +418,48 @@ __global__ __launch_bounds__(256) void segment_csr_hub_chunk_kernel(const T* __r
         }
       }
     }
-    if (whole) continue;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&hw.hubs[cr.x].done, 1) == hub.nch - 1;
-    __syncthreads();
-    if (last) {
-      __threadfence();
-      for (int64_t ci = threadIdx.x; ci < kv; ci += 256) {
-        const int64_t c = ci * V;
-        T* op = out + n * s.K + c;
-        acc_t tot[V];
-        int64_t tb[V];
-        hub_seed<T, OP, V>(op, true, fresh, tot);
+  }
+}
+
+// ... and a third launch adds a longer hub's slots up in chunk order: one thread per (hub, 16-byte slice).  (One launch for
+// both -- the workgroup that writes a hub's last slot combines them -- needs device-scope fences around the count: each
+// writes back and invalidates the XCD's whole L2, 4000 chunks took 650 us that way instead of 60.)
+template <typename T, int OP, int V>
+__global__ __launch_bounds__(256) void segment_csr_hub_combine_kernel(const int64_t* __restrict__ indptr, T* __restrict__ out,
+                                                                      int64_t* __restrict__ arg, int fresh, CsrShape s, HubWs hw) {
+  using acc_t = typename Math<T>::acc_t;
+  constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
+  const int64_t kv = s.K / V;
+  const int64_t items = (int64_t)hw.counters[0] * kv;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.x * blockDim.x) {
+    const HubRec hub = hw.hubs[t / kv];
+    if (hub.nch == 1) continue;
+    const int64_t c = (t % kv) * V;
+    const int64_t n = hub.n;
+    const int64_t slice = n / s.rows, row = n % s.rows;
+    const int64_t len = indptr[slice * s.indptr_stride + row + 1] - indptr[slice * s.indptr_stride + row];
+    T* op = out + n * s.K + c;
+    acc_t tot[V];
+    int64_t tb[V];
+    hub_seed<T, OP, V>(op, true, fresh, tot);
 #pragma unroll
-        for (int i = 0; i < V; ++i) tb[i] = s.E;
-        for (int j = 0; j < hub.nch; ++j) {   // chunk order
-          const int64_t sj = (int64_t)(hub.slot_base + j) * s.K + c;
+    for (int i = 0; i < V; ++i) tb[i] = s.E;
+    for (int j = 0; j < hub.nch; ++j) {   // chunk order
+      const int64_t sj = (int64_t)(hub.slot_base + j) * s.K + c;
 #pragma unroll
-          for (int i = 0; i < V; ++i) {
-            const acc_t ov = __builtin_nontemporal_load(reinterpret_cast<const acc_t*>(hw.partial) + sj + i);
-            if constexpr (!MINMAX) {
-              tot[i] += ov;
-            } else {
-              const int64_t ob = __builtin_nontemporal_load(hw.partial_best + sj + i);
-              const bool better = OP == CSR_MIN ? ov < tot[i] : ov > tot[i];
-              const bool worse = OP == CSR_MIN ? tot[i] < ov : tot[i] > ov;
-              if (better || (!worse && ob < tb[i])) tot[i] = ov, tb[i] = ob;
-            }
-          }
+      for (int i = 0; i < V; ++i) {
+        const acc_t ov = reinterpret_cast<const acc_t*>(hw.partial)[sj + i];
+        if constexpr (!MINMAX) {
+          tot[i] += ov;
+        } else {
+          const int64_t ob = hw.partial_best[sj + i];
+          const bool better = OP == CSR_MIN ? ov < tot[i] : ov > tot[i];
+          const bool worse = OP == CSR_MIN ? tot[i] < ov : tot[i] > ov;
+          if (better || (!worse && ob < tb[i])) tot[i] = ov, tb[i] = ob;
         }
-        hub_store<T, OP, V>(op, MINMAX ? arg + n * s.K + c : nullptr, tot, tb, b - a, fresh, s.E);
       }
     }
-    __syncthreads();   // `last` is rewritten on the next trip
+    hub_store<T, OP, V>(op, MINMAX ? arg + n * s.K + c : nullptr, tot, tb, len, fresh, s.E);
   }
 }
 
@@ -706,39 +712,44 @@ __global__ __launch_bounds__(256) void softmax_csr_long_kernel(const T* __restri
 // Hub rows (more than `long_cut` positions) are not streamed: the chunk loop jumps over their spans, their threads stand
 // by, and the hub kernels take them (a thread walking 200 000 positions out of LDS: 7 ms of a 0.02 ms call).
 struct StreamHubs {
-  int64_t a[256], b[256];   // spans of this workgroup's hub rows, in row order
-  unsigned char flag[256];
+  int64_t a[16], b[16];     // spans of this workgroup's (first 16) hub rows, in row order
+  unsigned char flag[256];  // per row of the workgroup: longer than the cut
   int n;
-};
-// every thread of the workgroup; `hub`: this thread's row is one (threads of the same row alike), `first`: its k == 0 thread
-__device__ __forceinline__ void stream_hubs_collect(StreamHubs& h, bool hub, bool first, int rl, int rpb, const int64_t* ip,
-                                                    int64_t r0) {
-  if (threadIdx.x < 256) h.flag[threadIdx.x] = 0;
-  if (threadIdx.x == 0) h.n = 0;
-  if (!__syncthreads_or(hub)) return;
+};                          // (516 bytes: with kStreamValues below, five workgroups' LDS still fit a CU)
+// every thread of the workgroup; `hub`: this thread's row is one (threads of the same row alike), `first`: its k == 0 thread.
+// Returns the number of spans listed.  (The span of a 17th hub among one workgroup's rows is streamed like the short rows'
+// and ignored.)  Only called when the workgroup's whole span is longer than the cut: most workgroups never pay its barriers.
+__device__ __forceinline__ int stream_hubs_collect(StreamHubs& h, bool hub, bool first, int rl, int rpb, const int64_t* ip,
+                                                   int64_t r0) {
+  if (!__syncthreads_or(hub)) return 0;
+  h.flag[threadIdx.x] = 0;
+  __syncthreads();
   if (hub && first) h.flag[rl] = 1;
   __syncthreads();
   if (threadIdx.x == 0) {
     int n = 0;
-    for (int r = 0; r < rpb; ++r)
+    for (int r = 0; r < rpb && n < 16; ++r)
       if (h.flag[r]) h.a[n] = ip[r0 + r], h.b[n] = ip[r0 + r + 1], ++n;
     h.n = n;
   }
   __syncthreads();
+  return h.n;
 }
-// the next chunk [base, base + ce) of [.., b0) that touches no hub span; false at the end (uniform over the workgroup)
-__device__ __forceinline__ bool stream_next(const StreamHubs& h, int& hi, int64_t& base, int64_t& ce, int64_t b0, int64_t CE) {
-  while (hi < h.n && h.a[hi] <= base) {
+// the next chunk [base, base + ce) of [.., b0) that touches none of the nh listed hub spans; false at the end (uniform over
+// the workgroup)
+__device__ __forceinline__ bool stream_next(const StreamHubs& h, int nh, int& hi, int64_t& base, int64_t& ce, int64_t b0,
+                                            int64_t CE) {
+  while (hi < nh && h.a[hi] <= base) {
     if (h.b[hi] > base) base = h.b[hi];
     ++hi;
   }
   if (base >= b0) return false;
-  const int64_t lim = hi < h.n ? h.a[hi] : b0;
+  const int64_t lim = hi < nh ? h.a[hi] : b0;
   ce = lim - base < CE ? lim - base : CE;
   return true;
 }
 
-constexpr int kStreamValues = 8192;    // LDS values per chunk (32 KB of fp32)
+constexpr int kStreamValues = 8192 - 192;   // LDS values per chunk (32 KB of fp32 less what StreamHubs takes)
 constexpr int kSoftmaxValues = 16384;  // softmax: bigger chunks so that typical spans need ONE pass over HBM
 // (float64 backward: two images of 16384 doubles are 256 KB -- more LDS than a CU has; half the values)
 template <typename T, bool BACKWARD>
@@ -764,9 +775,10 @@ __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __rest
   bool valid = rl < rpb && row < rN;
   int64_t a = valid ? ip[row] : 0, b = valid ? ip[row + 1] : 0;
   const int64_t n = slice * s.rows + row;
+  int nh = 0;
   {
     const bool hub = valid && b - a > s.long_cut;
-    stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ip, r0);
+    if (b0 - a0 > s.long_cut) nh = stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ip, r0);
     if (hub) {
       if (hw.counters && k == 0) hub_register(hw, n, b - a);
       valid = false, a = b = 0;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __rest
   const T* sp = src + slice * s.E * K;
   int hi_ = 0;
   int64_t ce;
-  for (int64_t base = a0; stream_next(hubs, hi_, base, ce, b0, CE); base += ce) {
+  for (int64_t base = a0; stream_next(hubs, nh, hi_, base, ce, b0, CE); base += ce) {
     const int64_t nv = ce * K;
     for (int64_t i = threadIdx.x; i < nv; i += 256) buf[i] = sp[base * K + i];
     __syncthreads();
@@ -825,23 +837,24 @@ __global__ __launch_bounds__(256) void softmax_csr_stream_kernel(const T* __rest
   const int64_t row = r0 + rl;
   const bool valid = rl < rpb && row < rN;
   int64_t a = valid ? ptr[row] : 0, b = valid ? ptr[row + 1] : 0;
+  int nh = 0;
   {
     const bool hub = valid && b - a > s.long_cut;   // softmax_csr_long_kernel's
-    stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ptr, r0);
+    if (b0 - a0 > s.long_cut) nh = stream_hubs_collect(hubs, hub, k == 0, rl, rpb, ptr, r0);
     if (hub) a = b = 0;
   }
   const int64_t CE = softmax_values<T, BACKWARD>() / K;
   const T* xp = x + slice * s.E * K;
   const T* dp = BACKWARD ? dy + slice * s.E * K : nullptr;
   T* yp = y + slice * s.E * K;
-  const bool single = b0 - a0 <= CE && hubs.n == 0;
+  const bool single = b0 - a0 <= CE && nh == 0;
   const bool one = !BACKWARD && b - a == 1;  // single-element groups are exactly 1
   T mx = type_lowest<T>(), sum = T(0);
   // pass p: 0 = max (forward only), 1 = sum, 2 = write
   for (int pass = BACKWARD ? 1 : 0; pass < 3; ++pass) {
     int hi_ = 0;
     int64_t ce;
-    for (int64_t base = a0; stream_next(hubs, hi_, base, ce, b0, CE); base += ce) {
+    for (int64_t base = a0; stream_next(hubs, nh, hi_, base, ce, b0, CE); base += ce) {
       const int64_t nv = ce * K;
       if (!single || pass == (BACKWARD ? 1 : 0)) {
         __syncthreads();
@@ -907,9 +920,12 @@ inline size_t hub_plan(void* ws, size_t ws_bytes, int64_t total, int64_t K, size
 }
 
 // lanes per item: long rows + too few items to fill the chip
-int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
+int pick_lanes(int64_t items, int64_t total_len, int64_t units, int64_t row_bytes = 64) {
   if (units <= 0 || items <= 0) return 1;
   const int64_t avg = total_len / units;
+  // rows narrower than a cache line that are too long for the LDS-streamed kernels: the lanes of an item read neighbouring
+  // positions -- one contiguous piece per trip, whatever the number of items (K = 1, 300 positions per row: 0.168 -> ms)
+  if (row_bytes < 64 && avg >= 64) return avg >= 256 ? 64 : 8;
   const int64_t chip = (int64_t)device_info().num_cus * 2048;  // resident threads
   if (avg >= 1024 && items * 8 < chip) return 64;
   if (avg >= 64 && items < chip) return 8;
@@ -921,7 +937,7 @@ int pick_lanes(int64_t items, int64_t total_len, int64_t units) {
 struct HubStage {
   CsrShape sc;
   HubWs hw;
-  int64_t max_chunks = 0;
+  int64_t max_chunks = 0, max_hubs = 0;
   bool hubs = false;
 };
 template <typename T, int OP>
@@ -934,6 +950,7 @@ int hub_begin(const CsrShape& s, int64_t cut, HubStage& st, hipStream_t stream) 
   st.sc.long_cut = cut;
   if (hub_plan(s.hub_ws, s.hub_ws_bytes, s.leading * s.E, s.K, sizeof(acc_t), OP == CSR_MIN || OP == CSR_MAX, &st.hw, &st.max_chunks))
     PYG_HIP_CHECK(hipMemsetAsync(st.hw.counters, 0, 16, stream));
+  st.max_hubs = s.leading * s.E / cut;   // every hub is longer than the cut
   return PYG_HIP_OK;
 }
 template <typename T, int OP, int V, bool PERM>
@@ -944,6 +961,12 @@ int hub_end(const T* sp, const int64_t* indptr, const int64_t* perm, T* op, int6
     const int64_t grid = std::min<int64_t>(st.max_chunks, (int64_t)device_info().num_cus * 8);
     hipLaunchKernelGGL((segment_csr_hub_chunk_kernel<T, OP, V, PERM>), dim3((unsigned)grid), dim3(256), 0, stream, sp, indptr, perm,
                        op, arg, fresh, st.sc, st.hw);
+    PYG_HIP_CHECK(hipGetLastError());
+    if (st.sc.E > st.hw.CH) {   // (else every hub is one chunk long)
+      const int64_t cgrid = std::min<int64_t>((st.max_hubs * (st.sc.K / V) + 255) / 256, (int64_t)device_info().num_cus * 4);
+      hipLaunchKernelGGL((segment_csr_hub_combine_kernel<T, OP, V>), dim3((unsigned)cgrid), dim3(256), 0, stream, indptr, op, arg,
+                         fresh, st.sc, st.hw);
+    }
   } else {
     const int64_t batches = (st.sc.leading * st.sc.rows + 255) / 256;
     const int64_t grid = std::min<int64_t>(batches, (int64_t)device_info().num_cus * 8);
@@ -958,7 +981,7 @@ template <typename T, int OP, int V, bool PERM = false>
 int launch_segment(const void* src, const int64_t* indptr, const int64_t* perm, void* out, int64_t* arg, int fresh,
                    const CsrShape& s, hipStream_t stream) {
   const int64_t items = s.leading * s.rows * (s.K / V);
-  const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
+  const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows, s.K * (int64_t)sizeof(T));
   const T* sp = static_cast<const T*>(src);
   T* op = static_cast<T*>(out);
   HubStage st;
@@ -987,12 +1010,17 @@ int launch_stream(const void* src, const int64_t* indptr, void* out, int64_t* ar
   return hub_end<T, OP, 1, false>(static_cast<const T*>(src), indptr, nullptr, static_cast<T*>(out), arg, fresh, st, stream);
 }
 
-// rows of less than 64 bytes that are not very long on average take the LDS-streamed kernel
+// rows of less than 64 bytes that are not very long on average take the LDS-streamed kernel (a thread walks its row out of LDS:
+// from ~64 positions per row on, lanes over the positions are faster)
+#ifndef PYG_CSR_STREAM_MAX_AVG
+#define PYG_CSR_STREAM_MAX_AVG 64
+#endif
+constexpr int64_t kStreamMaxAvg = PYG_CSR_STREAM_MAX_AVG;
 template <typename T>
 bool use_stream(const CsrShape& s) {
   if (s.K < 1 || s.K > 16 || s.K * (int64_t)sizeof(T) >= 64) return false;
   const int64_t units = s.leading * s.rows;
-  return units > 0 && (s.leading * s.E) / units < 1024 && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
+  return units > 0 && (s.leading * s.E) / units < kStreamMaxAvg && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
 }
 
 template <typename T>
@@ -1099,7 +1127,7 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
     }
   }
   const int64_t items = groups * outer * inner;
-  const int L = pick_lanes(items, D * outer * inner, items);
+  const int L = pick_lanes(items, D * outer * inner, items, inner * (int64_t)sizeof(T));
   const int64_t cut = kHubCut * (int64_t)L;
   const bool hubs = D > cut && groups > 1;
   const int64_t long_cut = hubs ? cut : INT64_MAX;

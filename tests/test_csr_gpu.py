@@ -188,6 +188,30 @@ def test_hub_rows_take_a_workgroup_each(dtype, K):
     assert same_bits(got, torch.repeat_interleave(rows_t, torch.from_numpy(np.diff(indptr)), dim=0))
 
 
+@pytest.mark.parametrize('K', [1, 4])
+def test_more_hubs_than_a_workgroup_lists(K):
+    # the LDS-streamed kernels keep 16 hub spans per workgroup (256 / K consecutive rows): 24 hubs in a row, sums INTO an
+    # existing output (a hub handled twice would be added twice), min / max, softmax
+    rng = np.random.default_rng(37)
+    lens = rng.integers(0, 6, 700)
+    lens[100:124] = rng.integers(4200, 6000, 24)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    E, N = int(indptr[-1]), len(lens)
+    src = rng.integers(-6, 7, (E, K)).astype(np.float32)
+    base = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    s, ip = torch.from_numpy(src).to(DEV), torch.from_numpy(indptr).to(DEV)
+    for op in ('sum', 'min', 'max'):
+        want, warg = oracle.segment_csr(OPS[op], src, indptr, base)
+        res = getattr(ops, f'segment_{op}_csr')(s, ip, torch.from_numpy(base).to(DEV))
+        val = res if op == 'sum' else res[0]
+        assert torch.equal(val.cpu(), torch.from_numpy(want)), op
+        if op != 'sum':
+            assert torch.equal(res[1].cpu(), torch.from_numpy(warg))
+    x = (rng.standard_normal((E, K)) * 3).astype(np.float32)
+    out = ops.softmax_csr(torch.from_numpy(x).to(DEV), ip)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(oracle.softmax_csr(x, indptr)), rtol=2e-4, atol=1e-9)
+
+
 def test_hub_rows_float_sums_within_tolerance_and_repeatable():
     rng = np.random.default_rng(33)
     indptr, at = hub_csr(rng)
