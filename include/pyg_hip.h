@@ -694,8 +694,8 @@ PYG_HIP_API int pyg_hip_segment_csr(int op, int dtype, const void* src, const in
  * lane (a power-law graph's popular destination) is skipped there.  Without scratch a second launch gives every such row to
  * ONE workgroup (~9 GB/s per row: a row holding 2.5 % of 8 M positions of 256 bytes then takes 6 ms of a 0.5 ms call).
  * With `workspace` (pyg_hip_csr_hub_workspace_size() bytes of device memory, contents irrelevant, not kept) the skipped rows
- * are registered there in chunks of 2048 positions, a second launch deals the chunks to all workgroups, and the workgroup
- * that finishes a row's last chunk combines the chunks' partial results in chunk order: no float atomics, the same bits on
+ * are registered there in chunks of 2048 positions, a second launch deals the chunks to all workgroups, and a third
+ * combines the chunks' partial results of a row in chunk order: no float atomics, the same bits on
  * every run; sums of hub rows differ from the sequential order by rounding (like the lane-split rows), min / max / arg
  * stay exact.  A smaller workspace is legal: the chunk length doubles until the partial results fit, too small means "without".
  * pyg_hip_csr_hub_workspace_size: op 0 ... 3 as above, 4 = gather_csr; 0 when no row can be a hub (leading * E <= 512).
