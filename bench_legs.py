@@ -505,6 +505,15 @@ def leg_scatter_sum(device, E=20_000_000, N=2_000_000, K=128, dtype=torch.bfloat
     res['segment_sum_coo_sorted'] = _rate(8 * E + esz * E * K + esz * N * K, ms2)
     ms3 = _event_ms(lambda: ops.gather_coo(src[:N], idx_sorted), iters)
     res['gather_coo'] = _rate(8 * E + 2 * esz * E * K, ms3)
+    # the same call on a power-law-shaped index: ONE destination collects 2.5 % of the edges (a hub row: csr.hip deals its
+    # chunks to all workgroups; round 6 start: 99 ms for the shape of tools/hub_sweep.py)
+    hub = idx.clone()
+    hub[torch.randperm(E, device=device, generator=g)[:E // 40]] = N // 3
+    ms4 = _event_ms(lambda: ops.scatter_sum(src, hub, dim=0, dim_size=N), iters)
+    res['hub_2_5_percent'] = dict(_rate(8 * E + esz * E * K + esz * N * K, ms4), slowdown_vs_uniform=round(ms4 / ms, 3))
+    hub_sorted = hub.sort().values
+    ms5 = _event_ms(lambda: ops.segment_sum_coo(src, hub_sorted, dim_size=N), iters)
+    res['hub_2_5_percent']['segment_sum_coo_sorted_ms'] = round(ms5, 4)
     return res
 
 

@@ -1,5 +1,7 @@
+"""segment_sum_csr on the `skewed` degree distribution of tools/csr_shape_sweep.py (1000 hubs of 8000 positions = half of all
+positions), a few calls: a driver for `rocprofv3 --kernel-trace --stats --output-format csv` (NOTES_r6 section 7)."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyg_lib_amd import ops
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev).manual_seed(0)
