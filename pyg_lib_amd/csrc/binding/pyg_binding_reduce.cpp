@@ -113,6 +113,9 @@ static const char* op_name(int op, bool coo) {
 }
 
 // Core of scatter_* and segment_*_coo: `index_b` has src.dim() dims.
+// Set around scatter_mean's count: one unsorted index vector takes the stable sort + CSR-row path for ANY row width.
+static thread_local bool tl_prefer_sorted_sum = false;
+
 static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& src, const Tensor& index_b, int64_t dim,
                                               const std::optional<Tensor>& optional_out,
                                               std::optional<int64_t> dim_size, int64_t inferred_size) {
@@ -185,7 +188,10 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
   // vector of ANY size (stable sort + CSR rows, source order); where there is none, torch's own convention applies:
   // alertNotDeterministic raises, or warns under warn_only and the atomic kernel runs.
   const bool floating = at::isFloatingType(src_c.scalar_type());
-  bool det = at::globalContext().deterministicAlgorithms() && floating && (op == OP_SUM || op == OP_MUL);
+  // (tl_prefer_sorted_sum: scatter_mean's bucket sizes -- see ScatterMean -- ask for the same path without the mode)
+  const bool prefer_sorted = tl_prefer_sorted_sum && op == OP_SUM && floating && !coo && l.B == 1 && l.isk == 0 && l.ise == 1 &&
+                             !at::globalContext().deterministicAlgorithms();
+  bool det = (at::globalContext().deterministicAlgorithms() || prefer_sorted) && floating && (op == OP_SUM || op == OP_MUL);
   const bool det_sort = det && op == OP_SUM && !coo && l.B == 1 && l.isk == 0 && l.ise == 1;
   if (sort_sum || csr_minmax || csr_sum || det_sort)
     ws = at::empty({(int64_t)pyg_hip_scatter_workspace_size(l.B, l.E, l.N)}, src_c.options().dtype(at::kByte));
@@ -195,7 +201,7 @@ static std::tuple<Tensor, Tensor> reduce_core(int op, bool coo, const Tensor& sr
                            l.K, l.N, base_flags | (det ? PYG_HIP_SCATTER_DETERMINISTIC : 0),
                            ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0, stream);
   if (rc == PYG_HIP_ERR_UNSUPPORTED && det) {
-    at::globalContext().alertNotDeterministic(
+    if (!prefer_sorted) at::globalContext().alertNotDeterministic(
         op == OP_MUL ? "pyg::scatter_mul on floating-point HIP tensors"
                      : "pyg::scatter_sum / scatter_mean on HIP tensors with an element-wise (or batched unsorted) index");
     rc = pyg_hip_scatter(op, dt, src_c.data_ptr(), l.index.data_ptr<int64_t>(), l.isb, l.ise, l.isk, out.data_ptr(),
@@ -486,8 +492,21 @@ class ScatterMean : public torch::autograd::Function<ScatterMean> {
     auto index_b = broadcast(index, src, dim_norm);
     auto out = op.call(src, index_b, dim_norm, optional_out, dim_size);
     const int64_t count_dim = index.dim() <= dim_norm ? index.dim() - 1 : dim_norm;
-    auto ones = at::ones(index.sizes(), src.options());
+    // The bucket sizes are a K = 1 scatter of ones: through atomics, ONE popular destination serialises them (8 M edges, 2.5 %
+    // of them into one bucket: 5 ms in float32, 43 ms through the 16-bit compare-and-swap loop, of a 1.5 ms call).  On the
+    // device a 16-bit source is counted in float32 (native atomics; a count above 256 is the true count rounded to the storage
+    // type afterwards, where `+= 1` in bf16 -- the reference's and the 16-bit atomic path's -- stops at 256), and an index
+    // vector of >= 4 M entries through its stable sort (row sums of ones, no atomics: 20 % slower than the atomics without
+    // a popular bucket from that size on, 2 x slower at 1 M entries; `tools/narrow_scatter_paths.py`).
+    const bool half = src.is_cuda() && (src.scalar_type() == at::kBFloat16 || src.scalar_type() == at::kHalf);
+    auto ones = at::ones(index.sizes(), half ? src.options().dtype(at::kFloat) : src.options());
+    struct Prefer {
+      bool old;
+      explicit Prefer(bool on) : old(tl_prefer_sorted_sum) { tl_prefer_sorted_sum = on; }
+      ~Prefer() { tl_prefer_sorted_sum = old; }
+    } prefer(src.is_cuda() && index.dim() == 1 && index.numel() >= (1 << 22) && at::isFloatingType(src.scalar_type()));
     auto count = op.call(ones, index, count_dim, std::nullopt, out.size(dim_norm));
+    if (half) count = count.to(src.scalar_type());
     count.masked_fill_(count < 1, 1);
     auto count_b = broadcast(count, out, dim_norm);
     if (out.is_floating_point()) out.true_divide_(count_b);

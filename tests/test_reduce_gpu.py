@@ -267,3 +267,46 @@ def test_rgcn_scale_scatter_and_gather_properties():
     assert torch.equal(out.long(), ref)
     gat = ops.gather_coo(out, index)
     assert torch.equal(gat, out[index])
+
+
+@pytest.mark.parametrize('dtype,K', [(torch.float32, 1), (torch.float32, 64), (torch.bfloat16, 64), (torch.float16, 8)])
+def test_scatter_mean_counts_a_popular_bucket(dtype, K):
+    # the bucket sizes of a 16-bit source are counted in float32 (a count above 256 is the true count, where `+= 1` in bf16
+    # stops at 256 -- and no 16-bit compare-and-swap loop on ONE popular counter); index vectors of >= 4 M entries are counted
+    # through their stable sort (test_scatter_mean_large_index_counts_through_the_sort)
+    torch.manual_seed(11)
+    E, N = 60_000, 3000
+    index = torch.randint(0, N, (E,))
+    index[torch.randperm(E)[:9000]] = 77
+    src = torch.randint(-4, 5, (E, K)).to(dtype)
+    got = ops.scatter_mean(src.to(DEV), index.to(DEV), 0, None, N)
+    cnt = torch.bincount(index, minlength=N).clamp(min=1).double()
+    want = torch.zeros(N, K, dtype=torch.float64).index_add_(0, index, src.double()) / cnt[:, None]
+    if dtype == torch.float32:
+        torch.testing.assert_close(got.cpu().double(), want, rtol=1e-6, atol=1e-6)
+    elif K * 2 >= 64:   # 16-bit rows of >= 64 bytes: the sums are float32 accumulations too
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2 ** -7, atol=2 ** -7)
+    else:               # narrow 16-bit rows add in the storage type (like the reference): leave the popular bucket out
+        keep = torch.arange(N) != 77
+        torch.testing.assert_close(got.cpu().double()[keep], want[keep], rtol=2 ** -5, atol=2 ** -4)
+    # constant ones into a bucket of 9000+: the mean is 1 (16-bit: only if the count did not stop at 256)
+    if K * src.element_size() >= 64:
+        ones = torch.ones(E, K, dtype=dtype)
+        m = ops.scatter_mean(ones.to(DEV), index.to(DEV), 0, None, N)
+        assert float(m[77].float().min()) > 0.99 and float(m[77].float().max()) < 1.01
+    # gradients still flow (count is a constant)
+    x = src.float().to(DEV).requires_grad_()
+    ops.scatter_mean(x, index.to(DEV), 0, None, N).sum().backward()
+    torch.testing.assert_close(x.grad.cpu()[:, 0], (1.0 / cnt)[index].float(), rtol=1e-5, atol=1e-7)
+
+
+def test_scatter_mean_large_index_counts_through_the_sort():
+    torch.manual_seed(12)
+    E, N, K = (1 << 22) + 5, 50_000, 2
+    index = torch.randint(0, N, (E,), device=DEV)
+    index[torch.randperm(E, device=DEV)[:E // 8]] = 123
+    src = torch.randint(-4, 5, (E, K), device=DEV).float()
+    got = ops.scatter_mean(src, index, 0, None, N)
+    cnt = torch.bincount(index, minlength=N).clamp(min=1).double()
+    want = torch.zeros(N, K, dtype=torch.float64, device=DEV).index_add_(0, index, src.double()) / cnt[:, None]
+    torch.testing.assert_close(got.double(), want, rtol=1e-6, atol=1e-6)
