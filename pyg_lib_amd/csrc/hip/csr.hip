@@ -31,6 +31,41 @@ struct alignas(sizeof(T) * V) Pack {
   T v[V];
 };
 
+// pin_all(a): every element of `a` is needed HERE, all of them at once.  The row kernels load U positions' values "in flight
+// together" and then use them under `if (position < end)`; the compiler sinks each load to its conditional use, and the
+// kernel runs with ONE load in flight per thread (load, s_waitcnt vmcnt(0), branch, load, ...: the ISA of every such loop
+// before this existed).  One empty asm statement that takes all U values as register operands cannot be split.
+template <int BYTES> struct PinReg { using type = uint32_t; };
+template <> struct PinReg<8> { using type = uint64_t; };
+template <> struct PinReg<16> { typedef unsigned type __attribute__((ext_vector_type(4))); };
+template <typename X, int U>
+__device__ __forceinline__ void pin_all(X (&a)[U]) {
+  static_assert(U == 4 || U == 8 || U == 16, "pin_all: 4, 8 or 16 values");
+  static_assert(sizeof(X) == 1 || sizeof(X) == 2 || sizeof(X) == 4 || sizeof(X) == 8 || sizeof(X) == 16, "pin_all: value size");
+  using R = typename PinReg<sizeof(X)>::type;
+  R r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if constexpr (sizeof(X) == 1) r[u] = __builtin_bit_cast(uint8_t, a[u]);
+    else if constexpr (sizeof(X) == 2) r[u] = __builtin_bit_cast(uint16_t, a[u]);
+    else r[u] = __builtin_bit_cast(R, a[u]);
+  }
+  if constexpr (U == 4) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+  } else if constexpr (U == 8) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+  } else {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                 "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if constexpr (sizeof(X) == 1) a[u] = __builtin_bit_cast(X, (uint8_t)r[u]);
+    else if constexpr (sizeof(X) == 2) a[u] = __builtin_bit_cast(X, (uint16_t)r[u]);
+    else a[u] = __builtin_bit_cast(X, r[u]);
+  }
+}
+
 template <typename A>
 __device__ __forceinline__ A shfl_xor_any(A v, int mask) {
   static_assert(sizeof(A) % 4 == 0 || sizeof(A) < 4, "unsupported accumulator");
@@ -151,8 +186,10 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
         const int64_t ec = e < b ? e : e0;  // clamped: the load is issued unconditionally, the value is ignored below
         pp[u] = PERM ? perm[ec] : ec;
       }
+      if constexpr (PERM) pin_all(pp);
 #pragma unroll
       for (int u = 0; u < U; ++u) xx[u] = *reinterpret_cast<const P*>(sp + pp[u] * s.K);
+      pin_all(xx);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (e0 + (int64_t)u * L >= b) break;
@@ -249,8 +286,10 @@ __device__ __forceinline__ void hub_span(const T* __restrict__ sp, const int64_t
         const int64_t ec = e < pb ? e : e0;
         pp[u] = PERM ? perm[ec] : ec;
       }
+      if constexpr (PERM) pin_all(pp);
 #pragma unroll
       for (int u = 0; u < U; ++u) xx[u] = *reinterpret_cast<const P*>(sp + pp[u] * rowK);
+      pin_all(xx);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (e0 + (int64_t)u * g.EL >= pb) break;
@@ -661,8 +700,8 @@ __global__ __launch_bounds__(256) void softmax_csr_long_kernel(const T* __restri
             __syncthreads();
             return r;
           };
-          // eight positions per trip, their loads in flight together (one workgroup has the whole group to itself)
-          constexpr int U = 8;
+          // 16 positions per trip, their loads in flight together (pin_all): one workgroup has the whole group to itself
+          constexpr int U = 16;
           auto walk = [&](auto&& body) {
             if (!on) return;
             for (int64_t p0 = a + lane; p0 < b; p0 += (int64_t)U * EL) {
@@ -674,6 +713,8 @@ __global__ __launch_bounds__(256) void softmax_csr_long_kernel(const T* __restri
                 xv[u] = x[base + pc * inner];
                 dv[u] = BACKWARD ? dy[base + pc * inner] : T(0);
               }
+              pin_all(xv);
+              if constexpr (BACKWARD) pin_all(dv);
 #pragma unroll
               for (int u = 0; u < U; ++u) {
                 const int64_t p = p0 + (int64_t)u * EL;
