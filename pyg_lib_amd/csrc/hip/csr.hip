@@ -108,13 +108,24 @@ struct HubWs {
   char* partial = nullptr;  // slots of K accumulators ...
   int64_t* partial_best = nullptr;  // ... and, for min / max, of K positions
   int64_t CH = 0;
+  int max_hubs = 0, max_chunks = 0, max_slots = 0;   // capacities: valid offsets never reach them; garbage offsets set counters[3]
 };
 
 __device__ __forceinline__ void hub_register(const HubWs& hw, int64_t n, int64_t len) {
-  const int nch = (int)((len + hw.CH - 1) / hw.CH);
+  const int64_t nch64 = (len + hw.CH - 1) / hw.CH;
+  if (nch64 > hw.max_chunks) {   // offsets that are no offsets (the reference does not check them either): nothing is written
+    hw.counters[3] = 1;          // behind the scratch's ends, the hub kernels of this call stand down
+    return;
+  }
+  const int nch = (int)nch64;
   const int h = atomicAdd(&hw.counters[0], 1);
   const int cb = atomicAdd(&hw.counters[1], nch);
-  const int sb = nch > 1 ? atomicAdd(&hw.counters[2], nch) : 0;
+  const bool slots = nch > 1 && hw.max_slots > 0;   // (gather_csr keeps no partial results)
+  const int sb = slots ? atomicAdd(&hw.counters[2], nch) : 0;
+  if (h >= hw.max_hubs || cb + nch > hw.max_chunks || (slots && sb + nch > hw.max_slots)) {
+    hw.counters[3] = 1;
+    return;
+  }
   hw.hubs[h] = HubRec{n, cb, nch, sb, 0};
   for (int j = 0; j < nch; ++j) hw.chunks[cb + j] = make_int2(h, j);
 }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void segment_csr_hub_chunk_kernel(const T* __r
   __shared__ int64_t part_best[MINMAX ? 256 * V : 1];
   const int64_t kv = s.K / V;
   const HubGeom<T, V> g(kv);
-  const int nchunks = hw.counters[1];
+  const int nchunks = hw.counters[3] ? 0 : hw.counters[1];
   for (int q = blockIdx.x; q < nchunks; q += gridDim.x) {
     const int2 cr = hw.chunks[q];
     const HubRec hub = hw.hubs[cr.x];
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(256) void segment_csr_hub_combine_kernel(const int6
   using acc_t = typename Math<T>::acc_t;
   constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
   const int64_t kv = s.K / V;
-  const int64_t items = (int64_t)hw.counters[0] * kv;
+  const int64_t items = hw.counters[3] ? 0 : (int64_t)hw.counters[0] * kv;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < items; t += (int64_t)gridDim.x * blockDim.x) {
     const HubRec hub = hw.hubs[t / kv];
     if (hub.nch == 1) continue;
@@ -580,7 +591,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void gather_csr_hub_chunk_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
                                                                    T* __restrict__ out, CsrShape s, HubWs hw) {
   const int64_t kv = s.K / V;
-  const int nchunks = hw.counters[1];
+  const int nchunks = hw.counters[3] ? 0 : hw.counters[1];
   for (int q = blockIdx.x; q < nchunks; q += gridDim.x) {
     const int2 cr = hw.chunks[q];
     const int64_t n = hw.hubs[cr.x].n;
@@ -952,6 +963,9 @@ inline size_t hub_plan(void* ws, size_t ws_bytes, int64_t total, int64_t K, size
       hw->partial = w + o_part;
       hw->partial_best = reinterpret_cast<int64_t*>(w + o_best);
       hw->CH = CH;
+      const int64_t cap = 0x7fffffff;
+      hw->max_hubs = (int)std::min(max_hubs, cap), hw->max_chunks = (int)std::min(max_chunks, cap);
+      hw->max_slots = (int)std::min(max_slots, cap);
       *max_chunks_out = max_chunks;
       return end + skew;
     }

