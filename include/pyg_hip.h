@@ -676,10 +676,11 @@ PYG_HIP_API int pyg_hip_gather_coo(int dtype, const void* src, const int64_t* in
  *   op 0 sum : every row adds src[slice, indptr[r] .. indptr[r+1]) to the CURRENT contents of its out
  *              slot (the caller zero-fills a fresh output; a caller-supplied `out` accumulates)
  *   op 1 mean: out = row sum / max(row length, 1), previous contents ignored; floating dtypes only
- *   op 2 min / 3 max: strict < / >, first match; the running state starts from the current contents
- *              of `out` (numeric_limits max()/lowest() for a fresh output: pyg_hip_fill_reduce_identity);
- *              arg_out receives the winning source position or the sentinel E; fresh != 0 resets rows
- *              without a contribution to 0.
+ *   op 2 min / 3 max: strict < / >, first match; fresh == 0: the running state starts from the current contents
+ *              of `out`; fresh != 0: from numeric_limits max() / lowest() WITHOUT reading `out` (it need not be
+ *              pre-filled; ABI <= 7 read it and wanted pyg_hip_fill_reduce_identity first -- still harmless), and rows
+ *              without a contribution are reset to 0.  arg_out receives the winning source position or the
+ *              sentinel E for EVERY slot (it need not be pre-filled either).
  * Rows are reduced in source order in the reference's opmath, so results are bit-identical to the CPU
  * kernel for every dtype unless rows are long and few (then lanes split a row) or longer than 512
  * positions per lane (4096 for rows narrower than 64 bytes: hub rows, see pyg_hip_segment_csr_ws); floating

@@ -89,7 +89,10 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
   }
   Tensor arg;
   const int64_t E = src_c.size(dim);
-  if (op == CSR_MIN || op == CSR_MAX) arg = at::full(out.sizes(), E, v.indptr.options());
+  // (the device kernels write every arg slot -- rows without entries get the sentinel E -- so only the CPU key and the
+  // empty source pre-fill it: K x 8 bytes per row that were written twice)
+  if (op == CSR_MIN || op == CSR_MAX)
+    arg = (on_cpu || src_c.numel() == 0) ? at::full(out.sizes(), E, v.indptr.options()) : at::empty(out.sizes(), v.indptr.options());
   if (src_c.numel() == 0) {
     if (fresh && (op == CSR_MIN || op == CSR_MAX)) out.fill_(0);
     return std::make_tuple(out, arg);
@@ -106,9 +109,7 @@ std::tuple<Tensor, Tensor> segment_any(int op, const char* name, const Tensor& s
   }
   const int code = dtype_code(src_c.scalar_type());
   void* stream = current_stream(src_c);
-  if (fresh && (op == CSR_MIN || op == CSR_MAX))
-    check_status(pyg_hip_fill_reduce_identity(op == CSR_MIN ? PYG_REDUCE_MIN : PYG_REDUCE_MAX, code, out.data_ptr(),
-                                              out.numel(), stream));
+  // (fresh != 0: a min / max output starts from the identity inside the kernels without being read -- no pre-fill)
   // scratch for hub rows (0 bytes when no row can be one): their chunks are dealt to all workgroups
   const size_t hub_bytes = pyg_hip_csr_hub_workspace_size(op, code, v.leading, E, K);
   Tensor hub_ws;

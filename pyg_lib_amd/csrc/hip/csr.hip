@@ -31,6 +31,12 @@ struct alignas(sizeof(T) * V) Pack {
   T v[V];
 };
 
+// what a FRESH min / max output starts from (pyg_hip_fill_reduce_identity's value): with fresh != 0 the kernels do not read `out`
+template <typename T, int OP>
+__device__ __forceinline__ typename Math<T>::acc_t minmax_identity() {
+  return Math<T>::up(OP == CSR_MIN ? type_max<T>() : type_lowest<T>());
+}
+
 // pin_all(a): every element of `a` is needed HERE, all of them at once.  The row kernels load U positions' values "in flight
 // together" and then use them under `if (position < end)`; the compiler sinks each load to its conditional use, and the
 // kernel runs with ONE load in flight per thread (load, s_waitcnt vmcnt(0), branch, load, ...: the ISA of every such loop
@@ -189,10 +195,12 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = acc_t(0);
   } else {
-    P cur = *reinterpret_cast<const P*>(op);
+    // (a fresh output starts from the identity without being read -- and need not be pre-filled: 2 x N x K bytes less traffic)
+    P cur;
+    if (!fresh) cur = *reinterpret_cast<const P*>(op);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      acc[i] = Math<T>::up(cur.v[i]);
+      acc[i] = fresh ? minmax_identity<T, OP>() : Math<T>::up(cur.v[i]);
       best[i] = s.E;
     }
   }
@@ -385,8 +393,8 @@ __device__ __forceinline__ void hub_seed(const T* __restrict__ op, bool on, int 
   using acc_t = typename Math<T>::acc_t;
   constexpr bool MINMAX = OP == CSR_MIN || OP == CSR_MAX;
 #pragma unroll
-  for (int i = 0; i < V; ++i) seed[i] = acc_t(0);
-  if (on && (MINMAX || (OP == CSR_SUM && !fresh))) {
+  for (int i = 0; i < V; ++i) seed[i] = MINMAX ? minmax_identity<T, MINMAX ? OP : CSR_MIN>() : acc_t(0);
+  if (on && !fresh && (MINMAX || OP == CSR_SUM)) {
     const Pack<T, V> cur = *reinterpret_cast<const Pack<T, V>*>(op);
 #pragma unroll
     for (int i = 0; i < V; ++i) seed[i] = Math<T>::up(cur.v[i]);
@@ -869,7 +877,8 @@ __global__ __launch_bounds__(256) void segment_csr_stream_kernel(const T* __rest
   }
   acc_t acc = acc_t(0);
   int64_t best = s.E;
-  if (valid && OP != CSR_MEAN && !(OP == CSR_SUM && fresh)) acc = Math<T>::up(out[n * K + k]);
+  if constexpr (OP == CSR_MIN || OP == CSR_MAX) acc = minmax_identity<T, OP>();
+  if (valid && OP != CSR_MEAN && !fresh) acc = Math<T>::up(out[n * K + k]);
   const int64_t CE = kStreamValues / K;
   const T* sp = src + slice * s.E * K;
   int hi_ = 0;

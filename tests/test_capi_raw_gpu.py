@@ -133,10 +133,9 @@ def test_segment_and_gather_csr_hub_rows_with_and_without_scratch(lib, dtype, K)
         assert full > 0
         for ws_bytes in (0, full, full // 3):
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
-            out = torch.empty(N, K, dtype=dtype, device=DEV)
-            arg = torch.full((N, K), E, dtype=torch.int64, device=DEV)
-            if op >= 2:
-                assert L.pyg_hip_fill_reduce_identity(2 if op == 2 else 3, code, out.data_ptr(), out.numel(), stream) == 0
+            # fresh = 1: neither `out` nor `arg_out` is read or needs a pre-fill (ABI 8): hand over rubbish
+            out = torch.full((N, K), 123, dtype=dtype, device=DEV)
+            arg = torch.full((N, K), -7, dtype=torch.int64, device=DEV)
             rc = L.pyg_hip_segment_csr_ws(op, code, sd.data_ptr(), ip.data_ptr(), 0, out.data_ptr(), arg.data_ptr() if op >= 2 else None,
                                           1, 1, N, E, K, ws.data_ptr() if ws_bytes else None, ws_bytes, stream)
             assert rc == 0, L.pyg_hip_last_error()
