@@ -347,22 +347,33 @@ __device__ __forceinline__ void hub_span(const T* __restrict__ sp, const int64_t
     if constexpr (MINMAX) part_best[threadIdx.x * V + i] = best[i];
   }
   __syncthreads();
+  // the lanes of a slice combine pairwise, lane l with lane l + stride (a fixed tree: the same bits on every run; one thread
+  // walking 256 lanes x 8 values out of LDS took 60 us per chunk)
+  for (int st = g.EL >> 1; st >= 1; st >>= 1) {
+    if (g.lane < st) {
+      const int ia = threadIdx.x * V, ib = (((g.lane + st) << g.logS) + g.sl) * V;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const acc_t ov = part[ib + i];
+        if constexpr (!MINMAX) {
+          part[ia + i] += ov;
+        } else {
+          const acc_t cv = part[ia + i];
+          const int64_t ob = part_best[ib + i], cb = part_best[ia + i];
+          const bool better = OP == CSR_MIN ? ov < cv : ov > cv;
+          const bool worse = OP == CSR_MIN ? cv < ov : cv > ov;
+          if (better || (!worse && ob < cb)) part[ia + i] = ov, part_best[ia + i] = ob;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (on && g.lane == 0) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      tot[i] = MINMAX ? acc[i] : start[i];
-      tb[i] = best[i];
-      for (int l = MINMAX ? 1 : 0; l < g.EL; ++l) {   // lane order
-        const acc_t ov = part[((l << g.logS) + g.sl) * V + i];
-        if constexpr (!MINMAX) {
-          tot[i] += ov;
-        } else {
-          const int64_t ob = part_best[((l << g.logS) + g.sl) * V + i];
-          const bool better = OP == CSR_MIN ? ov < tot[i] : ov > tot[i];
-          const bool worse = OP == CSR_MIN ? tot[i] < ov : tot[i] > ov;
-          if (better || (!worse && ob < tb[i])) tot[i] = ov, tb[i] = ob;
-        }
-      }
+      // (min / max: every lane started from `start`, it is inside the combined value already)
+      tot[i] = MINMAX ? part[threadIdx.x * V + i] : start[i] + part[threadIdx.x * V + i];
+      tb[i] = MINMAX ? part_best[threadIdx.x * V + i] : E;
     }
   }
   __syncthreads();
@@ -1111,17 +1122,29 @@ int launch_stream(const void* src, const int64_t* indptr, void* out, int64_t* ar
 #define PYG_CSR_STREAM_MAX_AVG 64
 #endif
 constexpr int64_t kStreamMaxAvg = PYG_CSR_STREAM_MAX_AVG;
+#ifndef PYG_CSR_STREAM_MAX_ROW_BYTES
+#define PYG_CSR_STREAM_MAX_ROW_BYTES 64
+#endif
+constexpr int64_t kStreamMaxRowBytes = PYG_CSR_STREAM_MAX_ROW_BYTES;
+// (`slices16`: the rows are whole 16-byte slices the row kernel can load as such.  Then the row kernel wins from 32 bytes per
+// row on -- fp32 K = 8, 2 positions per row, 16 M positions: 0.71 ms streamed, 0.15 direct; 48 per row: 0.22 / 0.14 -- and
+// for 16-byte rows below ~32 positions per row: 0.38 / 0.087 ms at 2 per row, 0.090 / 0.103 at 48; `tools/narrow_row_kernels.py`)
 template <typename T>
-bool use_stream(const CsrShape& s) {
-  if (s.K < 1 || s.K > 16 || s.K * (int64_t)sizeof(T) >= 64) return false;
+bool use_stream(const CsrShape& s, bool slices16 = false) {
+  if (s.K < 1 || s.K > 16 || s.K * (int64_t)sizeof(T) >= kStreamMaxRowBytes) return false;
   const int64_t units = s.leading * s.rows;
-  return units > 0 && (s.leading * s.E) / units < kStreamMaxAvg && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
+  if (units <= 0) return false;
+  const int64_t avg = (s.leading * s.E) / units;
+  if (slices16 && (s.K * (int64_t)sizeof(T) >= 32 || avg < 32)) return false;
+  return avg < kStreamMaxAvg && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
 }
 
 template <typename T>
 int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64_t* arg, int fresh, const CsrShape& s,
                 hipStream_t stream) {
-  if (use_stream<T>(s)) {
+  constexpr int VMAX = 16 / (int)sizeof(T);
+  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (use_stream<T>(s, vec)) {
     switch (op) {
       case CSR_SUM: return launch_stream<T, CSR_SUM>(src, indptr, out, arg, fresh, s, stream);
       case CSR_MEAN:
@@ -1132,8 +1155,6 @@ int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64
       default: return fail(PYG_HIP_ERR_INVALID, "segment_csr: unknown reduction %d", op);
     }
   }
-  constexpr int VMAX = 16 / (int)sizeof(T);
-  const bool vec = VMAX > 1 && s.K % VMAX == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
 #define PYG_CSR_OP(OPC)                                                                              \
   return vec ? launch_segment<T, OPC, VMAX>(src, indptr, nullptr, out, arg, fresh, s, stream)        \
              : launch_segment<T, OPC, 1>(src, indptr, nullptr, out, arg, fresh, s, stream)

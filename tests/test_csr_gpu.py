@@ -49,7 +49,18 @@ def test_segment_csr_matches_reference(name):
     out = out0.to(DEV) if out0 is not None else None
     res = getattr(ops, f"segment_{c['op']}_csr")(src, indptr, out)
     val = res[0] if c['op'] in ('min', 'max') else res
-    assert same_bits(val, to_t(c['res'], c['bf16'])), name
+    want = to_t(c['res'], c['bf16'])
+    # floating sums of rows of more than 512 positions (hub rows: their chunks are summed by several lanes / workgroups) equal
+    # the reference's sequential sum up to rounding; every other row and every other operation bit for bit
+    lens = np.diff(np.asarray(c['indptr']), axis=-1)
+    if c['op'] in ('sum', 'mean') and want.is_floating_point() and lens.ndim == 1 and lens.size and lens.max() > 512:
+        hub = torch.from_numpy(lens > 512)
+        dim = np.asarray(c['indptr']).ndim - 1
+        assert dim == 0
+        torch.testing.assert_close(val.cpu()[hub].float(), want[hub].float(), rtol=2e-5 if not c['bf16'] else 2 ** -7, atol=1e-4)
+        assert same_bits(val.cpu()[~hub], want[~hub]), name
+    else:
+        assert same_bits(val, want), name
     if c['op'] in ('min', 'max'):
         assert torch.equal(res[1].cpu(), to_t(c['arg']))
     if out is not None:
