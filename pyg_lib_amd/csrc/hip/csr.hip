@@ -1228,7 +1228,11 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
                 int64_t groups, hipStream_t stream) {
   {
     const CsrShape s{outer, groups, D, inner, 0};
-    if (use_stream<T>(s)) {
+    // the LDS-streamed kernel: inner sizes below 32 bytes in groups of 12 ... 63 positions on average.  Shorter groups and
+    // wider heads are faster with one thread per head reading global memory (fp32 inner = 8, 2 per group, 8 M positions: 1.32 ->
+    // 0.55 ms forward, 1.52 -> 0.39 backward; inner = 1, 2 per group: 0.37 -> 0.14; but inner = 1, 16 per group: 0.16 streamed,
+    // 0.35 direct; `tools/narrow_softmax_kernels.py`)
+    if (use_stream<T>(s) && inner * (int64_t)sizeof(T) < 32 && D * outer >= 12 * groups * outer) {
       const int rpb = 256 / (int)inner;
       const int64_t blocks = outer * ((groups + rpb - 1) / rpb);
       const int lds = (int)(sizeof(T) * softmax_values<T, BACKWARD>() * (BACKWARD ? 2 : 1));
