@@ -1126,6 +1126,12 @@ constexpr int64_t kStreamMaxAvg = PYG_CSR_STREAM_MAX_AVG;
 #define PYG_CSR_STREAM_MAX_ROW_BYTES 64
 #endif
 constexpr int64_t kStreamMaxRowBytes = PYG_CSR_STREAM_MAX_ROW_BYTES;
+// (rows of fewer than 12 positions on average: one thread per (row, element) on global memory is 1.3 - 2 x faster than the
+// workgroup's trip through LDS -- fp32 K = 1, 2 per row: 0.088 -> 0.049 ms; K = 5, 8 per row: 0.194 -> 0.104)
+#ifndef PYG_CSR_STREAM_MIN_AVG
+#define PYG_CSR_STREAM_MIN_AVG 12
+#endif
+constexpr int64_t kStreamMinAvg = PYG_CSR_STREAM_MIN_AVG;
 // (`slices16`: the rows are whole 16-byte slices the row kernel can load as such.  Then the row kernel wins from 32 bytes per
 // row on -- fp32 K = 8, 2 positions per row, 16 M positions: 0.71 ms streamed, 0.15 direct; 48 per row: 0.22 / 0.14 -- and
 // for 16-byte rows below ~32 positions per row: 0.38 / 0.087 ms at 2 per row, 0.090 / 0.103 at 48; `tools/narrow_row_kernels.py`)
@@ -1136,6 +1142,7 @@ bool use_stream(const CsrShape& s, bool slices16 = false) {
   if (units <= 0) return false;
   const int64_t avg = (s.leading * s.E) / units;
   if (slices16 && (s.K * (int64_t)sizeof(T) >= 32 || avg < 32)) return false;
+  if (avg < kStreamMinAvg) return false;
   return avg < kStreamMaxAvg && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
 }
 
