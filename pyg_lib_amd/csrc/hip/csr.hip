@@ -1180,7 +1180,14 @@ int run_segment(int op, const void* src, const int64_t* indptr, void* out, int64
 template <typename T, int V>
 int launch_gather(const void* src, const int64_t* indptr, void* out, const CsrShape& s, hipStream_t stream) {
   const int64_t items = s.leading * s.rows * (s.K / V);
-  const int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows);
+  int L = pick_lanes(items, s.leading * s.E, s.leading * s.rows, s.K * (int64_t)sizeof(T));
+  // narrow rows: a thread writing its slice of position after position leaves 16 bytes per row and store instruction; with
+  // 8 lanes per item a store covers 8 consecutive positions.  Rows of whole 16-byte slices from 8 positions per row on (fp32
+  // K = 4, 16 per row, 16 M positions: 0.213 -> 0.092 ms; K = 12, 48 per row: 0.46 -> 0.22), element-wise rows from 32 (K = 1, 48
+  // per row: 0.062 -> 0.039; at 16 per row K = 5 loses: 0.154 -> 0.212): `tools/lease/ab_gather_lanes.sh`
+  if (L == 1 && s.K * (int64_t)sizeof(T) < 64 && s.leading * s.rows > 0 &&
+      (s.leading * s.E) / (s.leading * s.rows) >= (V > 1 ? 8 : 32))
+    L = 8;
   CsrShape sc = s;
   sc.hub_ws = nullptr, sc.hub_ws_bytes = 0;
   const int64_t cut = kHubCut * (int64_t)L;

@@ -16,4 +16,6 @@ for dtype, K in ((torch.float32, 1), (torch.float32, 2), (torch.float32, 3), (to
         src = torch.randn(E, K, device=dev, generator=g).to(dtype)
         a = bench_legs._event_ms(lambda: ops.segment_sum_csr(src, ptr), 5, warmup=2)
         b = bench_legs._event_ms(lambda: ops.segment_max_csr(src, ptr), 5, warmup=2)
-        print(f'{str(dtype)[6:]:9s} K={K:3d} deg {mean_deg:3d}: sum {a:.3f} | max {b:.3f} ms', flush=True)
+        small = src[:N].contiguous()
+        c = bench_legs._event_ms(lambda: ops.gather_csr(small, ptr), 5, warmup=2)
+        print(f'{str(dtype)[6:]:9s} K={K:3d} deg {mean_deg:3d}: sum {a:.3f} | max {b:.3f} | gather {c:.3f} ms', flush=True)
