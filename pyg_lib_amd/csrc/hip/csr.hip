@@ -1025,6 +1025,13 @@ inline size_t hub_plan(void* ws, size_t ws_bytes, int64_t total, int64_t K, size
   return 0;
 }
 
+// (narrow rows of whole 16-byte slices: 8 lanes per item from 16 positions per row on -- a load instruction then covers 8
+// consecutive positions of a row: fp32 K = 4, 48 per row: 0.096 (streamed) -> 0.044 ms; bf16 K = 8, 16 per row: 0.103 -> 0.062;
+// from 8 per row on it loses: fp32 K = 12: 0.19 -> 0.27.  `tools/lease/ab_narrow_vec_lanes.sh`)
+#ifndef PYG_CSR_NARROW_VEC_LANES_AVG
+#define PYG_CSR_NARROW_VEC_LANES_AVG 16
+#endif
+constexpr int64_t kNarrowVecLanesAvg = PYG_CSR_NARROW_VEC_LANES_AVG;
 // lanes per item: long rows + too few items to fill the chip
 int pick_lanes(int64_t items, int64_t total_len, int64_t units, int64_t row_bytes = 64) {
   if (units <= 0 || items <= 0) return 1;
@@ -1032,6 +1039,7 @@ int pick_lanes(int64_t items, int64_t total_len, int64_t units, int64_t row_byte
   // rows narrower than a cache line that are too long for the LDS-streamed kernels: the lanes of an item read neighbouring
   // positions -- one contiguous piece per trip, whatever the number of items (K = 1, 300 positions per row: 0.168 -> ms)
   if (row_bytes < 64 && avg >= 64) return avg >= 256 ? 64 : 8;
+  if (row_bytes < 64 && row_bytes % 16 == 0 && avg >= kNarrowVecLanesAvg) return 8;
   const int64_t chip = (int64_t)device_info().num_cus * 2048;  // resident threads
   if (avg >= 1024 && items * 8 < chip) return 64;
   if (avg >= 64 && items < chip) return 8;
@@ -1132,16 +1140,16 @@ constexpr int64_t kStreamMaxRowBytes = PYG_CSR_STREAM_MAX_ROW_BYTES;
 #define PYG_CSR_STREAM_MIN_AVG 12
 #endif
 constexpr int64_t kStreamMinAvg = PYG_CSR_STREAM_MIN_AVG;
-// (`slices16`: the rows are whole 16-byte slices the row kernel can load as such.  Then the row kernel wins from 32 bytes per
-// row on -- fp32 K = 8, 2 positions per row, 16 M positions: 0.71 ms streamed, 0.15 direct; 48 per row: 0.22 / 0.14 -- and
-// for 16-byte rows below ~32 positions per row: 0.38 / 0.087 ms at 2 per row, 0.090 / 0.103 at 48; `tools/narrow_row_kernels.py`)
+// (`slices16`: the rows are whole 16-byte slices the row kernel can load as such.  Then the row kernel always wins -- fp32
+// K = 8, 2 positions per row, 16 M positions: 0.71 ms streamed, 0.15 direct; 48 per row: 0.22 streamed, 0.14 with one lane per
+// item, 0.095 with eight; `tools/narrow_row_kernels.py`)
 template <typename T>
 bool use_stream(const CsrShape& s, bool slices16 = false) {
   if (s.K < 1 || s.K > 16 || s.K * (int64_t)sizeof(T) >= kStreamMaxRowBytes) return false;
   const int64_t units = s.leading * s.rows;
   if (units <= 0) return false;
   const int64_t avg = (s.leading * s.E) / units;
-  if (slices16 && (s.K * (int64_t)sizeof(T) >= 32 || avg < 32)) return false;
+  if (slices16 && (s.K * (int64_t)sizeof(T) >= 32 || avg < 32 || kNarrowVecLanesAvg < 64)) return false;
   if (avg < kStreamMinAvg) return false;
   return avg < kStreamMaxAvg && s.leading * ((s.rows + 255) / 256) < (1ll << 31);
 }
