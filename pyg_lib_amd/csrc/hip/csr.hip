@@ -677,6 +677,67 @@ __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ 
     }
     return v;
   };
+  if constexpr (L == 1) {
+    // groups of up to 32 positions: the head's values stay in registers between the passes -- one read and one write of the
+    // data instead of two or three reads and two writes (same operations in the same order: the same bits).  Three sizes, so
+    // that a group of two does not issue 32 loads.
+    const int64_t len = b - a;
+    auto in_registers = [&](auto rc) __attribute__((always_inline)) {
+      constexpr int R = decltype(rc)::value;
+      T xv[R], dv[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t p = a + (u < len ? u : 0);
+        xv[u] = x[base + p * inner];
+        dv[u] = BACKWARD ? dy[base + p * inner] : T(0);
+      }
+      if constexpr (R <= 16) {
+        pin_all(xv);
+        if constexpr (BACKWARD) pin_all(dv);
+      } else {
+        T(&x0)[16] = reinterpret_cast<T(&)[16]>(xv[0]);
+        T(&x1)[16] = reinterpret_cast<T(&)[16]>(xv[16]);
+        pin_all(x0), pin_all(x1);
+        if constexpr (BACKWARD) {
+          T(&d0)[16] = reinterpret_cast<T(&)[16]>(dv[0]);
+          T(&d1)[16] = reinterpret_cast<T(&)[16]>(dv[16]);
+          pin_all(d0), pin_all(d1);
+        }
+      }
+      if constexpr (BACKWARD) {
+        T sum = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+          if (u < len) sum += xv[u] * dv[u];
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+          if (u < len) y[base + (a + u) * inner] = xv[u] * (dv[u] - sum);
+      } else {
+        T mx = type_lowest<T>();
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+          if (u < len) mx = mx < xv[u] ? xv[u] : mx;
+        T sum = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+          if (u < len) {
+            xv[u] = exp(xv[u] - mx);
+            sum += xv[u];
+          }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+          if (u < len) y[base + (a + u) * inner] = xv[u] / sum;
+      }
+    };
+    // (backward: two values per position -- 32 positions cost the kernel its occupancy: 2 per group 0.39 -> 0.55 ms)
+    constexpr int RMAX = BACKWARD ? 16 : 32;
+    if (live && len > 1 && len <= RMAX) {
+      if (len <= 4) in_registers(std::integral_constant<int, 4>{});
+      else if (len <= 16) in_registers(std::integral_constant<int, 16>{});
+      else if constexpr (RMAX > 16) in_registers(std::integral_constant<int, 32>{});
+      return;
+    }
+  }
   if constexpr (BACKWARD) {
     // x = out, dy = out_grad, y = in_grad (softmax_kernel.cpp:148-222)
     T sum = 0;
@@ -1250,11 +1311,17 @@ int run_softmax(const void* x, const void* dy, const int64_t* ptr, void* y, int6
                 int64_t groups, hipStream_t stream) {
   {
     const CsrShape s{outer, groups, D, inner, 0};
-    // the LDS-streamed kernel: inner sizes below 32 bytes in groups of 12 ... 63 positions on average.  Shorter groups and
+    // the LDS-streamed kernel: inner sizes below 32 bytes in groups of 33 ... 63 positions on average (shorter groups stay in
+    // the registers of the one-thread-per-head kernel: inner = 1, 16 per group 0.161 -> 0.114 ms).  Shorter groups and
     // wider heads are faster with one thread per head reading global memory (fp32 inner = 8, 2 per group, 8 M positions: 1.32 ->
     // 0.55 ms forward, 1.52 -> 0.39 backward; inner = 1, 2 per group: 0.37 -> 0.14; but inner = 1, 16 per group: 0.16 streamed,
     // 0.35 direct; `tools/narrow_softmax_kernels.py`)
-    if (use_stream<T>(s) && inner * (int64_t)sizeof(T) < 32 && D * outer >= 12 * groups * outer) {
+#ifndef PYG_SOFTMAX_STREAM_MIN_AVG
+#define PYG_SOFTMAX_STREAM_MIN_AVG 33
+#endif
+    // (backward keeps two values per position: 16 in registers, so the streamed kernel takes over earlier)
+    constexpr int64_t kMinAvg = BACKWARD ? 12 : PYG_SOFTMAX_STREAM_MIN_AVG;
+    if (use_stream<T>(s) && inner * (int64_t)sizeof(T) < 32 && D * outer >= kMinAvg * groups * outer) {
       const int rpb = 256 / (int)inner;
       const int64_t blocks = outer * ((groups + rpb - 1) / rpb);
       const int lds = (int)(sizeof(T) * softmax_values<T, BACKWARD>() * (BACKWARD ? 2 : 1));
