@@ -753,23 +753,40 @@ __global__ __launch_bounds__(256) void softmax_csr_kernel(const T* __restrict__ 
       // (falls through the reductions below with an empty range)
     }
     const bool work = live && b - a != 1;
+    // four positions per trip, their loads pinned together (a head's positions are a row apart: one load in flight per thread
+    // left long groups of wide heads at 0.17 of HBM)
+    auto walk = [&](auto&& body) __attribute__((always_inline)) {
+      if (!work) return;
+      if constexpr (L > 1) {   // (lanes share a group: a lane has few positions, a batch would be mostly clamped loads)
+        for (int64_t p = a + lane; p < b; p += L) body(p, x[base + p * inner]);
+        return;
+      }
+      constexpr int U = 4;
+      for (int64_t p0 = a + lane; p0 < b; p0 += (int64_t)U * L) {
+        T xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t p = p0 + (int64_t)u * L;
+          xv[u] = x[base + (p < b ? p : p0) * inner];
+        }
+        pin_all(xv);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t p = p0 + (int64_t)u * L;
+          if (p >= b) break;
+          body(p, xv[u]);
+        }
+      }
+    };
     T mx = type_lowest<T>();
-    if (work)
-      for (int64_t p = a + lane; p < b; p += L) {
-        const T v = x[base + p * inner];
-        mx = mx < v ? v : mx;  // std::max(max, v)
-      }
+    walk([&](int64_t, T v) { mx = mx < v ? v : mx; });  // std::max(max, v)
     if (L > 1) mx = reduce(mx, true);
+    // (the exponentials are computed again in the last pass instead of being parked in `y`: x is read three times and y
+    // written once, instead of two reads of x and two writes + one read of y)
     T sum = 0;
-    if (work)
-      for (int64_t p = a + lane; p < b; p += L) {
-        const T v = exp(x[base + p * inner] - mx);
-        sum += v;
-        y[base + p * inner] = v;
-      }
+    walk([&](int64_t, T v) { sum += exp(v - mx); });
     if (L > 1) sum = reduce(sum, false);
-    if (work)
-      for (int64_t p = a + lane; p < b; p += L) y[base + p * inner] /= sum;
+    walk([&](int64_t p, T v) { y[base + p * inner] = exp(v - mx) / sum; });
   }
 }
 
