@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(const T* __restrict__ 
 }
 
 // The hub kernels.  256 threads take positions [pa, pb) of one row as S 16-byte slices x 256 / S position lanes (lane j
-// takes pa + j, pa + j + 256 / S, ..., eight loads in flight); the lanes' partial results are combined through LDS in lane
-// order: the same bits on every run; floating sums differ from the sequential order by rounding like the L > 1 variants
+// takes pa + j, pa + j + 256 / S, ..., eight loads in flight); the lanes' partial results are combined through LDS by a
+// fixed pairwise tree: the same bits on every run; floating sums differ from the sequential order by rounding like the L > 1 variants
 // above; min / max and their first-match arg stay exact.
 template <typename T, int V>
 struct HubGeom {
