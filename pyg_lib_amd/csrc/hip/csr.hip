@@ -608,7 +608,6 @@ __device__ __forceinline__ void gather_span(const T* __restrict__ sp, T* __restr
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gather_csr_long_kernel(const T* __restrict__ src, const int64_t* __restrict__ indptr,
                                                               T* __restrict__ out, CsrShape s) {
-  using P = Pack<T, V>;
   __shared__ int64_t long_rows[256];
   __shared__ int n_long;
   const int64_t kv = s.K / V;
