@@ -63,7 +63,14 @@ for case in range(cases):
     try:
         idx_k = idx_call if idx_call.dim() == src.dim() else idx_call.unsqueeze(-1).expand_as(src)
         got = ops.scatter_sum(src, idx_k if full_index or len(lead) else idx_d, dim, out_arg, N)
-        if not torch.equal(got.double().cpu(), want):
+        # (16-bit atomic paths add in the storage type in the order the atomics land: with more than 128 contributions to a
+        # bucket a PARTIAL sum can leave the exactly representable integers (|s| <= 256) although the final sum is inside,
+        # and every further addition up there rounds -- case 174 of seed 7: 5000 bf16 values into one bucket, off by up to 45
+        # in one run of five, with hardware atomics and with the compare-and-swap flavour alike: tools/crowded_bf16_bucket.py)
+        crowd = int(torch.bincount(idx1, minlength=N).max())
+        crowded = dtype in (torch.bfloat16, torch.float16) and crowd > 128
+        same = (torch.allclose(got.double().cpu(), want, rtol=0, atol=0.02 * crowd) if crowded else torch.equal(got.double().cpu(), want))
+        if not same:
             bad += 1
             print('MISMATCH scatter_sum', case, dtype, K, E, N, lead, full_index, sorted_idx, det, given_out, flush=True)
         if sorted_idx and not full_index and not len(lead):
